@@ -1,0 +1,257 @@
+/* vag_nmt.h -- C ABI of libvagnmt.so: the VAG-NMT per-step training / decode hot path on MI355X (gfx950).
+ *
+ * This is the drop-in boundary.  The reference (Eurus-Holmes/VAG-NMT) is pure Python on torch; the functions
+ * below replace the torch-op sequences of its hot path, and each comment cites the reference code it stands
+ * in for (paths relative to the reference checkout).  The Python host side in
+ * vag-nmt_amd/machine_translation_vision/ mirrors the reference's module API and calls these entry points
+ * through ctypes.
+ *
+ * Conventions
+ *   - All tensors are dense row-major fp32 on the current HIP device unless stated; token ids are int64
+ *     (torch.LongTensor, as in the reference); lengths are int32 on the device.
+ *   - Source-side sequences are batch-major inside the library: enc/pe are (B,Ts,C), C = 2H.
+ *     Decoder-side per-step tensors are time-major: (Tt,B,*).
+ *   - Ownership: the caller owns every buffer, including workspaces ("ws", sizes from *_ws_floats()).  The
+ *     library never allocates or frees device memory and keeps no pointer after a call returns.
+ *   - All work is enqueued on `stream`; nothing synchronises with the host, so every call can be captured
+ *     into a HIP graph.  Calls are re-entrant across streams.
+ *   - Gradient outputs named g_* are ACCUMULATED (+=) into the caller's buffers (zero them per step);
+ *     outputs named d_* are written.
+ *   - Return value: 0 ok; <0 argument/shape error (-22 = EINVAL); >0 a hipError_t.
+ *   - Dropout: `rng` points to two device uint64 {seed, step}; masks are a pure function of
+ *     (seed, step, stream-id, element index) so backward recomputes them.  rng == NULL or p == 0: no dropout
+ *     (eval mode).  vag_dropout_mask() materialises a mask for tests.
+ */
+#ifndef VAG_NMT_H
+#define VAG_NMT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vag_stream_t; /* hipStream_t */
+
+/* GRU parameter bundle, torch gate order (r,z,n): w_ih (3H,in), w_hh (3H,H), b_ih (3H), b_hh (3H). */
+typedef struct { const float *w_ih, *w_hh, *b_ih, *b_hh; } vag_gru_w;
+typedef struct { float *w_ih, *w_hh, *b_ih, *b_hh; } vag_gru_g;
+
+/* Decoder recurrent parameters (layers/NMT_Decoder.py:78-86): embedding (V,E); gru_1 (in=E); attn_h (C,H);
+ * attn.v (C); context2hid (H,C); gru_2 (in=H). */
+typedef struct {
+    const float* emb;
+    vag_gru_w gru1;
+    const float *attn_h, *attn_v, *c2h;
+    vag_gru_w gru2;
+} vag_dec_w;
+typedef struct {
+    float* emb;
+    vag_gru_g gru1;
+    float *attn_h, *attn_v, *c2h;
+    vag_gru_g gru2;
+} vag_dec_g;
+
+/* Output-head parameters (layers/NMT_Decoder.py:89-106): W1 (E,H), W2 (E,C), W3 (E,E), out (V,E)+(V).
+ * With tied embeddings `out_w` is the decoder embedding matrix. */
+typedef struct { const float *w1, *b1, *w2, *b2, *w3, *b3, *out_w, *out_b; } vag_head_w;
+typedef struct { float *w1, *b1, *w2, *b2, *w3, *b3, *out_w, *out_b; } vag_head_g;
+
+int vag_version(void);
+
+/* ---- generic dense products (torch.nn.Linear / torch.mm call sites on the path) ---------------------- */
+/* C[M,N] = act(alpha * op(A) op(B) + beta*C + bias[n]).  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn];
+ * one stride of each operand must be 1.  act: 0 none, 1 tanh.  fp32 MFMA (exact f32 fma chains). */
+int vag_gemm_f32(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
+                 const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc,
+                 const float* bias, int act, vag_stream_t stream);
+/* y[M,N] = act(x[M,K] W[N,K]^T + bias)  -- nn.Linear forward; picks the small-M kernel for M <= 128. */
+int vag_linear_fwd(int64_t M, int64_t N, int64_t K, const float* x, const float* W, const float* bias, int act,
+                   float* y, vag_stream_t stream);
+/* nn.Linear backward.  If act==1, dy is first multiplied in place by (1 - y^2).  d_x (may be NULL) is
+ * written or, if accumulate_dx, added to; g_W, g_b (may be NULL) are accumulated. */
+int vag_linear_bwd(int64_t M, int64_t N, int64_t K, const float* x, const float* W, const float* y, float* dy,
+                   int act, float* d_x, int accumulate_dx, float* g_W, float* g_b, vag_stream_t stream);
+
+/* ---- embedding (nn.Embedding(padding_idx=0), layers/Encoder.py:22,50; layers/NMT_Decoder.py:78,118) --- */
+int vag_embed_fwd(const int64_t* idx, int64_t n, const float* W, int64_t E, float* out, vag_stream_t stream);
+int vag_embed_bwd(const int64_t* idx, int64_t n, const float* d_out, int64_t E, float* g_W, vag_stream_t stream);
+
+/* ---- a3: bi-GRU encoder, layers/Encoder.py:36-66 ------------------------------------------------------ */
+/* src (B,Ts) int64 padded with 0; lengths int32[B] on device (descending).  Writes enc (B,Ts,2H)
+ * (forward direction in [:H], reverse in [H:], zeros past each row's length) and mask (B,Ts) = (src != 0).
+ * p_emb / p_ctx: dropout on the embedded input / on the output (Encoder.py:51-52,:63-64).
+ * ws: vag_bigru_ws_floats(B,Ts,E,H) floats, must stay untouched until the matching backward. */
+int64_t vag_bigru_ws_floats(int64_t B, int64_t Ts, int64_t E, int64_t H);
+int vag_bigru_seq_fwd(const int64_t* src, const int32_t* lengths, const float* emb, vag_gru_w fwd, vag_gru_w bwd,
+                      float p_emb, float p_ctx, const uint64_t* rng, int64_t B, int64_t Ts, int64_t E, int64_t H,
+                      float* enc, float* mask, float* ws, vag_stream_t stream);
+/* d_enc (B,Ts,2H) is consumed (overwritten).  Accumulates g_emb (Vs,E; pad row untouched) and both GRUs. */
+int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fwd, vag_gru_w bwd, float p_emb,
+                      float p_ctx, const uint64_t* rng, int64_t B, int64_t Ts, int64_t E, int64_t H, float* d_enc,
+                      float* ws, float* g_emb, vag_gru_g g_fwd, vag_gru_g g_bwd, vag_stream_t stream);
+
+/* ---- a4 (hoisted part): attention keys pe = enc W_e^T, layers/NMT_Decoder.py:47 ----------------------- */
+/* The reference recomputes attn_e(encoder_outputs) at every decoder step; it does not depend on the step,
+ * so it is computed once per batch.  rows = B*Ts. */
+int vag_attn_keys_proj(const float* enc, const float* attn_e, int64_t rows, int64_t C, float* pe,
+                       vag_stream_t stream);
+/* a4 stand-alone (BahdanauAttn.forward, layers/NMT_Decoder.py:27-51), inference: q (N,C) = attn_h(hidden);
+ * alpha[n,:] = softmax_s(v . tanh(pe[n/rows_per_src,s] + q[n])) with masked positions at -inf; ctx = alpha . enc. */
+int vag_bahdanau_attn_fwd(const float* pe, const float* q, const float* v, const float* mask, const float* enc,
+                          int64_t N, int64_t rows_per_src, int64_t Ts, int64_t C, float* scores, float* alpha,
+                          float* ctx, vag_stream_t stream);
+/* d_enc (+)= d_pe attn_e ; g_attn_e += d_pe^T enc */
+int vag_attn_keys_proj_bwd(const float* enc, const float* attn_e, const float* d_pe, int64_t rows, int64_t C,
+                           float* d_enc, int accumulate_enc, float* g_attn_e, vag_stream_t stream);
+
+/* ---- a5: cGRU decoder with Bahdanau attention, layers/NMT_Decoder.py:109-131 -------------------------- */
+/* Whole target sequence.  tok (Tt+1,B) int64: row 0 = SOS, row t+1 = input of step t+1.  Teacher forcing
+ * (models/...V11.py:138-146): the caller fills every row.  Free running (V11.py:148-160, free_run=1): rows
+ * 1.. are written here with the argmax of each step's output distribution, for which the head parameters,
+ * `tmid` (Tt,B,E) and `logits` (Tt*B, ldl) are also produced step by step (p_out = head dropout).
+ * Outputs for the head: h2_all (Tt,B,H), c_all (Tt,B,C), e_all (Tt,B,E).
+ * ws: vag_cgru_ws_floats(B,Ts,Tt,E,H) floats, kept for the backward. */
+int64_t vag_cgru_ws_floats(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H);
+int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float* mask, const float* h0,
+                                 int64_t* tok, vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt, int64_t E,
+                                 int64_t H, int64_t V, float* h2_all, float* c_all, float* e_all, float* ws,
+                                 int free_run, const vag_head_w* head, float p_out, const uint64_t* rng,
+                                 float* tmid, float* logits, int64_t ldl, vag_stream_t stream);
+/* Backward through time.  Inputs: gradients w.r.t. the three outputs (d_h2_all, d_c_all are consumed;
+ * d_e_all may be NULL).  Writes d_enc_out (B,Ts,C) (accumulate_enc: adds), d_pe (B,Ts,C), d_h0 (B,H);
+ * accumulates the parameter gradients in g (g.emb: pad row untouched). */
+int vag_cgru_attn_decode_seq_bwd(const float* enc, const float* pe, const float* mask, const float* h0,
+                                 const int64_t* tok, vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt, int64_t E,
+                                 int64_t H, int64_t V, const float* h2_all, const float* c_all, const float* e_all,
+                                 float* d_h2_all, float* d_c_all, const float* d_e_all, float* ws, float* d_enc_out,
+                                 int accumulate_enc, float* d_pe, float* d_h0, vag_dec_g g, float* scratch,
+                                 vag_stream_t stream);
+int64_t vag_cgru_bwd_scratch_floats(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H);
+
+/* One inference step for N hypotheses (greedy / beam search, models/...V11.py:207-226,259-313).  Hypothesis n
+ * attends over source sentence n / rows_per_src (the reference tiles encoder_outputs by beam_size, :253).
+ * tok int64[N]; h_in (N,H) -> h_out (N,H), c (N,C), e (N,E).  scratch: vag_cgru_step_scratch_floats(). */
+int64_t vag_cgru_step_scratch_floats(int64_t N, int64_t Ts, int64_t E, int64_t H);
+int vag_cgru_attn_decode_step(const float* enc, const float* pe, const float* mask, int64_t rows_per_src,
+                              const int64_t* tok, const float* h_in, vag_dec_w w, int64_t N, int64_t Ts,
+                              int64_t E, int64_t H, float* h_out, float* c, float* e, float* alpha,
+                              float* scratch, vag_stream_t stream);
+
+/* ---- a5 (head) + a2 loss: layers/NMT_Decoder.py:137-143, models/...V11.py:140,164 --------------------- */
+/* t = tanh(W1 h2 + W2 c + W3 e + b1+b2+b3); dropout p_out; logits = t out_w^T + out_b; log_softmax;
+ * nll[t,b] = -weight[tgt[b,t]] * logp[tgt[b,t]]  (nn.NLLLoss(weight, reduce=False));
+ * loss_mt = mean_b( sum_t nll[t,b] / #nonpad(tgt[b,:]) ).
+ * rows = Tt*B time-major; tgt (B,Tt) int64; logits (rows, ldl) with ldl >= V, ldl % 4 == 0 (kept for bwd).
+ * logits_ready=1: tmid/logits were already produced (free-running decode), only the loss is computed.
+ * Outputs: lse (rows), nll (rows), loss_mt (1), inv_cnt (B). */
+int vag_head_ce_seq_fwd(const float* h2_all, const float* c_all, const float* e_all, vag_head_w w,
+                        const int64_t* tgt, const float* vocab_weight, int64_t B, int64_t Tt, int64_t E, int64_t H,
+                        int64_t V, float p_out, const uint64_t* rng, int logits_ready, float* tmid, float* logits,
+                        int64_t ldl, float* lse, float* nll, float* inv_cnt, float* loss_mt, vag_stream_t stream);
+/* d_loss: device scalar (gradient of loss_mt).  logits is overwritten with d(logits).  Writes d_h2_all,
+ * d_c_all, d_e_all; accumulates g.  scratch: rows*E floats. */
+int vag_head_ce_seq_bwd(const float* h2_all, const float* c_all, const float* e_all, vag_head_w w,
+                        const int64_t* tgt, const float* vocab_weight, int64_t B, int64_t Tt, int64_t E, int64_t H,
+                        int64_t V, float p_out, const uint64_t* rng, const float* tmid, float* logits, int64_t ldl,
+                        const float* lse, const float* inv_cnt, const float* d_loss, float* d_h2_all,
+                        float* d_c_all, float* d_e_all, vag_head_g g, float* scratch, vag_stream_t stream);
+/* Same head producing the log-probabilities themselves (R rows) with a backward from d_logp -- the form the
+ * per-step layer API (NMT_Decoder.forward -> logp, layers/NMT_Decoder.py:143) and arbitrary criteria need.
+ * tmid (R,E) saved; d_logp (R,ldl) is consumed.  scratch: R*E floats. */
+int vag_head_logp_seq_fwd(const float* h2, const float* c, const float* e, vag_head_w w, int64_t R, int64_t E, int64_t H,
+                          int64_t V, float p_out, const uint64_t* rng, float* tmid, float* logp, int64_t ldl,
+                          vag_stream_t stream);
+int vag_head_logp_seq_bwd(const float* h2, const float* c, const float* e, vag_head_w w, int64_t R, int64_t E, int64_t H,
+                          int64_t V, float p_out, const uint64_t* rng, const float* tmid, const float* logp,
+                          float* d_logp, int64_t ldl, float* d_h2, float* d_c, float* d_e, vag_head_g g, float* scratch,
+                          vag_stream_t stream);
+/* Single step, inference: logp (N,V) = log_softmax(out(tanh(...))) and argmax (int64[N], may be NULL).
+ * scratch: N*E floats. */
+int vag_head_logp_step(const float* h2, const float* c, const float* e, vag_head_w w, int64_t N, int64_t E,
+                       int64_t H, int64_t V, float* logp, int64_t ldl, int64_t* argmax, float* scratch,
+                       vag_stream_t stream);
+
+/* ---- a7/a8: shared-space projections, layers/VSE_Imagine_Enc.py:123-132,138-145; utils/utils.py:6-10 - */
+/* out = l2norm(act(x W^T + b)); x (B,K), W (S,K).  y (B,S) = activation output and nrm (B) are saved. */
+int vag_img_proj_l2_fwd(const float* x, const float* W, const float* b, int64_t B, int64_t K, int64_t S, int act,
+                        float* y, float* nrm, float* out, vag_stream_t stream);
+/* d_out is consumed.  d_x may be NULL; g_W, g_b accumulated. */
+int vag_img_proj_l2_bwd(const float* x, const float* W, const float* y, const float* nrm, const float* out,
+                        float* d_out, int64_t B, int64_t K, int64_t S, int act, float* d_x, float* g_W, float* g_b,
+                        vag_stream_t stream);
+
+/* a8 alone: out = x / max(||x||, 1e-12) per row (utils/utils.py:6-10). */
+int vag_l2norm_fwd(const float* x, int64_t B, int64_t S, float* nrm, float* out, vag_stream_t stream);
+int vag_l2norm_bwd(const float* x, const float* nrm, const float* out, const float* d_out, int64_t B, int64_t S,
+                   float* dx, vag_stream_t stream);
+
+/* ---- a6: image-conditioned attention + attended context, VSE_Imagine_Enc.py:29-79,135-137 ------------- */
+/* method 0 = 'dot' (score_dot), 1 = 'mlp' (score_mlp; mlp_w (C)).  im_emb (B,S), enc (B,Ts,C), mask (B,Ts).
+ * Outputs alpha (B,Ts), ctx (B,C).  ws: vag_imagine_ws_floats() floats kept for backward.
+ * 'dot' uses e[b,t] = enc[b,t] . (W_cc^T (W_ec im_emb[b])): identical in exact arithmetic to the reference's
+ * bmm(emb2ctx(im), ctx2ctx(enc)^T) and avoids the (B*Ts,C,C) product. */
+int64_t vag_imagine_ws_floats(int64_t B, int64_t Ts, int64_t C, int64_t S, int method);
+int vag_imagine_attn_ctx_fwd(const float* im_emb, const float* enc, const float* mask, const float* ctx2ctx,
+                             const float* emb2ctx, const float* mlp_w, int method, int64_t B, int64_t Ts,
+                             int64_t C, int64_t S, float* alpha, float* ctx, float* ws, vag_stream_t stream);
+/* d_ctx (B,C) in.  d_enc (B,Ts,C) is written or added to (accumulate_enc); d_im_emb (B,S) written. */
+int vag_imagine_attn_ctx_bwd(const float* im_emb, const float* enc, const float* mask, const float* ctx2ctx,
+                             const float* emb2ctx, const float* mlp_w, int method, int64_t B, int64_t Ts,
+                             int64_t C, int64_t S, const float* alpha, const float* d_ctx, float* ws,
+                             float* d_enc, int accumulate_enc, float* d_im_emb, float* g_ctx2ctx,
+                             float* g_emb2ctx, float* g_mlp_w, vag_stream_t stream);
+
+/* ---- a9: max-margin ranking losses, losses/PairwiseRankingLoss.py:9-24, ImageRetrievalRankingLoss.py -- */
+/* kind 0 = pairwise (both directions), 1 = image retrieval (cost_s only).  im, s (B,S).
+ * loss (1).  G (B,B) = d loss / d scores, kept for backward.  scores (B,B) scratch. */
+int vag_rank_loss_fwd(const float* im, const float* s, int64_t B, int64_t S, float margin, int kind, float* scores,
+                      float* G, float* loss, vag_stream_t stream);
+int vag_rank_loss_bwd(const float* im, const float* s, const float* G, const float* d_loss, int64_t B, int64_t S,
+                      float* d_im, float* d_s, vag_stream_t stream);
+
+/* ---- a2: decoder initial state, models/...V11.py:118 / NMT_Seq2Seq_Beam_V2.py:85 ---------------------- */
+/* x = split*ctx + (1-split)*sum_t enc/sum_t mask (ctx NULL: text-only, x = mean);  h0 = tanh(W x + b).
+ * xmix (B,C) is saved. */
+int vag_dec_init_fwd(const float* enc, const float* mask, const float* ctx, float split, const float* W,
+                     const float* b, int64_t B, int64_t Ts, int64_t C, int64_t H, float* xmix, float* h0,
+                     vag_stream_t stream);
+/* d_h0 consumed.  d_enc written or added; d_ctx (may be NULL) written.  scratch: B*C floats. */
+int vag_dec_init_bwd(const float* mask, const float* xmix, const float* h0, float split, const float* W,
+                     float* d_h0, int64_t B, int64_t Ts, int64_t C, int64_t H, float* d_enc, int accumulate_enc,
+                     float* d_ctx, float* g_W, float* g_b, float* scratch, vag_stream_t stream);
+
+/* ---- a10: beam-search step, models/...V11.py:262-313 -------------------------------------------------- */
+/* One expansion for B sentences x k beams over V words (step di >= 1).  logp (B*k, ldl) is modified in place
+ * (repeat-token suppression :279-280, finished hypotheses forced to EOS at cost 0 :291-294, inf = -1e5).
+ * nll (B,k) running scores in/out; beam (max_len,B,k) int64 history, rows < di permuted (:309), row di
+ * written (:306); h_in (B*k,H) -> h_out re-ordered by back-pointer (:273,:313); n_alive (1) int32 = number of
+ * hypotheses whose previous token is not EOS (host-sync-free early exit test).  scratch: B*k*2 floats + ... */
+int64_t vag_beam_scratch_bytes(int64_t B, int64_t k, int64_t V, int64_t max_len);
+int vag_beam_step(float* logp, int64_t ldl, float* nll, int64_t* beam, int64_t di, int64_t max_len,
+                  const float* h_in, float* h_out, int64_t B, int64_t k, int64_t V, int64_t H, int32_t* n_alive,
+                  void* scratch, vag_stream_t stream);
+/* Final selection (:315-324): force EOS in the last row, length-normalise, pick the best hypothesis.
+ * out (B,max_len) int64, best_score (B). */
+int vag_beam_finish(const float* nll, int64_t* beam, int64_t max_len, int64_t B, int64_t k, int64_t* out,
+                    float* best_score, vag_stream_t stream);
+
+/* ---- a13: optimiser step, train.py:46-49 + nmt_multimodal_beam_DE.py:303-332 -------------------------- */
+/* Global-norm clip (clip_grad_norm_, eps 1e-6) fused with Adam over one flat fp32 buffer of n elements split
+ * into nseg contiguous segments [seg_off[i], seg_off[i+1]) with their own lr / L2 weight decay (the reference's
+ * param groups).  grad_scale multiplies every gradient first (1/world_size after a sum all-reduce).
+ * seg_off (nseg+1), seg_lr, seg_wd are HOST arrays (read while enqueuing).  step: device int32 counter,
+ * incremented here.  norm_out (1): total gradient norm before clipping.  scratch: 32 bytes, 8-byte aligned. */
+int vag_clip_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
+                       const float* seg_lr, const float* seg_wd, float clip, float grad_scale, float beta1,
+                       float beta2, float eps, int32_t* step, float* norm_out, void* scratch, vag_stream_t stream);
+
+/* ---- dropout helpers ---------------------------------------------------------------------------------- */
+/* which: 1 encoder-embedding (Ts,B,E), 2 encoder-context (B,Ts,2H), 3 decoder-output (Tt,B,E). */
+int vag_dropout_mask(const uint64_t* rng, int which, int64_t n, float p, float* out, vag_stream_t stream);
+int vag_rng_advance(uint64_t* rng, vag_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAG_NMT_H */

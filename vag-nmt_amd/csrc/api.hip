@@ -1,0 +1,726 @@
+// C ABI of libvagnmt.so (include/vag_nmt.h): host-side orchestration of the kernel launches for every
+// operator of the VAG-NMT hot path.  No allocation, no host synchronisation: every function only enqueues
+// work on the caller's stream, so whole training steps can be captured into a HIP graph.
+#include "../../include/vag_nmt.h"
+#include "kernels.h"
+
+#define S_(x) reinterpret_cast<hipStream_t>(x)
+
+static inline int zero_async(void* p, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return VAG_OK;
+    hipError_t e = hipMemsetAsync(p, 0, bytes, s);
+    return e == hipSuccess ? VAG_OK : (int)e;
+}
+static inline int copy_async(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return VAG_OK;
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+    return e == hipSuccess ? VAG_OK : (int)e;
+}
+// y = act(x W^T + b): small-M kernel for a single time step, tiled kernel otherwise.
+static int linear_fwd(int64_t M, int64_t N, int64_t K, const float* x, int64_t ldx, const float* W, const float* bias,
+                      int act, float* y, int64_t ldy, hipStream_t s) {
+    if (M <= 128) return vag_skinny_launch(M, N, K, x, ldx, W, K, bias, nullptr, 0, y, ldy, act, s);
+    return vag_gemm_launch(M, N, K, 1.f, x, ldx, 1, W, 1, K, 0.f, y, ldy, bias, act, s);
+}
+// C (+)= A^T B with A (R,M) lda, B (R,N) ldb: weight gradients  g_W[m,n] += sum_r dY[r,m] X[r,n]
+static int gemm_tn_acc(int64_t M, int64_t N, int64_t R, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                       int64_t ldc, hipStream_t s) {
+    if (R == 0) return VAG_OK;
+    return vag_gemm_launch(M, N, R, 1.f, A, 1, lda, B, ldb, 1, 1.f, C, ldc, nullptr, VAG_ACT_NONE, s);
+}
+// C = beta*C + A B with A (M,K) lda, B (K,N) ldb: data gradients  dX = dY W
+static int gemm_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
+                   float* C, int64_t ldc, hipStream_t s) {
+    return vag_gemm_launch(M, N, K, 1.f, A, lda, 1, B, ldb, 1, beta, C, ldc, nullptr, VAG_ACT_NONE, s);
+}
+
+extern "C" {
+
+int vag_version(void) { return 100; }
+
+int vag_gemm_f32(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak, const float* B,
+                 int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc, const float* bias, int act,
+                 vag_stream_t stream) {
+    return vag_gemm_launch(M, N, K, alpha, A, sam, sak, B, sbk, sbn, beta, C, ldc, bias, act, S_(stream));
+}
+
+int vag_linear_fwd(int64_t M, int64_t N, int64_t K, const float* x, const float* W, const float* bias, int act, float* y,
+                   vag_stream_t stream) {
+    VAG_CHECK_ARG(x && W && y && M >= 0 && N > 0 && K > 0);
+    return linear_fwd(M, N, K, x, K, W, bias, act, y, N, S_(stream));
+}
+
+int vag_linear_bwd(int64_t M, int64_t N, int64_t K, const float* x, const float* W, const float* y, float* dy, int act,
+                   float* d_x, int accumulate_dx, float* g_W, float* g_b, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(x && W && dy && M >= 0 && N > 0 && K > 0 && (!act || y));
+    if (M == 0) return VAG_OK;
+    if (act) VAG_TRY(vag_tanh_bwd_launch(y, dy, dy, M * N, nullptr, 0, 0.f, s));
+    if (d_x) VAG_TRY(gemm_nn(M, K, N, dy, N, W, K, accumulate_dx ? 1.f : 0.f, d_x, K, s));
+    if (g_W) VAG_TRY(gemm_tn_acc(N, K, M, dy, N, x, K, g_W, K, s));
+    if (g_b) VAG_TRY(vag_colsum_launch(dy, M, N, N, g_b, s));
+    return VAG_OK;
+}
+
+int vag_embed_fwd(const int64_t* idx, int64_t n, const float* W, int64_t E, float* out, vag_stream_t stream) {
+    return vag_embed_gather_launch(idx, 1, 0, n, 1, W, E, out, nullptr, 0, 0.f, S_(stream));
+}
+int vag_embed_bwd(const int64_t* idx, int64_t n, const float* d_out, int64_t E, float* g_W, vag_stream_t stream) {
+    return vag_embed_scatter_launch(idx, 1, 0, n, 1, d_out, E, g_W, nullptr, 0, 0.f, S_(stream));
+}
+
+// =====================================================================================================
+// bi-GRU encoder
+// =====================================================================================================
+struct BiGruWs {
+    float *x, *xp, *hst, *gates, *dgh, *carry, *dx, *whhT;
+    int64_t total;
+};
+static BiGruWs bigru_ws(float* ws, int64_t B, int64_t Ts, int64_t E, int64_t H) {
+    BiGruWs w;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { float* p = ws ? ws + o : nullptr; o += (n + 3) & ~3ll; return p; };
+    w.x = take(Ts * B * E);              // embedded (+dropout) input, time-major (Ts,B,E)
+    w.xp = take(Ts * B * 6 * H);         // input projections [fwd 3H | rev 3H]; reused as d_xp in backward
+    w.hst = take(2 * (Ts + 1) * B * H);  // [dir][step][B][H] hidden states in processing order, step 0 = zeros
+    w.gates = take(2 * Ts * 4 * B * H);  // [dir][step][r,z,n,hn][B][H]
+    w.dgh = take(2 * Ts * B * 3 * H);    // backward: [dir][step][B][3H]
+    w.carry = take(4 * B * H);           // backward: [dir][2][B][H]
+    w.dx = take(Ts * B * E);             // backward: d(embedded input)
+    w.whhT = take(2 * 3 * H * H);        // backward: W_hh^T per direction (H,3H)
+    w.total = o;
+    return w;
+}
+int64_t vag_bigru_ws_floats(int64_t B, int64_t Ts, int64_t E, int64_t H) { return bigru_ws(nullptr, B, Ts, E, H).total; }
+
+int vag_bigru_seq_fwd(const int64_t* src, const int32_t* lengths, const float* emb, vag_gru_w fw, vag_gru_w bw, float p_emb,
+                      float p_ctx, const uint64_t* rng, int64_t B, int64_t Ts, int64_t E, int64_t H, float* enc,
+                      float* mask, float* ws, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(src && lengths && emb && enc && mask && ws && B > 0 && Ts > 0 && E > 0 && H > 0);
+    VAG_CHECK_ARG(E % 4 == 0 && H % 4 == 0 && aligned16(ws) && aligned16(enc));
+    VAG_CHECK_ARG(fw.w_ih && fw.w_hh && fw.b_ih && fw.b_hh && bw.w_ih && bw.w_hh && bw.b_ih && bw.b_hh);
+    BiGruWs w = bigru_ws(ws, B, Ts, E, H);
+    const int64_t R = Ts * B;
+    VAG_TRY(vag_src_mask_launch(src, B * Ts, mask, s));
+    VAG_TRY(vag_embed_gather_launch(src, 1, Ts, Ts, B, emb, E, w.x, rng, VAG_DROP_ENC_EMB, p_emb, s));
+    VAG_TRY(vag_gemm_launch(R, 3 * H, E, 1.f, w.x, E, 1, fw.w_ih, 1, E, 0.f, w.xp, 6 * H, fw.b_ih, 0, s));
+    VAG_TRY(vag_gemm_launch(R, 3 * H, E, 1.f, w.x, E, 1, bw.w_ih, 1, E, 0.f, w.xp + 3 * H, 6 * H, bw.b_ih, 0, s));
+    const int64_t BH = B * H;
+    VAG_TRY(zero_async(w.hst, BH * sizeof(float), s));
+    VAG_TRY(zero_async(w.hst + (Ts + 1) * BH, BH * sizeof(float), s));
+    GruStepArgs a = {};
+    a.lda = H; a.ldw = H; a.ldother = 6 * H; a.ldh = H; a.ld2 = Ts * 2 * H;
+    a.M = (int)B; a.K = (int)H; a.H = (int)H; a.lengths = lengths; a.comp_hidden = 1;
+    for (int64_t k = 0; k < Ts; ++k) {
+        for (int d = 0; d < 2; ++d) {
+            const int64_t t = d == 0 ? k : Ts - 1 - k;
+            const vag_gru_w& g = d == 0 ? fw : bw;
+            float* hs = w.hst + d * (Ts + 1) * BH;
+            GruSide& sd = a.s[d];
+            sd.A = hs + k * BH; sd.W = g.w_hh; sd.bias = g.b_hh;
+            sd.other = w.xp + t * B * 6 * H + d * 3 * H;
+            sd.hprev = hs + k * BH; sd.hout = hs + (k + 1) * BH;
+            sd.out2 = enc + t * 2 * H + d * H;
+            sd.save = w.gates + (d * Ts + k) * 4 * BH;
+            sd.t = (int)t;
+        }
+        VAG_TRY(vag_gru_step_launch(a, 2, s));
+    }
+    VAG_TRY(vag_dropout_apply_launch(enc, B * Ts * 2 * H, 0, rng, VAG_DROP_ENC_CTX, p_ctx, s));
+    return VAG_OK;
+}
+
+int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, vag_gru_w bw, float p_emb, float p_ctx,
+                      const uint64_t* rng, int64_t B, int64_t Ts, int64_t E, int64_t H, float* d_enc, float* ws,
+                      float* g_emb, vag_gru_g g_fw, vag_gru_g g_bw, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(src && lengths && d_enc && ws && g_emb && B > 0 && Ts > 0 && E % 4 == 0 && H % 4 == 0);
+    BiGruWs w = bigru_ws(ws, B, Ts, E, H);
+    const int64_t R = Ts * B, BH = B * H;
+    float* d_xp = w.xp;      // forward input projections are no longer needed (gates are saved)
+    for (int d = 0; d < 2; ++d) {
+        const vag_gru_w& g = d == 0 ? fw : bw;
+        VAG_TRY(vag_transpose_launch(g.w_hh, 3 * H, H, w.whhT + d * 3 * H * H, s));
+    }
+    VAG_TRY(zero_async(w.carry, 4 * BH * sizeof(float), s));
+    GruBwdArgs a = {};
+    a.ld_add = Ts * 2 * H; a.ldh = H; a.ldgi = 6 * H; a.ldgh = 3 * H;
+    a.M = (int)B; a.H = (int)H; a.lengths = lengths; a.rng = rng; a.sid = VAG_DROP_ENC_CTX; a.p = p_ctx;
+    int cur = 0;
+    for (int64_t k = Ts - 1; k >= 0; --k) {
+        for (int d = 0; d < 2; ++d) {
+            const int64_t t = d == 0 ? k : Ts - 1 - k;
+            GruBwdSide& sd = a.s[d];
+            sd.dh_carry = w.carry + (d * 2 + cur) * BH;
+            sd.dh_add = d_enc + t * 2 * H + d * H;
+            sd.drop_idx0 = t * 2 * H + d * H;
+            sd.save = w.gates + (d * Ts + k) * 4 * BH;
+            sd.hprev = w.hst + (d * (Ts + 1) + k) * BH;
+            sd.dgi = d_xp + t * B * 6 * H + d * 3 * H;
+            sd.dgh = w.dgh + (d * Ts + k) * B * 3 * H;
+            sd.dh_prev = w.carry + (d * 2 + (cur ^ 1)) * BH;
+            sd.t = (int)t;
+        }
+        VAG_TRY(vag_gru_bwd_elem_launch(a, 2, s));
+        for (int d = 0; d < 2; ++d) {
+            float* nxt = w.carry + (d * 2 + (cur ^ 1)) * BH;
+            VAG_TRY(vag_skinny_launch(B, H, 3 * H, w.dgh + (d * Ts + k) * B * 3 * H, 3 * H, w.whhT + d * 3 * H * H, 3 * H,
+                                      nullptr, nxt, H, nxt, H, 0, s));
+        }
+        cur ^= 1;
+    }
+    for (int d = 0; d < 2; ++d) {
+        const vag_gru_w& g = d == 0 ? fw : bw;
+        const vag_gru_g& gg = d == 0 ? g_fw : g_bw;
+        const float* dgh = w.dgh + d * Ts * B * 3 * H;
+        const float* hs = w.hst + d * (Ts + 1) * BH;
+        VAG_TRY(gemm_tn_acc(3 * H, H, R, dgh, 3 * H, hs, H, gg.w_hh, H, s));
+        VAG_TRY(vag_colsum_launch(dgh, R, 3 * H, 3 * H, gg.b_hh, s));
+        VAG_TRY(gemm_tn_acc(3 * H, E, R, d_xp + d * 3 * H, 6 * H, w.x, E, gg.w_ih, E, s));
+        VAG_TRY(vag_colsum_launch(d_xp + d * 3 * H, R, 3 * H, 6 * H, gg.b_ih, s));
+        VAG_TRY(gemm_nn(R, E, 3 * H, d_xp + d * 3 * H, 6 * H, g.w_ih, E, d == 0 ? 0.f : 1.f, w.dx, E, s));
+    }
+    VAG_TRY(vag_embed_scatter_launch(src, 1, Ts, Ts, B, w.dx, E, g_emb, rng, VAG_DROP_ENC_EMB, p_emb, s));
+    return VAG_OK;
+}
+
+// =====================================================================================================
+// attention keys
+// =====================================================================================================
+int vag_attn_keys_proj(const float* enc, const float* attn_e, int64_t rows, int64_t C, float* pe, vag_stream_t stream) {
+    VAG_CHECK_ARG(enc && attn_e && pe && rows > 0 && C > 0);
+    return linear_fwd(rows, C, C, enc, C, attn_e, nullptr, 0, pe, C, S_(stream));
+}
+// a4 stand-alone (inference): alpha = softmax_s(v . tanh(pe_s + q)), ctx = sum_s alpha_s enc_s
+int vag_bahdanau_attn_fwd(const float* pe, const float* q, const float* v, const float* mask, const float* enc, int64_t N,
+                          int64_t rows_per_src, int64_t Ts, int64_t C, float* scores, float* alpha, float* ctx,
+                          vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(pe && q && v && enc && scores && alpha && ctx);
+    VAG_TRY(vag_attn_scores_launch(0, pe, q, v, mask, N, rows_per_src, Ts, C, scores, s));
+    return vag_attn_ctx_launch(1, scores, enc, N, rows_per_src, Ts, C, alpha, ctx, s);
+}
+int vag_attn_keys_proj_bwd(const float* enc, const float* attn_e, const float* d_pe, int64_t rows, int64_t C, float* d_enc,
+                           int accumulate_enc, float* g_attn_e, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(enc && attn_e && d_pe && rows > 0 && C > 0);
+    if (d_enc) VAG_TRY(gemm_nn(rows, C, C, d_pe, C, attn_e, C, accumulate_enc ? 1.f : 0.f, d_enc, C, s));
+    if (g_attn_e) VAG_TRY(gemm_tn_acc(C, C, rows, d_pe, C, enc, C, g_attn_e, C, s));
+    return VAG_OK;
+}
+
+// =====================================================================================================
+// cGRU decoder
+// =====================================================================================================
+struct CgruWs {
+    float *xp1, *h1, *g1, *g2, *q, *hp2, *scores, *alpha, *cp, *tmp;
+    int64_t total;
+};
+static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
+    CgruWs w;
+    const int64_t C = 2 * H;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { float* p = ws ? ws + o : nullptr; o += (n + 3) & ~3ll; return p; };
+    w.xp1 = take(Tt * B * 3 * H);
+    w.h1 = take(Tt * B * H);
+    w.g1 = take(Tt * 4 * B * H);
+    w.g2 = take(Tt * 4 * B * H);
+    w.q = take(Tt * B * C);
+    w.hp2 = take(B * 3 * H);
+    w.scores = take(B * Ts);
+    w.alpha = take(Tt * B * Ts);
+    w.cp = take(Tt * B * H);
+    w.tmp = take(B * E);
+    w.total = o;
+    return w;
+}
+int64_t vag_cgru_ws_floats(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
+    return cgru_ws(nullptr, B, Ts, Tt, E, H).total;
+}
+
+struct StepBufs {   // per-step buffers of one decoder step (training: slices of the sequence arrays)
+    const float* xp1;   // (N,3H) input projection of gru_1 (bias included)
+    const float* hprev; // (N,H)
+    float *h1, *g1, *g2, *q, *hp2, *scores, *alpha, *c, *cp, *h2;
+};
+
+// One cGRU step for N rows (layers/NMT_Decoder.py:121-129).
+static int cgru_step(const float* enc, const float* pe, const float* mask, int64_t rps, const vag_dec_w& w, int64_t N,
+                     int64_t Ts, int64_t H, const StepBufs& b, hipStream_t s) {
+    const int64_t C = 2 * H;
+    GruStepArgs a = {};
+    a.lda = H; a.ldw = H; a.ldother = 3 * H; a.ldh = H; a.ld2 = 0;
+    a.M = (int)N; a.K = (int)H; a.H = (int)H; a.lengths = nullptr; a.comp_hidden = 1;
+    a.s[0].A = b.hprev; a.s[0].W = w.gru1.w_hh; a.s[0].bias = w.gru1.b_hh; a.s[0].other = b.xp1;
+    a.s[0].hprev = b.hprev; a.s[0].hout = b.h1; a.s[0].out2 = nullptr; a.s[0].save = b.g1; a.s[0].t = 0;
+    VAG_TRY(vag_gru_step_launch(a, 1, s));                                                        // :121
+    VAG_TRY(vag_skinny_launch(N, C, H, b.h1, H, w.attn_h, H, nullptr, nullptr, 0, b.q, C, 0, s)); // attn_h(hidden) :47
+    VAG_TRY(vag_skinny_launch(N, 3 * H, H, b.h1, H, w.gru2.w_hh, H, w.gru2.b_hh, nullptr, 0, b.hp2, 3 * H, 0, s));
+    VAG_TRY(vag_attn_scores_launch(0, pe, b.q, w.attn_v, mask, N, rps, Ts, C, b.scores, s));       // :47-51, :41-43
+    VAG_TRY(vag_attn_ctx_launch(1, b.scores, enc, N, rps, Ts, C, b.alpha, b.c, s));                // :44, :126
+    VAG_TRY(vag_skinny_launch(N, H, C, b.c, C, w.c2h, C, nullptr, nullptr, 0, b.cp, H, 0, s));     // :127
+    a.K = (int)H; a.comp_hidden = 0;
+    a.s[0].A = b.cp; a.s[0].W = w.gru2.w_ih; a.s[0].bias = w.gru2.b_ih; a.s[0].other = b.hp2;
+    a.s[0].hprev = b.h1; a.s[0].hout = b.h2; a.s[0].save = b.g2;
+    VAG_TRY(vag_gru_step_launch(a, 1, s));                                                        // :129
+    return VAG_OK;
+}
+
+// tanh(W1 h2 + W2 c + W3 e + biases) -> dropout -> logits   for N rows of one step (NMT_Decoder.py:137-143)
+static int head_step(const float* h2, const float* c, const float* e, const vag_head_w& w, int64_t N, int64_t E, int64_t H,
+                     int64_t V, float p_out, const uint64_t* rng, int64_t drop_idx0, float* tmp, float* tmid,
+                     float* logits, int64_t ldl, hipStream_t s) {
+    const int64_t C = 2 * H;
+    VAG_TRY(vag_skinny_launch(N, E, H, h2, H, w.w1, H, w.b1, nullptr, 0, tmp, E, 0, s));
+    VAG_TRY(vag_skinny_launch(N, E, C, c, C, w.w2, C, w.b2, tmp, E, tmp, E, 0, s));
+    VAG_TRY(vag_skinny_launch(N, E, E, e, E, w.w3, E, w.b3, tmp, E, tmid, E, VAG_ACT_TANH, s));
+    VAG_TRY(vag_dropout_apply_launch(tmid, N * E, drop_idx0, rng, VAG_DROP_DEC_OUT, p_out, s));
+    VAG_TRY(linear_fwd(N, V, E, tmid, E, w.out_w, w.out_b, 0, logits, ldl, s));
+    return VAG_OK;
+}
+
+static bool dec_w_ok(const vag_dec_w& w) {
+    return w.emb && w.gru1.w_ih && w.gru1.w_hh && w.gru1.b_ih && w.gru1.b_hh && w.attn_h && w.attn_v && w.c2h &&
+           w.gru2.w_ih && w.gru2.w_hh && w.gru2.b_ih && w.gru2.b_hh;
+}
+
+int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float* mask, const float* h0, int64_t* tok,
+                                 vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, int64_t V,
+                                 float* h2_all, float* c_all, float* e_all, float* ws, int free_run,
+                                 const vag_head_w* head, float p_out, const uint64_t* rng, float* tmid, float* logits,
+                                 int64_t ldl, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(enc && pe && mask && h0 && tok && h2_all && c_all && e_all && ws && dec_w_ok(w));
+    VAG_CHECK_ARG(B > 0 && Ts > 0 && Tt > 0 && E % 4 == 0 && H % 4 == 0 && E > 0 && H > 0 && aligned16(ws));
+    VAG_CHECK_ARG(!free_run || (head && tmid && logits && ldl >= V && ldl % 4 == 0));
+    const int64_t C = 2 * H, BH = B * H;
+    CgruWs k = cgru_ws(ws, B, Ts, Tt, E, H);
+    if (!free_run) {
+        // teacher forcing: every input token is known -> embed and project all steps at once
+        VAG_TRY(vag_embed_gather_launch(tok, B, 1, Tt, B, w.emb, E, e_all, nullptr, 0, 0.f, s));
+        VAG_TRY(vag_gemm_launch(Tt * B, 3 * H, E, 1.f, e_all, E, 1, w.gru1.w_ih, 1, E, 0.f, k.xp1, 3 * H, w.gru1.b_ih, 0, s));
+    }
+    for (int64_t t = 0; t < Tt; ++t) {
+        if (free_run) {
+            VAG_TRY(vag_embed_gather_launch(tok + t * B, B, 1, 1, B, w.emb, E, e_all + t * B * E, nullptr, 0, 0.f, s));
+            VAG_TRY(vag_skinny_launch(B, 3 * H, E, e_all + t * B * E, E, w.gru1.w_ih, E, w.gru1.b_ih, nullptr, 0,
+                                      k.xp1 + t * B * 3 * H, 3 * H, 0, s));
+        }
+        StepBufs b;
+        b.xp1 = k.xp1 + t * B * 3 * H;
+        b.hprev = t == 0 ? h0 : h2_all + (t - 1) * BH;
+        b.h1 = k.h1 + t * BH; b.g1 = k.g1 + t * 4 * BH; b.g2 = k.g2 + t * 4 * BH;
+        b.q = k.q + t * B * C; b.hp2 = k.hp2; b.scores = k.scores; b.alpha = k.alpha + t * B * Ts;
+        b.c = c_all + t * B * C; b.cp = k.cp + t * BH; b.h2 = h2_all + t * BH;
+        VAG_TRY(cgru_step(enc, pe, mask, 1, w, B, Ts, H, b, s));
+        if (free_run) {
+            VAG_TRY(head_step(b.h2, b.c, e_all + t * B * E, *head, B, E, H, V, p_out, rng, t * B * E, k.tmp,
+                              tmid + t * B * E, logits + t * B * ldl, ldl, s));
+            // next input = argmax of this step's distribution (V11.py:157), written to tok row t+1
+            VAG_TRY(vag_lse_nll_launch(logits + t * B * ldl, ldl, B, V, nullptr, 0, 0, nullptr, nullptr, nullptr,
+                                       tok + (t + 1) * B, 1, nullptr, 0, s));
+        }
+    }
+    return VAG_OK;
+}
+
+struct CgruBwdScratch {
+    float *wih2T, *c2hT, *whT, *whh2T, *whh1T, *dgi2, *dgh2, *dcp, *dalpha, *ds, *dq, *dgi1, *dgh1, *dh1, *carry, *de, *dvp;
+    int64_t total;
+};
+static CgruBwdScratch cgru_bwd_scratch(float* p, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
+    CgruBwdScratch w;
+    const int64_t C = 2 * H, R = Tt * B;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { float* q = p ? p + o : nullptr; o += (n + 3) & ~3ll; return q; };
+    w.wih2T = take(3 * H * H); w.c2hT = take(C * H); w.whT = take(C * H); w.whh2T = take(3 * H * H); w.whh1T = take(3 * H * H);
+    w.dgi2 = take(R * 3 * H); w.dgh2 = take(R * 3 * H); w.dcp = take(R * H);
+    w.dalpha = take(B * Ts); w.ds = take(R * Ts); w.dq = take(R * C);
+    w.dgi1 = take(R * 3 * H); w.dgh1 = take(R * 3 * H);
+    w.dh1 = take(B * H); w.carry = take(B * H); w.de = take(R * E); w.dvp = take(B * C);
+    w.total = o;
+    return w;
+}
+int64_t vag_cgru_bwd_scratch_floats(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
+    return cgru_bwd_scratch(nullptr, B, Ts, Tt, E, H).total;
+}
+
+int vag_cgru_attn_decode_seq_bwd(const float* enc, const float* pe, const float* mask, const float* h0, const int64_t* tok,
+                                 vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, int64_t V,
+                                 const float* h2_all, const float* c_all, const float* e_all, float* d_h2_all,
+                                 float* d_c_all, const float* d_e_all, float* ws, float* d_enc_out, int accumulate_enc,
+                                 float* d_pe, float* d_h0, vag_dec_g g, float* scratch, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(enc && pe && mask && h0 && tok && h2_all && c_all && e_all && d_h2_all && d_c_all && ws && d_enc_out &&
+                  d_pe && d_h0 && scratch && dec_w_ok(w));
+    VAG_CHECK_ARG(B > 0 && Ts > 0 && Tt > 0 && E % 4 == 0 && H % 4 == 0 && aligned16(ws) && aligned16(scratch));
+    (void)V; (void)mask;
+    const int64_t C = 2 * H, BH = B * H, R = Tt * B;
+    CgruWs k = cgru_ws(ws, B, Ts, Tt, E, H);
+    CgruBwdScratch z = cgru_bwd_scratch(scratch, B, Ts, Tt, E, H);
+    // all per-step products are written in "x W^T" form, so transpose the weights once per call
+    VAG_TRY(vag_transpose_launch(w.gru2.w_ih, 3 * H, H, z.wih2T, s));   // (H,3H)
+    VAG_TRY(vag_transpose_launch(w.c2h, H, C, z.c2hT, s));              // (C,H)
+    VAG_TRY(vag_transpose_launch(w.attn_h, C, H, z.whT, s));            // (H,C)
+    VAG_TRY(vag_transpose_launch(w.gru2.w_hh, 3 * H, H, z.whh2T, s));   // (H,3H)
+    VAG_TRY(vag_transpose_launch(w.gru1.w_hh, 3 * H, H, z.whh1T, s));   // (H,3H)
+    GruBwdArgs a = {};
+    a.ld_add = H; a.ldh = H; a.ldgi = 3 * H; a.ldgh = 3 * H; a.M = (int)B; a.H = (int)H;
+    a.lengths = nullptr; a.rng = nullptr; a.sid = 0; a.p = 0.f;
+    for (int64_t t = Tt - 1; t >= 0; --t) {
+        float* dgi2 = z.dgi2 + t * B * 3 * H; float* dgh2 = z.dgh2 + t * B * 3 * H;
+        float* dgi1 = z.dgi1 + t * B * 3 * H; float* dgh1 = z.dgh1 + t * B * 3 * H;
+        float* dcp = z.dcp + t * BH; float* dc = d_c_all + t * B * C;
+        float* ds = z.ds + t * B * Ts; float* dq = z.dq + t * B * C;
+        const float* h1 = k.h1 + t * BH;
+        // gru_2 backward (elementwise part): dh2 = d_h2_all[t] + carry from step t+1
+        GruBwdSide& sd = a.s[0];
+        sd.dh_carry = (t == Tt - 1) ? nullptr : z.carry;
+        sd.dh_add = d_h2_all + t * BH; sd.drop_idx0 = 0;
+        sd.save = k.g2 + t * 4 * BH; sd.hprev = h1; sd.dgi = dgi2; sd.dgh = dgh2; sd.dh_prev = z.dh1; sd.t = 0;
+        VAG_TRY(vag_gru_bwd_elem_launch(a, 1, s));
+        VAG_TRY(vag_skinny_launch(B, H, 3 * H, dgi2, 3 * H, z.wih2T, 3 * H, nullptr, nullptr, 0, dcp, H, 0, s));
+        VAG_TRY(vag_skinny_launch(B, C, H, dcp, H, z.c2hT, H, nullptr, dc, C, dc, C, 0, s));   // dc = dcp W_c2h + d_c_all[t]
+        // attention backward: c = sum_s alpha_s enc_s ; alpha = softmax(score)
+        VAG_TRY(vag_attn_scores_launch(1, enc, dc, nullptr, nullptr, B, 1, Ts, C, z.dalpha, s));
+        VAG_TRY(vag_softmax_bwd_launch(k.alpha + t * B * Ts, z.dalpha, B, Ts, ds, s));
+        VAG_TRY(vag_attn_dq_launch(pe, k.q + t * B * C, w.attn_v, ds, B, Ts, C, dq, s));
+        // dh1 = z2*dh2 + dq W_h + dgh2 W_hh2
+        VAG_TRY(vag_skinny_launch(B, H, C, dq, C, z.whT, C, nullptr, z.dh1, H, z.dh1, H, 0, s));
+        VAG_TRY(vag_skinny_launch(B, H, 3 * H, dgh2, 3 * H, z.whh2T, 3 * H, nullptr, z.dh1, H, z.dh1, H, 0, s));
+        // gru_1 backward
+        sd.dh_carry = z.dh1; sd.dh_add = nullptr;
+        sd.save = k.g1 + t * 4 * BH; sd.hprev = (t == 0) ? h0 : h2_all + (t - 1) * BH;
+        sd.dgi = dgi1; sd.dgh = dgh1; sd.dh_prev = z.carry;
+        VAG_TRY(vag_gru_bwd_elem_launch(a, 1, s));
+        VAG_TRY(vag_skinny_launch(B, H, 3 * H, dgh1, 3 * H, z.whh1T, 3 * H, nullptr, z.carry, H, z.carry, H, 0, s));
+    }
+    VAG_TRY(copy_async(d_h0, z.carry, BH * sizeof(float), s));
+    // after the loop: everything that does not sit on the recurrence's critical path, as large products
+    VAG_TRY(vag_attn_post_bwd_launch(pe, k.q, w.attn_v, z.ds, k.alpha, d_c_all, B, Ts, Tt, C, d_pe, z.dvp, d_enc_out,
+                                     accumulate_enc, s));
+    VAG_TRY(vag_colsum_launch(z.dvp, B, C, C, g.attn_v, s));
+    VAG_TRY(gemm_tn_acc(3 * H, H, R, z.dgh2, 3 * H, k.h1, H, g.gru2.w_hh, H, s));
+    VAG_TRY(vag_colsum_launch(z.dgh2, R, 3 * H, 3 * H, g.gru2.b_hh, s));
+    VAG_TRY(gemm_tn_acc(3 * H, H, R, z.dgi2, 3 * H, k.cp, H, g.gru2.w_ih, H, s));
+    VAG_TRY(vag_colsum_launch(z.dgi2, R, 3 * H, 3 * H, g.gru2.b_ih, s));
+    VAG_TRY(gemm_tn_acc(H, C, R, z.dcp, H, c_all, C, g.c2h, C, s));
+    VAG_TRY(gemm_tn_acc(C, H, R, z.dq, C, k.h1, H, g.attn_h, H, s));
+    VAG_TRY(gemm_tn_acc(3 * H, H, B, z.dgh1, 3 * H, h0, H, g.gru1.w_hh, H, s));
+    VAG_TRY(gemm_tn_acc(3 * H, H, R - B, z.dgh1 + B * 3 * H, 3 * H, h2_all, H, g.gru1.w_hh, H, s));
+    VAG_TRY(vag_colsum_launch(z.dgh1, R, 3 * H, 3 * H, g.gru1.b_hh, s));
+    VAG_TRY(gemm_tn_acc(3 * H, E, R, z.dgi1, 3 * H, e_all, E, g.gru1.w_ih, E, s));
+    VAG_TRY(vag_colsum_launch(z.dgi1, R, 3 * H, 3 * H, g.gru1.b_ih, s));
+    // d(embedded inputs) = dgi1 W_ih1 (+ the head's W3 path), scattered into the embedding gradient
+    if (d_e_all) VAG_TRY(copy_async(z.de, d_e_all, R * E * sizeof(float), s));
+    VAG_TRY(gemm_nn(R, E, 3 * H, z.dgi1, 3 * H, w.gru1.w_ih, E, d_e_all ? 1.f : 0.f, z.de, E, s));
+    VAG_TRY(vag_embed_scatter_launch(tok, B, 1, Tt, B, z.de, E, g.emb, nullptr, 0, 0.f, s));
+    return VAG_OK;
+}
+
+int64_t vag_cgru_step_scratch_floats(int64_t N, int64_t Ts, int64_t E, int64_t H) {
+    return N * (3 * H + H + 2 * H + 3 * H + Ts + H) + 64 + 0 * E;
+}
+int vag_cgru_attn_decode_step(const float* enc, const float* pe, const float* mask, int64_t rows_per_src, const int64_t* tok,
+                              const float* h_in, vag_dec_w w, int64_t N, int64_t Ts, int64_t E, int64_t H, float* h_out,
+                              float* c, float* e, float* alpha, float* scratch, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(enc && pe && mask && tok && h_in && h_out && c && e && alpha && scratch && dec_w_ok(w));
+    VAG_CHECK_ARG(N > 0 && Ts > 0 && E % 4 == 0 && H % 4 == 0 && rows_per_src >= 1 && aligned16(scratch));
+    const int64_t C = 2 * H;
+    float* p = scratch;
+    float* xp1 = p; p += N * 3 * H;
+    float* h1 = p; p += N * H;
+    float* q = p; p += N * C;
+    float* hp2 = p; p += N * 3 * H;
+    float* cp = p; p += N * H;
+    float* scores = p;
+    VAG_TRY(vag_embed_gather_launch(tok, 1, 0, N, 1, w.emb, E, e, nullptr, 0, 0.f, s));                   // :118
+    VAG_TRY(linear_fwd(N, 3 * H, E, e, E, w.gru1.w_ih, w.gru1.b_ih, 0, xp1, 3 * H, s));
+    StepBufs b;
+    b.xp1 = xp1; b.hprev = h_in; b.h1 = h1; b.g1 = nullptr; b.g2 = nullptr; b.q = q; b.hp2 = hp2; b.scores = scores;
+    b.alpha = alpha; b.c = c; b.cp = cp; b.h2 = h_out;
+    return cgru_step(enc, pe, mask, rows_per_src, w, N, Ts, H, b, s);
+}
+
+// =====================================================================================================
+// output head + cross entropy
+// =====================================================================================================
+int vag_head_ce_seq_fwd(const float* h2_all, const float* c_all, const float* e_all, vag_head_w w, const int64_t* tgt,
+                        const float* vocab_weight, int64_t B, int64_t Tt, int64_t E, int64_t H, int64_t V, float p_out,
+                        const uint64_t* rng, int logits_ready, float* tmid, float* logits, int64_t ldl, float* lse,
+                        float* nll, float* inv_cnt, float* loss_mt, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(h2_all && c_all && e_all && tgt && vocab_weight && tmid && logits && lse && nll && inv_cnt && loss_mt);
+    VAG_CHECK_ARG(w.w1 && w.b1 && w.w2 && w.b2 && w.w3 && w.b3 && w.out_w && w.out_b);
+    VAG_CHECK_ARG(B > 0 && Tt > 0 && E % 4 == 0 && H % 4 == 0 && V > 0 && ldl >= V && ldl % 4 == 0);
+    const int64_t C = 2 * H, R = Tt * B;
+    if (!logits_ready) {
+        // batched over all Tt steps (teacher forcing): three products accumulate into tmid, tanh on the last
+        VAG_TRY(vag_gemm_launch(R, E, H, 1.f, h2_all, H, 1, w.w1, 1, H, 0.f, tmid, E, w.b1, 0, s));
+        VAG_TRY(vag_gemm_launch(R, E, C, 1.f, c_all, C, 1, w.w2, 1, C, 1.f, tmid, E, w.b2, 0, s));
+        VAG_TRY(vag_gemm_launch(R, E, E, 1.f, e_all, E, 1, w.w3, 1, E, 1.f, tmid, E, w.b3, VAG_ACT_TANH, s));
+        VAG_TRY(vag_dropout_apply_launch(tmid, R * E, 0, rng, VAG_DROP_DEC_OUT, p_out, s));
+        VAG_TRY(vag_gemm_launch(R, V, E, 1.f, tmid, E, 1, w.out_w, 1, E, 0.f, logits, ldl, w.out_b, 0, s));
+    }
+    VAG_TRY(vag_inv_cnt_launch(tgt, B, Tt, inv_cnt, s));
+    VAG_TRY(vag_lse_nll_launch(logits, ldl, R, V, tgt, B, Tt, vocab_weight, lse, nll, nullptr, 0, nullptr, 0, s));
+    VAG_TRY(vag_loss_mt_launch(nll, inv_cnt, B, Tt, loss_mt, s));
+    return VAG_OK;
+}
+
+// Everything behind d(logits): out-layer gradients, tanh/dropout backward, W1/W2/W3 gradients, input gradients.
+static int head_bwd_from_dlogits(const float* h2_all, const float* c_all, const float* e_all, const vag_head_w& w,
+                                 int64_t R, int64_t E, int64_t H, int64_t V, float p_out, const uint64_t* rng,
+                                 const float* tmid, const float* dlogits, int64_t ldl, float* d_h2_all, float* d_c_all,
+                                 float* d_e_all, const vag_head_g& g, float* dt, hipStream_t s) {
+    const int64_t C = 2 * H;
+    VAG_TRY(gemm_tn_acc(V, E, R, dlogits, ldl, tmid, E, g.out_w, E, s));
+    VAG_TRY(vag_colsum_launch(dlogits, R, V, ldl, g.out_b, s));
+    VAG_TRY(gemm_nn(R, E, V, dlogits, ldl, w.out_w, E, 0.f, dt, E, s));
+    // through dropout and tanh: tmid holds tanh(.)*mul
+    VAG_TRY(vag_tanh_bwd_launch(tmid, dt, dt, R * E, rng, VAG_DROP_DEC_OUT, p_out, s));
+    VAG_TRY(gemm_tn_acc(E, H, R, dt, E, h2_all, H, g.w1, H, s));
+    VAG_TRY(gemm_tn_acc(E, C, R, dt, E, c_all, C, g.w2, C, s));
+    VAG_TRY(gemm_tn_acc(E, E, R, dt, E, e_all, E, g.w3, E, s));
+    VAG_TRY(vag_colsum_launch(dt, R, E, E, g.b1, s));
+    VAG_TRY(vag_colsum_launch(dt, R, E, E, g.b2, s));
+    VAG_TRY(vag_colsum_launch(dt, R, E, E, g.b3, s));
+    VAG_TRY(gemm_nn(R, H, E, dt, E, w.w1, H, 0.f, d_h2_all, H, s));
+    VAG_TRY(gemm_nn(R, C, E, dt, E, w.w2, C, 0.f, d_c_all, C, s));
+    VAG_TRY(gemm_nn(R, E, E, dt, E, w.w3, E, 0.f, d_e_all, E, s));
+    return VAG_OK;
+}
+
+int vag_head_ce_seq_bwd(const float* h2_all, const float* c_all, const float* e_all, vag_head_w w, const int64_t* tgt,
+                        const float* vocab_weight, int64_t B, int64_t Tt, int64_t E, int64_t H, int64_t V, float p_out,
+                        const uint64_t* rng, const float* tmid, float* logits, int64_t ldl, const float* lse,
+                        const float* inv_cnt, const float* d_loss, float* d_h2_all, float* d_c_all, float* d_e_all,
+                        vag_head_g g, float* scratch, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(h2_all && c_all && e_all && tgt && vocab_weight && tmid && logits && lse && inv_cnt && d_loss && scratch);
+    VAG_CHECK_ARG(d_h2_all && d_c_all && d_e_all && g.w1 && g.b1 && g.w2 && g.b2 && g.w3 && g.b3 && g.out_w && g.out_b);
+    VAG_CHECK_ARG(B > 0 && Tt > 0 && E % 4 == 0 && H % 4 == 0 && V > 0 && ldl >= V && ldl % 4 == 0);
+    const int64_t R = Tt * B;
+    VAG_TRY(vag_ce_bwd_launch(logits, ldl, R, V, tgt, B, Tt, vocab_weight, lse, inv_cnt, d_loss, s));
+    return head_bwd_from_dlogits(h2_all, c_all, e_all, w, R, E, H, V, p_out, rng, tmid, logits, ldl, d_h2_all, d_c_all,
+                                 d_e_all, g, scratch, s);
+}
+
+int vag_head_logp_seq_fwd(const float* h2, const float* c, const float* e, vag_head_w w, int64_t R, int64_t E, int64_t H,
+                          int64_t V, float p_out, const uint64_t* rng, float* tmid, float* logp, int64_t ldl,
+                          vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(h2 && c && e && tmid && logp && R > 0 && E % 4 == 0 && H % 4 == 0 && V > 0 && ldl >= V && ldl % 4 == 0);
+    VAG_CHECK_ARG(w.w1 && w.b1 && w.w2 && w.b2 && w.w3 && w.b3 && w.out_w && w.out_b);
+    const int64_t C = 2 * H;
+    VAG_TRY(vag_gemm_launch(R, E, H, 1.f, h2, H, 1, w.w1, 1, H, 0.f, tmid, E, w.b1, 0, s));
+    VAG_TRY(vag_gemm_launch(R, E, C, 1.f, c, C, 1, w.w2, 1, C, 1.f, tmid, E, w.b2, 0, s));
+    VAG_TRY(vag_gemm_launch(R, E, E, 1.f, e, E, 1, w.w3, 1, E, 1.f, tmid, E, w.b3, VAG_ACT_TANH, s));
+    VAG_TRY(vag_dropout_apply_launch(tmid, R * E, 0, rng, VAG_DROP_DEC_OUT, p_out, s));
+    VAG_TRY(linear_fwd(R, V, E, tmid, E, w.out_w, w.out_b, 0, logp, ldl, s));
+    return vag_lse_nll_launch(logp, ldl, R, V, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, logp, ldl, s);
+}
+
+int vag_head_logp_seq_bwd(const float* h2, const float* c, const float* e, vag_head_w w, int64_t R, int64_t E, int64_t H,
+                          int64_t V, float p_out, const uint64_t* rng, const float* tmid, const float* logp, float* d_logp,
+                          int64_t ldl, float* d_h2, float* d_c, float* d_e, vag_head_g g, float* scratch,
+                          vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(h2 && c && e && tmid && logp && d_logp && d_h2 && d_c && d_e && scratch && R > 0 && ldl >= V);
+    VAG_CHECK_ARG(g.w1 && g.b1 && g.w2 && g.b2 && g.w3 && g.b3 && g.out_w && g.out_b);
+    VAG_TRY(vag_logsoftmax_bwd_launch(logp, ldl, d_logp, ldl, R, V, s));
+    return head_bwd_from_dlogits(h2, c, e, w, R, E, H, V, p_out, rng, tmid, d_logp, ldl, d_h2, d_c, d_e, g, scratch, s);
+}
+
+int vag_head_logp_step(const float* h2, const float* c, const float* e, vag_head_w w, int64_t N, int64_t E, int64_t H,
+                       int64_t V, float* logp, int64_t ldl, int64_t* argmax, float* scratch, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(h2 && c && e && logp && scratch && N > 0 && E % 4 == 0 && H % 4 == 0 && V > 0 && ldl >= V);
+    VAG_CHECK_ARG(w.w1 && w.b1 && w.w2 && w.b2 && w.w3 && w.b3 && w.out_w && w.out_b);
+    float* tmp = scratch;            // (N,E)
+    float* tmid = scratch + N * E;   // (N,E)
+    VAG_TRY(head_step(h2, c, e, w, N, E, H, V, 0.f, nullptr, 0, tmp, tmid, logp, ldl, s));
+    VAG_TRY(vag_lse_nll_launch(logp, ldl, N, V, nullptr, 0, 0, nullptr, nullptr, nullptr, argmax, 1, logp, ldl, s));
+    return VAG_OK;
+}
+
+// =====================================================================================================
+// shared-space projections
+// =====================================================================================================
+int vag_img_proj_l2_fwd(const float* x, const float* W, const float* b, int64_t B, int64_t K, int64_t S, int act, float* y,
+                        float* nrm, float* out, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(x && W && b && y && nrm && out && B > 0 && K > 0 && S > 0);
+    VAG_TRY(linear_fwd(B, S, K, x, K, W, b, act ? VAG_ACT_TANH : 0, y, S, s));
+    return vag_l2norm_fwd_launch(y, B, S, nrm, out, s);
+}
+int vag_img_proj_l2_bwd(const float* x, const float* W, const float* y, const float* nrm, const float* out, float* d_out,
+                        int64_t B, int64_t K, int64_t S, int act, float* d_x, float* g_W, float* g_b, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(x && W && y && nrm && out && d_out && B > 0 && K > 0 && S > 0);
+    VAG_TRY(vag_l2norm_bwd_launch(y, nrm, out, d_out, B, S, act, d_out, s));
+    if (d_x) VAG_TRY(gemm_nn(B, K, S, d_out, S, W, K, 0.f, d_x, K, s));
+    if (g_W) VAG_TRY(gemm_tn_acc(S, K, B, d_out, S, x, K, g_W, K, s));
+    if (g_b) VAG_TRY(vag_colsum_launch(d_out, B, S, S, g_b, s));
+    return VAG_OK;
+}
+
+int vag_l2norm_fwd(const float* x, int64_t B, int64_t S, float* nrm, float* out, vag_stream_t stream) {
+    return vag_l2norm_fwd_launch(x, B, S, nrm, out, S_(stream));
+}
+int vag_l2norm_bwd(const float* x, const float* nrm, const float* out, const float* d_out, int64_t B, int64_t S, float* dx,
+                   vag_stream_t stream) {
+    return vag_l2norm_bwd_launch(x, nrm, out, d_out, B, S, 0, dx, S_(stream));
+}
+
+// =====================================================================================================
+// image-conditioned attention
+// =====================================================================================================
+struct ImgWs {
+    float *u, *w, *scores, *dalpha, *de, *dw, *du, *pre, *dpre, *dvp;
+    int64_t total;
+};
+static ImgWs imagine_ws(float* p, int64_t B, int64_t Ts, int64_t C, int method) {
+    ImgWs w;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { float* q = p ? p + o : nullptr; o += (n + 3) & ~3ll; return q; };
+    w.u = take(B * C); w.w = take(B * C); w.scores = take(B * Ts); w.dalpha = take(B * Ts); w.de = take(B * Ts);
+    w.dw = take(B * C); w.du = take(B * C); w.dvp = take(B * C);
+    w.pre = method == 1 ? take(B * Ts * C) : nullptr;
+    w.dpre = method == 1 ? take(B * Ts * C) : nullptr;
+    w.total = o;
+    return w;
+}
+int64_t vag_imagine_ws_floats(int64_t B, int64_t Ts, int64_t C, int64_t S, int method) {
+    (void)S;
+    return imagine_ws(nullptr, B, Ts, C, method).total;
+}
+
+int vag_imagine_attn_ctx_fwd(const float* im_emb, const float* enc, const float* mask, const float* ctx2ctx,
+                             const float* emb2ctx, const float* mlp_w, int method, int64_t B, int64_t Ts, int64_t C,
+                             int64_t S, float* alpha, float* ctx, float* ws, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(im_emb && enc && mask && ctx2ctx && emb2ctx && alpha && ctx && ws && (method == 0 || (method == 1 && mlp_w)));
+    VAG_CHECK_ARG(B > 0 && Ts > 0 && C % 4 == 0 && S % 4 == 0 && aligned16(ws));
+    ImgWs w = imagine_ws(ws, B, Ts, C, method);
+    VAG_TRY(linear_fwd(B, C, S, im_emb, S, emb2ctx, nullptr, 0, w.u, C, s));                     // emb2ctx(image_vec) :58/:76
+    if (method == 0) {
+        // e[b,t] = (W_cc enc[b,t]) . u[b] = enc[b,t] . (W_cc^T u[b])                                 :57-64
+        VAG_TRY(gemm_nn(B, C, C, w.u, C, ctx2ctx, C, 0.f, w.w, C, s));
+        VAG_TRY(vag_attn_scores_launch(1, enc, w.w, nullptr, mask, B, 1, Ts, C, w.scores, s));
+    } else {
+        VAG_TRY(linear_fwd(B * Ts, C, C, enc, C, ctx2ctx, nullptr, 0, w.pre, C, s));              // ctx2ctx(decoder_hidden) :75
+        VAG_TRY(vag_attn_scores_launch(0, w.pre, w.u, mlp_w, mask, B, 1, Ts, C, w.scores, s));   // mlp(tanh(ctx_+im_)) :78
+    }
+    return vag_attn_ctx_launch(1, w.scores, enc, B, 1, Ts, C, alpha, ctx, s);                      // softmax :46, bmm :137
+}
+
+int vag_imagine_attn_ctx_bwd(const float* im_emb, const float* enc, const float* mask, const float* ctx2ctx,
+                             const float* emb2ctx, const float* mlp_w, int method, int64_t B, int64_t Ts, int64_t C,
+                             int64_t S, const float* alpha, const float* d_ctx, float* ws, float* d_enc, int accumulate_enc,
+                             float* d_im_emb, float* g_ctx2ctx, float* g_emb2ctx, float* g_mlp_w, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(im_emb && enc && ctx2ctx && emb2ctx && alpha && d_ctx && ws && d_enc && d_im_emb && g_ctx2ctx && g_emb2ctx);
+    VAG_CHECK_ARG((method == 0) || (method == 1 && mlp_w && g_mlp_w));
+    VAG_CHECK_ARG(B > 0 && Ts > 0 && C % 4 == 0 && S % 4 == 0);
+    (void)mask;
+    ImgWs w = imagine_ws(ws, B, Ts, C, method);
+    VAG_TRY(vag_attn_scores_launch(1, enc, d_ctx, nullptr, nullptr, B, 1, Ts, C, w.dalpha, s));   // d alpha = d_ctx . enc
+    VAG_TRY(vag_softmax_bwd_launch(alpha, w.dalpha, B, Ts, w.de, s));
+    if (method == 0) {
+        VAG_TRY(vag_outer2_launch(alpha, d_ctx, w.de, w.w, B, Ts, C, d_enc, accumulate_enc, s));
+        VAG_TRY(vag_attn_ctx_launch(0, w.de, enc, B, 1, Ts, C, nullptr, w.dw, s));                // dw[b] = sum_t de enc
+        VAG_TRY(linear_fwd(B, C, C, w.dw, C, ctx2ctx, nullptr, 0, w.du, C, s));                   // du = dw W_cc^T
+        VAG_TRY(gemm_tn_acc(C, C, B, w.u, C, w.dw, C, g_ctx2ctx, C, s));                          // g_cc[i,j] += u[b,i] dw[b,j]
+    } else {
+        VAG_TRY(vag_outer2_launch(alpha, d_ctx, nullptr, nullptr, B, Ts, C, d_enc, accumulate_enc, s));
+        VAG_TRY(vag_attn_post_bwd_launch(w.pre, w.u, mlp_w, w.de, alpha, nullptr, B, Ts, 1, C, w.dpre, w.dvp, nullptr, 0, s));
+        VAG_TRY(vag_colsum_launch(w.dvp, B, C, C, g_mlp_w, s));
+        VAG_TRY(vag_attn_dq_launch(w.pre, w.u, mlp_w, w.de, B, Ts, C, w.du, s));
+        VAG_TRY(gemm_nn(B * Ts, C, C, w.dpre, C, ctx2ctx, C, 1.f, d_enc, C, s));
+        VAG_TRY(gemm_tn_acc(C, C, B * Ts, w.dpre, C, enc, C, g_ctx2ctx, C, s));
+    }
+    VAG_TRY(gemm_nn(B, S, C, w.du, C, emb2ctx, S, 0.f, d_im_emb, S, s));
+    VAG_TRY(gemm_tn_acc(C, S, B, w.du, C, im_emb, S, g_emb2ctx, S, s));
+    return VAG_OK;
+}
+
+// =====================================================================================================
+// ranking loss
+// =====================================================================================================
+int vag_rank_loss_fwd(const float* im, const float* sv, int64_t B, int64_t S, float margin, int kind, float* scores,
+                      float* G, float* loss, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(im && sv && scores && G && loss && B > 0 && S > 0);
+    VAG_TRY(vag_gemm_launch(B, B, S, 1.f, im, S, 1, sv, 1, S, 0.f, scores, B, nullptr, 0, s));   // im s^T  (:12)
+    return vag_rank_loss_launch(scores, B, margin, kind, G, loss, s);
+}
+int vag_rank_loss_bwd(const float* im, const float* sv, const float* G, const float* d_loss, int64_t B, int64_t S,
+                      float* d_im, float* d_s, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(im && sv && G && d_loss && d_im && d_s && B > 0 && S > 0);
+    VAG_TRY(gemm_nn(B, S, B, G, B, sv, S, 0.f, d_im, S, s));                                       // d_im = G s
+    VAG_TRY(vag_gemm_launch(B, S, B, 1.f, G, 1, B, im, S, 1, 0.f, d_s, S, nullptr, 0, s));        // d_s  = G^T im
+    VAG_TRY(vag_scale_by_dev_launch(d_im, B * S, d_loss, s));
+    return vag_scale_by_dev_launch(d_s, B * S, d_loss, s);
+}
+
+// =====================================================================================================
+// decoder initial state
+// =====================================================================================================
+int vag_dec_init_fwd(const float* enc, const float* mask, const float* ctx, float split, const float* W, const float* b,
+                     int64_t B, int64_t Ts, int64_t C, int64_t H, float* xmix, float* h0, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(enc && mask && W && b && xmix && h0 && B > 0 && Ts > 0 && C % 4 == 0 && H > 0);
+    VAG_TRY(vag_meanpool_mix_launch(enc, mask, ctx, split, B, Ts, C, xmix, s));
+    return linear_fwd(B, H, C, xmix, C, W, b, VAG_ACT_TANH, h0, H, s);
+}
+int vag_dec_init_bwd(const float* mask, const float* xmix, const float* h0, float split, const float* W, float* d_h0,
+                     int64_t B, int64_t Ts, int64_t C, int64_t H, float* d_enc, int accumulate_enc, float* d_ctx, float* g_W,
+                     float* g_b, float* scratch, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(mask && xmix && h0 && W && d_h0 && d_enc && g_W && g_b && scratch && B > 0 && Ts > 0 && C % 4 == 0);
+    float* dx = scratch;    // (B,C)
+    VAG_TRY(vag_tanh_bwd_launch(h0, d_h0, d_h0, B * H, nullptr, 0, 0.f, s));
+    VAG_TRY(gemm_tn_acc(H, C, B, d_h0, H, xmix, C, g_W, C, s));
+    VAG_TRY(vag_colsum_launch(d_h0, B, H, H, g_b, s));
+    VAG_TRY(gemm_nn(B, C, H, d_h0, H, W, C, 0.f, dx, C, s));
+    const float s_eff = d_ctx ? split : 0.f;
+    VAG_TRY(vag_meanpool_bwd_launch(mask, dx, 1.f - s_eff, B, Ts, C, d_enc, accumulate_enc, s));
+    if (d_ctx) VAG_TRY(vag_axpy_launch(split, dx, d_ctx, B * C, 0, s));
+    return VAG_OK;
+}
+
+// =====================================================================================================
+// beam search, optimiser, dropout helpers
+// =====================================================================================================
+int64_t vag_beam_scratch_bytes(int64_t B, int64_t k, int64_t V, int64_t max_len) {
+    (void)max_len;
+    return vag_beam_scratch_bytes_impl(B, k, V);
+}
+int vag_beam_step(float* logp, int64_t ldl, float* nll, int64_t* beam, int64_t di, int64_t max_len, const float* h_in,
+                  float* h_out, int64_t B, int64_t k, int64_t V, int64_t H, int32_t* n_alive, void* scratch,
+                  vag_stream_t stream) {
+    return vag_beam_step_launch(logp, ldl, nll, beam, di, max_len, h_in, h_out, B, k, V, H, n_alive, scratch, S_(stream));
+}
+int vag_beam_finish(const float* nll, int64_t* beam, int64_t max_len, int64_t B, int64_t k, int64_t* out, float* best_score,
+                    vag_stream_t stream) {
+    return vag_beam_finish_launch(nll, beam, max_len, B, k, out, best_score, S_(stream));
+}
+
+int vag_clip_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
+                       const float* seg_lr, const float* seg_wd, float clip, float grad_scale, float beta1, float beta2,
+                       float eps, int32_t* step, float* norm_out, void* scratch, vag_stream_t stream) {
+    return vag_clip_adam_launch(p, g, m, v, n, nseg, seg_off, seg_lr, seg_wd, clip, grad_scale, beta1, beta2, eps, step,
+                                norm_out, scratch, S_(stream));
+}
+
+int vag_dropout_mask(const uint64_t* rng, int which, int64_t n, float p, float* out, vag_stream_t stream) {
+    VAG_CHECK_ARG(which >= 1 && which <= 3);
+    return vag_dropout_mask_launch(rng, which, n, p, out, S_(stream));
+}
+int vag_rng_advance(uint64_t* rng, vag_stream_t stream) { return vag_rng_advance_launch(rng, S_(stream)); }
+
+}  // extern "C"

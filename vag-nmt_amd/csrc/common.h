@@ -1,0 +1,104 @@
+// Shared device helpers for the VAG-NMT gfx950 kernels.  CDNA4 only: 64-lane waves, MFMA f32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define VAG_OK 0
+#define VAG_EINVAL (-22)
+
+#define VAG_CHECK_ARG(cond)                     \
+    do {                                        \
+        if (!(cond)) return VAG_EINVAL;         \
+    } while (0)
+
+// After a launch: surface launch-configuration errors as a positive hipError_t.
+#define VAG_LAUNCH_CHECK()                                  \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return (int)e__;             \
+    } while (0)
+
+#define VAG_TRY(expr)                  \
+    do {                               \
+        int r__ = (expr);              \
+        if (r__ != 0) return r__;      \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// tanh / sigmoid on the v_exp_f32 path; absolute error ~1e-7, saturates cleanly at +-1 / 0,1.
+__device__ __forceinline__ float vag_tanh(float x) {
+    float e = __expf(2.0f * x);
+    return 1.0f - 2.0f / (e + 1.0f);
+}
+__device__ __forceinline__ float vag_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// Counter-based dropout: keep-mask and multiplier are a pure function of (seed, stream, index),
+// so the backward pass recomputes them instead of storing masks.  splitmix64 finaliser.
+__device__ __host__ __forceinline__ uint64_t vag_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// rng[0] = seed, rng[1] = step counter (bumped once per training step on the device).
+__device__ __forceinline__ float vag_drop_mul(const uint64_t* rng, uint32_t stream_id, uint64_t idx, float p) {
+    if (rng == nullptr || p <= 0.0f) return 1.0f;
+    uint64_t key = vag_mix64(rng[0] ^ (rng[1] * 0xD1342543DE82EF95ull) ^ ((uint64_t)stream_id << 56));
+    uint64_t r = vag_mix64(key + idx);
+    float u = (float)(r >> 40) * (1.0f / 16777216.0f);   // 24 random bits -> [0,1)
+    return (u >= p) ? 1.0f / (1.0f - p) : 0.0f;
+}
+
+enum { VAG_ACT_NONE = 0, VAG_ACT_TANH = 1 };
+enum { VAG_DROP_ENC_EMB = 1, VAG_DROP_ENC_CTX = 2, VAG_DROP_DEC_OUT = 3 };
+
+// ---- internal kernel-launching helpers shared across translation units (gemm.hip) ----
+// C[M,N] = act(alpha * op(A) op(B) + beta * C + bias[n]);  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn].
+int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
+                    const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc,
+                    const float* bias, int act, hipStream_t stream);
+// out[m,n] = act(sum_k A[m,k] W[n,k] + bias[n] + addend[m,n]);  M small (decode/recurrent steps).
+int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
+                      const float* bias, const float* addend, int64_t ldadd, float* out, int64_t ldo, int act,
+                      hipStream_t stream);
+// out[n] += sum_m X[m*ld + n]
+int vag_colsum_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* out, hipStream_t stream);
+// out[N,M] = in[M,N]^T
+int vag_transpose_launch(const float* in, int64_t M, int64_t N, float* out, hipStream_t stream);
+
+// ---- fused GRU cell step (gemm.hip) ----
+struct GruSide {
+    const float* A;      // (M,K) operand of the projection computed here (h_prev when comp_hidden, else x)
+    const float* W;      // (3H,K) weight of that projection, gate order r,z,n
+    const float* bias;   // (3H) bias of that projection (may be NULL)
+    const float* other;  // (M,3H) the other projection, bias already added
+    const float* hprev;  // (M,H) previous hidden state
+    float* hout;         // (M,H) new hidden state (rows past their length keep hprev)
+    float* out2;         // optional second copy with row stride ld2; zero for rows past their length
+    float* save;         // optional [4][M][H]: r, z, n, (W_hn h + b_hn) for the backward pass
+    int t;               // time index compared against lengths[]
+};
+struct GruStepArgs {
+    GruSide s[2];        // s[1] only used when two independent cells run in one launch (encoder directions)
+    int64_t lda, ldw, ldother, ldh, ld2;
+    int M, K, H;
+    const int* lengths;  // device int32[M] or NULL
+    int comp_hidden;     // 1: computed projection is the hidden one (W_hh h), 0: the input one (W_ih x)
+};
+int vag_gru_step_launch(const GruStepArgs& a, int nz, hipStream_t stream);

@@ -1,0 +1,266 @@
+// Bandwidth-bound helper kernels: embedding gather / scatter-add, GRU cell backward (elementwise part),
+// dropout, mean-pool.  All accesses are 16-byte vectors where the layout allows (E, H, C are multiples of 4).
+#include "kernels.h"
+
+static inline dim3 grid1d(int64_t n, int bs = 256) {
+    int64_t b = cdiv64(n, bs);
+    if (b > 65535ll * 16) b = 65535ll * 16;
+    return dim3((unsigned)(b < 1 ? 1 : b));
+}
+
+// ------------------------------------------------------------------ embedding
+__global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __restrict__ idx, int64_t ist, int64_t isb,
+                                                           int T, int B, const float* __restrict__ W, int E,
+                                                           float* __restrict__ out, const uint64_t* rng, int sid,
+                                                           float p) {
+    const int E4 = E >> 2;
+    const int64_t total = (int64_t)T * B * E4;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / E4;
+        const int e = (int)(i - row * E4) << 2;
+        const int t = (int)(row / B), b = (int)(row - (int64_t)t * B);
+        const int64_t tok = idx[b * isb + t * ist];
+        float4 v = *reinterpret_cast<const float4*>(W + tok * E + e);
+        if (rng && p > 0.f) {
+            const uint64_t o = (uint64_t)row * E + e;
+            v.x *= vag_drop_mul(rng, sid, o + 0, p);
+            v.y *= vag_drop_mul(rng, sid, o + 1, p);
+            v.z *= vag_drop_mul(rng, sid, o + 2, p);
+            v.w *= vag_drop_mul(rng, sid, o + 3, p);
+        }
+        *reinterpret_cast<float4*>(out + row * E + e) = v;
+    }
+}
+
+int vag_embed_gather_launch(const int64_t* idx, int64_t ist, int64_t isb, int64_t T, int64_t B, const float* W,
+                            int64_t E, float* out, const uint64_t* rng, int sid, float p, hipStream_t s) {
+    VAG_CHECK_ARG(idx && W && out && E > 0 && E % 4 == 0 && T >= 0 && B >= 0);
+    if (T * B == 0) return VAG_OK;
+    hipLaunchKernelGGL(embed_gather_kernel, grid1d(T * B * E / 4), dim3(256), 0, s, idx, ist, isb, (int)T, (int)B, W,
+                       (int)E, out, rng, sid, p);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ idx, int64_t ist, int64_t isb,
+                                                            int T, int B, const float* __restrict__ g, int E,
+                                                            float* __restrict__ gW, const uint64_t* rng, int sid,
+                                                            float p) {
+    const int E4 = E >> 2;
+    const int64_t total = (int64_t)T * B * E4;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / E4;
+        const int e = (int)(i - row * E4) << 2;
+        const int t = (int)(row / B), b = (int)(row - (int64_t)t * B);
+        const int64_t tok = idx[b * isb + t * ist];
+        if (tok == 0) continue;   // padding_idx: no gradient
+        float4 v = *reinterpret_cast<const float4*>(g + row * E + e);
+        if (rng && p > 0.f) {
+            const uint64_t o = (uint64_t)row * E + e;
+            v.x *= vag_drop_mul(rng, sid, o + 0, p);
+            v.y *= vag_drop_mul(rng, sid, o + 1, p);
+            v.z *= vag_drop_mul(rng, sid, o + 2, p);
+            v.w *= vag_drop_mul(rng, sid, o + 3, p);
+        }
+        float* d = gW + tok * E + e;
+        atomicAdd(d + 0, v.x);
+        atomicAdd(d + 1, v.y);
+        atomicAdd(d + 2, v.z);
+        atomicAdd(d + 3, v.w);
+    }
+}
+
+int vag_embed_scatter_launch(const int64_t* idx, int64_t ist, int64_t isb, int64_t T, int64_t B, const float* g,
+                             int64_t E, float* gW, const uint64_t* rng, int sid, float p, hipStream_t s) {
+    VAG_CHECK_ARG(idx && g && gW && E > 0 && E % 4 == 0 && T >= 0 && B >= 0);
+    if (T * B == 0) return VAG_OK;
+    hipLaunchKernelGGL(embed_scatter_kernel, grid1d(T * B * E / 4), dim3(256), 0, s, idx, ist, isb, (int)T, (int)B, g,
+                       (int)E, gW, rng, sid, p);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+// ------------------------------------------------------------------ GRU cell backward (elementwise part)
+// Given dh' and the saved gates:  dn = dh'(1-z); dz = dh'(h-n); dh_direct = dh' z;
+// dn_pre = dn(1-n^2); dr = dn_pre*hn; dr_pre = dr r(1-r); dz_pre = dz z(1-z);
+// dgi = [dr_pre, dz_pre, dn_pre];  dgh = [dr_pre, dz_pre, dn_pre*r].
+__global__ __launch_bounds__(256) void gru_bwd_elem_kernel(GruBwdArgs a) {
+    const GruBwdSide& sd = a.s[blockIdx.y];
+    const int H = a.H;
+    const int64_t total = (int64_t)a.M * H;
+    const int64_t MH = total;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / H), j = (int)(i - (int64_t)m * H);
+        const bool active = a.lengths ? (sd.t < a.lengths[m]) : true;
+        float dh = sd.dh_carry ? sd.dh_carry[i] : 0.f;
+        float* gi = sd.dgi + (int64_t)m * a.ldgi + j;
+        float* gh = sd.dgh + (int64_t)m * a.ldgh + j;
+        if (!active) {
+            gi[0] = 0.f; gi[H] = 0.f; gi[2 * H] = 0.f;
+            gh[0] = 0.f; gh[H] = 0.f; gh[2 * H] = 0.f;
+            sd.dh_prev[i] = dh;      // state was carried through unchanged
+            continue;
+        }
+        if (sd.dh_add) {
+            float e = sd.dh_add[(int64_t)m * a.ld_add + j];
+            if (a.rng && a.p > 0.f) e *= vag_drop_mul(a.rng, a.sid, (uint64_t)m * a.ld_add + sd.drop_idx0 + j, a.p);
+            dh += e;
+        }
+        const float r = sd.save[i], z = sd.save[MH + i], n = sd.save[2 * MH + i], hn = sd.save[3 * MH + i];
+        const float hp = sd.hprev[(int64_t)m * a.ldh + j];
+        const float dn_pre = dh * (1.f - z) * (1.f - n * n);
+        const float dz_pre = dh * (hp - n) * z * (1.f - z);
+        const float dr_pre = dn_pre * hn * r * (1.f - r);
+        gi[0] = dr_pre; gi[H] = dz_pre; gi[2 * H] = dn_pre;
+        gh[0] = dr_pre; gh[H] = dz_pre; gh[2 * H] = dn_pre * r;
+        sd.dh_prev[i] = dh * z;
+    }
+}
+
+int vag_gru_bwd_elem_launch(const GruBwdArgs& a, int nz, hipStream_t s) {
+    VAG_CHECK_ARG(a.M > 0 && a.H > 0 && (nz == 1 || nz == 2));
+    dim3 grid(grid1d((int64_t)a.M * a.H).x, (unsigned)nz);
+    hipLaunchKernelGGL(gru_bwd_elem_kernel, grid, dim3(256), 0, s, a);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+// ------------------------------------------------------------------ small elementwise kernels
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                       float* __restrict__ dx, int64_t n, const uint64_t* rng,
+                                                       int sid, float p) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float yy = y[i];
+        float d = dy[i];
+        if (rng && p > 0.f) {
+            const float mlt = vag_drop_mul(rng, sid, (uint64_t)i, p);
+            d *= mlt;
+            yy = mlt > 0.f ? yy / mlt : 0.f;     // y holds tanh(.)*mul; undo the scale for kept elements
+        }
+        dx[i] = d * (1.f - yy * yy);
+    }
+}
+int vag_tanh_bwd_launch(const float* y, const float* dy, float* dx, int64_t n, const uint64_t* rng, int sid, float p,
+                        hipStream_t s) {
+    if (n == 0) return VAG_OK;
+    hipLaunchKernelGGL(tanh_bwd_kernel, grid1d(n), dim3(256), 0, s, y, dy, dx, n, rng, sid, p);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+__global__ __launch_bounds__(256) void dropout_apply_kernel(float* __restrict__ x, int64_t n, int64_t idx0,
+                                                            const uint64_t* rng, int sid, float p,
+                                                            float* __restrict__ mask_out) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float mlt = vag_drop_mul(rng, sid, (uint64_t)(idx0 + i), p);
+        if (mask_out) mask_out[i] = mlt;
+        else x[i] *= mlt;
+    }
+}
+int vag_dropout_apply_launch(float* x, int64_t n, int64_t idx0, const uint64_t* rng, int sid, float p, hipStream_t s) {
+    if (n == 0 || !rng || p <= 0.f) return VAG_OK;
+    hipLaunchKernelGGL(dropout_apply_kernel, grid1d(n), dim3(256), 0, s, x, n, idx0, rng, sid, p, (float*)nullptr);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+int vag_dropout_mask_launch(const uint64_t* rng, int sid, int64_t n, float p, float* out, hipStream_t s) {
+    VAG_CHECK_ARG(out && n >= 0);
+    if (n == 0) return VAG_OK;
+    hipLaunchKernelGGL(dropout_apply_kernel, grid1d(n), dim3(256), 0, s, (float*)nullptr, n, (int64_t)0, rng, sid, p, out);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float a, const float* __restrict__ x, float* __restrict__ y,
+                                                   int64_t n, int acc) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        y[i] = acc ? y[i] + a * x[i] : a * x[i];
+}
+int vag_axpy_launch(float a, const float* x, float* y, int64_t n, int accumulate, hipStream_t s) {
+    if (n == 0) return VAG_OK;
+    hipLaunchKernelGGL(axpy_kernel, grid1d(n), dim3(256), 0, s, a, x, y, n, accumulate);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+__global__ __launch_bounds__(256) void src_mask_kernel(const int64_t* __restrict__ src, int64_t n,
+                                                       float* __restrict__ mask) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        mask[i] = src[i] != 0 ? 1.f : 0.f;
+}
+int vag_src_mask_launch(const int64_t* src, int64_t n, float* mask, hipStream_t s) {
+    if (n == 0) return VAG_OK;
+    hipLaunchKernelGGL(src_mask_kernel, grid1d(n), dim3(256), 0, s, src, n, mask);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+// ------------------------------------------------------------------ mean-pool (+ mix with the attended context)
+__global__ __launch_bounds__(256) void meanpool_mix_kernel(const float* __restrict__ enc, const float* __restrict__ mask,
+                                                           const float* __restrict__ ctx, float split, int Ts, int C,
+                                                           float* __restrict__ xmix) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float cnt = 0.f;
+    for (int t = 0; t < Ts; ++t) cnt += mask[(int64_t)b * Ts + t];
+    float s = 0.f;
+    const float* e = enc + (int64_t)b * Ts * C + c;
+    for (int t = 0; t < Ts; ++t) s += e[(int64_t)t * C];
+    const float mean = s / cnt;
+    xmix[(int64_t)b * C + c] = ctx ? split * ctx[(int64_t)b * C + c] + (1.f - split) * mean : mean;
+}
+int vag_meanpool_mix_launch(const float* enc, const float* mask, const float* ctx, float split, int64_t B, int64_t Ts,
+                            int64_t C, float* xmix, hipStream_t s) {
+    VAG_CHECK_ARG(enc && mask && xmix && B > 0 && Ts > 0 && C > 0);
+    dim3 grid((unsigned)cdiv64(C, 256), (unsigned)B);
+    hipLaunchKernelGGL(meanpool_mix_kernel, grid, dim3(256), 0, s, enc, mask, ctx, split, (int)Ts, (int)C, xmix);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+__global__ __launch_bounds__(256) void meanpool_bwd_kernel(const float* __restrict__ mask, const float* __restrict__ dx,
+                                                           float coef, int Ts, int C, float* __restrict__ d_enc,
+                                                           int acc) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float cnt = 0.f;
+    for (int t = 0; t < Ts; ++t) cnt += mask[(int64_t)b * Ts + t];
+    const float v = coef * dx[(int64_t)b * C + c] / cnt;
+    float* d = d_enc + (int64_t)b * Ts * C + c;
+    for (int t = 0; t < Ts; ++t) d[(int64_t)t * C] = acc ? d[(int64_t)t * C] + v : v;
+}
+int vag_meanpool_bwd_launch(const float* mask, const float* dx, float coef, int64_t B, int64_t Ts, int64_t C,
+                            float* d_enc, int accumulate, hipStream_t s) {
+    VAG_CHECK_ARG(mask && dx && d_enc && B > 0 && Ts > 0 && C > 0);
+    dim3 grid((unsigned)cdiv64(C, 256), (unsigned)B);
+    hipLaunchKernelGGL(meanpool_bwd_kernel, grid, dim3(256), 0, s, mask, dx, coef, (int)Ts, (int)C, d_enc, accumulate);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+__global__ void rng_advance_kernel(uint64_t* rng) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += 1;
+}
+int vag_rng_advance_launch(uint64_t* rng, hipStream_t s) {
+    VAG_CHECK_ARG(rng);
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, s, rng);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ in, int64_t ldi, float* __restrict__ out,
+                                                     int64_t ldo, int64_t rows, int64_t cols) {
+    const int64_t total = rows * cols;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols, c = i - r * cols;
+        out[r * ldo + c] = in[r * ldi + c];
+    }
+}
+int vag_copy2d_launch(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t rows, int64_t cols, hipStream_t s) {
+    if (rows * cols == 0) return VAG_OK;
+    hipLaunchKernelGGL(copy2d_kernel, grid1d(rows * cols), dim3(256), 0, s, in, ldi, out, ldo, rows, cols);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}

@@ -1,0 +1,475 @@
+// fp32 GEMM kernels for gfx950 on the f32-input MFMA (exact f32 fma chains, no reduced precision).
+//
+//  * gemm_tiled_kernel : LDS-staged BMxBNx16 block tiles, 4 waves (2x2), v_mfma_f32_32x32x2_f32,
+//                        double-buffered LDS with register prefetch, optional split-K (atomic accumulate).
+//                        Used for the once-per-batch contractions (input projections, attention keys,
+//                        output head, every weight-gradient GEMM).
+//  * skinny_kernel     : M <= ~128 rows (one decoder/encoder time step).  One 16-row m-tile per workgroup,
+//                        K split across the waves, operands loaded straight from L2 into MFMA fragment
+//                        layout (no LDS staging: each weight element is used once per workgroup),
+//                        v_mfma_f32_16x16x4_f32, LDS only for the cross-wave reduction.  Epilogues: plain
+//                        (bias/addend/tanh) and the fused GRU cell.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// tiled GEMM
+// ------------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const float* A; const float* B; float* C; const float* bias;
+    int64_t sa_o, sa_k;   // A(m,k) = A[m*sa_o + k*sa_k]
+    int64_t sb_o, sb_k;   // B(k,n) = B[n*sb_o + k*sb_k]
+    int64_t ldc;
+    int M, N, K, kchunk;
+    float alpha, beta;
+    int act, splitk;
+};
+
+constexpr int BK = 16;
+
+// Load a (BT outer) x (BK k) operand tile into registers.  KC: k is the contiguous dimension.
+template <int BT, bool KC, bool VEC>
+__device__ __forceinline__ void tile_load(const float* __restrict__ P, int64_t so, int64_t sk, int o0, int k0,
+                                          int OUT, int KEND, float4 (&r)[BT / 64]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < BT / 64; ++i) {
+        const int idx = tid + i * 256;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KC) {
+            const int o = o0 + (idx >> 2), k = k0 + ((idx & 3) << 2);
+            if (o < OUT) {
+                const float* p = P + (int64_t)o * so + k;
+                if (VEC && k + 3 < KEND) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (k + 0 < KEND) v.x = p[0];
+                    if (k + 1 < KEND) v.y = p[1];
+                    if (k + 2 < KEND) v.z = p[2];
+                    if (k + 3 < KEND) v.w = p[3];
+                }
+            }
+        } else {
+            const int k = k0 + idx / (BT / 4), o = o0 + ((idx % (BT / 4)) << 2);
+            if (k < KEND) {
+                const float* p = P + (int64_t)k * sk + o;
+                if (VEC && o + 3 < OUT) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (o + 0 < OUT) v.x = p[0];
+                    if (o + 1 < OUT) v.y = p[1];
+                    if (o + 2 < OUT) v.z = p[2];
+                    if (o + 3 < OUT) v.w = p[3];
+                }
+            }
+        }
+        r[i] = v;
+    }
+}
+
+// LDS image: S[k][o], row stride BT+4 floats (MFMA operand reads are 32 consecutive floats -> conflict free).
+template <int BT, bool KC>
+__device__ __forceinline__ void tile_store(float* __restrict__ S, const float4 (&r)[BT / 64]) {
+    const int tid = threadIdx.x;
+    constexpr int LD = BT + 4;
+#pragma unroll
+    for (int i = 0; i < BT / 64; ++i) {
+        const int idx = tid + i * 256;
+        if (KC) {
+            const int o = idx >> 2, k = (idx & 3) << 2;
+            S[(k + 0) * LD + o] = r[i].x;
+            S[(k + 1) * LD + o] = r[i].y;
+            S[(k + 2) * LD + o] = r[i].z;
+            S[(k + 3) * LD + o] = r[i].w;
+        } else {
+            const int k = idx / (BT / 4), o = (idx % (BT / 4)) << 2;
+            *reinterpret_cast<float4*>(&S[k * LD + o]) = r[i];
+        }
+    }
+}
+
+template <int BM, int BN, bool AKC, bool BKC, bool VEC>
+__global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs a) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDA + 2 * BK * LDB];
+    float* As = smem;
+    float* Bs = smem + 2 * BK * LDA;
+
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * a.kchunk;
+    const int kend = min(a.K, kbeg + a.kchunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[BM / 64], rb[BN / 64];
+    tile_load<BM, AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, kbeg, a.M, kend, ra);
+    tile_load<BN, BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, kbeg, a.N, kend, rb);
+    tile_store<BM, AKC>(As, ra);
+    tile_store<BN, BKC>(Bs, rb);
+    __syncthreads();
+
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = (k0 + BK) < kend;
+        if (more) {
+            tile_load<BM, AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, k0 + BK, a.M, kend, ra);
+            tile_load<BN, BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, k0 + BK, a.N, kend, rb);
+        }
+        const float* Ac = As + cur * BK * LDA + wm * (BM / 2) + (lane & 31);
+        const float* Bc = Bs + cur * BK * LDB + wn * (BN / 2) + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int kr = kk + (lane >> 5);
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = Ac[kr * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = Bc[kr * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            tile_store<BM, AKC>(As + (cur ^ 1) * BK * LDA, ra);
+            tile_store<BN, BKC>(Bs + (cur ^ 1) * BK * LDB, rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    const bool atomic = a.splitk > 1;
+    const bool first = blockIdx.z == 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+            if (col >= a.N) continue;
+            const float bv = (a.bias && first) ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= a.M) continue;
+                float* cp = a.C + (int64_t)row * a.ldc + col;
+                float v = a.alpha * acc[i][j][r] + bv;
+                if (atomic) {
+                    atomicAdd(cp, v);
+                } else {
+                    if (a.beta != 0.f) v += a.beta * (*cp);
+                    if (a.act == VAG_ACT_TANH) v = vag_tanh(v);
+                    *cp = v;
+                }
+            }
+        }
+}
+
+template <int BM, int BN>
+static int gemm_dispatch(const GemmArgs& g, bool akc, bool bkc, bool vec, dim3 grid, hipStream_t s) {
+#define VAG_GEMM_CASE(AK, BKc, V)                                                                    \
+    if (akc == AK && bkc == BKc && vec == V) {                                                       \
+        hipLaunchKernelGGL((gemm_tiled_kernel<BM, BN, AK, BKc, V>), grid, dim3(256), 0, s, g);       \
+        VAG_LAUNCH_CHECK();                                                                          \
+        return VAG_OK;                                                                               \
+    }
+    VAG_GEMM_CASE(true, true, true)
+    VAG_GEMM_CASE(true, false, true)
+    VAG_GEMM_CASE(false, true, true)
+    VAG_GEMM_CASE(false, false, true)
+    VAG_GEMM_CASE(true, true, false)
+    VAG_GEMM_CASE(true, false, false)
+    VAG_GEMM_CASE(false, true, false)
+    VAG_GEMM_CASE(false, false, false)
+#undef VAG_GEMM_CASE
+    return VAG_EINVAL;
+}
+
+int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
+                    const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc,
+                    const float* bias, int act, hipStream_t stream) {
+    VAG_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && A && B && C);
+    if (M == 0 || N == 0) return VAG_OK;
+    VAG_CHECK_ARG(M < (1ll << 30) && N < (1ll << 30) && K < (1ll << 30));
+    VAG_CHECK_ARG(sam == 1 || sak == 1);
+    VAG_CHECK_ARG(sbk == 1 || sbn == 1);
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias;
+    const bool akc = (sak == 1);        // A: k contiguous
+    const bool bkc = (sbk == 1);        // B: k contiguous
+    g.sa_o = sam; g.sa_k = sak; g.sb_o = sbn; g.sb_k = sbk;
+    g.ldc = ldc; g.M = (int)M; g.N = (int)N; g.K = (int)K;
+    g.alpha = alpha; g.beta = beta; g.act = act;
+    const int64_t lda = akc ? sam : sak, ldb = bkc ? sbn : sbk;
+    const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
+    const int64_t b128 = cdiv64(M, 128) * cdiv64(N, 128);
+    int splitk = 1;
+    if (b128 >= 192) {
+        g.splitk = 1; g.kchunk = (int)K;
+        dim3 grid((unsigned)cdiv64(N, 128), (unsigned)cdiv64(M, 128), 1);
+        return gemm_dispatch<128, 128>(g, akc, bkc, vec, grid, stream);
+    }
+    const int64_t b64 = cdiv64(M, 64) * cdiv64(N, 64);
+    if (beta == 1.0f && act == VAG_ACT_NONE && b64 < 256 && K >= 256) {
+        // accumulate-into-C products (weight gradients): split K so the launch fills the chip
+        int64_t want = cdiv64(512, b64);
+        int64_t maxs = K / 128;
+        splitk = (int)(want < maxs ? want : maxs);
+        if (splitk < 1) splitk = 1;
+    }
+    int kchunk = (int)(cdiv64(cdiv64(K, splitk), BK) * BK);
+    splitk = (int)cdiv64(K, kchunk);
+    g.splitk = splitk; g.kchunk = kchunk;
+    dim3 grid((unsigned)cdiv64(N, 64), (unsigned)cdiv64(M, 64), (unsigned)splitk);
+    return gemm_dispatch<64, 64>(g, akc, bkc, vec, grid, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// skinny GEMM  out[m,n] = sum_k A[m,k] W[n,k]   (both k-contiguous), fused epilogues
+// ------------------------------------------------------------------------------------------------
+struct SkinnyArgs {
+    const float* A; const float* W; int64_t lda, ldw;
+    int M, N, K;
+    const float* bias; const float* addend; int64_t ldadd; float* out; int64_t ldo; int act;
+};
+
+// One 16-row m-tile x NT 16-col n-tiles per workgroup; K split over the WAVES waves; partial sums of all
+// waves end up in red[wave][j][lane][4] (C/D map of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4)+i).
+template <int WAVES, int NT>
+__device__ __forceinline__ void skinny_core(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+                                            int64_t ldw, int M, int N, int K, int m0, int nb, int jstep,
+                                            float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int kper = ((K + WAVES - 1) / WAVES + 15) & ~15;
+    const int kbeg = wave * kper;
+    const int kend = min(K, kbeg + kper);
+    const int arow = min(m0 + r, M - 1);
+    const float* ap = A + (int64_t)arow * lda + 4 * g;
+    const float* wp[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int wrow = min(nb + j * jstep + r, N - 1);
+        wp[j] = W + (int64_t)wrow * ldw + 4 * g;
+    }
+    f32x4 acc[NT][2];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    constexpr int U = 4;
+    for (int c0 = kbeg; c0 < kend; c0 += 16 * U) {
+        float4 av[U], wv[NT][U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = c0 + 16 * u + 4 * g;
+            const bool ok = k < kend;
+            av[u] = ok ? *reinterpret_cast<const float4*>(ap + c0 + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                wv[j][u] = ok ? *reinterpret_cast<const float4*>(wp[j] + c0 + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                // lane group g supplies k = 4g+i to MFMA i; A and W use the same k order, so the sum is exact.
+                acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, wv[j][u].x, acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, wv[j][u].y, acc[j][1], 0, 0, 0);
+                acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, wv[j][u].z, acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, wv[j][u].w, acc[j][1], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        f32x4 s = acc[j][0] + acc[j][1];
+        *reinterpret_cast<f32x4*>(&red[((wave * NT + j) * 64 + lane) * 4]) = s;
+    }
+    __syncthreads();
+}
+
+template <int WAVES, int NT>
+__device__ __forceinline__ f32x4 skinny_reduce(const float* red, int j) {
+    const int lane = threadIdx.x & 63;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) s += *reinterpret_cast<const f32x4*>(&red[((w * NT + j) * 64 + lane) * 4]);
+    return s;
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void skinny_plain_kernel(SkinnyArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4];
+    const int m0 = blockIdx.y * 16, nb = blockIdx.x * 16;
+    skinny_core<WAVES, 1>(a.A, a.lda, a.W, a.ldw, a.M, a.N, a.K, m0, nb, 16, red);
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+    const f32x4 s = skinny_reduce<WAVES, 1>(red, 0);
+    const int col = nb + r;
+    if (col >= a.N) return;
+    const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 4 * g + i;
+        if (m >= a.M) continue;
+        float v = s[i] + bv;
+        if (a.addend) v += a.addend[(int64_t)m * a.ldadd + col];
+        if (a.act == VAG_ACT_TANH) v = vag_tanh(v);
+        a.out[(int64_t)m * a.ldo + col] = v;
+    }
+}
+
+// Fused GRU cell: one projection (3 gate tiles of 16 hidden units) is computed here, the other is read.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gru_step_kernel(GruStepArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[WAVES * 3 * 64 * 4];
+    const GruSide& sd = a.s[blockIdx.z];
+    const int m0 = blockIdx.y * 16, nb = blockIdx.x * 16;
+    const int H = a.H;
+    skinny_core<WAVES, 3>(sd.A, a.lda, sd.W, a.ldw, a.M, 3 * H, a.K, m0, nb, H, red);
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+    const f32x4 S0 = skinny_reduce<WAVES, 3>(red, 0);
+    const f32x4 S1 = skinny_reduce<WAVES, 3>(red, 1);
+    const f32x4 S2 = skinny_reduce<WAVES, 3>(red, 2);
+    const int col = nb + r;
+    if (col >= H) return;
+    const float b_r = sd.bias ? sd.bias[col] : 0.f, b_z = sd.bias ? sd.bias[H + col] : 0.f,
+                b_n = sd.bias ? sd.bias[2 * H + col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 4 * g + i;
+        if (m >= a.M) continue;
+        const float c_r = S0[i] + b_r, c_z = S1[i] + b_z, c_n = S2[i] + b_n;
+        const float* op = sd.other + (int64_t)m * a.ldother + col;
+        const float o_r = op[0], o_z = op[H], o_n = op[2 * H];
+        const float gi_n = a.comp_hidden ? o_n : c_n;
+        const float gh_n = a.comp_hidden ? c_n : o_n;
+        const float rr = vag_sigmoid(c_r + o_r);
+        const float zz = vag_sigmoid(c_z + o_z);
+        const float nn = vag_tanh(gi_n + rr * gh_n);
+        const float hp = sd.hprev[(int64_t)m * a.ldh + col];
+        const float hn = (1.f - zz) * nn + zz * hp;
+        const bool active = a.lengths ? (sd.t < a.lengths[m]) : true;
+        if (sd.save) {
+            const int64_t MH = (int64_t)a.M * H;
+            const int64_t o = (int64_t)m * H + col;
+            sd.save[o] = rr; sd.save[MH + o] = zz; sd.save[2 * MH + o] = nn; sd.save[3 * MH + o] = gh_n;
+        }
+        sd.hout[(int64_t)m * H + col] = active ? hn : hp;
+        if (sd.out2) sd.out2[(int64_t)m * a.ld2 + col] = active ? hn : 0.f;
+    }
+}
+
+static bool skinny_ok(const float* A, int64_t lda, const float* W, int64_t ldw, int64_t K) {
+    return aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && K % 4 == 0 && K >= 4;
+}
+
+int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
+                      const float* bias, const float* addend, int64_t ldadd, float* out, int64_t ldo, int act,
+                      hipStream_t stream) {
+    VAG_CHECK_ARG(M >= 0 && N >= 0 && K > 0 && A && W && out);
+    if (M == 0 || N == 0) return VAG_OK;
+    if (!skinny_ok(A, lda, W, ldw, K) || M > 128) {
+        // generic path through the tiled kernel; an addend is folded in with beta = 1
+        if (addend) {
+            if (addend != out) {
+                hipError_t e = hipMemcpy2DAsync(out, ldo * sizeof(float), addend, ldadd * sizeof(float),
+                                                N * sizeof(float), M, hipMemcpyDeviceToDevice, stream);
+                if (e != hipSuccess) return (int)e;
+            }
+            return vag_gemm_launch(M, N, K, 1.f, A, lda, 1, W, 1, ldw, 1.f, out, ldo, bias, act, stream);
+        }
+        return vag_gemm_launch(M, N, K, 1.f, A, lda, 1, W, 1, ldw, 0.f, out, ldo, bias, act, stream);
+    }
+    SkinnyArgs a;
+    a.A = A; a.W = W; a.lda = lda; a.ldw = ldw; a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.bias = bias; a.addend = addend; a.ldadd = ldadd; a.out = out; a.ldo = ldo; a.act = act;
+    dim3 grid((unsigned)cdiv64(N, 16), (unsigned)cdiv64(M, 16), 1);
+    if (K <= 256) hipLaunchKernelGGL((skinny_plain_kernel<4>), grid, dim3(256), 0, stream, a);
+    else if (K <= 1024) hipLaunchKernelGGL((skinny_plain_kernel<8>), grid, dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((skinny_plain_kernel<16>), grid, dim3(1024), 0, stream, a);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+int vag_gru_step_launch(const GruStepArgs& a, int nz, hipStream_t stream) {
+    VAG_CHECK_ARG(a.H > 0 && a.M > 0 && a.K > 0 && (nz == 1 || nz == 2));
+    for (int z = 0; z < nz; ++z) {
+        VAG_CHECK_ARG(a.s[z].A && a.s[z].W && a.s[z].other && a.s[z].hprev && a.s[z].hout);
+        VAG_CHECK_ARG(skinny_ok(a.s[z].A, a.lda, a.s[z].W, a.ldw, a.K));
+    }
+    dim3 grid((unsigned)cdiv64(a.H, 16), (unsigned)cdiv64(a.M, 16), (unsigned)nz);
+    if (a.K <= 256) hipLaunchKernelGGL((gru_step_kernel<4>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((gru_step_kernel<8>), grid, dim3(512), 0, stream, a);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums (bias gradients) and transpose
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, int64_t ld,
+                                                     int rows_per, float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
+    float s0 = 0.f, s1 = 0.f;
+    int m = m0;
+    for (; m + 1 < m1; m += 2) {
+        s0 += X[(int64_t)m * ld + n];
+        s1 += X[(int64_t)(m + 1) * ld + n];
+    }
+    if (m < m1) s0 += X[(int64_t)m * ld + n];
+    atomicAdd(out + n, s0 + s1);
+}
+
+int vag_colsum_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* out, hipStream_t stream) {
+    VAG_CHECK_ARG(X && out && M >= 0 && N >= 0);
+    if (M == 0 || N == 0) return VAG_OK;
+    const int64_t nbx = cdiv64(N, 256);
+    int64_t splits = cdiv64(1024, nbx);
+    if (splits > cdiv64(M, 8)) splits = cdiv64(M, 8);
+    if (splits < 1) splits = 1;
+    const int rows_per = (int)cdiv64(M, splits);
+    dim3 grid((unsigned)nbx, (unsigned)cdiv64(M, rows_per));
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, X, (int)M, (int)N, ld, rows_per, out);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int M, int N,
+                                                        float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int m = m0 + ty + i, n = n0 + tx;
+        if (m < M && n < N) tile[ty + i][tx] = in[(int64_t)m * N + n];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int n = n0 + ty + i, m = m0 + tx;
+        if (m < M && n < N) out[(int64_t)n * M + m] = tile[tx][ty + i];
+    }
+}
+
+int vag_transpose_launch(const float* in, int64_t M, int64_t N, float* out, hipStream_t stream) {
+    VAG_CHECK_ARG(in && out && M > 0 && N > 0);
+    dim3 grid((unsigned)cdiv64(N, 32), (unsigned)cdiv64(M, 32));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, in, (int)M, (int)N, out);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}

@@ -1,0 +1,172 @@
+// Output-head loss kernels: row-wise log-sum-exp + weighted NLL (+ argmax for free-running / greedy decode),
+// the softmax-minus-onehot backward (in place over the logits buffer) and the per-sentence normalisation.
+#include "kernels.h"
+
+__device__ __forceinline__ float block_reduce_max(float v, float* sh) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fmaxf(r, sh[i]);
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+    __syncthreads();
+    return r;
+}
+
+// One 256-thread block per row.
+__global__ __launch_bounds__(256) void lse_nll_kernel(const float* __restrict__ logits, int64_t ldl, int V,
+                                                      const int64_t* __restrict__ tgt, int B, int Tt,
+                                                      const float* __restrict__ vw, float* __restrict__ lse,
+                                                      float* __restrict__ nll, int64_t* __restrict__ argmax,
+                                                      int64_t argmax_stride, float* __restrict__ logp_out,
+                                                      int64_t ldlp) {
+    __shared__ float sh[4];
+    __shared__ int shi[4];
+    const int64_t row = blockIdx.x;
+    const float* x = logits + row * ldl;
+    float mx = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int j = threadIdx.x; j < V; j += 256) {
+        const float v = x[j];
+        if (v > mx) { mx = v; mi = j; }      // strict >: first occurrence within a thread
+    }
+    const float bm = block_reduce_max(mx, sh);
+    float sum = 0.f;
+    for (int j = threadIdx.x; j < V; j += 256) sum += __expf(x[j] - bm);
+    sum = block_reduce_sum(sum, sh);
+    const float l = bm + __logf(sum);
+    if (argmax) {
+        // smallest index attaining the maximum (torch.topk/argmax tie-break is unspecified; this is deterministic)
+        int cand = (mx == bm) ? mi : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+        if ((threadIdx.x & 63) == 0) shi[threadIdx.x >> 6] = cand;
+        __syncthreads();
+        if (threadIdx.x == 0) argmax[row * argmax_stride] = (int64_t)min(min(shi[0], shi[1]), min(shi[2], shi[3]));
+    }
+    if (threadIdx.x == 0) {
+        if (lse) lse[row] = l;
+        if (tgt) {
+            const int t = (int)(row / B), b = (int)(row - (int64_t)t * B);
+            const int64_t tg = tgt[(int64_t)b * Tt + t];
+            nll[row] = -vw[tg] * (x[tg] - l);
+        }
+    }
+    if (logp_out) {
+        float* o = logp_out + row * ldlp;
+        for (int j = threadIdx.x; j < V; j += 256) o[j] = x[j] - l;
+    }
+}
+
+int vag_lse_nll_launch(const float* logits, int64_t ldl, int64_t rows, int64_t V, const int64_t* tgt, int64_t B,
+                       int64_t Tt, const float* vw, float* lse, float* nll, int64_t* argmax, int64_t argmax_stride,
+                       float* logp_out, int64_t ldlp, hipStream_t s) {
+    VAG_CHECK_ARG(logits && rows >= 0 && V > 0 && ldl >= V);
+    VAG_CHECK_ARG(!tgt || (vw && nll && B > 0 && Tt > 0));
+    if (rows == 0) return VAG_OK;
+    hipLaunchKernelGGL(lse_nll_kernel, dim3((unsigned)rows), dim3(256), 0, s, logits, ldl, (int)V, tgt, (int)B, (int)Tt,
+                       vw, lse, nll, argmax, argmax_stride, logp_out, ldlp);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+// inv_cnt[b] = 1 / #(tgt[b,:] != 0)       (models/...V11.py:164: loss_mt / tgt_mask.sum(-1))
+__global__ __launch_bounds__(256) void inv_cnt_kernel(const int64_t* __restrict__ tgt, int B, int Tt,
+                                                      float* __restrict__ inv_cnt) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    int c = 0;
+    for (int t = 0; t < Tt; ++t) c += tgt[(int64_t)b * Tt + t] != 0;
+    inv_cnt[b] = 1.f / (float)c;
+}
+int vag_inv_cnt_launch(const int64_t* tgt, int64_t B, int64_t Tt, float* inv_cnt, hipStream_t s) {
+    VAG_CHECK_ARG(tgt && inv_cnt && B > 0 && Tt > 0);
+    hipLaunchKernelGGL(inv_cnt_kernel, dim3((unsigned)cdiv64(B, 256)), dim3(256), 0, s, tgt, (int)B, (int)Tt, inv_cnt);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+// loss = (1/B) sum_b inv_cnt[b] sum_t nll[t,b]    (single block; fixed summation order -> deterministic)
+__global__ __launch_bounds__(256) void loss_mt_kernel(const float* __restrict__ nll, const float* __restrict__ inv_cnt,
+                                                      int B, int Tt, float* __restrict__ loss) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        float L = 0.f;
+        for (int t = 0; t < Tt; ++t) L += nll[(int64_t)t * B + b];
+        acc += L * inv_cnt[b];
+    }
+    acc = block_reduce_sum(acc, sh);
+    if (threadIdx.x == 0) loss[0] = acc / (float)B;
+}
+int vag_loss_mt_launch(const float* nll, const float* inv_cnt, int64_t B, int64_t Tt, float* loss, hipStream_t s) {
+    VAG_CHECK_ARG(nll && inv_cnt && loss && B > 0 && Tt > 0);
+    hipLaunchKernelGGL(loss_mt_kernel, dim3(1), dim3(256), 0, s, nll, inv_cnt, (int)B, (int)Tt, loss);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+// grid (ceil(ldl/1024), rows): d logits in place.
+__global__ __launch_bounds__(256) void ce_bwd_kernel(float* __restrict__ logits, int64_t ldl, int V,
+                                                     const int64_t* __restrict__ tgt, int B, int Tt,
+                                                     const float* __restrict__ vw, const float* __restrict__ lse,
+                                                     const float* __restrict__ inv_cnt, const float* __restrict__ d_loss) {
+    const int64_t row = blockIdx.y;
+    const int t = (int)(row / B), b = (int)(row - (int64_t)t * B);
+    const int64_t tg = tgt[(int64_t)b * Tt + t];
+    const float coef = d_loss[0] * inv_cnt[b] / (float)B * vw[tg];
+    const float l = lse[row];
+    float* x = logits + row * ldl;
+    const int j0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = j0 + i;
+        if (j < ldl) {
+            float g = 0.f;
+            if (j < V) g = coef * (__expf(x[j] - l) - (j == tg ? 1.f : 0.f));
+            x[j] = g;
+        }
+    }
+}
+int vag_ce_bwd_launch(float* logits, int64_t ldl, int64_t rows, int64_t V, const int64_t* tgt, int64_t B, int64_t Tt,
+                      const float* vw, const float* lse, const float* inv_cnt, const float* d_loss, hipStream_t s) {
+    VAG_CHECK_ARG(logits && tgt && vw && lse && inv_cnt && d_loss && rows == B * Tt && V > 0 && ldl >= V);
+    if (rows == 0) return VAG_OK;
+    dim3 grid((unsigned)cdiv64(ldl, 1024), (unsigned)rows);
+    hipLaunchKernelGGL(ce_bwd_kernel, grid, dim3(256), 0, s, logits, ldl, (int)V, tgt, (int)B, (int)Tt, vw, lse, inv_cnt,
+                       d_loss);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+// d logits from d log-softmax, in place over d_logp: dl_j = d_j - exp(logp_j) * sum_j d_j.  One block per row.
+__global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* __restrict__ logp, int64_t ldlp,
+                                                             float* __restrict__ d, int64_t ldd, int V) {
+    __shared__ float sh[4];
+    const int64_t row = blockIdx.x;
+    const float* lp = logp + row * ldlp;
+    float* dr = d + row * ldd;
+    float sum = 0.f;
+    for (int j = threadIdx.x; j < V; j += 256) sum += dr[j];
+    sum = block_reduce_sum(sum, sh);
+    for (int j = threadIdx.x; j < V; j += 256) dr[j] = dr[j] - __expf(lp[j]) * sum;
+    for (int j = V + threadIdx.x; j < ldd; j += 256) dr[j] = 0.f;
+}
+int vag_logsoftmax_bwd_launch(const float* logp, int64_t ldlp, float* d, int64_t ldd, int64_t rows, int64_t V,
+                              hipStream_t s) {
+    VAG_CHECK_ARG(logp && d && rows >= 0 && V > 0 && ldlp >= V && ldd >= V);
+    if (rows == 0) return VAG_OK;
+    hipLaunchKernelGGL(logsoftmax_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, s, logp, ldlp, d, ldd, (int)V);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}

@@ -1,0 +1,112 @@
+// Internal launcher prototypes (one per kernel family).  Not part of the C ABI.
+#pragma once
+#include "common.h"
+
+// ---------------- elem.hip ----------------
+// out[(t*B+b), :] = W[idx[b*isb + t*ist], :] * dropout
+int vag_embed_gather_launch(const int64_t* idx, int64_t ist, int64_t isb, int64_t T, int64_t B, const float* W,
+                            int64_t E, float* out, const uint64_t* rng, int sid, float p, hipStream_t s);
+// gW[idx, :] += g[(t*B+b), :] * dropout, skipping idx == 0 (padding_idx)
+int vag_embed_scatter_launch(const int64_t* idx, int64_t ist, int64_t isb, int64_t T, int64_t B, const float* g,
+                             int64_t E, float* gW, const uint64_t* rng, int sid, float p, hipStream_t s);
+
+struct GruBwdSide {
+    const float* dh_carry;   // (M,H) gradient arriving from the later time step, or NULL
+    const float* dh_add;     // optional extra gradient source, element (m,j) at dh_add[m*ld_add + j]
+    int64_t drop_idx0;       // dropout index of dh_add element (m,j) = m*ld_add + drop_idx0 + j
+    const float* save;       // [4][M][H] r,z,n,hn from the forward step
+    const float* hprev;      // (M,H) ld = ldh
+    float* dgi;              // (M,3H) ld = ldgi
+    float* dgh;              // (M,3H) ld = ldgh
+    float* dh_prev;          // (M,H): z * dh (the W_hh^T dgh part is added by the following GEMM)
+    int t;
+};
+struct GruBwdArgs {
+    GruBwdSide s[2];
+    int64_t ld_add, ldh, ldgi, ldgh;
+    int M, H;
+    const int* lengths;
+    const uint64_t* rng; int sid; float p;   // dropout applied to dh_add (encoder context dropout)
+};
+int vag_gru_bwd_elem_launch(const GruBwdArgs& a, int nz, hipStream_t s);
+
+// dx = dy * dropout(i) * (1 - t*t)   (in place allowed).  With dropout, y is the post-dropout value t*mul;
+// t is recovered from it (dropped elements have zero gradient).
+int vag_tanh_bwd_launch(const float* y, const float* dy, float* dx, int64_t n, const uint64_t* rng, int sid, float p,
+                        hipStream_t s);
+// x[i] *= dropout(idx0 + i)
+int vag_dropout_apply_launch(float* x, int64_t n, int64_t idx0, const uint64_t* rng, int sid, float p, hipStream_t s);
+int vag_dropout_mask_launch(const uint64_t* rng, int sid, int64_t n, float p, float* out, hipStream_t s);
+// y (+)= a*x
+int vag_axpy_launch(float a, const float* x, float* y, int64_t n, int accumulate, hipStream_t s);
+// mask[b,t] = src[b,t] != 0
+int vag_src_mask_launch(const int64_t* src, int64_t n, float* mask, hipStream_t s);
+// xmix[b,c] = split*ctx[b,c] + (1-split) * sum_t enc[b,t,c] / sum_t mask[b,t]   (ctx NULL -> split treated as 0)
+int vag_meanpool_mix_launch(const float* enc, const float* mask, const float* ctx, float split, int64_t B, int64_t Ts,
+                            int64_t C, float* xmix, hipStream_t s);
+// d_enc[b,t,c] (+)= coef * dx[b,c] / sum_t mask[b,t]
+int vag_meanpool_bwd_launch(const float* mask, const float* dx, float coef, int64_t B, int64_t Ts, int64_t C,
+                            float* d_enc, int accumulate, hipStream_t s);
+int vag_rng_advance_launch(uint64_t* rng, hipStream_t s);
+// out[i*ldo + j] = in[i*ldi + j] for a (rows x cols) block
+int vag_copy2d_launch(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t rows, int64_t cols, hipStream_t s);
+
+// ---------------- attn.hip ----------------
+// mode 0: scores[n,s] = sum_c v[c] tanh(pe[b,s,c] + q[n,c]); mode 1: scores[n,s] = sum_c q[n,c] * pe[b,s,c].
+// b = n / rps.  mask (Bsrc,Ts) float or NULL: masked positions get -inf.
+int vag_attn_scores_launch(int mode, const float* pe, const float* q, const float* v, const float* mask, int64_t N,
+                           int64_t rps, int64_t Ts, int64_t C, float* scores, hipStream_t s);
+// softmax=1: alpha[n,:] = softmax(scores[n,:]) (written to alpha), ctx[n,c] = sum_s alpha[n,s] enc[b,s,c]
+// softmax=0: weights = scores as given (alpha not written)
+int vag_attn_ctx_launch(int softmax, const float* scores, const float* enc, int64_t N, int64_t rps, int64_t Ts,
+                        int64_t C, float* alpha, float* ctx, hipStream_t s);
+// dscore[n,s] = alpha[n,s] * (dalpha[n,s] - sum_s' alpha dalpha)
+int vag_softmax_bwd_launch(const float* alpha, const float* dalpha, int64_t N, int64_t Ts, float* dscore, hipStream_t s);
+// dq[n,c] = sum_s dscore[n,s] * v[c] * (1 - tanh^2(pe[n,s,c] + q[n,c]))      (training: rps = 1)
+int vag_attn_dq_launch(const float* pe, const float* q, const float* v, const float* dscore, int64_t N, int64_t Ts,
+                       int64_t C, float* dq, hipStream_t s);
+// After the time loop: d_pe[b,s,c] = v[c] sum_t ds[t,b,s] (1-th^2);  dvp[b,c] = sum_{t,s} ds*th;
+// d_enc[b,s,c] (+)= sum_t alpha[t,b,s] dc[t,b,c]   (skipped when dc == NULL)
+int vag_attn_post_bwd_launch(const float* pe, const float* q_all, const float* v, const float* ds_all,
+                             const float* alpha_all, const float* dc_all, int64_t B, int64_t Ts, int64_t Tt,
+                             int64_t C, float* d_pe, float* dvp, float* d_enc, int accumulate_enc, hipStream_t s);
+// out[b,t,c] (+)= a1[b,t]*x1[b,c] + a2[b,t]*x2[b,c]
+int vag_outer2_launch(const float* a1, const float* x1, const float* a2, const float* x2, int64_t B, int64_t Ts,
+                      int64_t C, float* out, int accumulate, hipStream_t s);
+
+// ---------------- head.hip ----------------
+// per row: lse, nll = -w[tgt]*(x[tgt]-lse) (tgt NULL: skipped), argmax (may be NULL), logp_out (may be NULL)
+// row r = t*B + b;  tgt index = tgt[b*Tt + t]
+int vag_lse_nll_launch(const float* logits, int64_t ldl, int64_t rows, int64_t V, const int64_t* tgt, int64_t B,
+                       int64_t Tt, const float* vw, float* lse, float* nll, int64_t* argmax, int64_t argmax_stride,
+                       float* logp_out, int64_t ldlp, hipStream_t s);
+int vag_inv_cnt_launch(const int64_t* tgt, int64_t B, int64_t Tt, float* inv_cnt, hipStream_t s);
+int vag_loss_mt_launch(const float* nll, const float* inv_cnt, int64_t B, int64_t Tt, float* loss, hipStream_t s);
+// in place: logits[r,j] = d_loss * inv_cnt[b]/B * w[tgt] * (softmax_j - [j==tgt]); pad columns [V,ldl) = 0
+int vag_ce_bwd_launch(float* logits, int64_t ldl, int64_t rows, int64_t V, const int64_t* tgt, int64_t B, int64_t Tt,
+                      const float* vw, const float* lse, const float* inv_cnt, const float* d_loss, hipStream_t s);
+
+int vag_logsoftmax_bwd_launch(const float* logp, int64_t ldlp, float* d, int64_t ldd, int64_t rows, int64_t V,
+                              hipStream_t s);
+
+// ---------------- vse.hip ----------------
+int vag_l2norm_fwd_launch(const float* y, int64_t B, int64_t S, float* nrm, float* out, hipStream_t s);
+// dy = l2norm backward of d_out, then (act) * (1 - y^2); written to dy (may alias d_out)
+int vag_l2norm_bwd_launch(const float* y, const float* nrm, const float* out, const float* d_out, int64_t B, int64_t S,
+                          int act, float* dy, hipStream_t s);
+int vag_rank_loss_launch(const float* scores, int64_t B, float margin, int kind, float* G, float* loss, hipStream_t s);
+// x[i] *= *scalar
+int vag_scale_by_dev_launch(float* x, int64_t n, const float* scalar, hipStream_t s);
+
+// ---------------- optim.hip ----------------
+int vag_clip_adam_launch(float* p, const float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
+                         const float* seg_lr, const float* seg_wd, float clip, float grad_scale, float beta1,
+                         float beta2, float eps, int32_t* step, float* norm_out, void* scratch, hipStream_t s);
+
+// ---------------- beam.hip ----------------
+int64_t vag_beam_scratch_bytes_impl(int64_t B, int64_t k, int64_t V);
+int vag_beam_step_launch(float* logp, int64_t ldl, float* nll, int64_t* beam, int64_t di, int64_t max_len,
+                         const float* h_in, float* h_out, int64_t B, int64_t k, int64_t V, int64_t H,
+                         int32_t* n_alive, void* scratch, hipStream_t s);
+int vag_beam_finish_launch(const float* nll, int64_t* beam, int64_t max_len, int64_t B, int64_t k, int64_t* out,
+                           float* best, hipStream_t s);

@@ -1,0 +1,111 @@
+// Visual-semantic-embedding kernels: row L2 normalisation (fwd/bwd, fused with the tanh backward) and the
+// max-margin ranking loss over the BxB similarity matrix (loss value and d loss / d scores in one pass).
+#include "kernels.h"
+
+// one wave per row
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ y, int64_t B, int S,
+                                                         float* __restrict__ nrm, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* r = y + b * S;
+    float ss = 0.f;
+    for (int j = lane; j < S; j += 64) ss += r[j] * r[j];
+    ss = wave_sum(ss);
+    const float n = fmaxf(sqrtf(ss), 1e-12f);       // utils/utils.py:10  clamp(min=eps)
+    if (lane == 0) nrm[b] = n;
+    const float inv = 1.f / n;
+    for (int j = lane; j < S; j += 64) out[b * S + j] = r[j] * inv;
+}
+int vag_l2norm_fwd_launch(const float* y, int64_t B, int64_t S, float* nrm, float* out, hipStream_t s) {
+    VAG_CHECK_ARG(y && nrm && out && B > 0 && S > 0);
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)cdiv64(B, 4)), dim3(256), 0, s, y, B, (int)S, nrm, out);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+// out = y / n, n = max(|y|, eps).  If |y| > eps: dy = (d_out - out (out . d_out)) / n, else dy = d_out / n.
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ nrm,
+                                                         const float* __restrict__ out, const float* __restrict__ d_out,
+                                                         int64_t B, int S, int act, float* __restrict__ dy) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float n = nrm[b];
+    float dot = 0.f;
+    for (int j = lane; j < S; j += 64) dot += out[b * S + j] * d_out[b * S + j];
+    dot = wave_sum(dot);
+    if (!(n > 1e-12f)) dot = 0.f;
+    const float inv = 1.f / n;
+    for (int j = lane; j < S; j += 64) {
+        float g = (d_out[b * S + j] - out[b * S + j] * dot) * inv;
+        if (act) {
+            const float yy = y[b * S + j];
+            g *= (1.f - yy * yy);
+        }
+        dy[b * S + j] = g;
+    }
+}
+int vag_l2norm_bwd_launch(const float* y, const float* nrm, const float* out, const float* d_out, int64_t B, int64_t S,
+                          int act, float* dy, hipStream_t s) {
+    VAG_CHECK_ARG(y && nrm && out && d_out && dy && B > 0 && S > 0);
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)cdiv64(B, 4)), dim3(256), 0, s, y, nrm, out, d_out, B, (int)S,
+                       act, dy);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+// loss = sum_{i != j} max(0, m - d_j + S_ij)  [+ sum_{i != j} max(0, m - d_i + S_ij) when kind == 0]
+// G = d loss / d S.  Single 1024-thread block (B is a mini-batch size); column/row hinge counts go through LDS.
+__global__ __launch_bounds__(1024) void rank_loss_kernel(const float* __restrict__ S, int B, float margin, int kind,
+                                                         float* __restrict__ G, float* __restrict__ loss) {
+    extern __shared__ float sh[];        // [B] diag-grad accumulators, then 16 floats of reduction space
+    float* dacc = sh;
+    float* red = sh + B;
+    for (int i = threadIdx.x; i < B; i += 1024) dacc[i] = 0.f;
+    __syncthreads();
+    float part = 0.f;
+    const int64_t total = (int64_t)B * B;
+    for (int64_t e = threadIdx.x; e < total; e += 1024) {
+        const int i = (int)(e / B), j = (int)(e - (int64_t)i * B);
+        if (i == j) continue;
+        const float sij = S[e];
+        float g = 0.f;
+        const float cs = margin - S[(int64_t)j * B + j] + sij;      // PairwiseRankingLoss.py:16
+        if (cs > 0.f) { part += cs; g += 1.f; atomicAdd(&dacc[j], -1.f); }
+        if (kind == 0) {
+            const float ci = margin - S[(int64_t)i * B + i] + sij;  // PairwiseRankingLoss.py:18
+            if (ci > 0.f) { part += ci; g += 1.f; atomicAdd(&dacc[i], -1.f); }
+        }
+        G[e] = g;
+    }
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        loss[0] = t;
+    }
+    for (int i = threadIdx.x; i < B; i += 1024) G[(int64_t)i * B + i] = dacc[i];
+}
+int vag_rank_loss_launch(const float* scores, int64_t B, float margin, int kind, float* G, float* loss, hipStream_t s) {
+    VAG_CHECK_ARG(scores && G && loss && B > 0 && B <= 8192 && (kind == 0 || kind == 1));
+    hipLaunchKernelGGL(rank_loss_kernel, dim3(1), dim3(1024), (size_t)(B + 16) * sizeof(float), s, scores, (int)B, margin,
+                       kind, G, loss);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+__global__ __launch_bounds__(256) void scale_by_dev_kernel(float* __restrict__ x, int64_t n, const float* __restrict__ sc) {
+    const float a = sc[0];
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= a;
+}
+int vag_scale_by_dev_launch(float* x, int64_t n, const float* scalar, hipStream_t s) {
+    if (n == 0) return VAG_OK;
+    int64_t b = cdiv64(n, 256);
+    if (b > 4096) b = 4096;
+    hipLaunchKernelGGL(scale_by_dev_kernel, dim3((unsigned)b), dim3(256), 0, s, x, n, scalar);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}

@@ -1,0 +1,140 @@
+"""Shared machinery of the two model classes on the hot path (text-only V2 and multimodal V11)."""
+import random
+
+import torch
+import torch.nn as nn
+
+from vagnmt_hip import ops
+from vagnmt_hip._lib import call, ptr, stream
+from vagnmt_hip import _lib
+from vagnmt_hip.state import dropout_rng
+
+SOS_token = 2
+EOS_token = 3
+UNK_token = 1
+
+
+class Seq2SeqBase(nn.Module):
+    """encoder -> [visual grounding] -> decoder init -> cGRU decoder over the target -> loss / decode."""
+
+    def reset_parameters(self):
+        # models/...V11.py:77-80: every >=2-D non-bias parameter (embeddings included) gets kaiming_normal_
+        for name, param in self.named_parameters():
+            if param.requires_grad and 'bias' not in name and param.data.dim() > 1:
+                nn.init.kaiming_normal_(param.data)
+
+    # ------------------------------------------------------------------------------------------ training
+    def _train_rng(self, device):
+        """Advance the dropout counter once per training forward; backward re-derives the same masks."""
+        if not self.training:
+            return None
+        if max(self.encoder.dropout_emb, self.encoder.dropout_ctx, self.decoder.dropout_out) <= 0:
+            return None
+        rng = dropout_rng(self, device)
+        call("vag_rng_advance", ptr(rng, torch.int64), stream())
+        return rng
+
+    def _encode(self, src_var, src_lengths, rng):
+        enc_mod = self.encoder
+        g = enc_mod.gru
+        train = self.training and rng is not None
+        from vagnmt_hip.state import lengths_tensor
+        return ops.BiGRUEncode.apply(
+            src_var, lengths_tensor(src_lengths, src_var.device), enc_mod.embedding.weight,
+            g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0,
+            g.weight_ih_l0_reverse, g.weight_hh_l0_reverse, g.bias_ih_l0_reverse, g.bias_hh_l0_reverse,
+            float(enc_mod.dropout_emb) if train else 0.0, float(enc_mod.dropout_ctx) if train else 0.0, rng)
+
+    def _translation_loss(self, enc, mask, h0, tgt_var, teacher_force_ratio, criterion, rng):
+        """The decoder loop of models/...V11.py:136-164 as two fused operators.
+        teacher forcing (python ``random`` coin, V11.py:136): whole-sequence cGRU + batched head/CE;
+        free running: the sequence operator also runs the head per step and feeds back the argmax."""
+        dec = self.decoder
+        B, Tt = tgt_var.shape
+        V = dec.out.bias.shape[0]
+        ldl = (V + 3) // 4 * 4
+        pe = ops.KeysProj.apply(enc, dec.attn.attn_e.weight)
+        is_teacher = random.random() < teacher_force_ratio
+        sos = torch.full((1, B), SOS_token, dtype=torch.int64, device=tgt_var.device)
+        tok = torch.cat([sos, tgt_var.t()], 0).contiguous()          # (Tt+1,B): inputs of steps 0..Tt-1 (+1 unused row)
+        p_out = float(dec.dropout_out) if (self.training and rng is not None) else 0.0
+        head = dec.head_params()
+        fused = (type(criterion) is nn.NLLLoss and criterion.reduction == 'none' and criterion.weight is not None
+                 and criterion.ignore_index < 0)
+        if is_teacher:
+            h2, c, e = ops.cgru_decode_seq(enc, pe, mask, h0, tok, dec.embedding.weight, dec.dec_params(), V=V)
+            tmid = logits = None
+        else:
+            h2, c, e, tmid, logits = ops.cgru_decode_seq(enc, pe, mask, h0, tok, dec.embedding.weight, dec.dec_params(),
+                                                         free_run=True, head=head, p_out=p_out, rng=rng, V=V, ldl=ldl)
+        if fused:
+            return ops.HeadCE.apply(h2, c, e, tgt_var, criterion.weight, p_out, rng, tmid, logits, ldl, *head)
+        # any other criterion: materialise the log-probabilities and call it per step, as the reference does
+        H = h2.shape[2]
+        logp = ops.HeadLogp.apply(h2.view(Tt * B, H), c.view(Tt * B, 2 * H), e.view(Tt * B, -1), p_out, rng, *head)
+        logp = logp.view(Tt, B, V)
+        loss = 0
+        for di in range(Tt):
+            loss = loss + criterion(logp[di], tgt_var[:, di])
+        tgt_mask = (tgt_var != 0).float()
+        return (loss / tgt_mask.sum(-1)).mean()
+
+    # ------------------------------------------------------------------------------------------ decoding
+    def _greedy(self, enc, mask, h, tgt_l):
+        """beam_size == 1 branch (V11.py:207-226): argmax for exactly tgt_l steps, cut at EOS on the host."""
+        dec = self.decoder
+        B = enc.shape[0]
+        pe = ops.KeysProj.apply(enc, dec.attn.attn_e.weight)
+        tok = torch.full((B,), SOS_token, dtype=torch.int64, device=enc.device)
+        toks = torch.empty(tgt_l, B, dtype=torch.int64, device=enc.device)
+        dp, hp, emb = dec.dec_params(), dec.head_params(), dec.embedding.weight
+        for di in range(tgt_l):
+            h, c, e, _ = ops.decode_step(enc, pe, mask, 1, tok, h, emb, dp)
+            _, tok = ops.head_logp_step(h, c, e, hp, want_argmax=True)
+            toks[di] = tok
+        return self._cut(toks.t().cpu().numpy())
+
+    def _beam(self, enc, mask, h, beam_size, max_length):
+        """Batched beam search (V11.py:233-337): avoid_double=True, avoid_unk=False."""
+        dec = self.decoder
+        B, k = enc.shape[0], beam_size
+        H = h.shape[1]
+        V = dec.out.bias.shape[0]
+        dev = enc.device
+        pe = ops.KeysProj.apply(enc, dec.attn.attn_e.weight)
+        dp, hp, emb = dec.dec_params(), dec.head_params(), dec.embedding.weight
+        beam = torch.zeros(max_length, B, k, dtype=torch.int64, device=dev)
+        nll = torch.zeros(B, k, dtype=torch.float32, device=dev)
+        n_alive = torch.zeros(1, dtype=torch.int32, device=dev)
+        h_next = torch.empty(B * k, H, dtype=torch.float32, device=dev)
+        scratch = torch.empty(_lib.lib().vag_beam_scratch_bytes(B, k, V, max_length), dtype=torch.uint8, device=dev)
+        tok = torch.full((B,), SOS_token, dtype=torch.int64, device=dev)
+        for di in range(max_length):
+            rps = 1 if di == 0 else k
+            h, c, e, _ = ops.decode_step(enc, pe, mask, rps, tok, h, emb, dp)
+            logp, _ = ops.head_logp_step(h, c, e, hp)
+            call("vag_beam_step", ptr(logp), logp.shape[1], ptr(nll), ptr(beam, torch.int64), di, max_length, ptr(h),
+                 ptr(h_next), B, k, V, H, ptr(n_alive, torch.int32), scratch.data_ptr(), stream())
+            h, h_next = h_next, torch.empty(B * k, H, dtype=torch.float32, device=dev)
+            tok = beam[di].view(-1)
+            # the reference stops once every hypothesis has emitted EOS (V11.py:266-269); running on is harmless
+            # (finished hypotheses only re-emit EOS at cost 0), so the device counter is polled only now and then.
+            if di % 8 == 7 and int(n_alive.item()) == 0:
+                break
+        out = torch.empty(B, max_length, dtype=torch.int64, device=dev)
+        best = torch.empty(B, dtype=torch.float32, device=dev)
+        call("vag_beam_finish", ptr(nll), ptr(beam, torch.int64), max_length, B, k, ptr(out, torch.int64), ptr(best), stream())
+        self.last_beam_scores = best
+        return self._cut(out.cpu().numpy())
+
+    @staticmethod
+    def _cut(hyps):
+        final = []
+        for row in hyps:
+            cur = []
+            for t in row:
+                if t == EOS_token:
+                    break
+                cur.append(t)
+            final.append(cur)
+        return final

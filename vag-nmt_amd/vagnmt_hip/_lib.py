@@ -1,0 +1,145 @@
+"""ctypes binding of libvagnmt.so (include/vag_nmt.h).
+
+The library is the product: there is NO CPU or pure-torch fallback.  If the shared object is missing, or a
+tensor is not a contiguous fp32/int64 HIP tensor, the call raises."""
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)                       # .../vag-nmt_amd
+CSRC = os.path.join(PKG_ROOT, "csrc")
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libvagnmt.so")
+
+P = C.c_void_p
+I64 = C.c_int64
+I32 = C.c_int
+F = C.c_float
+
+
+class GruW(C.Structure):
+    _fields_ = [("w_ih", P), ("w_hh", P), ("b_ih", P), ("b_hh", P)]
+
+
+class DecW(C.Structure):
+    _fields_ = [("emb", P), ("gru1", GruW), ("attn_h", P), ("attn_v", P), ("c2h", P), ("gru2", GruW)]
+
+
+class HeadW(C.Structure):
+    _fields_ = [("w1", P), ("b1", P), ("w2", P), ("b2", P), ("w3", P), ("b3", P), ("out_w", P), ("out_b", P)]
+
+
+# name -> (restype, argtypes); mirrors include/vag_nmt.h declaration by declaration
+PROTOS = {
+    "vag_version": (I32, []),
+    "vag_gemm_f32": (I32, [I64, I64, I64, F, P, I64, I64, P, I64, I64, F, P, I64, P, I32, P]),
+    "vag_linear_fwd": (I32, [I64, I64, I64, P, P, P, I32, P, P]),
+    "vag_linear_bwd": (I32, [I64, I64, I64, P, P, P, P, I32, P, I32, P, P, P]),
+    "vag_embed_fwd": (I32, [P, I64, P, I64, P, P]),
+    "vag_embed_bwd": (I32, [P, I64, P, I64, P, P]),
+    "vag_bigru_ws_floats": (I64, [I64, I64, I64, I64]),
+    "vag_bigru_seq_fwd": (I32, [P, P, P, GruW, GruW, F, F, P, I64, I64, I64, I64, P, P, P, P]),
+    "vag_bigru_seq_bwd": (I32, [P, P, GruW, GruW, F, F, P, I64, I64, I64, I64, P, P, P, GruW, GruW, P]),
+    "vag_attn_keys_proj": (I32, [P, P, I64, I64, P, P]),
+    "vag_bahdanau_attn_fwd": (I32, [P, P, P, P, P, I64, I64, I64, I64, P, P, P, P]),
+    "vag_attn_keys_proj_bwd": (I32, [P, P, P, I64, I64, P, I32, P, P]),
+    "vag_cgru_ws_floats": (I64, [I64, I64, I64, I64, I64]),
+    "vag_cgru_attn_decode_seq_fwd": (I32, [P, P, P, P, P, DecW, I64, I64, I64, I64, I64, I64, P, P, P, P, I32,
+                                           C.POINTER(HeadW), F, P, P, P, I64, P]),
+    "vag_cgru_bwd_scratch_floats": (I64, [I64, I64, I64, I64, I64]),
+    "vag_cgru_attn_decode_seq_bwd": (I32, [P, P, P, P, P, DecW, I64, I64, I64, I64, I64, I64, P, P, P, P, P, P, P, P,
+                                           I32, P, P, DecW, P, P]),
+    "vag_cgru_step_scratch_floats": (I64, [I64, I64, I64, I64]),
+    "vag_cgru_attn_decode_step": (I32, [P, P, P, I64, P, P, DecW, I64, I64, I64, I64, P, P, P, P, P, P]),
+    "vag_head_ce_seq_fwd": (I32, [P, P, P, HeadW, P, P, I64, I64, I64, I64, I64, F, P, I32, P, P, I64, P, P, P, P, P]),
+    "vag_head_ce_seq_bwd": (I32, [P, P, P, HeadW, P, P, I64, I64, I64, I64, I64, F, P, P, P, I64, P, P, P, P, P, P,
+                                  HeadW, P, P]),
+    "vag_head_logp_seq_fwd": (I32, [P, P, P, HeadW, I64, I64, I64, I64, F, P, P, P, I64, P]),
+    "vag_head_logp_seq_bwd": (I32, [P, P, P, HeadW, I64, I64, I64, I64, F, P, P, P, P, I64, P, P, P, HeadW, P, P]),
+    "vag_l2norm_fwd": (I32, [P, I64, I64, P, P, P]),
+    "vag_l2norm_bwd": (I32, [P, P, P, P, I64, I64, P, P]),
+    "vag_head_logp_step": (I32, [P, P, P, HeadW, I64, I64, I64, I64, P, I64, P, P, P]),
+    "vag_img_proj_l2_fwd": (I32, [P, P, P, I64, I64, I64, I32, P, P, P, P]),
+    "vag_img_proj_l2_bwd": (I32, [P, P, P, P, P, P, I64, I64, I64, I32, P, P, P, P]),
+    "vag_imagine_ws_floats": (I64, [I64, I64, I64, I64, I32]),
+    "vag_imagine_attn_ctx_fwd": (I32, [P, P, P, P, P, P, I32, I64, I64, I64, I64, P, P, P, P]),
+    "vag_imagine_attn_ctx_bwd": (I32, [P, P, P, P, P, P, I32, I64, I64, I64, I64, P, P, P, P, I32, P, P, P, P, P]),
+    "vag_rank_loss_fwd": (I32, [P, P, I64, I64, F, I32, P, P, P, P]),
+    "vag_rank_loss_bwd": (I32, [P, P, P, P, I64, I64, P, P, P]),
+    "vag_dec_init_fwd": (I32, [P, P, P, F, P, P, I64, I64, I64, I64, P, P, P]),
+    "vag_dec_init_bwd": (I32, [P, P, P, F, P, P, I64, I64, I64, I64, P, I32, P, P, P, P, P]),
+    "vag_beam_scratch_bytes": (I64, [I64, I64, I64, I64]),
+    "vag_beam_step": (I32, [P, I64, P, P, I64, I64, P, P, I64, I64, I64, I64, P, P, P]),
+    "vag_beam_finish": (I32, [P, P, I64, I64, I64, P, P, P]),
+    "vag_clip_adam_flat": (I32, [P, P, P, P, I64, I32, C.POINTER(I64), C.POINTER(F), C.POINTER(F), F, F, F, F, F, P, P,
+                                 P, P]),
+    "vag_dropout_mask": (I32, [P, I32, I64, F, P, P]),
+    "vag_rng_advance": (I32, [P, P]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile libvagnmt.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:])
+        print(r.stderr[-4000:])
+    if r.returncode != 0:
+        raise RuntimeError("building libvagnmt.so failed")
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libvagnmt.so not found at %s: build it with `make -C %s` (or __graft_entry__.build()). "
+                "There is no CPU fallback for the VAG-NMT hot path." % (LIB_PATH, CSRC))
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOS.items():
+            fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class VagError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        kind = "argument/shape error" if rc < 0 else "hipError_t"
+        raise VagError("libvagnmt %s failed: %s %d" % (what, kind, rc))
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=torch.float32):
+    """Device pointer of a contiguous HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise VagError("the VAG-NMT HIP path needs tensors on the GPU (got a %s tensor); there is no CPU fallback"
+                       % t.device)
+    if t.dtype != dtype:
+        raise VagError("expected %s, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise VagError("expected a contiguous tensor")
+    return t.data_ptr()
+
+
+def gru_w(w_ih, w_hh, b_ih, b_hh):
+    return GruW(ptr(w_ih), ptr(w_hh), ptr(b_ih), ptr(b_hh))
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)
