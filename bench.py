@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training sentence-pairs/sec of the VAG-NMT multimodal step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = zero-grad + forward + backward (+ RCCL all-reduce of the flat gradient when N > 1) + global-norm clip +
+Adam on one synthetic Multi30K-shaped batch per GPU (BASELINE.json configs[1]: B=64, Ts=Tt=40, E=256, H=512, S=512,
+I=2048, Vs=8507, V=9391, fp32, reference dropouts 0.3/0.5/0.5, tied embeddings, teacher forcing).  Inputs are
+resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "vag-nmt_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+CFG2 = dict(Vs=8507, V=9391, I=2048, E=256, H=512, S=512, B=64, Ts=40, Tt=40)
+HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md (spec)
+MFMA_F32_PEAK = 157.3e12   # FLOP/s dense, f32-input MFMA (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(c, w=4):
+    """SURVEY.md section 8(d) streaming model, per training step (bytes)."""
+    B, Ts, Tt, E, H, S, I, V, Vs = c["B"], c["Ts"], c["Tt"], c["E"], c["H"], c["S"], c["I"], c["V"], c["Vs"]
+    C = 2 * H
+    F_dec = w * (2 * B * Ts * C + 9 * H * H + 2 * C * H + C + B * (6 * H + C + Ts))
+    F_enc = w * (3 * H * H + 3 * B * H + 2 * B * H)
+    Bk_dec = w * (6 * B * Ts * C + 9 * H * H + 2 * C * H + B * (16 * H + 2 * C + 2 * Ts))
+    Bk_enc = w * (3 * H * H + 6 * B * H + 4 * B * H)
+    return dict(F_dec=F_dec, F_enc=F_enc, Bk_dec=Bk_dec, Bk_enc=Bk_enc)
+
+
+def make_batch(c, rank, dev, ragged=False):
+    g = torch.Generator().manual_seed(1234 + rank)
+    B, Ts, Tt = c["B"], c["Ts"], c["Tt"]
+    src = torch.randint(4, c["Vs"], (B, Ts), generator=g)
+    lens = [Ts] * B
+    if ragged:
+        lens = sorted(torch.clamp((torch.randn(B, generator=g) * 5 + 15).round().long(), 4, Ts).tolist(), reverse=True)
+        lens[0] = Ts
+        for b, L in enumerate(lens):
+            src[b, L:] = 0
+    tgt = torch.randint(4, c["V"], (B, Tt), generator=g)
+    tgt[:, -1] = 3
+    im = torch.randn(B, c["I"], generator=g).abs()
+    return src.to(dev), lens, tgt.to(dev), im.to(dev)
+
+
+def build_model(c, dev, seed=1234, dropout=True):
+    from machine_translation_vision.models import NMT_AttentionImagine_Seq2Seq_Beam_V11
+    torch.manual_seed(seed)
+    d = 1.0 if dropout else 0.0
+    m = NMT_AttentionImagine_Seq2Seq_Beam_V11(c["Vs"], c["V"], c["I"], c["E"], c["E"], c["H"], c["S"], 0.99,
+                                              attn_model="dot", dropout_ctx=0.5 * d, dropout_emb=0.3 * d,
+                                              dropout_out=0.5 * d, tied_emb=True, init_split=0.5)
+    return m.to(dev)
+
+
+def cpu_baseline(c, steps=2):
+    """The oracle (reference op order: per-step attn_e, per-step head) timed on this host's cores, full step
+    (fwd + bwd + clip + Adam), same synthetic shapes."""
+    from oracle import vag_oracle as O
+    torch.manual_seed(1234)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = min(cores, 32)
+    torch.set_num_threads(cores)
+    m = build_model(c, torch.device("cpu"))
+    P = {n: p.detach().clone() for n, p in m.named_parameters()}
+    src, lens, tgt, im = make_batch(c, 0, torch.device("cpu"))
+    state = {}
+    times = []
+    for i in range(steps + 1):
+        t0 = time.time()
+        _, _, _, P, state = O.train_step(P, src, lens, tgt, im, teacher=True, state=state)
+        times.append(time.time() - t0)
+    dt = sum(times[1:]) / steps
+    return dict(value=c["B"] / dt, unit="sentence-pairs/s", cores=cores, kind="port",
+                sample="%d full optimiser steps (after 1 warm-up) of the same B=%d x T=%d batch, torch CPU threads=%d, "
+                       "eval-mode oracle in the reference's op order" % (steps, c["B"], c["Tt"], cores),
+                s_per_step=dt)
+
+
+def measure_families(c, dev, reps=5):
+    """Live HIP-event timing of the recurrent operators on the current stream: average duration of one
+    decoder-sequence forward launch (Tt GRU+attention steps) and one encoder forward launch."""
+    from vagnmt_hip import ops, _lib
+    from vagnmt_hip._lib import ptr
+    m = build_model(c, dev).eval()
+    src, lens, tgt, im = make_batch(c, 0, dev)
+    out = {}
+    with torch.no_grad():
+        enc, mask = m._encode(src, lens, None)
+        _, ctx = m.vse_imagine.forward_bm(im, enc, mask, None)
+        h0 = ops.DecInit.apply(enc, mask, ctx, m.decoderini.weight, m.decoderini.bias, 0.5)
+        pe = ops.KeysProj.apply(enc, m.decoder.attn.attn_e.weight)
+        sos = torch.full((1, c["B"]), 2, dtype=torch.int64, device=dev)
+        tok = torch.cat([sos, tgt.t()], 0).contiguous()
+        dec = m.decoder
+
+        def run_dec():
+            ops.cgru_decode_seq(enc, pe, mask, h0, tok, dec.embedding.weight, dec.dec_params(), V=c["V"])
+
+        def run_enc():
+            m._encode(src, lens, None)
+
+        for name, fn in (("decoder_seq_fwd", run_dec), ("encoder_fwd", run_enc)):
+            fn()
+            torch.cuda.synchronize()
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(reps):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            out[name] = s.elapsed_time(e) / reps * 1e-3       # seconds per launch of the operator
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tfr", type=float, default=1.0, help="teacher forcing ratio (headline: 1.0)")
+    ap.add_argument("--ragged", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true", help="debug: disable the reference dropouts")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import random
+    from vagnmt_hip.trainer import TrainStep
+    from machine_translation_vision.losses import PairwiseRankingLoss
+    c = CFG2
+    random.seed(1234)      # same teacher-forcing coin on every rank
+    model = build_model(c, dev, dropout=not args.no_dropout)
+    vw = torch.ones(c["V"], device=dev)
+    vw[0] = 0
+    crit_mt = torch.nn.NLLLoss(weight=vw, reduction="none")
+    crit_vse = PairwiseRankingLoss(margin=0.1)
+    ts = TrainStep(model, crit_mt, crit_vse, lr=4e-4, weight_decay=1e-5, clip=1.0, teacher_force_ratio=args.tfr,
+                   use_graph=not args.no_graph, process_group=pg, world_size=world)
+    src, lens, tgt, im = make_batch(c, rank, dev, ragged=args.ragged)
+    lens_t = torch.tensor(lens, dtype=torch.int32, device=dev)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def log(msg):
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    log("model built; warm-up")
+    for i in range(max(args.warmup, 3)):
+        out = ts.step(src, lens_t, tgt, im)
+        if i < 6:
+            torch.cuda.synchronize()
+            log("warm-up step %d done (loss %.4f)" % (i, float(out[0].item())))
+    barrier()
+    log("timing %d steps" % args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = ts.step(src, lens_t, tgt, im)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(out[0].item())
+
+    log("timed region done: %.3f ms/step" % (dt / args.steps * 1e3))
+    if rank == 0:
+        ab = algorithmic_bytes(c)
+        fam = measure_families(c, dev)
+        log("operator timings: %s" % fam)
+        t_dec_step = fam["decoder_seq_fwd"] / c["Tt"]
+        achieved = ab["F_dec"] / t_dec_step
+        res = {
+            "metric": "training sentence-pairs/sec (Multi30K en->de, B=64)",
+            "value": c["B"] * world * args.steps / dt,
+            "unit": "sentence-pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: multimodal en->de train step, B=64/GPU, Ts=Tt=40, E=256, H=512, S=512, "
+                                   "I=2048, Vs=8507, V=9391, dropout 0.3/0.5/0.5, tied emb, teacher_force_ratio=%g%s"
+                                   % (args.tfr, ", ragged source lengths" if args.ragged else ""),
+                       "global_batch": c["B"] * world, "parallelism": "dp%d" % world,
+                       "hip_graph": not args.no_graph, "final_loss": loss},
+            "roofline": {"bound": "hbm", "kernel": "cgru_attn_decode_seq_fwd (per GRU+attention time step)",
+                         "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "algorithmic_bytes_per_step": ab["F_dec"], "us_per_decoder_step": t_dec_step * 1e6,
+                         "us_per_encoder_step": fam["encoder_fwd"] / c["Ts"] * 1e6},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(c)
+        print(json.dumps(res))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,15 +6,14 @@
 
 #define S_(x) reinterpret_cast<hipStream_t>(x)
 
+// Fills and copies are kernels (not hipMemset/hipMemcpy nodes) so a captured step is a pure chain of kernel nodes.
 static inline int zero_async(void* p, size_t bytes, hipStream_t s) {
     if (bytes == 0) return VAG_OK;
-    hipError_t e = hipMemsetAsync(p, 0, bytes, s);
-    return e == hipSuccess ? VAG_OK : (int)e;
+    return vag_axpy_launch(0.f, reinterpret_cast<const float*>(p), reinterpret_cast<float*>(p), (int64_t)(bytes / 4), 2, s);
 }
 static inline int copy_async(void* dst, const void* src, size_t bytes, hipStream_t s) {
     if (bytes == 0) return VAG_OK;
-    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
-    return e == hipSuccess ? VAG_OK : (int)e;
+    return vag_axpy_launch(1.f, reinterpret_cast<const float*>(src), reinterpret_cast<float*>(dst), (int64_t)(bytes / 4), 0, s);
 }
 // y = act(x W^T + b): small-M kernel for a single time step, tiled kernel otherwise.
 static int linear_fwd(int64_t M, int64_t N, int64_t K, const float* x, int64_t ldx, const float* W, const float* bias,

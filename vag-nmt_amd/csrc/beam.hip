@@ -38,8 +38,9 @@ __device__ __forceinline__ Cand block_best(Cand c, Cand* sh) {
 __global__ __launch_bounds__(256) void beam_stage1_kernel(const float* __restrict__ logp, int64_t ldl,
                                                           const float* __restrict__ nll, const int64_t* __restrict__ prev_tok,
                                                           int k_in, int k, int V, int penal, float* __restrict__ cval,
-                                                          int* __restrict__ cidx) {
+                                                          int* __restrict__ cidx, int32_t* __restrict__ n_alive) {
     __shared__ Cand sh[4];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *n_alive = 0;   // stage 2 (next launch) counts into it
     const int b = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
     const int total = k_in * V;
     float val[EPT];
@@ -144,11 +145,9 @@ int vag_beam_step_launch(float* logp, int64_t ldl, float* nll, int64_t* beam, in
     const int chunks = (int)cdiv64(total, CHUNK);
     float* cval = reinterpret_cast<float*>(scratch);
     int* cidx = reinterpret_cast<int*>(cval + B * cdiv64(k * V, CHUNK) * k);
-    hipError_t e = hipMemsetAsync(n_alive, 0, sizeof(int32_t), s);
-    if (e != hipSuccess) return (int)e;
     const int64_t* prev = di > 0 ? beam + (di - 1) * B * k : nullptr;
     hipLaunchKernelGGL(beam_stage1_kernel, dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, s, logp, ldl,
-                       di > 0 ? nll : (const float*)nullptr, prev, k_in, (int)k, (int)V, di > 0 ? 1 : 0, cval, cidx);
+                       di > 0 ? nll : (const float*)nullptr, prev, k_in, (int)k, (int)V, di > 0 ? 1 : 0, cval, cidx, n_alive);
     VAG_LAUNCH_CHECK();
     hipLaunchKernelGGL(beam_stage2_kernel, dim3((unsigned)B), dim3(256), 0, s, cval, cidx, chunks, k_in, (int)k, (int)V,
                        (int)H, nll, beam, (int)di, (int)B, h_in, h_out, n_alive);

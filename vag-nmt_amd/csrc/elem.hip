@@ -173,8 +173,9 @@ int vag_dropout_mask_launch(const uint64_t* rng, int sid, int64_t n, float p, fl
 
 __global__ __launch_bounds__(256) void axpy_kernel(float a, const float* __restrict__ x, float* __restrict__ y,
                                                    int64_t n, int acc) {
+    // acc: 0 -> y = a*x, 1 -> y += a*x, 2 -> y = 0 (fill; x is not read)
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        y[i] = acc ? y[i] + a * x[i] : a * x[i];
+        y[i] = acc == 2 ? 0.f : (acc ? y[i] + a * x[i] : a * x[i]);
 }
 int vag_axpy_launch(float a, const float* x, float* y, int64_t n, int accumulate, hipStream_t s) {
     if (n == 0) return VAG_OK;

@@ -10,6 +10,7 @@
 //                        v_mfma_f32_16x16x4_f32, LDS only for the cross-wave reduction.  Epilogues: plain
 //                        (bias/addend/tanh) and the fused GRU cell.
 #include "common.h"
+int vag_copy2d_launch(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t rows, int64_t cols, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // tiled GEMM
@@ -384,9 +385,7 @@ int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
         // generic path through the tiled kernel; an addend is folded in with beta = 1
         if (addend) {
             if (addend != out) {
-                hipError_t e = hipMemcpy2DAsync(out, ldo * sizeof(float), addend, ldadd * sizeof(float),
-                                                N * sizeof(float), M, hipMemcpyDeviceToDevice, stream);
-                if (e != hipSuccess) return (int)e;
+                VAG_TRY(vag_copy2d_launch(addend, ldadd, out, ldo, M, N, stream));
             }
             return vag_gemm_launch(M, N, K, 1.f, A, lda, 1, W, 1, ldw, 1.f, out, ldo, bias, act, stream);
         }

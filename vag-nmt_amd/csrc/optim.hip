@@ -31,6 +31,10 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     if (threadIdx.x == 0) atomicAdd(&sc->sumsq, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
+__global__ void adam_zero_kernel(AdamScalars* sc) {
+    if (threadIdx.x == 0) { sc->sumsq = 0.0; sc->coef = 0.f; sc->bc1 = 1.f; sc->bc2_sqrt = 1.f; sc->pad = 0.f; }
+}
+
 __global__ void adam_prep_kernel(AdamScalars* sc, float clip, float grad_scale, float beta1, float beta2,
                                  int32_t* step, float* norm_out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -73,8 +77,8 @@ int vag_clip_adam_launch(float* p, const float* g, float* m, float* v, int64_t n
     VAG_CHECK_ARG(p && g && m && v && n > 0 && nseg >= 1 && nseg <= 16 && seg_off && seg_lr && seg_wd && step && scratch);
     VAG_CHECK_ARG(aligned16(g) && seg_off[0] == 0 && seg_off[nseg] == n);
     AdamScalars* sc = reinterpret_cast<AdamScalars*>(scratch);
-    hipError_t e = hipMemsetAsync(sc, 0, sizeof(AdamScalars), s);
-    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(adam_zero_kernel, dim3(1), dim3(64), 0, s, sc);
+    VAG_LAUNCH_CHECK();
     int64_t blocks = cdiv64(n / 4 + 1, 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, n, sc);
