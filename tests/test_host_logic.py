@@ -1,0 +1,118 @@
+"""CPU: host-side behaviour of the drop-in modules (API surface, parameter names, pickling, loud failure on CPU)."""
+import inspect
+import io
+
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+def models():
+    from machine_translation_vision.models import NMT_AttentionImagine_Seq2Seq_Beam_V11, NMT_Seq2Seq_Beam_V2
+    return NMT_AttentionImagine_Seq2Seq_Beam_V11, NMT_Seq2Seq_Beam_V2
+
+
+def test_import_surface_matches_reference_names():
+    from machine_translation_vision.models import NMT_AttentionImagine_Seq2Seq_Beam_V11, NMT_Seq2Seq_Beam_V2  # noqa
+    from machine_translation_vision.layers import LIUMCVC_Encoder, NMT_Decoder, VSE_Imagine_Enc  # noqa
+    from machine_translation_vision.losses import PairwiseRankingLoss, ImageRetrievalRankingLoss  # noqa
+    from machine_translation_vision.utils.utils import l2norm  # noqa
+
+
+def test_constructor_and_forward_signatures():
+    V11, V2 = models()
+    assert list(inspect.signature(V11.__init__).parameters)[1:] == [
+        "src_size", "tgt_size", "im_feats_size", "src_embedding_size", "tgt_embedding_size", "hidden_size",
+        "shared_embedding_size", "loss_w", "beam_size", "attn_model", "n_layers", "dropout_ctx", "dropout_emb",
+        "dropout_out", "dropout_rnn_enc", "dropout_rnn_dec", "dropout_im_emb", "dropout_txt_emb", "activation_vse",
+        "tied_emb", "init_split"]
+    assert list(inspect.signature(V11.forward).parameters)[1:] == [
+        "src_var", "src_lengths", "tgt_var", "im_var", "teacher_force_ratio", "max_length", "criterion_mt",
+        "criterion_vse"]
+    assert list(inspect.signature(V11.beamsearch_decode).parameters)[1:] == [
+        "src_var", "src_lengths", "im_var", "beam_size", "max_length", "tgt_var"]
+    assert list(inspect.signature(V2.__init__).parameters)[1:] == [
+        "src_size", "tgt_size", "src_embedding_size", "tgt_embedding_size", "hidden_size", "beam_size", "n_layers",
+        "dropout_ctx", "dropout_emb", "dropout_out", "dropout_rnn", "tied_emb"]
+    assert list(inspect.signature(V2.forward).parameters)[1:] == [
+        "src_var", "src_lengths", "tgt_var", "teacher_force_ratio", "max_length", "criterion"]
+
+
+@pytest.mark.parametrize("name", ["mm_dot_tied_s0_f32", "mm_mlp_untied_s1_f32", "text_tied_s0_f32"])
+def test_parameter_names_and_shapes_equal_the_reference(name):
+    V11, V2 = models()
+    meta, P, _ = load_golden(name)
+    Vs, Vt, I, E, H, S, B, Ts, Tt = meta["dims"]
+    if meta["kind"] == "mm":
+        m = V11(Vs, Vt, I, E, E, H, S, 0.99, attn_model=meta["attn"], tied_emb=meta["tied"])
+    else:
+        m = V2(Vs, Vt, E, E, H, tied_emb=meta["tied"])
+    ours = {n: tuple(p.shape) for n, p in m.named_parameters()}
+    ref = {n: tuple(p.shape) for n, p in P.items()}
+    assert ours == ref
+    assert list(ours) == list(ref)      # same registration order as well
+    missing, unexpected = m.load_state_dict(P, strict=False)
+    assert not unexpected and set(missing) <= {"decoder.out.weight"}
+    if meta["tied"]:
+        assert m.decoder.out.weight is m.decoder.embedding.weight
+
+
+def test_reset_parameters_statistics():
+    V11, _ = models()
+    torch.manual_seed(0)
+    m = V11(500, 600, 256, 64, 64, 128, 96, 0.99, tied_emb=True)
+    w = m.decoder.gru_2.weight_hh_l0          # kaiming_normal_: std = sqrt(2 / fan_in)
+    assert abs(float(w.std()) - (2.0 / 128) ** 0.5) < 0.01
+    assert float(m.encoder.embedding.weight[0].norm()) > 0.1      # the pad row is re-initialised too (V11.py:77-80)
+    assert float(m.decoder.W1.bias.abs().max()) == 0.0            # bias_zero
+    assert m.decoder.attn.v.dim() == 1
+
+
+def test_whole_module_pickle_roundtrip():
+    V11, _ = models()
+    m = V11(50, 60, 96, 16, 16, 24, 20, 0.99, tied_emb=True)
+    buf = io.BytesIO()
+    torch.save(m, buf)                      # the reference checkpoints whole modules (nmt_multimodal_beam_DE.py:492)
+    buf.seek(0)
+    m2 = torch.load(buf, weights_only=False)
+    for (n1, p1), (n2, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2)
+    assert m2.shared_embedding_size == 20 and m2.tgt_size == 60 and m2.hidden_size == 24
+
+
+def test_cpu_tensors_fail_loudly_no_fallback():
+    from vagnmt_hip._lib import VagError
+    from machine_translation_vision.losses import PairwiseRankingLoss
+    V11, _ = models()
+    m = V11(50, 60, 96, 16, 16, 24, 20, 0.99)
+    crit = torch.nn.NLLLoss(weight=torch.ones(60), reduction="none")
+    with pytest.raises(VagError):
+        m(torch.ones(2, 3, dtype=torch.long), [3, 3], torch.ones(2, 3, dtype=torch.long), torch.zeros(2, 96),
+          criterion_mt=crit, criterion_vse=PairwiseRankingLoss(0.1))
+    with pytest.raises(VagError):
+        PairwiseRankingLoss(0.1)(torch.zeros(2, 4), torch.zeros(2, 4))
+    with pytest.raises(VagError):
+        m.beamsearch_decode(torch.ones(2, 3, dtype=torch.long), [3, 3], torch.zeros(2, 96), 3, 5)
+
+
+def test_optimizer_grouping_follows_reference_rule():
+    from vagnmt_hip.trainer import flat_layout, param_groups
+    V11, _ = models()
+    m = V11(50, 60, 96, 16, 16, 24, 20, 0.99, tied_emb=True)
+    named = list(m.named_parameters())
+    g = param_groups(named)
+    assert [x[0] for x in g] == ["weight", "bias"]
+    assert "decoder.attn.v" in g[0][1]            # 1-D but no 'bias' in its name -> weight-decayed (DE.py:306)
+    assert all("bias" in n for n in g[1][1])
+    g4 = param_groups(named, vse_separate=True)
+    assert [x[3] for x in g4] == [1.0, 1.0, 0.5, 0.5]
+    assert all("vse_imagine" in n for n in g4[2][1] + g4[3][1])
+    groups, offs, seg, n = flat_layout(named)
+    assert seg[0] == 0 and seg[-1] == n and all(o % 4 == 0 for o in offs.values())
+    assert sum(len(x[1]) for x in groups) == len(named)
+
+
+def test_eos_cut():
+    from machine_translation_vision.models._seq2seq import Seq2SeqBase
+    assert Seq2SeqBase._cut([[5, 6, 3, 7], [3, 1], [4, 4, 4]]) == [[5, 6], [], [4, 4, 4]]
