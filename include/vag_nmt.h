@@ -132,10 +132,14 @@ int64_t vag_cgru_bwd_scratch_floats(int64_t B, int64_t Ts, int64_t Tt, int64_t E
 /* One inference step for N hypotheses (greedy / beam search, models/...V11.py:207-226,259-313).  Hypothesis n
  * attends over source sentence n / rows_per_src (the reference tiles encoder_outputs by beam_size, :253).
  * tok int64[N]; h_in (N,H) -> h_out (N,H), c (N,C), e (N,E).  scratch: vag_cgru_step_scratch_floats(). */
+/* `prep`: vag_cgru_prep_floats(H) floats filled by vag_cgru_prepare() once per decode call (derived weights:
+ * [attn_h ; gru_2.w_hh] stacked so both products of h1 are one launch, and gru_2.w_ih . context2hid folded). */
+int64_t vag_cgru_prep_floats(int64_t H);
+int vag_cgru_prepare(vag_dec_w w, int64_t H, float* prep, vag_stream_t stream);
 int64_t vag_cgru_step_scratch_floats(int64_t N, int64_t Ts, int64_t E, int64_t H);
 int vag_cgru_attn_decode_step(const float* enc, const float* pe, const float* mask, int64_t rows_per_src,
-                              const int64_t* tok, const float* h_in, vag_dec_w w, int64_t N, int64_t Ts,
-                              int64_t E, int64_t H, float* h_out, float* c, float* e, float* alpha,
+                              const int64_t* tok, const float* h_in, vag_dec_w w, const float* prep, int64_t N,
+                              int64_t Ts, int64_t E, int64_t H, float* h_out, float* c, float* e, float* alpha,
                               float* scratch, vag_stream_t stream);
 
 /* ---- a5 (head) + a2 loss: layers/NMT_Decoder.py:137-143, models/...V11.py:140,164 --------------------- */

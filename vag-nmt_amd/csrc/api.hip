@@ -142,31 +142,52 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
         const vag_gru_w& g = d == 0 ? fw : bw;
         VAG_TRY(vag_transpose_launch(g.w_hh, 3 * H, H, w.whhT + d * 3 * H * H, s));
     }
-    VAG_TRY(zero_async(w.carry, 4 * BH * sizeof(float), s));
+    // last processed step: plain elementwise cell backward (no gradient arrives from a later step)
     GruBwdArgs a = {};
     a.ld_add = Ts * 2 * H; a.ldh = H; a.ldgi = 6 * H; a.ldgh = 3 * H;
     a.M = (int)B; a.H = (int)H; a.lengths = lengths; a.rng = rng; a.sid = VAG_DROP_ENC_CTX; a.p = p_ctx;
     int cur = 0;
-    for (int64_t k = Ts - 1; k >= 0; --k) {
+    {
+        const int64_t k = Ts - 1;
         for (int d = 0; d < 2; ++d) {
             const int64_t t = d == 0 ? k : Ts - 1 - k;
             GruBwdSide& sd = a.s[d];
-            sd.dh_carry = w.carry + (d * 2 + cur) * BH;
+            sd.dh_carry = nullptr;
             sd.dh_add = d_enc + t * 2 * H + d * H;
             sd.drop_idx0 = t * 2 * H + d * H;
             sd.save = w.gates + (d * Ts + k) * 4 * BH;
             sd.hprev = w.hst + (d * (Ts + 1) + k) * BH;
             sd.dgi = d_xp + t * B * 6 * H + d * 3 * H;
             sd.dgh = w.dgh + (d * Ts + k) * B * 3 * H;
-            sd.dh_prev = w.carry + (d * 2 + (cur ^ 1)) * BH;
+            sd.dh_prev = w.carry + (d * 2 + cur) * BH;
             sd.t = (int)t;
         }
         VAG_TRY(vag_gru_bwd_elem_launch(a, 2, s));
+    }
+    // every other step: dh = dgh[k] W_hh + z*dh[k]  fused with the cell backward of step k-1 (both directions / launch)
+    GruBwdStepArgs f = {};
+    f.lda = 3 * H; f.ldw = 3 * H; f.ld_add = Ts * 2 * H; f.ldh = H; f.ldgi = 6 * H; f.ldgh = 3 * H;
+    f.M = (int)B; f.K = (int)(3 * H); f.H = (int)H; f.lengths = lengths; f.rng = rng; f.sid = VAG_DROP_ENC_CTX; f.p = p_ctx;
+    f.has_cell = 1;
+    for (int64_t k = Ts - 1; k >= 1; --k) {
         for (int d = 0; d < 2; ++d) {
-            float* nxt = w.carry + (d * 2 + (cur ^ 1)) * BH;
-            VAG_TRY(vag_skinny_launch(B, H, 3 * H, w.dgh + (d * Ts + k) * B * 3 * H, 3 * H, w.whhT + d * 3 * H * H, 3 * H,
-                                      nullptr, nxt, H, nxt, H, 0, s));
+            const int64_t k1 = k - 1;
+            const int64_t t1 = d == 0 ? k1 : Ts - 1 - k1;
+            GruBwdStepSide& sd = f.s[d];
+            sd.A = w.dgh + (d * Ts + k) * B * 3 * H;
+            sd.WT = w.whhT + d * 3 * H * H;
+            sd.addend = w.carry + (d * 2 + cur) * BH;
+            sd.dh_add = d_enc + t1 * 2 * H + d * H;
+            sd.drop_idx0 = t1 * 2 * H + d * H;
+            sd.save = w.gates + (d * Ts + k1) * 4 * BH;
+            sd.hprev = w.hst + (d * (Ts + 1) + k1) * BH;
+            sd.dgi = d_xp + t1 * B * 6 * H + d * 3 * H;
+            sd.dgh = w.dgh + (d * Ts + k1) * B * 3 * H;
+            sd.dh_direct = w.carry + (d * 2 + (cur ^ 1)) * BH;
+            sd.dh_out = nullptr;
+            sd.t = (int)t1;
         }
+        VAG_TRY(vag_gru_bwd_step_launch(f, 2, s));
         cur ^= 1;
     }
     for (int d = 0; d < 2; ++d) {
@@ -197,7 +218,7 @@ int vag_bahdanau_attn_fwd(const float* pe, const float* q, const float* v, const
                           vag_stream_t stream) {
     hipStream_t s = S_(stream);
     VAG_CHECK_ARG(pe && q && v && enc && scores && alpha && ctx);
-    VAG_TRY(vag_attn_scores_launch(0, pe, q, v, mask, N, rows_per_src, Ts, C, scores, s));
+    VAG_TRY(vag_attn_scores_launch(0, pe, q, C, v, mask, N, rows_per_src, Ts, C, scores, s));
     return vag_attn_ctx_launch(1, scores, enc, N, rows_per_src, Ts, C, alpha, ctx, s);
 }
 int vag_attn_keys_proj_bwd(const float* enc, const float* attn_e, const float* d_pe, int64_t rows, int64_t C, float* d_enc,
@@ -212,8 +233,44 @@ int vag_attn_keys_proj_bwd(const float* enc, const float* attn_e, const float* d
 // =====================================================================================================
 // cGRU decoder
 // =====================================================================================================
+// Per-call derived weights (vag_cgru_prepare): Wcat = [attn_h ; gru_2.w_hh] (C+3H,H) so that q = attn_h(h1) and the
+// hidden projection of gru_2 come out of ONE product; bcat = [0 ; gru_2.b_hh]; Wp = gru_2.w_ih . context2hid (3H,C)
+// so that gru_2's input projection is taken straight from the context (context2hid folded in; exact in real
+// arithmetic, fp32 reassociation only).
+struct CgruPrep {
+    float *wcat, *bcat, *wp;
+    int64_t total;
+};
+static CgruPrep cgru_prep(float* p, int64_t H) {
+    CgruPrep w;
+    const int64_t C = 2 * H, Q = C + 3 * H;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { float* q = p ? p + o : nullptr; o += (n + 3) & ~3ll; return q; };
+    w.wcat = take(Q * H); w.bcat = take(Q); w.wp = take(3 * H * C);
+    w.total = o;
+    return w;
+}
+int64_t vag_cgru_prep_floats(int64_t H) { return cgru_prep(nullptr, H).total; }
+
+static bool dec_w_ok(const vag_dec_w& w) {
+    return w.emb && w.gru1.w_ih && w.gru1.w_hh && w.gru1.b_ih && w.gru1.b_hh && w.attn_h && w.attn_v && w.c2h &&
+           w.gru2.w_ih && w.gru2.w_hh && w.gru2.b_ih && w.gru2.b_hh;
+}
+
+int vag_cgru_prepare(vag_dec_w w, int64_t H, float* prep, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(dec_w_ok(w) && prep && H > 0 && H % 4 == 0 && aligned16(prep));
+    const int64_t C = 2 * H;
+    CgruPrep p = cgru_prep(prep, H);
+    VAG_TRY(copy_async(p.wcat, w.attn_h, C * H * sizeof(float), s));
+    VAG_TRY(copy_async(p.wcat + C * H, w.gru2.w_hh, 3 * H * H * sizeof(float), s));
+    VAG_TRY(zero_async(p.bcat, C * sizeof(float), s));
+    VAG_TRY(copy_async(p.bcat + C, w.gru2.b_hh, 3 * H * sizeof(float), s));
+    return gemm_nn(3 * H, C, H, w.gru2.w_ih, H, w.c2h, C, 0.f, p.wp, C, s);
+}
+
 struct CgruWs {
-    float *xp1, *h1, *g1, *g2, *q, *hp2, *scores, *alpha, *cp, *tmp;
+    float *xp1, *h1, *g1, *g2, *qhp, *scores, *alpha, *tmp, *prep;
     int64_t total;
 };
 static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
@@ -225,12 +282,11 @@ static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, i
     w.h1 = take(Tt * B * H);
     w.g1 = take(Tt * 4 * B * H);
     w.g2 = take(Tt * 4 * B * H);
-    w.q = take(Tt * B * C);
-    w.hp2 = take(B * 3 * H);
+    w.qhp = take(Tt * B * (C + 3 * H));     // [q | W_hh2 h1 + b_hh2] per step
     w.scores = take(B * Ts);
     w.alpha = take(Tt * B * Ts);
-    w.cp = take(Tt * B * H);
     w.tmp = take(B * E);
+    w.prep = take(cgru_prep(nullptr, H).total);
     w.total = o;
     return w;
 }
@@ -241,28 +297,26 @@ int64_t vag_cgru_ws_floats(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t
 struct StepBufs {   // per-step buffers of one decoder step (training: slices of the sequence arrays)
     const float* xp1;   // (N,3H) input projection of gru_1 (bias included)
     const float* hprev; // (N,H)
-    float *h1, *g1, *g2, *q, *hp2, *scores, *alpha, *c, *cp, *h2;
+    float *h1, *g1, *g2, *qhp, *scores, *alpha, *c, *h2;
 };
 
-// One cGRU step for N rows (layers/NMT_Decoder.py:121-129).
-static int cgru_step(const float* enc, const float* pe, const float* mask, int64_t rps, const vag_dec_w& w, int64_t N,
-                     int64_t Ts, int64_t H, const StepBufs& b, hipStream_t s) {
-    const int64_t C = 2 * H;
+// One cGRU step for N rows (layers/NMT_Decoder.py:121-129): 5 launches.
+static int cgru_step(const float* enc, const float* pe, const float* mask, int64_t rps, const vag_dec_w& w,
+                     const CgruPrep& p, int64_t N, int64_t Ts, int64_t H, const StepBufs& b, hipStream_t s) {
+    const int64_t C = 2 * H, Q = C + 3 * H;
     GruStepArgs a = {};
     a.lda = H; a.ldw = H; a.ldother = 3 * H; a.ldh = H; a.ld2 = 0;
     a.M = (int)N; a.K = (int)H; a.H = (int)H; a.lengths = nullptr; a.comp_hidden = 1;
     a.s[0].A = b.hprev; a.s[0].W = w.gru1.w_hh; a.s[0].bias = w.gru1.b_hh; a.s[0].other = b.xp1;
     a.s[0].hprev = b.hprev; a.s[0].hout = b.h1; a.s[0].out2 = nullptr; a.s[0].save = b.g1; a.s[0].t = 0;
-    VAG_TRY(vag_gru_step_launch(a, 1, s));                                                        // :121
-    VAG_TRY(vag_skinny_launch(N, C, H, b.h1, H, w.attn_h, H, nullptr, nullptr, 0, b.q, C, 0, s)); // attn_h(hidden) :47
-    VAG_TRY(vag_skinny_launch(N, 3 * H, H, b.h1, H, w.gru2.w_hh, H, w.gru2.b_hh, nullptr, 0, b.hp2, 3 * H, 0, s));
-    VAG_TRY(vag_attn_scores_launch(0, pe, b.q, w.attn_v, mask, N, rps, Ts, C, b.scores, s));       // :47-51, :41-43
-    VAG_TRY(vag_attn_ctx_launch(1, b.scores, enc, N, rps, Ts, C, b.alpha, b.c, s));                // :44, :126
-    VAG_TRY(vag_skinny_launch(N, H, C, b.c, C, w.c2h, C, nullptr, nullptr, 0, b.cp, H, 0, s));     // :127
-    a.K = (int)H; a.comp_hidden = 0;
-    a.s[0].A = b.cp; a.s[0].W = w.gru2.w_ih; a.s[0].bias = w.gru2.b_ih; a.s[0].other = b.hp2;
+    VAG_TRY(vag_gru_step_launch(a, 1, s));                                                         // gru_1        :121
+    VAG_TRY(vag_skinny_launch(N, Q, H, b.h1, H, p.wcat, H, p.bcat, nullptr, 0, b.qhp, Q, 0, s));    // attn_h(h1) :47 | W_hh2 h1
+    VAG_TRY(vag_attn_scores_launch(0, pe, b.qhp, Q, w.attn_v, mask, N, rps, Ts, C, b.scores, s));   // :47-51, :41-43
+    VAG_TRY(vag_attn_ctx_launch(1, b.scores, enc, N, rps, Ts, C, b.alpha, b.c, s));                 // :44, :126
+    a.lda = C; a.ldw = C; a.ldother = Q; a.K = (int)C; a.comp_hidden = 0;
+    a.s[0].A = b.c; a.s[0].W = p.wp; a.s[0].bias = w.gru2.b_ih; a.s[0].other = b.qhp + C;
     a.s[0].hprev = b.h1; a.s[0].hout = b.h2; a.s[0].save = b.g2;
-    VAG_TRY(vag_gru_step_launch(a, 1, s));                                                        // :129
+    VAG_TRY(vag_gru_step_launch(a, 1, s));                                                         // context2hid + gru_2 :127-129
     return VAG_OK;
 }
 
@@ -279,11 +333,6 @@ static int head_step(const float* h2, const float* c, const float* e, const vag_
     return VAG_OK;
 }
 
-static bool dec_w_ok(const vag_dec_w& w) {
-    return w.emb && w.gru1.w_ih && w.gru1.w_hh && w.gru1.b_ih && w.gru1.b_hh && w.attn_h && w.attn_v && w.c2h &&
-           w.gru2.w_ih && w.gru2.w_hh && w.gru2.b_ih && w.gru2.b_hh;
-}
-
 int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float* mask, const float* h0, int64_t* tok,
                                  vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, int64_t V,
                                  float* h2_all, float* c_all, float* e_all, float* ws, int free_run,
@@ -293,8 +342,10 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
     VAG_CHECK_ARG(enc && pe && mask && h0 && tok && h2_all && c_all && e_all && ws && dec_w_ok(w));
     VAG_CHECK_ARG(B > 0 && Ts > 0 && Tt > 0 && E % 4 == 0 && H % 4 == 0 && E > 0 && H > 0 && aligned16(ws));
     VAG_CHECK_ARG(!free_run || (head && tmid && logits && ldl >= V && ldl % 4 == 0));
-    const int64_t C = 2 * H, BH = B * H;
+    const int64_t C = 2 * H, Q = C + 3 * H, BH = B * H;
     CgruWs k = cgru_ws(ws, B, Ts, Tt, E, H);
+    CgruPrep p = cgru_prep(k.prep, H);
+    VAG_TRY(vag_cgru_prepare(w, H, k.prep, stream));
     if (!free_run) {
         // teacher forcing: every input token is known -> embed and project all steps at once
         VAG_TRY(vag_embed_gather_launch(tok, B, 1, Tt, B, w.emb, E, e_all, nullptr, 0, 0.f, s));
@@ -310,9 +361,9 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
         b.xp1 = k.xp1 + t * B * 3 * H;
         b.hprev = t == 0 ? h0 : h2_all + (t - 1) * BH;
         b.h1 = k.h1 + t * BH; b.g1 = k.g1 + t * 4 * BH; b.g2 = k.g2 + t * 4 * BH;
-        b.q = k.q + t * B * C; b.hp2 = k.hp2; b.scores = k.scores; b.alpha = k.alpha + t * B * Ts;
-        b.c = c_all + t * B * C; b.cp = k.cp + t * BH; b.h2 = h2_all + t * BH;
-        VAG_TRY(cgru_step(enc, pe, mask, 1, w, B, Ts, H, b, s));
+        b.qhp = k.qhp + t * B * Q; b.scores = k.scores; b.alpha = k.alpha + t * B * Ts;
+        b.c = c_all + t * B * C; b.h2 = h2_all + t * BH;
+        VAG_TRY(cgru_step(enc, pe, mask, 1, w, p, B, Ts, H, b, s));
         if (free_run) {
             VAG_TRY(head_step(b.h2, b.c, e_all + t * B * E, *head, B, E, H, V, p_out, rng, t * B * E, k.tmp,
                               tmid + t * B * E, logits + t * B * ldl, ldl, s));
@@ -325,19 +376,19 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
 }
 
 struct CgruBwdScratch {
-    float *wih2T, *c2hT, *whT, *whh2T, *whh1T, *dgi2, *dgh2, *dcp, *dalpha, *ds, *dq, *dgi1, *dgh1, *dh1, *carry, *de, *dvp;
+    float *wcatT, *wpT, *whh1T, *dgi2, *dqgh, *dalpha, *ds, *dgi1, *dgh1, *dh1d, *carry, *de, *dvp, *dwp;
     int64_t total;
 };
 static CgruBwdScratch cgru_bwd_scratch(float* p, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
     CgruBwdScratch w;
-    const int64_t C = 2 * H, R = Tt * B;
+    const int64_t C = 2 * H, Q = C + 3 * H, R = Tt * B;
     int64_t o = 0;
     auto take = [&](int64_t n) { float* q = p ? p + o : nullptr; o += (n + 3) & ~3ll; return q; };
-    w.wih2T = take(3 * H * H); w.c2hT = take(C * H); w.whT = take(C * H); w.whh2T = take(3 * H * H); w.whh1T = take(3 * H * H);
-    w.dgi2 = take(R * 3 * H); w.dgh2 = take(R * 3 * H); w.dcp = take(R * H);
-    w.dalpha = take(B * Ts); w.ds = take(R * Ts); w.dq = take(R * C);
+    w.wcatT = take(Q * H); w.wpT = take(3 * H * C); w.whh1T = take(3 * H * H);
+    w.dgi2 = take(R * 3 * H); w.dqgh = take(R * Q);
+    w.dalpha = take(B * Ts); w.ds = take(R * Ts);
     w.dgi1 = take(R * 3 * H); w.dgh1 = take(R * 3 * H);
-    w.dh1 = take(B * H); w.carry = take(B * H); w.de = take(R * E); w.dvp = take(B * C);
+    w.dh1d = take(B * H); w.carry = take(B * H); w.de = take(R * E); w.dvp = take(B * C); w.dwp = take(3 * H * C);
     w.total = o;
     return w;
 }
@@ -355,57 +406,73 @@ int vag_cgru_attn_decode_seq_bwd(const float* enc, const float* pe, const float*
                   d_pe && d_h0 && scratch && dec_w_ok(w));
     VAG_CHECK_ARG(B > 0 && Ts > 0 && Tt > 0 && E % 4 == 0 && H % 4 == 0 && aligned16(ws) && aligned16(scratch));
     (void)V; (void)mask;
-    const int64_t C = 2 * H, BH = B * H, R = Tt * B;
+    const int64_t C = 2 * H, Q = C + 3 * H, BH = B * H, R = Tt * B;
     CgruWs k = cgru_ws(ws, B, Ts, Tt, E, H);
+    CgruPrep p = cgru_prep(k.prep, H);          // Wcat / Wp from the forward call are still in the workspace
     CgruBwdScratch z = cgru_bwd_scratch(scratch, B, Ts, Tt, E, H);
-    // all per-step products are written in "x W^T" form, so transpose the weights once per call
-    VAG_TRY(vag_transpose_launch(w.gru2.w_ih, 3 * H, H, z.wih2T, s));   // (H,3H)
-    VAG_TRY(vag_transpose_launch(w.c2h, H, C, z.c2hT, s));              // (C,H)
-    VAG_TRY(vag_transpose_launch(w.attn_h, C, H, z.whT, s));            // (H,C)
-    VAG_TRY(vag_transpose_launch(w.gru2.w_hh, 3 * H, H, z.whh2T, s));   // (H,3H)
-    VAG_TRY(vag_transpose_launch(w.gru1.w_hh, 3 * H, H, z.whh1T, s));   // (H,3H)
-    GruBwdArgs a = {};
-    a.ld_add = H; a.ldh = H; a.ldgi = 3 * H; a.ldgh = 3 * H; a.M = (int)B; a.H = (int)H;
-    a.lengths = nullptr; a.rng = nullptr; a.sid = 0; a.p = 0.f;
-    for (int64_t t = Tt - 1; t >= 0; --t) {
-        float* dgi2 = z.dgi2 + t * B * 3 * H; float* dgh2 = z.dgh2 + t * B * 3 * H;
-        float* dgi1 = z.dgi1 + t * B * 3 * H; float* dgh1 = z.dgh1 + t * B * 3 * H;
-        float* dcp = z.dcp + t * BH; float* dc = d_c_all + t * B * C;
-        float* ds = z.ds + t * B * Ts; float* dq = z.dq + t * B * C;
-        const float* h1 = k.h1 + t * BH;
-        // gru_2 backward (elementwise part): dh2 = d_h2_all[t] + carry from step t+1
+    // per-step products are written as x W^T, so transpose the (derived) weights once per call
+    VAG_TRY(vag_transpose_launch(p.wcat, Q, H, z.wcatT, s));            // (H, C+3H) = [attn_h^T | W_hh2^T]
+    VAG_TRY(vag_transpose_launch(p.wp, 3 * H, C, z.wpT, s));            // (C, 3H)
+    VAG_TRY(vag_transpose_launch(w.gru1.w_hh, 3 * H, H, z.whh1T, s));   // (H, 3H)
+    // gru_2 cell backward of the last step: nothing arrives from a later step
+    {
+        GruBwdArgs a = {};
+        a.ld_add = H; a.ldh = H; a.ldgi = 3 * H; a.ldgh = Q; a.M = (int)B; a.H = (int)H;
+        const int64_t t = Tt - 1;
         GruBwdSide& sd = a.s[0];
-        sd.dh_carry = (t == Tt - 1) ? nullptr : z.carry;
-        sd.dh_add = d_h2_all + t * BH; sd.drop_idx0 = 0;
-        sd.save = k.g2 + t * 4 * BH; sd.hprev = h1; sd.dgi = dgi2; sd.dgh = dgh2; sd.dh_prev = z.dh1; sd.t = 0;
+        sd.dh_carry = nullptr; sd.dh_add = d_h2_all + t * BH; sd.drop_idx0 = 0;
+        sd.save = k.g2 + t * 4 * BH; sd.hprev = k.h1 + t * BH;
+        sd.dgi = z.dgi2 + t * B * 3 * H; sd.dgh = z.dqgh + t * B * Q + C; sd.dh_prev = z.dh1d; sd.t = 0;
         VAG_TRY(vag_gru_bwd_elem_launch(a, 1, s));
-        VAG_TRY(vag_skinny_launch(B, H, 3 * H, dgi2, 3 * H, z.wih2T, 3 * H, nullptr, nullptr, 0, dcp, H, 0, s));
-        VAG_TRY(vag_skinny_launch(B, C, H, dcp, H, z.c2hT, H, nullptr, dc, C, dc, C, 0, s));   // dc = dcp W_c2h + d_c_all[t]
-        // attention backward: c = sum_s alpha_s enc_s ; alpha = softmax(score)
-        VAG_TRY(vag_attn_scores_launch(1, enc, dc, nullptr, nullptr, B, 1, Ts, C, z.dalpha, s));
-        VAG_TRY(vag_softmax_bwd_launch(k.alpha + t * B * Ts, z.dalpha, B, Ts, ds, s));
-        VAG_TRY(vag_attn_dq_launch(pe, k.q + t * B * C, w.attn_v, ds, B, Ts, C, dq, s));
-        // dh1 = z2*dh2 + dq W_h + dgh2 W_hh2
-        VAG_TRY(vag_skinny_launch(B, H, C, dq, C, z.whT, C, nullptr, z.dh1, H, z.dh1, H, 0, s));
-        VAG_TRY(vag_skinny_launch(B, H, 3 * H, dgh2, 3 * H, z.whh2T, 3 * H, nullptr, z.dh1, H, z.dh1, H, 0, s));
-        // gru_1 backward
-        sd.dh_carry = z.dh1; sd.dh_add = nullptr;
-        sd.save = k.g1 + t * 4 * BH; sd.hprev = (t == 0) ? h0 : h2_all + (t - 1) * BH;
-        sd.dgi = dgi1; sd.dgh = dgh1; sd.dh_prev = z.carry;
-        VAG_TRY(vag_gru_bwd_elem_launch(a, 1, s));
-        VAG_TRY(vag_skinny_launch(B, H, 3 * H, dgh1, 3 * H, z.whh1T, 3 * H, nullptr, z.carry, H, z.carry, H, 0, s));
     }
-    VAG_TRY(copy_async(d_h0, z.carry, BH * sizeof(float), s));
+    GruBwdStepArgs f = {};
+    f.ld_add = H; f.ldh = H; f.M = (int)B; f.H = (int)H; f.lengths = nullptr; f.rng = nullptr; f.sid = 0; f.p = 0.f;
+    for (int64_t t = Tt - 1; t >= 0; --t) {
+        float* dgi2 = z.dgi2 + t * B * 3 * H;
+        float* dqgh = z.dqgh + t * B * Q;
+        float* dc = d_c_all + t * B * C;
+        // dc = dgi2 (W_ih2 W_c2h) + head's d_c                                    (context2hid and gru_2 input, folded)
+        VAG_TRY(vag_skinny_launch(B, C, 3 * H, dgi2, 3 * H, z.wpT, 3 * H, nullptr, dc, C, dc, C, 0, s));
+        // attention backward: d alpha = dc . enc ; softmax backward ; dq = sum_s ds v (1 - tanh^2)
+        VAG_TRY(vag_attn_scores_launch(1, enc, dc, C, nullptr, nullptr, B, 1, Ts, C, z.dalpha, s));
+        VAG_TRY(vag_attn_dq_launch(pe, k.qhp + t * B * Q, Q, w.attn_v, k.alpha + t * B * Ts, z.dalpha, z.ds + t * B * Ts, B,
+                                   Ts, C, dqgh, Q, s));
+        // dh1 = [dq | dgh2] [attn_h ; W_hh2] + z2*dh2   -> gru_1 cell backward of this step
+        f.lda = Q; f.ldw = Q; f.K = (int)Q; f.ldgi = 3 * H; f.ldgh = 3 * H; f.has_cell = 1;
+        GruBwdStepSide& sd = f.s[0];
+        sd.A = dqgh; sd.WT = z.wcatT; sd.addend = z.dh1d; sd.dh_add = nullptr; sd.drop_idx0 = 0;
+        sd.save = k.g1 + t * 4 * BH; sd.hprev = (t == 0) ? h0 : h2_all + (t - 1) * BH;
+        sd.dgi = z.dgi1 + t * B * 3 * H; sd.dgh = z.dgh1 + t * B * 3 * H; sd.dh_direct = z.carry; sd.dh_out = nullptr; sd.t = 0;
+        VAG_TRY(vag_gru_bwd_step_launch(f, 1, s));
+        // d h2[t-1] = dgh1 W_hh1 + z1*dh1 (+ head's d_h2[t-1])   -> gru_2 cell backward of step t-1 (or d_h0 at t = 0)
+        f.lda = 3 * H; f.ldw = 3 * H; f.K = (int)(3 * H);
+        sd.A = z.dgh1 + t * B * 3 * H; sd.WT = z.whh1T; sd.addend = z.carry;
+        if (t > 0) {
+            const int64_t t1 = t - 1;
+            f.has_cell = 1; f.ldgi = 3 * H; f.ldgh = Q;
+            sd.dh_add = d_h2_all + t1 * BH;
+            sd.save = k.g2 + t1 * 4 * BH; sd.hprev = k.h1 + t1 * BH;
+            sd.dgi = z.dgi2 + t1 * B * 3 * H; sd.dgh = z.dqgh + t1 * B * Q + C; sd.dh_direct = z.dh1d; sd.dh_out = nullptr;
+        } else {
+            f.has_cell = 0;
+            sd.dh_add = nullptr; sd.save = nullptr; sd.hprev = nullptr; sd.dgi = nullptr; sd.dgh = nullptr;
+            sd.dh_direct = nullptr; sd.dh_out = d_h0;
+        }
+        VAG_TRY(vag_gru_bwd_step_launch(f, 1, s));
+    }
     // after the loop: everything that does not sit on the recurrence's critical path, as large products
-    VAG_TRY(vag_attn_post_bwd_launch(pe, k.q, w.attn_v, z.ds, k.alpha, d_c_all, B, Ts, Tt, C, d_pe, z.dvp, d_enc_out,
+    VAG_TRY(vag_attn_post_bwd_launch(pe, k.qhp, Q, w.attn_v, z.ds, k.alpha, d_c_all, B, Ts, Tt, C, d_pe, z.dvp, d_enc_out,
                                      accumulate_enc, s));
     VAG_TRY(vag_colsum_launch(z.dvp, B, C, C, g.attn_v, s));
-    VAG_TRY(gemm_tn_acc(3 * H, H, R, z.dgh2, 3 * H, k.h1, H, g.gru2.w_hh, H, s));
-    VAG_TRY(vag_colsum_launch(z.dgh2, R, 3 * H, 3 * H, g.gru2.b_hh, s));
-    VAG_TRY(gemm_tn_acc(3 * H, H, R, z.dgi2, 3 * H, k.cp, H, g.gru2.w_ih, H, s));
+    const float* dgh2 = z.dqgh + C;      // (R,3H) row stride Q
+    VAG_TRY(gemm_tn_acc(3 * H, H, R, dgh2, Q, k.h1, H, g.gru2.w_hh, H, s));
+    VAG_TRY(vag_colsum_launch(dgh2, R, 3 * H, Q, g.gru2.b_hh, s));
+    VAG_TRY(gemm_tn_acc(C, H, R, z.dqgh, Q, k.h1, H, g.attn_h, H, s));
+    // d(W_ih2 W_c2h) = dgi2^T c, then the chain rule through the folded product
+    VAG_TRY(vag_gemm_launch(3 * H, C, R, 1.f, z.dgi2, 1, 3 * H, c_all, C, 1, 0.f, z.dwp, C, nullptr, 0, s));
+    VAG_TRY(vag_gemm_launch(3 * H, H, C, 1.f, z.dwp, C, 1, w.c2h, 1, C, 1.f, g.gru2.w_ih, H, nullptr, 0, s));
+    VAG_TRY(vag_gemm_launch(H, C, 3 * H, 1.f, w.gru2.w_ih, 1, H, z.dwp, C, 1, 1.f, g.c2h, C, nullptr, 0, s));
     VAG_TRY(vag_colsum_launch(z.dgi2, R, 3 * H, 3 * H, g.gru2.b_ih, s));
-    VAG_TRY(gemm_tn_acc(H, C, R, z.dcp, H, c_all, C, g.c2h, C, s));
-    VAG_TRY(gemm_tn_acc(C, H, R, z.dq, C, k.h1, H, g.attn_h, H, s));
     VAG_TRY(gemm_tn_acc(3 * H, H, B, z.dgh1, 3 * H, h0, H, g.gru1.w_hh, H, s));
     VAG_TRY(gemm_tn_acc(3 * H, H, R - B, z.dgh1 + B * 3 * H, 3 * H, h2_all, H, g.gru1.w_hh, H, s));
     VAG_TRY(vag_colsum_launch(z.dgh1, R, 3 * H, 3 * H, g.gru1.b_hh, s));
@@ -419,28 +486,28 @@ int vag_cgru_attn_decode_seq_bwd(const float* enc, const float* pe, const float*
 }
 
 int64_t vag_cgru_step_scratch_floats(int64_t N, int64_t Ts, int64_t E, int64_t H) {
-    return N * (3 * H + H + 2 * H + 3 * H + Ts + H) + 64 + 0 * E;
+    (void)E;
+    return N * (3 * H + H + 5 * H + Ts) + 64;
 }
 int vag_cgru_attn_decode_step(const float* enc, const float* pe, const float* mask, int64_t rows_per_src, const int64_t* tok,
-                              const float* h_in, vag_dec_w w, int64_t N, int64_t Ts, int64_t E, int64_t H, float* h_out,
-                              float* c, float* e, float* alpha, float* scratch, vag_stream_t stream) {
+                              const float* h_in, vag_dec_w w, const float* prep, int64_t N, int64_t Ts, int64_t E, int64_t H,
+                              float* h_out, float* c, float* e, float* alpha, float* scratch, vag_stream_t stream) {
     hipStream_t s = S_(stream);
-    VAG_CHECK_ARG(enc && pe && mask && tok && h_in && h_out && c && e && alpha && scratch && dec_w_ok(w));
-    VAG_CHECK_ARG(N > 0 && Ts > 0 && E % 4 == 0 && H % 4 == 0 && rows_per_src >= 1 && aligned16(scratch));
-    const int64_t C = 2 * H;
-    float* p = scratch;
-    float* xp1 = p; p += N * 3 * H;
-    float* h1 = p; p += N * H;
-    float* q = p; p += N * C;
-    float* hp2 = p; p += N * 3 * H;
-    float* cp = p; p += N * H;
-    float* scores = p;
+    VAG_CHECK_ARG(enc && pe && mask && tok && h_in && h_out && c && e && alpha && scratch && prep && dec_w_ok(w));
+    VAG_CHECK_ARG(N > 0 && Ts > 0 && E % 4 == 0 && H % 4 == 0 && rows_per_src >= 1 && aligned16(scratch) && aligned16(prep));
+    const int64_t C = 2 * H, Q = C + 3 * H;
+    CgruPrep p = cgru_prep(const_cast<float*>(prep), H);
+    float* q = scratch;
+    float* xp1 = q; q += N * 3 * H;
+    float* h1 = q; q += N * H;
+    float* qhp = q; q += N * Q;
+    float* scores = q;
     VAG_TRY(vag_embed_gather_launch(tok, 1, 0, N, 1, w.emb, E, e, nullptr, 0, 0.f, s));                   // :118
     VAG_TRY(linear_fwd(N, 3 * H, E, e, E, w.gru1.w_ih, w.gru1.b_ih, 0, xp1, 3 * H, s));
     StepBufs b;
-    b.xp1 = xp1; b.hprev = h_in; b.h1 = h1; b.g1 = nullptr; b.g2 = nullptr; b.q = q; b.hp2 = hp2; b.scores = scores;
-    b.alpha = alpha; b.c = c; b.cp = cp; b.h2 = h_out;
-    return cgru_step(enc, pe, mask, rows_per_src, w, N, Ts, H, b, s);
+    b.xp1 = xp1; b.hprev = h_in; b.h1 = h1; b.g1 = nullptr; b.g2 = nullptr; b.qhp = qhp; b.scores = scores;
+    b.alpha = alpha; b.c = c; b.h2 = h_out;
+    return cgru_step(enc, pe, mask, rows_per_src, w, p, N, Ts, H, b, s);
 }
 
 // =====================================================================================================
@@ -608,10 +675,10 @@ int vag_imagine_attn_ctx_fwd(const float* im_emb, const float* enc, const float*
     if (method == 0) {
         // e[b,t] = (W_cc enc[b,t]) . u[b] = enc[b,t] . (W_cc^T u[b])                                 :57-64
         VAG_TRY(gemm_nn(B, C, C, w.u, C, ctx2ctx, C, 0.f, w.w, C, s));
-        VAG_TRY(vag_attn_scores_launch(1, enc, w.w, nullptr, mask, B, 1, Ts, C, w.scores, s));
+        VAG_TRY(vag_attn_scores_launch(1, enc, w.w, C, nullptr, mask, B, 1, Ts, C, w.scores, s));
     } else {
         VAG_TRY(linear_fwd(B * Ts, C, C, enc, C, ctx2ctx, nullptr, 0, w.pre, C, s));              // ctx2ctx(decoder_hidden) :75
-        VAG_TRY(vag_attn_scores_launch(0, w.pre, w.u, mlp_w, mask, B, 1, Ts, C, w.scores, s));   // mlp(tanh(ctx_+im_)) :78
+        VAG_TRY(vag_attn_scores_launch(0, w.pre, w.u, C, mlp_w, mask, B, 1, Ts, C, w.scores, s));   // mlp(tanh(ctx_+im_)) :78
     }
     return vag_attn_ctx_launch(1, w.scores, enc, B, 1, Ts, C, alpha, ctx, s);                      // softmax :46, bmm :137
 }
@@ -626,7 +693,7 @@ int vag_imagine_attn_ctx_bwd(const float* im_emb, const float* enc, const float*
     VAG_CHECK_ARG(B > 0 && Ts > 0 && C % 4 == 0 && S % 4 == 0);
     (void)mask;
     ImgWs w = imagine_ws(ws, B, Ts, C, method);
-    VAG_TRY(vag_attn_scores_launch(1, enc, d_ctx, nullptr, nullptr, B, 1, Ts, C, w.dalpha, s));   // d alpha = d_ctx . enc
+    VAG_TRY(vag_attn_scores_launch(1, enc, d_ctx, C, nullptr, nullptr, B, 1, Ts, C, w.dalpha, s));   // d alpha = d_ctx . enc
     VAG_TRY(vag_softmax_bwd_launch(alpha, w.dalpha, B, Ts, w.de, s));
     if (method == 0) {
         VAG_TRY(vag_outer2_launch(alpha, d_ctx, w.de, w.w, B, Ts, C, d_enc, accumulate_enc, s));
@@ -635,9 +702,9 @@ int vag_imagine_attn_ctx_bwd(const float* im_emb, const float* enc, const float*
         VAG_TRY(gemm_tn_acc(C, C, B, w.u, C, w.dw, C, g_ctx2ctx, C, s));                          // g_cc[i,j] += u[b,i] dw[b,j]
     } else {
         VAG_TRY(vag_outer2_launch(alpha, d_ctx, nullptr, nullptr, B, Ts, C, d_enc, accumulate_enc, s));
-        VAG_TRY(vag_attn_post_bwd_launch(w.pre, w.u, mlp_w, w.de, alpha, nullptr, B, Ts, 1, C, w.dpre, w.dvp, nullptr, 0, s));
+        VAG_TRY(vag_attn_post_bwd_launch(w.pre, w.u, C, mlp_w, w.de, alpha, nullptr, B, Ts, 1, C, w.dpre, w.dvp, nullptr, 0, s));
         VAG_TRY(vag_colsum_launch(w.dvp, B, C, C, g_mlp_w, s));
-        VAG_TRY(vag_attn_dq_launch(w.pre, w.u, mlp_w, w.de, B, Ts, C, w.du, s));
+        VAG_TRY(vag_attn_dq_launch(w.pre, w.u, C, mlp_w, nullptr, nullptr, w.de, B, Ts, C, w.du, C, s));
         VAG_TRY(gemm_nn(B * Ts, C, C, w.dpre, C, ctx2ctx, C, 1.f, d_enc, C, s));
         VAG_TRY(gemm_tn_acc(C, C, B * Ts, w.dpre, C, enc, C, g_ctx2ctx, C, s));
     }

@@ -7,7 +7,7 @@
 template <int MODE>
 __global__ __launch_bounds__(256) void attn_scores_kernel(const float* __restrict__ pe, const float* __restrict__ q,
                                                           const float* __restrict__ v, const float* __restrict__ mask,
-                                                          int64_t total, int rps, int Ts, int C,
+                                                          int64_t total, int rps, int Ts, int C, int64_t ldq,
                                                           float* __restrict__ scores) {
     const int lane = threadIdx.x & 63;
     const int64_t pair = blockIdx.x * 4ll + (threadIdx.x >> 6);
@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(const float* __restric
     const int s = (int)(pair - n * Ts);
     const int64_t b = n / rps;
     const float* pr = pe + (b * Ts + s) * C;
-    const float* qr = q + n * C;
+    const float* qr = q + n * ldq;
     float acc = 0.f;
     for (int c = lane * 4; c < C; c += 256) {
         const float4 pv = *reinterpret_cast<const float4*>(pr + c);
@@ -38,65 +38,79 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(const float* __restric
     }
 }
 
-int vag_attn_scores_launch(int mode, const float* pe, const float* q, const float* v, const float* mask, int64_t N,
-                           int64_t rps, int64_t Ts, int64_t C, float* scores, hipStream_t s) {
-    VAG_CHECK_ARG(pe && q && scores && N > 0 && Ts > 0 && C > 0 && C % 4 == 0 && rps >= 1);
+int vag_attn_scores_launch(int mode, const float* pe, const float* q, int64_t ldq, const float* v, const float* mask,
+                           int64_t N, int64_t rps, int64_t Ts, int64_t C, float* scores, hipStream_t s) {
+    VAG_CHECK_ARG(pe && q && scores && N > 0 && Ts > 0 && C > 0 && C % 4 == 0 && rps >= 1 && ldq % 4 == 0 && ldq >= C);
     VAG_CHECK_ARG(mode == 1 || v);
     const int64_t total = N * Ts;
     dim3 grid((unsigned)cdiv64(total, 4));
     if (mode == 0)
-        hipLaunchKernelGGL(attn_scores_kernel<0>, grid, dim3(256), 0, s, pe, q, v, mask, total, (int)rps, (int)Ts, (int)C, scores);
+        hipLaunchKernelGGL(attn_scores_kernel<0>, grid, dim3(256), 0, s, pe, q, v, mask, total, (int)rps, (int)Ts, (int)C, ldq, scores);
     else
-        hipLaunchKernelGGL(attn_scores_kernel<1>, grid, dim3(256), 0, s, pe, q, v, mask, total, (int)rps, (int)Ts, (int)C, scores);
+        hipLaunchKernelGGL(attn_scores_kernel<1>, grid, dim3(256), 0, s, pe, q, v, mask, total, (int)rps, (int)Ts, (int)C, ldq, scores);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
 
 // ------------------------------------------------------------------ softmax + context
-// grid (ceil(C/1024), N); 256 threads, each owns one float4 of c.
-__global__ __launch_bounds__(256) void attn_ctx_kernel(int softmax, const float* __restrict__ scores,
-                                                       const float* __restrict__ enc, int rps, int Ts, int C,
-                                                       float* __restrict__ alpha, float* __restrict__ ctx) {
+// grid (ceil(C/256), N); one 64-lane wave per workgroup, each lane owns one float4 of c.  Small workgroups on
+// purpose: the kernel streams Ts x 1 KB of enc per wave, and per-CU fetch bandwidth is the limit, so the row is
+// spread over 4 CUs (C=1024) instead of one.  The Ts-element softmax is recomputed by every wave (it is tiny).
+__global__ __launch_bounds__(64) void attn_ctx_kernel(int softmax, const float* __restrict__ scores,
+                                                      const float* __restrict__ enc, int rps, int Ts, int C,
+                                                      float* __restrict__ alpha, float* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) float w[];   // Ts weights
+    const int lane = threadIdx.x;
     const int64_t n = blockIdx.y;
     const int64_t b = n / rps;
     const float* sc = scores + n * Ts;
     if (softmax) {
         float mx = -INFINITY;
-        for (int s = 0; s < Ts; ++s) mx = fmaxf(mx, sc[s]);           // uniform (broadcast) loads
-        for (int s = threadIdx.x; s < Ts; s += 256) w[s] = __expf(sc[s] - mx);
-        __syncthreads();
+        for (int s = lane; s < Ts; s += 64) mx = fmaxf(mx, sc[s]);
+        mx = wave_max(mx);
         float sum = 0.f;
-        for (int s = 0; s < Ts; ++s) sum += w[s];
+        for (int s = lane; s < Ts; s += 64) {
+            const float e = __expf(sc[s] - mx);
+            w[s] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
         const float inv = 1.f / sum;
-        __syncthreads();
-        for (int s = threadIdx.x; s < Ts; s += 256) {
+        for (int s = lane; s < Ts; s += 64) {
             const float a = w[s] * inv;
             w[s] = a;
             if (blockIdx.x == 0 && alpha) alpha[n * Ts + s] = a;
         }
-        __syncthreads();
     } else {
-        for (int s = threadIdx.x; s < Ts; s += 256) w[s] = sc[s];
-        __syncthreads();
+        for (int s = lane; s < Ts; s += 64) w[s] = sc[s];
     }
-    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    __syncthreads();
+    const int c = (blockIdx.x * 64 + lane) * 4;
     if (c >= C) return;
     const float* e = enc + b * Ts * C + c;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < Ts; ++s) {
-        const float a = w[s];
-        const float4 ev = *reinterpret_cast<const float4*>(e + (int64_t)s * C);
-        acc.x += a * ev.x; acc.y += a * ev.y; acc.z += a * ev.z; acc.w += a * ev.w;
+    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 1 < Ts; s += 2) {
+        const float a0 = w[s], a1 = w[s + 1];
+        const float4 e0 = *reinterpret_cast<const float4*>(e + (int64_t)s * C);
+        const float4 e1 = *reinterpret_cast<const float4*>(e + (int64_t)(s + 1) * C);
+        acc0.x += a0 * e0.x; acc0.y += a0 * e0.y; acc0.z += a0 * e0.z; acc0.w += a0 * e0.w;
+        acc1.x += a1 * e1.x; acc1.y += a1 * e1.y; acc1.z += a1 * e1.z; acc1.w += a1 * e1.w;
     }
-    *reinterpret_cast<float4*>(ctx + n * C + c) = acc;
+    if (s < Ts) {
+        const float a0 = w[s];
+        const float4 e0 = *reinterpret_cast<const float4*>(e + (int64_t)s * C);
+        acc0.x += a0 * e0.x; acc0.y += a0 * e0.y; acc0.z += a0 * e0.z; acc0.w += a0 * e0.w;
+    }
+    acc0.x += acc1.x; acc0.y += acc1.y; acc0.z += acc1.z; acc0.w += acc1.w;
+    *reinterpret_cast<float4*>(ctx + n * C + c) = acc0;
 }
 
 int vag_attn_ctx_launch(int softmax, const float* scores, const float* enc, int64_t N, int64_t rps, int64_t Ts,
                         int64_t C, float* alpha, float* ctx, hipStream_t s) {
     VAG_CHECK_ARG(scores && enc && ctx && N > 0 && Ts > 0 && C > 0 && C % 4 == 0 && rps >= 1);
-    dim3 grid((unsigned)cdiv64(C, 1024), (unsigned)N);
-    hipLaunchKernelGGL(attn_ctx_kernel, grid, dim3(256), (size_t)Ts * sizeof(float), s, softmax, scores, enc, (int)rps,
+    dim3 grid((unsigned)cdiv64(C, 256), (unsigned)N);
+    hipLaunchKernelGGL(attn_ctx_kernel, grid, dim3(64), (size_t)Ts * sizeof(float), s, softmax, scores, enc, (int)rps,
                        (int)Ts, (int)C, alpha, ctx);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
@@ -121,23 +135,39 @@ int vag_softmax_bwd_launch(const float* alpha, const float* dalpha, int64_t N, i
 }
 
 // ------------------------------------------------------------------ dq (inside the backward time loop)
-// grid (ceil(C/1024), N); thread owns a float4 of c and walks the Ts source positions.
-__global__ __launch_bounds__(256) void attn_dq_kernel(const float* __restrict__ pe, const float* __restrict__ q,
-                                                      const float* __restrict__ v, const float* __restrict__ dscore,
-                                                      int Ts, int C, float* __restrict__ dq) {
+// grid (ceil(C/256), N); one wave per workgroup, lane owns a float4 of c and walks the Ts source positions.
+// With alpha/dalpha given, the softmax backward  ds = alpha * (dalpha - sum alpha dalpha)  is done in the prologue
+// (every wave recomputes the Ts values; the first column block stores them for the post-loop kernel).
+__global__ __launch_bounds__(64) void attn_dq_kernel(const float* __restrict__ pe, const float* __restrict__ q,
+                                                     int64_t ldq, const float* __restrict__ v,
+                                                     const float* __restrict__ alpha, const float* __restrict__ dalpha,
+                                                     float* __restrict__ dscore, int Ts, int C, float* __restrict__ dq,
+                                                     int64_t lddq) {
     extern __shared__ __attribute__((aligned(16))) float w[];
+    const int lane = threadIdx.x;
     const int64_t n = blockIdx.y;
-    for (int s = threadIdx.x; s < Ts; s += 256) w[s] = dscore[n * Ts + s];
+    if (alpha) {
+        float dot = 0.f;
+        for (int s = lane; s < Ts; s += 64) dot += alpha[n * Ts + s] * dalpha[n * Ts + s];
+        dot = wave_sum(dot);
+        for (int s = lane; s < Ts; s += 64) {
+            const float d = alpha[n * Ts + s] * (dalpha[n * Ts + s] - dot);
+            w[s] = d;
+            if (blockIdx.x == 0) dscore[n * Ts + s] = d;
+        }
+    } else {
+        for (int s = lane; s < Ts; s += 64) w[s] = dscore[n * Ts + s];
+    }
     __syncthreads();
-    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int c = (blockIdx.x * 64 + lane) * 4;
     if (c >= C) return;
-    const float4 qv = *reinterpret_cast<const float4*>(q + n * C + c);
+    const float4 qv = *reinterpret_cast<const float4*>(q + n * ldq + c);
     const float4 vv = *reinterpret_cast<const float4*>(v + c);
     const float* p = pe + n * Ts * C + c;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = 0; s < Ts; ++s) {
         const float d = w[s];
-        if (d == 0.f) continue;       // masked positions (alpha = 0); uniform branch
+        if (d == 0.f) continue;       // masked positions (alpha = 0); wave-uniform branch
         const float4 pv = *reinterpret_cast<const float4*>(p + (int64_t)s * C);
         float th;
         th = vag_tanh(pv.x + qv.x); acc.x += d * (1.f - th * th);
@@ -146,13 +176,16 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(const float* __restrict__ 
         th = vag_tanh(pv.w + qv.w); acc.w += d * (1.f - th * th);
     }
     acc.x *= vv.x; acc.y *= vv.y; acc.z *= vv.z; acc.w *= vv.w;
-    *reinterpret_cast<float4*>(dq + n * C + c) = acc;
+    *reinterpret_cast<float4*>(dq + n * lddq + c) = acc;
 }
-int vag_attn_dq_launch(const float* pe, const float* q, const float* v, const float* dscore, int64_t N, int64_t Ts,
-                       int64_t C, float* dq, hipStream_t s) {
-    VAG_CHECK_ARG(pe && q && v && dscore && dq && N > 0 && Ts > 0 && C > 0 && C % 4 == 0);
-    dim3 grid((unsigned)cdiv64(C, 1024), (unsigned)N);
-    hipLaunchKernelGGL(attn_dq_kernel, grid, dim3(256), (size_t)Ts * sizeof(float), s, pe, q, v, dscore, (int)Ts, (int)C, dq);
+int vag_attn_dq_launch(const float* pe, const float* q, int64_t ldq, const float* v, const float* alpha,
+                       const float* dalpha, float* dscore, int64_t N, int64_t Ts, int64_t C, float* dq, int64_t lddq,
+                       hipStream_t s) {
+    VAG_CHECK_ARG(pe && q && v && dscore && dq && N > 0 && Ts > 0 && C > 0 && C % 4 == 0 && ldq % 4 == 0 && lddq % 4 == 0);
+    VAG_CHECK_ARG((alpha == nullptr) == (dalpha == nullptr));
+    dim3 grid((unsigned)cdiv64(C, 256), (unsigned)N);
+    hipLaunchKernelGGL(attn_dq_kernel, grid, dim3(64), (size_t)Ts * sizeof(float), s, pe, q, ldq, v, alpha, dalpha, dscore,
+                       (int)Ts, (int)C, dq, lddq);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
@@ -164,7 +197,7 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restr
                                                             const float* __restrict__ v, const float* __restrict__ ds_all,
                                                             const float* __restrict__ alpha_all,
                                                             const float* __restrict__ dc_all, int B, int Ts, int Tt, int C,
-                                                            float* __restrict__ d_pe, float* __restrict__ dvp,
+                                                            int64_t ldq, float* __restrict__ d_pe, float* __restrict__ dvp,
                                                             float* __restrict__ d_enc, int acc_enc) {
     const int b = blockIdx.y;
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -180,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restr
             ape[i] = 0.f; aen[i] = 0.f;
         }
         for (int t = 0; t < Tt; ++t) {
-            const float qv = q_all[((int64_t)t * B + b) * C + c];
+            const float qv = q_all[((int64_t)t * B + b) * ldq + c];
             const float dcv = dc_all ? dc_all[((int64_t)t * B + b) * C + c] : 0.f;
             const float* dsr = ds_all + ((int64_t)t * B + b) * Ts;
             const float* alr = alpha_all + ((int64_t)t * B + b) * Ts;
@@ -206,13 +239,13 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restr
     }
     if (dvp) dvp[(int64_t)b * C + c] = dv;
 }
-int vag_attn_post_bwd_launch(const float* pe, const float* q_all, const float* v, const float* ds_all,
+int vag_attn_post_bwd_launch(const float* pe, const float* q_all, int64_t ldq, const float* v, const float* ds_all,
                              const float* alpha_all, const float* dc_all, int64_t B, int64_t Ts, int64_t Tt,
                              int64_t C, float* d_pe, float* dvp, float* d_enc, int accumulate_enc, hipStream_t s) {
     VAG_CHECK_ARG(pe && q_all && v && ds_all && alpha_all && d_pe && B > 0 && Ts > 0 && Tt > 0 && C > 0);
     dim3 grid((unsigned)cdiv64(C, 256), (unsigned)B);
     hipLaunchKernelGGL(attn_post_bwd_kernel, grid, dim3(256), 0, s, pe, q_all, v, ds_all, alpha_all, dc_all, (int)B,
-                       (int)Ts, (int)Tt, (int)C, d_pe, dvp, d_enc, accumulate_enc);
+                       (int)Ts, (int)Tt, (int)C, ldq, d_pe, dvp, d_enc, accumulate_enc);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

@@ -102,3 +102,32 @@ struct GruStepArgs {
     int comp_hidden;     // 1: computed projection is the hidden one (W_hh h), 0: the input one (W_ih x)
 };
 int vag_gru_step_launch(const GruStepArgs& a, int nz, hipStream_t stream);
+
+// ---- fused "gradient w.r.t. a hidden state, then the GRU cell backward it feeds" (gemm.hip) ----
+// dh[m,j] = sum_k A[m,k] WT[j,k] + addend[m,j]   (WT = transposed weights, one row per hidden unit)
+// then, if has_cell, the elementwise backward of the GRU cell whose OUTPUT gradient dh is:
+//   dh += dropout(dh_add[m*ld_add + j]);  (dgi, dgh, dh_direct) = cell_bwd(dh, saved gates, hprev)
+// Rows past their length (encoder): dgi = dgh = 0 and dh_direct = dh (state was carried through).
+struct GruBwdStepSide {
+    const float* A;          // (M,K) row stride lda
+    const float* WT;         // (H,K) row stride ldw
+    const float* addend;     // (M,H) contiguous, may be NULL
+    const float* dh_add;     // optional upstream gradient of the cell's output
+    int64_t drop_idx0;       // dropout index of dh_add element (m,j) = m*ld_add + drop_idx0 + j
+    const float* save;       // [4][M][H] gates of the target cell
+    const float* hprev;      // (M,H) row stride ldh: the target cell's previous state
+    float* dgi;              // (M,3H) row stride ldgi
+    float* dgh;              // (M,3H) row stride ldgh
+    float* dh_direct;        // (M,H): z * dh
+    float* dh_out;           // (M,H): written when !has_cell
+    int t;
+};
+struct GruBwdStepArgs {
+    GruBwdStepSide s[2];
+    int64_t lda, ldw, ld_add, ldh, ldgi, ldgh;
+    int M, K, H;
+    const int* lengths;
+    const uint64_t* rng; int sid; float p;
+    int has_cell;
+};
+int vag_gru_bwd_step_launch(const GruBwdStepArgs& a, int nz, hipStream_t stream);

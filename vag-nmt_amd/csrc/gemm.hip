@@ -372,6 +372,56 @@ __global__ __launch_bounds__(WAVES * 64) void gru_step_kernel(GruStepArgs a) {
     }
 }
 
+// dh = A WT^T + addend, then the GRU cell backward (elementwise) that consumes dh -- see common.h.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gru_bwd_step_kernel(GruBwdStepArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4];
+    const GruBwdStepSide& sd = a.s[blockIdx.z];
+    const int m0 = blockIdx.y * 16, nb = blockIdx.x * 16;
+    const int H = a.H;
+    skinny_core<WAVES, 1>(sd.A, a.lda, sd.WT, a.ldw, a.M, H, a.K, m0, nb, 16, red);
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+    const f32x4 S = skinny_reduce<WAVES, 1>(red, 0);
+    const int j = nb + r;
+    if (j >= H) return;
+    const int64_t MH = (int64_t)a.M * H;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 4 * g + i;
+        if (m >= a.M) continue;
+        const int64_t o = (int64_t)m * H + j;
+        float dh = S[i];
+        if (sd.addend) dh += sd.addend[o];
+        if (!a.has_cell) {
+            sd.dh_out[o] = dh;
+            continue;
+        }
+        float* gi = sd.dgi + (int64_t)m * a.ldgi + j;
+        float* gh = sd.dgh + (int64_t)m * a.ldgh + j;
+        const bool active = a.lengths ? (sd.t < a.lengths[m]) : true;
+        if (!active) {
+            gi[0] = 0.f; gi[H] = 0.f; gi[2 * H] = 0.f;
+            gh[0] = 0.f; gh[H] = 0.f; gh[2 * H] = 0.f;
+            sd.dh_direct[o] = dh;
+            continue;
+        }
+        if (sd.dh_add) {
+            float e = sd.dh_add[(int64_t)m * a.ld_add + j];
+            if (a.rng && a.p > 0.f) e *= vag_drop_mul(a.rng, a.sid, (uint64_t)m * a.ld_add + sd.drop_idx0 + j, a.p);
+            dh += e;
+        }
+        const float rr = sd.save[o], zz = sd.save[MH + o], nn = sd.save[2 * MH + o], hn = sd.save[3 * MH + o];
+        const float hp = sd.hprev[(int64_t)m * a.ldh + j];
+        const float dn_pre = dh * (1.f - zz) * (1.f - nn * nn);
+        const float dz_pre = dh * (hp - nn) * zz * (1.f - zz);
+        const float dr_pre = dn_pre * hn * rr * (1.f - rr);
+        gi[0] = dr_pre; gi[H] = dz_pre; gi[2 * H] = dn_pre;
+        gh[0] = dr_pre; gh[H] = dz_pre; gh[2 * H] = dn_pre * rr;
+        sd.dh_direct[o] = dh * zz;
+    }
+}
+
 static bool skinny_ok(const float* A, int64_t lda, const float* W, int64_t ldw, int64_t K) {
     return aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && K % 4 == 0 && K >= 4;
 }
@@ -469,6 +519,21 @@ int vag_transpose_launch(const float* in, int64_t M, int64_t N, float* out, hipS
     VAG_CHECK_ARG(in && out && M > 0 && N > 0);
     dim3 grid((unsigned)cdiv64(N, 32), (unsigned)cdiv64(M, 32));
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, in, (int)M, (int)N, out);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+int vag_gru_bwd_step_launch(const GruBwdStepArgs& a, int nz, hipStream_t stream) {
+    VAG_CHECK_ARG(a.H > 0 && a.M > 0 && a.K > 0 && (nz == 1 || nz == 2));
+    for (int z = 0; z < nz; ++z) {
+        VAG_CHECK_ARG(a.s[z].A && a.s[z].WT && skinny_ok(a.s[z].A, a.lda, a.s[z].WT, a.ldw, a.K));
+        if (a.has_cell) VAG_CHECK_ARG(a.s[z].save && a.s[z].hprev && a.s[z].dgi && a.s[z].dgh && a.s[z].dh_direct);
+        else VAG_CHECK_ARG(a.s[z].dh_out != nullptr);
+    }
+    dim3 grid((unsigned)cdiv64(a.H, 16), (unsigned)cdiv64(a.M, 16), (unsigned)nz);
+    if (a.K <= 256) hipLaunchKernelGGL((gru_bwd_step_kernel<4>), grid, dim3(256), 0, stream, a);
+    else if (a.K <= 1024) hipLaunchKernelGGL((gru_bwd_step_kernel<8>), grid, dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((gru_bwd_step_kernel<16>), grid, dim3(1024), 0, stream, a);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

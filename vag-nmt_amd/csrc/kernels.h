@@ -54,8 +54,9 @@ int vag_copy2d_launch(const float* in, int64_t ldi, float* out, int64_t ldo, int
 // ---------------- attn.hip ----------------
 // mode 0: scores[n,s] = sum_c v[c] tanh(pe[b,s,c] + q[n,c]); mode 1: scores[n,s] = sum_c q[n,c] * pe[b,s,c].
 // b = n / rps.  mask (Bsrc,Ts) float or NULL: masked positions get -inf.
-int vag_attn_scores_launch(int mode, const float* pe, const float* q, const float* v, const float* mask, int64_t N,
-                           int64_t rps, int64_t Ts, int64_t C, float* scores, hipStream_t s);
+// q row stride ldq (>= C).
+int vag_attn_scores_launch(int mode, const float* pe, const float* q, int64_t ldq, const float* v, const float* mask,
+                           int64_t N, int64_t rps, int64_t Ts, int64_t C, float* scores, hipStream_t s);
 // softmax=1: alpha[n,:] = softmax(scores[n,:]) (written to alpha), ctx[n,c] = sum_s alpha[n,s] enc[b,s,c]
 // softmax=0: weights = scores as given (alpha not written)
 int vag_attn_ctx_launch(int softmax, const float* scores, const float* enc, int64_t N, int64_t rps, int64_t Ts,
@@ -63,11 +64,13 @@ int vag_attn_ctx_launch(int softmax, const float* scores, const float* enc, int6
 // dscore[n,s] = alpha[n,s] * (dalpha[n,s] - sum_s' alpha dalpha)
 int vag_softmax_bwd_launch(const float* alpha, const float* dalpha, int64_t N, int64_t Ts, float* dscore, hipStream_t s);
 // dq[n,c] = sum_s dscore[n,s] * v[c] * (1 - tanh^2(pe[n,s,c] + q[n,c]))      (training: rps = 1)
-int vag_attn_dq_launch(const float* pe, const float* q, const float* v, const float* dscore, int64_t N, int64_t Ts,
-                       int64_t C, float* dq, hipStream_t s);
+// alpha/dalpha given: dscore is first computed (softmax backward) and stored; NULL: dscore is an input.
+int vag_attn_dq_launch(const float* pe, const float* q, int64_t ldq, const float* v, const float* alpha,
+                       const float* dalpha, float* dscore, int64_t N, int64_t Ts, int64_t C, float* dq, int64_t lddq,
+                       hipStream_t s);
 // After the time loop: d_pe[b,s,c] = v[c] sum_t ds[t,b,s] (1-th^2);  dvp[b,c] = sum_{t,s} ds*th;
 // d_enc[b,s,c] (+)= sum_t alpha[t,b,s] dc[t,b,c]   (skipped when dc == NULL)
-int vag_attn_post_bwd_launch(const float* pe, const float* q_all, const float* v, const float* ds_all,
+int vag_attn_post_bwd_launch(const float* pe, const float* q_all, int64_t ldq, const float* v, const float* ds_all,
                              const float* alpha_all, const float* dc_all, int64_t B, int64_t Ts, int64_t Tt,
                              int64_t C, float* d_pe, float* dvp, float* d_enc, int accumulate_enc, hipStream_t s);
 // out[b,t,c] (+)= a1[b,t]*x1[b,c] + a2[b,t]*x2[b,c]

@@ -88,8 +88,9 @@ class Seq2SeqBase(nn.Module):
         tok = torch.full((B,), SOS_token, dtype=torch.int64, device=enc.device)
         toks = torch.empty(tgt_l, B, dtype=torch.int64, device=enc.device)
         dp, hp, emb = dec.dec_params(), dec.head_params(), dec.embedding.weight
+        prep = ops.decode_prepare(emb, dp)
         for di in range(tgt_l):
-            h, c, e, _ = ops.decode_step(enc, pe, mask, 1, tok, h, emb, dp)
+            h, c, e, _ = ops.decode_step(enc, pe, mask, 1, tok, h, emb, dp, prep)
             _, tok = ops.head_logp_step(h, c, e, hp, want_argmax=True)
             toks[di] = tok
         return self._cut(toks.t().cpu().numpy())
@@ -103,6 +104,7 @@ class Seq2SeqBase(nn.Module):
         dev = enc.device
         pe = ops.KeysProj.apply(enc, dec.attn.attn_e.weight)
         dp, hp, emb = dec.dec_params(), dec.head_params(), dec.embedding.weight
+        prep = ops.decode_prepare(emb, dp)
         beam = torch.zeros(max_length, B, k, dtype=torch.int64, device=dev)
         nll = torch.zeros(B, k, dtype=torch.float32, device=dev)
         n_alive = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -111,7 +113,7 @@ class Seq2SeqBase(nn.Module):
         tok = torch.full((B,), SOS_token, dtype=torch.int64, device=dev)
         for di in range(max_length):
             rps = 1 if di == 0 else k
-            h, c, e, _ = ops.decode_step(enc, pe, mask, rps, tok, h, emb, dp)
+            h, c, e, _ = ops.decode_step(enc, pe, mask, rps, tok, h, emb, dp, prep)
             logp, _ = ops.head_logp_step(h, c, e, hp)
             call("vag_beam_step", ptr(logp), logp.shape[1], ptr(nll), ptr(beam, torch.int64), di, max_length, ptr(h),
                  ptr(h_next), B, k, V, H, ptr(n_alive, torch.int32), scratch.data_ptr(), stream())

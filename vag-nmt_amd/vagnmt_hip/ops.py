@@ -452,7 +452,15 @@ class DecInit(Function):
 # ----------------------------------------------------------------------------------------------------
 # inference-only helpers (no autograd)
 # ----------------------------------------------------------------------------------------------------
-def decode_step(enc, pe, mask, rows_per_src, tok, h_in, emb, dec):
+def decode_prepare(emb, dec):
+    """Derived decoder weights for the inference step (once per decode call)."""
+    H = dec[1].shape[1]
+    prep = _f32(L.lib().vag_cgru_prep_floats(H), like=emb)
+    call("vag_cgru_prepare", _dec_w(emb, dec), H, ptr(prep), stream())
+    return prep
+
+
+def decode_step(enc, pe, mask, rows_per_src, tok, h_in, emb, dec, prep):
     """One cGRU step for N hypotheses -> (h_out (N,H), c (N,C), e (N,E), alpha (N,Ts))."""
     B, Ts, Cc = enc.shape
     H = Cc // 2
@@ -464,7 +472,7 @@ def decode_step(enc, pe, mask, rows_per_src, tok, h_in, emb, dec):
     alpha = _f32(N, Ts, like=enc)
     scratch = _f32(L.lib().vag_cgru_step_scratch_floats(N, Ts, E, H), like=enc)
     call("vag_cgru_attn_decode_step", ptr(enc), ptr(pe), ptr(mask), rows_per_src, ptr(_c(tok).view(-1), I64), ptr(_c(h_in)),
-         _dec_w(emb, dec), N, Ts, E, H, ptr(h_out), ptr(c), ptr(e), ptr(alpha), ptr(scratch), stream())
+         _dec_w(emb, dec), ptr(prep), N, Ts, E, H, ptr(h_out), ptr(c), ptr(e), ptr(alpha), ptr(scratch), stream())
     return h_out, c, e, alpha
 
 
