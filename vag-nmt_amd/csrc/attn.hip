@@ -88,21 +88,20 @@ __global__ __launch_bounds__(64) void attn_ctx_kernel(int softmax, const float* 
     const int c = (blockIdx.x * 64 + lane) * 4;
     if (c >= C) return;
     const float* e = enc + b * Ts * C + c;
-    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    int s = 0;
-    for (; s + 1 < Ts; s += 2) {
-        const float a0 = w[s], a1 = w[s + 1];
-        const float4 e0 = *reinterpret_cast<const float4*>(e + (int64_t)s * C);
-        const float4 e1 = *reinterpret_cast<const float4*>(e + (int64_t)(s + 1) * C);
-        acc0.x += a0 * e0.x; acc0.y += a0 * e0.y; acc0.z += a0 * e0.z; acc0.w += a0 * e0.w;
-        acc1.x += a1 * e1.x; acc1.y += a1 * e1.y; acc1.z += a1 * e1.z; acc1.w += a1 * e1.w;
+    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = 0; s0 < Ts; s0 += 8) {
+        float4 ev[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int s = min(s0 + i, Ts - 1);
+            ev[i] = *reinterpret_cast<const float4*>(e + (int64_t)s * C);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float a = (s0 + i < Ts) ? w[s0 + i] : 0.f;
+            acc0.x += a * ev[i].x; acc0.y += a * ev[i].y; acc0.z += a * ev[i].z; acc0.w += a * ev[i].w;
+        }
     }
-    if (s < Ts) {
-        const float a0 = w[s];
-        const float4 e0 = *reinterpret_cast<const float4*>(e + (int64_t)s * C);
-        acc0.x += a0 * e0.x; acc0.y += a0 * e0.y; acc0.z += a0 * e0.z; acc0.w += a0 * e0.w;
-    }
-    acc0.x += acc1.x; acc0.y += acc1.y; acc0.z += acc1.z; acc0.w += acc1.w;
     *reinterpret_cast<float4*>(ctx + n * C + c) = acc0;
 }
 
@@ -165,15 +164,23 @@ __global__ __launch_bounds__(64) void attn_dq_kernel(const float* __restrict__ p
     const float4 vv = *reinterpret_cast<const float4*>(v + c);
     const float* p = pe + n * Ts * C + c;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < Ts; ++s) {
-        const float d = w[s];
-        if (d == 0.f) continue;       // masked positions (alpha = 0); wave-uniform branch
-        const float4 pv = *reinterpret_cast<const float4*>(p + (int64_t)s * C);
-        float th;
-        th = vag_tanh(pv.x + qv.x); acc.x += d * (1.f - th * th);
-        th = vag_tanh(pv.y + qv.y); acc.y += d * (1.f - th * th);
-        th = vag_tanh(pv.z + qv.z); acc.z += d * (1.f - th * th);
-        th = vag_tanh(pv.w + qv.w); acc.w += d * (1.f - th * th);
+    // straight-line, 8 key rows in flight per lane: the loop is latency-bound on the pe stream otherwise
+    for (int s0 = 0; s0 < Ts; s0 += 8) {
+        float4 pv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int s = min(s0 + i, Ts - 1);
+            pv[i] = *reinterpret_cast<const float4*>(p + (int64_t)s * C);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float d = (s0 + i < Ts) ? w[s0 + i] : 0.f;     // masked positions carry d = 0
+            float th;
+            th = vag_tanh(pv[i].x + qv.x); acc.x += d * (1.f - th * th);
+            th = vag_tanh(pv[i].y + qv.y); acc.y += d * (1.f - th * th);
+            th = vag_tanh(pv[i].z + qv.z); acc.z += d * (1.f - th * th);
+            th = vag_tanh(pv[i].w + qv.w); acc.w += d * (1.f - th * th);
+        }
     }
     acc.x *= vv.x; acc.y *= vv.y; acc.z *= vv.z; acc.w *= vv.w;
     *reinterpret_cast<float4*>(dq + n * lddq + c) = acc;

@@ -42,11 +42,12 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 // tanh / sigmoid on the v_exp_f32 path; absolute error ~1e-7, saturates cleanly at +-1 / 0,1.
+// v_rcp_f32 is accurate to 1 ulp; one v_exp_f32 + one v_rcp_f32 per activation instead of an IEEE division.
 __device__ __forceinline__ float vag_tanh(float x) {
     float e = __expf(2.0f * x);
-    return 1.0f - 2.0f / (e + 1.0f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
-__device__ __forceinline__ float vag_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float vag_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // Counter-based dropout: keep-mask and multiplier are a pure function of (seed, stream, index),
 // so the backward pass recomputes them instead of storing masks.  splitmix64 finaliser.

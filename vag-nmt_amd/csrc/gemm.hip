@@ -195,6 +195,17 @@ static int gemm_dispatch(const GemmArgs& g, bool akc, bool bkc, bool vec, dim3 g
     return VAG_EINVAL;
 }
 
+__global__ __launch_bounds__(256) void fill2d_kernel(float* __restrict__ C, int64_t ldc, int64_t rows, int64_t cols) {
+    const int64_t total = rows * cols;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols;
+        C[r * ldc + (i - r * cols)] = 0.f;
+    }
+}
+
+// Tile / split-K choice.  One 128x128 block keeps a CU's four MFMA pipes busy for 128*k cycles, so a launch is only
+// efficient with >= 2 blocks per CU in flight (latency hiding across co-resident blocks) and every CU busy: small-output,
+// deep-K products (every weight gradient: K = Tt*B) are split along K and accumulated with fp32 atomics.
 int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
                     const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc,
                     const float* bias, int act, hipStream_t stream) {
@@ -212,25 +223,40 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     g.alpha = alpha; g.beta = beta; g.act = act;
     const int64_t lda = akc ? sam : sak, ldb = bkc ? sbn : sbk;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
-    const int64_t b128 = cdiv64(M, 128) * cdiv64(N, 128);
-    int splitk = 1;
-    if (b128 >= 192) {
-        g.splitk = 1; g.kchunk = (int)K;
-        dim3 grid((unsigned)cdiv64(N, 128), (unsigned)cdiv64(M, 128), 1);
-        return gemm_dispatch<128, 128>(g, akc, bkc, vec, grid, stream);
+    // cost model (microseconds) over tile in {64,128} x split-K: MFMA time of the busiest CU + output traffic
+    // (fp32 atomics run at ~1 TB/s chip-wide, plain stores at ~4 TB/s) -- constants fitted to measured launches.
+    const bool can_split = (act == VAG_ACT_NONE) && (beta == 0.f || beta == 1.f);
+    double best = 1e30;
+    int64_t T = 64, splitk = 1;
+    for (int64_t t = 64; t <= 128; t *= 2) {
+        if (t == 128 && (M <= 64 || N <= 64)) continue;
+        const double eff = (t == 128) ? 0.62 : 0.42;
+        const int64_t base = cdiv64(M, t) * cdiv64(N, t);
+        for (int64_t sp = 1; sp <= 16; ++sp) {
+            if (sp > 1 && (!can_split || K / sp < 128)) break;
+            const int64_t kper = cdiv64(cdiv64(K, sp), BK) * BK;
+            const int64_t blocks = base * sp;
+            const double rounds = (double)cdiv64(blocks, 256);
+            const double t_mfma = rounds * (double)kper * (double)(t * t) * 2.0 / (256.0 * eff) / 2400.0;
+            const double bytes = (double)M * (double)N * 4.0;
+            const double t_out = sp > 1 ? sp * bytes / 1.0e6 + (beta == 0.f ? bytes / 4.0e6 + 2.0 : 0.0)
+                                        : bytes * (beta != 0.f ? 2.0 : 1.0) / 4.0e6;
+            const double cost = t_mfma + t_out;
+            if (cost < best) { best = cost; T = t; splitk = sp; }
+        }
     }
-    const int64_t b64 = cdiv64(M, 64) * cdiv64(N, 64);
-    if (beta == 1.0f && act == VAG_ACT_NONE && b64 < 256 && K >= 256) {
-        // accumulate-into-C products (weight gradients): split K so the launch fills the chip
-        int64_t want = cdiv64(512, b64);
-        int64_t maxs = K / 128;
-        splitk = (int)(want < maxs ? want : maxs);
-        if (splitk < 1) splitk = 1;
-    }
+    const bool big = (T == 128);
     int kchunk = (int)(cdiv64(cdiv64(K, splitk), BK) * BK);
-    splitk = (int)cdiv64(K, kchunk);
-    g.splitk = splitk; g.kchunk = kchunk;
-    dim3 grid((unsigned)cdiv64(N, 64), (unsigned)cdiv64(M, 64), (unsigned)splitk);
+    splitk = cdiv64(K, kchunk);
+    g.splitk = (int)splitk; g.kchunk = kchunk;
+    if (splitk > 1 && beta == 0.f) {
+        int64_t nb = cdiv64(M * N, 256 * 8);
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(fill2d_kernel, dim3((unsigned)nb), dim3(256), 0, stream, C, ldc, M, N);
+        VAG_LAUNCH_CHECK();
+    }
+    dim3 grid((unsigned)cdiv64(N, T), (unsigned)cdiv64(M, T), (unsigned)splitk);
+    if (big) return gemm_dispatch<128, 128>(g, akc, bkc, vec, grid, stream);
     return gemm_dispatch<64, 64>(g, akc, bkc, vec, grid, stream);
 }
 
