@@ -10,6 +10,8 @@
 //                        v_mfma_f32_16x16x4_f32, LDS only for the cross-wave reduction.  Epilogues: plain
 //                        (bias/addend/tanh) and the fused GRU cell.
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 int vag_copy2d_launch(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t rows, int64_t cols, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
@@ -262,6 +264,10 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
 
 // ------------------------------------------------------------------------------------------------
 // skinny GEMM  out[m,n] = sum_k A[m,k] W[n,k]   (both k-contiguous), fused epilogues
+//
+// These launches are bound by bytes fetched per CU (each CU pulls ~33 GB/s out of the Infinity Cache; L2 is dropped
+// at every kernel boundary), so the workgroup tile is chosen to (a) put one workgroup on every one of the 256 CUs
+// and (b) minimise (A rows + W rows) * K per workgroup: see pick_plain_tile().
 // ------------------------------------------------------------------------------------------------
 struct SkinnyArgs {
     const float* A; const float* W; int64_t lda, ldw;
@@ -269,39 +275,36 @@ struct SkinnyArgs {
     const float* bias; const float* addend; int64_t ldadd; float* out; int64_t ldo; int act;
 };
 
-// One 16-row m-tile x NT 16-col n-tiles per workgroup; K split over the WAVES waves; partial sums of all
-// waves end up in red[wave][j][lane][4] (C/D map of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4)+i).
-template <int WAVES, int NT>
-__device__ __forceinline__ void skinny_core(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
-                                            int64_t ldw, int M, int N, int K, int m0, int nb, int jstep,
-                                            float* red) {
+// MT 16-row m-tiles x NT 16-col n-tiles per workgroup; K split over the WAVES waves.  ap/wp are this lane's row
+// pointers (row = lane&15 of each tile, already offset by 4*(lane>>4) floats).  Partial sums of all waves end up in
+// red[wave][tile][lane][4] (C/D map of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4)+i).
+template <int WAVES, int MT, int NT>
+__device__ __forceinline__ void skinny_mma(const float* const (&ap)[MT], const float* const (&wp)[NT], int K, float* red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, g = lane >> 4;
+    const int g = lane >> 4;
     const int kper = ((K + WAVES - 1) / WAVES + 15) & ~15;
     const int kbeg = wave * kper;
     const int kend = min(K, kbeg + kper);
-    const int arow = min(m0 + r, M - 1);
-    const float* ap = A + (int64_t)arow * lda + 4 * g;
-    const float* wp[NT];
+    f32x4 acc[MT][NT][2];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int wrow = min(nb + j * jstep + r, N - 1);
-        wp[j] = W + (int64_t)wrow * ldw + 4 * g;
-    }
-    f32x4 acc[NT][2];
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+        for (int j = 0; j < NT; ++j) {
+            acc[i][j][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[i][j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    // 4 chunks (64 of K) in flight per wave; deeper request queues measured no faster (tools/skinny_probe.hip:
+    // the memory pipeline's request rate, not round trips, paces these kernels).
     constexpr int U = 4;
     for (int c0 = kbeg; c0 < kend; c0 += 16 * U) {
-        float4 av[U], wv[NT][U];
+        float4 av[MT][U], wv[NT][U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = c0 + 16 * u + 4 * g;
             const bool ok = k < kend;
-            av[u] = ok ? *reinterpret_cast<const float4*>(ap + c0 + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                av[i][u] = ok ? *reinterpret_cast<const float4*>(ap[i] + c0 + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 wv[j][u] = ok ? *reinterpret_cast<const float4*>(wp[j] + c0 + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -309,45 +312,66 @@ __device__ __forceinline__ void skinny_core(const float* __restrict__ A, int64_t
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                // lane group g supplies k = 4g+i to MFMA i; A and W use the same k order, so the sum is exact.
-                acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, wv[j][u].x, acc[j][0], 0, 0, 0);
-                acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, wv[j][u].y, acc[j][1], 0, 0, 0);
-                acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, wv[j][u].z, acc[j][0], 0, 0, 0);
-                acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, wv[j][u].w, acc[j][1], 0, 0, 0);
-            }
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    // lane group g supplies k = 4g+e to MFMA e; A and W use the same k order, so the sum is exact.
+                    acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][u].x, wv[j][u].x, acc[i][j][0], 0, 0, 0);
+                    acc[i][j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][u].y, wv[j][u].y, acc[i][j][1], 0, 0, 0);
+                    acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][u].z, wv[j][u].z, acc[i][j][0], 0, 0, 0);
+                    acc[i][j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][u].w, wv[j][u].w, acc[i][j][1], 0, 0, 0);
+                }
     }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        f32x4 s = acc[j][0] + acc[j][1];
-        *reinterpret_cast<f32x4*>(&red[((wave * NT + j) * 64 + lane) * 4]) = s;
-    }
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            f32x4 s = acc[i][j][0] + acc[i][j][1];
+            *reinterpret_cast<f32x4*>(&red[((wave * (MT * NT) + i * NT + j) * 64 + lane) * 4]) = s;
+        }
     __syncthreads();
 }
 
-template <int WAVES, int NT>
-__device__ __forceinline__ f32x4 skinny_reduce(const float* red, int j) {
-    const int lane = threadIdx.x & 63;
+// sum over the waves of tile `tile`, for this lane's 4 accumulator rows
+template <int WAVES, int TILES>
+__device__ __forceinline__ f32x4 skinny_sum(const float* red, int tile, int lane) {
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) s += *reinterpret_cast<const f32x4*>(&red[((w * NT + j) * 64 + lane) * 4]);
+    for (int w = 0; w < WAVES; ++w) s += *reinterpret_cast<const f32x4*>(&red[((w * TILES + tile) * 64 + lane) * 4]);
+    return s;
+}
+// sum over the waves of ONE element (row mrow in [0,16), col in [0,16)) of tile `tile`
+template <int WAVES, int TILES>
+__device__ __forceinline__ float skinny_sum1(const float* red, int tile, int mrow, int col) {
+    const int lane = (mrow >> 2) * 16 + col, i = mrow & 3;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) s += red[((w * TILES + tile) * 64 + lane) * 4 + i];
     return s;
 }
 
-template <int WAVES>
+// COLS = 16: one full n-tile per workgroup; COLS = 8: half a tile (lanes with col >= 8 duplicate rows and are idle
+// in the epilogue) -- twice the workgroups for small N, so that all 256 CUs pull weights.
+template <int WAVES, int MT, int COLS>
 __global__ __launch_bounds__(WAVES * 64) void skinny_plain_kernel(SkinnyArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4];
-    const int m0 = blockIdx.y * 16, nb = blockIdx.x * 16;
-    skinny_core<WAVES, 1>(a.A, a.lda, a.W, a.ldw, a.M, a.N, a.K, m0, nb, 16, red);
-    if (threadIdx.x >= 64) return;
-    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
-    const f32x4 s = skinny_reduce<WAVES, 1>(red, 0);
+    __shared__ __attribute__((aligned(16))) float red[WAVES * MT * 64 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * 16 * MT, nb = blockIdx.x * COLS;
+    const float* ap[MT];
+    const float* wp[1];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) ap[i] = a.A + (int64_t)min(m0 + 16 * i + r, a.M - 1) * a.lda + 4 * g;
+    wp[0] = a.W + (int64_t)min(nb + (COLS == 16 ? r : (r & 7)), a.N - 1) * a.ldw + 4 * g;
+    skinny_mma<WAVES, MT, 1>(ap, wp, a.K, red);
+    if (wave >= MT) return;
+    const f32x4 s = skinny_sum<WAVES, MT>(red, wave, lane);
     const int col = nb + r;
-    if (col >= a.N) return;
+    if (r >= COLS || col >= a.N) return;
     const float bv = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + 4 * g + i;
+        const int m = m0 + 16 * wave + 4 * g + i;
         if (m >= a.M) continue;
         float v = s[i] + bv;
         if (a.addend) v += a.addend[(int64_t)m * a.ldadd + col];
@@ -356,61 +380,96 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_plain_kernel(SkinnyArgs a) 
     }
 }
 
-// Fused GRU cell: one projection (3 gate tiles of 16 hidden units) is computed here, the other is read.
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void gru_step_kernel(GruStepArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[WAVES * 3 * 64 * 4];
-    const GruSide& sd = a.s[blockIdx.z];
-    const int m0 = blockIdx.y * 16, nb = blockIdx.x * 16;
+// GRU gate math shared by both GRU step kernels.
+__device__ __forceinline__ void gru_cell_epilogue(const GruStepArgs& a, const GruSide& sd, int m, int col, float c_r, float c_z,
+                                                  float c_n) {
     const int H = a.H;
-    skinny_core<WAVES, 3>(sd.A, a.lda, sd.W, a.ldw, a.M, 3 * H, a.K, m0, nb, H, red);
-    if (threadIdx.x >= 64) return;
-    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
-    const f32x4 S0 = skinny_reduce<WAVES, 3>(red, 0);
-    const f32x4 S1 = skinny_reduce<WAVES, 3>(red, 1);
-    const f32x4 S2 = skinny_reduce<WAVES, 3>(red, 2);
-    const int col = nb + r;
-    if (col >= H) return;
-    const float b_r = sd.bias ? sd.bias[col] : 0.f, b_z = sd.bias ? sd.bias[H + col] : 0.f,
-                b_n = sd.bias ? sd.bias[2 * H + col] : 0.f;
+    if (sd.bias) { c_r += sd.bias[col]; c_z += sd.bias[H + col]; c_n += sd.bias[2 * H + col]; }
+    const float* op = sd.other + (int64_t)m * a.ldother + col;
+    const float o_r = op[0], o_z = op[H], o_n = op[2 * H];
+    const float gi_n = a.comp_hidden ? o_n : c_n;
+    const float gh_n = a.comp_hidden ? c_n : o_n;
+    const float rr = vag_sigmoid(c_r + o_r);
+    const float zz = vag_sigmoid(c_z + o_z);
+    const float nn = vag_tanh(gi_n + rr * gh_n);
+    const float hp = sd.hprev[(int64_t)m * a.ldh + col];
+    const float hn = (1.f - zz) * nn + zz * hp;
+    const bool active = a.lengths ? (sd.t < a.lengths[m]) : true;
+    if (sd.save) {
+        const int64_t MH = (int64_t)a.M * H;
+        const int64_t o = (int64_t)m * H + col;
+        sd.save[o] = rr; sd.save[MH + o] = zz; sd.save[2 * MH + o] = nn; sd.save[3 * MH + o] = gh_n;
+    }
+    sd.hout[(int64_t)m * H + col] = active ? hn : hp;
+    if (sd.out2) sd.out2[(int64_t)m * a.ld2 + col] = active ? hn : 0.f;
+}
+
+// Fused GRU cell, UNITS hidden units per workgroup.  UNITS = 16: three n-tiles (r, z, n).  UNITS = 8: two n-tiles laid
+// out [r0..7 | z0..7] and [n0..7 | n0..7]; the gates of one unit then sit in different lanes and are gathered through
+// the LDS reduction buffer.
+template <int WAVES, int UNITS>
+__global__ __launch_bounds__(WAVES * 64) void gru_step_kernel(GruStepArgs a) {
+    constexpr int NT = UNITS == 16 ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) float red[WAVES * NT * 64 * 4];
+    const GruSide& sd = a.s[blockIdx.z];
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * 16, u0 = blockIdx.x * UNITS;
+    const int H = a.H;
+    const float* ap[1];
+    const float* wp[NT];
+    ap[0] = sd.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + 4 * g;
+    if (UNITS == 16) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + 4 * g + i;
-        if (m >= a.M) continue;
-        const float c_r = S0[i] + b_r, c_z = S1[i] + b_z, c_n = S2[i] + b_n;
-        const float* op = sd.other + (int64_t)m * a.ldother + col;
-        const float o_r = op[0], o_z = op[H], o_n = op[2 * H];
-        const float gi_n = a.comp_hidden ? o_n : c_n;
-        const float gh_n = a.comp_hidden ? c_n : o_n;
-        const float rr = vag_sigmoid(c_r + o_r);
-        const float zz = vag_sigmoid(c_z + o_z);
-        const float nn = vag_tanh(gi_n + rr * gh_n);
-        const float hp = sd.hprev[(int64_t)m * a.ldh + col];
-        const float hn = (1.f - zz) * nn + zz * hp;
-        const bool active = a.lengths ? (sd.t < a.lengths[m]) : true;
-        if (sd.save) {
-            const int64_t MH = (int64_t)a.M * H;
-            const int64_t o = (int64_t)m * H + col;
-            sd.save[o] = rr; sd.save[MH + o] = zz; sd.save[2 * MH + o] = nn; sd.save[3 * MH + o] = gh_n;
+        for (int j = 0; j < NT; ++j) wp[j] = sd.W + (int64_t)min(j * H + u0 + r, 3 * H - 1) * a.ldw + 4 * g;
+    } else {
+        const int u = min(u0 + (r & 7), H - 1);
+        wp[0] = sd.W + (int64_t)((r < 8 ? 0 : H) + u) * a.ldw + 4 * g;
+        wp[NT - 1] = sd.W + (int64_t)(2 * H + u) * a.ldw + 4 * g;
+    }
+    skinny_mma<WAVES, 1, NT>(ap, wp, a.K, red);
+    if (UNITS == 16) {
+        if (threadIdx.x >= 64) return;
+        const f32x4 S0 = skinny_sum<WAVES, NT>(red, 0, lane);
+        const f32x4 S1 = skinny_sum<WAVES, NT>(red, 1, lane);
+        const f32x4 S2 = skinny_sum<WAVES, NT>(red, NT - 1, lane);
+        const int col = u0 + r;
+        if (col >= H) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + 4 * g + i;
+            if (m < a.M) gru_cell_epilogue(a, sd, m, col, S0[i], S1[i], S2[i]);
         }
-        sd.hout[(int64_t)m * H + col] = active ? hn : hp;
-        if (sd.out2) sd.out2[(int64_t)m * a.ld2 + col] = active ? hn : 0.f;
+    } else {
+        if (threadIdx.x >= 128) return;
+        const int mrow = threadIdx.x >> 3, u = threadIdx.x & 7;       // 16 rows x 8 units
+        const int m = m0 + mrow, col = u0 + u;
+        if (m >= a.M || col >= H) return;
+        const float c_r = skinny_sum1<WAVES, NT>(red, 0, mrow, u);
+        const float c_z = skinny_sum1<WAVES, NT>(red, 0, mrow, 8 + u);
+        const float c_n = skinny_sum1<WAVES, NT>(red, NT - 1, mrow, u);
+        gru_cell_epilogue(a, sd, m, col, c_r, c_z, c_n);
     }
 }
 
 // dh = A WT^T + addend, then the GRU cell backward (elementwise) that consumes dh -- see common.h.
-template <int WAVES>
+template <int WAVES, int COLS>
 __global__ __launch_bounds__(WAVES * 64) void gru_bwd_step_kernel(GruBwdStepArgs a) {
     __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4];
     const GruBwdStepSide& sd = a.s[blockIdx.z];
-    const int m0 = blockIdx.y * 16, nb = blockIdx.x * 16;
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * 16, nb = blockIdx.x * COLS;
     const int H = a.H;
-    skinny_core<WAVES, 1>(sd.A, a.lda, sd.WT, a.ldw, a.M, H, a.K, m0, nb, 16, red);
+    const float* ap[1];
+    const float* wp[1];
+    ap[0] = sd.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + 4 * g;
+    wp[0] = sd.WT + (int64_t)min(nb + (COLS == 16 ? r : (r & 7)), H - 1) * a.ldw + 4 * g;
+    skinny_mma<WAVES, 1, 1>(ap, wp, a.K, red);
     if (threadIdx.x >= 64) return;
-    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
-    const f32x4 S = skinny_reduce<WAVES, 1>(red, 0);
+    const f32x4 S = skinny_sum<WAVES, 1>(red, 0, lane);
     const int j = nb + r;
-    if (j >= H) return;
+    if (r >= COLS || j >= H) return;
     const int64_t MH = (int64_t)a.M * H;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -452,6 +511,14 @@ static bool skinny_ok(const float* A, int64_t lda, const float* W, int64_t ldw, 
     return aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && K % 4 == 0 && K >= 4;
 }
 
+template <int MT, int COLS>
+static void skinny_plain_go(const SkinnyArgs& a, hipStream_t stream) {
+    dim3 grid((unsigned)cdiv64(a.N, COLS), (unsigned)cdiv64(a.M, 16 * MT), 1);
+    if (a.K <= 256) hipLaunchKernelGGL((skinny_plain_kernel<4, MT, COLS>), grid, dim3(256), 0, stream, a);
+    else if (a.K <= 1024) hipLaunchKernelGGL((skinny_plain_kernel<8, MT, COLS>), grid, dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((skinny_plain_kernel<16, MT, COLS>), grid, dim3(1024), 0, stream, a);
+}
+
 int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
                       const float* bias, const float* addend, int64_t ldadd, float* out, int64_t ldo, int act,
                       hipStream_t stream) {
@@ -460,9 +527,7 @@ int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
     if (!skinny_ok(A, lda, W, ldw, K) || M > 128) {
         // generic path through the tiled kernel; an addend is folded in with beta = 1
         if (addend) {
-            if (addend != out) {
-                VAG_TRY(vag_copy2d_launch(addend, ldadd, out, ldo, M, N, stream));
-            }
+            if (addend != out) VAG_TRY(vag_copy2d_launch(addend, ldadd, out, ldo, M, N, stream));
             return vag_gemm_launch(M, N, K, 1.f, A, lda, 1, W, 1, ldw, 1.f, out, ldo, bias, act, stream);
         }
         return vag_gemm_launch(M, N, K, 1.f, A, lda, 1, W, 1, ldw, 0.f, out, ldo, bias, act, stream);
@@ -470,10 +535,10 @@ int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
     SkinnyArgs a;
     a.A = A; a.W = W; a.lda = lda; a.ldw = ldw; a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.bias = bias; a.addend = addend; a.ldadd = ldadd; a.out = out; a.ldo = ldo; a.act = act;
-    dim3 grid((unsigned)cdiv64(N, 16), (unsigned)cdiv64(M, 16), 1);
-    if (K <= 256) hipLaunchKernelGGL((skinny_plain_kernel<4>), grid, dim3(256), 0, stream, a);
-    else if (K <= 1024) hipLaunchKernelGGL((skinny_plain_kernel<8>), grid, dim3(512), 0, stream, a);
-    else hipLaunchKernelGGL((skinny_plain_kernel<16>), grid, dim3(1024), 0, stream, a);
+    // Tile choice, from measurements (tools/exp_tiles.py, tools/skinny_probe.hip): these launches are bound by the bytes
+    // REQUESTED chip-wide (L2 is dropped at every kernel boundary; ~6.3 TB/s aggregate, ~50 GB/s per CU), duplicates
+    // included, so wider/taller tiles or half tiles do not pay at M <= 128; 16x16 with K split over the waves it is.
+    skinny_plain_go<1, 16>(a, stream);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
@@ -484,9 +549,39 @@ int vag_gru_step_launch(const GruStepArgs& a, int nz, hipStream_t stream) {
         VAG_CHECK_ARG(a.s[z].A && a.s[z].W && a.s[z].other && a.s[z].hprev && a.s[z].hout);
         VAG_CHECK_ARG(skinny_ok(a.s[z].A, a.lda, a.s[z].W, a.ldw, a.K));
     }
-    dim3 grid((unsigned)cdiv64(a.H, 16), (unsigned)cdiv64(a.M, 16), (unsigned)nz);
-    if (a.K <= 256) hipLaunchKernelGGL((gru_step_kernel<4>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((gru_step_kernel<8>), grid, dim3(512), 0, stream, a);
+    // 8 hidden units per workgroup (twice the workgroups) was measured to be no faster: requested bytes, not CU count,
+    // bound these launches.  Kept selectable for experiments.
+    const bool units8 = getenv("VAG_GRU_UNITS8") != nullptr && a.H % 8 == 0;
+    if (units8) {
+        dim3 grid((unsigned)cdiv64(a.H, 8), (unsigned)cdiv64(a.M, 16), (unsigned)nz);
+        if (a.K <= 256) hipLaunchKernelGGL((gru_step_kernel<4, 8>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((gru_step_kernel<8, 8>), grid, dim3(512), 0, stream, a);
+    } else {
+        dim3 grid((unsigned)cdiv64(a.H, 16), (unsigned)cdiv64(a.M, 16), (unsigned)nz);
+        if (a.K <= 256) hipLaunchKernelGGL((gru_step_kernel<4, 16>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((gru_step_kernel<8, 16>), grid, dim3(512), 0, stream, a);
+    }
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+template <int COLS>
+static void gru_bwd_step_go(const GruBwdStepArgs& a, int nz, hipStream_t stream) {
+    dim3 grid((unsigned)cdiv64(a.H, COLS), (unsigned)cdiv64(a.M, 16), (unsigned)nz);
+    if (a.K <= 256) hipLaunchKernelGGL((gru_bwd_step_kernel<4, COLS>), grid, dim3(256), 0, stream, a);
+    else if (a.K <= 1024) hipLaunchKernelGGL((gru_bwd_step_kernel<8, COLS>), grid, dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((gru_bwd_step_kernel<16, COLS>), grid, dim3(1024), 0, stream, a);
+}
+
+int vag_gru_bwd_step_launch(const GruBwdStepArgs& a, int nz, hipStream_t stream) {
+    VAG_CHECK_ARG(a.H > 0 && a.M > 0 && a.K > 0 && (nz == 1 || nz == 2));
+    for (int z = 0; z < nz; ++z) {
+        VAG_CHECK_ARG(a.s[z].A && a.s[z].WT && skinny_ok(a.s[z].A, a.lda, a.s[z].WT, a.ldw, a.K));
+        if (a.has_cell) VAG_CHECK_ARG(a.s[z].save && a.s[z].hprev && a.s[z].dgi && a.s[z].dgh && a.s[z].dh_direct);
+        else VAG_CHECK_ARG(a.s[z].dh_out != nullptr);
+    }
+    if (getenv("VAG_GRU_COLS8") != nullptr) gru_bwd_step_go<8>(a, nz, stream);
+    else gru_bwd_step_go<16>(a, nz, stream);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
@@ -549,17 +644,3 @@ int vag_transpose_launch(const float* in, int64_t M, int64_t N, float* out, hipS
     return VAG_OK;
 }
 
-int vag_gru_bwd_step_launch(const GruBwdStepArgs& a, int nz, hipStream_t stream) {
-    VAG_CHECK_ARG(a.H > 0 && a.M > 0 && a.K > 0 && (nz == 1 || nz == 2));
-    for (int z = 0; z < nz; ++z) {
-        VAG_CHECK_ARG(a.s[z].A && a.s[z].WT && skinny_ok(a.s[z].A, a.lda, a.s[z].WT, a.ldw, a.K));
-        if (a.has_cell) VAG_CHECK_ARG(a.s[z].save && a.s[z].hprev && a.s[z].dgi && a.s[z].dgh && a.s[z].dh_direct);
-        else VAG_CHECK_ARG(a.s[z].dh_out != nullptr);
-    }
-    dim3 grid((unsigned)cdiv64(a.H, 16), (unsigned)cdiv64(a.M, 16), (unsigned)nz);
-    if (a.K <= 256) hipLaunchKernelGGL((gru_bwd_step_kernel<4>), grid, dim3(256), 0, stream, a);
-    else if (a.K <= 1024) hipLaunchKernelGGL((gru_bwd_step_kernel<8>), grid, dim3(512), 0, stream, a);
-    else hipLaunchKernelGGL((gru_bwd_step_kernel<16>), grid, dim3(1024), 0, stream, a);
-    VAG_LAUNCH_CHECK();
-    return VAG_OK;
-}
