@@ -91,41 +91,73 @@ def cpu_baseline(c, steps=2):
                 s_per_step=dt)
 
 
-def measure_families(c, dev, reps=5):
-    """Live HIP-event timing of the recurrent operators on the current stream: average duration of one
-    decoder-sequence forward launch (Tt GRU+attention steps) and one encoder forward launch."""
+def _time_graph(fn, reps=20):
+    """Average device time of `fn` replayed from a HIP graph, with HIP events on the replay stream (the stream the
+    kernels run on; a graph removes the host launch cost that would otherwise dominate these small kernels)."""
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    g.replay()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        g.replay()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e-3
+
+
+def measure_operators(c, dev):
+    """Live timings for the roofline block:
+      decoder_seq_fwd : one vag_cgru_attn_decode_seq_fwd launch = Tt GRU+attention steps (5 kernels each)
+      encoder_fwd     : one vag_bigru_seq_fwd launch = Ts steps, both directions per kernel
+      gru_cell        : the dominant single kernel (gru_step_kernel, decoder gru_1 shape), 100 launches per graph"""
     from vagnmt_hip import ops, _lib
-    from vagnmt_hip._lib import ptr
+    from vagnmt_hip._lib import ptr, call, stream
     m = build_model(c, dev).eval()
     src, lens, tgt, im = make_batch(c, 0, dev)
+    lens_t = torch.tensor(lens, dtype=torch.int32, device=dev)
     out = {}
+    B, H = c["B"], c["H"]
     with torch.no_grad():
-        enc, mask = m._encode(src, lens, None)
+        enc, mask = m._encode(src, lens_t, None)
         _, ctx = m.vse_imagine.forward_bm(im, enc, mask, None)
         h0 = ops.DecInit.apply(enc, mask, ctx, m.decoderini.weight, m.decoderini.bias, 0.5)
         pe = ops.KeysProj.apply(enc, m.decoder.attn.attn_e.weight)
-        sos = torch.full((1, c["B"]), 2, dtype=torch.int64, device=dev)
+        sos = torch.full((1, B), 2, dtype=torch.int64, device=dev)
         tok = torch.cat([sos, tgt.t()], 0).contiguous()
         dec = m.decoder
+        out["decoder_seq_fwd"] = _time_graph(
+            lambda: ops.cgru_decode_seq(enc, pe, mask, h0, tok, dec.embedding.weight, dec.dec_params(), V=c["V"]))
+        out["encoder_fwd"] = _time_graph(lambda: m._encode(src, lens_t, None))
+        gi = torch.randn(B, 3 * H, device=dev)
+        hp = torch.randn(B, H, device=dev)
+        ho = torch.empty(B, H, device=dev)
+        sv = torch.empty(4, B, H, device=dev)
+        g1 = dec.gru_1
 
-        def run_dec():
-            ops.cgru_decode_seq(enc, pe, mask, h0, tok, dec.embedding.weight, dec.dec_params(), V=c["V"])
-
-        def run_enc():
-            m._encode(src, lens, None)
-
-        for name, fn in (("decoder_seq_fwd", run_dec), ("encoder_fwd", run_enc)):
-            fn()
-            torch.cuda.synchronize()
-            s = torch.cuda.Event(enable_timing=True)
-            e = torch.cuda.Event(enable_timing=True)
-            s.record()
-            for _ in range(reps):
-                fn()
-            e.record()
-            torch.cuda.synchronize()
-            out[name] = s.elapsed_time(e) / reps * 1e-3       # seconds per launch of the operator
+        def cells():
+            for _ in range(100):
+                call("vag_gru_cell_fwd", ptr(gi), ptr(hp), ptr(g1.weight_hh_l0), ptr(g1.bias_hh_l0), B, H, ptr(ho), ptr(sv),
+                     stream())
+        out["gru_cell"] = _time_graph(cells) / 100
     return out
+
+
+def pmc_traffic():
+    """HBM traffic per launch of the dominant kernel from rocprofv3 PMC passes (profiles/r01_pmc.json, produced by
+    tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs, FETCH doubled as MI355X_MICROARCH.md prescribes)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    if os.path.exists(path):
+        try:
+            return json.load(open(path))
+        except Exception:
+            return None
+    return None
 
 
 def main():
@@ -201,10 +233,13 @@ def main():
     log("timed region done: %.3f ms/step" % (dt / args.steps * 1e3))
     if rank == 0:
         ab = algorithmic_bytes(c)
-        fam = measure_families(c, dev)
+        fam = measure_operators(c, dev)
         log("operator timings: %s" % fam)
+        B, H = c["B"], c["H"]
         t_dec_step = fam["decoder_seq_fwd"] / c["Tt"]
         achieved = ab["F_dec"] / t_dec_step
+        cell_bytes = 4 * (3 * H * H + 3 * H + 9 * B * H)   # W_hh, b_hh, h_prev, gi (3), h_out, 4 saved gate planes
+        pmc = pmc_traffic() or {}
         res = {
             "metric": "training sentence-pairs/sec (Multi30K en->de, B=64)",
             "value": c["B"] * world * args.steps / dt,
@@ -223,11 +258,20 @@ def main():
                                    % (args.tfr, ", ragged source lengths" if args.ragged else ""),
                        "global_batch": c["B"] * world, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph, "final_loss": loss},
-            "roofline": {"bound": "hbm", "kernel": "cgru_attn_decode_seq_fwd (per GRU+attention time step)",
-                         "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None,
-                         "algorithmic_bytes_per_step": ab["F_dec"], "us_per_decoder_step": t_dec_step * 1e6,
-                         "us_per_encoder_step": fam["encoder_fwd"] / c["Ts"] * 1e6},
+            # dominant kernel by total time (profiles/): the fused GRU-cell step kernel, decoder gru_1 shape
+            "roofline": {"bound": "hbm", "kernel": "gru_step_kernel<8,16> (M=64, H=512, K=512)",
+                         "achieved": cell_bytes / fam["gru_cell"] / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": cell_bytes / fam["gru_cell"] / HBM_PEAK,
+                         "traffic": pmc.get("gru_step_kernel_bytes_per_launch"),
+                         "algorithmic_bytes_per_launch": cell_bytes, "us_per_launch": fam["gru_cell"] * 1e6},
+            # the BASELINE.json target quantity: one GRU+attention decoder step against the HBM streaming model
+            "roofline_decoder_step": {"bound": "hbm", "kernel": "vag_cgru_attn_decode_seq_fwd / Tt (5 kernels per step)",
+                                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                      "frac": achieved / HBM_PEAK,
+                                      "traffic": pmc.get("decoder_step_bytes"),
+                                      "algorithmic_bytes_per_step": ab["F_dec"],
+                                      "us_per_decoder_step": t_dec_step * 1e6,
+                                      "us_per_encoder_step": fam["encoder_fwd"] / c["Ts"] * 1e6},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(c)

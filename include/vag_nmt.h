@@ -91,6 +91,12 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fwd,
                       float p_ctx, const uint64_t* rng, int64_t B, int64_t Ts, int64_t E, int64_t H, float* d_enc,
                       float* ws, float* g_emb, vag_gru_g g_fwd, vag_gru_g g_bwd, vag_stream_t stream);
 
+/* ---- one GRU cell step (torch nn.GRU on a length-1 sequence, layers/NMT_Decoder.py:121) ------------------ */
+/* gi (M,3H) = W_ih x + b_ih (already projected); computes W_hh h_prev + b_hh, the gates and the blend in one
+ * launch (the kernel every recurrent step of the encoder and decoder runs).  save: NULL or [4][M][H] (r,z,n,hn). */
+int vag_gru_cell_fwd(const float* gi, const float* h_prev, const float* w_hh, const float* b_hh, int64_t M,
+                     int64_t H, float* h_out, float* save, vag_stream_t stream);
+
 /* ---- a4 (hoisted part): attention keys pe = enc W_e^T, layers/NMT_Decoder.py:47 ----------------------- */
 /* The reference recomputes attn_e(encoder_outputs) at every decoder step; it does not depend on the step,
  * so it is computed once per batch.  rows = B*Ts. */

@@ -1,0 +1,35 @@
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_decoder_fwd.py into profiles/r01_pmc.json.
+FETCH_SIZE / WRITE_SIZE are in KiB... per dispatch; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced
+reads (MI355X_MICROARCH.md, HBM section) and is doubled here; WRITE_SIZE is taken as is."""
+import csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def load(d, counter):
+    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+    rows = list(csv.DictReader(open(f[0])))
+    out = {}
+    for r in rows:
+        if r["Counter_Name"] != counter:
+            continue
+        out.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+    return out
+fetch = load(sys.argv[1], "FETCH_SIZE")
+write = load(sys.argv[2], "WRITE_SIZE")
+Tt, NSEQ = 40, 3
+DEC = ("gru_step_kernel", "skinny_plain_kernel", "attn_scores_kernel", "attn_ctx_kernel")
+def total(d, pred):
+    return sum(sum(v) for k, v in d.items() if pred(k))
+def kib(x):
+    return x * 1024.0
+# decoder step = everything the seq op launches inside its loop (isolated gru-cell launches are the LAST 200 gru_step dispatches)
+g_f = [v for k, v in fetch.items() if "gru_step_kernel" in k][0]
+g_w = [v for k, v in write.items() if "gru_step_kernel" in k][0]
+cell_fetch = sum(g_f[-200:]) / 200; cell_write = sum(g_w[-200:]) / 200
+dec_fetch = (total(fetch, lambda k: any(n in k for n in DEC)) - sum(g_f[-200:]))
+dec_write = (total(write, lambda k: any(n in k for n in DEC)) - sum(g_w[-200:]))
+res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/prof_decoder_fwd.py",
+       "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B), KiB -> bytes",
+       "gru_step_kernel_bytes_per_launch": kib(2 * cell_fetch + cell_write),
+       "gru_step_kernel_fetch_bytes": kib(2 * cell_fetch), "gru_step_kernel_write_bytes": kib(cell_write),
+       "decoder_step_bytes": kib(2 * dec_fetch + dec_write) / (NSEQ * Tt)}
+json.dump(res, open(os.path.join(ROOT, "profiles", "r01_pmc.json"), "w"), indent=1)
+print(json.dumps(res, indent=1))

@@ -1,0 +1,30 @@
+"""Workload for PMC passes: N launches of the decoder sequence forward (cfg2) + 200 isolated GRU-cell launches."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "vag-nmt_amd"))
+import torch
+import bench
+from vagnmt_hip import ops
+from vagnmt_hip._lib import call, ptr, stream
+c = bench.CFG2
+dev = torch.device("cuda:0")
+m = bench.build_model(c, dev).eval()
+src, lens, tgt, im = bench.make_batch(c, 0, dev)
+lens_t = torch.tensor(lens, dtype=torch.int32, device=dev)
+with torch.no_grad():
+    enc, mask = m._encode(src, lens_t, None)
+    _, ctx = m.vse_imagine.forward_bm(im, enc, mask, None)
+    h0 = ops.DecInit.apply(enc, mask, ctx, m.decoderini.weight, m.decoderini.bias, 0.5)
+    pe = ops.KeysProj.apply(enc, m.decoder.attn.attn_e.weight)
+    sos = torch.full((1, c["B"]), 2, dtype=torch.int64, device=dev)
+    tok = torch.cat([sos, tgt.t()], 0).contiguous()
+    dec = m.decoder
+    for _ in range(3):
+        ops.cgru_decode_seq(enc, pe, mask, h0, tok, dec.embedding.weight, dec.dec_params(), V=c["V"])
+    B, H = c["B"], c["H"]
+    gi = torch.randn(B, 3 * H, device=dev); hp = torch.randn(B, H, device=dev)
+    ho = torch.empty(B, H, device=dev); sv = torch.empty(4, B, H, device=dev)
+    for _ in range(200):
+        call("vag_gru_cell_fwd", ptr(gi), ptr(hp), ptr(dec.gru_1.weight_hh_l0), ptr(dec.gru_1.bias_hh_l0), B, H, ptr(ho), ptr(sv), stream())
+torch.cuda.synchronize()
+print("done")

@@ -206,6 +206,20 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
 }
 
 // =====================================================================================================
+// single GRU cell step (torch nn.GRU on a length-1 sequence: layers/NMT_Decoder.py:121,129)
+// =====================================================================================================
+int vag_gru_cell_fwd(const float* gi, const float* h_prev, const float* w_hh, const float* b_hh, int64_t M, int64_t H,
+                     float* h_out, float* save, vag_stream_t stream) {
+    VAG_CHECK_ARG(gi && h_prev && w_hh && b_hh && h_out && M > 0 && H > 0 && H % 4 == 0);
+    GruStepArgs a = {};
+    a.lda = H; a.ldw = H; a.ldother = 3 * H; a.ldh = H; a.ld2 = 0;
+    a.M = (int)M; a.K = (int)H; a.H = (int)H; a.lengths = nullptr; a.comp_hidden = 1;
+    a.s[0].A = h_prev; a.s[0].W = w_hh; a.s[0].bias = b_hh; a.s[0].other = gi; a.s[0].hprev = h_prev;
+    a.s[0].hout = h_out; a.s[0].out2 = nullptr; a.s[0].save = save; a.s[0].t = 0;
+    return vag_gru_step_launch(a, 1, S_(stream));
+}
+
+// =====================================================================================================
 // attention keys
 // =====================================================================================================
 int vag_attn_keys_proj(const float* enc, const float* attn_e, int64_t rows, int64_t C, float* pe, vag_stream_t stream) {
