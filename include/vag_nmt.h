@@ -134,6 +134,19 @@ int vag_cgru_attn_decode_seq_bwd(const float* enc, const float* pe, const float*
                                  int accumulate_enc, float* d_pe, float* d_h0, vag_dec_g g, float* scratch,
                                  vag_stream_t stream);
 int64_t vag_cgru_bwd_scratch_floats(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H);
+/* The same backward in two phases, for callers that overlap them on two streams: _loop is the recurrence (writes
+ * d_enc_out, d_pe, d_h0 and leaves the per-step tensors in `scratch`); _weights turns those into the parameter
+ * gradients (large products nothing downstream waits for).  ws/scratch must stay untouched in between. */
+int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const float* mask, const float* h0,
+                                      const int64_t* tok, vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt, int64_t E,
+                                      int64_t H, int64_t V, const float* h2_all, const float* c_all,
+                                      const float* e_all, float* d_h2_all, float* d_c_all, const float* d_e_all,
+                                      float* ws, float* d_enc_out, int accumulate_enc, float* d_pe, float* d_h0,
+                                      float* scratch, vag_stream_t stream);
+int vag_cgru_attn_decode_seq_bwd_weights(const float* h0, const int64_t* tok, vag_dec_w w, int64_t B, int64_t Ts,
+                                         int64_t Tt, int64_t E, int64_t H, const float* h2_all, const float* c_all,
+                                         const float* e_all, const float* d_e_all, float* ws, vag_dec_g g,
+                                         float* scratch, vag_stream_t stream);
 
 /* One inference step for N hypotheses (greedy / beam search, models/...V11.py:207-226,259-313).  Hypothesis n
  * attends over source sentence n / rows_per_src (the reference tiles encoder_outputs by beam_size, :253).
@@ -166,6 +179,15 @@ int vag_head_ce_seq_bwd(const float* h2_all, const float* c_all, const float* e_
                         int64_t V, float p_out, const uint64_t* rng, const float* tmid, float* logits, int64_t ldl,
                         const float* lse, const float* inv_cnt, const float* d_loss, float* d_h2_all,
                         float* d_c_all, float* d_e_all, vag_head_g g, float* scratch, vag_stream_t stream);
+/* vag_head_ce_seq_bwd in two phases (see vag_cgru_attn_decode_seq_bwd_loop): _data writes d_h2_all/d_c_all/d_e_all and
+ * leaves d(logits) in `logits` and d(pre-activation) in `scratch` (R*E floats); vag_head_bwd_weights accumulates g. */
+int vag_head_ce_seq_bwd_data(vag_head_w w, const int64_t* tgt, const float* vocab_weight, int64_t B, int64_t Tt,
+                             int64_t E, int64_t H, int64_t V, float p_out, const uint64_t* rng, const float* tmid,
+                             float* logits, int64_t ldl, const float* lse, const float* inv_cnt, const float* d_loss,
+                             float* d_h2_all, float* d_c_all, float* d_e_all, float* scratch, vag_stream_t stream);
+int vag_head_bwd_weights(const float* h2_all, const float* c_all, const float* e_all, int64_t R, int64_t E, int64_t H,
+                         int64_t V, const float* tmid, const float* dlogits, int64_t ldl, const float* dt, vag_head_g g,
+                         vag_stream_t stream);
 /* Same head producing the log-probabilities themselves (R rows) with a backward from d_logp -- the form the
  * per-step layer API (NMT_Decoder.forward -> logp, layers/NMT_Decoder.py:143) and arbitrary criteria need.
  * tmid (R,E) saved; d_logp (R,ldl) is consumed.  scratch: R*E floats. */

@@ -410,17 +410,17 @@ int64_t vag_cgru_bwd_scratch_floats(int64_t B, int64_t Ts, int64_t Tt, int64_t E
     return cgru_bwd_scratch(nullptr, B, Ts, Tt, E, H).total;
 }
 
-int vag_cgru_attn_decode_seq_bwd(const float* enc, const float* pe, const float* mask, const float* h0, const int64_t* tok,
+int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const float* mask, const float* h0, const int64_t* tok,
                                  vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, int64_t V,
                                  const float* h2_all, const float* c_all, const float* e_all, float* d_h2_all,
                                  float* d_c_all, const float* d_e_all, float* ws, float* d_enc_out, int accumulate_enc,
-                                 float* d_pe, float* d_h0, vag_dec_g g, float* scratch, vag_stream_t stream) {
+                                 float* d_pe, float* d_h0, float* scratch, vag_stream_t stream) {
     hipStream_t s = S_(stream);
     VAG_CHECK_ARG(enc && pe && mask && h0 && tok && h2_all && c_all && e_all && d_h2_all && d_c_all && ws && d_enc_out &&
                   d_pe && d_h0 && scratch && dec_w_ok(w));
     VAG_CHECK_ARG(B > 0 && Ts > 0 && Tt > 0 && E % 4 == 0 && H % 4 == 0 && aligned16(ws) && aligned16(scratch));
-    (void)V; (void)mask;
-    const int64_t C = 2 * H, Q = C + 3 * H, BH = B * H, R = Tt * B;
+    (void)V; (void)mask; (void)d_e_all;
+    const int64_t C = 2 * H, Q = C + 3 * H, BH = B * H;
     CgruWs k = cgru_ws(ws, B, Ts, Tt, E, H);
     CgruPrep p = cgru_prep(k.prep, H);          // Wcat / Wp from the forward call are still in the workspace
     CgruBwdScratch z = cgru_bwd_scratch(scratch, B, Ts, Tt, E, H);
@@ -477,6 +477,21 @@ int vag_cgru_attn_decode_seq_bwd(const float* enc, const float* pe, const float*
     // after the loop: everything that does not sit on the recurrence's critical path, as large products
     VAG_TRY(vag_attn_post_bwd_launch(pe, k.qhp, Q, w.attn_v, z.ds, k.alpha, d_c_all, B, Ts, Tt, C, d_pe, z.dvp, d_enc_out,
                                      accumulate_enc, s));
+    return VAG_OK;
+}
+
+// Parameter gradients of the decoder from the per-step tensors the loop left in `scratch` (large products; nothing
+// downstream waits for them, so they may run on a side stream beside the encoder's backward recurrence).
+int vag_cgru_attn_decode_seq_bwd_weights(const float* h0, const int64_t* tok, vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt,
+                                         int64_t E, int64_t H, const float* h2_all, const float* c_all, const float* e_all,
+                                         const float* d_e_all, float* ws, vag_dec_g g, float* scratch, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(h0 && tok && h2_all && c_all && e_all && ws && scratch && dec_w_ok(w));
+    VAG_CHECK_ARG(g.emb && g.gru1.w_ih && g.gru1.w_hh && g.gru1.b_ih && g.gru1.b_hh && g.attn_h && g.attn_v && g.c2h &&
+                  g.gru2.w_ih && g.gru2.w_hh && g.gru2.b_ih && g.gru2.b_hh);
+    const int64_t C = 2 * H, Q = C + 3 * H, R = Tt * B;
+    CgruWs k = cgru_ws(ws, B, Ts, Tt, E, H);
+    CgruBwdScratch z = cgru_bwd_scratch(scratch, B, Ts, Tt, E, H);
     VAG_TRY(vag_colsum_launch(z.dvp, B, C, C, g.attn_v, s));
     const float* dgh2 = z.dqgh + C;      // (R,3H) row stride Q
     VAG_TRY(gemm_tn_acc(3 * H, H, R, dgh2, Q, k.h1, H, g.gru2.w_hh, H, s));
@@ -497,6 +512,17 @@ int vag_cgru_attn_decode_seq_bwd(const float* enc, const float* pe, const float*
     VAG_TRY(gemm_nn(R, E, 3 * H, z.dgi1, 3 * H, w.gru1.w_ih, E, d_e_all ? 1.f : 0.f, z.de, E, s));
     VAG_TRY(vag_embed_scatter_launch(tok, B, 1, Tt, B, z.de, E, g.emb, nullptr, 0, 0.f, s));
     return VAG_OK;
+}
+
+int vag_cgru_attn_decode_seq_bwd(const float* enc, const float* pe, const float* mask, const float* h0, const int64_t* tok,
+                                 vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, int64_t V,
+                                 const float* h2_all, const float* c_all, const float* e_all, float* d_h2_all,
+                                 float* d_c_all, const float* d_e_all, float* ws, float* d_enc_out, int accumulate_enc,
+                                 float* d_pe, float* d_h0, vag_dec_g g, float* scratch, vag_stream_t stream) {
+    VAG_TRY(vag_cgru_attn_decode_seq_bwd_loop(enc, pe, mask, h0, tok, w, B, Ts, Tt, E, H, V, h2_all, c_all, e_all, d_h2_all,
+                                              d_c_all, d_e_all, ws, d_enc_out, accumulate_enc, d_pe, d_h0, scratch, stream));
+    return vag_cgru_attn_decode_seq_bwd_weights(h0, tok, w, B, Ts, Tt, E, H, h2_all, c_all, e_all, d_e_all, ws, g, scratch,
+                                                stream);
 }
 
 int64_t vag_cgru_step_scratch_floats(int64_t N, int64_t Ts, int64_t E, int64_t H) {
@@ -550,27 +576,55 @@ int vag_head_ce_seq_fwd(const float* h2_all, const float* c_all, const float* e_
     return VAG_OK;
 }
 
-// Everything behind d(logits): out-layer gradients, tanh/dropout backward, W1/W2/W3 gradients, input gradients.
-static int head_bwd_from_dlogits(const float* h2_all, const float* c_all, const float* e_all, const vag_head_w& w,
-                                 int64_t R, int64_t E, int64_t H, int64_t V, float p_out, const uint64_t* rng,
-                                 const float* tmid, const float* dlogits, int64_t ldl, float* d_h2_all, float* d_c_all,
-                                 float* d_e_all, const vag_head_g& g, float* dt, hipStream_t s) {
+// d(logits) -> d(tmid) -> through dropout+tanh -> input gradients.  dt (R,E) is left holding d(pre-activation).
+static int head_bwd_data(const vag_head_w& w, int64_t R, int64_t E, int64_t H, int64_t V, float p_out, const uint64_t* rng,
+                         const float* tmid, const float* dlogits, int64_t ldl, float* d_h2_all, float* d_c_all,
+                         float* d_e_all, float* dt, hipStream_t s) {
+    const int64_t C = 2 * H;
+    VAG_TRY(gemm_nn(R, E, V, dlogits, ldl, w.out_w, E, 0.f, dt, E, s));
+    VAG_TRY(vag_tanh_bwd_launch(tmid, dt, dt, R * E, rng, VAG_DROP_DEC_OUT, p_out, s));   // tmid holds tanh(.)*mul
+    VAG_TRY(gemm_nn(R, H, E, dt, E, w.w1, H, 0.f, d_h2_all, H, s));
+    VAG_TRY(gemm_nn(R, C, E, dt, E, w.w2, C, 0.f, d_c_all, C, s));
+    VAG_TRY(gemm_nn(R, E, E, dt, E, w.w3, E, 0.f, d_e_all, E, s));
+    return VAG_OK;
+}
+// Parameter gradients of the head from d(logits) and dt = d(pre-activation): nothing downstream waits for these,
+// so they may run on a side stream beside the decoder's backward recurrence.
+static int head_bwd_weights(const float* h2_all, const float* c_all, const float* e_all, int64_t R, int64_t E, int64_t H,
+                            int64_t V, const float* tmid, const float* dlogits, int64_t ldl, const float* dt,
+                            const vag_head_g& g, hipStream_t s) {
     const int64_t C = 2 * H;
     VAG_TRY(gemm_tn_acc(V, E, R, dlogits, ldl, tmid, E, g.out_w, E, s));
     VAG_TRY(vag_colsum_launch(dlogits, R, V, ldl, g.out_b, s));
-    VAG_TRY(gemm_nn(R, E, V, dlogits, ldl, w.out_w, E, 0.f, dt, E, s));
-    // through dropout and tanh: tmid holds tanh(.)*mul
-    VAG_TRY(vag_tanh_bwd_launch(tmid, dt, dt, R * E, rng, VAG_DROP_DEC_OUT, p_out, s));
     VAG_TRY(gemm_tn_acc(E, H, R, dt, E, h2_all, H, g.w1, H, s));
     VAG_TRY(gemm_tn_acc(E, C, R, dt, E, c_all, C, g.w2, C, s));
     VAG_TRY(gemm_tn_acc(E, E, R, dt, E, e_all, E, g.w3, E, s));
     VAG_TRY(vag_colsum_launch(dt, R, E, E, g.b1, s));
     VAG_TRY(vag_colsum_launch(dt, R, E, E, g.b2, s));
     VAG_TRY(vag_colsum_launch(dt, R, E, E, g.b3, s));
-    VAG_TRY(gemm_nn(R, H, E, dt, E, w.w1, H, 0.f, d_h2_all, H, s));
-    VAG_TRY(gemm_nn(R, C, E, dt, E, w.w2, C, 0.f, d_c_all, C, s));
-    VAG_TRY(gemm_nn(R, E, E, dt, E, w.w3, E, 0.f, d_e_all, E, s));
     return VAG_OK;
+}
+
+static bool head_g_ok(const vag_head_g& g) { return g.w1 && g.b1 && g.w2 && g.b2 && g.w3 && g.b3 && g.out_w && g.out_b; }
+
+int vag_head_ce_seq_bwd_data(vag_head_w w, const int64_t* tgt, const float* vocab_weight, int64_t B, int64_t Tt, int64_t E,
+                             int64_t H, int64_t V, float p_out, const uint64_t* rng, const float* tmid, float* logits,
+                             int64_t ldl, const float* lse, const float* inv_cnt, const float* d_loss, float* d_h2_all,
+                             float* d_c_all, float* d_e_all, float* scratch, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(tgt && vocab_weight && tmid && logits && lse && inv_cnt && d_loss && scratch && d_h2_all && d_c_all && d_e_all);
+    VAG_CHECK_ARG(w.w1 && w.w2 && w.w3 && w.out_w);
+    VAG_CHECK_ARG(B > 0 && Tt > 0 && E % 4 == 0 && H % 4 == 0 && V > 0 && ldl >= V && ldl % 4 == 0);
+    const int64_t R = Tt * B;
+    VAG_TRY(vag_ce_bwd_launch(logits, ldl, R, V, tgt, B, Tt, vocab_weight, lse, inv_cnt, d_loss, s));
+    return head_bwd_data(w, R, E, H, V, p_out, rng, tmid, logits, ldl, d_h2_all, d_c_all, d_e_all, scratch, s);
+}
+
+int vag_head_bwd_weights(const float* h2_all, const float* c_all, const float* e_all, int64_t R, int64_t E, int64_t H,
+                         int64_t V, const float* tmid, const float* dlogits, int64_t ldl, const float* dt, vag_head_g g,
+                         vag_stream_t stream) {
+    VAG_CHECK_ARG(h2_all && c_all && e_all && tmid && dlogits && dt && head_g_ok(g) && R > 0 && ldl >= V);
+    return head_bwd_weights(h2_all, c_all, e_all, R, E, H, V, tmid, dlogits, ldl, dt, g, S_(stream));
 }
 
 int vag_head_ce_seq_bwd(const float* h2_all, const float* c_all, const float* e_all, vag_head_w w, const int64_t* tgt,
@@ -578,14 +632,10 @@ int vag_head_ce_seq_bwd(const float* h2_all, const float* c_all, const float* e_
                         const uint64_t* rng, const float* tmid, float* logits, int64_t ldl, const float* lse,
                         const float* inv_cnt, const float* d_loss, float* d_h2_all, float* d_c_all, float* d_e_all,
                         vag_head_g g, float* scratch, vag_stream_t stream) {
-    hipStream_t s = S_(stream);
-    VAG_CHECK_ARG(h2_all && c_all && e_all && tgt && vocab_weight && tmid && logits && lse && inv_cnt && d_loss && scratch);
-    VAG_CHECK_ARG(d_h2_all && d_c_all && d_e_all && g.w1 && g.b1 && g.w2 && g.b2 && g.w3 && g.b3 && g.out_w && g.out_b);
-    VAG_CHECK_ARG(B > 0 && Tt > 0 && E % 4 == 0 && H % 4 == 0 && V > 0 && ldl >= V && ldl % 4 == 0);
-    const int64_t R = Tt * B;
-    VAG_TRY(vag_ce_bwd_launch(logits, ldl, R, V, tgt, B, Tt, vocab_weight, lse, inv_cnt, d_loss, s));
-    return head_bwd_from_dlogits(h2_all, c_all, e_all, w, R, E, H, V, p_out, rng, tmid, logits, ldl, d_h2_all, d_c_all,
-                                 d_e_all, g, scratch, s);
+    VAG_CHECK_ARG(h2_all && c_all && e_all && head_g_ok(g));
+    VAG_TRY(vag_head_ce_seq_bwd_data(w, tgt, vocab_weight, B, Tt, E, H, V, p_out, rng, tmid, logits, ldl, lse, inv_cnt, d_loss,
+                                     d_h2_all, d_c_all, d_e_all, scratch, stream));
+    return head_bwd_weights(h2_all, c_all, e_all, Tt * B, E, H, V, tmid, logits, ldl, scratch, g, S_(stream));
 }
 
 int vag_head_logp_seq_fwd(const float* h2, const float* c, const float* e, vag_head_w w, int64_t R, int64_t E, int64_t H,
@@ -611,7 +661,8 @@ int vag_head_logp_seq_bwd(const float* h2, const float* c, const float* e, vag_h
     VAG_CHECK_ARG(h2 && c && e && tmid && logp && d_logp && d_h2 && d_c && d_e && scratch && R > 0 && ldl >= V);
     VAG_CHECK_ARG(g.w1 && g.b1 && g.w2 && g.b2 && g.w3 && g.b3 && g.out_w && g.out_b);
     VAG_TRY(vag_logsoftmax_bwd_launch(logp, ldl, d_logp, ldl, R, V, s));
-    return head_bwd_from_dlogits(h2, c, e, w, R, E, H, V, p_out, rng, tmid, d_logp, ldl, d_h2, d_c, d_e, g, scratch, s);
+    VAG_TRY(head_bwd_data(w, R, E, H, V, p_out, rng, tmid, d_logp, ldl, d_h2, d_c, d_e, scratch, s));
+    return head_bwd_weights(h2, c, e, R, E, H, V, tmid, d_logp, ldl, scratch, g, s);
 }
 
 int vag_head_logp_step(const float* h2, const float* c, const float* e, vag_head_w w, int64_t N, int64_t E, int64_t H,

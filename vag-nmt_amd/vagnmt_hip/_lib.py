@@ -52,6 +52,9 @@ PROTOS = {
     "vag_cgru_bwd_scratch_floats": (I64, [I64, I64, I64, I64, I64]),
     "vag_cgru_attn_decode_seq_bwd": (I32, [P, P, P, P, P, DecW, I64, I64, I64, I64, I64, I64, P, P, P, P, P, P, P, P,
                                            I32, P, P, DecW, P, P]),
+    "vag_cgru_attn_decode_seq_bwd_loop": (I32, [P, P, P, P, P, DecW, I64, I64, I64, I64, I64, I64, P, P, P, P, P, P, P, P,
+                                                I32, P, P, P, P]),
+    "vag_cgru_attn_decode_seq_bwd_weights": (I32, [P, P, DecW, I64, I64, I64, I64, I64, P, P, P, P, P, DecW, P, P]),
     "vag_cgru_step_scratch_floats": (I64, [I64, I64, I64, I64]),
     "vag_cgru_prep_floats": (I64, [I64]),
     "vag_cgru_prepare": (I32, [DecW, I64, P, P]),
@@ -59,6 +62,8 @@ PROTOS = {
     "vag_head_ce_seq_fwd": (I32, [P, P, P, HeadW, P, P, I64, I64, I64, I64, I64, F, P, I32, P, P, I64, P, P, P, P, P]),
     "vag_head_ce_seq_bwd": (I32, [P, P, P, HeadW, P, P, I64, I64, I64, I64, I64, F, P, P, P, I64, P, P, P, P, P, P,
                                   HeadW, P, P]),
+    "vag_head_ce_seq_bwd_data": (I32, [HeadW, P, P, I64, I64, I64, I64, I64, F, P, P, P, I64, P, P, P, P, P, P, P, P]),
+    "vag_head_bwd_weights": (I32, [P, P, P, I64, I64, I64, I64, P, P, I64, P, HeadW, P]),
     "vag_head_logp_seq_fwd": (I32, [P, P, P, HeadW, I64, I64, I64, I64, F, P, P, P, I64, P]),
     "vag_head_logp_seq_bwd": (I32, [P, P, P, HeadW, I64, I64, I64, I64, F, P, P, P, P, I64, P, P, P, HeadW, P, P]),
     "vag_l2norm_fwd": (I32, [P, I64, I64, P, P, P]),

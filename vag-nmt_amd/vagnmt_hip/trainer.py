@@ -76,7 +76,7 @@ class TrainStep:
 
     def __init__(self, model, criterion_mt, criterion_vse=None, lr=4e-4, weight_decay=1e-5, clip=1.0,
                  teacher_force_ratio=0.8, betas=(0.9, 0.999), eps=1e-8, vse_separate=False, use_graph=True,
-                 process_group=None, world_size=1):
+                 process_group=None, world_size=1, overlap=False):
         self.model = model
         self.criterion_mt = criterion_mt
         self.criterion_vse = criterion_vse
@@ -99,6 +99,9 @@ class TrainStep:
         self._scratch = torch.zeros(8, dtype=torch.float32, device=dev)
         self._graphs = {}
         self._eager_done = set()
+        # optional second stream for the weight-gradient products.  Measured (round 1): no gain -- the products' blocks
+        # fill every CU and the recurrence's small kernels queue behind them -- so it is off by default.
+        self._side = torch.cuda.Stream(device=dev) if overlap and dev.type == "cuda" else None
 
     def set_lr(self, lr):
         """ReduceLROnPlateau equivalent hook (nmt_multimodal_beam_DE.py:335,469): lr is a host scalar per call."""
@@ -114,7 +117,14 @@ class TrainStep:
         else:
             loss = self.model(src, lengths, tgt, tfr, criterion=self.criterion_mt)
             loss_mt, loss_vse = loss, None
-        loss.backward()
+        from . import ops
+        if self._side is not None:
+            ops.SIDE.enable(self._side)
+        try:
+            loss.backward()
+        finally:
+            if self._side is not None:
+                ops.SIDE.disable()        # joins: the gradients are complete on the current stream after this
         return loss, loss_mt, loss_vse
 
     def _optimizer(self):
