@@ -27,19 +27,19 @@ struct GemmArgs {
     int act, splitk;
 };
 
-constexpr int BK = 16;
+constexpr int BK = 32;      // k-depth of one LDS stage (one barrier per 32 of K)
 
 // Load a (BT outer) x (BK k) operand tile into registers.  KC: k is the contiguous dimension.  NTH threads.
 template <int BT, bool KC, bool VEC, int NTH>
 __device__ __forceinline__ void tile_load(const float* __restrict__ P, int64_t so, int64_t sk, int o0, int k0,
-                                          int OUT, int KEND, float4 (&r)[BT * 4 / NTH]) {
+                                          int OUT, int KEND, float4 (&r)[BT * (BK / 4) / NTH]) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < BT * 4 / NTH; ++i) {
+    for (int i = 0; i < BT * (BK / 4) / NTH; ++i) {
         const int idx = tid + i * NTH;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (KC) {
-            const int o = o0 + (idx >> 2), k = k0 + ((idx & 3) << 2);
+            const int o = o0 + idx / (BK / 4), k = k0 + ((idx % (BK / 4)) << 2);
             if (o < OUT) {
                 const float* p = P + (int64_t)o * so + k;
                 if (VEC && k + 3 < KEND) {
@@ -71,14 +71,14 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ P, int64_t s
 
 // LDS image: S[k][o], row stride BT+4 floats (MFMA operand reads are 32 consecutive floats -> conflict free).
 template <int BT, bool KC, int NTH>
-__device__ __forceinline__ void tile_store(float* __restrict__ S, const float4 (&r)[BT * 4 / NTH]) {
+__device__ __forceinline__ void tile_store(float* __restrict__ S, const float4 (&r)[BT * (BK / 4) / NTH]) {
     const int tid = threadIdx.x;
     constexpr int LD = BT + 4;
 #pragma unroll
-    for (int i = 0; i < BT * 4 / NTH; ++i) {
+    for (int i = 0; i < BT * (BK / 4) / NTH; ++i) {
         const int idx = tid + i * NTH;
         if (KC) {
-            const int o = idx >> 2, k = (idx & 3) << 2;
+            const int o = idx / (BK / 4), k = (idx % (BK / 4)) << 2;
             S[(k + 0) * LD + o] = r[i].x;
             S[(k + 1) * LD + o] = r[i].y;
             S[(k + 2) * LD + o] = r[i].z;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(NTH) void gemm_tiled_kernel(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[BM * 4 / NTH], rb[BN * 4 / NTH];
+    float4 ra[BM * (BK / 4) / NTH], rb[BN * (BK / 4) / NTH];
     tile_load<BM, AKC, VEC, NTH>(a.A, a.sa_o, a.sa_k, m0, kbeg, a.M, kend, ra);
     tile_load<BN, BKC, VEC, NTH>(a.B, a.sb_o, a.sb_k, n0, kbeg, a.N, kend, rb);
     tile_store<BM, AKC, NTH>(As, ra);
@@ -180,6 +180,221 @@ __global__ __launch_bounds__(NTH) void gemm_tiled_kernel(GemmArgs a) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp32 GEMM on the bf16 matrix pipes: 3-way operand split, 6 products ("bf16x6")
+//
+// gfx950's f32-input MFMA runs at 1/16 of the bf16 MFMA rate.  Every fp32 value is the exact sum of three bf16 numbers
+// x = x1 + x2 + x3 (8 significand bits each: x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2); the residual is
+// below 2^-24 |x|), so a*b = sum_{i+j<=4} a_i b_j up to 2^-24 relative: the six bf16 x bf16 products are exact in fp32
+// and are accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  That is fp32-grade arithmetic (same error class as a
+// reassociated fp32 sum) at 6/16 of the f32-MFMA instruction time.  The split is done once per element on its way from
+// global memory into LDS (three bf16 planes per operand), so global traffic is unchanged.
+// Block 128x128x32, 8 waves (2x4, 64x32 each), LDS single-staged (61 KB: two blocks per CU), register prefetch.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int SP_BK = 32;
+constexpr int SP_LD = SP_BK + 4;            // bf16 elements per LDS row: 72 B = 18 dwords.  Fragments are read as two
+                                            // ds_read_b64 (conflict-free over 32 rows); k-pair dword writes are 2-way at most
+constexpr int SP_PLANE = 128 * SP_LD;       // bf16 elements per plane
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    f32x2 v = {a, b};
+    bf16x2 h = __builtin_convertvector(v, bf16x2);     // v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned, h);
+}
+// split two floats into three packed bf16 pairs (low half = first element)
+__device__ __forceinline__ void split3(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = pack_bf16(a, b);
+    const float a1 = __builtin_bit_cast(float, p1 << 16), b1 = __builtin_bit_cast(float, p1 & 0xffff0000u);
+    const float ra = a - a1, rb = b - b1;
+    p2 = pack_bf16(ra, rb);
+    const float a2 = __builtin_bit_cast(float, p2 << 16), b2 = __builtin_bit_cast(float, p2 & 0xffff0000u);
+    p3 = pack_bf16(ra - a2, rb - b2);
+}
+
+// global -> registers (8 floats per thread per operand tile).
+// KC (k contiguous): two float4 = (row, 4 consecutive k) items.  OC (outer contiguous): lanes run along the
+// contiguous outer dimension with one float each (256-B rows per wave load), four (k, k+1) pairs per thread, so that
+// the LDS scatter below writes whole dwords to distinct banks.
+struct SpRegs { float v[8]; };
+
+template <bool KC, bool VEC>
+__device__ __forceinline__ void sp_load(const float* __restrict__ P, int64_t so, int64_t sk, int o0, int k0, int OUT,
+                                        int KEND, SpRegs& r) {
+    const int tid = threadIdx.x;
+    if (KC) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 512;
+            const int o = o0 + (idx >> 3), k = k0 + ((idx & 7) << 2);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (o < OUT) {
+                const float* p = P + (int64_t)o * so + k;
+                if (VEC && k + 3 < KEND) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (k + 0 < KEND) v.x = p[0];
+                    if (k + 1 < KEND) v.y = p[1];
+                    if (k + 2 < KEND) v.z = p[2];
+                    if (k + 3 < KEND) v.w = p[3];
+                }
+            }
+            r.v[4 * i + 0] = v.x; r.v[4 * i + 1] = v.y; r.v[4 * i + 2] = v.z; r.v[4 * i + 3] = v.w;
+        }
+    } else {
+        const int o = o0 + (tid & 127), kq = tid >> 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + 2 * (kq + 4 * i);
+            const float* p = P + (int64_t)k * sk + o;
+            r.v[2 * i + 0] = (o < OUT && k < KEND) ? p[0] : 0.f;
+            r.v[2 * i + 1] = (o < OUT && k + 1 < KEND) ? p[sk] : 0.f;
+        }
+    }
+}
+
+// registers -> three bf16 planes in LDS, image [outer][k] per plane
+template <bool KC>
+__device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r) {
+    const int tid = threadIdx.x;
+    if (KC) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 512;
+            const int o = idx >> 3, k = (idx & 7) << 2;
+            unsigned a1, a2, a3, b1, b2, b3;
+            split3(r.v[4 * i + 0], r.v[4 * i + 1], a1, a2, a3);
+            split3(r.v[4 * i + 2], r.v[4 * i + 3], b1, b2, b3);
+            __bf16* d = S + o * SP_LD + k;
+            *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
+            *reinterpret_cast<uint2*>(d + SP_PLANE) = make_uint2(a2, b2);
+            *reinterpret_cast<uint2*>(d + 2 * SP_PLANE) = make_uint2(a3, b3);
+        }
+    } else {
+        const int o = tid & 127, kq = tid >> 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned p1, p2, p3;
+            split3(r.v[2 * i], r.v[2 * i + 1], p1, p2, p3);       // (k, k+1) packed into one dword
+            __bf16* d = S + o * SP_LD + 2 * (kq + 4 * i);
+            *reinterpret_cast<unsigned*>(d) = p1;
+            *reinterpret_cast<unsigned*>(d + SP_PLANE) = p2;
+            *reinterpret_cast<unsigned*>(d + 2 * SP_PLANE) = p3;
+        }
+    }
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 sp_frag(const __bf16* p) {      // 8 consecutive k of one row, as two 8-byte LDS reads
+    const uint2 lo = *reinterpret_cast<const uint2*>(p);
+    const uint2 hi = *reinterpret_cast<const uint2*>(p + 4);
+    const u32x4 q = {lo.x, lo.y, hi.x, hi.y};
+    return __builtin_bit_cast(bf16x8, q);
+}
+
+template <bool AKC, bool BKC, bool VEC>
+__global__ __launch_bounds__(512) void gemm_split_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) __bf16 smem[6 * SP_PLANE];
+    __bf16* As = smem;
+    __bf16* Bs = smem + 3 * SP_PLANE;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int kbeg = blockIdx.z * a.kchunk;
+    const int kend = min(a.K, kbeg + a.kchunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    SpRegs ra, rb;
+    sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, kbeg, a.M, kend, ra);
+    sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, kbeg, a.N, kend, rb);
+
+    // fragment addresses: lane (r = lane&31, h = lane>>5) holds 8 consecutive k (8h..8h+7) of row r
+    const __bf16* Af = As + (wm * 64 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
+    const __bf16* Bf = Bs + (wn * 32 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
+
+    for (int k0 = kbeg; k0 < kend; k0 += SP_BK) {
+        sp_store<AKC>(As, ra);
+        sp_store<BKC>(Bs, rb);
+        __syncthreads();
+        if (k0 + SP_BK < kend) {
+            sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, k0 + SP_BK, a.M, kend, ra);
+            sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, k0 + SP_BK, a.N, kend, rb);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2][3], bf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                bf[p] = sp_frag(Bf + p * SP_PLANE + ks * 16);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    af[i][p] = sp_frag(Af + p * SP_PLANE + i * 32 * SP_LD + ks * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                // smallest terms first
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[2], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[1], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[0], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[1], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[0], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    const bool atomic = a.splitk > 1;
+    const bool first = blockIdx.z == 0;
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col >= a.N) return;
+    const float bv = (a.bias && first) ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= a.M) continue;
+            float* cp = a.C + (int64_t)row * a.ldc + col;
+            float v = a.alpha * acc[i][r] + bv;
+            if (atomic) {
+                atomicAdd(cp, v);
+            } else {
+                if (a.beta != 0.f) v += a.beta * (*cp);
+                if (a.act == VAG_ACT_TANH) v = vag_tanh(v);
+                *cp = v;
+            }
+        }
+}
+
+static int gemm_split_dispatch(const GemmArgs& g, bool akc, bool bkc, bool vec, dim3 grid, hipStream_t s) {
+#define VAG_SPLIT_CASE(AK, BKc, V)                                                                    \
+    if (akc == AK && bkc == BKc && vec == V) {                                                        \
+        hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V>), grid, dim3(512), 0, s, g);                \
+        VAG_LAUNCH_CHECK();                                                                           \
+        return VAG_OK;                                                                                \
+    }
+    VAG_SPLIT_CASE(true, true, true)
+    VAG_SPLIT_CASE(true, false, true)
+    VAG_SPLIT_CASE(false, true, true)
+    VAG_SPLIT_CASE(false, false, true)
+    VAG_SPLIT_CASE(true, true, false)
+    VAG_SPLIT_CASE(true, false, false)
+    VAG_SPLIT_CASE(false, true, false)
+    VAG_SPLIT_CASE(false, false, false)
+#undef VAG_SPLIT_CASE
+    return VAG_EINVAL;
+}
+
 template <int BM, int BN, int NTH>
 static int gemm_dispatch(const GemmArgs& g, bool akc, bool bkc, bool vec, dim3 grid, hipStream_t s) {
 #define VAG_GEMM_CASE(AK, BKc, V)                                                                          \
@@ -235,7 +450,7 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     int64_t T = 64, splitk = 1;
     for (int64_t t = 64; t <= 128; t *= 2) {
         if (t == 128 && (M <= 64 || N <= 64)) continue;
-        const double eff = (t == 128) ? 0.62 : 0.42;
+        const double eff = (t == 128) ? (getenv("VAG_GEMM_F32MFMA") ? 0.62 : 0.85) : 0.42;   // fraction of the f32-MFMA peak
         const int64_t base = cdiv64(M, t) * cdiv64(N, t);
         for (int64_t sp = 1; sp <= 16; ++sp) {
             if (sp > 1 && (!can_split || K / sp < 128)) break;
@@ -262,7 +477,8 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     }
     dim3 grid((unsigned)cdiv64(N, T), (unsigned)cdiv64(M, T), (unsigned)splitk);
     if (big) {
-        // 128x128 blocks run 8 waves (2 per SIMD): measured 5-20 % faster than 4 waves at every grid size
+        if (getenv("VAG_GEMM_F32MFMA") == nullptr) return gemm_split_dispatch(g, akc, bkc, vec, grid, stream);
+        // f32-input MFMA path (v_mfma_f32_32x32x2_f32), 8 waves (2 per SIMD)
         return gemm_dispatch<128, 128, 512>(g, akc, bkc, vec, grid, stream);
     }
     return gemm_dispatch<64, 64, 256>(g, akc, bkc, vec, grid, stream);
