@@ -572,173 +572,149 @@ __device__ __forceinline__ float skinny_sum1(const float* red, int tile, int mro
     return s;
 }
 
-// COLS = 16: one full n-tile per workgroup; COLS = 8: half a tile (lanes with col >= 8 duplicate rows and are idle
-// in the epilogue) -- twice the workgroups for small N, so that all 256 CUs pull weights.
-template <int WAVES, int MT, int COLS>
+// One 16x16 output tile per workgroup; the 256 outputs are finished by the first 256 threads (bias / addend requested
+// before the product).
+template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void skinny_plain_kernel(SkinnyArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[WAVES * MT * 64 * 4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4];
+    const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.y * 16 * MT, nb = blockIdx.x * COLS;
-    const float* ap[MT];
-    const float* wp[1];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) ap[i] = a.A + (int64_t)min(m0 + 16 * i + r, a.M - 1) * a.lda + 4 * g;
-    wp[0] = a.W + (int64_t)min(nb + (COLS == 16 ? r : (r & 7)), a.N - 1) * a.ldw + 4 * g;
-    skinny_mma<WAVES, MT, 1>(ap, wp, a.K, red);
-    if (wave >= MT) return;
-    const f32x4 s = skinny_sum<WAVES, MT>(red, wave, lane);
-    const int col = nb + r;
-    if (r >= COLS || col >= a.N) return;
-    const float bv = a.bias ? a.bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + 16 * wave + 4 * g + i;
-        if (m >= a.M) continue;
-        float v = s[i] + bv;
-        if (a.addend) v += a.addend[(int64_t)m * a.ldadd + col];
-        if (a.act == VAG_ACT_TANH) v = vag_tanh(v);
-        a.out[(int64_t)m * a.ldo + col] = v;
+    const int m0 = blockIdx.y * 16, nb = blockIdx.x * 16;
+    const int erow = (threadIdx.x >> 4) & 15, ecol = threadIdx.x & 15;
+    const int em = m0 + erow, ej = nb + ecol;
+    const bool eok = threadIdx.x < 256 && em < a.M && ej < a.N;
+    float pre = 0.f;
+    if (eok) {
+        if (a.bias) pre = a.bias[ej];
+        if (a.addend) pre += a.addend[(int64_t)em * a.ldadd + ej];
     }
+    const float* ap[1];
+    const float* wp[1];
+    ap[0] = a.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + 4 * g;
+    wp[0] = a.W + (int64_t)min(nb + r, a.N - 1) * a.ldw + 4 * g;
+    skinny_mma<WAVES, 1, 1>(ap, wp, a.K, red);
+    if (!eok) return;
+    float v = skinny_sum1<WAVES, 1>(red, 0, erow, ecol) + pre;
+    if (a.act == VAG_ACT_TANH) v = vag_tanh(v);
+    a.out[(int64_t)em * a.ldo + ej] = v;
 }
 
-// GRU gate math shared by both GRU step kernels.
-__device__ __forceinline__ void gru_cell_epilogue(const GruStepArgs& a, const GruSide& sd, int m, int col, float c_r, float c_z,
-                                                  float c_n) {
+// Fused GRU cell: 16 rows x 16 hidden units x 3 gates per workgroup.  The 256 (row, unit) outputs are finished by the
+// first 256 threads, one each; their epilogue operands (the other projection, h_prev, bias) are requested BEFORE the
+// product so that they arrive under it instead of costing a second memory round trip.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gru_step_kernel(GruStepArgs a) {
+    constexpr int NT = 3;
+    __shared__ __attribute__((aligned(16))) float red[WAVES * NT * 64 * 4];
+    const GruSide& sd = a.s[blockIdx.z];
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * 16, u0 = blockIdx.x * 16;
     const int H = a.H;
-    if (sd.bias) { c_r += sd.bias[col]; c_z += sd.bias[H + col]; c_n += sd.bias[2 * H + col]; }
-    const float* op = sd.other + (int64_t)m * a.ldother + col;
-    const float o_r = op[0], o_z = op[H], o_n = op[2 * H];
+    // epilogue operands of thread t < 256: output (row m0 + t/16, unit u0 + t%16)
+    const int erow = (threadIdx.x >> 4) & 15, ecol = threadIdx.x & 15;
+    const int em = m0 + erow, ej = u0 + ecol;
+    const bool eok = threadIdx.x < 256 && em < a.M && ej < H;
+    float o_r = 0.f, o_z = 0.f, o_n = 0.f, hp = 0.f, b_r = 0.f, b_z = 0.f, b_n = 0.f;
+    bool active = true;
+    if (eok) {
+        const float* op = sd.other + (int64_t)em * a.ldother + ej;
+        o_r = op[0]; o_z = op[H]; o_n = op[2 * H];
+        hp = sd.hprev[(int64_t)em * a.ldh + ej];
+        if (sd.bias) { b_r = sd.bias[ej]; b_z = sd.bias[H + ej]; b_n = sd.bias[2 * H + ej]; }
+        if (a.lengths) active = sd.t < a.lengths[em];
+    }
+    const float* ap[1];
+    const float* wp[NT];
+    ap[0] = sd.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + 4 * g;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wp[j] = sd.W + (int64_t)min(j * H + u0 + r, 3 * H - 1) * a.ldw + 4 * g;
+    skinny_mma<WAVES, 1, NT>(ap, wp, a.K, red);
+    if (!eok) return;
+    const float c_r = skinny_sum1<WAVES, NT>(red, 0, erow, ecol) + b_r;
+    const float c_z = skinny_sum1<WAVES, NT>(red, 1, erow, ecol) + b_z;
+    const float c_n = skinny_sum1<WAVES, NT>(red, 2, erow, ecol) + b_n;
     const float gi_n = a.comp_hidden ? o_n : c_n;
     const float gh_n = a.comp_hidden ? c_n : o_n;
     const float rr = vag_sigmoid(c_r + o_r);
     const float zz = vag_sigmoid(c_z + o_z);
     const float nn = vag_tanh(gi_n + rr * gh_n);
-    const float hp = sd.hprev[(int64_t)m * a.ldh + col];
     const float hn = (1.f - zz) * nn + zz * hp;
-    const bool active = a.lengths ? (sd.t < a.lengths[m]) : true;
+    const int64_t o = (int64_t)em * H + ej;
     if (sd.save) {
         const int64_t MH = (int64_t)a.M * H;
-        const int64_t o = (int64_t)m * H + col;
         sd.save[o] = rr; sd.save[MH + o] = zz; sd.save[2 * MH + o] = nn; sd.save[3 * MH + o] = gh_n;
     }
-    sd.hout[(int64_t)m * H + col] = active ? hn : hp;
-    if (sd.out2) sd.out2[(int64_t)m * a.ld2 + col] = active ? hn : 0.f;
-}
-
-// Fused GRU cell, UNITS hidden units per workgroup.  UNITS = 16: three n-tiles (r, z, n).  UNITS = 8: two n-tiles laid
-// out [r0..7 | z0..7] and [n0..7 | n0..7]; the gates of one unit then sit in different lanes and are gathered through
-// the LDS reduction buffer.
-template <int WAVES, int UNITS>
-__global__ __launch_bounds__(WAVES * 64) void gru_step_kernel(GruStepArgs a) {
-    constexpr int NT = UNITS == 16 ? 3 : 2;
-    __shared__ __attribute__((aligned(16))) float red[WAVES * NT * 64 * 4];
-    const GruSide& sd = a.s[blockIdx.z];
-    const int lane = threadIdx.x & 63;
-    const int r = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.y * 16, u0 = blockIdx.x * UNITS;
-    const int H = a.H;
-    const float* ap[1];
-    const float* wp[NT];
-    ap[0] = sd.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + 4 * g;
-    if (UNITS == 16) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) wp[j] = sd.W + (int64_t)min(j * H + u0 + r, 3 * H - 1) * a.ldw + 4 * g;
-    } else {
-        const int u = min(u0 + (r & 7), H - 1);
-        wp[0] = sd.W + (int64_t)((r < 8 ? 0 : H) + u) * a.ldw + 4 * g;
-        wp[NT - 1] = sd.W + (int64_t)(2 * H + u) * a.ldw + 4 * g;
-    }
-    skinny_mma<WAVES, 1, NT>(ap, wp, a.K, red);
-    if (UNITS == 16) {
-        if (threadIdx.x >= 64) return;
-        const f32x4 S0 = skinny_sum<WAVES, NT>(red, 0, lane);
-        const f32x4 S1 = skinny_sum<WAVES, NT>(red, 1, lane);
-        const f32x4 S2 = skinny_sum<WAVES, NT>(red, NT - 1, lane);
-        const int col = u0 + r;
-        if (col >= H) return;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + 4 * g + i;
-            if (m < a.M) gru_cell_epilogue(a, sd, m, col, S0[i], S1[i], S2[i]);
-        }
-    } else {
-        if (threadIdx.x >= 128) return;
-        const int mrow = threadIdx.x >> 3, u = threadIdx.x & 7;       // 16 rows x 8 units
-        const int m = m0 + mrow, col = u0 + u;
-        if (m >= a.M || col >= H) return;
-        const float c_r = skinny_sum1<WAVES, NT>(red, 0, mrow, u);
-        const float c_z = skinny_sum1<WAVES, NT>(red, 0, mrow, 8 + u);
-        const float c_n = skinny_sum1<WAVES, NT>(red, NT - 1, mrow, u);
-        gru_cell_epilogue(a, sd, m, col, c_r, c_z, c_n);
-    }
+    sd.hout[o] = active ? hn : hp;
+    if (sd.out2) sd.out2[(int64_t)em * a.ld2 + ej] = active ? hn : 0.f;
 }
 
 // dh = A WT^T + addend, then the GRU cell backward (elementwise) that consumes dh -- see common.h.
-template <int WAVES, int COLS>
+// Same structure: 256 outputs finished by 256 threads, epilogue operands prefetched under the product.
+template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gru_bwd_step_kernel(GruBwdStepArgs a) {
     __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4];
     const GruBwdStepSide& sd = a.s[blockIdx.z];
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.y * 16, nb = blockIdx.x * COLS;
+    const int m0 = blockIdx.y * 16, nb = blockIdx.x * 16;
     const int H = a.H;
+    const int erow = (threadIdx.x >> 4) & 15, ecol = threadIdx.x & 15;
+    const int em = m0 + erow, ej = nb + ecol;
+    const bool eok = threadIdx.x < 256 && em < a.M && ej < H;
+    const int64_t o = (int64_t)em * H + ej;
+    const int64_t MH = (int64_t)a.M * H;
+    float add = 0.f, e = 0.f, rr = 0.f, zz = 0.f, nn = 0.f, hn = 0.f, hp = 0.f;
+    bool active = true;
+    if (eok) {
+        if (sd.addend) add = sd.addend[o];
+        if (a.has_cell) {
+            if (a.lengths) active = sd.t < a.lengths[em];
+            if (sd.dh_add) {
+                e = sd.dh_add[(int64_t)em * a.ld_add + ej];
+                if (a.rng && a.p > 0.f) e *= vag_drop_mul(a.rng, a.sid, (uint64_t)em * a.ld_add + sd.drop_idx0 + ej, a.p);
+            }
+            rr = sd.save[o]; zz = sd.save[MH + o]; nn = sd.save[2 * MH + o]; hn = sd.save[3 * MH + o];
+            hp = sd.hprev[(int64_t)em * a.ldh + ej];
+        }
+    }
     const float* ap[1];
     const float* wp[1];
     ap[0] = sd.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + 4 * g;
-    wp[0] = sd.WT + (int64_t)min(nb + (COLS == 16 ? r : (r & 7)), H - 1) * a.ldw + 4 * g;
+    wp[0] = sd.WT + (int64_t)min(nb + r, H - 1) * a.ldw + 4 * g;
     skinny_mma<WAVES, 1, 1>(ap, wp, a.K, red);
-    if (threadIdx.x >= 64) return;
-    const f32x4 S = skinny_sum<WAVES, 1>(red, 0, lane);
-    const int j = nb + r;
-    if (r >= COLS || j >= H) return;
-    const int64_t MH = (int64_t)a.M * H;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + 4 * g + i;
-        if (m >= a.M) continue;
-        const int64_t o = (int64_t)m * H + j;
-        float dh = S[i];
-        if (sd.addend) dh += sd.addend[o];
-        if (!a.has_cell) {
-            sd.dh_out[o] = dh;
-            continue;
-        }
-        float* gi = sd.dgi + (int64_t)m * a.ldgi + j;
-        float* gh = sd.dgh + (int64_t)m * a.ldgh + j;
-        const bool active = a.lengths ? (sd.t < a.lengths[m]) : true;
-        if (!active) {
-            gi[0] = 0.f; gi[H] = 0.f; gi[2 * H] = 0.f;
-            gh[0] = 0.f; gh[H] = 0.f; gh[2 * H] = 0.f;
-            sd.dh_direct[o] = dh;
-            continue;
-        }
-        if (sd.dh_add) {
-            float e = sd.dh_add[(int64_t)m * a.ld_add + j];
-            if (a.rng && a.p > 0.f) e *= vag_drop_mul(a.rng, a.sid, (uint64_t)m * a.ld_add + sd.drop_idx0 + j, a.p);
-            dh += e;
-        }
-        const float rr = sd.save[o], zz = sd.save[MH + o], nn = sd.save[2 * MH + o], hn = sd.save[3 * MH + o];
-        const float hp = sd.hprev[(int64_t)m * a.ldh + j];
-        const float dn_pre = dh * (1.f - zz) * (1.f - nn * nn);
-        const float dz_pre = dh * (hp - nn) * zz * (1.f - zz);
-        const float dr_pre = dn_pre * hn * rr * (1.f - rr);
-        gi[0] = dr_pre; gi[H] = dz_pre; gi[2 * H] = dn_pre;
-        gh[0] = dr_pre; gh[H] = dz_pre; gh[2 * H] = dn_pre * rr;
-        sd.dh_direct[o] = dh * zz;
+    if (!eok) return;
+    float dh = skinny_sum1<WAVES, 1>(red, 0, erow, ecol) + add;
+    if (!a.has_cell) {
+        sd.dh_out[o] = dh;
+        return;
     }
+    float* gi = sd.dgi + (int64_t)em * a.ldgi + ej;
+    float* gh = sd.dgh + (int64_t)em * a.ldgh + ej;
+    if (!active) {
+        gi[0] = 0.f; gi[H] = 0.f; gi[2 * H] = 0.f;
+        gh[0] = 0.f; gh[H] = 0.f; gh[2 * H] = 0.f;
+        sd.dh_direct[o] = dh;
+        return;
+    }
+    dh += e;
+    const float dn_pre = dh * (1.f - zz) * (1.f - nn * nn);
+    const float dz_pre = dh * (hp - nn) * zz * (1.f - zz);
+    const float dr_pre = dn_pre * hn * rr * (1.f - rr);
+    gi[0] = dr_pre; gi[H] = dz_pre; gi[2 * H] = dn_pre;
+    gh[0] = dr_pre; gh[H] = dz_pre; gh[2 * H] = dn_pre * rr;
+    sd.dh_direct[o] = dh * zz;
 }
 
 static bool skinny_ok(const float* A, int64_t lda, const float* W, int64_t ldw, int64_t K) {
     return aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && K % 4 == 0 && K >= 4;
 }
 
-template <int MT, int COLS>
 static void skinny_plain_go(const SkinnyArgs& a, hipStream_t stream) {
-    dim3 grid((unsigned)cdiv64(a.N, COLS), (unsigned)cdiv64(a.M, 16 * MT), 1);
-    if (a.K <= 256) hipLaunchKernelGGL((skinny_plain_kernel<4, MT, COLS>), grid, dim3(256), 0, stream, a);
-    else if (a.K <= 1024) hipLaunchKernelGGL((skinny_plain_kernel<8, MT, COLS>), grid, dim3(512), 0, stream, a);
-    else hipLaunchKernelGGL((skinny_plain_kernel<16, MT, COLS>), grid, dim3(1024), 0, stream, a);
+    dim3 grid((unsigned)cdiv64(a.N, 16), (unsigned)cdiv64(a.M, 16), 1);
+    if (a.K <= 256) hipLaunchKernelGGL((skinny_plain_kernel<4>), grid, dim3(256), 0, stream, a);
+    else if (a.K <= 1024) hipLaunchKernelGGL((skinny_plain_kernel<8>), grid, dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((skinny_plain_kernel<16>), grid, dim3(1024), 0, stream, a);
 }
 
 int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
@@ -760,7 +736,7 @@ int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
     // Tile choice, from measurements (tools/exp_tiles.py, tools/skinny_probe.hip): these launches are bound by the bytes
     // REQUESTED chip-wide (L2 is dropped at every kernel boundary; ~6.3 TB/s aggregate, ~50 GB/s per CU), duplicates
     // included, so wider/taller tiles or half tiles do not pay at M <= 128; 16x16 with K split over the waves it is.
-    skinny_plain_go<1, 16>(a, stream);
+    skinny_plain_go(a, stream);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
@@ -771,28 +747,13 @@ int vag_gru_step_launch(const GruStepArgs& a, int nz, hipStream_t stream) {
         VAG_CHECK_ARG(a.s[z].A && a.s[z].W && a.s[z].other && a.s[z].hprev && a.s[z].hout);
         VAG_CHECK_ARG(skinny_ok(a.s[z].A, a.lda, a.s[z].W, a.ldw, a.K));
     }
-    // 8 hidden units per workgroup (twice the workgroups) was measured to be no faster: requested bytes, not CU count,
-    // bound these launches.  Kept selectable for experiments.
-    const bool units8 = getenv("VAG_GRU_UNITS8") != nullptr && a.H % 8 == 0;
-    if (units8) {
-        dim3 grid((unsigned)cdiv64(a.H, 8), (unsigned)cdiv64(a.M, 16), (unsigned)nz);
-        if (a.K <= 256) hipLaunchKernelGGL((gru_step_kernel<4, 8>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((gru_step_kernel<8, 8>), grid, dim3(512), 0, stream, a);
-    } else {
-        dim3 grid((unsigned)cdiv64(a.H, 16), (unsigned)cdiv64(a.M, 16), (unsigned)nz);
-        if (a.K <= 256) hipLaunchKernelGGL((gru_step_kernel<4, 16>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((gru_step_kernel<8, 16>), grid, dim3(512), 0, stream, a);
-    }
+    // tile choice from measurements (tools/exp_tiles.py, tools/skinny_probe.hip): 16 units x 16 rows; half tiles on
+    // twice the CUs were no faster (the launch is paced by load requests issued chip-wide, duplicates included).
+    dim3 grid((unsigned)cdiv64(a.H, 16), (unsigned)cdiv64(a.M, 16), (unsigned)nz);
+    if (a.K <= 256) hipLaunchKernelGGL((gru_step_kernel<4>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((gru_step_kernel<8>), grid, dim3(512), 0, stream, a);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
-}
-
-template <int COLS>
-static void gru_bwd_step_go(const GruBwdStepArgs& a, int nz, hipStream_t stream) {
-    dim3 grid((unsigned)cdiv64(a.H, COLS), (unsigned)cdiv64(a.M, 16), (unsigned)nz);
-    if (a.K <= 256) hipLaunchKernelGGL((gru_bwd_step_kernel<4, COLS>), grid, dim3(256), 0, stream, a);
-    else if (a.K <= 1024) hipLaunchKernelGGL((gru_bwd_step_kernel<8, COLS>), grid, dim3(512), 0, stream, a);
-    else hipLaunchKernelGGL((gru_bwd_step_kernel<16, COLS>), grid, dim3(1024), 0, stream, a);
 }
 
 int vag_gru_bwd_step_launch(const GruBwdStepArgs& a, int nz, hipStream_t stream) {
@@ -802,8 +763,10 @@ int vag_gru_bwd_step_launch(const GruBwdStepArgs& a, int nz, hipStream_t stream)
         if (a.has_cell) VAG_CHECK_ARG(a.s[z].save && a.s[z].hprev && a.s[z].dgi && a.s[z].dgh && a.s[z].dh_direct);
         else VAG_CHECK_ARG(a.s[z].dh_out != nullptr);
     }
-    if (getenv("VAG_GRU_COLS8") != nullptr) gru_bwd_step_go<8>(a, nz, stream);
-    else gru_bwd_step_go<16>(a, nz, stream);
+    dim3 grid((unsigned)cdiv64(a.H, 16), (unsigned)cdiv64(a.M, 16), (unsigned)nz);
+    if (a.K <= 256) hipLaunchKernelGGL((gru_bwd_step_kernel<4>), grid, dim3(256), 0, stream, a);
+    else if (a.K <= 1024) hipLaunchKernelGGL((gru_bwd_step_kernel<8>), grid, dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((gru_bwd_step_kernel<16>), grid, dim3(1024), 0, stream, a);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
