@@ -402,7 +402,8 @@ static CgruBwdScratch cgru_bwd_scratch(float* p, int64_t B, int64_t Ts, int64_t 
     w.dgi2 = take(R * 3 * H); w.dqgh = take(R * Q);
     w.dalpha = take(B * Ts); w.ds = take(R * Ts);
     w.dgi1 = take(R * 3 * H); w.dgh1 = take(R * 3 * H);
-    w.dh1d = take(B * H); w.carry = take(B * H); w.de = take(R * E); w.dvp = take(B * C); w.dwp = take(3 * H * C);
+    w.dh1d = take(B * H); w.carry = take(B * H); w.de = take(R * E); w.dvp = take(VAG_POST_CHUNKS(Ts) * B * C);
+    w.dwp = take(3 * H * C);
     w.total = o;
     return w;
 }
@@ -492,7 +493,7 @@ int vag_cgru_attn_decode_seq_bwd_weights(const float* h0, const int64_t* tok, va
     const int64_t C = 2 * H, Q = C + 3 * H, R = Tt * B;
     CgruWs k = cgru_ws(ws, B, Ts, Tt, E, H);
     CgruBwdScratch z = cgru_bwd_scratch(scratch, B, Ts, Tt, E, H);
-    VAG_TRY(vag_colsum_launch(z.dvp, B, C, C, g.attn_v, s));
+    VAG_TRY(vag_colsum_launch(z.dvp, VAG_POST_CHUNKS(Ts) * B, C, C, g.attn_v, s));
     const float* dgh2 = z.dqgh + C;      // (R,3H) row stride Q
     VAG_TRY(gemm_tn_acc(3 * H, H, R, dgh2, Q, k.h1, H, g.gru2.w_hh, H, s));
     VAG_TRY(vag_colsum_launch(dgh2, R, 3 * H, Q, g.gru2.b_hh, s));
@@ -718,7 +719,7 @@ static ImgWs imagine_ws(float* p, int64_t B, int64_t Ts, int64_t C, int method) 
     int64_t o = 0;
     auto take = [&](int64_t n) { float* q = p ? p + o : nullptr; o += (n + 3) & ~3ll; return q; };
     w.u = take(B * C); w.w = take(B * C); w.scores = take(B * Ts); w.dalpha = take(B * Ts); w.de = take(B * Ts);
-    w.dw = take(B * C); w.du = take(B * C); w.dvp = take(B * C);
+    w.dw = take(B * C); w.du = take(B * C); w.dvp = take(VAG_POST_CHUNKS(Ts) * B * C);
     w.pre = method == 1 ? take(B * Ts * C) : nullptr;
     w.dpre = method == 1 ? take(B * Ts * C) : nullptr;
     w.total = o;
@@ -768,7 +769,7 @@ int vag_imagine_attn_ctx_bwd(const float* im_emb, const float* enc, const float*
     } else {
         VAG_TRY(vag_outer2_launch(alpha, d_ctx, nullptr, nullptr, B, Ts, C, d_enc, accumulate_enc, s));
         VAG_TRY(vag_attn_post_bwd_launch(w.pre, w.u, C, mlp_w, w.de, alpha, nullptr, B, Ts, 1, C, w.dpre, w.dvp, nullptr, 0, s));
-        VAG_TRY(vag_colsum_launch(w.dvp, B, C, C, g_mlp_w, s));
+        VAG_TRY(vag_colsum_launch(w.dvp, VAG_POST_CHUNKS(Ts) * B, C, C, g_mlp_w, s));
         VAG_TRY(vag_attn_dq_launch(w.pre, w.u, C, mlp_w, nullptr, nullptr, w.de, B, Ts, C, w.du, C, s));
         VAG_TRY(gemm_nn(B * Ts, C, C, w.dpre, C, ctx2ctx, C, 1.f, d_enc, C, s));
         VAG_TRY(gemm_tn_acc(C, C, B * Ts, w.dpre, C, enc, C, g_ctx2ctx, C, s));

@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restr
     if (c >= C) return;
     const float vc = v[c];
     float dv = 0.f;
-    for (int s0 = 0; s0 < Ts; s0 += SC) {
+    {
+        const int s0 = blockIdx.z * SC;          // one chunk of SC source positions per block (grid.z chunks)
         float pv[SC], ape[SC], aen[SC];
 #pragma unroll
         for (int i = 0; i < SC; ++i) {
@@ -244,13 +245,13 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restr
             }
         }
     }
-    if (dvp) dvp[(int64_t)b * C + c] = dv;
+    if (dvp) dvp[((int64_t)blockIdx.z * B + b) * C + c] = dv;      // partial per chunk: rows z*B + b
 }
 int vag_attn_post_bwd_launch(const float* pe, const float* q_all, int64_t ldq, const float* v, const float* ds_all,
                              const float* alpha_all, const float* dc_all, int64_t B, int64_t Ts, int64_t Tt,
                              int64_t C, float* d_pe, float* dvp, float* d_enc, int accumulate_enc, hipStream_t s) {
     VAG_CHECK_ARG(pe && q_all && v && ds_all && alpha_all && d_pe && B > 0 && Ts > 0 && Tt > 0 && C > 0);
-    dim3 grid((unsigned)cdiv64(C, 256), (unsigned)B);
+    dim3 grid((unsigned)cdiv64(C, 256), (unsigned)B, (unsigned)cdiv64(Ts, SC));
     hipLaunchKernelGGL(attn_post_bwd_kernel, grid, dim3(256), 0, s, pe, q_all, v, ds_all, alpha_all, dc_all, (int)B,
                        (int)Ts, (int)Tt, (int)C, ldq, d_pe, dvp, d_enc, accumulate_enc);
     VAG_LAUNCH_CHECK();

@@ -52,6 +52,7 @@ int vag_rng_advance_launch(uint64_t* rng, hipStream_t s);
 int vag_copy2d_launch(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t rows, int64_t cols, hipStream_t s);
 
 // ---------------- attn.hip ----------------
+static inline int64_t VAG_POST_CHUNKS(int64_t Ts) { return (Ts + 7) / 8; }
 // mode 0: scores[n,s] = sum_c v[c] tanh(pe[b,s,c] + q[n,c]); mode 1: scores[n,s] = sum_c q[n,c] * pe[b,s,c].
 // b = n / rps.  mask (Bsrc,Ts) float or NULL: masked positions get -inf.
 // q row stride ldq (>= C).
@@ -68,7 +69,8 @@ int vag_softmax_bwd_launch(const float* alpha, const float* dalpha, int64_t N, i
 int vag_attn_dq_launch(const float* pe, const float* q, int64_t ldq, const float* v, const float* alpha,
                        const float* dalpha, float* dscore, int64_t N, int64_t Ts, int64_t C, float* dq, int64_t lddq,
                        hipStream_t s);
-// After the time loop: d_pe[b,s,c] = v[c] sum_t ds[t,b,s] (1-th^2);  dvp[b,c] = sum_{t,s} ds*th;
+// After the time loop: d_pe[b,s,c] = v[c] sum_t ds[t,b,s] (1-th^2);  dvp[(z*B+b),c] = sum_{t, s in chunk z} ds*th
+// (VAG_POST_CHUNKS(Ts) = ceil(Ts/8) chunk rows per batch row; column-sum all rows for dv);
 // d_enc[b,s,c] (+)= sum_t alpha[t,b,s] dc[t,b,c]   (skipped when dc == NULL)
 int vag_attn_post_bwd_launch(const float* pe, const float* q_all, int64_t ldq, const float* v, const float* ds_all,
                              const float* alpha_all, const float* dc_all, int64_t B, int64_t Ts, int64_t Tt,
