@@ -177,13 +177,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # VAG_DP_SMOKE=1: rehearse the multi-rank code path on ONE GPU (all ranks on cuda:0, gloo transport)
+    smoke_dp = os.environ.get("VAG_DP_SMOKE") == "1"
+    if smoke_dp:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if smoke_dp:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
 
     import random
     from vagnmt_hip.trainer import TrainStep
@@ -259,7 +266,7 @@ def main():
                        "global_batch": c["B"] * world, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph, "final_loss": loss},
             # dominant kernel by total time (profiles/): the fused GRU-cell step kernel, decoder gru_1 shape
-            "roofline": {"bound": "hbm", "kernel": "gru_step_kernel<8,16> (M=64, H=512, K=512)",
+            "roofline": {"bound": "hbm", "kernel": "gru_step_kernel<8> (fused GRU cell, M=64, H=512, K=512)",
                          "achieved": cell_bytes / fam["gru_cell"] / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": cell_bytes / fam["gru_cell"] / HBM_PEAK,
                          "traffic": pmc.get("gru_step_kernel_bytes_per_launch"),
