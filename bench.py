@@ -170,6 +170,7 @@ def main():
     ap.add_argument("--tfr", type=float, default=1.0, help="teacher forcing ratio (headline: 1.0)")
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="debug: disable the reference dropouts")
+    ap.add_argument("--overlap", type=int, default=-1, help="1/0: force the side-stream overlap of weight-gradient products")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -203,7 +204,8 @@ def main():
     crit_mt = torch.nn.NLLLoss(weight=vw, reduction="none")
     crit_vse = PairwiseRankingLoss(margin=0.1)
     ts = TrainStep(model, crit_mt, crit_vse, lr=4e-4, weight_decay=1e-5, clip=1.0, teacher_force_ratio=args.tfr,
-                   use_graph=not args.no_graph, process_group=pg, world_size=world)
+                   use_graph=not args.no_graph, process_group=pg, world_size=world,
+                   **({} if args.overlap < 0 else {"overlap": bool(args.overlap)}))
     src, lens, tgt, im = make_batch(c, rank, dev, ragged=args.ragged)
     lens_t = torch.tensor(lens, dtype=torch.int32, device=dev)
 

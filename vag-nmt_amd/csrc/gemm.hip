@@ -376,6 +376,8 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(GemmArgs a) {
         }
 }
 
+// (A double-buffered variant -- 110 KB of LDS, one block per CU, split/store of tile t+1 issued between the k-halves of
+// tile t -- measured 6-9 % slower than this single-stage kernel at two blocks per CU, and was dropped.)
 static int gemm_split_dispatch(const GemmArgs& g, bool akc, bool bkc, bool vec, dim3 grid, hipStream_t s) {
 #define VAG_SPLIT_CASE(AK, BKc, V)                                                                    \
     if (akc == AK && bkc == BKc && vec == V) {                                                        \
