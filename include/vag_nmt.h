@@ -242,6 +242,13 @@ int vag_rank_loss_fwd(const float* im, const float* s, int64_t B, int64_t S, flo
 int vag_rank_loss_bwd(const float* im, const float* s, const float* G, const float* d_loss, int64_t B, int64_t S,
                       float* d_im, float* d_s, vag_stream_t stream);
 
+/* ---- next: retrieval evaluation, utils/im_retrieval_eval.py:4-57 --------------------------- */
+/* The reference loops over N queries with one torch.mm + torch.sort each; here: one (N,S)x(S,N) product into
+ * `scores` (N,N scratch) and one rank kernel.  ranks[i] = 0-based position of key i in the descending sort of
+ * scores[i,:].  t2i: queries = caption embeddings, keys = image embeddings; i2t: the other way round. */
+int vag_retrieval_ranks(const float* queries, const float* keys, int64_t N, int64_t S, float* scores, int32_t* ranks,
+                        vag_stream_t stream);
+
 /* ---- a2: decoder initial state, models/...V11.py:118 / NMT_Seq2Seq_Beam_V2.py:85 ---------------------- */
 /* x = split*ctx + (1-split)*sum_t enc/sum_t mask (ctx NULL: text-only, x = mean);  h0 = tanh(W x + b).
  * xmix (B,C) is saved. */

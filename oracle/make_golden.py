@@ -206,6 +206,15 @@ def run_losses():
     x[2] = 0
     out["l2norm/x"] = np32(x)
     out["l2norm/y"] = np32(l2norm(x))
+    # retrieval metrics (utils/im_retrieval_eval.py) on correlated random embeddings
+    import machine_translation_vision.utils.im_retrieval_eval as RE
+    for N in (7, 100):
+        im = l2norm(torch.randn(N, 16, generator=g))
+        cap = l2norm(im + 0.6 * torch.randn(N, 16, generator=g))
+        out["retr%d/im" % N] = np32(im)
+        out["retr%d/cap" % N] = np32(cap)
+        out["retr%d/t2i" % N] = np.array(RE.t2i(im, cap), dtype=np.float64)
+        out["retr%d/i2t" % N] = np.array(RE.i2t(im, cap), dtype=np.float64)
     np.savez_compressed(os.path.join(OUT, "losses.npz"), **out)
     print("losses.npz written")
 

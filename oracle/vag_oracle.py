@@ -432,3 +432,29 @@ def train_step(P, src, lengths, tgt, im=None, *, clip=1.0, lr=4e-4, weight_decay
     with torch.no_grad():
         newP = adam_step({k: v.detach() for k, v in leaves.items()}, cg, state, lr=lr, weight_decay=weight_decay)
     return out, grads, total, newP, state
+
+
+# --------------------------------------------------------------------------
+# retrieval evaluation  (utils/im_retrieval_eval.py:4-57)
+# --------------------------------------------------------------------------
+def retrieval_ranks(queries, keys):
+    """rank[i] = position of key i in the descending sort of queries[i] . keys^T  (:15-24)."""
+    d = queries @ keys.t()
+    inds = torch.sort(d, dim=1, descending=True, stable=True)[1]
+    return (inds == torch.arange(d.shape[0]).unsqueeze(1)).nonzero()[:, 1]
+
+
+def retrieval_metrics(ranks):
+    """(R@1, R@5, R@10, median rank)  (:25-30)."""
+    import numpy as np
+    r = ranks.numpy().astype("float64")
+    return (100.0 * (r < 1).sum() / len(r), 100.0 * (r < 5).sum() / len(r), 100.0 * (r < 10).sum() / len(r),
+            float(np.floor(np.median(r)) + 1))
+
+
+def t2i(images, captions):
+    return retrieval_metrics(retrieval_ranks(captions, images))
+
+
+def i2t(images, captions):
+    return retrieval_metrics(retrieval_ranks(images, captions))

@@ -140,10 +140,28 @@ def test_ranking_losses_and_l2norm():
     from machine_translation_vision.losses import PairwiseRankingLoss, ImageRetrievalRankingLoss
     from machine_translation_vision.utils.utils import l2norm
     z = dict(np.load(os.path.join(GOLDEN, "losses.npz")))
-    for key in [k for k in z if k.endswith("/im")]:
+    for key in [k for k in z if k.endswith("/im") and k.startswith("B")]:
         pre = key[:-3]
         mg = float(pre.split("_m")[1])
         im, s = torch.from_numpy(z[pre + "/im"]).cuda(), torch.from_numpy(z[pre + "/s"]).cuda()
         close(PairwiseRankingLoss(mg)(im, s), z[pre + "/pairwise"], what=pre)
         close(ImageRetrievalRankingLoss(mg)(im, s), z[pre + "/imageretrieval"], what=pre)
     close(l2norm(torch.from_numpy(z["l2norm/x"]).cuda()), z["l2norm/y"], 1e-6, "l2norm")
+
+
+def test_retrieval_metrics_t2i_i2t():
+    import os
+    from conftest import GOLDEN
+    from machine_translation_vision.utils import im_retrieval_eval as RE
+    z = dict(np.load(os.path.join(GOLDEN, "losses.npz")))
+    for N in (7, 100):
+        im, cap = torch.from_numpy(z["retr%d/im" % N]).cuda(), torch.from_numpy(z["retr%d/cap" % N]).cuda()
+        assert list(RE.t2i(im, cap)) == list(z["retr%d/t2i" % N])      # integer-exact statistics
+        assert list(RE.i2t(im, cap)) == list(z["retr%d/i2t" % N])
+    # a larger case against the oracle (N = 1014 like the Multi30K validation set)
+    from oracle import vag_oracle as O
+    g = torch.Generator().manual_seed(9)
+    im = torch.nn.functional.normalize(torch.randn(1014, 512, generator=g))
+    cap = torch.nn.functional.normalize(im + 0.08 * torch.randn(1014, 512, generator=g))
+    assert RE.t2i(im.cuda(), cap.cuda()) == O.t2i(im, cap)
+    assert RE.i2t(im.cuda(), cap.cuda()) == O.i2t(im, cap)

@@ -87,10 +87,18 @@ def test_decode(name):
 
 def test_ranking_losses_and_l2norm():
     z = dict(np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "losses.npz")))
-    for key in [k for k in z if k.endswith("/im")]:
+    for key in [k for k in z if k.endswith("/im") and k.startswith("B")]:
         pre = key[:-3]
         m = float(pre.split("_m")[1])
         im, s = torch.from_numpy(z[pre + "/im"]), torch.from_numpy(z[pre + "/s"])
         close(O.pairwise_ranking_loss(im, s, m), z[pre + "/pairwise"], 1e-6, what=pre)
         close(O.image_retrieval_ranking_loss(im, s, m), z[pre + "/imageretrieval"], 1e-6, what=pre)
     close(O.l2norm(torch.from_numpy(z["l2norm/x"])), z["l2norm/y"], 1e-7, what="l2norm")
+
+
+def test_retrieval_metrics():
+    z = dict(np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "losses.npz")))
+    for N in (7, 100):
+        im, cap = torch.from_numpy(z["retr%d/im" % N]), torch.from_numpy(z["retr%d/cap" % N])
+        assert list(O.t2i(im, cap)) == list(z["retr%d/t2i" % N])
+        assert list(O.i2t(im, cap)) == list(z["retr%d/i2t" % N])

@@ -800,6 +800,17 @@ int vag_rank_loss_bwd(const float* im, const float* sv, const float* G, const fl
 }
 
 // =====================================================================================================
+// retrieval evaluation: utils/im_retrieval_eval.py:4-57
+// =====================================================================================================
+int vag_retrieval_ranks(const float* queries, const float* keys, int64_t N, int64_t S, float* scores, int32_t* ranks,
+                        vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(queries && keys && scores && ranks && N > 0 && S > 0);
+    VAG_TRY(vag_gemm_launch(N, N, S, 1.f, queries, S, 1, keys, 1, S, 0.f, scores, N, nullptr, 0, s));   // one (N,S)x(S,N) product
+    return vag_retrieval_rank_launch(scores, N, ranks, s);
+}
+
+// =====================================================================================================
 // decoder initial state
 // =====================================================================================================
 int vag_dec_init_fwd(const float* enc, const float* mask, const float* ctx, float split, const float* W, const float* b,

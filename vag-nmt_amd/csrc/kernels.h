@@ -100,6 +100,7 @@ int vag_l2norm_fwd_launch(const float* y, int64_t B, int64_t S, float* nrm, floa
 int vag_l2norm_bwd_launch(const float* y, const float* nrm, const float* out, const float* d_out, int64_t B, int64_t S,
                           int act, float* dy, hipStream_t s);
 int vag_rank_loss_launch(const float* scores, int64_t B, float margin, int kind, float* G, float* loss, hipStream_t s);
+int vag_retrieval_rank_launch(const float* scores, int64_t N, int* ranks, hipStream_t s);
 // x[i] *= *scalar
 int vag_scale_by_dev_launch(float* x, int64_t n, const float* scalar, hipStream_t s);
 

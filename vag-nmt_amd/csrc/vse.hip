@@ -109,3 +109,27 @@ int vag_scale_by_dev_launch(float* x, int64_t n, const float* scalar, hipStream_
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
+
+// Retrieval ranks (utils/im_retrieval_eval.py:15-24): rank[i] = position of key i in the descending sort of scores[i,:]
+// = #{j : S_ij > S_ii} (+ equal scores at smaller j, the order a stable descending sort gives).  One wave per query.
+__global__ __launch_bounds__(256) void retrieval_rank_kernel(const float* __restrict__ S, int N, int* __restrict__ ranks) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const float* row = S + (int64_t)i * N;
+    const float d = row[i];
+    int cnt = 0;
+    for (int j = lane; j < N; j += 64) {
+        const float v = row[j];
+        cnt += (v > d) || (v == d && j < i);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) ranks[i] = cnt;
+}
+int vag_retrieval_rank_launch(const float* scores, int64_t N, int* ranks, hipStream_t s) {
+    VAG_CHECK_ARG(scores && ranks && N > 0 && N < (1ll << 30));
+    hipLaunchKernelGGL(retrieval_rank_kernel, dim3((unsigned)cdiv64(N, 4)), dim3(256), 0, s, scores, (int)N, ranks);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
