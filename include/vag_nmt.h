@@ -242,6 +242,12 @@ int vag_rank_loss_fwd(const float* im, const float* s, int64_t B, int64_t S, flo
 int vag_rank_loss_bwd(const float* im, const float* s, const float* G, const float* d_loss, int64_t B, int64_t S,
                       float* d_im, float* d_s, vag_stream_t stream);
 
+/* ---- next: batch assembly from a device-resident corpus, preprocessing.py:308-384 ---------- */
+/* out[i, 0:w] = in[idx[i], 0:w] for int64 token matrices (in: (N, ld) padded with 0).  Image-feature rows use
+ * vag_embed_fwd (a row gather of an fp32 matrix). */
+int vag_gather_rows_i64(const int64_t* in, int64_t ld, const int64_t* idx, int64_t rows, int64_t w, int64_t* out,
+                        vag_stream_t stream);
+
 /* ---- next: retrieval evaluation, utils/im_retrieval_eval.py:4-57 --------------------------- */
 /* The reference loops over N queries with one torch.mm + torch.sort each; here: one (N,S)x(S,N) product into
  * `scores` (N,N scratch) and one rank kernel.  ranks[i] = 0-based position of key i in the descending sort of

@@ -219,6 +219,23 @@ def run_losses():
     print("losses.npz written")
 
 
+def run_sampler():
+    """Batches produced by the reference's BucketBatchSampler (samplers/bucket.py) under a fixed numpy seed."""
+    from machine_translation_vision.samplers.bucket import BucketBatchSampler
+    rs = np.random.RandomState(3)
+    lengths = rs.randint(1, 13, size=203)
+    out = {"lengths": lengths}
+    for bs in (16, 64):
+        smp = BucketBatchSampler(list(lengths), bs)
+        np.random.seed(5)
+        batches = [np.asarray(b) for b in smp]
+        out["bs%d/flat" % bs] = np.concatenate(batches)
+        out["bs%d/sizes" % bs] = np.array([len(b) for b in batches])
+        out["bs%d/n_batches" % bs] = np.array([len(smp)])
+    np.savez_compressed(os.path.join(OUT, "sampler.npz"), **out)
+    print("sampler.npz written")
+
+
 def main():
     sys.path.insert(0, REF)
     sys.dont_write_bytecode = True
@@ -238,6 +255,7 @@ def main():
     run_case("mm_dot_full_len_f32", "mm", 3, (40, 44, 64, 16, 32, 16, 4, 6, 6), attn="dot", tied=True,
              ragged=False, beams=(3,), max_len=8)
     run_losses()
+    run_sampler()
 
 
 if __name__ == "__main__":

@@ -458,3 +458,22 @@ def t2i(images, captions):
 
 def i2t(images, captions):
     return retrieval_metrics(retrieval_ranks(images, captions))
+
+
+# --------------------------------------------------------------------------
+# batch assembly  (preprocessing.py:308-384 data_generator_tl_mtv; restated from the source text -- the module
+# itself cannot be imported here (it needs nltk), so this function is NOT pinned by a reference run)
+# --------------------------------------------------------------------------
+def assemble_batch(data_pairs, data_im, bidx):
+    import numpy as np
+    xs = [data_pairs[i][0] for i in bidx]
+    ys = [data_pairs[i][1] for i in bidx]
+    x_length = max(len(x) for x in xs)                                   # :346
+    y_length = max(len(y) for y in ys)
+    x_lens = [len(x) for x in xs]
+    order = [i for i in reversed(list(np.argsort(x_lens)))]              # :354-356
+    pad = lambda seq, n: list(seq) + [0] * (n - len(seq))                 # pad_seq
+    bx = torch.tensor([pad(xs[i], x_length) for i in order], dtype=torch.long)
+    by = torch.tensor([pad(ys[i], y_length) for i in order], dtype=torch.long)
+    bim = torch.from_numpy(np.asarray(data_im)[np.asarray(bidx)][order]).float() if data_im is not None else None   # :370-372
+    return bx, by, bim, list(reversed(sorted(x_lens))), [len(ys[i]) for i in order]              # :384

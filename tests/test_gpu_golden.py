@@ -165,3 +165,31 @@ def test_retrieval_metrics_t2i_i2t():
     cap = torch.nn.functional.normalize(im + 0.08 * torch.randn(1014, 512, generator=g))
     assert RE.t2i(im.cuda(), cap.cuda()) == O.t2i(im, cap)
     assert RE.i2t(im.cuda(), cap.cuda()) == O.i2t(im, cap)
+
+
+def test_device_resident_batch_pipeline():
+    """vagnmt_hip.data: batches assembled on the device equal the host restatement of preprocessing.py:308-384."""
+    from vagnmt_hip.data import DeviceCorpus, data_generator_tl_mtv
+    from oracle import vag_oracle as O
+    rs = np.random.RandomState(0)
+    N = 150
+    pairs = [[list(rs.randint(4, 50, size=rs.randint(1, 9))) + [3], list(rs.randint(4, 60, size=rs.randint(1, 7))) + [3]]
+             for _ in range(N)]
+    feats = rs.rand(N, 24).astype(np.float32)
+    corpus = DeviceCorpus(pairs, feats, torch.device("cuda:0"))
+    np.random.seed(11)
+    got = list(data_generator_tl_mtv(corpus, 16))
+    np.random.seed(11)
+    from machine_translation_vision.samplers import BucketBatchSampler
+    want = [O.assemble_batch(pairs, feats, b) for b in BucketBatchSampler([len(p[1]) for p in pairs], 16)]
+    assert len(got) == len(want) and sum(g[0].shape[0] for g in got) == N
+    for g, w in zip(got, want):
+        assert torch.equal(g[0].cpu(), w[0]) and torch.equal(g[1].cpu(), w[1]) and torch.equal(g[2].cpu(), w[2])
+        assert g[3] == w[3] and g[4] == w[4]
+        assert g[3] == sorted(g[3], reverse=True) and len(set(g[4])) == 1
+    # data-parallel sharding: ranks see disjoint batches that together cover the epoch
+    np.random.seed(11)
+    r0 = list(data_generator_tl_mtv(corpus, 16, rank=0, world_size=2))
+    np.random.seed(11)
+    r1 = list(data_generator_tl_mtv(corpus, 16, rank=1, world_size=2))
+    assert len(r0) + len(r1) == len(got) and torch.equal(r0[0][0], got[0][0]) and torch.equal(r1[0][0], got[1][0])

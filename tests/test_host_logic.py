@@ -116,3 +116,53 @@ def test_optimizer_grouping_follows_reference_rule():
 def test_eos_cut():
     from machine_translation_vision.models._seq2seq import Seq2SeqBase
     assert Seq2SeqBase._cut([[5, 6, 3, 7], [3, 1], [4, 4, 4]]) == [[5, 6], [], [4, 4, 4]]
+
+
+def test_bucket_sampler_reproduces_reference_batches():
+    """tests/golden/sampler.npz: batches of the reference's own BucketBatchSampler under numpy seed 5."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from machine_translation_vision.samplers import BucketBatchSampler
+    z = dict(np.load(os.path.join(GOLDEN, "sampler.npz")))
+    lengths = list(z["lengths"])
+    for bs in (16, 64):
+        smp = BucketBatchSampler(lengths, bs)
+        assert len(smp) == int(z["bs%d/n_batches" % bs][0])
+        np.random.seed(5)
+        batches = [np.asarray(b) for b in smp]
+        assert [len(b) for b in batches] == list(z["bs%d/sizes" % bs])
+        assert np.array_equal(np.concatenate(batches), z["bs%d/flat" % bs])
+        for b in batches:                                   # every batch: equal lengths, at most bs samples
+            assert len(set(lengths[i] for i in b)) == 1 and len(b) <= bs
+        assert sorted(np.concatenate(batches).tolist()) == list(range(len(lengths)))   # each sample exactly once
+
+
+def test_checkpoint_roundtrip_with_optimizer_state(tmp_path):
+    from vagnmt_hip.checkpoint import load_checkpoint, save_checkpoint
+    from vagnmt_hip.trainer import TrainStep
+    V11, _ = models()
+    torch.manual_seed(0)
+    m = V11(50, 60, 96, 16, 16, 24, 20, 0.99, tied_emb=True)
+    ts = TrainStep(m, None, None, use_graph=False)              # flat buffers work on any device
+    ts.fp.m.copy_(torch.randn_like(ts.fp.m))
+    ts.fp.v.copy_(torch.rand_like(ts.fp.v))
+    ts.step_count.fill_(17)
+    ts.set_lr(8e-5)
+    path = str(tmp_path / "ck.pt")
+    save_checkpoint(path, m, ts, extra={"epoch": 3})
+    torch.manual_seed(1)
+    m2 = V11(50, 60, 96, 16, 16, 24, 20, 0.99, tied_emb=True)
+    ts2 = TrainStep(m2, None, None, use_graph=False)
+    ck = load_checkpoint(path, m2, ts2)
+    assert ck["extra"] == {"epoch": 3} and int(ts2.step_count) == 17 and ts2.lr == 8e-5
+    for (n1, p1), (n2, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2)
+    assert torch.equal(ts.fp.m, ts2.fp.m) and torch.equal(ts.fp.v, ts2.fp.v)
+    # a bare reference-named state_dict and a pickled module load as well
+    torch.save({k: v for k, v in m.state_dict().items()}, str(tmp_path / "sd.pt"))
+    m3 = V11(50, 60, 96, 16, 16, 24, 20, 0.99, tied_emb=True)
+    load_checkpoint(str(tmp_path / "sd.pt"), m3)
+    assert torch.equal(m3.decoder.attn.v, m.decoder.attn.v)
+    # parameters are still views of the flat buffer after loading (the fused optimiser keeps working)
+    assert m2.decoder.attn.v.data_ptr() == ts2.fp.flat[ts2.fp.offsets["decoder.attn.v"]:].data_ptr()

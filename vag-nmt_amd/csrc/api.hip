@@ -799,6 +799,12 @@ int vag_rank_loss_bwd(const float* im, const float* sv, const float* G, const fl
     return vag_scale_by_dev_launch(d_s, B * S, d_loss, s);
 }
 
+// batch assembly from a device-resident corpus (preprocessing.py:308-384)
+int vag_gather_rows_i64(const int64_t* in, int64_t ld, const int64_t* idx, int64_t rows, int64_t w, int64_t* out,
+                        vag_stream_t stream) {
+    return vag_gather_rows_i64_launch(in, ld, idx, rows, w, out, S_(stream));
+}
+
 // =====================================================================================================
 // retrieval evaluation: utils/im_retrieval_eval.py:4-57
 // =====================================================================================================

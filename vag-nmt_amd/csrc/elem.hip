@@ -265,3 +265,22 @@ int vag_copy2d_launch(const float* in, int64_t ldi, float* out, int64_t ldo, int
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
+
+// out[i, 0:w] = in[idx[i], 0:w]   (int64 token matrices; batch assembly from the device-resident corpus)
+__global__ __launch_bounds__(256) void gather_rows_i64_kernel(const int64_t* __restrict__ in, int64_t ld,
+                                                              const int64_t* __restrict__ idx, int64_t rows, int64_t w,
+                                                              int64_t* __restrict__ out) {
+    const int64_t total = rows * w;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / w, c = i - r * w;
+        out[i] = in[idx[r] * ld + c];
+    }
+}
+int vag_gather_rows_i64_launch(const int64_t* in, int64_t ld, const int64_t* idx, int64_t rows, int64_t w, int64_t* out,
+                               hipStream_t s) {
+    VAG_CHECK_ARG(in && idx && out && rows >= 0 && w >= 0 && w <= ld);
+    if (rows * w == 0) return VAG_OK;
+    hipLaunchKernelGGL(gather_rows_i64_kernel, grid1d(rows * w), dim3(256), 0, s, in, ld, idx, rows, w, out);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}

@@ -51,6 +51,9 @@ int vag_rng_advance_launch(uint64_t* rng, hipStream_t s);
 // out[i*ldo + j] = in[i*ldi + j] for a (rows x cols) block
 int vag_copy2d_launch(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t rows, int64_t cols, hipStream_t s);
 
+int vag_gather_rows_i64_launch(const int64_t* in, int64_t ld, const int64_t* idx, int64_t rows, int64_t w, int64_t* out,
+                               hipStream_t s);
+
 // ---------------- attn.hip ----------------
 static inline int64_t VAG_POST_CHUNKS(int64_t Ts) { return (Ts + 7) / 8; }
 // mode 0: scores[n,s] = sum_c v[c] tanh(pe[b,s,c] + q[n,c]); mode 1: scores[n,s] = sum_c q[n,c] * pe[b,s,c].

@@ -76,6 +76,7 @@ PROTOS = {
     "vag_imagine_attn_ctx_bwd": (I32, [P, P, P, P, P, P, I32, I64, I64, I64, I64, P, P, P, P, I32, P, P, P, P, P]),
     "vag_rank_loss_fwd": (I32, [P, P, I64, I64, F, I32, P, P, P, P]),
     "vag_rank_loss_bwd": (I32, [P, P, P, P, I64, I64, P, P, P]),
+    "vag_gather_rows_i64": (I32, [P, I64, P, I64, I64, P, P]),
     "vag_retrieval_ranks": (I32, [P, P, I64, I64, P, P, P]),
     "vag_dec_init_fwd": (I32, [P, P, P, F, P, P, I64, I64, I64, I64, P, P, P]),
     "vag_dec_init_bwd": (I32, [P, P, P, F, P, P, I64, I64, I64, I64, P, I32, P, P, P, P, P]),
