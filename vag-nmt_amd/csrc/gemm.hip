@@ -499,13 +499,31 @@ struct SkinnyArgs {
     const float* bias; const float* addend; int64_t ldadd; float* out; int64_t ldo; int act;
 };
 
-// MT 16-row m-tiles x NT 16-col n-tiles per workgroup; K split over the WAVES waves.  ap/wp are this lane's row
-// pointers (row = lane&15 of each tile, already offset by 4*(lane>>4) floats).  Partial sums of all waves end up in
-// red[wave][tile][lane][4] (C/D map of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4)+i).
+// Load pattern.  The MFMA wants lane l to hold row l&15, k-group l>>4, but a wave request whose lane QUADS each touch
+// a different row is processed at about half the rate of one whose quads read 64 contiguous bytes (measured,
+// tools/skinny_probe.hip: 11.5 -> 6.5 us for 64x512x2560).  So lane l LOADS row skinny_ldrow(l), 16-byte segment
+// l&3 (every quad = 64 contiguous bytes of one row), and the float4s are then moved to the MFMA's lanes with a fixed
+// permutation through ds_bpermute (no LDS storage; it swaps lane bits {0,1} with {4,5}).
+__device__ __forceinline__ int skinny_ldrow(int lane) { return 4 * ((lane >> 2) & 3) + (lane >> 4); }
+__device__ __forceinline__ int skinny_ldseg(int lane) { return lane & 3; }
+__device__ __forceinline__ float4 skinny_xpose(float4 v, int src4) {
+    float4 o;
+    o.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(v.x)));
+    o.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(v.y)));
+    o.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(v.z)));
+    o.w = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(v.w)));
+    return o;
+}
+
+// MT 16-row m-tiles x NT 16-col n-tiles per workgroup; K split over the WAVES waves.  ap/wp are this lane's LOAD
+// pointers (row skinny_ldrow(lane) of each tile, already offset by 4*skinny_ldseg(lane) floats).  Partial sums of all
+// waves end up in red[wave][tile][lane][4] (C/D map of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4)+i).
 template <int WAVES, int MT, int NT>
 __device__ __forceinline__ void skinny_mma(const float* const (&ap)[MT], const float* const (&wp)[NT], int K, float* red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 4;
+    const int g = skinny_ldseg(lane);
+    // MFMA lane (k-group G = lane>>4, row 4a+j = lane&15) takes the float4 loaded by lane 16j + 4a + G
+    const int src4 = 4 * (16 * (lane & 3) + (lane & 12) + (lane >> 4));
     const int kper = ((K + WAVES - 1) / WAVES + 15) & ~15;
     const int kbeg = wave * kper;
     const int kend = min(K, kbeg + kper);
@@ -532,6 +550,13 @@ __device__ __forceinline__ void skinny_mma(const float* const (&ap)[MT], const f
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 wv[j][u] = ok ? *reinterpret_cast<const float4*>(wp[j] + c0 + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[i][u] = skinny_xpose(av[i][u], src4);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wv[j][u] = skinny_xpose(wv[j][u], src4);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -580,7 +605,7 @@ template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void skinny_plain_kernel(SkinnyArgs a) {
     __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4];
     const int lane = threadIdx.x & 63;
-    const int r = lane & 15, g = lane >> 4;
+    const int r = skinny_ldrow(lane), g = skinny_ldseg(lane);
     const int m0 = blockIdx.y * 16, nb = blockIdx.x * 16;
     const int erow = (threadIdx.x >> 4) & 15, ecol = threadIdx.x & 15;
     const int em = m0 + erow, ej = nb + ecol;
@@ -610,7 +635,7 @@ __global__ __launch_bounds__(WAVES * 64) void gru_step_kernel(GruStepArgs a) {
     __shared__ __attribute__((aligned(16))) float red[WAVES * NT * 64 * 4];
     const GruSide& sd = a.s[blockIdx.z];
     const int lane = threadIdx.x & 63;
-    const int r = lane & 15, g = lane >> 4;
+    const int r = skinny_ldrow(lane), g = skinny_ldseg(lane);
     const int m0 = blockIdx.y * 16, u0 = blockIdx.x * 16;
     const int H = a.H;
     // epilogue operands of thread t < 256: output (row m0 + t/16, unit u0 + t%16)
@@ -658,7 +683,7 @@ __global__ __launch_bounds__(WAVES * 64) void gru_bwd_step_kernel(GruBwdStepArgs
     __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4];
     const GruBwdStepSide& sd = a.s[blockIdx.z];
     const int lane = threadIdx.x & 63;
-    const int r = lane & 15, g = lane >> 4;
+    const int r = skinny_ldrow(lane), g = skinny_ldseg(lane);
     const int m0 = blockIdx.y * 16, nb = blockIdx.x * 16;
     const int H = a.H;
     const int erow = (threadIdx.x >> 4) & 15, ecol = threadIdx.x & 15;
