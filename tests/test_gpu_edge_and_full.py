@@ -90,7 +90,7 @@ def test_cfg2_ragged_lengths_and_properties():
         assert torch.allclose(enc2, enc[:, perm.cuda()], atol=1e-6)
 
 
-@pytest.mark.parametrize("case", ["b1", "t1", "odd", "text_b1"])
+@pytest.mark.parametrize("case", ["b1", "t1", "odd", "text_b1", "wide"])
 def test_edge_shapes(case):
     if case == "b1":        # a bucket's last batch can hold a single sentence (samplers/bucket.py:59-60,93)
         lens = [5]
@@ -106,6 +106,11 @@ def test_edge_shapes(case):
         run_both(m, src, lens, tgt, im)
         m2, _, _, _ = make(51, 67, 100, 20, 28, 24, 5, 9, 7, lens, attn="mlp", tied=False)
         run_both(m2, src, lens, tgt, im, teacher=False, check_grads=False)
+    elif case == "wide":    # BASELINE configs[4] widths (H=1024, B=256, 2048-d features) at reduced length / vocabulary, fp32
+        lens = sorted([int(x) for x in torch.randint(1, 7, (256,), generator=torch.Generator().manual_seed(9))], reverse=True)
+        lens[0] = 6
+        m, src, tgt, im = make(700, 1003, 2048, 256, 1024, 512, 256, 6, 5, lens, seed=7)
+        run_both(m, src, lens, tgt, im)
     else:
         lens = [6]
         m, src, tgt, im = make(40, 45, 64, 16, 24, 20, 1, 6, 5, lens, kind="text")

@@ -30,9 +30,13 @@ for name, M, N, K, lay, beta in SHAPES:
     run(); torch.cuda.synchronize()
     s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
     reps = 20
+    g = torch.cuda.CUDAGraph()           # graph replay: eager ctypes launches cost ~20 us of host time each
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            run()
+    g.replay(); torch.cuda.synchronize()
     s.record()
-    for _ in range(reps):
-        run()
+    g.replay()
     e.record(); torch.cuda.synchronize()
     us = s.elapsed_time(e) / reps * 1e3
     fl = 2.0 * M * N * K

@@ -1,6 +1,6 @@
 """Per-step kernel breakdown from a rocprofv3 kernel trace of bench.py (one optimiser step between two Adam launches)."""
 import csv, glob, collections, sys
-f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
+f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('adam_kernel')]

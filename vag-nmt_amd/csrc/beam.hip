@@ -35,6 +35,8 @@ __device__ __forceinline__ Cand block_best(Cand c, Cand* sh) {
     return r;
 }
 
+// Selection in both stages: every thread caches the best of the candidates it owns; a round is one block-wide argmax
+// of the cached bests, and only the winner's owner rescans its (register- or LDS-resident) candidates.
 __global__ __launch_bounds__(256) void beam_stage1_kernel(const float* __restrict__ logp, int64_t ldl,
                                                           const float* __restrict__ nll, const int64_t* __restrict__ prev_tok,
                                                           int k_in, int k, int V, int penal, float* __restrict__ cval,
@@ -43,13 +45,18 @@ __global__ __launch_bounds__(256) void beam_stage1_kernel(const float* __restric
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *n_alive = 0;   // stage 2 (next launch) counts into it
     const int b = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
     const int total = k_in * V;
+    const int f0 = chunk * CHUNK + threadIdx.x;
+    const float rV = 1.f / (float)V;
     float val[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-        const int f = chunk * CHUNK + e * 256 + threadIdx.x;     // flat index j*V + w
+        const int f = f0 + e * 256;                               // flat index j*V + w
         float v = -INFINITY;
         if (f < total) {
-            const int j = f / V, w = f - j * V;
+            int j = (int)((float)f * rV);                         // f < 2^24: exact up to one unit
+            if (j * V > f) --j;
+            else if ((j + 1) * V <= f) ++j;
+            const int w = f - j * V;
             const int64_t n = (int64_t)b * k_in + j;
             float lp = logp[n * ldl + w];
             if (penal) {
@@ -61,27 +68,33 @@ __global__ __launch_bounds__(256) void beam_stage1_kernel(const float* __restric
         }
         val[e] = v;
     }
-    float pv = INFINITY;
-    int pi = -1;
-    for (int r = 0; r < k; ++r) {
+    unsigned taken = 0;
+    auto scan = [&]() {
         Cand c = {-INFINITY, 0x7fffffff};
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            const int f = chunk * CHUNK + e * 256 + threadIdx.x;
-            const float v = val[e];
-            const bool after = (v < pv) || (v == pv && f > pi);   // strictly after the previous pick
-            if (after && f < total && better(v, f, c.v, c.idx)) { c.v = v; c.idx = f; }
+            const int f = f0 + e * 256;
+            if (!((taken >> e) & 1u) && f < total && better(val[e], f, c.v, c.idx)) { c.v = val[e]; c.idx = f; }
         }
-        c = block_best(c, sh);
-        pv = c.v; pi = c.idx;
+        return c;
+    };
+    Cand mine = scan();
+    for (int r = 0; r < k; ++r) {
+        const Cand c = block_best(mine, sh);
         if (threadIdx.x == 0) {
             const int64_t o = ((int64_t)b * chunks + chunk) * k + r;
             cval[o] = c.v; cidx[o] = c.idx;
         }
+        if (c.idx != 0x7fffffff && mine.idx == c.idx) {
+            taken |= 1u << ((c.idx - f0) >> 8);
+            mine = scan();
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void beam_stage2_kernel(const float* __restrict__ cval, const int* __restrict__ cidx,
+constexpr int S2_LDS = 2048;             // candidates kept in LDS by stage 2 (more: selection works on the scratch copy)
+
+__global__ __launch_bounds__(256) void beam_stage2_kernel(float* __restrict__ cval, int* __restrict__ cidx,
                                                           int chunks, int k_in, int k, int V, int H,
                                                           float* __restrict__ nll, int64_t* __restrict__ beam, int di,
                                                           int B, const float* __restrict__ h_in, float* __restrict__ h_out,
@@ -89,21 +102,35 @@ __global__ __launch_bounds__(256) void beam_stage2_kernel(const float* __restric
     __shared__ Cand sh[4];
     __shared__ int sel_idx[64];
     __shared__ float sel_val[64];
+    __shared__ float lv[S2_LDS];
+    __shared__ int li[S2_LDS];
     const int b = blockIdx.x;
     const int ncand = chunks * k;
-    float pv = INFINITY;
-    int pi = -1;
-    for (int r = 0; r < k; ++r) {
+    float* pv = cval + (int64_t)b * ncand;
+    int* pi = cidx + (int64_t)b * ncand;
+    if (ncand <= S2_LDS) {
+        for (int e = threadIdx.x; e < ncand; e += 256) { lv[e] = pv[e]; li[e] = pi[e]; }
+        pv = lv; pi = li;
+        __syncthreads();
+    }
+    int mine_e = -1;
+    auto scan = [&]() {
         Cand c = {-INFINITY, 0x7fffffff};
+        mine_e = -1;
         for (int e = threadIdx.x; e < ncand; e += 256) {
-            const float v = cval[(int64_t)b * ncand + e];
-            const int f = cidx[(int64_t)b * ncand + e];
-            const bool after = (v < pv) || (v == pv && f > pi);
-            if (after && f != 0x7fffffff && better(v, f, c.v, c.idx)) { c.v = v; c.idx = f; }
+            const int f = pi[e];
+            if (f != 0x7fffffff && better(pv[e], f, c.v, c.idx)) { c.v = pv[e]; c.idx = f; mine_e = e; }
         }
-        c = block_best(c, sh);
-        pv = c.v; pi = c.idx;
+        return c;
+    };
+    Cand mine = scan();
+    for (int r = 0; r < k; ++r) {
+        const Cand c = block_best(mine, sh);
         if (threadIdx.x == 0) { sel_idx[r] = c.idx; sel_val[r] = c.v; }
+        if (c.idx != 0x7fffffff && mine.idx == c.idx) {
+            pi[mine_e] = 0x7fffffff;                               // taken (only its owner reads this slot again)
+            mine = scan();
+        }
     }
     __syncthreads();
     // history permutation (V11.py:309): every thread owns time steps t, reads the k old tokens, writes the new ones
@@ -122,10 +149,20 @@ __global__ __launch_bounds__(256) void beam_stage2_kernel(const float* __restric
         if (w != EOS) atomicAdd(n_alive, 1);
     }
     // hidden-state re-tiling for the next step (V11.py:273,:313)
-    for (int e = threadIdx.x; e < k * H; e += 256) {
-        const int j = e / H, c = e - j * H;
-        const int src = sel_idx[j] / V;
-        h_out[((int64_t)b * k + j) * H + c] = h_in[((int64_t)b * k_in + src) * H + c];
+    if ((H & 3) == 0) {
+        const int H4 = H >> 2;
+        for (int e = threadIdx.x; e < k * H4; e += 256) {
+            const int j = e / H4, c = e - j * H4;
+            const int src = sel_idx[j] / V;
+            reinterpret_cast<float4*>(h_out + ((int64_t)b * k + j) * H)[c] =
+                reinterpret_cast<const float4*>(h_in + ((int64_t)b * k_in + src) * H)[c];
+        }
+    } else {
+        for (int e = threadIdx.x; e < k * H; e += 256) {
+            const int j = e / H, c = e - j * H;
+            const int src = sel_idx[j] / V;
+            h_out[((int64_t)b * k + j) * H + c] = h_in[((int64_t)b * k_in + src) * H + c];
+        }
     }
 }
 

@@ -12,6 +12,8 @@
 #include "common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cstdio>
+#include <cstdlib>
 int vag_copy2d_launch(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t rows, int64_t cols, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
@@ -377,7 +379,11 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(GemmArgs a) {
 }
 
 // (A double-buffered variant -- 110 KB of LDS, one block per CU, split/store of tile t+1 issued between the k-halves of
-// tile t -- measured 6-9 % slower than this single-stage kernel at two blocks per CU, and was dropped.)
+// tile t -- measured 6-9 % slower than this single-stage kernel at two blocks per CU, and was dropped.  So was a
+// wave-specialised one -- 4 producer waves splitting into a second LDS stage while 4 consumer waves run 64x64 MFMA
+// tiles: 128 vs 138 TFLOP/s at 4096^3, up to 35 % slower at K = 256 -- and a 3-tile register prefetch (154 VGPRs, one
+// block per CU).  Reference points: PMC on this kernel shows MFMA 31 %, LDS 39 %, VALU 26 % busy; a pure MFMA loop
+// (tools/mfma_probe.hip) sustains 1.9-2.1 PFLOP/s bf16, i.e. 315-350 TFLOP/s fp32-equivalent at six products.)
 static int gemm_split_dispatch(const GemmArgs& g, bool akc, bool bkc, bool vec, dim3 grid, hipStream_t s) {
 #define VAG_SPLIT_CASE(AK, BKc, V)                                                                    \
     if (akc == AK && bkc == BKc && vec == V) {                                                        \
@@ -467,6 +473,13 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
             if (cost < best) { best = cost; T = t; splitk = sp; }
         }
     }
+    if (const char* f = getenv("VAG_GEMM_FORCE")) {          // tuning hook: "T,splitk"
+        int ft = 0, fs = 0;
+        if (sscanf(f, "%d,%d", &ft, &fs) == 2 && (ft == 64 || ft == 128) && fs >= 1 && (fs == 1 || can_split)) { T = ft; splitk = fs; }
+    }
+    if (getenv("VAG_GEMM_DEBUG"))
+        fprintf(stderr, "[vag_gemm] M=%lld N=%lld K=%lld akc=%d bkc=%d beta=%g -> T=%lld splitk=%lld model=%.1f us\n",
+                (long long)M, (long long)N, (long long)K, (int)akc, (int)bkc, (double)beta, (long long)T, (long long)splitk, best);
     const bool big = (T == 128);
     int kchunk = (int)(cdiv64(cdiv64(K, splitk), BK) * BK);
     splitk = cdiv64(K, kchunk);
@@ -749,7 +762,7 @@ int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
                       hipStream_t stream) {
     VAG_CHECK_ARG(M >= 0 && N >= 0 && K > 0 && A && W && out);
     if (M == 0 || N == 0) return VAG_OK;
-    if (!skinny_ok(A, lda, W, ldw, K) || M > 128) {
+    if (!skinny_ok(A, lda, W, ldw, K) || M > 256) {      // beam decode runs B*k = 192 rows per step
         // generic path through the tiled kernel; an addend is folded in with beta = 1
         if (addend) {
             if (addend != out) VAG_TRY(vag_copy2d_launch(addend, ldadd, out, ldo, M, N, stream));

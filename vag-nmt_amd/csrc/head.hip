@@ -23,7 +23,9 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
     return r;
 }
 
-// One 256-thread block per row.
+// One 256-thread block per row.  NV > 0: V <= 256*NV and the row is held in registers (one read of the logits, all of
+// a thread's loads in flight together); NV == 0: any V, the row is re-read from L2 by the later passes.
+template <int NV>
 __global__ __launch_bounds__(256) void lse_nll_kernel(const float* __restrict__ logits, int64_t ldl, int V,
                                                       const int64_t* __restrict__ tgt, int B, int Tt,
                                                       const float* __restrict__ vw, float* __restrict__ lse,
@@ -34,15 +36,34 @@ __global__ __launch_bounds__(256) void lse_nll_kernel(const float* __restrict__ 
     __shared__ int shi[4];
     const int64_t row = blockIdx.x;
     const float* x = logits + row * ldl;
+    float c[NV > 0 ? NV : 1];
+    if (NV > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int j = threadIdx.x + 256 * i;
+            c[i] = j < V ? x[j] : -INFINITY;
+        }
+    }
     float mx = -INFINITY;
     int mi = 0x7fffffff;
-    for (int j = threadIdx.x; j < V; j += 256) {
-        const float v = x[j];
-        if (v > mx) { mx = v; mi = j; }      // strict >: first occurrence within a thread
+    if (NV > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (c[i] > mx) { mx = c[i]; mi = threadIdx.x + 256 * i; }      // strict >: first occurrence within a thread
+    } else {
+        for (int j = threadIdx.x; j < V; j += 256) {
+            const float v = x[j];
+            if (v > mx) { mx = v; mi = j; }
+        }
     }
     const float bm = block_reduce_max(mx, sh);
     float sum = 0.f;
-    for (int j = threadIdx.x; j < V; j += 256) sum += __expf(x[j] - bm);
+    if (NV > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sum += __expf(c[i] - bm);             // exp(-inf) = 0 past V
+    } else {
+        for (int j = threadIdx.x; j < V; j += 256) sum += __expf(x[j] - bm);
+    }
     sum = block_reduce_sum(sum, sh);
     const float l = bm + __logf(sum);
     if (argmax) {
@@ -64,7 +85,15 @@ __global__ __launch_bounds__(256) void lse_nll_kernel(const float* __restrict__ 
     }
     if (logp_out) {
         float* o = logp_out + row * ldlp;
-        for (int j = threadIdx.x; j < V; j += 256) o[j] = x[j] - l;
+        if (NV > 0) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int j = threadIdx.x + 256 * i;
+                if (j < V) o[j] = c[i] - l;
+            }
+        } else {
+            for (int j = threadIdx.x; j < V; j += 256) o[j] = x[j] - l;
+        }
     }
 }
 
@@ -74,8 +103,13 @@ int vag_lse_nll_launch(const float* logits, int64_t ldl, int64_t rows, int64_t V
     VAG_CHECK_ARG(logits && rows >= 0 && V > 0 && ldl >= V);
     VAG_CHECK_ARG(!tgt || (vw && nll && B > 0 && Tt > 0));
     if (rows == 0) return VAG_OK;
-    hipLaunchKernelGGL(lse_nll_kernel, dim3((unsigned)rows), dim3(256), 0, s, logits, ldl, (int)V, tgt, (int)B, (int)Tt,
-                       vw, lse, nll, argmax, argmax_stride, logp_out, ldlp);
+#define VAG_LSE_GO(NV)                                                                                              \
+    hipLaunchKernelGGL(lse_nll_kernel<NV>, dim3((unsigned)rows), dim3(256), 0, s, logits, ldl, (int)V, tgt, (int)B,  \
+                       (int)Tt, vw, lse, nll, argmax, argmax_stride, logp_out, ldlp)
+    if (V <= 256 * 8) VAG_LSE_GO(8);
+    else if (V <= 256 * 40) VAG_LSE_GO(40);
+    else VAG_LSE_GO(0);
+#undef VAG_LSE_GO
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
