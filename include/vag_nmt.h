@@ -267,19 +267,29 @@ int vag_dec_init_bwd(const float* mask, const float* xmix, const float* h0, floa
                      float* d_ctx, float* g_W, float* g_b, float* scratch, vag_stream_t stream);
 
 /* ---- a10: beam-search step, models/...V11.py:262-313 -------------------------------------------------- */
-/* One expansion for B sentences x k beams over V words (step di >= 1).  logp (B*k, ldl) is modified in place
- * (repeat-token suppression :279-280, finished hypotheses forced to EOS at cost 0 :291-294, inf = -1e5).
- * nll (B,k) running scores in/out; beam (max_len,B,k) int64 history, rows < di permuted (:309), row di
- * written (:306); h_in (B*k,H) -> h_out re-ordered by back-pointer (:273,:313); n_alive (1) int32 = number of
- * hypotheses whose previous token is not EOS (host-sync-free early exit test).  scratch: B*k*2 floats + ... */
+/* One expansion for B sentences x k beams over V words (step di >= 0; step 0 expands one hypothesis per sentence).
+ * logp (B*k_in, ldl) is read through the reference's penalties (repeat-token suppression :279-280, finished
+ * hypotheses may only emit EOS at cost 0 :291-294, inf = -1e5).  nll (B,k) running scores in/out.
+ * beam (2*max_len,B,k) int64 history: row di receives the chosen words (:306) and row max_len+di the index of the
+ * hypothesis each one extends (:303); the reference's per-step permutation of all earlier rows (:309) is replaced
+ * by these back-pointers, resolved once in vag_beam_finish.  h_in (B*k_in,H) -> h_out (B*k,H) re-ordered by
+ * back-pointer (:273,:313); n_alive (1) int32 = number of new hypotheses whose word is not EOS (host-sync-free
+ * early-exit test).  scratch: vag_beam_scratch_bytes. */
 int64_t vag_beam_scratch_bytes(int64_t B, int64_t k, int64_t V, int64_t max_len);
 int vag_beam_step(float* logp, int64_t ldl, float* nll, int64_t* beam, int64_t di, int64_t max_len,
                   const float* h_in, float* h_out, int64_t B, int64_t k, int64_t V, int64_t H, int32_t* n_alive,
                   void* scratch, vag_stream_t stream);
-/* Final selection (:315-324): force EOS in the last row, length-normalise, pick the best hypothesis.
- * out (B,max_len) int64, best_score (B). */
-int vag_beam_finish(const float* nll, int64_t* beam, int64_t max_len, int64_t B, int64_t k, int64_t* out,
-                    float* best_score, vag_stream_t stream);
+/* The same expansion with the step index held in device memory, so that one captured HIP graph serves every step:
+ * di_state int32[2] = {di (>= 1 on entry, incremented by the call), 0 (internal arrival counter)}.  A call with
+ * di >= max_len does nothing.  tok_out (B*k) int64 (may be NULL) also receives row di, the next step's input words. */
+int vag_beam_step_dev(float* logp, int64_t ldl, float* nll, int64_t* beam, int32_t* di_state, int64_t max_len,
+                      const float* h_in, float* h_out, int64_t* tok_out, int64_t B, int64_t k, int64_t V, int64_t H,
+                      int32_t* n_alive, void* scratch, vag_stream_t stream);
+/* Final selection (:315-324) after `steps` calls of vag_beam_step (steps < max_len after an early stop): follow the
+ * back-pointers, force EOS in the last row, length-normalise, pick the best hypothesis.
+ * out (B,max_len) int64 (0 past the written rows), best_score (B). */
+int vag_beam_finish(const float* nll, const int64_t* beam, int64_t max_len, int64_t steps, int64_t B, int64_t k,
+                    int64_t* out, float* best_score, vag_stream_t stream);
 
 /* ---- a13: optimiser step, train.py:46-49 + nmt_multimodal_beam_DE.py:303-332 -------------------------- */
 /* Global-norm clip (clip_grad_norm_, eps 1e-6) fused with Adam over one flat fp32 buffer of n elements split

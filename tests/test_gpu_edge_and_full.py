@@ -132,3 +132,34 @@ def test_decode_matches_oracle_at_eval_batch():
     # topk(sorted=False) leaves the order of equal-score beams unspecified: compare the normalised scores too
     assert np.allclose(mg.last_beam_scores.cpu().numpy(), want_scores.numpy(), rtol=1e-4, atol=1e-4)
     assert got_b == want_b
+
+
+def test_decode_graph_replay_equals_launch_by_launch():
+    """The captured decode graphs (device-side step counter, source padded to 8 positions) against the same kernels
+    launched step by step: identical hypotheses and scores, also when the cached graph is reused for another batch of a
+    different true length, when max_length is not a multiple of the chunk, and on an early stop."""
+    lens_a = [12, 11, 11, 9, 9, 8, 7, 7, 6, 5, 5, 4, 3, 2, 2, 1]
+    lens_b = [10, 9, 9, 9, 8, 8, 7, 7, 6, 5, 5, 4, 3, 2, 2, 1]
+    m, src_a, _, im_a = make(300, 333, 256, 32, 64, 48, 16, 12, 8, lens_a, seed=11)
+    _, src_b, _, im_b = make(300, 333, 256, 32, 64, 48, 16, 10, 8, lens_b, seed=12)
+    mg = m.cuda().eval()
+    for max_len in (20, 13, 1):
+        for k in (1, 3, 12):
+            for src, lens, im in ((src_a, lens_a, im_a), (src_b, lens_b, im_b), (src_a, lens_a, im_a)):
+                mg.decode_graph = False
+                want = mg.beamsearch_decode(src.cuda(), lens, im.cuda(), k, max_len)
+                want_s = mg.last_beam_scores.cpu().numpy() if k > 1 else None
+                mg.decode_graph = True
+                got = mg.beamsearch_decode(src.cuda(), lens, im.cuda(), k, max_len)
+                assert [[int(t) for t in h] for h in got] == [[int(t) for t in h] for h in want], (max_len, k)
+                if k > 1:
+                    assert np.array_equal(mg.last_beam_scores.cpu().numpy(), want_s)
+    # early stop: make EOS overwhelmingly likely so that every hypothesis finishes within the first chunk
+    with torch.no_grad():
+        mg.decoder.out.bias[3] += 50.0
+    mg.decode_graph = False
+    want = mg.beamsearch_decode(src_a.cuda(), lens_a, im_a.cuda(), 5, 40)
+    mg.decode_graph = True
+    got = mg.beamsearch_decode(src_a.cuda(), lens_a, im_a.cuda(), 5, 40)
+    assert [[int(t) for t in h] for h in got] == [[int(t) for t in h] for h in want]
+    assert all(len(h) == 0 for h in got)

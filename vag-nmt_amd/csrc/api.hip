@@ -18,7 +18,7 @@ static inline int copy_async(void* dst, const void* src, size_t bytes, hipStream
 // y = act(x W^T + b): small-M kernel for a single time step, tiled kernel otherwise.
 static int linear_fwd(int64_t M, int64_t N, int64_t K, const float* x, int64_t ldx, const float* W, const float* bias,
                       int act, float* y, int64_t ldy, hipStream_t s) {
-    if (M <= 128) return vag_skinny_launch(M, N, K, x, ldx, W, K, bias, nullptr, 0, y, ldy, act, s);
+    if (M <= 256) return vag_skinny_launch(M, N, K, x, ldx, W, K, bias, nullptr, 0, y, ldy, act, s);
     return vag_gemm_launch(M, N, K, 1.f, x, ldx, 1, W, 1, K, 0.f, y, ldy, bias, act, s);
 }
 // C (+)= A^T B with A (R,M) lda, B (R,N) ldb: weight gradients  g_W[m,n] += sum_r dY[r,m] X[r,n]
@@ -852,11 +852,19 @@ int64_t vag_beam_scratch_bytes(int64_t B, int64_t k, int64_t V, int64_t max_len)
 int vag_beam_step(float* logp, int64_t ldl, float* nll, int64_t* beam, int64_t di, int64_t max_len, const float* h_in,
                   float* h_out, int64_t B, int64_t k, int64_t V, int64_t H, int32_t* n_alive, void* scratch,
                   vag_stream_t stream) {
-    return vag_beam_step_launch(logp, ldl, nll, beam, di, max_len, h_in, h_out, B, k, V, H, n_alive, scratch, S_(stream));
+    return vag_beam_step_launch(logp, ldl, nll, beam, di, nullptr, max_len, h_in, h_out, nullptr, B, k, V, H, n_alive, scratch,
+                                S_(stream));
 }
-int vag_beam_finish(const float* nll, int64_t* beam, int64_t max_len, int64_t B, int64_t k, int64_t* out, float* best_score,
-                    vag_stream_t stream) {
-    return vag_beam_finish_launch(nll, beam, max_len, B, k, out, best_score, S_(stream));
+int vag_beam_step_dev(float* logp, int64_t ldl, float* nll, int64_t* beam, int32_t* di_state, int64_t max_len,
+                      const float* h_in, float* h_out, int64_t* tok_out, int64_t B, int64_t k, int64_t V, int64_t H,
+                      int32_t* n_alive, void* scratch, vag_stream_t stream) {
+    VAG_CHECK_ARG(di_state != nullptr);
+    return vag_beam_step_launch(logp, ldl, nll, beam, 0, di_state, max_len, h_in, h_out, tok_out, B, k, V, H, n_alive, scratch,
+                                S_(stream));
+}
+int vag_beam_finish(const float* nll, const int64_t* beam, int64_t max_len, int64_t steps, int64_t B, int64_t k, int64_t* out,
+                    float* best_score, vag_stream_t stream) {
+    return vag_beam_finish_launch(nll, beam, max_len, steps, B, k, out, best_score, S_(stream));
 }
 
 int vag_clip_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,

@@ -1,14 +1,16 @@
 // Batched beam-search expansion (models/NMT_AttentionImagine_Seq2Seq_Beam_V11.py:259-324) without host syncs.
-//   stage 1: grid (chunks, B): each block selects the k best of an 8192-candidate slice of the k_in*V
+//   stage 1: grid (chunks, B): each block selects the k best of a 2048-candidate slice of the k_in*V
 //            continuations, applying the reference's penalties on the fly (repeat-token suppression,
 //            finished hypotheses may only emit EOS at cost 0).
-//   stage 2: one block per sentence merges the chunk winners, updates running scores, token history
-//            (back-pointer permutation) and re-orders the decoder hidden state for the next step.
+//   stage 2: one block per sentence merges the chunk winners, updates running scores, appends (token, parent) to the
+//            history and re-orders the decoder hidden state for the next step.  The history is kept as back-pointers
+//            (rows [max_len, 2 max_len) of the beam buffer) and resolved once by the finish kernel, instead of
+//            permuting all earlier rows at every step as the reference does (V11.py:309) -- same hypotheses.
 // Selection uses the total order (score desc, flat index asc), so results are deterministic; the reference's
 // topk(sorted=False) leaves the order of equal-score candidates unspecified.
 #include "kernels.h"
 
-constexpr int EPT = 32;                  // candidates per thread in stage 1
+constexpr int EPT = 8;                   // candidates per thread in stage 1 (a rescan after each pick walks these)
 constexpr int CHUNK = 256 * EPT;
 constexpr float NEG_PEN = -1e5f;         // the reference's "inf" (V11.py:257)
 constexpr int64_t EOS = 3;
@@ -37,36 +39,41 @@ __device__ __forceinline__ Cand block_best(Cand c, Cand* sh) {
 
 // Selection in both stages: every thread caches the best of the candidates it owns; a round is one block-wide argmax
 // of the cached bests, and only the winner's owner rescans its (register- or LDS-resident) candidates.
+// The step index comes from the host (di_host) or, for launches replayed from a HIP graph, from device memory
+// (di_state[0], advanced by stage 2; such launches are always steps >= 1, i.e. k_in == k).
 __global__ __launch_bounds__(256) void beam_stage1_kernel(const float* __restrict__ logp, int64_t ldl,
-                                                          const float* __restrict__ nll, const int64_t* __restrict__ prev_tok,
-                                                          int k_in, int k, int V, int penal, float* __restrict__ cval,
+                                                          const float* __restrict__ nll_in, const int64_t* __restrict__ beam,
+                                                          const int32_t* di_state, int di_host, int max_len, int B,
+                                                          int k_in, int k, int V, float* __restrict__ cval,
                                                           int* __restrict__ cidx, int32_t* __restrict__ n_alive) {
     __shared__ Cand sh[4];
+    const int di = di_state ? __atomic_load_n(di_state, __ATOMIC_RELAXED) : di_host;
+    if (di >= max_len || (di_state && di < 1)) return;                          // replayed past the end: nothing to do
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *n_alive = 0;   // stage 2 (next launch) counts into it
+    const int penal = di > 0;
+    const float* nll = di > 0 ? nll_in : nullptr;
+    const int64_t* prev_tok = di > 0 ? beam + (int64_t)(di - 1) * B * k : beam;
     const int b = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
     const int total = k_in * V;
     const int f0 = chunk * CHUNK + threadIdx.x;
     const float rV = 1.f / (float)V;
+    // branch-free so that all 3*EPT loads of a thread are in flight together (indices clamped, result selected)
     float val[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int f = f0 + e * 256;                               // flat index j*V + w
-        float v = -INFINITY;
-        if (f < total) {
-            int j = (int)((float)f * rV);                         // f < 2^24: exact up to one unit
-            if (j * V > f) --j;
-            else if ((j + 1) * V <= f) ++j;
-            const int w = f - j * V;
-            const int64_t n = (int64_t)b * k_in + j;
-            float lp = logp[n * ldl + w];
-            if (penal) {
-                const int64_t pt = prev_tok[n];
-                if (pt == EOS) lp = (w == EOS) ? 0.f : NEG_PEN;   // V11.py:291-294
-                else if (w == pt) lp = NEG_PEN;                   // V11.py:279-280
-            }
-            v = (nll ? nll[n] : 0.f) + lp;                        // V11.py:297
-        }
-        val[e] = v;
+        const int fc = min(f, total - 1);
+        int j = (int)((float)fc * rV);                            // fc < 2^24: exact up to one unit
+        if (j * V > fc) --j;
+        else if ((j + 1) * V <= fc) ++j;
+        const int w = fc - j * V;
+        const int64_t n = (int64_t)b * k_in + j;
+        float lp = logp[n * ldl + w];
+        const int64_t pt = penal ? prev_tok[n] : (int64_t)-1;
+        const float base = nll ? nll[n] : 0.f;
+        if (pt == EOS) lp = (w == EOS) ? 0.f : NEG_PEN;           // V11.py:291-294
+        else if (w == pt) lp = NEG_PEN;                           // V11.py:279-280
+        val[e] = f < total ? base + lp : -INFINITY;               // V11.py:297
     }
     unsigned taken = 0;
     auto scan = [&]() {
@@ -92,15 +99,18 @@ __global__ __launch_bounds__(256) void beam_stage1_kernel(const float* __restric
     }
 }
 
-constexpr int S2_LDS = 2048;             // candidates kept in LDS by stage 2 (more: selection works on the scratch copy)
+constexpr int S2_LDS = 4096;             // candidates kept in LDS by stage 2 (more: selection works on the scratch copy)
 
 __global__ __launch_bounds__(256) void beam_stage2_kernel(float* __restrict__ cval, int* __restrict__ cidx,
                                                           int chunks, int k_in, int k, int V, int H,
-                                                          float* __restrict__ nll, int64_t* __restrict__ beam, int di,
-                                                          int B, const float* __restrict__ h_in, float* __restrict__ h_out,
-                                                          int32_t* __restrict__ n_alive) {
+                                                          float* __restrict__ nll, int64_t* __restrict__ beam,
+                                                          int32_t* di_state, int di_host, int max_len, int B,
+                                                          const float* __restrict__ h_in, float* __restrict__ h_out,
+                                                          int64_t* __restrict__ tok_out, int32_t* __restrict__ n_alive) {
     __shared__ Cand sh[4];
     __shared__ int sel_idx[64];
+    const int di = di_state ? __atomic_load_n(di_state, __ATOMIC_RELAXED) : di_host;
+    if (di >= max_len || (di_state && di < 1)) return;
     __shared__ float sel_val[64];
     __shared__ float lv[S2_LDS];
     __shared__ int li[S2_LDS];
@@ -133,18 +143,13 @@ __global__ __launch_bounds__(256) void beam_stage2_kernel(float* __restrict__ cv
         }
     }
     __syncthreads();
-    // history permutation (V11.py:309): every thread owns time steps t, reads the k old tokens, writes the new ones
-    for (int t = threadIdx.x; t < di; t += 256) {
-        int64_t* row = beam + ((int64_t)t * B + b) * k;
-        int64_t old[64];
-        for (int j = 0; j < k_in; ++j) old[j] = row[j];
-        for (int j = 0; j < k; ++j) row[j] = old[sel_idx[j] / V];
-    }
     if (threadIdx.x < k) {
         const int j = threadIdx.x;
         const int f = sel_idx[j];
         const int64_t w = f % V;
-        beam[((int64_t)di * B + b) * k + j] = w;                    // V11.py:306
+        beam[((int64_t)di * B + b) * k + j] = w;                                // V11.py:306
+        beam[((int64_t)(max_len + di) * B + b) * k + j] = f / V;                // parent hypothesis (V11.py:303,309)
+        if (tok_out) tok_out[(int64_t)b * k + j] = w;                           // next step's input words
         nll[(int64_t)b * k + j] = sel_val[j];
         if (w != EOS) atomicAdd(n_alive, 1);
     }
@@ -164,6 +169,14 @@ __global__ __launch_bounds__(256) void beam_stage2_kernel(float* __restrict__ cv
             h_out[((int64_t)b * k + j) * H + c] = h_in[((int64_t)b * k_in + src) * H + c];
         }
     }
+    if (di_state && threadIdx.x == 0) {
+        // every block has read di_state[0] before it arrives here; the last one to arrive advances the step
+        __threadfence();
+        if (atomicAdd(&di_state[1], 1) == B - 1) {
+            di_state[1] = 0;
+            __atomic_store_n(di_state, di + 1, __ATOMIC_RELAXED);
+        }
+    }
 }
 
 int64_t vag_beam_scratch_bytes_impl(int64_t B, int64_t k, int64_t V) {
@@ -171,37 +184,43 @@ int64_t vag_beam_scratch_bytes_impl(int64_t B, int64_t k, int64_t V) {
     return B * chunks * k * 8 + 64;
 }
 
-int vag_beam_step_launch(float* logp, int64_t ldl, float* nll, int64_t* beam, int64_t di, int64_t max_len,
-                         const float* h_in, float* h_out, int64_t B, int64_t k, int64_t V, int64_t H,
-                         int32_t* n_alive, void* scratch, hipStream_t s) {
+int vag_beam_step_launch(float* logp, int64_t ldl, float* nll, int64_t* beam, int64_t di, int32_t* di_state,
+                         int64_t max_len, const float* h_in, float* h_out, int64_t* tok_out, int64_t B, int64_t k,
+                         int64_t V, int64_t H, int32_t* n_alive, void* scratch, hipStream_t s) {
     VAG_CHECK_ARG(logp && nll && beam && h_in && h_out && n_alive && scratch);
-    VAG_CHECK_ARG(B > 0 && k > 0 && k <= 64 && V > 0 && H > 0 && di >= 0 && di < max_len && ldl >= V);
-    const int k_in = di == 0 ? 1 : (int)k;
+    VAG_CHECK_ARG(B > 0 && k > 0 && k <= 64 && V > 0 && H > 0 && ldl >= V && max_len > 0);
+    VAG_CHECK_ARG(di_state || (di >= 0 && di < max_len));
+    const int k_in = (!di_state && di == 0) ? 1 : (int)k;
     const int64_t total = (int64_t)k_in * V;
-    VAG_CHECK_ARG(total < (1ll << 31) && total >= k);
+    VAG_CHECK_ARG(total < (1ll << 24) && total >= k);          // stage 1 splits flat indices with a float reciprocal
     const int chunks = (int)cdiv64(total, CHUNK);
     float* cval = reinterpret_cast<float*>(scratch);
     int* cidx = reinterpret_cast<int*>(cval + B * cdiv64(k * V, CHUNK) * k);
-    const int64_t* prev = di > 0 ? beam + (di - 1) * B * k : nullptr;
-    hipLaunchKernelGGL(beam_stage1_kernel, dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, s, logp, ldl,
-                       di > 0 ? nll : (const float*)nullptr, prev, k_in, (int)k, (int)V, di > 0 ? 1 : 0, cval, cidx, n_alive);
+    hipLaunchKernelGGL(beam_stage1_kernel, dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, s, logp, ldl, nll, beam,
+                       di_state, (int)di, (int)max_len, (int)B, k_in, (int)k, (int)V, cval, cidx, n_alive);
     VAG_LAUNCH_CHECK();
     hipLaunchKernelGGL(beam_stage2_kernel, dim3((unsigned)B), dim3(256), 0, s, cval, cidx, chunks, k_in, (int)k, (int)V,
-                       (int)H, nll, beam, (int)di, (int)B, h_in, h_out, n_alive);
+                       (int)H, nll, beam, di_state, (int)di, (int)max_len, (int)B, h_in, h_out, tok_out, n_alive);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
 
 // V11.py:315-324: force EOS in the last row, normalise by the number of tokens > 3, pick the best hypothesis.
-__global__ __launch_bounds__(64) void beam_finish_kernel(const float* __restrict__ nll, int64_t* __restrict__ beam,
-                                                         int max_len, int B, int k, int64_t* __restrict__ out,
+// `steps` rows of history were written (fewer than max_len after an early stop; the rest reads as padding 0).
+// Thread j walks the back-pointers of final hypothesis j (steps dependent 8-byte loads, once per decode).
+__global__ __launch_bounds__(64) void beam_finish_kernel(const float* __restrict__ nll, const int64_t* __restrict__ beam,
+                                                         int max_len, int steps, int B, int k, int64_t* __restrict__ out,
                                                          float* __restrict__ best) {
     const int b = blockIdx.x, j = threadIdx.x;
+    const int64_t* par = beam + (int64_t)max_len * B * k;
     float sc = -INFINITY;
     if (j < k) {
-        beam[((int64_t)(max_len - 1) * B + b) * k + j] = EOS;    // EOS (=3) never counts towards the length
-        int len = 0;
-        for (int t = 0; t < max_len - 1; ++t) len += beam[((int64_t)t * B + b) * k + j] > 3;
+        int len = 0, p = j;
+        for (int t = steps - 1; t >= 0; --t) {
+            const int64_t o = ((int64_t)t * B + b) * k + p;
+            if (t < max_len - 1) len += beam[o] > 3;       // row max_len-1 is forced to EOS (= 3), which never counts
+            p = (int)par[o];
+        }
         if (len < 1) len = 1;
         sc = nll[(int64_t)b * k + j] / (float)len;
     }
@@ -213,15 +232,25 @@ __global__ __launch_bounds__(64) void beam_finish_kernel(const float* __restrict
         const int oi = __shfl_xor(bi, o, 64);
         if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
     }
-    for (int t = j; t < max_len; t += 64)
-        out[(int64_t)b * max_len + t] = (t == max_len - 1) ? EOS : beam[((int64_t)t * B + b) * k + bi];
-    if (j == 0 && best) best[b] = bv;
+    int64_t* row = out + (int64_t)b * max_len;
+    for (int t = steps + j; t < max_len; t += 64) row[t] = 0;
+    if (j == 0) {
+        int p = bi;
+        for (int t = steps - 1; t >= 0; --t) {
+            const int64_t o = ((int64_t)t * B + b) * k + p;
+            row[t] = beam[o];
+            p = (int)par[o];
+        }
+        row[max_len - 1] = EOS;
+        if (best) best[b] = bv;
+    }
 }
 
-int vag_beam_finish_launch(const float* nll, int64_t* beam, int64_t max_len, int64_t B, int64_t k, int64_t* out,
-                           float* best, hipStream_t s) {
-    VAG_CHECK_ARG(nll && beam && out && max_len > 0 && B > 0 && k > 0 && k <= 64);
-    hipLaunchKernelGGL(beam_finish_kernel, dim3((unsigned)B), dim3(64), 0, s, nll, beam, (int)max_len, (int)B, (int)k, out, best);
+int vag_beam_finish_launch(const float* nll, const int64_t* beam, int64_t max_len, int64_t steps, int64_t B, int64_t k,
+                           int64_t* out, float* best, hipStream_t s) {
+    VAG_CHECK_ARG(nll && beam && out && max_len > 0 && steps > 0 && steps <= max_len && B > 0 && k > 0 && k <= 64);
+    hipLaunchKernelGGL(beam_finish_kernel, dim3((unsigned)B), dim3(64), 0, s, nll, beam, (int)max_len, (int)steps, (int)B,
+                       (int)k, out, best);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

@@ -762,7 +762,10 @@ int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
                       hipStream_t stream) {
     VAG_CHECK_ARG(M >= 0 && N >= 0 && K > 0 && A && W && out);
     if (M == 0 || N == 0) return VAG_OK;
-    if (!skinny_ok(A, lda, W, ldw, K) || M > 256) {      // beam decode runs B*k = 192 rows per step
+    // every 16x16 output tile re-reads its operand rows: M*N*K/2 bytes requested in all.  Measured at the beam-decode
+    // shape (B*k = 192 rows): the 192x2560x512 query/gate product (126 MB) is still faster here (5 vs 16 us), the
+    // 192x9391x256 vocabulary product (230 MB) is faster on the LDS-tiled kernel (19 vs 38 us).
+    if (!skinny_ok(A, lda, W, ldw, K) || M > 256 || (M > 64 && (double)M * (double)N * (double)K > 350e6)) {
         // generic path through the tiled kernel; an addend is folded in with beta = 1
         if (addend) {
             if (addend != out) VAG_TRY(vag_copy2d_launch(addend, ldadd, out, ldo, M, N, stream));

@@ -114,8 +114,8 @@ int vag_clip_adam_launch(float* p, const float* g, float* m, float* v, int64_t n
 
 // ---------------- beam.hip ----------------
 int64_t vag_beam_scratch_bytes_impl(int64_t B, int64_t k, int64_t V);
-int vag_beam_step_launch(float* logp, int64_t ldl, float* nll, int64_t* beam, int64_t di, int64_t max_len,
-                         const float* h_in, float* h_out, int64_t B, int64_t k, int64_t V, int64_t H,
-                         int32_t* n_alive, void* scratch, hipStream_t s);
-int vag_beam_finish_launch(const float* nll, int64_t* beam, int64_t max_len, int64_t B, int64_t k, int64_t* out,
-                           float* best, hipStream_t s);
+int vag_beam_step_launch(float* logp, int64_t ldl, float* nll, int64_t* beam, int64_t di, int32_t* di_state,
+                         int64_t max_len, const float* h_in, float* h_out, int64_t* tok_out, int64_t B, int64_t k,
+                         int64_t V, int64_t H, int32_t* n_alive, void* scratch, hipStream_t s);
+int vag_beam_finish_launch(const float* nll, const int64_t* beam, int64_t max_len, int64_t steps, int64_t B, int64_t k,
+                           int64_t* out, float* best, hipStream_t s);

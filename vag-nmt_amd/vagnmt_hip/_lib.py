@@ -82,7 +82,8 @@ PROTOS = {
     "vag_dec_init_bwd": (I32, [P, P, P, F, P, P, I64, I64, I64, I64, P, I32, P, P, P, P, P]),
     "vag_beam_scratch_bytes": (I64, [I64, I64, I64, I64]),
     "vag_beam_step": (I32, [P, I64, P, P, I64, I64, P, P, I64, I64, I64, I64, P, P, P]),
-    "vag_beam_finish": (I32, [P, P, I64, I64, I64, P, P, P]),
+    "vag_beam_step_dev": (I32, [P, I64, P, P, P, I64, P, P, P, I64, I64, I64, I64, P, P, P]),
+    "vag_beam_finish": (I32, [P, P, I64, I64, I64, I64, P, P, P]),
     "vag_clip_adam_flat": (I32, [P, P, P, P, I64, I32, C.POINTER(I64), C.POINTER(F), C.POINTER(F), F, F, F, F, F, P, P,
                                  P, P]),
     "vag_dropout_mask": (I32, [P, I32, I64, F, P, P]),
