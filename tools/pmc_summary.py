@@ -4,7 +4,7 @@ reads (MI355X_MICROARCH.md, HBM section) and is doubled here; WRITE_SIZE is take
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def load(d, counter):
-    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+    f = [d] if os.path.isfile(d) else glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     rows = list(csv.DictReader(open(f[0])))
     out = {}
     for r in rows:
