@@ -23,6 +23,9 @@ for p in (ROOT, os.path.join(ROOT, "vag-nmt_amd")):
 import torch  # noqa: E402
 
 CFG2 = dict(Vs=8507, V=9391, I=2048, E=256, H=512, S=512, B=64, Ts=40, Tt=40)
+# BASELINE.json configs[4] dimensions.  Only fp32 storage is built so far: `--config cfg5-f32` is a stress run of the same
+# kernels at that size, not the fp16 configuration itself, and never the default bench line.
+CFG5 = dict(Vs=40000, V=40000, I=2048, E=256, H=1024, S=512, B=256, Ts=80, Tt=80)
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md (spec)
 MFMA_F32_PEAK = 157.3e12   # FLOP/s dense, f32-input MFMA (MI355X_MICROARCH.md)
 
@@ -171,6 +174,8 @@ def main():
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="debug: disable the reference dropouts")
     ap.add_argument("--overlap", type=int, default=-1, help="1/0: force the side-stream overlap of weight-gradient products")
+    ap.add_argument("--config", choices=["cfg2", "cfg5-f32"], default="cfg2",
+                    help="cfg2 = BASELINE configs[1] (the metric's configuration); cfg5-f32 = configs[4] sizes in fp32")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -196,7 +201,7 @@ def main():
     import random
     from vagnmt_hip.trainer import TrainStep
     from machine_translation_vision.losses import PairwiseRankingLoss
-    c = CFG2
+    c = CFG2 if args.config == "cfg2" else CFG5
     random.seed(1234)      # same teacher-forcing coin on every rank
     model = build_model(c, dev, dropout=not args.no_dropout)
     vw = torch.ones(c["V"], device=dev)
@@ -250,7 +255,7 @@ def main():
         cell_bytes = 4 * (3 * H * H + 3 * H + 9 * B * H)   # W_hh, b_hh, h_prev, gi (3), h_out, 4 saved gate planes
         pmc = pmc_traffic() or {}
         res = {
-            "metric": "training sentence-pairs/sec (Multi30K en->de, B=64)",
+            "metric": "training sentence-pairs/sec (Multi30K en->de, B=%d)" % c["B"],
             "value": c["B"] * world * args.steps / dt,
             "unit": "sentence-pairs/s",
             "n_gpus": world,
@@ -262,13 +267,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: multimodal en->de train step, B=64/GPU, Ts=Tt=40, E=256, H=512, S=512, "
-                                   "I=2048, Vs=8507, V=9391, dropout 0.3/0.5/0.5, tied emb, teacher_force_ratio=%g%s"
-                                   % (args.tfr, ", ragged source lengths" if args.ragged else ""),
+            "config": {"workload": "%s: multimodal en->de train step, B=%d/GPU, Ts=Tt=%d, E=%d, H=%d, S=%d, "
+                                   "I=%d, Vs=%d, V=%d, dropout 0.3/0.5/0.5, tied emb, teacher_force_ratio=%g%s"
+                                   % ("configs[1]" if args.config == "cfg2" else "configs[4] sizes, fp32 storage",
+                                      c["B"], c["Ts"], c["E"], c["H"], c["S"], c["I"], c["Vs"], c["V"],
+                                      args.tfr, ", ragged source lengths" if args.ragged else ""),
                        "global_batch": c["B"] * world, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph, "final_loss": loss},
             # dominant kernel by total time (profiles/): the fused GRU-cell step kernel, decoder gru_1 shape
-            "roofline": {"bound": "hbm", "kernel": "gru_step_kernel<8> (fused GRU cell, M=64, H=512, K=512)",
+            "roofline": {"bound": "hbm", "kernel": "gru_step_kernel<8> (fused GRU cell, M=%d, H=%d, K=%d)" % (B, H, H),
                          "achieved": cell_bytes / fam["gru_cell"] / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": cell_bytes / fam["gru_cell"] / HBM_PEAK,
                          "traffic": pmc.get("gru_step_kernel_bytes_per_launch"),
@@ -282,7 +289,9 @@ def main():
                                       "us_per_decoder_step": t_dec_step * 1e6,
                                       "us_per_encoder_step": fam["encoder_fwd"] / c["Ts"] * 1e6},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.config != "cfg2":
+            res["roofline"]["traffic"] = res["roofline_decoder_step"]["traffic"] = None     # PMC passes were taken at cfg2
+        if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
             res["cpu_baseline"] = cpu_baseline(c)
         print(json.dumps(res))
     if world > 1:

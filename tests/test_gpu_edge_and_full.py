@@ -90,7 +90,7 @@ def test_cfg2_ragged_lengths_and_properties():
         assert torch.allclose(enc2, enc[:, perm.cuda()], atol=1e-6)
 
 
-@pytest.mark.parametrize("case", ["b1", "t1", "odd", "text_b1", "wide"])
+@pytest.mark.parametrize("case", ["b1", "t1", "odd", "text_b1", "wide", "bigvocab"])
 def test_edge_shapes(case):
     if case == "b1":        # a bucket's last batch can hold a single sentence (samplers/bucket.py:59-60,93)
         lens = [5]
@@ -105,6 +105,12 @@ def test_edge_shapes(case):
         m, src, tgt, im = make(51, 67, 100, 20, 28, 24, 5, 9, 7, lens, attn="mlp", tied=False)
         run_both(m, src, lens, tgt, im)
         m2, _, _, _ = make(51, 67, 100, 20, 28, 24, 5, 9, 7, lens, attn="mlp", tied=False)
+        run_both(m2, src, lens, tgt, im, teacher=False, check_grads=False)
+    elif case == "bigvocab":  # V > 10240: log-softmax rows no longer fit the register-resident path (head.hip, NV = 0)
+        lens = [5, 3, 2]
+        m, src, tgt, im = make(60, 10301, 64, 16, 24, 20, 3, 5, 4, lens, seed=5)
+        run_both(m, src, lens, tgt, im)
+        m2, _, _, _ = make(60, 10301, 64, 16, 24, 20, 3, 5, 4, lens, seed=5)
         run_both(m2, src, lens, tgt, im, teacher=False, check_grads=False)
     elif case == "wide":    # BASELINE configs[4] widths (H=1024, B=256, 2048-d features) at reduced length / vocabulary, fp32
         lens = sorted([int(x) for x in torch.randint(1, 7, (256,), generator=torch.Generator().manual_seed(9))], reverse=True)
