@@ -452,10 +452,12 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     const int64_t lda = akc ? sam : sak, ldb = bkc ? sbn : sbk;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     // cost model (microseconds) over tile in {64,128} x split-K: MFMA time of the busiest CU + output traffic
-    // (fp32 atomics run at ~1 TB/s chip-wide, plain stores at ~4 TB/s) -- constants fitted to measured launches.
+    // (split-K partial sums as fp32 atomics ~3 TB/s chip-wide, plain stores ~4 TB/s) -- constants fitted to measured launches.
     const bool can_split = (act == VAG_ACT_NONE) && (beta == 0.f || beta == 1.f);
     double best = 1e30;
     int64_t T = 64, splitk = 1;
+    // bytes/us of split-K partial sums landing as fp32 atomics (fitted: tools/exp_gemm_sweep.py; 1e6 was too pessimistic)
+    static const double atomic_rate = getenv("VAG_GEMM_ATOMIC") ? atof(getenv("VAG_GEMM_ATOMIC")) : 3.0e6;
     for (int64_t t = 64; t <= 128; t *= 2) {
         if (t == 128 && (M <= 64 || N <= 64)) continue;
         const double eff = (t == 128) ? (getenv("VAG_GEMM_F32MFMA") ? 0.62 : 0.85) : 0.42;   // fraction of the f32-MFMA peak
@@ -467,7 +469,7 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
             const double rounds = (double)cdiv64(blocks, 256);
             const double t_mfma = rounds * (double)kper * (double)(t * t) * 2.0 / (256.0 * eff) / 2400.0;
             const double bytes = (double)M * (double)N * 4.0;
-            const double t_out = sp > 1 ? sp * bytes / 1.0e6 + (beta == 0.f ? bytes / 4.0e6 + 2.0 : 0.0)
+            const double t_out = sp > 1 ? sp * bytes / atomic_rate + (beta == 0.f ? bytes / 4.0e6 + 2.0 : 0.0)
                                         : bytes * (beta != 0.f ? 2.0 : 1.0) / 4.0e6;
             const double cost = t_mfma + t_out;
             if (cost < best) { best = cost; T = t; splitk = sp; }
