@@ -593,16 +593,14 @@ static int head_bwd_data(const vag_head_w& w, int64_t R, int64_t E, int64_t H, i
 // so they may run on a side stream beside the decoder's backward recurrence.
 static int head_bwd_weights(const float* h2_all, const float* c_all, const float* e_all, int64_t R, int64_t E, int64_t H,
                             int64_t V, const float* tmid, const float* dlogits, int64_t ldl, const float* dt,
-                            const vag_head_g& g, hipStream_t s) {
+                            const vag_head_g& g, hipStream_t s, bool out_b_done = false) {
     const int64_t C = 2 * H;
     VAG_TRY(gemm_tn_acc(V, E, R, dlogits, ldl, tmid, E, g.out_w, E, s));
-    VAG_TRY(vag_colsum_launch(dlogits, R, V, ldl, g.out_b, s));
+    if (!out_b_done) VAG_TRY(vag_colsum_launch(dlogits, R, V, ldl, g.out_b, s));
     VAG_TRY(gemm_tn_acc(E, H, R, dt, E, h2_all, H, g.w1, H, s));
     VAG_TRY(gemm_tn_acc(E, C, R, dt, E, c_all, C, g.w2, C, s));
     VAG_TRY(gemm_tn_acc(E, E, R, dt, E, e_all, E, g.w3, E, s));
-    VAG_TRY(vag_colsum_launch(dt, R, E, E, g.b1, s));
-    VAG_TRY(vag_colsum_launch(dt, R, E, E, g.b2, s));
-    VAG_TRY(vag_colsum_launch(dt, R, E, E, g.b3, s));
+    VAG_TRY(vag_colsum3_launch(dt, R, E, E, g.b1, g.b2, g.b3, s));     // b1, b2, b3 enter the same sum (NMT_Decoder.py:137)
     return VAG_OK;
 }
 
@@ -633,10 +631,16 @@ int vag_head_ce_seq_bwd(const float* h2_all, const float* c_all, const float* e_
                         const uint64_t* rng, const float* tmid, float* logits, int64_t ldl, const float* lse,
                         const float* inv_cnt, const float* d_loss, float* d_h2_all, float* d_c_all, float* d_e_all,
                         vag_head_g g, float* scratch, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
     VAG_CHECK_ARG(h2_all && c_all && e_all && head_g_ok(g));
-    VAG_TRY(vag_head_ce_seq_bwd_data(w, tgt, vocab_weight, B, Tt, E, H, V, p_out, rng, tmid, logits, ldl, lse, inv_cnt, d_loss,
-                                     d_h2_all, d_c_all, d_e_all, scratch, stream));
-    return head_bwd_weights(h2_all, c_all, e_all, Tt * B, E, H, V, tmid, logits, ldl, scratch, g, S_(stream));
+    VAG_CHECK_ARG(tgt && vocab_weight && tmid && logits && lse && inv_cnt && d_loss && scratch && d_h2_all && d_c_all && d_e_all);
+    VAG_CHECK_ARG(w.w1 && w.w2 && w.w3 && w.out_w);
+    VAG_CHECK_ARG(B > 0 && Tt > 0 && E % 4 == 0 && H % 4 == 0 && V > 0 && ldl >= V && ldl % 4 == 0);
+    const int64_t R = Tt * B;
+    // d(logits) and the output-bias gradient in one pass over the logits
+    VAG_TRY(vag_ce_bwd_colsum_launch(logits, ldl, R, V, tgt, B, Tt, vocab_weight, lse, inv_cnt, d_loss, g.out_b, s));
+    VAG_TRY(head_bwd_data(w, R, E, H, V, p_out, rng, tmid, logits, ldl, d_h2_all, d_c_all, d_e_all, scratch, s));
+    return head_bwd_weights(h2_all, c_all, e_all, R, E, H, V, tmid, logits, ldl, scratch, g, s, true);
 }
 
 int vag_head_logp_seq_fwd(const float* h2, const float* c, const float* e, vag_head_w w, int64_t R, int64_t E, int64_t H,

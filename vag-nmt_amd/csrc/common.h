@@ -80,6 +80,8 @@ int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
                       hipStream_t stream);
 // out[n] += sum_m X[m*ld + n]
 int vag_colsum_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* out, hipStream_t stream);
+int vag_colsum3_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* out, float* out2, float* out3,
+                       hipStream_t stream);
 // out[N,M] = in[M,N]^T
 int vag_transpose_launch(const float* in, int64_t M, int64_t N, float* out, hipStream_t stream);
 

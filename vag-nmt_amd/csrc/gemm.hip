@@ -819,22 +819,30 @@ int vag_gru_bwd_step_launch(const GruBwdStepArgs& a, int nz, hipStream_t stream)
 // ------------------------------------------------------------------------------------------------
 // column sums (bias gradients) and transpose
 // ------------------------------------------------------------------------------------------------
+// out (and, when given, out2 / out3: parameters whose gradients are the same column sums) += column sums of X
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, int64_t ld,
-                                                     int rows_per, float* __restrict__ out) {
+                                                     int rows_per, float* __restrict__ out, float* __restrict__ out2,
+                                                     float* __restrict__ out3) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int m = m0;
-    for (; m + 1 < m1; m += 2) {
+    for (; m + 3 < m1; m += 4) {
         s0 += X[(int64_t)m * ld + n];
         s1 += X[(int64_t)(m + 1) * ld + n];
+        s2 += X[(int64_t)(m + 2) * ld + n];
+        s3 += X[(int64_t)(m + 3) * ld + n];
     }
-    if (m < m1) s0 += X[(int64_t)m * ld + n];
-    atomicAdd(out + n, s0 + s1);
+    for (; m < m1; ++m) s0 += X[(int64_t)m * ld + n];
+    const float t = (s0 + s1) + (s2 + s3);
+    atomicAdd(out + n, t);
+    if (out2) atomicAdd(out2 + n, t);
+    if (out3) atomicAdd(out3 + n, t);
 }
 
-int vag_colsum_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* out, hipStream_t stream) {
+int vag_colsum3_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* out, float* out2, float* out3,
+                       hipStream_t stream) {
     VAG_CHECK_ARG(X && out && M >= 0 && N >= 0);
     if (M == 0 || N == 0) return VAG_OK;
     const int64_t nbx = cdiv64(N, 256);
@@ -843,9 +851,12 @@ int vag_colsum_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* o
     if (splits < 1) splits = 1;
     const int rows_per = (int)cdiv64(M, splits);
     dim3 grid((unsigned)nbx, (unsigned)cdiv64(M, rows_per));
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, X, (int)M, (int)N, ld, rows_per, out);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, X, (int)M, (int)N, ld, rows_per, out, out2, out3);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
+}
+int vag_colsum_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* out, hipStream_t stream) {
+    return vag_colsum3_launch(X, M, N, ld, out, nullptr, nullptr, stream);
 }
 
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int M, int N,

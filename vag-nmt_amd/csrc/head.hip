@@ -183,6 +183,61 @@ int vag_ce_bwd_launch(float* logits, int64_t ldl, int64_t rows, int64_t V, const
     return VAG_OK;
 }
 
+// The same transformation fused with the column sums of its result (the gradient of the output bias): a thread owns
+// one vocabulary column over a strip of rows, so d(logits) is not read a second time (96 MB at cfg2).
+// grid (ceil(ldl/256), ceil(rows/rows_per)).
+__global__ __launch_bounds__(256) void ce_bwd_colsum_kernel(float* __restrict__ logits, int64_t ldl, int V,
+                                                            const int64_t* __restrict__ tgt, int B, int Tt,
+                                                            const float* __restrict__ vw, const float* __restrict__ lse,
+                                                            const float* __restrict__ inv_cnt,
+                                                            const float* __restrict__ d_loss, int rows, int rows_per,
+                                                            float* __restrict__ g_bias) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= ldl) return;
+    const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+    const float dl = d_loss[0] / (float)B;
+    float acc = 0.f;
+    for (int r = r0; r < r1; r += 4) {
+        float x[4], coef[4], l[4];
+        int tg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = min(r + u, r1 - 1);                    // uniform over the block
+            const int t = row / B, b = row - t * B;
+            const int64_t g = tgt[(int64_t)b * Tt + t];
+            tg[u] = (int)g;
+            coef[u] = dl * inv_cnt[b] * vw[g];
+            l[u] = lse[row];
+            x[u] = logits[(int64_t)row * ldl + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (r + u < r1) {
+                float g = 0.f;
+                if (j < V) g = coef[u] * (__expf(x[u] - l[u]) - (j == tg[u] ? 1.f : 0.f));
+                logits[(int64_t)(r + u) * ldl + j] = g;
+                acc += g;
+            }
+        }
+    }
+    if (j < V) atomicAdd(g_bias + j, acc);
+}
+int vag_ce_bwd_colsum_launch(float* logits, int64_t ldl, int64_t rows, int64_t V, const int64_t* tgt, int64_t B, int64_t Tt,
+                             const float* vw, const float* lse, const float* inv_cnt, const float* d_loss, float* g_bias,
+                             hipStream_t s) {
+    VAG_CHECK_ARG(logits && tgt && vw && lse && inv_cnt && d_loss && g_bias && rows == B * Tt && V > 0 && ldl >= V);
+    if (rows == 0) return VAG_OK;
+    const int64_t nbx = cdiv64(ldl, 256);
+    int64_t splits = cdiv64(2048, nbx);
+    if (splits > cdiv64(rows, 8)) splits = cdiv64(rows, 8);
+    const int rows_per = (int)cdiv64(rows, splits);
+    dim3 grid((unsigned)nbx, (unsigned)cdiv64(rows, rows_per));
+    hipLaunchKernelGGL(ce_bwd_colsum_kernel, grid, dim3(256), 0, s, logits, ldl, (int)V, tgt, (int)B, (int)Tt, vw, lse,
+                       inv_cnt, d_loss, (int)rows, rows_per, g_bias);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
 // d logits from d log-softmax, in place over d_logp: dl_j = d_j - exp(logp_j) * sum_j d_j.  One block per row.
 __global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* __restrict__ logp, int64_t ldlp,
                                                              float* __restrict__ d, int64_t ldd, int V) {

@@ -93,6 +93,9 @@ int vag_loss_mt_launch(const float* nll, const float* inv_cnt, int64_t B, int64_
 // in place: logits[r,j] = d_loss * inv_cnt[b]/B * w[tgt] * (softmax_j - [j==tgt]); pad columns [V,ldl) = 0
 int vag_ce_bwd_launch(float* logits, int64_t ldl, int64_t rows, int64_t V, const int64_t* tgt, int64_t B, int64_t Tt,
                       const float* vw, const float* lse, const float* inv_cnt, const float* d_loss, hipStream_t s);
+int vag_ce_bwd_colsum_launch(float* logits, int64_t ldl, int64_t rows, int64_t V, const int64_t* tgt, int64_t B, int64_t Tt,
+                             const float* vw, const float* lse, const float* inv_cnt, const float* d_loss, float* g_bias,
+                             hipStream_t s);
 
 int vag_logsoftmax_bwd_launch(const float* logp, int64_t ldlp, float* d, int64_t ldd, int64_t rows, int64_t V,
                               hipStream_t s);
