@@ -503,8 +503,13 @@ int vag_cgru_attn_decode_seq_bwd_weights(const float* h0, const int64_t* tok, va
     VAG_TRY(vag_gemm_launch(3 * H, H, C, 1.f, z.dwp, C, 1, w.c2h, 1, C, 1.f, g.gru2.w_ih, H, nullptr, 0, s));
     VAG_TRY(vag_gemm_launch(H, C, 3 * H, 1.f, w.gru2.w_ih, 1, H, z.dwp, C, 1, 1.f, g.c2h, C, nullptr, 0, s));
     VAG_TRY(vag_colsum_launch(z.dgi2, R, 3 * H, 3 * H, g.gru2.b_ih, s));
-    VAG_TRY(gemm_tn_acc(3 * H, H, B, z.dgh1, 3 * H, h0, H, g.gru1.w_hh, H, s));
-    VAG_TRY(gemm_tn_acc(3 * H, H, R - B, z.dgh1 + B * 3 * H, 3 * H, h2_all, H, g.gru1.w_hh, H, s));
+    if (h0 + B * H == h2_all) {
+        // caller keeps [h0, h2_all] in one buffer: the previous states of all steps are one (R,H) operand
+        VAG_TRY(gemm_tn_acc(3 * H, H, R, z.dgh1, 3 * H, h0, H, g.gru1.w_hh, H, s));
+    } else {
+        VAG_TRY(gemm_tn_acc(3 * H, H, B, z.dgh1, 3 * H, h0, H, g.gru1.w_hh, H, s));
+        VAG_TRY(gemm_tn_acc(3 * H, H, R - B, z.dgh1 + B * 3 * H, 3 * H, h2_all, H, g.gru1.w_hh, H, s));
+    }
     VAG_TRY(vag_colsum_launch(z.dgh1, R, 3 * H, 3 * H, g.gru1.b_hh, s));
     VAG_TRY(gemm_tn_acc(3 * H, E, R, z.dgi1, 3 * H, e_all, E, g.gru1.w_ih, E, s));
     VAG_TRY(vag_colsum_launch(z.dgi1, R, 3 * H, 3 * H, g.gru1.b_ih, s));

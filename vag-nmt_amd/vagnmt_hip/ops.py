@@ -223,7 +223,11 @@ class _CGRUDecodeSeq(Function):
         H = Cc // 2
         E = emb.shape[1]
         Tt = tok.shape[0] - 1
-        h2 = _f32(Tt, B, H, like=enc)
+        # h0 and the Tt hidden states share one buffer, so that backward sees the previous-state sequence
+        # [h0, h2_0 .. h2_{Tt-2}] as ONE (Tt*B, H) operand of the W_hh1 gradient product
+        hseq = _f32(Tt + 1, B, H, like=enc)
+        hseq[0].copy_(h0)
+        h0, h2 = hseq[0], hseq[1:]
         c = _f32(Tt, B, Cc, like=enc)
         e = _f32(Tt, B, E, like=enc)
         ws = _f32(L.lib().vag_cgru_ws_floats(B, Ts, Tt, E, H), like=enc)
