@@ -30,6 +30,7 @@ static int gemm_tn_acc(int64_t M, int64_t N, int64_t R, const float* A, int64_t 
 // C = beta*C + A B with A (M,K) lda, B (K,N) ldb: data gradients  dX = dY W
 static int gemm_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
                    float* C, int64_t ldc, hipStream_t s) {
+    if (M <= 128 && (beta == 0.f || beta == 1.f)) return vag_skinny_nn_launch(M, N, K, A, lda, B, ldb, beta, C, ldc, s);
     return vag_gemm_launch(M, N, K, 1.f, A, lda, 1, B, ldb, 1, beta, C, ldc, nullptr, VAG_ACT_NONE, s);
 }
 
@@ -795,7 +796,7 @@ int vag_rank_loss_fwd(const float* im, const float* sv, int64_t B, int64_t S, fl
                       float* G, float* loss, vag_stream_t stream) {
     hipStream_t s = S_(stream);
     VAG_CHECK_ARG(im && sv && scores && G && loss && B > 0 && S > 0);
-    VAG_TRY(vag_gemm_launch(B, B, S, 1.f, im, S, 1, sv, 1, S, 0.f, scores, B, nullptr, 0, s));   // im s^T  (:12)
+    VAG_TRY(linear_fwd(B, B, S, im, S, sv, nullptr, 0, scores, B, s));                             // im s^T  (:12)
     return vag_rank_loss_launch(scores, B, margin, kind, G, loss, s);
 }
 int vag_rank_loss_bwd(const float* im, const float* sv, const float* G, const float* d_loss, int64_t B, int64_t S,

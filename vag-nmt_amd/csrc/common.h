@@ -79,6 +79,8 @@ int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
                       const float* bias, const float* addend, int64_t ldadd, float* out, int64_t ldo, int act,
                       hipStream_t stream);
 // out[n] += sum_m X[m*ld + n]
+int vag_skinny_nn_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                         float beta, float* C, int64_t ldc, hipStream_t stream);
 int vag_colsum_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* out, hipStream_t stream);
 int vag_colsum3_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* out, float* out2, float* out3,
                        hipStream_t stream);

@@ -641,6 +641,55 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_plain_kernel(SkinnyArgs a) 
     a.out[(int64_t)em * a.ldo + ej] = v;
 }
 
+// out[m,n] = sum_k A[m,k] B[k,n] with B stored (K,N) row-major (data gradients dX = dY W of the once-per-batch
+// M <= 128-row operators: the LDS-tiled kernels need ~14 us for these however small they are).  A is loaded as in
+// skinny_mma; B is read directly in MFMA layout, one dword per lane and k (16 consecutive n = 64 contiguous bytes).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void skinny_bt_kernel(SkinnyArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * 16, nb = blockIdx.x * 16;
+    const int erow = (threadIdx.x >> 4) & 15, ecol = threadIdx.x & 15;
+    const int em = m0 + erow, ej = nb + ecol;
+    const bool eok = threadIdx.x < 256 && em < a.M && ej < a.N;
+    const float* ap = a.A + (int64_t)min(m0 + skinny_ldrow(lane), a.M - 1) * a.lda + 4 * skinny_ldseg(lane);
+    const int src4 = 4 * (16 * (lane & 3) + (lane & 12) + (lane >> 4));
+    const int g = lane >> 4;
+    const float* bp = a.W + min(nb + (lane & 15), a.N - 1);
+    const int kper = ((a.K + WAVES - 1) / WAVES + 15) & ~15;
+    const int kbeg = wave * kper;
+    const int kend = min(a.K, kbeg + kper);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 2;
+    for (int c0 = kbeg; c0 < kend; c0 += 16 * U) {
+        float4 av[U];
+        float bv[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ka = c0 + 16 * u + 4 * skinny_ldseg(lane);
+            av[u] = ka < kend ? *reinterpret_cast<const float4*>(ap + c0 + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int kb = c0 + 16 * u + 4 * g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[u][e] = kb < kend ? bp[(int64_t)(kb + e) * a.ldw] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float4 x = skinny_xpose(av[u], src4);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, bv[u][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, bv[u][1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, bv[u][2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, bv[u][3], acc1, 0, 0, 0);
+        }
+    }
+    *reinterpret_cast<f32x4*>(&red[(wave * 64 + lane) * 4]) = acc0 + acc1;
+    __syncthreads();
+    if (!eok) return;
+    float v = skinny_sum1<WAVES, 1>(red, 0, erow, ecol);
+    if (a.bias) v += a.bias[ej];
+    if (a.addend) v += a.addend[(int64_t)em * a.ldadd + ej];
+    a.out[(int64_t)em * a.ldo + ej] = v;
+}
+
 // Fused GRU cell: 16 rows x 16 hidden units x 3 gates per workgroup.  The 256 (row, unit) outputs are finished by the
 // first 256 threads, one each; their epilogue operands (the other projection, h_prev, bias) are requested BEFORE the
 // product so that they arrive under it instead of costing a second memory round trip.
@@ -782,6 +831,24 @@ int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
     // REQUESTED chip-wide (L2 is dropped at every kernel boundary; ~6.3 TB/s aggregate, ~50 GB/s per CU), duplicates
     // included, so wider/taller tiles or half tiles do not pay at M <= 128; 16x16 with K split over the waves it is.
     skinny_plain_go(a, stream);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+// C (M,N) = beta C + A (M,K) B (K,N), B row-major with row stride ldb; M <= 128 (skinny path), else the tiled kernels.
+int vag_skinny_nn_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                         float beta, float* C, int64_t ldc, hipStream_t stream) {
+    VAG_CHECK_ARG(M >= 0 && N >= 0 && K > 0 && A && B && C && (beta == 0.f || beta == 1.f));
+    if (M == 0 || N == 0) return VAG_OK;
+    if (M > 128 || !aligned16(A) || lda % 4 != 0 || K % 4 != 0 || (double)M * (double)N * (double)K > 350e6)
+        return vag_gemm_launch(M, N, K, 1.f, A, lda, 1, B, ldb, 1, beta, C, ldc, nullptr, VAG_ACT_NONE, stream);
+    SkinnyArgs a;
+    a.A = A; a.W = B; a.lda = lda; a.ldw = ldb; a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.bias = nullptr; a.addend = beta != 0.f ? C : nullptr; a.ldadd = ldc; a.out = C; a.ldo = ldc; a.act = VAG_ACT_NONE;
+    dim3 grid((unsigned)cdiv64(N, 16), (unsigned)cdiv64(M, 16), 1);
+    if (K <= 256) hipLaunchKernelGGL((skinny_bt_kernel<4>), grid, dim3(256), 0, stream, a);
+    else if (K <= 1024) hipLaunchKernelGGL((skinny_bt_kernel<8>), grid, dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((skinny_bt_kernel<16>), grid, dim3(1024), 0, stream, a);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
