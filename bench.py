@@ -275,7 +275,7 @@ def main():
                        "global_batch": c["B"] * world, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph, "final_loss": loss},
             # dominant kernel by total time (profiles/): the fused GRU-cell step kernel, decoder gru_1 shape
-            "roofline": {"bound": "hbm", "kernel": "gru_step_kernel<8> (fused GRU cell, M=%d, H=%d, K=%d)" % (B, H, H),
+            "roofline": {"bound": "hbm", "kernel": "gru_step_small_kernel<8,8> / gru_step_kernel<8> (fused GRU cell, M=%d, H=%d, K=%d)" % (B, H, H),
                          "achieved": cell_bytes / fam["gru_cell"] / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": cell_bytes / fam["gru_cell"] / HBM_PEAK,
                          "traffic": pmc.get("gru_step_kernel_bytes_per_launch"),

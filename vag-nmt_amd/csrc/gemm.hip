@@ -563,8 +563,8 @@ __device__ __forceinline__ void skinny_mma(const float* const (&ap)[MT], const f
             for (int i = 0; i < MT; ++i)
                 av[i][u] = ok ? *reinterpret_cast<const float4*>(ap[i] + c0 + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-                wv[j][u] = ok ? *reinterpret_cast<const float4*>(wp[j] + c0 + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < NT; ++j)      // a null row pointer = this lane's row of the tile is unused: zeros, no request
+                wv[j][u] = (ok && wp[j]) ? *reinterpret_cast<const float4*>(wp[j] + c0 + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -740,8 +740,68 @@ __global__ __launch_bounds__(WAVES * 64) void gru_step_kernel(GruStepArgs a) {
     if (sd.out2) sd.out2[(int64_t)em * a.ld2 + ej] = active ? hn : 0.f;
 }
 
+// The same cell with 8 or 4 hidden units per workgroup (2x / 4x the workgroups).  UNITS = 8: tile 0 holds [r | z] of
+// the 8 units, tile 1 [n | unused]; UNITS = 4: one tile [r | z | n | unused].  For single-direction launches with
+// M <= 64 rows this puts a workgroup on every CU instead of every other one, with less MFMA time and fewer bytes per
+// workgroup (unused tile rows issue no loads).
+template <int WAVES, int UNITS>
+__global__ __launch_bounds__(WAVES * 64) void gru_step_small_kernel(GruStepArgs a) {
+    constexpr int NT = UNITS == 8 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float red[WAVES * NT * 64 * 4];
+    const GruSide& sd = a.s[blockIdx.z];
+    const int lane = threadIdx.x & 63;
+    const int r = skinny_ldrow(lane), g = skinny_ldseg(lane);
+    const int m0 = blockIdx.y * 16, u0 = blockIdx.x * UNITS;
+    const int H = a.H;
+    // epilogue operands of thread t < 16*UNITS: output (row m0 + t/UNITS, unit u0 + t%UNITS)
+    const int erow = (threadIdx.x / UNITS) & 15, ecol = threadIdx.x % UNITS;
+    const int em = m0 + erow, ej = u0 + ecol;
+    const bool eok = threadIdx.x < 16 * UNITS && em < a.M && ej < H;
+    float o_r = 0.f, o_z = 0.f, o_n = 0.f, hp = 0.f, b_r = 0.f, b_z = 0.f, b_n = 0.f;
+    bool active = true;
+    if (eok) {
+        const float* op = sd.other + (int64_t)em * a.ldother + ej;
+        o_r = op[0]; o_z = op[H]; o_n = op[2 * H];
+        hp = sd.hprev[(int64_t)em * a.ldh + ej];
+        if (sd.bias) { b_r = sd.bias[ej]; b_z = sd.bias[H + ej]; b_n = sd.bias[2 * H + ej]; }
+        if (a.lengths) active = sd.t < a.lengths[em];
+    }
+    const float* ap[1];
+    const float* wp[NT];
+    ap[0] = sd.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + 4 * g;
+    const int unit = min(u0 + (r % UNITS), H - 1);
+    const int gate = r / UNITS;                                   // gate of tile 0's row r
+    if (UNITS == 8) {
+        wp[0] = sd.W + (int64_t)(gate * H + unit) * a.ldw + 4 * g;                                  // r | z
+        wp[NT - 1] = r < 8 ? sd.W + (int64_t)(2 * H + unit) * a.ldw + 4 * g : nullptr;              // n | -
+    } else {
+        wp[0] = gate < 3 ? sd.W + (int64_t)(gate * H + unit) * a.ldw + 4 * g : nullptr;             // r | z | n | -
+    }
+    skinny_mma<WAVES, 1, NT>(ap, wp, a.K, red);
+    if (!eok) return;
+    const float c_r = skinny_sum1<WAVES, NT>(red, 0, erow, ecol) + b_r;
+    const float c_z = skinny_sum1<WAVES, NT>(red, 0, erow, UNITS + ecol) + b_z;
+    const float c_n = (UNITS == 8 ? skinny_sum1<WAVES, NT>(red, NT - 1, erow, ecol)
+                                  : skinny_sum1<WAVES, NT>(red, 0, erow, 2 * UNITS + ecol)) + b_n;
+    const float gi_n = a.comp_hidden ? o_n : c_n;
+    const float gh_n = a.comp_hidden ? c_n : o_n;
+    const float rr = vag_sigmoid(c_r + o_r);
+    const float zz = vag_sigmoid(c_z + o_z);
+    const float nn = vag_tanh(gi_n + rr * gh_n);
+    const float hn = (1.f - zz) * nn + zz * hp;
+    const int64_t o = (int64_t)em * H + ej;
+    if (sd.save) {
+        const int64_t MH = (int64_t)a.M * H;
+        sd.save[o] = rr; sd.save[MH + o] = zz; sd.save[2 * MH + o] = nn; sd.save[3 * MH + o] = gh_n;
+    }
+    sd.hout[o] = active ? hn : hp;
+    if (sd.out2) sd.out2[(int64_t)em * a.ld2 + ej] = active ? hn : 0.f;
+}
+
 // dh = A WT^T + addend, then the GRU cell backward (elementwise) that consumes dh -- see common.h.
 // Same structure: 256 outputs finished by 256 threads, epilogue operands prefetched under the product.
+// (A half-tile variant -- 8 output columns per workgroup on twice the workgroups, as gru_step_small_kernel does for the
+// forward cell -- measured no gain here: the MFMA count per workgroup stays that of a full tile.)
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gru_bwd_step_kernel(GruBwdStepArgs a) {
     __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4];
@@ -862,6 +922,21 @@ int vag_gru_step_launch(const GruStepArgs& a, int nz, hipStream_t stream) {
     // tile choice from measurements (tools/exp_tiles.py, tools/skinny_probe.hip): 16 units x 16 rows; half tiles on
     // twice the CUs were no faster (the launch is paced by load requests issued chip-wide, duplicates included).
     dim3 grid((unsigned)cdiv64(a.H, 16), (unsigned)cdiv64(a.M, 16), (unsigned)nz);
+    static const int small = getenv("VAG_GRU_UNITS") ? atoi(getenv("VAG_GRU_UNITS")) : 8;
+    const int64_t wgs = (int64_t)grid.x * grid.y * grid.z;
+    static const int64_t maxwg = getenv("VAG_GRU_SMALL_MAXWG") ? atoi(getenv("VAG_GRU_SMALL_MAXWG")) : 160;
+    if (a.K > 256 && wgs <= maxwg && (small == 8 || small == 4)) {
+        // fewer than ~2/3 of the CUs would get a workgroup: fewer units each on more workgroups
+        if (small == 8) {
+            hipLaunchKernelGGL((gru_step_small_kernel<8, 8>), dim3((unsigned)cdiv64(a.H, 8), grid.y, grid.z), dim3(512), 0,
+                               stream, a);
+        } else {
+            hipLaunchKernelGGL((gru_step_small_kernel<8, 4>), dim3((unsigned)cdiv64(a.H, 4), grid.y, grid.z), dim3(512), 0,
+                               stream, a);
+        }
+        VAG_LAUNCH_CHECK();
+        return VAG_OK;
+    }
     if (a.K <= 256) hipLaunchKernelGGL((gru_step_kernel<4>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((gru_step_kernel<8>), grid, dim3(512), 0, stream, a);
     VAG_LAUNCH_CHECK();
