@@ -199,7 +199,7 @@ int vag_attn_dq_launch(const float* pe, const float* q, int64_t ldq, const float
 
 // ------------------------------------------------------------------ after the time loop: d_pe, dv partials, d_enc
 // grid (ceil(C/256), B); thread owns one c and walks source positions in chunks of SC, all Tt steps per chunk.
-constexpr int SC = 8;
+constexpr int SC = VAG_POST_SC;
 __global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restrict__ pe, const float* __restrict__ q_all,
                                                             const float* __restrict__ v, const float* __restrict__ ds_all,
                                                             const float* __restrict__ alpha_all,

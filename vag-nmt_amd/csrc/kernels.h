@@ -55,7 +55,10 @@ int vag_gather_rows_i64_launch(const int64_t* in, int64_t ld, const int64_t* idx
                                hipStream_t s);
 
 // ---------------- attn.hip ----------------
-static inline int64_t VAG_POST_CHUNKS(int64_t Ts) { return (Ts + 7) / 8; }
+#ifndef VAG_POST_SC
+#define VAG_POST_SC 8          // source positions per attn_post_bwd block
+#endif
+static inline int64_t VAG_POST_CHUNKS(int64_t Ts) { return (Ts + VAG_POST_SC - 1) / VAG_POST_SC; }
 // mode 0: scores[n,s] = sum_c v[c] tanh(pe[b,s,c] + q[n,c]); mode 1: scores[n,s] = sum_c q[n,c] * pe[b,s,c].
 // b = n / rps.  mask (Bsrc,Ts) float or NULL: masked positions get -inf.
 // q row stride ldq (>= C).
