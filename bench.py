@@ -148,6 +148,21 @@ def measure_operators(c, dev):
                 call("vag_gru_cell_fwd", ptr(gi), ptr(hp), ptr(g1.weight_hh_l0), ptr(g1.bias_hh_l0), B, H, ptr(ho), ptr(sv),
                      stream())
         out["gru_cell"] = _time_graph(cells) / 100
+        # the dominant kernel by total time (profiles/): gru_bwd_step_kernel, encoder / decoder gru_1 shape (K = 3H)
+        dgh_next = torch.randn(B, 3 * H, device=dev)
+        wt = g1.weight_hh_l0.t().contiguous()
+        carry = torch.randn(B, H, device=dev)
+        d_out = torch.randn(B, H, device=dev)
+        sv.uniform_(0.1, 0.9)
+        dgi = torch.empty(B, 3 * H, device=dev)
+        dgh = torch.empty(B, 3 * H, device=dev)
+        cout = torch.empty(B, H, device=dev)
+
+        def cells_bwd():
+            for _ in range(100):
+                call("vag_gru_cell_bwd", ptr(dgh_next), ptr(wt), ptr(carry), ptr(d_out), ptr(sv), ptr(hp), B, H, ptr(dgi),
+                     ptr(dgh), ptr(cout), stream())
+        out["gru_cell_bwd"] = _time_graph(cells_bwd) / 100
     return out
 
 
@@ -253,6 +268,8 @@ def main():
         t_dec_step = fam["decoder_seq_fwd"] / c["Tt"]
         achieved = ab["F_dec"] / t_dec_step
         cell_bytes = 4 * (3 * H * H + 3 * H + 9 * B * H)   # W_hh, b_hh, h_prev, gi (3), h_out, 4 saved gate planes
+        # W_hh^T, dgh_next (3), carry, d_out, 4 saved gate planes, h_prev | dgi (3), dgh (3), carry_out
+        cell_bwd_bytes = 4 * (3 * H * H + 17 * B * H)
         pmc = pmc_traffic() or {}
         res = {
             "metric": "training sentence-pairs/sec (Multi30K en->de, B=%d)" % c["B"],
@@ -274,12 +291,22 @@ def main():
                                       args.tfr, ", ragged source lengths" if args.ragged else ""),
                        "global_batch": c["B"] * world, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph, "final_loss": loss},
-            # dominant kernel by total time (profiles/): the fused GRU-cell step kernel, decoder gru_1 shape
-            "roofline": {"bound": "hbm", "kernel": "gru_step_small_kernel<8,8> / gru_step_kernel<8> (fused GRU cell, M=%d, H=%d, K=%d)" % (B, H, H),
-                         "achieved": cell_bytes / fam["gru_cell"] / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": cell_bytes / fam["gru_cell"] / HBM_PEAK,
-                         "traffic": pmc.get("gru_step_kernel_bytes_per_launch"),
-                         "algorithmic_bytes_per_launch": cell_bytes, "us_per_launch": fam["gru_cell"] * 1e6},
+            # dominant kernel by total time per step (profiles/r01_bench_cfg2_kernel_stats.csv): the fused backward step of
+            # the GRU recurrences (dh product + cell backward), encoder / decoder gru_1 shape
+            "roofline": {"bound": "hbm", "kernel": "gru_bwd_step_kernel<16> (dh = dgh W_hh + cell backward, M=%d, H=%d, K=%d)"
+                                                   % (B, H, 3 * H),
+                         "achieved": cell_bwd_bytes / fam["gru_cell_bwd"] / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": cell_bwd_bytes / fam["gru_cell_bwd"] / HBM_PEAK,
+                         "traffic": pmc.get("gru_bwd_step_kernel_bytes_per_launch"),
+                         "algorithmic_bytes_per_launch": cell_bwd_bytes, "us_per_launch": fam["gru_cell_bwd"] * 1e6},
+            # second by total time: the fused forward GRU cell, decoder gru_1 shape
+            "roofline_gru_cell_fwd": {"bound": "hbm",
+                                      "kernel": "gru_step_small_kernel<8,8> / gru_step_kernel<8> (fused GRU cell, M=%d, H=%d, K=%d)"
+                                                % (B, H, H),
+                                      "achieved": cell_bytes / fam["gru_cell"] / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                      "frac": cell_bytes / fam["gru_cell"] / HBM_PEAK,
+                                      "traffic": pmc.get("gru_step_kernel_bytes_per_launch"),
+                                      "algorithmic_bytes_per_launch": cell_bytes, "us_per_launch": fam["gru_cell"] * 1e6},
             # the BASELINE.json target quantity: one GRU+attention decoder step against the HBM streaming model
             "roofline_decoder_step": {"bound": "hbm", "kernel": "vag_cgru_attn_decode_seq_fwd / Tt (5 kernels per step)",
                                       "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
@@ -291,6 +318,7 @@ def main():
         }
         if args.config != "cfg2":
             res["roofline"]["traffic"] = res["roofline_decoder_step"]["traffic"] = None     # PMC passes were taken at cfg2
+            res["roofline_gru_cell_fwd"]["traffic"] = None
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
             res["cpu_baseline"] = cpu_baseline(c)
         print(json.dumps(res))

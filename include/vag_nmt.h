@@ -97,6 +97,16 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fwd,
 int vag_gru_cell_fwd(const float* gi, const float* h_prev, const float* w_hh, const float* b_hh, int64_t M,
                      int64_t H, float* h_out, float* save, vag_stream_t stream);
 
+/* One backward step of the same recurrence (what autograd replays per time step for nn.GRU, layers/Encoder.py:58,
+ * layers/NMT_Decoder.py:121,129), fused the way the sequence operators run it:
+ *   dh  = dgh_next W_hh + carry + d_out        dgh_next (M,3H): gradient of the LATER step's hidden projection,
+ *                                              w_hh_t (H,3H) = W_hh^T, carry / d_out (M,H) may be NULL
+ *   dgi (M,3H), dgh (M,3H) = cell backward of THIS step (save [4][M][H] from vag_gru_cell_fwd, h_prev (M,H))
+ *   carry_out (M,H) = z * dh                   (the part of dh that flows to the previous step directly) */
+int vag_gru_cell_bwd(const float* dgh_next, const float* w_hh_t, const float* carry, const float* d_out,
+                     const float* save, const float* h_prev, int64_t M, int64_t H, float* dgi, float* dgh,
+                     float* carry_out, vag_stream_t stream);
+
 /* ---- a4 (hoisted part): attention keys pe = enc W_e^T, layers/NMT_Decoder.py:47 ----------------------- */
 /* The reference recomputes attn_e(encoder_outputs) at every decoder step; it does not depend on the step,
  * so it is computed once per batch.  rows = B*Ts. */

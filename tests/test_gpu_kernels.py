@@ -93,3 +93,45 @@ def test_linear_bwd():
     for got, want in ((dx, x.grad), (gW, W.grad), (gb, b.grad)):
         err = (got.cpu().double() - want).abs().max() / want.abs().max()
         assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("M,H", [(64, 512), (5, 24), (16, 128), (33, 40)])
+def test_gru_cell_fwd_bwd_match_torch_autograd(M, H):
+    """vag_gru_cell_fwd / vag_gru_cell_bwd (one recurrence step each way) against torch.nn.GRUCell + autograd, fp32
+    tolerance 1e-4 of the largest entry: two chained steps, so that the backward of the first step receives its
+    hidden-state gradient through the recurrent projection of the second (the fused form the sequence kernels use)."""
+    L = _lib()
+    torch.manual_seed(M * 131 + H)
+    cell = torch.nn.GRUCell(H, H)
+    x1, x2, h0 = torch.randn(M, H), torch.randn(M, H), torch.randn(M, H, requires_grad=True)
+    h1 = cell(x1, h0)
+    h2 = cell(x2, h1)
+    d_out1, d_out2 = torch.randn(M, H), torch.randn(M, H)
+    (h1 * d_out1).sum().add((h2 * d_out2).sum()).backward()
+    dev = "cuda:0"
+    W_ih, W_hh, b_ih, b_hh = [p.detach().to(dev) for p in (cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)]
+    gi1 = (x1.to(dev) @ W_ih.t() + b_ih).contiguous()
+    gi2 = (x2.to(dev) @ W_ih.t() + b_ih).contiguous()
+    h0d = h0.detach().to(dev)
+    h1d, h2d = torch.empty(M, H, device=dev), torch.empty(M, H, device=dev)
+    s1, s2 = torch.empty(4, M, H, device=dev), torch.empty(4, M, H, device=dev)
+    L.call("vag_gru_cell_fwd", L.ptr(gi1), L.ptr(h0d), L.ptr(W_hh), L.ptr(b_hh), M, H, L.ptr(h1d), L.ptr(s1), L.stream())
+    L.call("vag_gru_cell_fwd", L.ptr(gi2), L.ptr(h1d), L.ptr(W_hh), L.ptr(b_hh), M, H, L.ptr(h2d), L.ptr(s2), L.stream())
+    assert (h1d.cpu() - h1.detach()).abs().max() < 1e-4 and (h2d.cpu() - h2.detach()).abs().max() < 1e-4
+    # last step: no later step -> zero recurrent contribution (a zero dgh_next), no carry
+    WT = W_hh.t().contiguous()                       # (H, 3H)
+    zero = torch.zeros(M, 3 * H, device=dev)
+    dgi2, dgh2, c2 = torch.empty(M, 3 * H, device=dev), torch.empty(M, 3 * H, device=dev), torch.empty(M, H, device=dev)
+    L.call("vag_gru_cell_bwd", L.ptr(zero), L.ptr(WT), None, L.ptr(d_out2.to(dev)), L.ptr(s2), L.ptr(h1d), M, H,
+           L.ptr(dgi2), L.ptr(dgh2), L.ptr(c2), L.stream())
+    dgi1, dgh1, c1 = torch.empty(M, 3 * H, device=dev), torch.empty(M, 3 * H, device=dev), torch.empty(M, H, device=dev)
+    L.call("vag_gru_cell_bwd", L.ptr(dgh2), L.ptr(WT), L.ptr(c2), L.ptr(d_out1.to(dev)), L.ptr(s1), L.ptr(h0d), M, H,
+           L.ptr(dgi1), L.ptr(dgh1), L.ptr(c1), L.stream())
+    # parameter gradients follow from the per-step gate gradients; d h0 = dgh1 W_hh + z1 * dh1
+    got = {"weight_ih": dgi1.t() @ x1.to(dev) + dgi2.t() @ x2.to(dev), "weight_hh": dgh1.t() @ h0d + dgh2.t() @ h1d,
+           "bias_ih": dgi1.sum(0) + dgi2.sum(0), "bias_hh": dgh1.sum(0) + dgh2.sum(0)}
+    for n, g in got.items():
+        ref = getattr(cell, n).grad
+        assert (g.cpu() - ref).abs().max() <= 1e-4 * max(1.0, ref.abs().max().item()), n
+    d_h0 = dgh1 @ W_hh + c1
+    assert (d_h0.cpu() - h0.grad).abs().max() <= 1e-4 * max(1.0, h0.grad.abs().max().item())

@@ -15,21 +15,26 @@ def load(d, counter):
 fetch = load(sys.argv[1], "FETCH_SIZE")
 write = load(sys.argv[2], "WRITE_SIZE")
 Tt, NSEQ = 40, 3
-DEC = ("gru_step_kernel", "skinny_plain_kernel", "attn_scores_kernel", "attn_ctx_kernel")
+DEC = ("gru_step_kernel", "gru_step_small_kernel", "skinny_plain_kernel", "attn_scores_kernel", "attn_ctx_kernel")
 def total(d, pred):
     return sum(sum(v) for k, v in d.items() if pred(k))
 def kib(x):
     return x * 1024.0
 # decoder step = everything the seq op launches inside its loop (isolated gru-cell launches are the LAST 200 gru_step dispatches)
-g_f = [v for k, v in fetch.items() if "gru_step_kernel" in k][0]
-g_w = [v for k, v in write.items() if "gru_step_kernel" in k][0]
+g_f = [v for k, v in fetch.items() if "gru_step_small_kernel" in k][0]      # decoder-shape cells (M=64, one direction)
+g_w = [v for k, v in write.items() if "gru_step_small_kernel" in k][0]
 cell_fetch = sum(g_f[-200:]) / 200; cell_write = sum(g_w[-200:]) / 200
 dec_fetch = (total(fetch, lambda k: any(n in k for n in DEC)) - sum(g_f[-200:]))
 dec_write = (total(write, lambda k: any(n in k for n in DEC)) - sum(g_w[-200:]))
+b_f = [v for k, v in fetch.items() if "gru_bwd_step_kernel" in k][0]
+b_w = [v for k, v in write.items() if "gru_bwd_step_kernel" in k][0]
+bwd_fetch = sum(b_f[-200:]) / 200; bwd_write = sum(b_w[-200:]) / 200
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/prof_decoder_fwd.py",
        "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B), KiB -> bytes",
        "gru_step_kernel_bytes_per_launch": kib(2 * cell_fetch + cell_write),
        "gru_step_kernel_fetch_bytes": kib(2 * cell_fetch), "gru_step_kernel_write_bytes": kib(cell_write),
+       "gru_bwd_step_kernel_bytes_per_launch": kib(2 * bwd_fetch + bwd_write),
+       "gru_bwd_step_kernel_fetch_bytes": kib(2 * bwd_fetch), "gru_bwd_step_kernel_write_bytes": kib(bwd_write),
        "decoder_step_bytes": kib(2 * dec_fetch + dec_write) / (NSEQ * Tt)}
 json.dump(res, open(os.path.join(ROOT, "profiles", "r01_pmc.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -1,4 +1,5 @@
-"""Workload for PMC passes: N launches of the decoder sequence forward (cfg2) + 200 isolated GRU-cell launches."""
+"""Workload for PMC passes: N launches of the decoder sequence forward (cfg2) + 200 isolated GRU-cell launches
+(forward) + 200 isolated GRU backward-step launches."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "vag-nmt_amd"))
@@ -26,5 +27,12 @@ with torch.no_grad():
     ho = torch.empty(B, H, device=dev); sv = torch.empty(4, B, H, device=dev)
     for _ in range(200):
         call("vag_gru_cell_fwd", ptr(gi), ptr(hp), ptr(dec.gru_1.weight_hh_l0), ptr(dec.gru_1.bias_hh_l0), B, H, ptr(ho), ptr(sv), stream())
+    # 200 isolated launches of the backward step kernel (encoder / decoder gru_1 shape)
+    dgh_next = torch.randn(B, 3 * H, device=dev); wt = dec.gru_1.weight_hh_l0.t().contiguous()
+    carry = torch.randn(B, H, device=dev); d_out = torch.randn(B, H, device=dev); sv.uniform_(0.1, 0.9)
+    dgi = torch.empty(B, 3 * H, device=dev); dgh = torch.empty(B, 3 * H, device=dev); cout = torch.empty(B, H, device=dev)
+    for _ in range(200):
+        call("vag_gru_cell_bwd", ptr(dgh_next), ptr(wt), ptr(carry), ptr(d_out), ptr(sv), ptr(hp), B, H, ptr(dgi), ptr(dgh),
+             ptr(cout), stream())
 torch.cuda.synchronize()
 print("done")

@@ -220,6 +220,23 @@ int vag_gru_cell_fwd(const float* gi, const float* h_prev, const float* w_hh, co
     return vag_gru_step_launch(a, 1, S_(stream));
 }
 
+// One backward step of a GRU recurrence (what torch autograd replays per time step for nn.GRU): the hidden-state
+// gradient arriving through the later step's recurrent projection, plus the carried and the direct contributions, then
+// the cell backward.  save = [4][M][H] (r, z, n, W_hn h + b_hn) as written by vag_gru_cell_fwd.
+int vag_gru_cell_bwd(const float* dgh_next, const float* w_hh_t, const float* carry, const float* d_out, const float* save,
+                     const float* h_prev, int64_t M, int64_t H, float* dgi, float* dgh, float* carry_out,
+                     vag_stream_t stream) {
+    VAG_CHECK_ARG(dgh_next && w_hh_t && save && h_prev && dgi && dgh && carry_out && M > 0 && H > 0 && H % 4 == 0);
+    GruBwdStepArgs f = {};
+    f.lda = 3 * H; f.ldw = 3 * H; f.ld_add = H; f.ldh = H; f.ldgi = 3 * H; f.ldgh = 3 * H;
+    f.M = (int)M; f.K = (int)(3 * H); f.H = (int)H; f.lengths = nullptr; f.rng = nullptr; f.sid = 0; f.p = 0.f;
+    f.has_cell = 1;
+    GruBwdStepSide& sd = f.s[0];
+    sd.A = dgh_next; sd.WT = w_hh_t; sd.addend = carry; sd.dh_add = d_out; sd.drop_idx0 = 0; sd.save = save;
+    sd.hprev = h_prev; sd.dgi = dgi; sd.dgh = dgh; sd.dh_direct = carry_out; sd.dh_out = nullptr; sd.t = 0;
+    return vag_gru_bwd_step_launch(f, 1, S_(stream));
+}
+
 // =====================================================================================================
 // attention keys
 // =====================================================================================================

@@ -43,6 +43,7 @@ PROTOS = {
     "vag_bigru_seq_fwd": (I32, [P, P, P, GruW, GruW, F, F, P, I64, I64, I64, I64, P, P, P, P]),
     "vag_bigru_seq_bwd": (I32, [P, P, GruW, GruW, F, F, P, I64, I64, I64, I64, P, P, P, GruW, GruW, P]),
     "vag_gru_cell_fwd": (I32, [P, P, P, P, I64, I64, P, P, P]),
+    "vag_gru_cell_bwd": (I32, [P, P, P, P, P, P, I64, I64, P, P, P, P]),
     "vag_attn_keys_proj": (I32, [P, P, I64, I64, P, P]),
     "vag_bahdanau_attn_fwd": (I32, [P, P, P, P, P, I64, I64, I64, I64, P, P, P, P]),
     "vag_attn_keys_proj_bwd": (I32, [P, P, P, I64, I64, P, I32, P, P]),
