@@ -3,6 +3,7 @@
 // work on the caller's stream, so whole training steps can be captured into a HIP graph.
 #include "../../include/vag_nmt.h"
 #include "kernels.h"
+#include <cstdlib>
 
 #define S_(x) reinterpret_cast<hipStream_t>(x)
 

@@ -53,14 +53,17 @@ int vag_attn_scores_launch(int mode, const float* pe, const float* q, int64_t ld
 }
 
 // ------------------------------------------------------------------ softmax + context
-// grid (ceil(C/256), N); one 64-lane wave per workgroup, each lane owns one float4 of c.  Small workgroups on
-// purpose: the kernel streams Ts x 1 KB of enc per wave, and per-CU fetch bandwidth is the limit, so the row is
-// spread over 4 CUs (C=1024) instead of one.  The Ts-element softmax is recomputed by every wave (it is tiny).
-__global__ __launch_bounds__(64) void attn_ctx_kernel(int softmax, const float* __restrict__ scores,
+// grid (ceil(C/256), N), CTX_WAVES waves per workgroup: lane owns one float4 of c, wave w walks the source positions
+// s = w, w + CTX_WAVES, ... with 5 value rows in flight, partial sums meet in LDS.  (One wave per workgroup streamed its
+// 41 KB in ~3.5 us; tools/stream_probe.hip: the more waves of a CU have loads in flight, the closer to HBM rate.)
+// The Ts-element softmax is recomputed by every wave (it is tiny).
+constexpr int CTX_WAVES = 4;
+__global__ __launch_bounds__(64 * CTX_WAVES) void attn_ctx_kernel(int softmax, const float* __restrict__ scores,
                                                       const float* __restrict__ enc, int rps, int Ts, int C,
                                                       float* __restrict__ alpha, float* __restrict__ ctx) {
-    extern __shared__ __attribute__((aligned(16))) float w[];   // Ts weights
-    const int lane = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float w[];   // Ts weights, then CTX_WAVES x 64 float4 partials
+    float4* part = reinterpret_cast<float4*>(w + ((Ts + 3) & ~3));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t n = blockIdx.y;
     const int64_t b = n / rps;
     const float* sc = scores + n * Ts;
@@ -69,51 +72,65 @@ __global__ __launch_bounds__(64) void attn_ctx_kernel(int softmax, const float* 
         for (int s = lane; s < Ts; s += 64) mx = fmaxf(mx, sc[s]);
         mx = wave_max(mx);
         float sum = 0.f;
-        for (int s = lane; s < Ts; s += 64) {
-            const float e = __expf(sc[s] - mx);
-            w[s] = e;
-            sum += e;
-        }
+        for (int s = lane; s < Ts; s += 64) sum += __expf(sc[s] - mx);
         sum = wave_sum(sum);
         const float inv = 1.f / sum;
-        for (int s = lane; s < Ts; s += 64) {
-            const float a = w[s] * inv;
+        for (int s = threadIdx.x; s < Ts; s += 64 * CTX_WAVES) {
+            const float a = __expf(sc[s] - mx) * inv;
             w[s] = a;
             if (blockIdx.x == 0 && alpha) alpha[n * Ts + s] = a;
         }
     } else {
-        for (int s = lane; s < Ts; s += 64) w[s] = sc[s];
+        for (int s = threadIdx.x; s < Ts; s += 64 * CTX_WAVES) w[s] = sc[s];
     }
     __syncthreads();
     const int c = (blockIdx.x * 64 + lane) * 4;
-    if (c >= C) return;
-    const float* e = enc + b * Ts * C + c;
+    const bool cok = c < C;
     float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s0 = 0; s0 < Ts; s0 += 8) {
-        float4 ev[8];
+    if (cok) {
+        const float* e = enc + b * Ts * C + c;
+        constexpr int U = 5;
+        for (int s0 = wave; s0 < Ts; s0 += U * CTX_WAVES) {
+            float4 ev[U];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int s = min(s0 + i, Ts - 1);
-            ev[i] = *reinterpret_cast<const float4*>(e + (int64_t)s * C);
-        }
+            for (int i = 0; i < U; ++i) {
+                const int s = min(s0 + i * CTX_WAVES, Ts - 1);
+                ev[i] = *reinterpret_cast<const float4*>(e + (int64_t)s * C);
+            }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float a = (s0 + i < Ts) ? w[s0 + i] : 0.f;
-            acc0.x += a * ev[i].x; acc0.y += a * ev[i].y; acc0.z += a * ev[i].z; acc0.w += a * ev[i].w;
+            for (int i = 0; i < U; ++i) {
+                const int s = s0 + i * CTX_WAVES;
+                const float a = (s < Ts) ? w[s] : 0.f;
+                acc0.x += a * ev[i].x; acc0.y += a * ev[i].y; acc0.z += a * ev[i].z; acc0.w += a * ev[i].w;
+            }
         }
     }
-    *reinterpret_cast<float4*>(ctx + n * C + c) = acc0;
+    part[wave * 64 + lane] = acc0;
+    __syncthreads();
+    if (wave == 0 && cok) {
+#pragma unroll
+        for (int k = 1; k < CTX_WAVES; ++k) {
+            const float4 o = part[k * 64 + lane];
+            acc0.x += o.x; acc0.y += o.y; acc0.z += o.z; acc0.w += o.w;
+        }
+        *reinterpret_cast<float4*>(ctx + n * C + c) = acc0;
+    }
 }
 
 int vag_attn_ctx_launch(int softmax, const float* scores, const float* enc, int64_t N, int64_t rps, int64_t Ts,
                         int64_t C, float* alpha, float* ctx, hipStream_t s) {
     VAG_CHECK_ARG(scores && enc && ctx && N > 0 && Ts > 0 && C > 0 && C % 4 == 0 && rps >= 1);
     dim3 grid((unsigned)cdiv64(C, 256), (unsigned)N);
-    hipLaunchKernelGGL(attn_ctx_kernel, grid, dim3(64), (size_t)Ts * sizeof(float), s, softmax, scores, enc, (int)rps,
+    const size_t lds = (size_t)((Ts + 3) & ~3) * sizeof(float) + (size_t)CTX_WAVES * 64 * 16;
+    hipLaunchKernelGGL(attn_ctx_kernel, grid, dim3(64 * CTX_WAVES), lds, s, softmax, scores, enc, (int)rps,
                        (int)Ts, (int)C, alpha, ctx);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
+
+// (A one-launch scores + softmax + context kernel -- one 1024-thread workgroup per query row, 3.8 us for its 328 KB by
+// tools/stream_probe.hip -- measured the same 9.9 us as the two launches: the Ts*C tanh evaluations of a row are bound
+// by the transcendental rate of the 64 CUs that then hold them, 3.2 us, instead of 0.8 us spread over the chip.)
 
 // ------------------------------------------------------------------ softmax backward (one wave per row)
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ alpha, const float* __restrict__ dalpha,
@@ -134,56 +151,72 @@ int vag_softmax_bwd_launch(const float* alpha, const float* dalpha, int64_t N, i
 }
 
 // ------------------------------------------------------------------ dq (inside the backward time loop)
-// grid (ceil(C/256), N); one wave per workgroup, lane owns a float4 of c and walks the Ts source positions.
-// With alpha/dalpha given, the softmax backward  ds = alpha * (dalpha - sum alpha dalpha)  is done in the prologue
-// (every wave recomputes the Ts values; the first column block stores them for the post-loop kernel).
-__global__ __launch_bounds__(64) void attn_dq_kernel(const float* __restrict__ pe, const float* __restrict__ q,
+// grid (ceil(C/256), N), 4 waves per workgroup: lane owns a float4 of c, wave w walks the source positions s = w, w+4, ...
+// (the Ts*C tanh evaluations of a row are transcendental-rate bound: one wave per (row, column block) left three of a
+// CU's four SIMDs idle), partial sums meet in LDS.  With alpha/dalpha given, the softmax backward
+// ds = alpha * (dalpha - sum alpha dalpha) is done in the prologue (the first column block stores it for the post-loop
+// kernel).
+constexpr int DQ_WAVES = 4;
+__global__ __launch_bounds__(64 * DQ_WAVES) void attn_dq_kernel(const float* __restrict__ pe, const float* __restrict__ q,
                                                      int64_t ldq, const float* __restrict__ v,
                                                      const float* __restrict__ alpha, const float* __restrict__ dalpha,
                                                      float* __restrict__ dscore, int Ts, int C, float* __restrict__ dq,
                                                      int64_t lddq) {
-    extern __shared__ __attribute__((aligned(16))) float w[];
-    const int lane = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float w[];      // Ts weights, then DQ_WAVES x 64 float4 partials
+    float4* part = reinterpret_cast<float4*>(w + ((Ts + 3) & ~3));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t n = blockIdx.y;
     if (alpha) {
         float dot = 0.f;
         for (int s = lane; s < Ts; s += 64) dot += alpha[n * Ts + s] * dalpha[n * Ts + s];
         dot = wave_sum(dot);
-        for (int s = lane; s < Ts; s += 64) {
+        for (int s = threadIdx.x; s < Ts; s += 64 * DQ_WAVES) {
             const float d = alpha[n * Ts + s] * (dalpha[n * Ts + s] - dot);
             w[s] = d;
             if (blockIdx.x == 0) dscore[n * Ts + s] = d;
         }
     } else {
-        for (int s = lane; s < Ts; s += 64) w[s] = dscore[n * Ts + s];
+        for (int s = threadIdx.x; s < Ts; s += 64 * DQ_WAVES) w[s] = dscore[n * Ts + s];
     }
     __syncthreads();
     const int c = (blockIdx.x * 64 + lane) * 4;
-    if (c >= C) return;
-    const float4 qv = *reinterpret_cast<const float4*>(q + n * ldq + c);
-    const float4 vv = *reinterpret_cast<const float4*>(v + c);
-    const float* p = pe + n * Ts * C + c;
+    const bool cok = c < C;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    // straight-line, 8 key rows in flight per lane: the loop is latency-bound on the pe stream otherwise
-    for (int s0 = 0; s0 < Ts; s0 += 8) {
-        float4 pv[8];
+    if (cok) {
+        const float4 qv = *reinterpret_cast<const float4*>(q + n * ldq + c);
+        const float* p = pe + n * Ts * C + c;
+        // 4 key rows in flight per lane
+        for (int s0 = wave; s0 < Ts; s0 += 4 * DQ_WAVES) {
+            float4 pv[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int s = min(s0 + i, Ts - 1);
-            pv[i] = *reinterpret_cast<const float4*>(p + (int64_t)s * C);
-        }
+            for (int i = 0; i < 4; ++i) {
+                const int s = min(s0 + i * DQ_WAVES, Ts - 1);
+                pv[i] = *reinterpret_cast<const float4*>(p + (int64_t)s * C);
+            }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float d = (s0 + i < Ts) ? w[s0 + i] : 0.f;     // masked positions carry d = 0
-            float th;
-            th = vag_tanh(pv[i].x + qv.x); acc.x += d * (1.f - th * th);
-            th = vag_tanh(pv[i].y + qv.y); acc.y += d * (1.f - th * th);
-            th = vag_tanh(pv[i].z + qv.z); acc.z += d * (1.f - th * th);
-            th = vag_tanh(pv[i].w + qv.w); acc.w += d * (1.f - th * th);
+            for (int i = 0; i < 4; ++i) {
+                const int s = s0 + i * DQ_WAVES;
+                const float d = (s < Ts) ? w[s] : 0.f;             // masked positions carry d = 0
+                float th;
+                th = vag_tanh(pv[i].x + qv.x); acc.x += d * (1.f - th * th);
+                th = vag_tanh(pv[i].y + qv.y); acc.y += d * (1.f - th * th);
+                th = vag_tanh(pv[i].z + qv.z); acc.z += d * (1.f - th * th);
+                th = vag_tanh(pv[i].w + qv.w); acc.w += d * (1.f - th * th);
+            }
         }
     }
-    acc.x *= vv.x; acc.y *= vv.y; acc.z *= vv.z; acc.w *= vv.w;
-    *reinterpret_cast<float4*>(dq + n * lddq + c) = acc;
+    part[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (wave == 0 && cok) {
+#pragma unroll
+        for (int k = 1; k < DQ_WAVES; ++k) {
+            const float4 o = part[k * 64 + lane];
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+        const float4 vv = *reinterpret_cast<const float4*>(v + c);
+        acc.x *= vv.x; acc.y *= vv.y; acc.z *= vv.z; acc.w *= vv.w;
+        *reinterpret_cast<float4*>(dq + n * lddq + c) = acc;
+    }
 }
 int vag_attn_dq_launch(const float* pe, const float* q, int64_t ldq, const float* v, const float* alpha,
                        const float* dalpha, float* dscore, int64_t N, int64_t Ts, int64_t C, float* dq, int64_t lddq,
@@ -191,7 +224,8 @@ int vag_attn_dq_launch(const float* pe, const float* q, int64_t ldq, const float
     VAG_CHECK_ARG(pe && q && v && dscore && dq && N > 0 && Ts > 0 && C > 0 && C % 4 == 0 && ldq % 4 == 0 && lddq % 4 == 0);
     VAG_CHECK_ARG((alpha == nullptr) == (dalpha == nullptr));
     dim3 grid((unsigned)cdiv64(C, 256), (unsigned)N);
-    hipLaunchKernelGGL(attn_dq_kernel, grid, dim3(64), (size_t)Ts * sizeof(float), s, pe, q, ldq, v, alpha, dalpha, dscore,
+    const size_t lds = (size_t)((Ts + 3) & ~3) * sizeof(float) + (size_t)DQ_WAVES * 64 * 16;
+    hipLaunchKernelGGL(attn_dq_kernel, grid, dim3(64 * DQ_WAVES), lds, s, pe, q, ldq, v, alpha, dalpha, dscore,
                        (int)Ts, (int)C, dq, lddq);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
