@@ -192,6 +192,7 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
         VAG_TRY(vag_gru_bwd_step_launch(f, 2, s));
         cur ^= 1;
     }
+    vag_gemm_group_begin();      // the four weight gradients (both directions) go out as one grouped launch
     for (int d = 0; d < 2; ++d) {
         const vag_gru_w& g = d == 0 ? fw : bw;
         const vag_gru_g& gg = d == 0 ? g_fw : g_bw;
@@ -203,6 +204,7 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
         VAG_TRY(vag_colsum_launch(d_xp + d * 3 * H, R, 3 * H, 6 * H, gg.b_ih, s));
         VAG_TRY(gemm_nn(R, E, 3 * H, d_xp + d * 3 * H, 6 * H, g.w_ih, E, d == 0 ? 0.f : 1.f, w.dx, E, s));
     }
+    VAG_TRY(vag_gemm_group_end(s));
     VAG_TRY(vag_embed_scatter_launch(src, 1, Ts, Ts, B, w.dx, E, g_emb, rng, VAG_DROP_ENC_EMB, p_emb, s));
     return VAG_OK;
 }
@@ -514,14 +516,12 @@ int vag_cgru_attn_decode_seq_bwd_weights(const float* h0, const int64_t* tok, va
     CgruBwdScratch z = cgru_bwd_scratch(scratch, B, Ts, Tt, E, H);
     VAG_TRY(vag_colsum_launch(z.dvp, VAG_POST_CHUNKS(Ts) * B, C, C, g.attn_v, s));
     const float* dgh2 = z.dqgh + C;      // (R,3H) row stride Q
+    vag_gemm_group_begin();              // the independent K = Tt*B weight gradients go out as one grouped launch
     VAG_TRY(gemm_tn_acc(3 * H, H, R, dgh2, Q, k.h1, H, g.gru2.w_hh, H, s));
     VAG_TRY(vag_colsum_launch(dgh2, R, 3 * H, Q, g.gru2.b_hh, s));
     VAG_TRY(gemm_tn_acc(C, H, R, z.dqgh, Q, k.h1, H, g.attn_h, H, s));
     // d(W_ih2 W_c2h) = dgi2^T c, then the chain rule through the folded product
     VAG_TRY(vag_gemm_launch(3 * H, C, R, 1.f, z.dgi2, 1, 3 * H, c_all, C, 1, 0.f, z.dwp, C, nullptr, 0, s));
-    VAG_TRY(vag_gemm_launch(3 * H, H, C, 1.f, z.dwp, C, 1, w.c2h, 1, C, 1.f, g.gru2.w_ih, H, nullptr, 0, s));
-    VAG_TRY(vag_gemm_launch(H, C, 3 * H, 1.f, w.gru2.w_ih, 1, H, z.dwp, C, 1, 1.f, g.c2h, C, nullptr, 0, s));
-    VAG_TRY(vag_colsum_launch(z.dgi2, R, 3 * H, 3 * H, g.gru2.b_ih, s));
     if (h0 + B * H == h2_all) {
         // caller keeps [h0, h2_all] in one buffer: the previous states of all steps are one (R,H) operand
         VAG_TRY(gemm_tn_acc(3 * H, H, R, z.dgh1, 3 * H, h0, H, g.gru1.w_hh, H, s));
@@ -529,8 +529,12 @@ int vag_cgru_attn_decode_seq_bwd_weights(const float* h0, const int64_t* tok, va
         VAG_TRY(gemm_tn_acc(3 * H, H, B, z.dgh1, 3 * H, h0, H, g.gru1.w_hh, H, s));
         VAG_TRY(gemm_tn_acc(3 * H, H, R - B, z.dgh1 + B * 3 * H, 3 * H, h2_all, H, g.gru1.w_hh, H, s));
     }
-    VAG_TRY(vag_colsum_launch(z.dgh1, R, 3 * H, 3 * H, g.gru1.b_hh, s));
     VAG_TRY(gemm_tn_acc(3 * H, E, R, z.dgi1, 3 * H, e_all, E, g.gru1.w_ih, E, s));
+    VAG_TRY(vag_gemm_group_end(s));      // z.dwp is complete from here on
+    VAG_TRY(vag_gemm_launch(3 * H, H, C, 1.f, z.dwp, C, 1, w.c2h, 1, C, 1.f, g.gru2.w_ih, H, nullptr, 0, s));
+    VAG_TRY(vag_gemm_launch(H, C, 3 * H, 1.f, w.gru2.w_ih, 1, H, z.dwp, C, 1, 1.f, g.c2h, C, nullptr, 0, s));
+    VAG_TRY(vag_colsum_launch(z.dgi2, R, 3 * H, 3 * H, g.gru2.b_ih, s));
+    VAG_TRY(vag_colsum_launch(z.dgh1, R, 3 * H, 3 * H, g.gru1.b_hh, s));
     VAG_TRY(vag_colsum_launch(z.dgi1, R, 3 * H, 3 * H, g.gru1.b_ih, s));
     // d(embedded inputs) = dgi1 W_ih1 (+ the head's W3 path), scattered into the embedding gradient
     if (d_e_all) VAG_TRY(copy_async(z.de, d_e_all, R * E * sizeof(float), s));
@@ -619,13 +623,14 @@ static int head_bwd_weights(const float* h2_all, const float* c_all, const float
                             int64_t V, const float* tmid, const float* dlogits, int64_t ldl, const float* dt,
                             const vag_head_g& g, hipStream_t s, bool out_b_done = false) {
     const int64_t C = 2 * H;
+    vag_gemm_group_begin();
     VAG_TRY(gemm_tn_acc(V, E, R, dlogits, ldl, tmid, E, g.out_w, E, s));
     if (!out_b_done) VAG_TRY(vag_colsum_launch(dlogits, R, V, ldl, g.out_b, s));
     VAG_TRY(gemm_tn_acc(E, H, R, dt, E, h2_all, H, g.w1, H, s));
     VAG_TRY(gemm_tn_acc(E, C, R, dt, E, c_all, C, g.w2, C, s));
     VAG_TRY(gemm_tn_acc(E, E, R, dt, E, e_all, E, g.w3, E, s));
     VAG_TRY(vag_colsum3_launch(dt, R, E, E, g.b1, g.b2, g.b3, s));     // b1, b2, b3 enter the same sum (NMT_Decoder.py:137)
-    return VAG_OK;
+    return vag_gemm_group_end(s);
 }
 
 static bool head_g_ok(const vag_head_g& g) { return g.w1 && g.b1 && g.w2 && g.b2 && g.w3 && g.b3 && g.out_w && g.out_b; }

@@ -81,6 +81,10 @@ int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
 // out[n] += sum_m X[m*ld + n]
 int vag_skinny_nn_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                          float beta, float* C, int64_t ldc, hipStream_t stream);
+// queue the qualifying (weight-gradient shaped) products issued between begin and end into one grouped launch;
+// nothing queued may be read or overwritten by work enqueued before vag_gemm_group_end
+void vag_gemm_group_begin();
+int vag_gemm_group_end(hipStream_t stream);
 int vag_colsum_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* out, hipStream_t stream);
 int vag_colsum3_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* out, float* out2, float* out3,
                        hipStream_t stream);

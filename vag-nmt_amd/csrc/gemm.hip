@@ -298,12 +298,11 @@ __device__ __forceinline__ bf16x8 sp_frag(const __bf16* p) {      // 8 consecuti
 }
 
 template <bool AKC, bool BKC, bool VEC>
-__global__ __launch_bounds__(512) void gemm_split_kernel(GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) __bf16 smem[6 * SP_PLANE];
+__device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem, int bx, int by, int bz) {
     __bf16* As = smem;
     __bf16* Bs = smem + 3 * SP_PLANE;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
-    const int kbeg = blockIdx.z * a.kchunk;
+    const int m0 = by * 128, n0 = bx * 128;
+    const int kbeg = bz * a.kchunk;
     const int kend = min(a.K, kbeg + a.kchunk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -356,7 +355,7 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(GemmArgs a) {
 
     // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     const bool atomic = a.splitk > 1;
-    const bool first = blockIdx.z == 0;
+    const bool first = bz == 0;
     const int col = n0 + wn * 32 + (lane & 31);
     if (col >= a.N) return;
     const float bv = (a.bias && first) ? a.bias[col] : 0.f;
@@ -376,6 +375,33 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(GemmArgs a) {
                 *cp = v;
             }
         }
+}
+
+template <bool AKC, bool BKC, bool VEC>
+__global__ __launch_bounds__(512) void gemm_split_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) __bf16 smem[6 * SP_PLANE];
+    gemm_split_body<AKC, BKC, VEC>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped launch: the blocks of up to GROUP_MAX independent products (all "TN": both operands outer-contiguous, the
+// weight gradients g_W += dY^T X of one operator) in ONE grid.  Each of these products alone is a few dozen 128x128 tiles
+// with K = Tt*B: launched one by one they need split-K by 5-10 (atomics) to fill the chip and still pay a ramp and a
+// partial last wave each; together they fill it with split-K 1-2.
+constexpr int GROUP_MAX = 12;
+struct GemmGroupArgs {
+    GemmArgs p[GROUP_MAX];
+    int start[GROUP_MAX + 1];      // first block of each product
+    int n;
+};
+__global__ __launch_bounds__(512) void gemm_split_group_kernel(GemmGroupArgs G) {
+    __shared__ __attribute__((aligned(16))) __bf16 smem[6 * SP_PLANE];
+    int p = 0;
+    while (p + 1 < G.n && (int)blockIdx.x >= G.start[p + 1]) ++p;
+    const GemmArgs& a = G.p[p];
+    const int id = blockIdx.x - G.start[p];
+    const int tn = (a.N + 127) / 128, tm = (a.M + 127) / 128;
+    const int bx = id % tn, by = (id / tn) % tm, bz = id / (tn * tm);
+    gemm_split_body<false, false, true>(a, smem, bx, by, bz);
 }
 
 // (A double-buffered variant -- 110 KB of LDS, one block per CU, split/store of tile t+1 issued between the k-halves of
@@ -434,6 +460,51 @@ __global__ __launch_bounds__(256) void fill2d_kernel(float* __restrict__ C, int6
 // Tile / split-K choice.  One 128x128 block keeps a CU's four MFMA pipes busy for 128*k cycles, so a launch is only
 // efficient with >= 2 blocks per CU in flight (latency hiding across co-resident blocks) and every CU busy: small-output,
 // deep-K products (every weight gradient: K = Tt*B) are split along K and accumulated with fp32 atomics.
+// ---- grouped launch queue (host side; the library is driven by one host thread per process) ----
+static bool g_group_on = false;
+static int g_group_n = 0;
+static GemmArgs g_group[GROUP_MAX];
+static int vag_gemm_launch_now(const GemmArgs& q, hipStream_t stream);
+void vag_gemm_group_begin() { g_group_on = true; g_group_n = 0; }
+int vag_gemm_group_end(hipStream_t stream) {
+    g_group_on = false;
+    const int n = g_group_n;
+    g_group_n = 0;
+    if (n == 0) return VAG_OK;
+    if (n == 1) return vag_gemm_launch_now(g_group[0], stream);
+    int64_t tiles = 0;
+    int kmin = 1 << 30;
+    for (int i = 0; i < n; ++i) {
+        tiles += cdiv64(g_group[i].M, 128) * cdiv64(g_group[i].N, 128);
+        if (g_group[i].beta != 0.f && g_group[i].K < kmin) kmin = g_group[i].K;
+    }
+    // two co-resident blocks per CU: aim at ~512 blocks; only accumulating (beta = 1) products may be split
+    int sp = (int)((512 + tiles / 2) / tiles);
+    if (sp < 1) sp = 1;
+    if (sp > 8) sp = 8;
+    while (sp > 1 && kmin / sp < 256) --sp;
+    GemmGroupArgs G;
+    G.n = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        GemmArgs& a = G.p[i];
+        a = g_group[i];
+        int s_i = a.beta != 0.f ? sp : 1;
+        int kchunk = (int)(cdiv64(cdiv64(a.K, s_i), SP_BK) * SP_BK);
+        s_i = (int)cdiv64(a.K, kchunk);
+        a.kchunk = kchunk;
+        // accumulating products always add atomically here (two of them may target the same gradient buffer);
+        // splitk > 1 is what selects the atomic epilogue, the block count below uses the real number of k-slices
+        a.splitk = a.beta != 0.f ? (s_i > 2 ? s_i : 2) : 1;
+        G.start[i] = total;
+        total += (int)(cdiv64(a.M, 128) * cdiv64(a.N, 128)) * s_i;
+    }
+    G.start[n] = total;
+    hipLaunchKernelGGL(gemm_split_group_kernel, dim3((unsigned)total), dim3(512), 0, stream, G);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
 int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
                     const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc,
                     const float* bias, int act, hipStream_t stream) {
@@ -451,6 +522,12 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     g.alpha = alpha; g.beta = beta; g.act = act;
     const int64_t lda = akc ? sam : sak, ldb = bkc ? sbn : sbk;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
+    if (g_group_on && g_group_n < GROUP_MAX && !akc && !bkc && vec && alpha == 1.f && (beta == 0.f || beta == 1.f) &&
+        bias == nullptr && act == VAG_ACT_NONE && M > 64 && N > 64 && K >= 256 && getenv("VAG_GEMM_NOGROUP") == nullptr) {
+        g.kchunk = (int)K; g.splitk = 1;
+        g_group[g_group_n++] = g;
+        return VAG_OK;
+    }
     // cost model (microseconds) over tile in {64,128} x split-K: MFMA time of the busiest CU + output traffic
     // (split-K partial sums as fp32 atomics ~3 TB/s chip-wide, plain stores ~4 TB/s) -- constants fitted to measured launches.
     const bool can_split = (act == VAG_ACT_NONE) && (beta == 0.f || beta == 1.f);
@@ -499,6 +576,11 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
         return gemm_dispatch<128, 128, 512>(g, akc, bkc, vec, grid, stream);
     }
     return gemm_dispatch<64, 64, 256>(g, akc, bkc, vec, grid, stream);
+}
+
+static int vag_gemm_launch_now(const GemmArgs& q, hipStream_t stream) {
+    return vag_gemm_launch(q.M, q.N, q.K, q.alpha, q.A, q.sa_o, q.sa_k, q.B, q.sb_k, q.sb_o, q.beta, q.C, q.ldc, q.bias, q.act,
+                           stream);
 }
 
 // ------------------------------------------------------------------------------------------------
