@@ -105,8 +105,10 @@ int vag_bigru_seq_fwd(const int64_t* src, const int32_t* lengths, const float* e
     const int64_t R = Ts * B;
     VAG_TRY(vag_src_mask_launch(src, B * Ts, mask, s));
     VAG_TRY(vag_embed_gather_launch(src, 1, Ts, Ts, B, emb, E, w.x, rng, VAG_DROP_ENC_EMB, p_emb, s));
+    vag_gemm_group_begin();              // both directions' input projections: one grouped launch
     VAG_TRY(vag_gemm_launch(R, 3 * H, E, 1.f, w.x, E, 1, fw.w_ih, 1, E, 0.f, w.xp, 6 * H, fw.b_ih, 0, s));
     VAG_TRY(vag_gemm_launch(R, 3 * H, E, 1.f, w.x, E, 1, bw.w_ih, 1, E, 0.f, w.xp + 3 * H, 6 * H, bw.b_ih, 0, s));
+    VAG_TRY(vag_gemm_group_end(s));
     const int64_t BH = B * H;
     VAG_TRY(zero_async(w.hst, BH * sizeof(float), s));
     VAG_TRY(zero_async(w.hst + (Ts + 1) * BH, BH * sizeof(float), s));
@@ -612,10 +614,11 @@ static int head_bwd_data(const vag_head_w& w, int64_t R, int64_t E, int64_t H, i
     const int64_t C = 2 * H;
     VAG_TRY(gemm_nn(R, E, V, dlogits, ldl, w.out_w, E, 0.f, dt, E, s));
     VAG_TRY(vag_tanh_bwd_launch(tmid, dt, dt, R * E, rng, VAG_DROP_DEC_OUT, p_out, s));   // tmid holds tanh(.)*mul
+    vag_gemm_group_begin();              // three independent products of d(pre-activation): one grouped launch
     VAG_TRY(gemm_nn(R, H, E, dt, E, w.w1, H, 0.f, d_h2_all, H, s));
     VAG_TRY(gemm_nn(R, C, E, dt, E, w.w2, C, 0.f, d_c_all, C, s));
     VAG_TRY(gemm_nn(R, E, E, dt, E, w.w3, E, 0.f, d_e_all, E, s));
-    return VAG_OK;
+    return vag_gemm_group_end(s);
 }
 // Parameter gradients of the head from d(logits) and dt = d(pre-activation): nothing downstream waits for these,
 // so they may run on a side stream beside the decoder's backward recurrence.

@@ -383,8 +383,8 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(GemmArgs a) {
     gemm_split_body<AKC, BKC, VEC>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-// Grouped launch: the blocks of up to GROUP_MAX independent products (all "TN": both operands outer-contiguous, the
-// weight gradients g_W += dY^T X of one operator) in ONE grid.  Each of these products alone is a few dozen 128x128 tiles
+// Grouped launch: the blocks of up to GROUP_MAX independent products of one operand layout (e.g. all "TN": both operands
+// outer-contiguous, the weight gradients g_W += dY^T X of one operator) in ONE grid.  Each of these products alone is a few dozen 128x128 tiles
 // with K = Tt*B: launched one by one they need split-K by 5-10 (atomics) to fill the chip and still pay a ramp and a
 // partial last wave each; together they fill it with split-K 1-2.
 constexpr int GROUP_MAX = 12;
@@ -393,6 +393,7 @@ struct GemmGroupArgs {
     int start[GROUP_MAX + 1];      // first block of each product
     int n;
 };
+template <bool AKC, bool BKC>
 __global__ __launch_bounds__(512) void gemm_split_group_kernel(GemmGroupArgs G) {
     __shared__ __attribute__((aligned(16))) __bf16 smem[6 * SP_PLANE];
     int p = 0;
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(512) void gemm_split_group_kernel(GemmGroupArgs G) 
     const int id = blockIdx.x - G.start[p];
     const int tn = (a.N + 127) / 128, tm = (a.M + 127) / 128;
     const int bx = id % tn, by = (id / tn) % tm, bz = id / (tn * tm);
-    gemm_split_body<false, false, true>(a, smem, bx, by, bz);
+    gemm_split_body<AKC, BKC, true>(a, smem, bx, by, bz);
 }
 
 // (A double-buffered variant -- 110 KB of LDS, one block per CU, split/store of tile t+1 issued between the k-halves of
@@ -463,6 +464,7 @@ __global__ __launch_bounds__(256) void fill2d_kernel(float* __restrict__ C, int6
 // ---- grouped launch queue (host side; the library is driven by one host thread per process) ----
 static bool g_group_on = false;
 static int g_group_n = 0;
+static bool g_group_akc = false, g_group_bkc = false;      // layout of the queued products (set by the first one)
 static GemmArgs g_group[GROUP_MAX];
 static int vag_gemm_launch_now(const GemmArgs& q, hipStream_t stream);
 void vag_gemm_group_begin() { g_group_on = true; g_group_n = 0; }
@@ -500,7 +502,14 @@ int vag_gemm_group_end(hipStream_t stream) {
         total += (int)(cdiv64(a.M, 128) * cdiv64(a.N, 128)) * s_i;
     }
     G.start[n] = total;
-    hipLaunchKernelGGL(gemm_split_group_kernel, dim3((unsigned)total), dim3(512), 0, stream, G);
+    if (!g_group_akc && !g_group_bkc)
+        hipLaunchKernelGGL((gemm_split_group_kernel<false, false>), dim3((unsigned)total), dim3(512), 0, stream, G);
+    else if (g_group_akc && !g_group_bkc)
+        hipLaunchKernelGGL((gemm_split_group_kernel<true, false>), dim3((unsigned)total), dim3(512), 0, stream, G);
+    else if (g_group_akc && g_group_bkc)
+        hipLaunchKernelGGL((gemm_split_group_kernel<true, true>), dim3((unsigned)total), dim3(512), 0, stream, G);
+    else
+        hipLaunchKernelGGL((gemm_split_group_kernel<false, true>), dim3((unsigned)total), dim3(512), 0, stream, G);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
@@ -522,8 +531,10 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     g.alpha = alpha; g.beta = beta; g.act = act;
     const int64_t lda = akc ? sam : sak, ldb = bkc ? sbn : sbk;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
-    if (g_group_on && g_group_n < GROUP_MAX && !akc && !bkc && vec && alpha == 1.f && (beta == 0.f || beta == 1.f) &&
-        bias == nullptr && act == VAG_ACT_NONE && M > 64 && N > 64 && K >= 256 && getenv("VAG_GEMM_NOGROUP") == nullptr) {
+    if (g_group_on && g_group_n < GROUP_MAX && vec && alpha == 1.f && (beta == 0.f || beta == 1.f) &&
+        act == VAG_ACT_NONE && M > 64 && N > 64 && K >= 256 && (g_group_n == 0 || (akc == g_group_akc && bkc == g_group_bkc)) &&
+        getenv("VAG_GEMM_NOGROUP") == nullptr) {
+        if (g_group_n == 0) { g_group_akc = akc; g_group_bkc = bkc; }
         g.kchunk = (int)K; g.splitk = 1;
         g_group[g_group_n++] = g;
         return VAG_OK;
