@@ -584,6 +584,20 @@ int vag_cgru_attn_decode_step(const float* enc, const float* pe, const float* ma
 // =====================================================================================================
 // output head + cross entropy
 // =====================================================================================================
+// tmid (R,E) = dropout(tanh(W1 h2 + b1 + W2 c + b2 + W3 e + b3)) for all R = Tt*B rows (NMT_Decoder.py:137-141): the three
+// products accumulate into a zeroed tmid from ONE grouped launch (each alone is 40 tiles), then one elementwise pass.
+static int head_pre_seq(const float* h2, const float* c, const float* e, const vag_head_w& w, int64_t R, int64_t E, int64_t H,
+                        float p_out, const uint64_t* rng, float* tmid, hipStream_t s) {
+    const int64_t C = 2 * H;
+    VAG_TRY(zero_async(tmid, R * E * sizeof(float), s));
+    vag_gemm_group_begin();
+    VAG_TRY(vag_gemm_launch(R, E, H, 1.f, h2, H, 1, w.w1, 1, H, 1.f, tmid, E, w.b1, 0, s));
+    VAG_TRY(vag_gemm_launch(R, E, C, 1.f, c, C, 1, w.w2, 1, C, 1.f, tmid, E, w.b2, 0, s));
+    VAG_TRY(vag_gemm_launch(R, E, E, 1.f, e, E, 1, w.w3, 1, E, 1.f, tmid, E, w.b3, 0, s));
+    VAG_TRY(vag_gemm_group_end(s));
+    return vag_tanh_dropout_launch(tmid, R * E, 0, rng, VAG_DROP_DEC_OUT, p_out, s);
+}
+
 int vag_head_ce_seq_fwd(const float* h2_all, const float* c_all, const float* e_all, vag_head_w w, const int64_t* tgt,
                         const float* vocab_weight, int64_t B, int64_t Tt, int64_t E, int64_t H, int64_t V, float p_out,
                         const uint64_t* rng, int logits_ready, float* tmid, float* logits, int64_t ldl, float* lse,
@@ -592,13 +606,9 @@ int vag_head_ce_seq_fwd(const float* h2_all, const float* c_all, const float* e_
     VAG_CHECK_ARG(h2_all && c_all && e_all && tgt && vocab_weight && tmid && logits && lse && nll && inv_cnt && loss_mt);
     VAG_CHECK_ARG(w.w1 && w.b1 && w.w2 && w.b2 && w.w3 && w.b3 && w.out_w && w.out_b);
     VAG_CHECK_ARG(B > 0 && Tt > 0 && E % 4 == 0 && H % 4 == 0 && V > 0 && ldl >= V && ldl % 4 == 0);
-    const int64_t C = 2 * H, R = Tt * B;
+    const int64_t R = Tt * B;
     if (!logits_ready) {
-        // batched over all Tt steps (teacher forcing): three products accumulate into tmid, tanh on the last
-        VAG_TRY(vag_gemm_launch(R, E, H, 1.f, h2_all, H, 1, w.w1, 1, H, 0.f, tmid, E, w.b1, 0, s));
-        VAG_TRY(vag_gemm_launch(R, E, C, 1.f, c_all, C, 1, w.w2, 1, C, 1.f, tmid, E, w.b2, 0, s));
-        VAG_TRY(vag_gemm_launch(R, E, E, 1.f, e_all, E, 1, w.w3, 1, E, 1.f, tmid, E, w.b3, VAG_ACT_TANH, s));
-        VAG_TRY(vag_dropout_apply_launch(tmid, R * E, 0, rng, VAG_DROP_DEC_OUT, p_out, s));
+        VAG_TRY(head_pre_seq(h2_all, c_all, e_all, w, R, E, H, p_out, rng, tmid, s));
         VAG_TRY(vag_gemm_launch(R, V, E, 1.f, tmid, E, 1, w.out_w, 1, E, 0.f, logits, ldl, w.out_b, 0, s));
     }
     VAG_TRY(vag_inv_cnt_launch(tgt, B, Tt, inv_cnt, s));
@@ -681,11 +691,7 @@ int vag_head_logp_seq_fwd(const float* h2, const float* c, const float* e, vag_h
     hipStream_t s = S_(stream);
     VAG_CHECK_ARG(h2 && c && e && tmid && logp && R > 0 && E % 4 == 0 && H % 4 == 0 && V > 0 && ldl >= V && ldl % 4 == 0);
     VAG_CHECK_ARG(w.w1 && w.b1 && w.w2 && w.b2 && w.w3 && w.b3 && w.out_w && w.out_b);
-    const int64_t C = 2 * H;
-    VAG_TRY(vag_gemm_launch(R, E, H, 1.f, h2, H, 1, w.w1, 1, H, 0.f, tmid, E, w.b1, 0, s));
-    VAG_TRY(vag_gemm_launch(R, E, C, 1.f, c, C, 1, w.w2, 1, C, 1.f, tmid, E, w.b2, 0, s));
-    VAG_TRY(vag_gemm_launch(R, E, E, 1.f, e, E, 1, w.w3, 1, E, 1.f, tmid, E, w.b3, VAG_ACT_TANH, s));
-    VAG_TRY(vag_dropout_apply_launch(tmid, R * E, 0, rng, VAG_DROP_DEC_OUT, p_out, s));
+    VAG_TRY(head_pre_seq(h2, c, e, w, R, E, H, p_out, rng, tmid, s));
     VAG_TRY(linear_fwd(R, V, E, tmid, E, w.out_w, w.out_b, 0, logp, ldl, s));
     return vag_lse_nll_launch(logp, ldl, R, V, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, logp, ldl, s);
 }

@@ -163,6 +163,18 @@ int vag_dropout_apply_launch(float* x, int64_t n, int64_t idx0, const uint64_t* 
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
+// x = tanh(x) * dropout multiplier (the head's pre-activation, accumulated by three grouped products)
+__global__ __launch_bounds__(256) void tanh_dropout_kernel(float* __restrict__ x, int64_t n, int64_t idx0,
+                                                           const uint64_t* rng, int sid, float p) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        x[i] = vag_tanh(x[i]) * vag_drop_mul(rng, sid, (uint64_t)(idx0 + i), p);
+}
+int vag_tanh_dropout_launch(float* x, int64_t n, int64_t idx0, const uint64_t* rng, int sid, float p, hipStream_t s) {
+    if (n == 0) return VAG_OK;
+    hipLaunchKernelGGL(tanh_dropout_kernel, grid1d(n), dim3(256), 0, s, x, n, idx0, rng, sid, p);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
 int vag_dropout_mask_launch(const uint64_t* rng, int sid, int64_t n, float p, float* out, hipStream_t s) {
     VAG_CHECK_ARG(out && n >= 0);
     if (n == 0) return VAG_OK;

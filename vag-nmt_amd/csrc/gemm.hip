@@ -475,16 +475,12 @@ int vag_gemm_group_end(hipStream_t stream) {
     if (n == 0) return VAG_OK;
     if (n == 1) return vag_gemm_launch_now(g_group[0], stream);
     int64_t tiles = 0;
-    int kmin = 1 << 30;
-    for (int i = 0; i < n; ++i) {
-        tiles += cdiv64(g_group[i].M, 128) * cdiv64(g_group[i].N, 128);
-        if (g_group[i].beta != 0.f && g_group[i].K < kmin) kmin = g_group[i].K;
-    }
-    // two co-resident blocks per CU: aim at ~512 blocks; only accumulating (beta = 1) products may be split
+    for (int i = 0; i < n; ++i) tiles += cdiv64(g_group[i].M, 128) * cdiv64(g_group[i].N, 128);
+    // two co-resident blocks per CU: aim at ~512 blocks; only accumulating (beta = 1) products may be split, and no
+    // k-slice shorter than 256
     int sp = (int)((512 + tiles / 2) / tiles);
     if (sp < 1) sp = 1;
     if (sp > 8) sp = 8;
-    while (sp > 1 && kmin / sp < 256) --sp;
     GemmGroupArgs G;
     G.n = n;
     int total = 0;
@@ -492,6 +488,7 @@ int vag_gemm_group_end(hipStream_t stream) {
         GemmArgs& a = G.p[i];
         a = g_group[i];
         int s_i = a.beta != 0.f ? sp : 1;
+        if (s_i > a.K / 256) s_i = a.K / 256 > 0 ? a.K / 256 : 1;
         int kchunk = (int)(cdiv64(cdiv64(a.K, s_i), SP_BK) * SP_BK);
         s_i = (int)cdiv64(a.K, kchunk);
         a.kchunk = kchunk;

@@ -36,6 +36,7 @@ int vag_tanh_bwd_launch(const float* y, const float* dy, float* dx, int64_t n, c
                         hipStream_t s);
 // x[i] *= dropout(idx0 + i)
 int vag_dropout_apply_launch(float* x, int64_t n, int64_t idx0, const uint64_t* rng, int sid, float p, hipStream_t s);
+int vag_tanh_dropout_launch(float* x, int64_t n, int64_t idx0, const uint64_t* rng, int sid, float p, hipStream_t s);
 int vag_dropout_mask_launch(const uint64_t* rng, int sid, int64_t n, float p, float* out, hipStream_t s);
 // y (+)= a*x
 int vag_axpy_launch(float a, const float* x, float* y, int64_t n, int accumulate, hipStream_t s);
