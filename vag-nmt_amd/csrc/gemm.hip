@@ -545,13 +545,21 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     static const double atomic_rate = getenv("VAG_GEMM_ATOMIC") ? atof(getenv("VAG_GEMM_ATOMIC")) : 3.0e6;
     for (int64_t t = 64; t <= 128; t *= 2) {
         if (t == 128 && (M <= 64 || N <= 64)) continue;
-        const double eff = (t == 128) ? (getenv("VAG_GEMM_F32MFMA") ? 0.62 : 0.85) : 0.42;   // fraction of the f32-MFMA peak
+        const double eff = (t == 128) ? (getenv("VAG_GEMM_F32MFMA") ? 0.62 : 0.64) : 0.42;   // fraction of the f32-MFMA peak
         const int64_t base = cdiv64(M, t) * cdiv64(N, t);
         for (int64_t sp = 1; sp <= 16; ++sp) {
             if (sp > 1 && (!can_split || K / sp < 128)) break;
             const int64_t kper = cdiv64(cdiv64(K, sp), BK) * BK;
             const int64_t blocks = base * sp;
-            const double rounds = (double)cdiv64(blocks, 256);
+            // a CU holds two 128x128 blocks, and a pair advances ~1.33x faster than two blocks one after the other:
+            // full waves of 512 blocks count 1.5 "single-block rounds", a remainder of <= 256 blocks counts 1
+            double rounds;
+            if (t == 128 && getenv("VAG_GEMM_F32MFMA") == nullptr) {
+                const int64_t full = blocks / 512, rem = blocks % 512;
+                rounds = 1.5 * (double)full + (rem == 0 ? 0.0 : (rem <= 256 ? 1.0 : 1.5));
+            } else {
+                rounds = (double)cdiv64(blocks, 256);
+            }
             const double t_mfma = rounds * (double)kper * (double)(t * t) * 2.0 / (256.0 * eff) / 2400.0;
             const double bytes = (double)M * (double)N * 4.0;
             const double t_out = sp > 1 ? sp * bytes / atomic_rate + (beta == 0.f ? bytes / 4.0e6 + 2.0 : 0.0)
