@@ -196,7 +196,6 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
     }
     vag_gemm_group_begin();      // the four weight gradients (both directions) go out as one grouped launch
     for (int d = 0; d < 2; ++d) {
-        const vag_gru_w& g = d == 0 ? fw : bw;
         const vag_gru_g& gg = d == 0 ? g_fw : g_bw;
         const float* dgh = w.dgh + d * Ts * B * 3 * H;
         const float* hs = w.hst + d * (Ts + 1) * BH;
@@ -204,8 +203,13 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
         VAG_TRY(vag_colsum_launch(dgh, R, 3 * H, 3 * H, gg.b_hh, s));
         VAG_TRY(gemm_tn_acc(3 * H, E, R, d_xp + d * 3 * H, 6 * H, w.x, E, gg.w_ih, E, s));
         VAG_TRY(vag_colsum_launch(d_xp + d * 3 * H, R, 3 * H, 6 * H, gg.b_ih, s));
-        VAG_TRY(gemm_nn(R, E, 3 * H, d_xp + d * 3 * H, 6 * H, g.w_ih, E, d == 0 ? 0.f : 1.f, w.dx, E, s));
     }
+    VAG_TRY(vag_gemm_group_end(s));
+    // d(embedded inputs) = sum over the directions of dgi W_ih: both products add into a zeroed buffer, one grouped launch
+    VAG_TRY(zero_async(w.dx, R * E * sizeof(float), s));
+    vag_gemm_group_begin();
+    for (int d = 0; d < 2; ++d)
+        VAG_TRY(gemm_nn(R, E, 3 * H, d_xp + d * 3 * H, 6 * H, (d == 0 ? fw : bw).w_ih, E, 1.f, w.dx, E, s));
     VAG_TRY(vag_gemm_group_end(s));
     VAG_TRY(vag_embed_scatter_launch(src, 1, Ts, Ts, B, w.dx, E, g_emb, rng, VAG_DROP_ENC_EMB, p_emb, s));
     return VAG_OK;
