@@ -9,12 +9,13 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(const float* __restric
                                                           const float* __restrict__ v, const float* __restrict__ mask,
                                                           int64_t total, int rps, int Ts, int C, int64_t ldq,
                                                           float* __restrict__ scores) {
+    // grid (ceil(Ts/4), N): no 64-bit divisions on the way to the first load (they cost more than the row's arithmetic)
     const int lane = threadIdx.x & 63;
-    const int64_t pair = blockIdx.x * 4ll + (threadIdx.x >> 6);
-    if (pair >= total) return;
-    const int64_t n = pair / Ts;
-    const int s = (int)(pair - n * Ts);
-    const int64_t b = n / rps;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= Ts) return;
+    const int64_t n = blockIdx.y;
+    const int64_t pair = n * Ts + s;
+    const int64_t b = rps == 1 ? n : (int64_t)((int)blockIdx.y / rps);
     const float* pr = pe + (b * Ts + s) * C;
     const float* qr = q + n * ldq;
     float acc = 0.f;
@@ -43,7 +44,8 @@ int vag_attn_scores_launch(int mode, const float* pe, const float* q, int64_t ld
     VAG_CHECK_ARG(pe && q && scores && N > 0 && Ts > 0 && C > 0 && C % 4 == 0 && rps >= 1 && ldq % 4 == 0 && ldq >= C);
     VAG_CHECK_ARG(mode == 1 || v);
     const int64_t total = N * Ts;
-    dim3 grid((unsigned)cdiv64(total, 4));
+    VAG_CHECK_ARG(N < 65536);
+    dim3 grid((unsigned)cdiv64(Ts, 4), (unsigned)N);
     if (mode == 0)
         hipLaunchKernelGGL(attn_scores_kernel<0>, grid, dim3(256), 0, s, pe, q, v, mask, total, (int)rps, (int)Ts, (int)C, ldq, scores);
     else
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(64 * CTX_WAVES) void attn_ctx_kernel(int softmax, c
     float4* part = reinterpret_cast<float4*>(w + ((Ts + 3) & ~3));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t n = blockIdx.y;
-    const int64_t b = n / rps;
+    const int64_t b = rps == 1 ? n : (int64_t)((int)blockIdx.y / rps);
     const float* sc = scores + n * Ts;
     if (softmax) {
         float mx = -INFINITY;
