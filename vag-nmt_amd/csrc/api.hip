@@ -520,9 +520,9 @@ int vag_cgru_attn_decode_seq_bwd_weights(const float* h0, const int64_t* tok, va
     const int64_t C = 2 * H, Q = C + 3 * H, R = Tt * B;
     CgruWs k = cgru_ws(ws, B, Ts, Tt, E, H);
     CgruBwdScratch z = cgru_bwd_scratch(scratch, B, Ts, Tt, E, H);
-    VAG_TRY(vag_colsum_launch(z.dvp, VAG_POST_CHUNKS(Ts) * B, C, C, g.attn_v, s));
     const float* dgh2 = z.dqgh + C;      // (R,3H) row stride Q
-    vag_gemm_group_begin();              // the independent K = Tt*B weight gradients go out as one grouped launch
+    vag_gemm_group_begin();              // the independent K = Tt*B weight gradients go out as one grouped launch,
+    VAG_TRY(vag_colsum_launch(z.dvp, VAG_POST_CHUNKS(Ts) * B, C, C, g.attn_v, s));      // the bias sums as another
     VAG_TRY(gemm_tn_acc(3 * H, H, R, dgh2, Q, k.h1, H, g.gru2.w_hh, H, s));
     VAG_TRY(vag_colsum_launch(dgh2, R, 3 * H, Q, g.gru2.b_hh, s));
     VAG_TRY(gemm_tn_acc(C, H, R, z.dqgh, Q, k.h1, H, g.attn_h, H, s));
@@ -536,12 +536,12 @@ int vag_cgru_attn_decode_seq_bwd_weights(const float* h0, const int64_t* tok, va
         VAG_TRY(gemm_tn_acc(3 * H, H, R - B, z.dgh1 + B * 3 * H, 3 * H, h2_all, H, g.gru1.w_hh, H, s));
     }
     VAG_TRY(gemm_tn_acc(3 * H, E, R, z.dgi1, 3 * H, e_all, E, g.gru1.w_ih, E, s));
-    VAG_TRY(vag_gemm_group_end(s));      // z.dwp is complete from here on
-    VAG_TRY(vag_gemm_launch(3 * H, H, C, 1.f, z.dwp, C, 1, w.c2h, 1, C, 1.f, g.gru2.w_ih, H, nullptr, 0, s));
-    VAG_TRY(vag_gemm_launch(H, C, 3 * H, 1.f, w.gru2.w_ih, 1, H, z.dwp, C, 1, 1.f, g.c2h, C, nullptr, 0, s));
     VAG_TRY(vag_colsum_launch(z.dgi2, R, 3 * H, 3 * H, g.gru2.b_ih, s));
     VAG_TRY(vag_colsum_launch(z.dgh1, R, 3 * H, 3 * H, g.gru1.b_hh, s));
     VAG_TRY(vag_colsum_launch(z.dgi1, R, 3 * H, 3 * H, g.gru1.b_ih, s));
+    VAG_TRY(vag_gemm_group_end(s));      // z.dwp is complete from here on
+    VAG_TRY(vag_gemm_launch(3 * H, H, C, 1.f, z.dwp, C, 1, w.c2h, 1, C, 1.f, g.gru2.w_ih, H, nullptr, 0, s));
+    VAG_TRY(vag_gemm_launch(H, C, 3 * H, 1.f, w.gru2.w_ih, 1, H, z.dwp, C, 1, 1.f, g.c2h, C, nullptr, 0, s));
     // d(embedded inputs) = dgi1 W_ih1 (+ the head's W3 path), scattered into the embedding gradient
     if (d_e_all) VAG_TRY(copy_async(z.de, d_e_all, R * E * sizeof(float), s));
     VAG_TRY(gemm_nn(R, E, 3 * H, z.dgi1, 3 * H, w.gru1.w_ih, E, d_e_all ? 1.f : 0.f, z.de, E, s));

@@ -467,8 +467,11 @@ static int g_group_n = 0;
 static bool g_group_akc = false, g_group_bkc = false;      // layout of the queued products (set by the first one)
 static GemmArgs g_group[GROUP_MAX];
 static int vag_gemm_launch_now(const GemmArgs& q, hipStream_t stream);
-void vag_gemm_group_begin() { g_group_on = true; g_group_n = 0; }
+void vag_colsum_queue_begin();
+int vag_colsum_queue_end(hipStream_t stream);
+void vag_gemm_group_begin() { g_group_on = true; g_group_n = 0; vag_colsum_queue_begin(); }
 int vag_gemm_group_end(hipStream_t stream) {
+    VAG_TRY(vag_colsum_queue_end(stream));
     g_group_on = false;
     const int n = g_group_n;
     g_group_n = 0;
@@ -1081,10 +1084,70 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     if (out3) atomicAdd(out3 + n, t);
 }
 
+// Several column sums in one grid (blockIdx.z = task): inside a vag_gemm_group_begin/end bracket the bias-gradient sums
+// of an operator are queued like its weight-gradient products and go out together.
+constexpr int COLSUM_MAX = 8;
+struct ColsumTasks {
+    const float* X[COLSUM_MAX]; float* out[COLSUM_MAX]; float* out2[COLSUM_MAX]; float* out3[COLSUM_MAX];
+    int64_t ld[COLSUM_MAX];
+    int M[COLSUM_MAX], N[COLSUM_MAX], rows_per[COLSUM_MAX];
+};
+__global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumTasks T) {
+    const int k = blockIdx.z;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int M = T.M[k], N = T.N[k], rows_per = T.rows_per[k];
+    const int m0 = blockIdx.y * rows_per;
+    if (n >= N || m0 >= M) return;
+    const int m1 = min(M, m0 + rows_per);
+    const float* X = T.X[k];
+    const int64_t ld = T.ld[k];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int m = m0;
+    for (; m + 3 < m1; m += 4) {
+        s0 += X[(int64_t)m * ld + n];
+        s1 += X[(int64_t)(m + 1) * ld + n];
+        s2 += X[(int64_t)(m + 2) * ld + n];
+        s3 += X[(int64_t)(m + 3) * ld + n];
+    }
+    for (; m < m1; ++m) s0 += X[(int64_t)m * ld + n];
+    const float t = (s0 + s1) + (s2 + s3);
+    atomicAdd(T.out[k] + n, t);
+    if (T.out2[k]) atomicAdd(T.out2[k] + n, t);
+    if (T.out3[k]) atomicAdd(T.out3[k] + n, t);
+}
+static bool g_colsum_queue_on = false;
+static int g_colsum_n = 0;
+static ColsumTasks g_colsum;
+static unsigned g_colsum_gx = 0, g_colsum_gy = 0;
+void vag_colsum_queue_begin() { g_colsum_queue_on = true; g_colsum_n = 0; g_colsum_gx = g_colsum_gy = 0; }
+int vag_colsum_queue_end(hipStream_t stream) {
+    g_colsum_queue_on = false;
+    const int n = g_colsum_n;
+    g_colsum_n = 0;
+    if (n == 0) return VAG_OK;
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3(g_colsum_gx, g_colsum_gy, (unsigned)n), dim3(256), 0, stream, g_colsum);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
 int vag_colsum3_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* out, float* out2, float* out3,
                        hipStream_t stream) {
     VAG_CHECK_ARG(X && out && M >= 0 && N >= 0);
     if (M == 0 || N == 0) return VAG_OK;
+    if (g_colsum_queue_on && g_colsum_n < COLSUM_MAX && M < (1ll << 30) && N < (1ll << 30)) {
+        const int64_t nbx = cdiv64(N, 256);
+        int64_t splits = cdiv64(1024, nbx);
+        if (splits > cdiv64(M, 8)) splits = cdiv64(M, 8);
+        if (splits < 1) splits = 1;
+        const int rows_per = (int)cdiv64(M, splits);
+        const int k = g_colsum_n++;
+        g_colsum.X[k] = X; g_colsum.out[k] = out; g_colsum.out2[k] = out2; g_colsum.out3[k] = out3; g_colsum.ld[k] = ld;
+        g_colsum.M[k] = (int)M; g_colsum.N[k] = (int)N; g_colsum.rows_per[k] = rows_per;
+        if ((unsigned)nbx > g_colsum_gx) g_colsum_gx = (unsigned)nbx;
+        const unsigned gy = (unsigned)cdiv64(M, rows_per);
+        if (gy > g_colsum_gy) g_colsum_gy = gy;
+        return VAG_OK;
+    }
     const int64_t nbx = cdiv64(N, 256);
     int64_t splits = cdiv64(1024, nbx);
     if (splits > cdiv64(M, 8)) splits = cdiv64(M, 8);
