@@ -105,10 +105,10 @@ int vag_bigru_seq_fwd(const int64_t* src, const int32_t* lengths, const float* e
     const int64_t R = Ts * B;
     VAG_TRY(vag_src_mask_launch(src, B * Ts, mask, s));
     VAG_TRY(vag_embed_gather_launch(src, 1, Ts, Ts, B, emb, E, w.x, rng, VAG_DROP_ENC_EMB, p_emb, s));
-    vag_gemm_group_begin();              // both directions' input projections: one grouped launch
+    VagGemmGroup grp0;              // both directions' input projections: one grouped launch
     VAG_TRY(vag_gemm_launch(R, 3 * H, E, 1.f, w.x, E, 1, fw.w_ih, 1, E, 0.f, w.xp, 6 * H, fw.b_ih, 0, s));
     VAG_TRY(vag_gemm_launch(R, 3 * H, E, 1.f, w.x, E, 1, bw.w_ih, 1, E, 0.f, w.xp + 3 * H, 6 * H, bw.b_ih, 0, s));
-    VAG_TRY(vag_gemm_group_end(s));
+    VAG_TRY(grp0.end(s));
     const int64_t BH = B * H;
     VAG_TRY(zero_async(w.hst, BH * sizeof(float), s));
     VAG_TRY(zero_async(w.hst + (Ts + 1) * BH, BH * sizeof(float), s));
@@ -194,7 +194,7 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
         VAG_TRY(vag_gru_bwd_step_launch(f, 2, s));
         cur ^= 1;
     }
-    vag_gemm_group_begin();      // the four weight gradients (both directions) go out as one grouped launch
+    VagGemmGroup grp1;      // the four weight gradients (both directions) go out as one grouped launch
     for (int d = 0; d < 2; ++d) {
         const vag_gru_g& gg = d == 0 ? g_fw : g_bw;
         const float* dgh = w.dgh + d * Ts * B * 3 * H;
@@ -204,13 +204,13 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
         VAG_TRY(gemm_tn_acc(3 * H, E, R, d_xp + d * 3 * H, 6 * H, w.x, E, gg.w_ih, E, s));
         VAG_TRY(vag_colsum_launch(d_xp + d * 3 * H, R, 3 * H, 6 * H, gg.b_ih, s));
     }
-    VAG_TRY(vag_gemm_group_end(s));
+    VAG_TRY(grp1.end(s));
     // d(embedded inputs) = sum over the directions of dgi W_ih: both products add into a zeroed buffer, one grouped launch
     VAG_TRY(zero_async(w.dx, R * E * sizeof(float), s));
-    vag_gemm_group_begin();
+    VagGemmGroup grp2;
     for (int d = 0; d < 2; ++d)
         VAG_TRY(gemm_nn(R, E, 3 * H, d_xp + d * 3 * H, 6 * H, (d == 0 ? fw : bw).w_ih, E, 1.f, w.dx, E, s));
-    VAG_TRY(vag_gemm_group_end(s));
+    VAG_TRY(grp2.end(s));
     VAG_TRY(vag_embed_scatter_launch(src, 1, Ts, Ts, B, w.dx, E, g_emb, rng, VAG_DROP_ENC_EMB, p_emb, s));
     return VAG_OK;
 }
@@ -521,7 +521,7 @@ int vag_cgru_attn_decode_seq_bwd_weights(const float* h0, const int64_t* tok, va
     CgruWs k = cgru_ws(ws, B, Ts, Tt, E, H);
     CgruBwdScratch z = cgru_bwd_scratch(scratch, B, Ts, Tt, E, H);
     const float* dgh2 = z.dqgh + C;      // (R,3H) row stride Q
-    vag_gemm_group_begin();              // the independent K = Tt*B weight gradients go out as one grouped launch,
+    VagGemmGroup grp3;              // the independent K = Tt*B weight gradients go out as one grouped launch,
     VAG_TRY(vag_colsum_launch(z.dvp, VAG_POST_CHUNKS(Ts) * B, C, C, g.attn_v, s));      // the bias sums as another
     VAG_TRY(gemm_tn_acc(3 * H, H, R, dgh2, Q, k.h1, H, g.gru2.w_hh, H, s));
     VAG_TRY(vag_colsum_launch(dgh2, R, 3 * H, Q, g.gru2.b_hh, s));
@@ -539,7 +539,7 @@ int vag_cgru_attn_decode_seq_bwd_weights(const float* h0, const int64_t* tok, va
     VAG_TRY(vag_colsum_launch(z.dgi2, R, 3 * H, 3 * H, g.gru2.b_ih, s));
     VAG_TRY(vag_colsum_launch(z.dgh1, R, 3 * H, 3 * H, g.gru1.b_hh, s));
     VAG_TRY(vag_colsum_launch(z.dgi1, R, 3 * H, 3 * H, g.gru1.b_ih, s));
-    VAG_TRY(vag_gemm_group_end(s));      // z.dwp is complete from here on
+    VAG_TRY(grp3.end(s));      // z.dwp is complete from here on
     VAG_TRY(vag_gemm_launch(3 * H, H, C, 1.f, z.dwp, C, 1, w.c2h, 1, C, 1.f, g.gru2.w_ih, H, nullptr, 0, s));
     VAG_TRY(vag_gemm_launch(H, C, 3 * H, 1.f, w.gru2.w_ih, 1, H, z.dwp, C, 1, 1.f, g.c2h, C, nullptr, 0, s));
     // d(embedded inputs) = dgi1 W_ih1 (+ the head's W3 path), scattered into the embedding gradient
@@ -594,11 +594,11 @@ static int head_pre_seq(const float* h2, const float* c, const float* e, const v
                         float p_out, const uint64_t* rng, float* tmid, hipStream_t s) {
     const int64_t C = 2 * H;
     VAG_TRY(zero_async(tmid, R * E * sizeof(float), s));
-    vag_gemm_group_begin();
+    VagGemmGroup grp4;
     VAG_TRY(vag_gemm_launch(R, E, H, 1.f, h2, H, 1, w.w1, 1, H, 1.f, tmid, E, w.b1, 0, s));
     VAG_TRY(vag_gemm_launch(R, E, C, 1.f, c, C, 1, w.w2, 1, C, 1.f, tmid, E, w.b2, 0, s));
     VAG_TRY(vag_gemm_launch(R, E, E, 1.f, e, E, 1, w.w3, 1, E, 1.f, tmid, E, w.b3, 0, s));
-    VAG_TRY(vag_gemm_group_end(s));
+    VAG_TRY(grp4.end(s));
     return vag_tanh_dropout_launch(tmid, R * E, 0, rng, VAG_DROP_DEC_OUT, p_out, s);
 }
 
@@ -628,11 +628,11 @@ static int head_bwd_data(const vag_head_w& w, int64_t R, int64_t E, int64_t H, i
     const int64_t C = 2 * H;
     VAG_TRY(gemm_nn(R, E, V, dlogits, ldl, w.out_w, E, 0.f, dt, E, s));
     VAG_TRY(vag_tanh_bwd_launch(tmid, dt, dt, R * E, rng, VAG_DROP_DEC_OUT, p_out, s));   // tmid holds tanh(.)*mul
-    vag_gemm_group_begin();              // three independent products of d(pre-activation): one grouped launch
+    VagGemmGroup grp5;              // three independent products of d(pre-activation): one grouped launch
     VAG_TRY(gemm_nn(R, H, E, dt, E, w.w1, H, 0.f, d_h2_all, H, s));
     VAG_TRY(gemm_nn(R, C, E, dt, E, w.w2, C, 0.f, d_c_all, C, s));
     VAG_TRY(gemm_nn(R, E, E, dt, E, w.w3, E, 0.f, d_e_all, E, s));
-    return vag_gemm_group_end(s);
+    return grp5.end(s);
 }
 // Parameter gradients of the head from d(logits) and dt = d(pre-activation): nothing downstream waits for these,
 // so they may run on a side stream beside the decoder's backward recurrence.
@@ -640,14 +640,14 @@ static int head_bwd_weights(const float* h2_all, const float* c_all, const float
                             int64_t V, const float* tmid, const float* dlogits, int64_t ldl, const float* dt,
                             const vag_head_g& g, hipStream_t s, bool out_b_done = false) {
     const int64_t C = 2 * H;
-    vag_gemm_group_begin();
+    VagGemmGroup grp6;
     VAG_TRY(gemm_tn_acc(V, E, R, dlogits, ldl, tmid, E, g.out_w, E, s));
     if (!out_b_done) VAG_TRY(vag_colsum_launch(dlogits, R, V, ldl, g.out_b, s));
     VAG_TRY(gemm_tn_acc(E, H, R, dt, E, h2_all, H, g.w1, H, s));
     VAG_TRY(gemm_tn_acc(E, C, R, dt, E, c_all, C, g.w2, C, s));
     VAG_TRY(gemm_tn_acc(E, E, R, dt, E, e_all, E, g.w3, E, s));
     VAG_TRY(vag_colsum3_launch(dt, R, E, E, g.b1, g.b2, g.b3, s));     // b1, b2, b3 enter the same sum (NMT_Decoder.py:137)
-    return vag_gemm_group_end(s);
+    return grp6.end(s);
 }
 
 static bool head_g_ok(const vag_head_g& g) { return g.w1 && g.b1 && g.w2 && g.b2 && g.w3 && g.b3 && g.out_w && g.out_b; }

@@ -85,6 +85,16 @@ int vag_skinny_nn_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_
 // nothing queued may be read or overwritten by work enqueued before vag_gemm_group_end
 void vag_gemm_group_begin();
 int vag_gemm_group_end(hipStream_t stream);
+void vag_gemm_group_abort();
+// scope guard: an early error return inside a bracket must not leave the queue open
+struct VagGemmGroup {
+    bool open = true;
+    VagGemmGroup() { vag_gemm_group_begin(); }
+    int end(hipStream_t s) { open = false; return vag_gemm_group_end(s); }
+    ~VagGemmGroup() { if (open) vag_gemm_group_abort(); }
+    VagGemmGroup(const VagGemmGroup&) = delete;
+    VagGemmGroup& operator=(const VagGemmGroup&) = delete;
+};
 int vag_colsum_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* out, hipStream_t stream);
 int vag_colsum3_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* out, float* out2, float* out3,
                        hipStream_t stream);

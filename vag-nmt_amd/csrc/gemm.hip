@@ -462,14 +462,17 @@ __global__ __launch_bounds__(256) void fill2d_kernel(float* __restrict__ C, int6
 // efficient with >= 2 blocks per CU in flight (latency hiding across co-resident blocks) and every CU busy: small-output,
 // deep-K products (every weight gradient: K = Tt*B) are split along K and accumulated with fp32 atomics.
 // ---- grouped launch queue (host side; the library is driven by one host thread per process) ----
-static bool g_group_on = false;
-static int g_group_n = 0;
-static bool g_group_akc = false, g_group_bkc = false;      // layout of the queued products (set by the first one)
-static GemmArgs g_group[GROUP_MAX];
+// thread_local: forward runs on the caller's thread, backward on the autograd engine's; a bracket never spans threads
+static thread_local bool g_group_on = false;
+static thread_local int g_group_n = 0;
+static thread_local bool g_group_akc = false, g_group_bkc = false;   // layout of the queued products (set by the first one)
+static thread_local GemmArgs g_group[GROUP_MAX];
 static int vag_gemm_launch_now(const GemmArgs& q, hipStream_t stream);
 void vag_colsum_queue_begin();
 int vag_colsum_queue_end(hipStream_t stream);
+void vag_colsum_queue_abort();
 void vag_gemm_group_begin() { g_group_on = true; g_group_n = 0; vag_colsum_queue_begin(); }
+void vag_gemm_group_abort() { g_group_on = false; g_group_n = 0; vag_colsum_queue_abort(); }   // error path: drop the queue
 int vag_gemm_group_end(hipStream_t stream) {
     VAG_TRY(vag_colsum_queue_end(stream));
     g_group_on = false;
@@ -1115,11 +1118,12 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumTasks T) {
     if (T.out2[k]) atomicAdd(T.out2[k] + n, t);
     if (T.out3[k]) atomicAdd(T.out3[k] + n, t);
 }
-static bool g_colsum_queue_on = false;
-static int g_colsum_n = 0;
-static ColsumTasks g_colsum;
-static unsigned g_colsum_gx = 0, g_colsum_gy = 0;
+static thread_local bool g_colsum_queue_on = false;
+static thread_local int g_colsum_n = 0;
+static thread_local ColsumTasks g_colsum;
+static thread_local unsigned g_colsum_gx = 0, g_colsum_gy = 0;
 void vag_colsum_queue_begin() { g_colsum_queue_on = true; g_colsum_n = 0; g_colsum_gx = g_colsum_gy = 0; }
+void vag_colsum_queue_abort() { g_colsum_queue_on = false; g_colsum_n = 0; }
 int vag_colsum_queue_end(hipStream_t stream) {
     g_colsum_queue_on = false;
     const int n = g_colsum_n;
