@@ -520,6 +520,9 @@ int vag_gemm_group_end(hipStream_t stream) {
 int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
                     const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc,
                     const float* bias, int act, hipStream_t stream) {
+    // mode switches read once per process (VAG_GEMM_FORCE / VAG_GEMM_DEBUG below stay dynamic: the tuning tools flip them)
+    static const bool opt_f32mfma = getenv("VAG_GEMM_F32MFMA") != nullptr;
+    static const bool opt_nogroup = getenv("VAG_GEMM_NOGROUP") != nullptr;
     VAG_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && A && B && C);
     if (M == 0 || N == 0) return VAG_OK;
     VAG_CHECK_ARG(M < (1ll << 30) && N < (1ll << 30) && K < (1ll << 30));
@@ -536,7 +539,7 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     if (g_group_on && g_group_n < GROUP_MAX && vec && alpha == 1.f && (beta == 0.f || beta == 1.f) &&
         act == VAG_ACT_NONE && M > 64 && N > 64 && K >= 256 && (g_group_n == 0 || (akc == g_group_akc && bkc == g_group_bkc)) &&
-        getenv("VAG_GEMM_NOGROUP") == nullptr) {
+        !opt_nogroup) {
         if (g_group_n == 0) { g_group_akc = akc; g_group_bkc = bkc; }
         g.kchunk = (int)K; g.splitk = 1;
         g_group[g_group_n++] = g;
@@ -551,7 +554,7 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     static const double atomic_rate = getenv("VAG_GEMM_ATOMIC") ? atof(getenv("VAG_GEMM_ATOMIC")) : 3.0e6;
     for (int64_t t = 64; t <= 128; t *= 2) {
         if (t == 128 && (M <= 64 || N <= 64)) continue;
-        const double eff = (t == 128) ? (getenv("VAG_GEMM_F32MFMA") ? 0.62 : 0.64) : 0.42;   // fraction of the f32-MFMA peak
+        const double eff = (t == 128) ? (opt_f32mfma ? 0.62 : 0.64) : 0.42;   // fraction of the f32-MFMA peak
         const int64_t base = cdiv64(M, t) * cdiv64(N, t);
         for (int64_t sp = 1; sp <= 16; ++sp) {
             if (sp > 1 && (!can_split || K / sp < 128)) break;
@@ -560,7 +563,7 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
             // a CU holds two 128x128 blocks, and a pair advances ~1.33x faster than two blocks one after the other:
             // full waves of 512 blocks count 1.5 "single-block rounds", a remainder of <= 256 blocks counts 1
             double rounds;
-            if (t == 128 && getenv("VAG_GEMM_F32MFMA") == nullptr) {
+            if (t == 128 && !opt_f32mfma) {
                 const int64_t full = blocks / 512, rem = blocks % 512;
                 rounds = 1.5 * (double)full + (rem == 0 ? 0.0 : (rem <= 256 ? 1.0 : 1.5));
             } else {
@@ -593,7 +596,7 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     }
     dim3 grid((unsigned)cdiv64(N, T), (unsigned)cdiv64(M, T), (unsigned)splitk);
     if (big) {
-        if (getenv("VAG_GEMM_F32MFMA") == nullptr) return gemm_split_dispatch(g, akc, bkc, vec, grid, stream);
+        if (!opt_f32mfma) return gemm_split_dispatch(g, akc, bkc, vec, grid, stream);
         // f32-input MFMA path (v_mfma_f32_32x32x2_f32), 8 waves (2 per SIMD)
         return gemm_dispatch<128, 128, 512>(g, akc, bkc, vec, grid, stream);
     }
