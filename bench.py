@@ -116,7 +116,8 @@ def _time_graph(fn, reps=20):
 
 def measure_operators(c, dev):
     """Live timings for the roofline block:
-      decoder_seq_fwd : one vag_cgru_attn_decode_seq_fwd launch = Tt GRU+attention steps (5 kernels each)
+      decoder_seq_fwd : one vag_cgru_attn_decode_seq_fwd call = Tt GRU+attention steps (4 kernels each) + the per-batch
+                        key projection and context products around the loop
       encoder_fwd     : one vag_bigru_seq_fwd launch = Ts steps, both directions per kernel
       gru_cell        : the dominant single kernel (gru_step_kernel, decoder gru_1 shape), 100 launches per graph"""
     from vagnmt_hip import ops, _lib
@@ -308,7 +309,7 @@ def main():
                                       "traffic": pmc.get("gru_step_kernel_bytes_per_launch"),
                                       "algorithmic_bytes_per_launch": cell_bytes, "us_per_launch": fam["gru_cell"] * 1e6},
             # the BASELINE.json target quantity: one GRU+attention decoder step against the HBM streaming model
-            "roofline_decoder_step": {"bound": "hbm", "kernel": "vag_cgru_attn_decode_seq_fwd / Tt (5 kernels per step)",
+            "roofline_decoder_step": {"bound": "hbm", "kernel": "vag_cgru_attn_decode_seq_fwd / Tt (4 kernels per step + per-batch projections)",
                                       "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                       "frac": achieved / HBM_PEAK,
                                       "traffic": pmc.get("decoder_step_bytes"),

@@ -311,7 +311,7 @@ int vag_cgru_prepare(vag_dec_w w, int64_t H, float* prep, vag_stream_t stream) {
 }
 
 struct CgruWs {
-    float *xp1, *h1, *g1, *g2, *qhp, *scores, *alpha, *tmp, *prep;
+    float *xp1, *h1, *g1, *g2, *qhp, *scores, *alpha, *tmp, *prep, *encwp;
     int64_t total;
 };
 static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
@@ -328,6 +328,7 @@ static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, i
     w.alpha = take(Tt * B * Ts);
     w.tmp = take(B * E);
     w.prep = take(cgru_prep(nullptr, H).total);
+    w.encwp = take(B * Ts * 3 * H);         // (W_ih2 W_c2h) enc[b,s,:]: the keys as gru_2 sees them, once per batch
     w.total = o;
     return w;
 }
@@ -387,11 +388,38 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
     CgruWs k = cgru_ws(ws, B, Ts, Tt, E, H);
     CgruPrep p = cgru_prep(k.prep, H);
     VAG_TRY(vag_cgru_prepare(w, H, k.prep, stream));
-    if (!free_run) {
-        // teacher forcing: every input token is known -> embed and project all steps at once
-        VAG_TRY(vag_embed_gather_launch(tok, B, 1, Tt, B, w.emb, E, e_all, nullptr, 0, 0.f, s));
-        VAG_TRY(vag_gemm_launch(Tt * B, 3 * H, E, 1.f, e_all, E, 1, w.gru1.w_ih, 1, E, 0.f, k.xp1, 3 * H, w.gru1.b_ih, 0, s));
+    // Teacher forcing runs the step with the context projection hoisted (4 launches, see attn_ctx_gru_kernel): the cell
+    // only needs sum_s alpha_s (W_ih2 W_c2h enc_s), the contexts themselves are formed for all steps after the loop.
+    // Free running needs each context at once for the head, so it keeps the 5-launch step; backward is common to both
+    // and always works on the projected keys.
+    static const bool opt_hoist = getenv("VAG_CGRU_NOHOIST") == nullptr;
+    const bool hoist = opt_hoist && !free_run;
+    {
+        VagGemmGroup grp;
+        if (!free_run) {
+            // every input token is known -> embed and project all steps at once
+            VAG_TRY(vag_embed_gather_launch(tok, B, 1, Tt, B, w.emb, E, e_all, nullptr, 0, 0.f, s));
+            VAG_TRY(vag_gemm_launch(Tt * B, 3 * H, E, 1.f, e_all, E, 1, w.gru1.w_ih, 1, E, 0.f, k.xp1, 3 * H, w.gru1.b_ih, 0, s));
+        }
+        VAG_TRY(vag_gemm_launch(B * Ts, 3 * H, C, 1.f, enc, C, 1, p.wp, 1, C, 0.f, k.encwp, 3 * H, nullptr, 0, s));
+        VAG_TRY(grp.end(s));
     }
+    for (int64_t t = 0; hoist && t < Tt; ++t) {
+        const float* hprev = t == 0 ? h0 : h2_all + (t - 1) * BH;
+        float* h1 = k.h1 + t * BH;
+        float* qhp = k.qhp + t * B * Q;
+        GruStepArgs a = {};
+        a.lda = H; a.ldw = H; a.ldother = 3 * H; a.ldh = H; a.ld2 = 0;
+        a.M = (int)B; a.K = (int)H; a.H = (int)H; a.lengths = nullptr; a.comp_hidden = 1;
+        a.s[0].A = hprev; a.s[0].W = w.gru1.w_hh; a.s[0].bias = w.gru1.b_hh; a.s[0].other = k.xp1 + t * B * 3 * H;
+        a.s[0].hprev = hprev; a.s[0].hout = h1; a.s[0].out2 = nullptr; a.s[0].save = k.g1 + t * 4 * BH; a.s[0].t = 0;
+        VAG_TRY(vag_gru_step_launch(a, 1, s));                                                              // gru_1 :121
+        VAG_TRY(vag_skinny_launch(B, Q, H, h1, H, p.wcat, H, p.bcat, nullptr, 0, qhp, Q, 0, s));             // attn_h(h1) | W_hh2 h1
+        VAG_TRY(vag_attn_scores_launch(0, pe, qhp, Q, w.attn_v, mask, B, 1, Ts, C, k.scores, s));           // :47-51, :41-43
+        VAG_TRY(vag_attn_ctx_gru_launch(k.scores, k.encwp, B, 1, Ts, H, w.gru2.b_ih, qhp + C, Q, h1, k.alpha + t * B * Ts,
+                                        h2_all + t * BH, k.g2 + t * 4 * BH, s));                            // :44, :126-129
+    }
+    if (hoist) return vag_attn_wsum_launch(1, k.alpha, enc, B, Ts, Tt, C, c_all, s);                       // all contexts :126
     for (int64_t t = 0; t < Tt; ++t) {
         if (free_run) {
             VAG_TRY(vag_embed_gather_launch(tok + t * B, B, 1, 1, B, w.emb, E, e_all + t * B * E, nullptr, 0, 0.f, s));
@@ -417,7 +445,7 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
 }
 
 struct CgruBwdScratch {
-    float *wcatT, *wpT, *whh1T, *dgi2, *dqgh, *dalpha, *ds, *dgi1, *dgh1, *dh1d, *carry, *de, *dvp, *dwp;
+    float *wcatT, *wpT, *whh1T, *dgi2, *dqgh, *dalpha, *ds, *dgi1, *dgh1, *dh1d, *carry, *de, *dvp, *dwp, *dah, *dencwp;
     int64_t total;
 };
 static CgruBwdScratch cgru_bwd_scratch(float* p, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
@@ -431,6 +459,8 @@ static CgruBwdScratch cgru_bwd_scratch(float* p, int64_t B, int64_t Ts, int64_t 
     w.dgi1 = take(R * 3 * H); w.dgh1 = take(R * 3 * H);
     w.dh1d = take(B * H); w.carry = take(B * H); w.de = take(R * E); w.dvp = take(VAG_POST_CHUNKS(Ts) * B * C);
     w.dwp = take(3 * H * C);
+    w.dah = take(R * Ts);                   // d alpha through the head's use of the context, all steps
+    w.dencwp = take(B * Ts * 3 * H);        // gradient of the projected keys
     w.total = o;
     return w;
 }
@@ -454,7 +484,6 @@ int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const f
     CgruBwdScratch z = cgru_bwd_scratch(scratch, B, Ts, Tt, E, H);
     // per-step products are written as x W^T, so transpose the (derived) weights once per call
     VAG_TRY(vag_transpose_launch(p.wcat, Q, H, z.wcatT, s));            // (H, C+3H) = [attn_h^T | W_hh2^T]
-    VAG_TRY(vag_transpose_launch(p.wp, 3 * H, C, z.wpT, s));            // (C, 3H)
     VAG_TRY(vag_transpose_launch(w.gru1.w_hh, 3 * H, H, z.whh1T, s));   // (H, 3H)
     // gru_2 cell backward of the last step: nothing arrives from a later step
     {
@@ -469,14 +498,16 @@ int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const f
     }
     GruBwdStepArgs f = {};
     f.ld_add = H; f.ldh = H; f.M = (int)B; f.H = (int)H; f.lengths = nullptr; f.rng = nullptr; f.sid = 0; f.p = 0.f;
+    // The context reaches the loss through the head (d_c_all) and through gru_2's input projection.  The first part of
+    // d alpha does not depend on the recurrence: all steps at once, before the loop.  The second is taken on the
+    // projected keys, d alpha[b,s] += encwp[b,s,:] . dgi2[b,:], so no per-step product dc = dgi2 W is needed.
+    VAG_TRY(vag_attn_scores_ex_launch(1, enc, d_c_all, C, nullptr, nullptr, Tt * B, 1, B, Ts, C, nullptr, z.dah, s));
     for (int64_t t = Tt - 1; t >= 0; --t) {
         float* dgi2 = z.dgi2 + t * B * 3 * H;
         float* dqgh = z.dqgh + t * B * Q;
-        float* dc = d_c_all + t * B * C;
-        // dc = dgi2 (W_ih2 W_c2h) + head's d_c                                    (context2hid and gru_2 input, folded)
-        VAG_TRY(vag_skinny_launch(B, C, 3 * H, dgi2, 3 * H, z.wpT, 3 * H, nullptr, dc, C, dc, C, 0, s));
-        // attention backward: d alpha = dc . enc ; softmax backward ; dq = sum_s ds v (1 - tanh^2)
-        VAG_TRY(vag_attn_scores_launch(1, enc, dc, C, nullptr, nullptr, B, 1, Ts, C, z.dalpha, s));
+        // attention backward: d alpha ; softmax backward ; dq = sum_s ds v (1 - tanh^2)
+        VAG_TRY(vag_attn_scores_ex_launch(1, k.encwp, dgi2, 3 * H, nullptr, nullptr, B, 1, 0, Ts, 3 * H, z.dah + t * B * Ts,
+                                          z.dalpha, s));
         VAG_TRY(vag_attn_dq_launch(pe, k.qhp + t * B * Q, Q, w.attn_v, k.alpha + t * B * Ts, z.dalpha, z.ds + t * B * Ts, B,
                                    Ts, C, dqgh, Q, s));
         // dh1 = [dq | dgh2] [attn_h ; W_hh2] + z2*dh2   -> gru_1 cell backward of this step
@@ -505,7 +536,9 @@ int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const f
     // after the loop: everything that does not sit on the recurrence's critical path, as large products
     VAG_TRY(vag_attn_post_bwd_launch(pe, k.qhp, Q, w.attn_v, z.ds, k.alpha, d_c_all, B, Ts, Tt, C, d_pe, z.dvp, d_enc_out,
                                      accumulate_enc, s));
-    return VAG_OK;
+    // d_enc += (sum_t alpha_t dgi2_t) (W_ih2 W_c2h): gru_2's share, through the projected keys
+    VAG_TRY(vag_attn_wsum_launch(0, k.alpha, z.dgi2, B, Ts, Tt, 3 * H, z.dencwp, s));
+    return gemm_nn(B * Ts, C, 3 * H, z.dencwp, 3 * H, p.wp, C, 1.f, d_enc_out, C, s);
 }
 
 // Parameter gradients of the decoder from the per-step tensors the loop left in `scratch` (large products; nothing

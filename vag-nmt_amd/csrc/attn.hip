@@ -7,15 +7,16 @@
 template <int MODE>
 __global__ __launch_bounds__(256) void attn_scores_kernel(const float* __restrict__ pe, const float* __restrict__ q,
                                                           const float* __restrict__ v, const float* __restrict__ mask,
-                                                          int64_t total, int rps, int Ts, int C, int64_t ldq,
-                                                          float* __restrict__ scores) {
+                                                          int64_t total, int rps, int rmod, int Ts, int C, int64_t ldq,
+                                                          const float* __restrict__ addend, float* __restrict__ scores) {
     // grid (ceil(Ts/4), N): no 64-bit divisions on the way to the first load (they cost more than the row's arithmetic)
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= Ts) return;
     const int64_t n = blockIdx.y;
     const int64_t pair = n * Ts + s;
-    const int64_t b = rps == 1 ? n : (int64_t)((int)blockIdx.y / rps);
+    // source row of query row n: n / rps (beam search: rps hypotheses per sentence) or n % rmod (time-major (t,b) rows)
+    const int64_t b = rmod > 0 ? (int64_t)((int)blockIdx.y % rmod) : (rps == 1 ? n : (int64_t)((int)blockIdx.y / rps));
     const float* pr = pe + (b * Ts + s) * C;
     const float* qr = q + n * ldq;
     float acc = 0.f;
@@ -34,24 +35,33 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(const float* __restric
     }
     acc = wave_sum(acc);
     if (lane == 0) {
+        if (addend) acc += addend[pair];
         if (mask && mask[b * Ts + s] == 0.f) acc = -INFINITY;
         scores[pair] = acc;
     }
 }
 
-int vag_attn_scores_launch(int mode, const float* pe, const float* q, int64_t ldq, const float* v, const float* mask,
-                           int64_t N, int64_t rps, int64_t Ts, int64_t C, float* scores, hipStream_t s) {
+// rows_mod > 0: query row n reads source row n % rows_mod (rows ordered (t, b)); else n / rps.  addend (N,Ts) may be NULL.
+int vag_attn_scores_ex_launch(int mode, const float* pe, const float* q, int64_t ldq, const float* v, const float* mask,
+                              int64_t N, int64_t rps, int64_t rows_mod, int64_t Ts, int64_t C, const float* addend,
+                              float* scores, hipStream_t s) {
     VAG_CHECK_ARG(pe && q && scores && N > 0 && Ts > 0 && C > 0 && C % 4 == 0 && rps >= 1 && ldq % 4 == 0 && ldq >= C);
     VAG_CHECK_ARG(mode == 1 || v);
     const int64_t total = N * Ts;
-    VAG_CHECK_ARG(N < 65536);
+    VAG_CHECK_ARG(N < 65536 && rows_mod >= 0);
     dim3 grid((unsigned)cdiv64(Ts, 4), (unsigned)N);
     if (mode == 0)
-        hipLaunchKernelGGL(attn_scores_kernel<0>, grid, dim3(256), 0, s, pe, q, v, mask, total, (int)rps, (int)Ts, (int)C, ldq, scores);
+        hipLaunchKernelGGL(attn_scores_kernel<0>, grid, dim3(256), 0, s, pe, q, v, mask, total, (int)rps, (int)rows_mod,
+                           (int)Ts, (int)C, ldq, addend, scores);
     else
-        hipLaunchKernelGGL(attn_scores_kernel<1>, grid, dim3(256), 0, s, pe, q, v, mask, total, (int)rps, (int)Ts, (int)C, ldq, scores);
+        hipLaunchKernelGGL(attn_scores_kernel<1>, grid, dim3(256), 0, s, pe, q, v, mask, total, (int)rps, (int)rows_mod,
+                           (int)Ts, (int)C, ldq, addend, scores);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
+}
+int vag_attn_scores_launch(int mode, const float* pe, const float* q, int64_t ldq, const float* v, const float* mask,
+                           int64_t N, int64_t rps, int64_t Ts, int64_t C, float* scores, hipStream_t s) {
+    return vag_attn_scores_ex_launch(mode, pe, q, ldq, v, mask, N, rps, 0, Ts, C, nullptr, scores, s);
 }
 
 // ------------------------------------------------------------------ softmax + context
@@ -133,6 +143,184 @@ int vag_attn_ctx_launch(int softmax, const float* scores, const float* enc, int6
 // (A one-launch scores + softmax + context kernel -- one 1024-thread workgroup per query row, 3.8 us for its 328 KB by
 // tools/stream_probe.hip -- measured the same 9.9 us as the two launches: the Ts*C tanh evaluations of a row are bound
 // by the transcendental rate of the 64 CUs that then hold them, 3.2 us, instead of 0.8 us spread over the chip.)
+
+// ------------------------------------------------------------------ softmax + projected context + GRU cell
+// The decoder's second cell takes W_ih2 W_c2h c as its input projection, c = sum_s alpha_s enc_s.  With
+// encwp[b,s,:] = (W_ih2 W_c2h) enc[b,s,:] computed once per batch, that projection is sum_s alpha_s encwp[b,s,:]: the
+// weighted sum this kernel already does, over 3H instead of C columns -- and the cell has no product left, so it is
+// this kernel's epilogue (the step loses a launch and the 6 MB weight re-read of the folded matrix).
+// grid (ceil(H/256), N), CG_WAVES waves: lane owns 4 hidden units (three float4 gate columns per position), wave w walks
+// the positions s = w, w + CG_WAVES, ...; partial sums meet in LDS, wave 0 finishes the cell.
+// hp (N, ldhp) = W_hh2 h1 + b_hh2 (three gate blocks of H), save = [4][N][H] (r, z, n, hp_n) or NULL.
+constexpr int CG_WAVES = 8;
+__global__ __launch_bounds__(64 * CG_WAVES) void attn_ctx_gru_kernel(const float* __restrict__ scores,
+                                                                     const float* __restrict__ encwp, int rps, int Ts, int H,
+                                                                     const float* __restrict__ b_ih,
+                                                                     const float* __restrict__ hp, int64_t ldhp,
+                                                                     const float* __restrict__ hprev, int64_t N,
+                                                                     float* __restrict__ alpha, float* __restrict__ hout,
+                                                                     float* __restrict__ save) {
+    extern __shared__ __attribute__((aligned(16))) float w[];   // Ts weights, then CG_WAVES x 3 x 64 float4 partials
+    float4* part = reinterpret_cast<float4*>(w + ((Ts + 3) & ~3));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n = blockIdx.y;
+    const int64_t b = rps == 1 ? n : (int64_t)((int)blockIdx.y / rps);
+    const float* sc = scores + n * Ts;
+    {
+        float mx = -INFINITY;
+        for (int s = lane; s < Ts; s += 64) mx = fmaxf(mx, sc[s]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int s = lane; s < Ts; s += 64) sum += __expf(sc[s] - mx);
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        for (int s = threadIdx.x; s < Ts; s += 64 * CG_WAVES) {
+            const float a = __expf(sc[s] - mx) * inv;
+            w[s] = a;
+            if (blockIdx.x == 0 && alpha) alpha[n * Ts + s] = a;
+        }
+    }
+    __syncthreads();
+    const int u = (blockIdx.x * 64 + lane) * 4;
+    const bool uok = u < H;
+    float4 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (uok) {
+        const float* e = encwp + b * Ts * 3 * H + u;
+        constexpr int U = 4;
+        for (int s0 = wave; s0 < Ts; s0 += U * CG_WAVES) {
+            float4 ev[U][3];
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const int s = min(s0 + i * CG_WAVES, Ts - 1);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) ev[i][g] = *reinterpret_cast<const float4*>(e + (int64_t)s * 3 * H + g * H);
+            }
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const int s = s0 + i * CG_WAVES;
+                const float a = (s < Ts) ? w[s] : 0.f;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    acc[g].x += a * ev[i][g].x; acc[g].y += a * ev[i][g].y; acc[g].z += a * ev[i][g].z; acc[g].w += a * ev[i][g].w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g) part[(wave * 3 + g) * 64 + lane] = acc[g];
+    __syncthreads();
+    if (wave != 0 || !uok) return;
+    float gi[3][4];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        float4 t = acc[g];
+#pragma unroll
+        for (int k = 1; k < CG_WAVES; ++k) {
+            const float4 o = part[(k * 3 + g) * 64 + lane];
+            t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+        }
+        const float4 bb = *reinterpret_cast<const float4*>(b_ih + g * H + u);
+        gi[g][0] = t.x + bb.x; gi[g][1] = t.y + bb.y; gi[g][2] = t.z + bb.z; gi[g][3] = t.w + bb.w;
+    }
+    const float4 hr = *reinterpret_cast<const float4*>(hp + n * ldhp + u);
+    const float4 hz = *reinterpret_cast<const float4*>(hp + n * ldhp + H + u);
+    const float4 hn = *reinterpret_cast<const float4*>(hp + n * ldhp + 2 * H + u);
+    const float4 h1 = *reinterpret_cast<const float4*>(hprev + n * H + u);
+    const float ghr[4] = {hr.x, hr.y, hr.z, hr.w}, ghz[4] = {hz.x, hz.y, hz.z, hz.w}, ghn[4] = {hn.x, hn.y, hn.z, hn.w};
+    const float hpv[4] = {h1.x, h1.y, h1.z, h1.w};
+    float rr[4], zz[4], nn[4], ho[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        rr[i] = vag_sigmoid(gi[0][i] + ghr[i]);
+        zz[i] = vag_sigmoid(gi[1][i] + ghz[i]);
+        nn[i] = vag_tanh(gi[2][i] + rr[i] * ghn[i]);
+        ho[i] = (1.f - zz[i]) * nn[i] + zz[i] * hpv[i];
+    }
+    const int64_t o = n * H + u;
+    *reinterpret_cast<float4*>(hout + o) = make_float4(ho[0], ho[1], ho[2], ho[3]);
+    if (save) {
+        const int64_t NH = N * H;
+        *reinterpret_cast<float4*>(save + o) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+        *reinterpret_cast<float4*>(save + NH + o) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+        *reinterpret_cast<float4*>(save + 2 * NH + o) = make_float4(nn[0], nn[1], nn[2], nn[3]);
+        *reinterpret_cast<float4*>(save + 3 * NH + o) = hn;
+    }
+}
+int vag_attn_ctx_gru_launch(const float* scores, const float* encwp, int64_t N, int64_t rps, int64_t Ts, int64_t H,
+                            const float* b_ih, const float* hp, int64_t ldhp, const float* hprev, float* alpha, float* hout,
+                            float* save, hipStream_t s) {
+    VAG_CHECK_ARG(scores && encwp && b_ih && hp && hprev && hout && N > 0 && N < 65536 && Ts > 0 && H > 0 && H % 4 == 0);
+    VAG_CHECK_ARG(ldhp % 4 == 0 && rps >= 1 && aligned16(encwp) && aligned16(hp) && aligned16(hprev) && aligned16(hout) &&
+                  aligned16(b_ih) && (!save || aligned16(save)));
+    dim3 grid((unsigned)cdiv64(H, 256), (unsigned)N);
+    const size_t lds = (size_t)((Ts + 3) & ~3) * sizeof(float) + (size_t)CG_WAVES * 3 * 64 * 16;
+    hipLaunchKernelGGL(attn_ctx_gru_kernel, grid, dim3(64 * CG_WAVES), lds, s, scores, encwp, (int)rps, (int)Ts, (int)H, b_ih,
+                       hp, ldhp, hprev, N, alpha, hout, save);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+// ------------------------------------------------------------------ batched over time: out[t,b,:] = sum_s a[t,b,s] x[b,s,:]
+// (the contexts of all steps after the loop) and out[b,s,:] = sum_t a[t,b,s] y[t,b,:] (gradient of the projected keys).
+// grid (ceil(W/256), B, ceil(T/8)) / (ceil(W/256), B, ceil(Ts/8)); thread owns one float4 column, 8 outputs in registers.
+__global__ __launch_bounds__(64) void attn_wsum_time_kernel(const float* __restrict__ a, const float* __restrict__ x, int B,
+                                                            int Ts, int T, int W, float* __restrict__ out) {
+    const int b = blockIdx.y, t0 = blockIdx.z * 8;
+    const int c = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (c >= W) return;
+    float4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* xr = x + (int64_t)b * Ts * W + c;
+    for (int s = 0; s < Ts; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + (int64_t)s * W);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = min(t0 + i, T - 1);
+            const float al = a[((int64_t)t * B + b) * Ts + s];
+            acc[i].x += al * v.x; acc[i].y += al * v.y; acc[i].z += al * v.z; acc[i].w += al * v.w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (t0 + i < T) *reinterpret_cast<float4*>(out + ((int64_t)(t0 + i) * B + b) * W + c) = acc[i];
+}
+__global__ __launch_bounds__(64) void attn_wsum_src_kernel(const float* __restrict__ a, const float* __restrict__ y, int B,
+                                                           int Ts, int T, int W, float* __restrict__ out) {
+    const int b = blockIdx.y, s0 = blockIdx.z * 8;
+    const int c = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (c >= W) return;
+    float4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < T; ++t) {
+        const float4 v = *reinterpret_cast<const float4*>(y + ((int64_t)t * B + b) * W + c);
+        const float* ar = a + ((int64_t)t * B + b) * Ts;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float al = ar[min(s0 + i, Ts - 1)];
+            acc[i].x += al * v.x; acc[i].y += al * v.y; acc[i].z += al * v.z; acc[i].w += al * v.w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (s0 + i < Ts) *reinterpret_cast<float4*>(out + ((int64_t)b * Ts + s0 + i) * W + c) = acc[i];
+}
+int vag_attn_wsum_launch(int over_src, const float* a, const float* x, int64_t B, int64_t Ts, int64_t T, int64_t W, float* out,
+                         hipStream_t s) {
+    VAG_CHECK_ARG(a && x && out && B > 0 && Ts > 0 && T > 0 && W > 0 && W % 4 == 0 && aligned16(x) && aligned16(out));
+    if (over_src) {     // out (T,B,W) = sum_s a x
+        hipLaunchKernelGGL(attn_wsum_time_kernel, dim3((unsigned)cdiv64(W, 256), (unsigned)B, (unsigned)cdiv64(T, 8)), dim3(64), 0,
+                           s, a, x, (int)B, (int)Ts, (int)T, (int)W, out);
+    } else {            // out (B,Ts,W) = sum_t a y
+        hipLaunchKernelGGL(attn_wsum_src_kernel, dim3((unsigned)cdiv64(W, 256), (unsigned)B, (unsigned)cdiv64(Ts, 8)), dim3(64), 0,
+                           s, a, x, (int)B, (int)Ts, (int)T, (int)W, out);
+    }
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
 
 // ------------------------------------------------------------------ softmax backward (one wave per row)
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ alpha, const float* __restrict__ dalpha,

@@ -65,6 +65,14 @@ static inline int64_t VAG_POST_CHUNKS(int64_t Ts) { return (Ts + VAG_POST_SC - 1
 // q row stride ldq (>= C).
 int vag_attn_scores_launch(int mode, const float* pe, const float* q, int64_t ldq, const float* v, const float* mask,
                            int64_t N, int64_t rps, int64_t Ts, int64_t C, float* scores, hipStream_t s);
+int vag_attn_scores_ex_launch(int mode, const float* pe, const float* q, int64_t ldq, const float* v, const float* mask,
+                              int64_t N, int64_t rps, int64_t rows_mod, int64_t Ts, int64_t C, const float* addend,
+                              float* scores, hipStream_t s);
+int vag_attn_ctx_gru_launch(const float* scores, const float* encwp, int64_t N, int64_t rps, int64_t Ts, int64_t H,
+                            const float* b_ih, const float* hp, int64_t ldhp, const float* hprev, float* alpha, float* hout,
+                            float* save, hipStream_t s);
+int vag_attn_wsum_launch(int over_src, const float* a, const float* x, int64_t B, int64_t Ts, int64_t T, int64_t W, float* out,
+                         hipStream_t s);
 // softmax=1: alpha[n,:] = softmax(scores[n,:]) (written to alpha), ctx[n,c] = sum_s alpha[n,s] enc[b,s,c]
 // softmax=0: weights = scores as given (alpha not written)
 int vag_attn_ctx_launch(int softmax, const float* scores, const float* enc, int64_t N, int64_t rps, int64_t Ts,
