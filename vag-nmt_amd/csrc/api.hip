@@ -445,7 +445,7 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
 }
 
 struct CgruBwdScratch {
-    float *wcatT, *wpT, *whh1T, *dgi2, *dqgh, *dalpha, *ds, *dgi1, *dgh1, *dh1d, *carry, *de, *dvp, *dwp, *dah, *dencwp;
+    float *wcatT, *wpT, *whh1T, *dgi2, *dqgh, *dalpha, *ds, *dgi1, *dgh1, *dh1d, *carry, *de, *dvp, *dwp, *dah, *dencwp, *pbuf;
     int64_t total;
 };
 static CgruBwdScratch cgru_bwd_scratch(float* p, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
@@ -461,6 +461,7 @@ static CgruBwdScratch cgru_bwd_scratch(float* p, int64_t B, int64_t Ts, int64_t 
     w.dwp = take(3 * H * C);
     w.dah = take(R * Ts);                   // d alpha through the head's use of the context, all steps
     w.dencwp = take(B * Ts * 3 * H);        // gradient of the projected keys
+    w.pbuf = take(B * H);                   // dgh2 W_hh2 + carry, computed beside the attention backward
     w.total = o;
     return w;
 }
@@ -501,19 +502,24 @@ int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const f
     // The context reaches the loss through the head (d_c_all) and through gru_2's input projection.  The first part of
     // d alpha does not depend on the recurrence: all steps at once, before the loop.  The second is taken on the
     // projected keys, d alpha[b,s] += encwp[b,s,:] . dgi2[b,:], so no per-step product dc = dgi2 W is needed.
-    VAG_TRY(vag_attn_scores_ex_launch(1, enc, d_c_all, C, nullptr, nullptr, Tt * B, 1, B, Ts, C, nullptr, z.dah, s));
+    // per sentence b: dah[:, b, :] (Tt,Ts) = d_c_all[:, b, :] (Tt,C) enc[b]^T (C,Ts): B small products in one launch
+    if (C % 4 == 0 && aligned16(enc) && aligned16(d_c_all) && B < 65536)
+        VAG_TRY(vag_skinny_batched_launch(B, Tt, Ts, C, d_c_all, B * C, C, enc, C, Ts * C, z.dah, B * Ts, Ts, s));
+    else
+        VAG_TRY(vag_attn_scores_ex_launch(1, enc, d_c_all, C, nullptr, nullptr, Tt * B, 1, B, Ts, C, nullptr, z.dah, s));
     for (int64_t t = Tt - 1; t >= 0; --t) {
         float* dgi2 = z.dgi2 + t * B * 3 * H;
         float* dqgh = z.dqgh + t * B * Q;
         // attention backward: d alpha ; softmax backward ; dq = sum_s ds v (1 - tanh^2)
-        VAG_TRY(vag_attn_scores_ex_launch(1, k.encwp, dgi2, 3 * H, nullptr, nullptr, B, 1, 0, Ts, 3 * H, z.dah + t * B * Ts,
-                                          z.dalpha, s));
+        // ... in one grid with the hidden-side half of dh1 (dgh2 W_hh2 + z2*dh2), whose operand is already known
+        VAG_TRY(vag_dalpha_side_launch(k.encwp, dgi2, 3 * H, z.dah + t * B * Ts, B, Ts, 3 * H, z.dalpha,
+                                       B, H, 3 * H, dqgh + C, Q, z.wcatT + C, Q, z.dh1d, z.pbuf, s));
         VAG_TRY(vag_attn_dq_launch(pe, k.qhp + t * B * Q, Q, w.attn_v, k.alpha + t * B * Ts, z.dalpha, z.ds + t * B * Ts, B,
                                    Ts, C, dqgh, Q, s));
-        // dh1 = [dq | dgh2] [attn_h ; W_hh2] + z2*dh2   -> gru_1 cell backward of this step
-        f.lda = Q; f.ldw = Q; f.K = (int)Q; f.ldgi = 3 * H; f.ldgh = 3 * H; f.has_cell = 1;
+        // dh1 = dq attn_h + (dgh2 W_hh2 + z2*dh2)   -> gru_1 cell backward of this step
+        f.lda = Q; f.ldw = Q; f.K = (int)C; f.ldgi = 3 * H; f.ldgh = 3 * H; f.has_cell = 1;
         GruBwdStepSide& sd = f.s[0];
-        sd.A = dqgh; sd.WT = z.wcatT; sd.addend = z.dh1d; sd.dh_add = nullptr; sd.drop_idx0 = 0;
+        sd.A = dqgh; sd.WT = z.wcatT; sd.addend = z.pbuf; sd.dh_add = nullptr; sd.drop_idx0 = 0;
         sd.save = k.g1 + t * 4 * BH; sd.hprev = (t == 0) ? h0 : h2_all + (t - 1) * BH;
         sd.dgi = z.dgi1 + t * B * 3 * H; sd.dgh = z.dgh1 + t * B * 3 * H; sd.dh_direct = z.carry; sd.dh_out = nullptr; sd.t = 0;
         VAG_TRY(vag_gru_bwd_step_launch(f, 1, s));

@@ -79,6 +79,12 @@ int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
                       const float* bias, const float* addend, int64_t ldadd, float* out, int64_t ldo, int act,
                       hipStream_t stream);
 // out[n] += sum_m X[m*ld + n]
+int vag_dalpha_side_launch(const float* x, const float* q, int64_t ldq, const float* addend, int64_t N, int64_t Ts, int64_t W,
+                           float* out, int64_t M, int64_t Np, int64_t K, const float* A, int64_t lda, const float* Wt,
+                           int64_t ldw, const float* padd, float* P, hipStream_t stream);
+int vag_skinny_batched_launch(int64_t nb, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t bsA,
+                              const float* W, int64_t ldw, int64_t bsW, float* out, int64_t ldo, int64_t bsO,
+                              hipStream_t stream);
 int vag_skinny_nn_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                          float beta, float* C, int64_t ldc, hipStream_t stream);
 // queue the qualifying (weight-gradient shaped) products issued between begin and end into one grouped launch;

@@ -619,6 +619,7 @@ struct SkinnyArgs {
     const float* A; const float* W; int64_t lda, ldw;
     int M, N, K;
     const float* bias; const float* addend; int64_t ldadd; float* out; int64_t ldo; int act;
+    int64_t bsA = 0, bsW = 0, bsO = 0;     // batched launches (blockIdx.z): element strides of A, W and out/addend
 };
 
 // Load pattern.  The MFMA wants lane l to hold row l&15, k-group l>>4, but a wave request whose lane QUADS each touch
@@ -724,11 +725,10 @@ __device__ __forceinline__ float skinny_sum1(const float* red, int tile, int mro
 // One 16x16 output tile per workgroup; the 256 outputs are finished by the first 256 threads (bias / addend requested
 // before the product).
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void skinny_plain_kernel(SkinnyArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4];
+__device__ __forceinline__ void skinny_plain_body(const SkinnyArgs& a, float* red, int bx, int by) {
     const int lane = threadIdx.x & 63;
     const int r = skinny_ldrow(lane), g = skinny_ldseg(lane);
-    const int m0 = blockIdx.y * 16, nb = blockIdx.x * 16;
+    const int m0 = by * 16, nb = bx * 16;
     const int erow = (threadIdx.x >> 4) & 15, ecol = threadIdx.x & 15;
     const int em = m0 + erow, ej = nb + ecol;
     const bool eok = threadIdx.x < 256 && em < a.M && ej < a.N;
@@ -746,6 +746,69 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_plain_kernel(SkinnyArgs a) 
     float v = skinny_sum1<WAVES, 1>(red, 0, erow, ecol) + pre;
     if (a.act == VAG_ACT_TANH) v = vag_tanh(v);
     a.out[(int64_t)em * a.ldo + ej] = v;
+}
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void skinny_plain_kernel(SkinnyArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4];
+    if (blockIdx.z) {
+        a.A += blockIdx.z * a.bsA; a.W += blockIdx.z * a.bsW; a.out += blockIdx.z * a.bsO;
+        if (a.addend) a.addend += blockIdx.z * a.bsO;
+    }
+    skinny_plain_body<WAVES>(a, red, blockIdx.x, blockIdx.y);
+}
+
+// Horizontal fusion for the decoder's backward step: the attention's d alpha (a streaming dot product per (row, position),
+// latency bound, most CUs half idle) and an INDEPENDENT skinny product in one grid.  The product is the hidden-side part
+// dgh2 W_hh2 (+ carry) of the next launch's dh1 = [dq | dgh2] [attn_h; W_hh2]: its operand is known one launch earlier
+// than dq, so it runs beside the attention backward instead of lengthening the critical path (K 2560 -> 1024 there).
+// Blocks [0, nscore) are (position chunk, row) pairs of the dot product, the rest are 16x16 tiles of the product.
+static bool skinny_ok(const float* A, int64_t lda, const float* W, int64_t ldw, int64_t K);
+struct DotArgs {
+    const float* x; const float* q; const float* addend; float* out;      // x (B,Ts,W), q (N,ldq), addend/out (N,Ts)
+    int64_t ldq;
+    int Ts, W, gx, nscore;
+};
+__global__ __launch_bounds__(256) void dalpha_side_kernel(DotArgs d, SkinnyArgs a, int tiles_x) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
+    const int id = blockIdx.x;
+    if (id >= d.nscore) {
+        const int t = id - d.nscore;
+        skinny_plain_body<4>(a, red, t % tiles_x, t / tiles_x);
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int s = (id % d.gx) * 4 + (threadIdx.x >> 6);
+    if (s >= d.Ts) return;
+    const int64_t n = id / d.gx;
+    const float* xr = d.x + (n * d.Ts + s) * d.W;
+    const float* qr = d.q + n * d.ldq;
+    float acc = 0.f;
+    for (int c = lane * 4; c < d.W; c += 256) {
+        const float4 pv = *reinterpret_cast<const float4*>(xr + c);
+        const float4 qv = *reinterpret_cast<const float4*>(qr + c);
+        acc += pv.x * qv.x + pv.y * qv.y + pv.z * qv.z + pv.w * qv.w;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) d.out[n * d.Ts + s] = acc + (d.addend ? d.addend[n * d.Ts + s] : 0.f);
+}
+// out (N,Ts) = x[n,s,:] . q[n,:] + addend;  side: P (M,Np) = A (M,K) Wt^T + padd, A row stride lda, Wt (Np,K) row stride ldw
+int vag_dalpha_side_launch(const float* x, const float* q, int64_t ldq, const float* addend, int64_t N, int64_t Ts, int64_t W,
+                           float* out, int64_t M, int64_t Np, int64_t K, const float* A, int64_t lda, const float* Wt,
+                           int64_t ldw, const float* padd, float* P, hipStream_t stream) {
+    VAG_CHECK_ARG(x && q && out && N > 0 && Ts > 0 && W > 0 && W % 4 == 0 && ldq % 4 == 0 && aligned16(x) && aligned16(q));
+    VAG_CHECK_ARG(A && Wt && P && M > 0 && Np > 0 && skinny_ok(A, lda, Wt, ldw, K));
+    DotArgs d;
+    d.x = x; d.q = q; d.addend = addend; d.out = out; d.ldq = ldq; d.Ts = (int)Ts; d.W = (int)W;
+    d.gx = (int)cdiv64(Ts, 4);
+    VAG_CHECK_ARG((int64_t)d.gx * N < (1ll << 30));
+    d.nscore = (int)(d.gx * N);
+    SkinnyArgs a;
+    a.A = A; a.W = Wt; a.lda = lda; a.ldw = ldw; a.M = (int)M; a.N = (int)Np; a.K = (int)K;
+    a.bias = nullptr; a.addend = padd; a.ldadd = Np; a.out = P; a.ldo = Np; a.act = VAG_ACT_NONE;
+    const int tiles_x = (int)cdiv64(Np, 16), tiles_y = (int)cdiv64(M, 16);
+    hipLaunchKernelGGL(dalpha_side_kernel, dim3((unsigned)(d.nscore + tiles_x * tiles_y)), dim3(256), 0, stream, d, a, tiles_x);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
 }
 
 // out[m,n] = sum_k A[m,k] B[k,n] with B stored (K,N) row-major (data gradients dX = dY W of the once-per-batch
@@ -1016,6 +1079,23 @@ int vag_skinny_nn_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_
     if (K <= 256) hipLaunchKernelGGL((skinny_bt_kernel<4>), grid, dim3(256), 0, stream, a);
     else if (K <= 1024) hipLaunchKernelGGL((skinny_bt_kernel<8>), grid, dim3(512), 0, stream, a);
     else hipLaunchKernelGGL((skinny_bt_kernel<16>), grid, dim3(1024), 0, stream, a);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+// nb independent products out_z (M,N) = A_z (M,K) W_z^T, operands and outputs at fixed element strides (one launch)
+int vag_skinny_batched_launch(int64_t nb, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t bsA,
+                              const float* W, int64_t ldw, int64_t bsW, float* out, int64_t ldo, int64_t bsO,
+                              hipStream_t stream) {
+    VAG_CHECK_ARG(nb > 0 && nb < 65536 && M > 0 && N > 0 && K > 0 && A && W && out && skinny_ok(A, lda, W, ldw, K));
+    VAG_CHECK_ARG(bsA % 4 == 0 && bsW % 4 == 0);
+    SkinnyArgs a;
+    a.A = A; a.W = W; a.lda = lda; a.ldw = ldw; a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.bias = nullptr; a.addend = nullptr; a.ldadd = 0; a.out = out; a.ldo = ldo; a.act = VAG_ACT_NONE;
+    a.bsA = bsA; a.bsW = bsW; a.bsO = bsO;
+    dim3 grid((unsigned)cdiv64(N, 16), (unsigned)cdiv64(M, 16), (unsigned)nb);
+    if (K <= 256) hipLaunchKernelGGL((skinny_plain_kernel<4>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((skinny_plain_kernel<8>), grid, dim3(512), 0, stream, a);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
