@@ -3,6 +3,13 @@ FETCH_SIZE / WRITE_SIZE are in KiB... per dispatch; on gfx950 FETCH_SIZE reports
 reads (MI355X_MICROARCH.md, HBM section) and is doubled here; WRITE_SIZE is taken as is."""
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def between_markers(d, counter, marker="rng_advance_kernel"):
+    """Sum of `counter` over the dispatches between the first two marker launches (file order = dispatch order)."""
+    f = [d] if os.path.isfile(d) else glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    rows = [r for r in csv.DictReader(open(f[0])) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
+    return sum(float(r["Counter_Value"]) for r in rows[idx[0] + 1:idx[1]])
 def load(d, counter):
     f = [d] if os.path.isfile(d) else glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     rows = list(csv.DictReader(open(f[0])))
@@ -24,8 +31,9 @@ def kib(x):
 g_f = [v for k, v in fetch.items() if "gru_step_small_kernel" in k][0]      # decoder-shape cells (M=64, one direction)
 g_w = [v for k, v in write.items() if "gru_step_small_kernel" in k][0]
 cell_fetch = sum(g_f[-200:]) / 200; cell_write = sum(g_w[-200:]) / 200
-dec_fetch = (total(fetch, lambda k: any(n in k for n in DEC)) - sum(g_f[-200:]))
-dec_write = (total(write, lambda k: any(n in k for n in DEC)) - sum(g_w[-200:]))
+# decoder step = every dispatch of the three bracketed sequence calls (4 kernels per step + the per-batch products), / steps
+dec_fetch = between_markers(sys.argv[1], "FETCH_SIZE")
+dec_write = between_markers(sys.argv[2], "WRITE_SIZE")
 b_f = [v for k, v in fetch.items() if "gru_bwd_step_kernel" in k][0]
 b_w = [v for k, v in write.items() if "gru_bwd_step_kernel" in k][0]
 bwd_fetch = sum(b_f[-200:]) / 200; bwd_write = sum(b_w[-200:]) / 200
