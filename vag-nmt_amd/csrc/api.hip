@@ -414,8 +414,16 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
         a.s[0].A = hprev; a.s[0].W = w.gru1.w_hh; a.s[0].bias = w.gru1.b_hh; a.s[0].other = k.xp1 + t * B * 3 * H;
         a.s[0].hprev = hprev; a.s[0].hout = h1; a.s[0].out2 = nullptr; a.s[0].save = k.g1 + t * 4 * BH; a.s[0].t = 0;
         VAG_TRY(vag_gru_step_launch(a, 1, s));                                                              // gru_1 :121
-        VAG_TRY(vag_skinny_launch(B, Q, H, h1, H, p.wcat, H, p.bcat, nullptr, 0, qhp, Q, 0, s));             // attn_h(h1) | W_hh2 h1
-        VAG_TRY(vag_attn_scores_launch(0, pe, qhp, Q, w.attn_v, mask, B, 1, Ts, C, k.scores, s));           // :47-51, :41-43
+        static const bool opt_side = getenv("VAG_CGRU_NOSIDE") == nullptr;
+        if (opt_side && Ts * B < (1ll << 28)) {
+            // q = attn_h h1, then the scores with W_hh2 h1 + b_hh2 (not needed before the cell) in the same grid
+            VAG_TRY(vag_skinny_launch(B, C, H, h1, H, p.wcat, H, nullptr, nullptr, 0, qhp, Q, 0, s));                  // :47
+            VAG_TRY(vag_attn_dot_side_launch(0, pe, qhp, Q, w.attn_v, mask, nullptr, B, Ts, C, k.scores, B, 3 * H, H, h1, H,
+                                             p.wcat + C * H, H, p.bcat + C, nullptr, qhp + C, Q, s));                   // :47-51, :41-43
+        } else {
+            VAG_TRY(vag_skinny_launch(B, Q, H, h1, H, p.wcat, H, p.bcat, nullptr, 0, qhp, Q, 0, s));         // attn_h(h1) | W_hh2 h1
+            VAG_TRY(vag_attn_scores_launch(0, pe, qhp, Q, w.attn_v, mask, B, 1, Ts, C, k.scores, s));       // :47-51, :41-43
+        }
         VAG_TRY(vag_attn_ctx_gru_launch(k.scores, k.encwp, B, 1, Ts, H, w.gru2.b_ih, qhp + C, Q, h1, k.alpha + t * B * Ts,
                                         h2_all + t * BH, k.g2 + t * 4 * BH, s));                            // :44, :126-129
     }
@@ -512,8 +520,8 @@ int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const f
         float* dqgh = z.dqgh + t * B * Q;
         // attention backward: d alpha ; softmax backward ; dq = sum_s ds v (1 - tanh^2)
         // ... in one grid with the hidden-side half of dh1 (dgh2 W_hh2 + z2*dh2), whose operand is already known
-        VAG_TRY(vag_dalpha_side_launch(k.encwp, dgi2, 3 * H, z.dah + t * B * Ts, B, Ts, 3 * H, z.dalpha,
-                                       B, H, 3 * H, dqgh + C, Q, z.wcatT + C, Q, z.dh1d, z.pbuf, s));
+        VAG_TRY(vag_attn_dot_side_launch(1, k.encwp, dgi2, 3 * H, nullptr, nullptr, z.dah + t * B * Ts, B, Ts, 3 * H, z.dalpha,
+                                         B, H, 3 * H, dqgh + C, Q, z.wcatT + C, Q, nullptr, z.dh1d, z.pbuf, H, s));
         VAG_TRY(vag_attn_dq_launch(pe, k.qhp + t * B * Q, Q, w.attn_v, k.alpha + t * B * Ts, z.dalpha, z.ds + t * B * Ts, B,
                                    Ts, C, dqgh, Q, s));
         // dh1 = dq attn_h + (dgh2 W_hh2 + z2*dh2)   -> gru_1 cell backward of this step

@@ -79,9 +79,10 @@ int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
                       const float* bias, const float* addend, int64_t ldadd, float* out, int64_t ldo, int act,
                       hipStream_t stream);
 // out[n] += sum_m X[m*ld + n]
-int vag_dalpha_side_launch(const float* x, const float* q, int64_t ldq, const float* addend, int64_t N, int64_t Ts, int64_t W,
-                           float* out, int64_t M, int64_t Np, int64_t K, const float* A, int64_t lda, const float* Wt,
-                           int64_t ldw, const float* padd, float* P, hipStream_t stream);
+int vag_attn_dot_side_launch(int mode, const float* x, const float* q, int64_t ldq, const float* v, const float* mask,
+                             const float* addend, int64_t N, int64_t Ts, int64_t W, float* out, int64_t M, int64_t Np,
+                             int64_t K, const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* pbias,
+                             const float* padd, float* P, int64_t ldp, hipStream_t stream);
 int vag_skinny_batched_launch(int64_t nb, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t bsA,
                               const float* W, int64_t ldw, int64_t bsW, float* out, int64_t ldo, int64_t bsO,
                               hipStream_t stream);

@@ -757,18 +757,21 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_plain_kernel(SkinnyArgs a) 
     skinny_plain_body<WAVES>(a, red, blockIdx.x, blockIdx.y);
 }
 
-// Horizontal fusion for the decoder's backward step: the attention's d alpha (a streaming dot product per (row, position),
-// latency bound, most CUs half idle) and an INDEPENDENT skinny product in one grid.  The product is the hidden-side part
-// dgh2 W_hh2 (+ carry) of the next launch's dh1 = [dq | dgh2] [attn_h; W_hh2]: its operand is known one launch earlier
-// than dq, so it runs beside the attention backward instead of lengthening the critical path (K 2560 -> 1024 there).
+// Horizontal fusion for the decoder steps: an attention dot-product pass (a streaming dot per (row, position), latency
+// bound, most CUs half idle) and an INDEPENDENT skinny product in one grid.  Backward: the hidden-side part dgh2 W_hh2
+// (+ carry) of the next launch's dh1 = [dq | dgh2] [attn_h; W_hh2] -- its operand is known one launch earlier than dq, so
+// it runs beside d alpha instead of lengthening the critical path (K 2560 -> 1024 there).  Forward: W_hh2 h1, which the
+// scores do not need (they only need attn_h h1), runs beside them instead of in front of them.
 // Blocks [0, nscore) are (position chunk, row) pairs of the dot product, the rest are 16x16 tiles of the product.
 static bool skinny_ok(const float* A, int64_t lda, const float* W, int64_t ldw, int64_t K);
 struct DotArgs {
     const float* x; const float* q; const float* addend; float* out;      // x (B,Ts,W), q (N,ldq), addend/out (N,Ts)
+    const float* v; const float* mask;                                     // MODE 0: out = v . tanh(x + q), masked to -inf
     int64_t ldq;
     int Ts, W, gx, nscore;
 };
-__global__ __launch_bounds__(256) void dalpha_side_kernel(DotArgs d, SkinnyArgs a, int tiles_x) {
+template <int MODE>
+__global__ __launch_bounds__(256) void attn_dot_side_kernel(DotArgs d, SkinnyArgs a, int tiles_x) {
     __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
     const int id = blockIdx.x;
     if (id >= d.nscore) {
@@ -786,27 +789,45 @@ __global__ __launch_bounds__(256) void dalpha_side_kernel(DotArgs d, SkinnyArgs 
     for (int c = lane * 4; c < d.W; c += 256) {
         const float4 pv = *reinterpret_cast<const float4*>(xr + c);
         const float4 qv = *reinterpret_cast<const float4*>(qr + c);
-        acc += pv.x * qv.x + pv.y * qv.y + pv.z * qv.z + pv.w * qv.w;
+        if (MODE == 0) {
+            const float4 vv = *reinterpret_cast<const float4*>(d.v + c);
+            acc += vv.x * vag_tanh(pv.x + qv.x);
+            acc += vv.y * vag_tanh(pv.y + qv.y);
+            acc += vv.z * vag_tanh(pv.z + qv.z);
+            acc += vv.w * vag_tanh(pv.w + qv.w);
+        } else {
+            acc += pv.x * qv.x + pv.y * qv.y + pv.z * qv.z + pv.w * qv.w;
+        }
     }
     acc = wave_sum(acc);
-    if (lane == 0) d.out[n * d.Ts + s] = acc + (d.addend ? d.addend[n * d.Ts + s] : 0.f);
+    if (lane == 0) {
+        if (d.addend) acc += d.addend[n * d.Ts + s];
+        if (MODE == 0 && d.mask && d.mask[n * d.Ts + s] == 0.f) acc = -INFINITY;
+        d.out[n * d.Ts + s] = acc;
+    }
 }
-// out (N,Ts) = x[n,s,:] . q[n,:] + addend;  side: P (M,Np) = A (M,K) Wt^T + padd, A row stride lda, Wt (Np,K) row stride ldw
-int vag_dalpha_side_launch(const float* x, const float* q, int64_t ldq, const float* addend, int64_t N, int64_t Ts, int64_t W,
-                           float* out, int64_t M, int64_t Np, int64_t K, const float* A, int64_t lda, const float* Wt,
-                           int64_t ldw, const float* padd, float* P, hipStream_t stream) {
+// mode 1: out (N,Ts) = x[n,s,:] . q[n,:] + addend;  mode 0: out = v . tanh(x[n,s,:] + q[n,:]), -inf where mask (N,Ts) == 0.
+// One source row per query row (training: N = B).  Side product in the same grid:
+// P (M,Np) = A (M,K) Wt^T + pbias + padd;  A row stride lda, Wt (Np,K) row stride ldw, padd (M,Np) contiguous, P row stride ldp.
+int vag_attn_dot_side_launch(int mode, const float* x, const float* q, int64_t ldq, const float* v, const float* mask,
+                             const float* addend, int64_t N, int64_t Ts, int64_t W, float* out, int64_t M, int64_t Np,
+                             int64_t K, const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* pbias,
+                             const float* padd, float* P, int64_t ldp, hipStream_t stream) {
     VAG_CHECK_ARG(x && q && out && N > 0 && Ts > 0 && W > 0 && W % 4 == 0 && ldq % 4 == 0 && aligned16(x) && aligned16(q));
-    VAG_CHECK_ARG(A && Wt && P && M > 0 && Np > 0 && skinny_ok(A, lda, Wt, ldw, K));
+    VAG_CHECK_ARG((mode == 1 || (mode == 0 && v && aligned16(v))) && A && Wt && P && M > 0 && Np > 0 &&
+                  skinny_ok(A, lda, Wt, ldw, K));
     DotArgs d;
-    d.x = x; d.q = q; d.addend = addend; d.out = out; d.ldq = ldq; d.Ts = (int)Ts; d.W = (int)W;
+    d.x = x; d.q = q; d.addend = addend; d.out = out; d.v = v; d.mask = mask; d.ldq = ldq; d.Ts = (int)Ts; d.W = (int)W;
     d.gx = (int)cdiv64(Ts, 4);
     VAG_CHECK_ARG((int64_t)d.gx * N < (1ll << 30));
     d.nscore = (int)(d.gx * N);
     SkinnyArgs a;
     a.A = A; a.W = Wt; a.lda = lda; a.ldw = ldw; a.M = (int)M; a.N = (int)Np; a.K = (int)K;
-    a.bias = nullptr; a.addend = padd; a.ldadd = Np; a.out = P; a.ldo = Np; a.act = VAG_ACT_NONE;
+    a.bias = pbias; a.addend = padd; a.ldadd = Np; a.out = P; a.ldo = ldp; a.act = VAG_ACT_NONE;
     const int tiles_x = (int)cdiv64(Np, 16), tiles_y = (int)cdiv64(M, 16);
-    hipLaunchKernelGGL(dalpha_side_kernel, dim3((unsigned)(d.nscore + tiles_x * tiles_y)), dim3(256), 0, stream, d, a, tiles_x);
+    const dim3 grid((unsigned)(d.nscore + tiles_x * tiles_y));
+    if (mode == 0) hipLaunchKernelGGL(attn_dot_side_kernel<0>, grid, dim3(256), 0, stream, d, a, tiles_x);
+    else hipLaunchKernelGGL(attn_dot_side_kernel<1>, grid, dim3(256), 0, stream, d, a, tiles_x);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
