@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * CG_WAVES) void attn_ctx_gru_kernel(const float
     for (int g = 0; g < 3; ++g) acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (uok) {
         const float* e = encwp + b * Ts * 3 * H + u;
-        constexpr int U = 4;
+        constexpr int U = 5;
         for (int s0 = wave; s0 < Ts; s0 += U * CG_WAVES) {
             float4 ev[U][3];
 #pragma unroll
