@@ -306,7 +306,8 @@ int vag_beam_finish(const float* nll, const int64_t* beam, int64_t max_len, int6
  * into nseg contiguous segments [seg_off[i], seg_off[i+1]) with their own lr / L2 weight decay (the reference's
  * param groups).  grad_scale multiplies every gradient first (1/world_size after a sum all-reduce).
  * seg_off (nseg+1), seg_lr, seg_wd are HOST arrays (read while enqueuing).  step: device int32 counter,
- * incremented here.  norm_out (1): total gradient norm before clipping.  scratch: 32 bytes, 8-byte aligned. */
+ * incremented here.  norm_out (1): total gradient norm before clipping.  scratch: VAG_ADAM_SCRATCH_BYTES, 8-byte aligned. */
+#define VAG_ADAM_SCRATCH_BYTES 2048
 int vag_clip_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
                        const float* seg_lr, const float* seg_wd, float clip, float grad_scale, float beta1,
                        float beta2, float eps, int32_t* step, float* norm_out, void* scratch, vag_stream_t stream);

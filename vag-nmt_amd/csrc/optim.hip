@@ -3,13 +3,18 @@
 // bias corrections in double, step counter), and the streaming update (7 x 4 B per parameter).
 #include "kernels.h"
 
-struct AdamScalars {          // lives in the caller's 32-byte scratch
+constexpr int SUMSQ_SLOTS = 128;
+struct AdamScalars {          // lives in the caller's scratch (VAG_ADAM_SCRATCH_BYTES)
     double sumsq;
     float coef;               // grad_scale * min(1, clip / (norm + 1e-6))
     float bc1;                // 1 - beta1^t
     float bc2_sqrt;           // sqrt(1 - beta2^t)
     float pad;
+    // the blocks' partial sums land in 128 slots (2048 double atomics on ONE address serialise in L2: ~25 of the
+    // pass's 31 us); adam_prep_kernel adds the slots up
+    double part[SUMSQ_SLOTS];
 };
+static_assert(sizeof(AdamScalars) <= 2048, "vag_clip_adam_flat scratch contract");
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, AdamScalars* sc) {
     __shared__ double sh[4];
@@ -39,17 +44,21 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&sc->sumsq, sh[0] + sh[1] + sh[2] + sh[3]);
+    if (threadIdx.x == 0) atomicAdd(&sc->part[blockIdx.x % SUMSQ_SLOTS], sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
 __global__ void adam_zero_kernel(AdamScalars* sc) {
     if (threadIdx.x == 0) { sc->sumsq = 0.0; sc->coef = 0.f; sc->bc1 = 1.f; sc->bc2_sqrt = 1.f; sc->pad = 0.f; }
+    for (int i = threadIdx.x; i < SUMSQ_SLOTS; i += blockDim.x) sc->part[i] = 0.0;
 }
 
 __global__ void adam_prep_kernel(AdamScalars* sc, float clip, float grad_scale, float beta1, float beta2,
                                  int32_t* step, float* norm_out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const double norm = sqrt(sc->sumsq) * (double)grad_scale;      // norm of the scaled (averaged) gradient
+    double ss = 0.0;
+    for (int i = 0; i < SUMSQ_SLOTS; ++i) ss += sc->part[i];       // fixed order
+    sc->sumsq = ss;
+    const double norm = sqrt(ss) * (double)grad_scale;             // norm of the scaled (averaged) gradient
     double c = (double)clip / (norm + 1e-6);                        // torch.nn.utils.clip_grad_norm_
     if (c > 1.0) c = 1.0;
     if (clip <= 0.f) c = 1.0;

@@ -96,7 +96,7 @@ class TrainStep:
         self._seg_wd = (C.c_float * ns)(*[weight_decay if g[2] else 0.0 for g in self.fp.groups])
         self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._scratch = torch.zeros(8, dtype=torch.float32, device=dev)
+        self._scratch = torch.zeros(512, dtype=torch.float32, device=dev)        # VAG_ADAM_SCRATCH_BYTES
         self._graphs = {}
         self._eager_done = set()
         # optional second stream for the weight-gradient products.  Measured (round 1): no gain -- the products' blocks
