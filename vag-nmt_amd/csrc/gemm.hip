@@ -770,17 +770,18 @@ struct DotArgs {
     int64_t ldq;
     int Ts, W, gx, nscore;
 };
-template <int MODE>
-__global__ __launch_bounds__(256) void attn_dot_side_kernel(DotArgs d, SkinnyArgs a, int tiles_x) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
+// DS_WAVES waves per block: that many (row, position) pairs, or the K split of one product tile
+template <int MODE, int DS_WAVES>
+__global__ __launch_bounds__(64 * DS_WAVES) void attn_dot_side_kernel(DotArgs d, SkinnyArgs a, int tiles_x) {
+    __shared__ __attribute__((aligned(16))) float red[DS_WAVES * 64 * 4];
     const int id = blockIdx.x;
     if (id >= d.nscore) {
         const int t = id - d.nscore;
-        skinny_plain_body<4>(a, red, t % tiles_x, t / tiles_x);
+        skinny_plain_body<DS_WAVES>(a, red, t % tiles_x, t / tiles_x);
         return;
     }
     const int lane = threadIdx.x & 63;
-    const int s = (id % d.gx) * 4 + (threadIdx.x >> 6);
+    const int s = (id % d.gx) * DS_WAVES + (threadIdx.x >> 6);
     if (s >= d.Ts) return;
     const int64_t n = id / d.gx;
     const float* xr = d.x + (n * d.Ts + s) * d.W;
@@ -818,7 +819,8 @@ int vag_attn_dot_side_launch(int mode, const float* x, const float* q, int64_t l
                   skinny_ok(A, lda, Wt, ldw, K));
     DotArgs d;
     d.x = x; d.q = q; d.addend = addend; d.out = out; d.v = v; d.mask = mask; d.ldq = ldq; d.Ts = (int)Ts; d.W = (int)W;
-    d.gx = (int)cdiv64(Ts, 4);
+    const int DS_WAVES = mode == 0 ? 8 : 16;        // measured: forward side product K = H, backward K = 3H
+    d.gx = (int)cdiv64(Ts, DS_WAVES);
     VAG_CHECK_ARG((int64_t)d.gx * N < (1ll << 30));
     d.nscore = (int)(d.gx * N);
     SkinnyArgs a;
@@ -826,8 +828,8 @@ int vag_attn_dot_side_launch(int mode, const float* x, const float* q, int64_t l
     a.bias = pbias; a.addend = padd; a.ldadd = Np; a.out = P; a.ldo = ldp; a.act = VAG_ACT_NONE;
     const int tiles_x = (int)cdiv64(Np, 16), tiles_y = (int)cdiv64(M, 16);
     const dim3 grid((unsigned)(d.nscore + tiles_x * tiles_y));
-    if (mode == 0) hipLaunchKernelGGL(attn_dot_side_kernel<0>, grid, dim3(256), 0, stream, d, a, tiles_x);
-    else hipLaunchKernelGGL(attn_dot_side_kernel<1>, grid, dim3(256), 0, stream, d, a, tiles_x);
+    if (mode == 0) hipLaunchKernelGGL((attn_dot_side_kernel<0, 8>), grid, dim3(512), 0, stream, d, a, tiles_x);
+    else hipLaunchKernelGGL((attn_dot_side_kernel<1, 16>), grid, dim3(1024), 0, stream, d, a, tiles_x);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
