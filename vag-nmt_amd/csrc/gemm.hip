@@ -688,10 +688,14 @@ __device__ __forceinline__ void skinny_mma(const float* const (&ap)[MT], const f
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     // lane group g supplies k = 4g+e to MFMA e; A and W use the same k order, so the sum is exact.
+#ifdef VAG_EXP_NO_MFMA      // timing experiment only (wrong results): how much of a chain launch is matrix-pipe time
+                    acc[i][j][0][0] += av[i][u].x + wv[j][u].x + av[i][u].y + wv[j][u].y + av[i][u].z + wv[j][u].z + av[i][u].w + wv[j][u].w;
+#else
                     acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][u].x, wv[j][u].x, acc[i][j][0], 0, 0, 0);
                     acc[i][j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][u].y, wv[j][u].y, acc[i][j][1], 0, 0, 0);
                     acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][u].z, wv[j][u].z, acc[i][j][0], 0, 0, 0);
                     acc[i][j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][u].w, wv[j][u].w, acc[i][j][1], 0, 0, 0);
+#endif
                 }
     }
 #pragma unroll
