@@ -641,7 +641,7 @@ __device__ __forceinline__ float4 skinny_xpose(float4 v, int src4) {
 // MT 16-row m-tiles x NT 16-col n-tiles per workgroup; K split over the WAVES waves.  ap/wp are this lane's LOAD
 // pointers (row skinny_ldrow(lane) of each tile, already offset by 4*skinny_ldseg(lane) floats).  Partial sums of all
 // waves end up in red[wave][tile][lane][4] (C/D map of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4)+i).
-template <int WAVES, int MT, int NT>
+template <int WAVES, int MT, int NT, int U = 4>
 __device__ __forceinline__ void skinny_mma(const float* const (&ap)[MT], const float* const (&wp)[NT], int K, float* red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = skinny_ldseg(lane);
@@ -658,9 +658,8 @@ __device__ __forceinline__ void skinny_mma(const float* const (&ap)[MT], const f
             acc[i][j][0] = f32x4{0.f, 0.f, 0.f, 0.f};
             acc[i][j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-    // 4 chunks (64 of K) in flight per wave; deeper request queues measured no faster (tools/skinny_probe.hip:
-    // the memory pipeline's request rate, not round trips, paces these kernels).
-    constexpr int U = 4;
+    // U chunks (16 of K each) in flight per wave.  Chosen by the caller so that a wave's whole K share is requested at
+    // once where it fits the registers: a second trip of the loop is a second dependent round of memory latency.
     for (int c0 = kbeg; c0 < kend; c0 += 16 * U) {
         float4 av[MT][U], wv[NT][U];
 #pragma unroll
@@ -728,7 +727,7 @@ __device__ __forceinline__ float skinny_sum1(const float* red, int tile, int mro
 
 // One 16x16 output tile per workgroup; the 256 outputs are finished by the first 256 threads (bias / addend requested
 // before the product).
-template <int WAVES>
+template <int WAVES, int U = 4>
 __device__ __forceinline__ void skinny_plain_body(const SkinnyArgs& a, float* red, int bx, int by) {
     const int lane = threadIdx.x & 63;
     const int r = skinny_ldrow(lane), g = skinny_ldseg(lane);
@@ -745,7 +744,7 @@ __device__ __forceinline__ void skinny_plain_body(const SkinnyArgs& a, float* re
     const float* wp[1];
     ap[0] = a.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + 4 * g;
     wp[0] = a.W + (int64_t)min(nb + r, a.N - 1) * a.ldw + 4 * g;
-    skinny_mma<WAVES, 1, 1>(ap, wp, a.K, red);
+    skinny_mma<WAVES, 1, 1, U>(ap, wp, a.K, red);
     if (!eok) return;
     float v = skinny_sum1<WAVES, 1>(red, 0, erow, ecol) + pre;
     if (a.act == VAG_ACT_TANH) v = vag_tanh(v);
@@ -781,7 +780,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void attn_dot_side_kernel(DotArgs d,
     const int id = blockIdx.x;
     if (id >= d.nscore) {
         const int t = id - d.nscore;
-        skinny_plain_body<DS_WAVES>(a, red, t % tiles_x, t / tiles_x);
+        skinny_plain_body<DS_WAVES, (MODE == 1 ? 6 : 4)>(a, red, t % tiles_x, t / tiles_x);
         return;
     }
     const int lane = threadIdx.x & 63;
@@ -999,7 +998,7 @@ __global__ __launch_bounds__(WAVES * 64) void gru_step_small_kernel(GruStepArgs 
 // Same structure: 256 outputs finished by 256 threads, epilogue operands prefetched under the product.
 // (A half-tile variant -- 8 output columns per workgroup on twice the workgroups, as gru_step_small_kernel does for the
 // forward cell -- measured no gain here: the MFMA count per workgroup stays that of a full tile.)
-template <int WAVES>
+template <int WAVES, int U>
 __global__ __launch_bounds__(WAVES * 64) void gru_bwd_step_kernel(GruBwdStepArgs a) {
     __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4];
     const GruBwdStepSide& sd = a.s[blockIdx.z];
@@ -1030,7 +1029,7 @@ __global__ __launch_bounds__(WAVES * 64) void gru_bwd_step_kernel(GruBwdStepArgs
     const float* wp[1];
     ap[0] = sd.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + 4 * g;
     wp[0] = sd.WT + (int64_t)min(nb + r, H - 1) * a.ldw + 4 * g;
-    skinny_mma<WAVES, 1, 1>(ap, wp, a.K, red);
+    skinny_mma<WAVES, 1, 1, U>(ap, wp, a.K, red);
     if (!eok) return;
     float dh = skinny_sum1<WAVES, 1>(red, 0, erow, ecol) + add;
     if (!a.has_cell) {
@@ -1165,9 +1164,12 @@ int vag_gru_bwd_step_launch(const GruBwdStepArgs& a, int nz, hipStream_t stream)
         else VAG_CHECK_ARG(a.s[z].dh_out != nullptr);
     }
     dim3 grid((unsigned)cdiv64(a.H, 16), (unsigned)cdiv64(a.M, 16), (unsigned)nz);
-    if (a.K <= 256) hipLaunchKernelGGL((gru_bwd_step_kernel<4>), grid, dim3(256), 0, stream, a);
-    else if (a.K <= 1024) hipLaunchKernelGGL((gru_bwd_step_kernel<8>), grid, dim3(512), 0, stream, a);
-    else hipLaunchKernelGGL((gru_bwd_step_kernel<16>), grid, dim3(1024), 0, stream, a);
+    // waves by K; chunks in flight so that a wave's K share (K / waves, in 16s) is one round of requests when it fits
+    if (a.K <= 256) hipLaunchKernelGGL((gru_bwd_step_kernel<4, 4>), grid, dim3(256), 0, stream, a);
+    else if (a.K <= 512) hipLaunchKernelGGL((gru_bwd_step_kernel<8, 4>), grid, dim3(512), 0, stream, a);
+    else if (a.K <= 1024) hipLaunchKernelGGL((gru_bwd_step_kernel<8, 8>), grid, dim3(512), 0, stream, a);
+    else if (a.K <= 1536) hipLaunchKernelGGL((gru_bwd_step_kernel<16, 6>), grid, dim3(1024), 0, stream, a);
+    else hipLaunchKernelGGL((gru_bwd_step_kernel<16, 4>), grid, dim3(1024), 0, stream, a);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
