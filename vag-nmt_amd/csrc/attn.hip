@@ -375,23 +375,26 @@ __global__ __launch_bounds__(64 * DQ_WAVES) void attn_dq_kernel(const float* __r
     if (cok) {
         const float4 qv = *reinterpret_cast<const float4*>(q + n * ldq + c);
         const float* p = pe + n * Ts * C + c;
-        // 4 key rows in flight per lane
-        for (int s0 = wave; s0 < Ts; s0 += 4 * DQ_WAVES) {
-            float4 pv[4];
+        // DQ_U key rows in flight per lane: a wave's whole share of a 40-position source in one round of requests
+        constexpr int DQ_U = 10;
+        for (int s0 = wave; s0 < Ts; s0 += DQ_U * DQ_WAVES) {
+            float4 pv[DQ_U];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < DQ_U; ++i) {
                 const int s = min(s0 + i * DQ_WAVES, Ts - 1);
                 pv[i] = *reinterpret_cast<const float4*>(p + (int64_t)s * C);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < DQ_U; ++i) {
                 const int s = s0 + i * DQ_WAVES;
-                const float d = (s < Ts) ? w[s] : 0.f;             // masked positions carry d = 0
-                float th;
-                th = vag_tanh(pv[i].x + qv.x); acc.x += d * (1.f - th * th);
-                th = vag_tanh(pv[i].y + qv.y); acc.y += d * (1.f - th * th);
-                th = vag_tanh(pv[i].z + qv.z); acc.z += d * (1.f - th * th);
-                th = vag_tanh(pv[i].w + qv.w); acc.w += d * (1.f - th * th);
+                if (s < Ts) {                                      // wave-uniform: no tanh work for slots past the end
+                    const float d = w[s];                          // masked positions carry d = 0
+                    float th;
+                    th = vag_tanh(pv[i].x + qv.x); acc.x += d * (1.f - th * th);
+                    th = vag_tanh(pv[i].y + qv.y); acc.y += d * (1.f - th * th);
+                    th = vag_tanh(pv[i].z + qv.z); acc.z += d * (1.f - th * th);
+                    th = vag_tanh(pv[i].w + qv.w); acc.w += d * (1.f - th * th);
+                }
             }
         }
     }
