@@ -166,6 +166,28 @@ __global__ __launch_bounds__(64 * CG_WAVES) void attn_ctx_gru_kernel(const float
     const int64_t n = blockIdx.y;
     const int64_t b = rps == 1 ? n : (int64_t)((int)blockIdx.y / rps);
     const float* sc = scores + n * Ts;
+    const int u = (blockIdx.x * 64 + lane) * 4;
+    const bool uok = u < H;
+    // Everything that does not depend on the softmax is requested first -- the first U value rows of this wave and, for
+    // wave 0, the cell's other operands -- so that the weights cost no extra round of memory latency.
+    constexpr int U = 5;
+    const float* e = encwp + b * Ts * 3 * H + (uok ? u : 0);
+    float4 ev[U][3];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int s = min(wave + i * CG_WAVES, Ts - 1);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) ev[i][g] = *reinterpret_cast<const float4*>(e + (int64_t)s * 3 * H + g * H);
+    }
+    float4 bb[3], hg[3], h1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (wave == 0 && uok) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            bb[g] = *reinterpret_cast<const float4*>(b_ih + g * H + u);
+            hg[g] = *reinterpret_cast<const float4*>(hp + n * ldhp + g * H + u);
+        }
+        h1 = *reinterpret_cast<const float4*>(hprev + n * H + u);
+    }
     {
         float mx = -INFINITY;
         for (int s = lane; s < Ts; s += 64) mx = fmaxf(mx, sc[s]);
@@ -181,21 +203,18 @@ __global__ __launch_bounds__(64 * CG_WAVES) void attn_ctx_gru_kernel(const float
         }
     }
     __syncthreads();
-    const int u = (blockIdx.x * 64 + lane) * 4;
-    const bool uok = u < H;
     float4 acc[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (uok) {
-        const float* e = encwp + b * Ts * 3 * H + u;
-        constexpr int U = 5;
         for (int s0 = wave; s0 < Ts; s0 += U * CG_WAVES) {
-            float4 ev[U][3];
+            if (s0 != wave) {       // later rounds (Ts > U * CG_WAVES)
 #pragma unroll
-            for (int i = 0; i < U; ++i) {
-                const int s = min(s0 + i * CG_WAVES, Ts - 1);
+                for (int i = 0; i < U; ++i) {
+                    const int s = min(s0 + i * CG_WAVES, Ts - 1);
 #pragma unroll
-                for (int g = 0; g < 3; ++g) ev[i][g] = *reinterpret_cast<const float4*>(e + (int64_t)s * 3 * H + g * H);
+                    for (int g = 0; g < 3; ++g) ev[i][g] = *reinterpret_cast<const float4*>(e + (int64_t)s * 3 * H + g * H);
+                }
             }
 #pragma unroll
             for (int i = 0; i < U; ++i) {
@@ -221,13 +240,9 @@ __global__ __launch_bounds__(64 * CG_WAVES) void attn_ctx_gru_kernel(const float
             const float4 o = part[(k * 3 + g) * 64 + lane];
             t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
         }
-        const float4 bb = *reinterpret_cast<const float4*>(b_ih + g * H + u);
-        gi[g][0] = t.x + bb.x; gi[g][1] = t.y + bb.y; gi[g][2] = t.z + bb.z; gi[g][3] = t.w + bb.w;
+        gi[g][0] = t.x + bb[g].x; gi[g][1] = t.y + bb[g].y; gi[g][2] = t.z + bb[g].z; gi[g][3] = t.w + bb[g].w;
     }
-    const float4 hr = *reinterpret_cast<const float4*>(hp + n * ldhp + u);
-    const float4 hz = *reinterpret_cast<const float4*>(hp + n * ldhp + H + u);
-    const float4 hn = *reinterpret_cast<const float4*>(hp + n * ldhp + 2 * H + u);
-    const float4 h1 = *reinterpret_cast<const float4*>(hprev + n * H + u);
+    const float4 hr = hg[0], hz = hg[1], hn = hg[2];
     const float ghr[4] = {hr.x, hr.y, hr.z, hr.w}, ghz[4] = {hz.x, hz.y, hz.z, hz.w}, ghn[4] = {hn.x, hn.y, hn.z, hn.w};
     const float hpv[4] = {h1.x, h1.y, h1.z, h1.w};
     float rr[4], zz[4], nn[4], ho[4];
@@ -356,6 +371,15 @@ __global__ __launch_bounds__(64 * DQ_WAVES) void attn_dq_kernel(const float* __r
     float4* part = reinterpret_cast<float4*>(w + ((Ts + 3) & ~3));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t n = blockIdx.y;
+    // the first round of key rows does not depend on the prologue: request it first
+    constexpr int DQ_U = 10;
+    const int c = (blockIdx.x * 64 + lane) * 4;
+    const bool cok = c < C;
+    const float* p = pe + n * Ts * C + (cok ? c : 0);
+    float4 pv[DQ_U];
+#pragma unroll
+    for (int i = 0; i < DQ_U; ++i) pv[i] = *reinterpret_cast<const float4*>(p + (int64_t)min(wave + i * DQ_WAVES, Ts - 1) * C);
+    const float4 qv = cok ? *reinterpret_cast<const float4*>(q + n * ldq + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (alpha) {
         float dot = 0.f;
         for (int s = lane; s < Ts; s += 64) dot += alpha[n * Ts + s] * dalpha[n * Ts + s];
@@ -369,20 +393,16 @@ __global__ __launch_bounds__(64 * DQ_WAVES) void attn_dq_kernel(const float* __r
         for (int s = threadIdx.x; s < Ts; s += 64 * DQ_WAVES) w[s] = dscore[n * Ts + s];
     }
     __syncthreads();
-    const int c = (blockIdx.x * 64 + lane) * 4;
-    const bool cok = c < C;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (cok) {
-        const float4 qv = *reinterpret_cast<const float4*>(q + n * ldq + c);
-        const float* p = pe + n * Ts * C + c;
         // DQ_U key rows in flight per lane: a wave's whole share of a 40-position source in one round of requests
-        constexpr int DQ_U = 10;
         for (int s0 = wave; s0 < Ts; s0 += DQ_U * DQ_WAVES) {
-            float4 pv[DQ_U];
+            if (s0 != wave) {       // later rounds (Ts > DQ_U * DQ_WAVES)
 #pragma unroll
-            for (int i = 0; i < DQ_U; ++i) {
-                const int s = min(s0 + i * DQ_WAVES, Ts - 1);
-                pv[i] = *reinterpret_cast<const float4*>(p + (int64_t)s * C);
+                for (int i = 0; i < DQ_U; ++i) {
+                    const int s = min(s0 + i * DQ_WAVES, Ts - 1);
+                    pv[i] = *reinterpret_cast<const float4*>(p + (int64_t)s * C);
+                }
             }
 #pragma unroll
             for (int i = 0; i < DQ_U; ++i) {
