@@ -209,6 +209,9 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 }
 // split two floats into three packed bf16 pairs (low half = first element)
 __device__ __forceinline__ void split3(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+#ifdef VAG_EXP_NO_SPLIT      // timing experiment only (wrong results): what the VALU side of the split costs
+    p1 = pack_bf16(a, b); p2 = p1; p3 = p1; return;
+#endif
     p1 = pack_bf16(a, b);
     const float a1 = __builtin_bit_cast(float, p1 << 16), b1 = __builtin_bit_cast(float, p1 & 0xffff0000u);
     const float ra = a - a1, rb = b - b1;
