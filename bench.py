@@ -186,10 +186,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-operators", action="store_true",
+                    help="profiling runs: skip the isolated operator timings so kernel counts in a trace are per step")
     ap.add_argument("--tfr", type=float, default=1.0, help="teacher forcing ratio (headline: 1.0)")
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="debug: disable the reference dropouts")
-    ap.add_argument("--overlap", type=int, default=-1, help="1/0: force the side-stream overlap of weight-gradient products")
+    ap.add_argument("--no-fused", action="store_true", help="debug: per-operator autograd path instead of vag_train_step")
     ap.add_argument("--config", choices=["cfg2", "cfg5-f32"], default="cfg2",
                     help="cfg2 = BASELINE configs[1] (the metric's configuration); cfg5-f32 = configs[4] sizes in fp32")
     args = ap.parse_args()
@@ -225,8 +227,7 @@ def main():
     crit_mt = torch.nn.NLLLoss(weight=vw, reduction="none")
     crit_vse = PairwiseRankingLoss(margin=0.1)
     ts = TrainStep(model, crit_mt, crit_vse, lr=4e-4, weight_decay=1e-5, clip=1.0, teacher_force_ratio=args.tfr,
-                   use_graph=not args.no_graph, process_group=pg, world_size=world,
-                   **({} if args.overlap < 0 else {"overlap": bool(args.overlap)}))
+                   use_graph=not args.no_graph, process_group=pg, world_size=world, fused=not args.no_fused)
     src, lens, tgt, im = make_batch(c, rank, dev, ragged=args.ragged)
     lens_t = torch.tensor(lens, dtype=torch.int32, device=dev)
 
@@ -263,6 +264,9 @@ def main():
     log("timed region done: %.3f ms/step" % (dt / args.steps * 1e3))
     if rank == 0:
         ab = algorithmic_bytes(c)
+        if args.no_operators:
+            print(json.dumps({"ms_per_step": dt / args.steps * 1e3, "final_loss": loss}))
+            return
         fam = measure_operators(c, dev)
         log("operator timings: %s" % fam)
         B, H = c["B"], c["H"]

@@ -61,7 +61,11 @@ int vag_version(void);
 
 /* ---- generic dense products (torch.nn.Linear / torch.mm call sites on the path) ---------------------- */
 /* C[M,N] = act(alpha * op(A) op(B) + beta*C + bias[n]).  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn];
- * one stride of each operand must be 1.  act: 0 none, 1 tanh.  fp32 MFMA (exact f32 fma chains). */
+ * one stride of each operand must be 1.  act: 0 none, 1 tanh.  Arithmetic: fp32-grade.  Products with M,N > 64 run on
+ * the bf16 matrix pipes with every fp32 operand split exactly into three bf16 parts and the six partial products with
+ * i+j <= 4 accumulated in fp32 ("bf16x6": relative error of a term ~2^-24, the class of a reassociated fp32 sum;
+ * bounded against the exact-f32 kernel in tests/test_gpu_kernels.py); smaller ones and VAG_GEMM_F32MFMA=1 use the
+ * f32-input MFMA (exact f32 fma chains). */
 int vag_gemm_f32(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
                  const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc,
                  const float* bias, int act, vag_stream_t stream);
@@ -129,6 +133,8 @@ int vag_attn_keys_proj_bwd(const float* enc, const float* attn_e, const float* d
  * Outputs for the head: h2_all (Tt,B,H), c_all (Tt,B,C), e_all (Tt,B,E).
  * ws: vag_cgru_ws_floats(B,Ts,Tt,E,H) floats, kept for the backward. */
 int64_t vag_cgru_ws_floats(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H);
+/* float offset of a saved per-step tensor inside ws (parity tests): 0 alpha (Tt,B,Ts), 1 h1 (Tt,B,H), 2 [q | W_hh2 h1 + b] */
+int64_t vag_cgru_ws_offset(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, int which);
 int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float* mask, const float* h0,
                                  int64_t* tok, vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt, int64_t E,
                                  int64_t H, int64_t V, float* h2_all, float* c_all, float* e_all, float* ws,
@@ -308,9 +314,65 @@ int vag_beam_finish(const float* nll, const int64_t* beam, int64_t max_len, int6
  * seg_off (nseg+1), seg_lr, seg_wd are HOST arrays (read while enqueuing).  step: device int32 counter,
  * incremented here.  norm_out (1): total gradient norm before clipping.  scratch: VAG_ADAM_SCRATCH_BYTES, 8-byte aligned. */
 #define VAG_ADAM_SCRATCH_BYTES 2048
-int vag_clip_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
+/* zero_grad != 0: g is left zeroed (the next step's backward accumulates into it; no separate fill pass).
+ * scratch must be zero before the FIRST call; every call leaves it ready for the next one.  Two launches. */
+int vag_clip_adam_flat(float* p, float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
                        const float* seg_lr, const float* seg_wd, float clip, float grad_scale, float beta1,
-                       float beta2, float eps, int32_t* step, float* norm_out, void* scratch, vag_stream_t stream);
+                       float beta2, float eps, int zero_grad, int32_t* step, float* norm_out, void* scratch,
+                       vag_stream_t stream);
+
+/* ---- a2 + a13: the whole training step (train.py:36-51 around models/...V11.py:82-168 and
+ * NMT_Seq2Seq_Beam_V2.py:58-113) as ONE call: every operator above in the order autograd would run them, on one
+ * caller-owned workspace.  Gradients are ACCUMULATED into g (keep it zeroed between steps: vag_clip_adam_flat with
+ * zero_grad does).  The per-operator entry points stay the public API for the reference's module-level calls
+ * (model.forward + loss.backward()); this is what the step driver (vagnmt_hip/trainer.py) replays from a HIP graph. */
+typedef struct {
+    const float* enc_emb;                 /* encoder.embedding.weight (Vs,Es) */
+    vag_gru_w enc_fw, enc_bw;             /* encoder.gru.*_l0 / *_l0_reverse */
+    /* vse_imagine.* -- all NULL for the text-only model (NMT_Seq2Seq_Beam_V2) */
+    const float *im_w, *im_b, *txt_w, *txt_b, *ctx2ctx, *emb2ctx, *mlp_w;
+    const float *ini_w, *ini_b;           /* decoderini */
+    const float* attn_e;                  /* decoder.attn.attn_e.weight (C,C) */
+    vag_dec_w dec;
+    vag_head_w head;
+} vag_model_w;
+typedef struct {
+    float* enc_emb;
+    vag_gru_g enc_fw, enc_bw;
+    float *im_w, *im_b, *txt_w, *txt_b, *ctx2ctx, *emb2ctx, *mlp_w;
+    float *ini_w, *ini_b;
+    float* attn_e;
+    vag_dec_g dec;
+    vag_head_g head;
+} vag_model_g;
+typedef struct {
+    int64_t B, Ts, Tt, Es, Et, H, S, I, V, ldl;   /* Es/Et: source/target embedding size; ldl = ceil4(V) */
+    int32_t multimodal;                   /* 1: V11 (image branch + ranking loss), 0: text-only V2 */
+    int32_t attn_method;                  /* imagine attention: 0 'dot', 1 'mlp' */
+    int32_t activation_vse;               /* tanh on the shared-space projections */
+    int32_t rank_kind;                    /* 0 pairwise, 1 image retrieval, -1 no criterion_vse (loss_vse = 0) */
+    int32_t free_run;                     /* 0 teacher forcing, 1 feed back the argmax (V11.py:148-160) */
+    int32_t reserved;
+    float margin, loss_w, init_split, p_emb, p_ctx, p_out;
+} vag_step_cfg;
+/* phases: bit 0 forward (losses[0..2] = loss, loss_mt, loss_vse), bit 1 backward down to the encoder states (final for
+ * every gradient except the encoder's), bit 2 the encoder's backward.  A data-parallel driver all-reduces the first
+ * gradient bucket while phase 4 runs.  rng: {seed, step} (step is advanced by the forward phase) or NULL (no dropout).
+ * derived: vag_derived_floats(H) floats kept current with vag_derive_weights() after every optimiser step, or NULL
+ * (derived weights are then rebuilt inside the call).  ws: vag_step_ws_floats(cfg) floats, kept between phases. */
+int64_t vag_step_ws_floats(const vag_step_cfg* cfg);
+int64_t vag_step_ws_offset(const vag_step_cfg* cfg, int which);
+int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* w, const vag_model_g* g, const int64_t* src,
+                   const int32_t* lengths, const int64_t* tgt, const float* im, const float* vocab_weight, uint64_t* rng,
+                   const float* derived, float* ws, float* losses, int phases, vag_stream_t stream);
+/* Up to four contiguous device byte ranges copied by one launch (src[i] -> dst[i], bytes[i]; host arrays): a batch's
+ * src / lengths / tgt / image rows into the step driver's static input buffers. */
+int vag_copy4(const void* const* src, void* const* dst, const int64_t* bytes, int n, vag_stream_t stream);
+/* Weights derived from the parameters alone ([attn_h; gru_2.w_hh] stacked and transposed, gru_2.w_ih . context2hid,
+ * gru_1.w_hh^T, both encoder w_hh^T): per optimiser step, not per training step. */
+int64_t vag_derived_floats(int64_t H);
+int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_whh_bw, int64_t H, float* derived,
+                       vag_stream_t stream);
 
 /* ---- dropout helpers ---------------------------------------------------------------------------------- */
 /* which: 1 encoder-embedding (Ts,B,E), 2 encoder-context (B,Ts,2H), 3 decoder-output (Tt,B,E). */

@@ -1,0 +1,101 @@
+"""GPU: the data-parallel step driver on the fused HIP back end -- two processes sharing the one GPU of the test box
+(gloo transport: RCCL refuses two ranks on one device; the driver's code path is the same, only the process-group
+backend differs) against a single-process step on the mean of the two shards' gradients."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT, PKG
+
+pytestmark = pytest.mark.gpu
+
+DIMS = (120, 140, 64, 32, 48, 40)       # Vs, Vt, I, E, H, S
+STEPS = 4
+
+
+def _model(seed):
+    from machine_translation_vision.models import NMT_AttentionImagine_Seq2Seq_Beam_V11
+    Vs, Vt, I, E, H, S = DIMS
+    torch.manual_seed(seed)
+    return NMT_AttentionImagine_Seq2Seq_Beam_V11(Vs, Vt, I, E, E, H, S, 0.99, tied_emb=True).cuda()
+
+
+def _batch(seed, B=6, Ts=9, Tt=7):
+    Vs, Vt, I = DIMS[:3]
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(4, Vs, (B, Ts), generator=g)
+    tgt = torch.randint(4, Vt, (B, Tt), generator=g)
+    tgt[:, -1] = 3
+    return src.cuda(), [Ts] * B, tgt.cuda(), torch.randn(B, I, generator=g).abs().cuda()
+
+
+def _criteria():
+    from machine_translation_vision.losses import PairwiseRankingLoss
+    vw = torch.ones(DIMS[1], device="cuda")
+    vw[0] = 0
+    return torch.nn.NLLLoss(weight=vw, reduction="none"), PairwiseRankingLoss(0.1)
+
+
+def _worker(rank, world, port, q, use_graph):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vagnmt_hip.trainer import TrainStep
+    m = _model(100 + rank)
+    cm, cv = _criteria()
+    ts = TrainStep(m, cm, cv, use_graph=use_graph, world_size=world)
+    losses = []
+    for step in range(STEPS):
+        out = ts.step(*_batch(1000 + 10 * step + rank), teacher=(step % 2 == 0))
+        losses.append(float(out[0]))
+    torch.cuda.synchronize()
+    q.put((rank, ts.fp.flat.cpu().numpy().copy(), losses, dict(ts.stats)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_ranks_on_one_gpu_equal_single_process_mean_gradient(use_graph):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 2000 + (1 if use_graph else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, use_graph)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, flat_a, losses_a, stats_a), (_, flat_b, losses_b, _) = res
+    assert np.array_equal(flat_a, flat_b)
+    assert losses_a != losses_b
+    if use_graph:
+        assert stats_a["captures"] >= 2 and stats_a["replays"] >= 2, stats_a      # both phase graphs of a shape
+    # single process: dropout is on in both runs (train mode) but the model here has p = 0 everywhere
+    from vagnmt_hip.trainer import TrainStep
+    m = _model(100)
+    cm, cv = _criteria()
+    ts = TrainStep(m, cm, cv, use_graph=False)
+    ts.world = 2                                    # 1/world folded into clip+Adam, as on the ranks
+    m.train()
+    for step in range(STEPS):
+        for rank in range(2):
+            src, lens, tgt, im = _batch(1000 + 10 * step + rank)
+            lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+            ts.backend.run(src, lt, tgt, im, step % 2 == 0, 7)          # gradients of both shards accumulate
+            if rank == 0:
+                assert abs(float(ts.backend.outputs()[0]) - losses_a[step]) <= 2e-4 * abs(losses_a[step])
+        ts._optimizer()
+    torch.cuda.synchronize()
+    ref = ts.fp.flat.cpu().numpy()
+    assert np.allclose(flat_a, ref, rtol=2e-4, atol=2e-6), np.abs(flat_a - ref).max()

@@ -187,9 +187,12 @@ def test_device_resident_batch_pipeline():
         assert torch.equal(g[0].cpu(), w[0]) and torch.equal(g[1].cpu(), w[1]) and torch.equal(g[2].cpu(), w[2])
         assert g[3] == w[3] and g[4] == w[4]
         assert g[3] == sorted(g[3], reverse=True) and len(set(g[4])) == 1
-    # data-parallel sharding: ranks see disjoint batches that together cover the epoch
+    # data-parallel sharding: a common seed, disjoint batches, the same number of batches on every rank
     np.random.seed(11)
-    r0 = list(data_generator_tl_mtv(corpus, 16, rank=0, world_size=2))
-    np.random.seed(11)
-    r1 = list(data_generator_tl_mtv(corpus, 16, rank=1, world_size=2))
-    assert len(r0) + len(r1) == len(got) and torch.equal(r0[0][0], got[0][0]) and torch.equal(r1[0][0], got[1][0])
+    state = np.random.get_state()[1].copy()
+    r0 = list(data_generator_tl_mtv(corpus, 16, rank=0, world_size=2, seed=11))
+    r1 = list(data_generator_tl_mtv(corpus, 16, rank=1, world_size=2, seed=11))
+    assert np.array_equal(np.random.get_state()[1], state)          # the global generator is left as it was
+    assert len(r0) == len(r1) == len(got) // 2 and torch.equal(r0[0][0], got[0][0]) and torch.equal(r1[0][0], got[1][0])
+    with pytest.raises(ValueError):
+        list(data_generator_tl_mtv(corpus, 16, rank=0, world_size=2))

@@ -35,9 +35,16 @@ static int gemm_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
     return vag_gemm_launch(M, N, K, 1.f, A, lda, 1, B, ldb, 1, beta, C, ldc, nullptr, VAG_ACT_NONE, s);
 }
 
+// Derived weights (functions of the parameters only: stacked / folded / transposed matrices the recurrences read).
+// The stand-alone operators rebuild them per call inside their workspaces; a step driver that owns the optimiser
+// refreshes them once per optimiser step (vag_derive_weights) and points the operators at that copy for the duration of a
+// call through this thread-local (same pattern as the grouped-GEMM bracket: one host thread drives a stream).
+static thread_local const float* g_derived = nullptr;
+void vag_set_derived_override(const float* d) { g_derived = d; }
+
 extern "C" {
 
-int vag_version(void) { return 100; }
+int vag_version(void) { return 200; }
 
 int vag_gemm_f32(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak, const float* B,
                  int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc, const float* bias, int act,
@@ -70,6 +77,23 @@ int vag_embed_bwd(const int64_t* idx, int64_t n, const float* d_out, int64_t E, 
     return vag_embed_scatter_launch(idx, 1, 0, n, 1, d_out, E, g_W, nullptr, 0, 0.f, S_(stream));
 }
 
+// Layout of the derived-weights buffer: [wcat | bcat | wp] (= CgruPrep), then the transposes the backward recurrences
+// read: wcatT (H, C+3H), whh1T (H, 3H), encT (2 x (H, 3H): forward / reverse encoder W_hh^T).
+struct DerivedW {
+    float *prep, *wcatT, *whh1T, *encT;
+    int64_t total;
+};
+static int64_t cgru_prep_total(int64_t H);
+static DerivedW derived_layout(float* p, int64_t H) {
+    DerivedW w;
+    const int64_t C = 2 * H, Q = C + 3 * H;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { float* q = p ? p + o : nullptr; o += (n + 63) & ~63ll; return q; };
+    w.prep = take(cgru_prep_total(H)); w.wcatT = take(Q * H); w.whh1T = take(3 * H * H); w.encT = take(2 * 3 * H * H);
+    w.total = o;
+    return w;
+}
+
 // =====================================================================================================
 // bi-GRU encoder
 // =====================================================================================================
@@ -80,7 +104,7 @@ struct BiGruWs {
 static BiGruWs bigru_ws(float* ws, int64_t B, int64_t Ts, int64_t E, int64_t H) {
     BiGruWs w;
     int64_t o = 0;
-    auto take = [&](int64_t n) { float* p = ws ? ws + o : nullptr; o += (n + 3) & ~3ll; return p; };
+    auto take = [&](int64_t n) { float* p = ws ? ws + o : nullptr; o += (n + 63) & ~63ll; return p; };
     w.x = take(Ts * B * E);              // embedded (+dropout) input, time-major (Ts,B,E)
     w.xp = take(Ts * B * 6 * H);         // input projections [fwd 3H | rev 3H]; reused as d_xp in backward
     w.hst = take(2 * (Ts + 1) * B * H);  // [dir][step][B][H] hidden states in processing order, step 0 = zeros
@@ -110,8 +134,10 @@ int vag_bigru_seq_fwd(const int64_t* src, const int32_t* lengths, const float* e
     VAG_TRY(vag_gemm_launch(R, 3 * H, E, 1.f, w.x, E, 1, bw.w_ih, 1, E, 0.f, w.xp + 3 * H, 6 * H, bw.b_ih, 0, s));
     VAG_TRY(grp0.end(s));
     const int64_t BH = B * H;
-    VAG_TRY(zero_async(w.hst, BH * sizeof(float), s));
-    VAG_TRY(zero_async(w.hst + (Ts + 1) * BH, BH * sizeof(float), s));
+    {
+        const VagJob zj[2] = {{nullptr, w.hst, B, H, H, H, 0}, {nullptr, w.hst + (Ts + 1) * BH, B, H, H, H, 0}};
+        VAG_TRY(vag_jobs_launch(zj, 2, s));          // initial states of both directions
+    }
     GruStepArgs a = {};
     a.lda = H; a.ldw = H; a.ldother = 6 * H; a.ldh = H; a.ld2 = Ts * 2 * H;
     a.M = (int)B; a.K = (int)H; a.H = (int)H; a.lengths = lengths; a.comp_hidden = 1;
@@ -142,9 +168,14 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
     BiGruWs w = bigru_ws(ws, B, Ts, E, H);
     const int64_t R = Ts * B, BH = B * H;
     float* d_xp = w.xp;      // forward input projections are no longer needed (gates are saved)
-    for (int d = 0; d < 2; ++d) {
-        const vag_gru_w& g = d == 0 ? fw : bw;
-        VAG_TRY(vag_transpose_launch(g.w_hh, 3 * H, H, w.whhT + d * 3 * H * H, s));
+    const float* whhT = w.whhT;
+    if (g_derived) {
+        whhT = derived_layout(const_cast<float*>(g_derived), H).encT;
+    } else {
+        for (int d = 0; d < 2; ++d) {
+            const vag_gru_w& g = d == 0 ? fw : bw;
+            VAG_TRY(vag_transpose_launch(g.w_hh, 3 * H, H, w.whhT + d * 3 * H * H, s));
+        }
     }
     // last processed step: plain elementwise cell backward (no gradient arrives from a later step)
     GruBwdArgs a = {};
@@ -179,7 +210,7 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
             const int64_t t1 = d == 0 ? k1 : Ts - 1 - k1;
             GruBwdStepSide& sd = f.s[d];
             sd.A = w.dgh + (d * Ts + k) * B * 3 * H;
-            sd.WT = w.whhT + d * 3 * H * H;
+            sd.WT = whhT + d * 3 * H * H;
             sd.addend = w.carry + (d * 2 + cur) * BH;
             sd.dh_add = d_enc + t1 * 2 * H + d * H;
             sd.drop_idx0 = t1 * 2 * H + d * H;
@@ -286,12 +317,14 @@ static CgruPrep cgru_prep(float* p, int64_t H) {
     CgruPrep w;
     const int64_t C = 2 * H, Q = C + 3 * H;
     int64_t o = 0;
-    auto take = [&](int64_t n) { float* q = p ? p + o : nullptr; o += (n + 3) & ~3ll; return q; };
+    auto take = [&](int64_t n) { float* q = p ? p + o : nullptr; o += (n + 63) & ~63ll; return q; };
     w.wcat = take(Q * H); w.bcat = take(Q); w.wp = take(3 * H * C);
     w.total = o;
     return w;
 }
 int64_t vag_cgru_prep_floats(int64_t H) { return cgru_prep(nullptr, H).total; }
+static int64_t cgru_prep_total(int64_t H) { return cgru_prep(nullptr, H).total; }
+int64_t vag_derived_floats(int64_t H) { return derived_layout(nullptr, H).total; }
 
 static bool dec_w_ok(const vag_dec_w& w) {
     return w.emb && w.gru1.w_ih && w.gru1.w_hh && w.gru1.b_ih && w.gru1.b_hh && w.attn_h && w.attn_v && w.c2h &&
@@ -310,6 +343,31 @@ int vag_cgru_prepare(vag_dec_w w, int64_t H, float* prep, vag_stream_t stream) {
     return gemm_nn(3 * H, C, H, w.gru2.w_ih, H, w.c2h, C, 0.f, p.wp, C, s);
 }
 
+// Everything the recurrences read that is a function of the parameters alone, refreshed once per optimiser step by a
+// step driver (the stand-alone operators rebuild their share per call): [attn_h; W_hh2] stacked and transposed, the
+// folded W_ih2 W_c2h, W_hh1^T, both encoder W_hh^T.  derived: vag_derived_floats(H) floats.
+int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_whh_bw, int64_t H, float* derived,
+                       vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(dec_w_ok(w) && enc_whh_fw && enc_whh_bw && derived && H > 0 && H % 4 == 0 && aligned16(derived));
+    const int64_t C = 2 * H, Q = C + 3 * H;
+    DerivedW d = derived_layout(derived, H);
+    CgruPrep p = cgru_prep(d.prep, H);
+    const VagJob jobs[9] = {
+        {w.attn_h, p.wcat, C, H, H, H, 1},                                 // wcat = [attn_h ; W_hh2]
+        {w.gru2.w_hh, p.wcat + C * H, 3 * H, H, H, H, 1},
+        {nullptr, p.bcat, 1, C, C, C, 0},                                  // bcat = [0 ; b_hh2]
+        {w.gru2.b_hh, p.bcat + C, 1, 3 * H, 3 * H, 3 * H, 1},
+        {w.attn_h, d.wcatT, C, H, H, Q, 2},                                // wcatT (H, C+3H) = [attn_h^T | W_hh2^T]
+        {w.gru2.w_hh, d.wcatT + C, 3 * H, H, H, Q, 2},
+        {w.gru1.w_hh, d.whh1T, 3 * H, H, H, 3 * H, 2},
+        {enc_whh_fw, d.encT, 3 * H, H, H, 3 * H, 2},
+        {enc_whh_bw, d.encT + 3 * H * H, 3 * H, H, H, 3 * H, 2},
+    };
+    VAG_TRY(vag_jobs_launch(jobs, 9, s));
+    return gemm_nn(3 * H, C, H, w.gru2.w_ih, H, w.c2h, C, 0.f, p.wp, C, s);      // Wp = W_ih2 W_c2h
+}
+
 struct CgruWs {
     float *xp1, *h1, *g1, *g2, *qhp, *scores, *alpha, *tmp, *prep, *encwp;
     int64_t total;
@@ -318,7 +376,7 @@ static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, i
     CgruWs w;
     const int64_t C = 2 * H;
     int64_t o = 0;
-    auto take = [&](int64_t n) { float* p = ws ? ws + o : nullptr; o += (n + 3) & ~3ll; return p; };
+    auto take = [&](int64_t n) { float* p = ws ? ws + o : nullptr; o += (n + 63) & ~63ll; return p; };
     w.xp1 = take(Tt * B * 3 * H);
     w.h1 = take(Tt * B * H);
     w.g1 = take(Tt * 4 * B * H);
@@ -334,6 +392,14 @@ static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, i
 }
 int64_t vag_cgru_ws_floats(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
     return cgru_ws(nullptr, B, Ts, Tt, E, H).total;
+}
+// float offset of a saved per-step tensor inside the workspace (parity tests read them): 0 = alpha (Tt,B,Ts),
+// 1 = h1 (Tt,B,H), 2 = [q | W_hh2 h1 + b] (Tt,B,C+3H)
+int64_t vag_cgru_ws_offset(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, int which) {
+    static float base[1];
+    CgruWs k = cgru_ws(base, B, Ts, Tt, E, H);
+    const float* p = which == 0 ? k.alpha : which == 1 ? k.h1 : which == 2 ? k.qhp : nullptr;
+    return p ? (int64_t)(p - base) : -1;
 }
 
 struct StepBufs {   // per-step buffers of one decoder step (training: slices of the sequence arrays)
@@ -387,7 +453,8 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
     const int64_t C = 2 * H, Q = C + 3 * H, BH = B * H;
     CgruWs k = cgru_ws(ws, B, Ts, Tt, E, H);
     CgruPrep p = cgru_prep(k.prep, H);
-    VAG_TRY(vag_cgru_prepare(w, H, k.prep, stream));
+    if (g_derived) p = cgru_prep(derived_layout(const_cast<float*>(g_derived), H).prep, H);
+    else VAG_TRY(vag_cgru_prepare(w, H, k.prep, stream));
     // Teacher forcing runs the step with the context projection hoisted (4 launches, see attn_ctx_gru_kernel): the cell
     // only needs sum_s alpha_s (W_ih2 W_c2h enc_s), the contexts themselves are formed for all steps after the loop.
     // Free running needs each context at once for the head, so it keeps the 5-launch step; backward is common to both
@@ -460,7 +527,7 @@ static CgruBwdScratch cgru_bwd_scratch(float* p, int64_t B, int64_t Ts, int64_t 
     CgruBwdScratch w;
     const int64_t C = 2 * H, Q = C + 3 * H, R = Tt * B;
     int64_t o = 0;
-    auto take = [&](int64_t n) { float* q = p ? p + o : nullptr; o += (n + 3) & ~3ll; return q; };
+    auto take = [&](int64_t n) { float* q = p ? p + o : nullptr; o += (n + 63) & ~63ll; return q; };
     w.wcatT = take(Q * H); w.wpT = take(3 * H * C); w.whh1T = take(3 * H * H);
     w.dgi2 = take(R * 3 * H); w.dqgh = take(R * Q);
     w.dalpha = take(B * Ts); w.ds = take(R * Ts);
@@ -491,9 +558,15 @@ int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const f
     CgruWs k = cgru_ws(ws, B, Ts, Tt, E, H);
     CgruPrep p = cgru_prep(k.prep, H);          // Wcat / Wp from the forward call are still in the workspace
     CgruBwdScratch z = cgru_bwd_scratch(scratch, B, Ts, Tt, E, H);
-    // per-step products are written as x W^T, so transpose the (derived) weights once per call
-    VAG_TRY(vag_transpose_launch(p.wcat, Q, H, z.wcatT, s));            // (H, C+3H) = [attn_h^T | W_hh2^T]
-    VAG_TRY(vag_transpose_launch(w.gru1.w_hh, 3 * H, H, z.whh1T, s));   // (H, 3H)
+    if (g_derived) {
+        DerivedW dw = derived_layout(const_cast<float*>(g_derived), H);
+        p = cgru_prep(dw.prep, H);
+        z.wcatT = dw.wcatT; z.whh1T = dw.whh1T;
+    } else {
+        // per-step products are written as x W^T, so transpose the (derived) weights once per call
+        VAG_TRY(vag_transpose_launch(p.wcat, Q, H, z.wcatT, s));            // (H, C+3H) = [attn_h^T | W_hh2^T]
+        VAG_TRY(vag_transpose_launch(w.gru1.w_hh, 3 * H, H, z.whh1T, s));   // (H, 3H)
+    }
     // gru_2 cell backward of the last step: nothing arrives from a later step
     {
         GruBwdArgs a = {};
@@ -653,8 +726,20 @@ int vag_head_ce_seq_fwd(const float* h2_all, const float* c_all, const float* e_
                         const float* vocab_weight, int64_t B, int64_t Tt, int64_t E, int64_t H, int64_t V, float p_out,
                         const uint64_t* rng, int logits_ready, float* tmid, float* logits, int64_t ldl, float* lse,
                         float* nll, float* inv_cnt, float* loss_mt, vag_stream_t stream) {
-    hipStream_t s = S_(stream);
-    VAG_CHECK_ARG(h2_all && c_all && e_all && tgt && vocab_weight && tmid && logits && lse && nll && inv_cnt && loss_mt);
+    VAG_CHECK_ARG(loss_mt != nullptr);
+    return vag_head_ce_seq_fwd_impl(h2_all, c_all, e_all, w, tgt, vocab_weight, B, Tt, E, H, V, p_out, rng, logits_ready, tmid,
+                                    logits, ldl, lse, nll, inv_cnt, 0, loss_mt, nullptr, 0.f, 0.f, 0, S_(stream));
+}
+}  // extern "C"
+// inv_cnt_ready: the caller has filled inv_cnt already (step prologue).  losses != NULL: losses[1] = loss_mt and the
+// weighted total losses[0] are written instead of loss_mt (one launch for both, V11.py:164-166).
+int vag_head_ce_seq_fwd_impl(const float* h2_all, const float* c_all, const float* e_all, vag_head_w w, const int64_t* tgt,
+                             const float* vocab_weight, int64_t B, int64_t Tt, int64_t E, int64_t H, int64_t V, float p_out,
+                             const uint64_t* rng, int logits_ready, float* tmid, float* logits, int64_t ldl, float* lse,
+                             float* nll, float* inv_cnt, int inv_cnt_ready, float* loss_mt, float* losses, float w_mt,
+                             float w_vse, int has_vse, hipStream_t s) {
+    VAG_CHECK_ARG(h2_all && c_all && e_all && tgt && vocab_weight && tmid && logits && lse && nll && inv_cnt &&
+                  (loss_mt || losses));
     VAG_CHECK_ARG(w.w1 && w.b1 && w.w2 && w.b2 && w.w3 && w.b3 && w.out_w && w.out_b);
     VAG_CHECK_ARG(B > 0 && Tt > 0 && E % 4 == 0 && H % 4 == 0 && V > 0 && ldl >= V && ldl % 4 == 0);
     const int64_t R = Tt * B;
@@ -662,11 +747,12 @@ int vag_head_ce_seq_fwd(const float* h2_all, const float* c_all, const float* e_
         VAG_TRY(head_pre_seq(h2_all, c_all, e_all, w, R, E, H, p_out, rng, tmid, s));
         VAG_TRY(vag_gemm_launch(R, V, E, 1.f, tmid, E, 1, w.out_w, 1, E, 0.f, logits, ldl, w.out_b, 0, s));
     }
-    VAG_TRY(vag_inv_cnt_launch(tgt, B, Tt, inv_cnt, s));
+    if (!inv_cnt_ready) VAG_TRY(vag_inv_cnt_launch(tgt, B, Tt, inv_cnt, s));
     VAG_TRY(vag_lse_nll_launch(logits, ldl, R, V, tgt, B, Tt, vocab_weight, lse, nll, nullptr, 0, nullptr, 0, s));
-    VAG_TRY(vag_loss_mt_launch(nll, inv_cnt, B, Tt, loss_mt, s));
-    return VAG_OK;
+    if (losses) return vag_loss_mt_mix_launch(nll, inv_cnt, B, Tt, losses, w_mt, w_vse, has_vse, s);
+    return vag_loss_mt_launch(nll, inv_cnt, B, Tt, loss_mt, s);
 }
+extern "C" {
 
 // d(logits) -> d(tmid) -> through dropout+tanh -> input gradients.  dt (R,E) is left holding d(pre-activation).
 static int head_bwd_data(const vag_head_w& w, int64_t R, int64_t E, int64_t H, int64_t V, float p_out, const uint64_t* rng,
@@ -810,7 +896,7 @@ struct ImgWs {
 static ImgWs imagine_ws(float* p, int64_t B, int64_t Ts, int64_t C, int method) {
     ImgWs w;
     int64_t o = 0;
-    auto take = [&](int64_t n) { float* q = p ? p + o : nullptr; o += (n + 3) & ~3ll; return q; };
+    auto take = [&](int64_t n) { float* q = p ? p + o : nullptr; o += (n + 63) & ~63ll; return q; };
     w.u = take(B * C); w.w = take(B * C); w.scores = take(B * Ts); w.dalpha = take(B * Ts); w.de = take(B * Ts);
     w.dw = take(B * C); w.du = take(B * C); w.dvp = take(VAG_POST_CHUNKS(Ts) * B * C);
     w.pre = method == 1 ? take(B * Ts * C) : nullptr;
@@ -846,7 +932,15 @@ int vag_imagine_attn_ctx_bwd(const float* im_emb, const float* enc, const float*
                              const float* emb2ctx, const float* mlp_w, int method, int64_t B, int64_t Ts, int64_t C,
                              int64_t S, const float* alpha, const float* d_ctx, float* ws, float* d_enc, int accumulate_enc,
                              float* d_im_emb, float* g_ctx2ctx, float* g_emb2ctx, float* g_mlp_w, vag_stream_t stream) {
-    hipStream_t s = S_(stream);
+    return vag_imagine_attn_ctx_bwd_impl(im_emb, enc, mask, ctx2ctx, emb2ctx, mlp_w, method, B, Ts, C, S, alpha, d_ctx, ws,
+                                         d_enc, accumulate_enc, d_im_emb, 0, g_ctx2ctx, g_emb2ctx, g_mlp_w, S_(stream));
+}
+}  // extern "C"
+int vag_imagine_attn_ctx_bwd_impl(const float* im_emb, const float* enc, const float* mask, const float* ctx2ctx,
+                                  const float* emb2ctx, const float* mlp_w, int method, int64_t B, int64_t Ts, int64_t C,
+                                  int64_t S, const float* alpha, const float* d_ctx, float* ws, float* d_enc,
+                                  int accumulate_enc, float* d_im_emb, int accumulate_im, float* g_ctx2ctx,
+                                  float* g_emb2ctx, float* g_mlp_w, hipStream_t s) {
     VAG_CHECK_ARG(im_emb && enc && ctx2ctx && emb2ctx && alpha && d_ctx && ws && d_enc && d_im_emb && g_ctx2ctx && g_emb2ctx);
     VAG_CHECK_ARG((method == 0) || (method == 1 && mlp_w && g_mlp_w));
     VAG_CHECK_ARG(B > 0 && Ts > 0 && C % 4 == 0 && S % 4 == 0);
@@ -867,10 +961,11 @@ int vag_imagine_attn_ctx_bwd(const float* im_emb, const float* enc, const float*
         VAG_TRY(gemm_nn(B * Ts, C, C, w.dpre, C, ctx2ctx, C, 1.f, d_enc, C, s));
         VAG_TRY(gemm_tn_acc(C, C, B * Ts, w.dpre, C, enc, C, g_ctx2ctx, C, s));
     }
-    VAG_TRY(gemm_nn(B, S, C, w.du, C, emb2ctx, S, 0.f, d_im_emb, S, s));
+    VAG_TRY(gemm_nn(B, S, C, w.du, C, emb2ctx, S, accumulate_im ? 1.f : 0.f, d_im_emb, S, s));
     VAG_TRY(gemm_tn_acc(C, S, B, w.du, C, im_emb, S, g_emb2ctx, S, s));
     return VAG_OK;
 }
+extern "C" {
 
 // =====================================================================================================
 // ranking loss
@@ -922,7 +1017,13 @@ int vag_dec_init_fwd(const float* enc, const float* mask, const float* ctx, floa
 int vag_dec_init_bwd(const float* mask, const float* xmix, const float* h0, float split, const float* W, float* d_h0,
                      int64_t B, int64_t Ts, int64_t C, int64_t H, float* d_enc, int accumulate_enc, float* d_ctx, float* g_W,
                      float* g_b, float* scratch, vag_stream_t stream) {
-    hipStream_t s = S_(stream);
+    return vag_dec_init_bwd_impl(mask, xmix, h0, split, W, d_h0, B, Ts, C, H, d_enc, accumulate_enc, d_ctx, 0, g_W, g_b,
+                                 scratch, S_(stream));
+}
+}  // extern "C"
+int vag_dec_init_bwd_impl(const float* mask, const float* xmix, const float* h0, float split, const float* W, float* d_h0,
+                          int64_t B, int64_t Ts, int64_t C, int64_t H, float* d_enc, int accumulate_enc, float* d_ctx,
+                          int accumulate_ctx, float* g_W, float* g_b, float* scratch, hipStream_t s) {
     VAG_CHECK_ARG(mask && xmix && h0 && W && d_h0 && d_enc && g_W && g_b && scratch && B > 0 && Ts > 0 && C % 4 == 0);
     float* dx = scratch;    // (B,C)
     VAG_TRY(vag_tanh_bwd_launch(h0, d_h0, d_h0, B * H, nullptr, 0, 0.f, s));
@@ -931,9 +1032,10 @@ int vag_dec_init_bwd(const float* mask, const float* xmix, const float* h0, floa
     VAG_TRY(gemm_nn(B, C, H, d_h0, H, W, C, 0.f, dx, C, s));
     const float s_eff = d_ctx ? split : 0.f;
     VAG_TRY(vag_meanpool_bwd_launch(mask, dx, 1.f - s_eff, B, Ts, C, d_enc, accumulate_enc, s));
-    if (d_ctx) VAG_TRY(vag_axpy_launch(split, dx, d_ctx, B * C, 0, s));
+    if (d_ctx) VAG_TRY(vag_axpy_launch(split, dx, d_ctx, B * C, accumulate_ctx ? 1 : 0, s));
     return VAG_OK;
 }
+extern "C" {
 
 // =====================================================================================================
 // beam search, optimiser, dropout helpers
@@ -960,11 +1062,15 @@ int vag_beam_finish(const float* nll, const int64_t* beam, int64_t max_len, int6
     return vag_beam_finish_launch(nll, beam, max_len, steps, B, k, out, best_score, S_(stream));
 }
 
-int vag_clip_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
+int vag_clip_adam_flat(float* p, float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
                        const float* seg_lr, const float* seg_wd, float clip, float grad_scale, float beta1, float beta2,
-                       float eps, int32_t* step, float* norm_out, void* scratch, vag_stream_t stream) {
-    return vag_clip_adam_launch(p, g, m, v, n, nseg, seg_off, seg_lr, seg_wd, clip, grad_scale, beta1, beta2, eps, step,
-                                norm_out, scratch, S_(stream));
+                       float eps, int zero_grad, int32_t* step, float* norm_out, void* scratch, vag_stream_t stream) {
+    return vag_clip_adam_launch(p, g, m, v, n, nseg, seg_off, seg_lr, seg_wd, clip, grad_scale, beta1, beta2, eps, zero_grad,
+                                step, norm_out, scratch, S_(stream));
+}
+
+int vag_copy4(const void* const* src, void* const* dst, const int64_t* bytes, int n, vag_stream_t stream) {
+    return vag_copy4_launch(src, dst, bytes, n, S_(stream));
 }
 
 int vag_dropout_mask(const uint64_t* rng, int which, int64_t n, float p, float* out, vag_stream_t stream) {

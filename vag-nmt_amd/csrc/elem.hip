@@ -296,3 +296,93 @@ int vag_gather_rows_i64_launch(const int64_t* in, int64_t ld, const int64_t* idx
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
+
+
+// ------------------------------------------------------------------ several small fills / copies / transposes, one launch
+// Each job covers a (rows x cols) fp32 matrix: kind 0 zero-fill, 1 copy, 2 transpose (dst[c*ld_dst + r] = src[r*ld_src + c]).
+// A block handles one 32x32 tile of one job.  Used for the per-optimiser-step derived weights and the zero rows of the
+// recurrent state buffers: a handful of tiny dependent-free operations that would otherwise be a launch each.
+__global__ __launch_bounds__(256) void jobs_kernel(VagJobs J) {
+    __shared__ float tile[32][33];
+    int k = 0;
+    while (k + 1 < J.n && (int)blockIdx.x >= J.start[k + 1]) ++k;
+    const VagJob& j = J.j[k];
+    const int id = blockIdx.x - J.start[k];
+    const int tc = (int)((j.cols + 31) / 32);
+    const int64_t r0 = (int64_t)(id / tc) * 32, c0 = (int64_t)(id % tc) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    if (j.kind != 2) {
+#pragma unroll
+        for (int i = 0; i < 32; i += 8) {
+            const int64_t r = r0 + ty + i, c = c0 + tx;
+            if (r < j.rows && c < j.cols) j.dst[r * j.ld_dst + c] = j.kind == 0 ? 0.f : j.src[r * j.ld_src + c];
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int64_t r = r0 + ty + i, c = c0 + tx;
+        if (r < j.rows && c < j.cols) tile[ty + i][tx] = j.src[r * j.ld_src + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int64_t c = c0 + ty + i, r = r0 + tx;
+        if (r < j.rows && c < j.cols) j.dst[c * j.ld_dst + r] = tile[tx][ty + i];
+    }
+}
+int vag_jobs_launch(const VagJob* jobs, int n, hipStream_t s) {
+    VAG_CHECK_ARG(jobs && n >= 1 && n <= VAG_MAXJOBS);
+    VagJobs J;
+    J.n = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        VAG_CHECK_ARG(jobs[i].dst && (jobs[i].kind == 0 || jobs[i].src) && jobs[i].rows >= 0 && jobs[i].cols >= 0);
+        J.j[i] = jobs[i];
+        J.start[i] = total;
+        total += (int)(cdiv64(jobs[i].rows, 32) * cdiv64(jobs[i].cols, 32));
+    }
+    J.start[n] = total;
+    if (total == 0) return VAG_OK;
+    hipLaunchKernelGGL(jobs_kernel, dim3((unsigned)total), dim3(256), 0, s, J);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+
+// ------------------------------------------------------------------ up to four contiguous byte ranges, one launch
+// (a batch's src / lengths / tgt / image rows into the step driver's static buffers: one launch instead of four copies)
+struct Copy4 { const unsigned char* s[4]; unsigned char* d[4]; int64_t n[4]; };
+__global__ __launch_bounds__(256) void copy4_kernel(Copy4 c) {
+    const int k = blockIdx.y;
+    const int64_t n = c.n[k];
+    const unsigned char* s = c.s[k];
+    unsigned char* d = c.d[k];
+    if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
+        const int64_t n16 = n >> 4;
+        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256)
+            reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+        for (int64_t i = (n16 << 4) + blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+    } else {
+        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+    }
+}
+int vag_copy4_launch(const void* const* src, void* const* dst, const int64_t* bytes, int n, hipStream_t s) {
+    VAG_CHECK_ARG(src && dst && bytes && n >= 1 && n <= 4);
+    Copy4 c;
+    int64_t mx = 0;
+    for (int i = 0; i < 4; ++i) {
+        c.s[i] = i < n ? reinterpret_cast<const unsigned char*>(src[i]) : nullptr;
+        c.d[i] = i < n ? reinterpret_cast<unsigned char*>(dst[i]) : nullptr;
+        c.n[i] = i < n ? bytes[i] : 0;
+        VAG_CHECK_ARG(c.n[i] >= 0 && (c.n[i] == 0 || (c.s[i] && c.d[i])));
+        if (c.n[i] > mx) mx = c.n[i];
+    }
+    if (mx == 0) return VAG_OK;
+    int64_t nb = cdiv64(mx, 256 * 16);
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(copy4_kernel, dim3((unsigned)nb, (unsigned)n), dim3(256), 0, s, c);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}

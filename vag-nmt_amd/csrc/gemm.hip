@@ -523,8 +523,7 @@ int vag_gemm_group_end(hipStream_t stream) {
 int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
                     const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc,
                     const float* bias, int act, hipStream_t stream) {
-    // mode switches read once per process (VAG_GEMM_FORCE / VAG_GEMM_DEBUG below stay dynamic: the tuning tools flip them)
-    static const bool opt_f32mfma = getenv("VAG_GEMM_F32MFMA") != nullptr;
+    const bool opt_f32mfma = getenv("VAG_GEMM_F32MFMA") != nullptr;      // read per call: the parity tests flip it
     static const bool opt_nogroup = getenv("VAG_GEMM_NOGROUP") != nullptr;
     VAG_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && A && B && C);
     if (M == 0 || N == 0) return VAG_OK;

@@ -130,22 +130,43 @@ int vag_inv_cnt_launch(const int64_t* tgt, int64_t B, int64_t Tt, float* inv_cnt
     return VAG_OK;
 }
 
-// loss = (1/B) sum_b inv_cnt[b] sum_t nll[t,b]    (single block; fixed summation order -> deterministic)
+// loss = (1/B) sum_b inv_cnt[b] sum_t nll[t,b]    (single block; fixed summation order -> deterministic).
+// Thread (g, b) = (tid / 64, tid % 64) walks t = g, g+4, ... of sentences b, b+64, ...; partial sums meet in LDS.
+// losses != NULL: also the weighted total of V11.py:166 (losses = {loss, loss_mt, loss_vse}).
 __global__ __launch_bounds__(256) void loss_mt_kernel(const float* __restrict__ nll, const float* __restrict__ inv_cnt,
-                                                      int B, int Tt, float* __restrict__ loss) {
+                                                      int B, int Tt, float* __restrict__ loss, float* __restrict__ losses,
+                                                      float w_mt, float w_vse, int has_vse) {
     __shared__ float sh[4];
+    const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float acc = 0.f;
-    for (int b = threadIdx.x; b < B; b += 256) {
+    for (int b = lane; b < B; b += 64) {
         float L = 0.f;
-        for (int t = 0; t < Tt; ++t) L += nll[(int64_t)t * B + b];
+        for (int t = g; t < Tt; t += 4) L += nll[(int64_t)t * B + b];
         acc += L * inv_cnt[b];
     }
     acc = block_reduce_sum(acc, sh);
-    if (threadIdx.x == 0) loss[0] = acc / (float)B;
+    if (threadIdx.x == 0) {
+        const float mt = acc / (float)B;
+        if (loss) loss[0] = mt;
+        if (losses) {
+            losses[1] = mt;
+            if (!has_vse) losses[2] = 0.f;
+            losses[0] = w_mt * mt + (has_vse ? w_vse * losses[2] : 0.f);
+        }
+    }
 }
 int vag_loss_mt_launch(const float* nll, const float* inv_cnt, int64_t B, int64_t Tt, float* loss, hipStream_t s) {
     VAG_CHECK_ARG(nll && inv_cnt && loss && B > 0 && Tt > 0);
-    hipLaunchKernelGGL(loss_mt_kernel, dim3(1), dim3(256), 0, s, nll, inv_cnt, (int)B, (int)Tt, loss);
+    hipLaunchKernelGGL(loss_mt_kernel, dim3(1), dim3(256), 0, s, nll, inv_cnt, (int)B, (int)Tt, loss, (float*)nullptr, 0.f,
+                       0.f, 0);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+int vag_loss_mt_mix_launch(const float* nll, const float* inv_cnt, int64_t B, int64_t Tt, float* losses, float w_mt,
+                           float w_vse, int has_vse, hipStream_t s) {
+    VAG_CHECK_ARG(nll && inv_cnt && losses && B > 0 && Tt > 0);
+    hipLaunchKernelGGL(loss_mt_kernel, dim3(1), dim3(256), 0, s, nll, inv_cnt, (int)B, (int)Tt, (float*)nullptr, losses, w_mt,
+                       w_vse, has_vse);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

@@ -1,6 +1,7 @@
 // Internal launcher prototypes (one per kernel family).  Not part of the C ABI.
 #pragma once
 #include "common.h"
+#include "../../include/vag_nmt.h"
 
 // ---------------- elem.hip ----------------
 // out[(t*B+b), :] = W[idx[b*isb + t*ist], :] * dropout
@@ -55,6 +56,14 @@ int vag_copy2d_launch(const float* in, int64_t ldi, float* out, int64_t ldo, int
 int vag_gather_rows_i64_launch(const int64_t* in, int64_t ld, const int64_t* idx, int64_t rows, int64_t w, int64_t* out,
                                hipStream_t s);
 
+// several small fills (kind 0) / copies (1) / transposes (2) of (rows x cols) fp32 matrices in one launch
+struct VagJob { const float* src; float* dst; int64_t rows, cols, ld_src, ld_dst; int kind; };
+constexpr int VAG_MAXJOBS = 12;
+struct VagJobs { VagJob j[VAG_MAXJOBS]; int start[VAG_MAXJOBS + 1]; int n; };
+int vag_jobs_launch(const VagJob* jobs, int n, hipStream_t s);
+
+int vag_copy4_launch(const void* const* src, void* const* dst, const int64_t* bytes, int n, hipStream_t s);
+
 // ---------------- attn.hip ----------------
 #ifndef VAG_POST_SC
 #define VAG_POST_SC 8          // source positions per attn_post_bwd block
@@ -102,6 +111,9 @@ int vag_lse_nll_launch(const float* logits, int64_t ldl, int64_t rows, int64_t V
                        float* logp_out, int64_t ldlp, hipStream_t s);
 int vag_inv_cnt_launch(const int64_t* tgt, int64_t B, int64_t Tt, float* inv_cnt, hipStream_t s);
 int vag_loss_mt_launch(const float* nll, const float* inv_cnt, int64_t B, int64_t Tt, float* loss, hipStream_t s);
+// the same, writing losses[1] = loss_mt and the mixed total losses[0] = w_mt*loss_mt + w_vse*losses[2] (V11.py:166)
+int vag_loss_mt_mix_launch(const float* nll, const float* inv_cnt, int64_t B, int64_t Tt, float* losses, float w_mt,
+                           float w_vse, int has_vse, hipStream_t s);
 // in place: logits[r,j] = d_loss * inv_cnt[b]/B * w[tgt] * (softmax_j - [j==tgt]); pad columns [V,ldl) = 0
 int vag_ce_bwd_launch(float* logits, int64_t ldl, int64_t rows, int64_t V, const int64_t* tgt, int64_t B, int64_t Tt,
                       const float* vw, const float* lse, const float* inv_cnt, const float* d_loss, hipStream_t s);
@@ -123,9 +135,10 @@ int vag_retrieval_rank_launch(const float* scores, int64_t N, int* ranks, hipStr
 int vag_scale_by_dev_launch(float* x, int64_t n, const float* scalar, hipStream_t s);
 
 // ---------------- optim.hip ----------------
-int vag_clip_adam_launch(float* p, const float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
+int vag_clip_adam_launch(float* p, float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
                          const float* seg_lr, const float* seg_wd, float clip, float grad_scale, float beta1,
-                         float beta2, float eps, int32_t* step, float* norm_out, void* scratch, hipStream_t s);
+                         float beta2, float eps, int zero_grad, int32_t* step, float* norm_out, void* scratch,
+                         hipStream_t s);
 
 // ---------------- beam.hip ----------------
 int64_t vag_beam_scratch_bytes_impl(int64_t B, int64_t k, int64_t V);
@@ -134,3 +147,19 @@ int vag_beam_step_launch(float* logp, int64_t ldl, float* nll, int64_t* beam, in
                          int64_t V, int64_t H, int32_t* n_alive, void* scratch, hipStream_t s);
 int vag_beam_finish_launch(const float* nll, const int64_t* beam, int64_t max_len, int64_t steps, int64_t B, int64_t k,
                            int64_t* out, float* best, hipStream_t s);
+
+// ---------------- api.hip internals shared with step.hip ----------------
+void vag_set_derived_override(const float* d);
+int vag_dec_init_bwd_impl(const float* mask, const float* xmix, const float* h0, float split, const float* W, float* d_h0,
+                          int64_t B, int64_t Ts, int64_t C, int64_t H, float* d_enc, int accumulate_enc, float* d_ctx,
+                          int accumulate_ctx, float* g_W, float* g_b, float* scratch, hipStream_t s);
+int vag_imagine_attn_ctx_bwd_impl(const float* im_emb, const float* enc, const float* mask, const float* ctx2ctx,
+                                  const float* emb2ctx, const float* mlp_w, int method, int64_t B, int64_t Ts, int64_t C,
+                                  int64_t S, const float* alpha, const float* d_ctx, float* ws, float* d_enc,
+                                  int accumulate_enc, float* d_im_emb, int accumulate_im, float* g_ctx2ctx,
+                                  float* g_emb2ctx, float* g_mlp_w, hipStream_t s);
+int vag_head_ce_seq_fwd_impl(const float* h2_all, const float* c_all, const float* e_all, vag_head_w w, const int64_t* tgt,
+                             const float* vocab_weight, int64_t B, int64_t Tt, int64_t E, int64_t H, int64_t V, float p_out,
+                             const uint64_t* rng, int logits_ready, float* tmid, float* logits, int64_t ldl, float* lse,
+                             float* nll, float* inv_cnt, int inv_cnt_ready, float* loss_mt, float* losses, float w_mt,
+                             float w_vse, int has_vse, hipStream_t s);

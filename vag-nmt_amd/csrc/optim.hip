@@ -1,23 +1,29 @@
 // Fused global-norm clip + Adam over one flat fp32 parameter buffer (train.py:46-49).
-// Three launches: sum of squares (per-block partials -> one double atomic), scalar prep (norm, clip coefficient,
-// bias corrections in double, step counter), and the streaming update (7 x 4 B per parameter).
+// Two launches: sum of squares (per-block partials; the last block to finish does the scalar work: norm, clip
+// coefficient, bias corrections in double, step counter) and the streaming update (7 x 4 B per parameter).
 #include "kernels.h"
 
 constexpr int SUMSQ_SLOTS = 128;
-struct AdamScalars {          // lives in the caller's scratch (VAG_ADAM_SCRATCH_BYTES)
+struct AdamScalars {          // lives in the caller's scratch (VAG_ADAM_SCRATCH_BYTES); zero before the first call
     double sumsq;
     float coef;               // grad_scale * min(1, clip / (norm + 1e-6))
     float bc1;                // 1 - beta1^t
     float bc2_sqrt;           // sqrt(1 - beta2^t)
-    float pad;
+    unsigned ticket;          // blocks of the norm pass that have delivered their partial sum
     // the blocks' partial sums land in 128 slots (2048 double atomics on ONE address serialise in L2: ~25 of the
-    // pass's 31 us); adam_prep_kernel adds the slots up
+    // pass's 31 us); the last block to arrive adds the slots up in a fixed order
     double part[SUMSQ_SLOTS];
 };
 static_assert(sizeof(AdamScalars) <= 2048, "vag_clip_adam_flat scratch contract");
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, AdamScalars* sc) {
+// Pass 1: sum of squares of the gradient.  The block whose ticket is the last one also does the scalar work (norm, clip
+// coefficient, bias corrections in double, step counter) and leaves the slots and the ticket zeroed for the next call,
+// so the optimiser step is two launches.
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, AdamScalars* sc, float clip,
+                                                    float grad_scale, float beta1, float beta2, int32_t* step,
+                                                    float* norm_out) {
     __shared__ double sh[4];
+    __shared__ unsigned last;
     double acc = 0.0;
     const int64_t n4 = n >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -44,19 +50,20 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&sc->part[blockIdx.x % SUMSQ_SLOTS], sh[0] + sh[1] + sh[2] + sh[3]);
-}
-
-__global__ void adam_zero_kernel(AdamScalars* sc) {
-    if (threadIdx.x == 0) { sc->sumsq = 0.0; sc->coef = 0.f; sc->bc1 = 1.f; sc->bc2_sqrt = 1.f; sc->pad = 0.f; }
-    for (int i = threadIdx.x; i < SUMSQ_SLOTS; i += blockDim.x) sc->part[i] = 0.0;
-}
-
-__global__ void adam_prep_kernel(AdamScalars* sc, float clip, float grad_scale, float beta1, float beta2,
-                                 int32_t* step, float* norm_out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x == 0) {
+        atomicAdd(&sc->part[blockIdx.x % SUMSQ_SLOTS], sh[0] + sh[1] + sh[2] + sh[3]);    // device-scope, memory side
+        __threadfence();
+        last = (atomicAdd(&sc->ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last || threadIdx.x != 0) return;
+    __threadfence();
     double ss = 0.0;
-    for (int i = 0; i < SUMSQ_SLOTS; ++i) ss += sc->part[i];       // fixed order
+    for (int k = 0; k < SUMSQ_SLOTS; ++k) {                        // fixed order
+        ss += __hip_atomic_load(&sc->part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sc->part[k] = 0.0;
+    }
+    sc->ticket = 0u;
     sc->sumsq = ss;
     const double norm = sqrt(ss) * (double)grad_scale;             // norm of the scaled (averaged) gradient
     double c = (double)clip / (norm + 1e-6);                        // torch.nn.utils.clip_grad_norm_
@@ -70,10 +77,19 @@ __global__ void adam_prep_kernel(AdamScalars* sc, float clip, float grad_scale, 
     if (norm_out) norm_out[0] = (float)norm;
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, int64_t off,
-                                                   int64_t cnt, float lr, float wd, float beta1, float beta2, float eps,
-                                                   const AdamScalars* __restrict__ sc) {
+constexpr int ADAM_MAX_SEG = 16;
+struct AdamSegs {
+    int64_t off[ADAM_MAX_SEG], cnt[ADAM_MAX_SEG];
+    float lr[ADAM_MAX_SEG], wd[ADAM_MAX_SEG];
+};
+// Pass 2: the streaming update, every segment (param group) in one grid (blockIdx.y = segment).  zero_grad: the gradient
+// buffer is left zeroed for the next step's accumulation (saves the separate 4 B/param fill pass).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, AdamSegs sg, float beta1, float beta2, float eps,
+                                                   int zero_grad, const AdamScalars* __restrict__ sc) {
+    const int seg = blockIdx.y;
+    const int64_t off = sg.off[seg], cnt = sg.cnt[seg];
+    const float lr = sg.lr[seg], wd = sg.wd[seg];
     const float coef = sc->coef;
     const float step_size = lr / sc->bc1;
     const float inv_bc2s = 1.f / sc->bc2_sqrt;
@@ -86,34 +102,41 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         const float vk = beta2 * v[k] + (1.f - beta2) * gk * gk;
         m[k] = mk;
         v[k] = vk;
+        if (zero_grad) g[k] = 0.f;
         const float denom = sqrtf(vk) * inv_bc2s + eps;
         p[k] = pk - step_size * (mk / denom);
     }
 }
 
-int vag_clip_adam_launch(float* p, const float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
+int vag_clip_adam_launch(float* p, float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
                          const float* seg_lr, const float* seg_wd, float clip, float grad_scale, float beta1,
-                         float beta2, float eps, int32_t* step, float* norm_out, void* scratch, hipStream_t s) {
-    VAG_CHECK_ARG(p && g && m && v && n > 0 && nseg >= 1 && nseg <= 16 && seg_off && seg_lr && seg_wd && step && scratch);
+                         float beta2, float eps, int zero_grad, int32_t* step, float* norm_out, void* scratch,
+                         hipStream_t s) {
+    VAG_CHECK_ARG(p && g && m && v && n > 0 && nseg >= 1 && nseg <= ADAM_MAX_SEG && seg_off && seg_lr && seg_wd && step &&
+                  scratch);
     VAG_CHECK_ARG(aligned16(g) && seg_off[0] == 0 && seg_off[nseg] == n);
     AdamScalars* sc = reinterpret_cast<AdamScalars*>(scratch);
-    hipLaunchKernelGGL(adam_zero_kernel, dim3(1), dim3(64), 0, s, sc);
+    // few enough blocks that the arrival tickets (one address) do not serialise the pass: 512 x 256 threads x 4 loads of
+    // 16 B in flight = 8 MB outstanding
+    int64_t blocks = cdiv64(n / 4 + 1, 256 * 4);
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, n, sc, clip, grad_scale, beta1, beta2, step,
+                       norm_out);
     VAG_LAUNCH_CHECK();
-    int64_t blocks = cdiv64(n / 4 + 1, 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, n, sc);
-    VAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, sc, clip, grad_scale, beta1, beta2, step, norm_out);
-    VAG_LAUNCH_CHECK();
+    AdamSegs sg;
+    int64_t maxcnt = 0;
     for (int i = 0; i < nseg; ++i) {
-        const int64_t off = seg_off[i], cnt = seg_off[i + 1] - off;
-        VAG_CHECK_ARG(cnt >= 0);
-        if (cnt == 0) continue;
-        int64_t b = cdiv64(cnt, 256);
-        if (b > 4096) b = 4096;
-        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)b), dim3(256), 0, s, p, g, m, v, off, cnt, seg_lr[i], seg_wd[i],
-                           beta1, beta2, eps, sc);
-        VAG_LAUNCH_CHECK();
+        sg.off[i] = seg_off[i]; sg.cnt[i] = seg_off[i + 1] - seg_off[i];
+        sg.lr[i] = seg_lr[i]; sg.wd[i] = seg_wd[i];
+        VAG_CHECK_ARG(sg.cnt[i] >= 0);
+        if (sg.cnt[i] > maxcnt) maxcnt = sg.cnt[i];
     }
+    int64_t b = cdiv64(maxcnt, 256);
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)b, (unsigned)nseg), dim3(256), 0, s, p, g, m, v, sg, beta1, beta2, eps,
+                       zero_grad, sc);
+    VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

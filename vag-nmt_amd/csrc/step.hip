@@ -1,0 +1,200 @@
+// Fused training step (train.py:36-51 around models/...V11.py:82-168 / NMT_Seq2Seq_Beam_V2.py:58-113): zero-grad is the
+// optimiser's job (vag_clip_adam_flat leaves the gradient buffer zeroed), so one call here enqueues the whole forward and
+// backward of one mini-batch on the caller's stream -- every operator of include/vag_nmt.h in the order autograd would run
+// them, on ONE caller-owned workspace, with the gradient w.r.t. the encoder states accumulated in place by its four
+// consumers (decoder, attention keys, decoder initial state, image-conditioned attention) instead of summed by the host
+// framework.  No allocation, no host synchronisation: a step is capturable into a HIP graph, and the `phases` mask lets a
+// data-parallel driver cut it where a gradient bucket becomes final (after the decoder side: everything but the encoder's
+// parameters; after the encoder's backward recurrence: the rest).
+#include "../../include/vag_nmt.h"
+#include "kernels.h"
+
+#define S_(x) reinterpret_cast<hipStream_t>(x)
+
+namespace {
+
+struct StepWs {
+    float *enc, *mask, *ws_enc, *pe;
+    float *y_im, *nrm_im, *im_emb, *ws_img, *alpha_v, *ctx, *y_txt, *nrm_txt, *txt_emb, *rscores, *G;
+    float *xmix, *hseq, *c_all, *e_all, *ws_dec, *tmid, *logits, *lse, *nll, *inv_cnt, *consts;
+    int64_t* tok;
+    float *d_enc, *d_pe, *d_h2, *d_c, *d_e, *d_h0, *d_ctx, *d_im, *d_txt, *scr_dec, *scr_head, *scr_ini;
+    int64_t total;
+};
+
+StepWs step_ws(float* p, const vag_step_cfg& c) {
+    StepWs w;
+    const int64_t B = c.B, Ts = c.Ts, Tt = c.Tt, H = c.H, C = 2 * c.H, S = c.S, R = c.Tt * c.B;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { float* q = p ? p + o : nullptr; o += (n + 63) & ~63ll; return q; };
+    w.enc = take(B * Ts * C); w.mask = take(B * Ts); w.ws_enc = take(vag_bigru_ws_floats(B, Ts, c.Es, H));
+    w.pe = take(B * Ts * C);
+    const bool mm = c.multimodal != 0;
+    w.y_im = take(mm ? B * S : 0); w.nrm_im = take(mm ? B : 0); w.im_emb = take(mm ? B * S : 0);
+    w.ws_img = take(mm ? vag_imagine_ws_floats(B, Ts, C, S, c.attn_method) : 0);
+    w.alpha_v = take(mm ? B * Ts : 0); w.ctx = take(mm ? B * C : 0);
+    w.y_txt = take(mm ? B * S : 0); w.nrm_txt = take(mm ? B : 0); w.txt_emb = take(mm ? B * S : 0);
+    w.rscores = take(mm ? B * B : 0); w.G = take(mm ? B * B : 0);
+    w.xmix = take(B * C); w.hseq = take((Tt + 1) * B * H); w.c_all = take(R * C); w.e_all = take(R * c.Et);
+    w.ws_dec = take(vag_cgru_ws_floats(B, Ts, Tt, c.Et, H));
+    w.tmid = take(R * c.Et); w.logits = take(R * c.ldl); w.lse = take(R); w.nll = take(R); w.inv_cnt = take(B);
+    w.consts = take(8);
+    w.tok = reinterpret_cast<int64_t*>(take(2 * (Tt + 1) * B));
+    w.d_enc = take(B * Ts * C); w.d_pe = take(B * Ts * C); w.d_h2 = take(R * H); w.d_c = take(R * C); w.d_e = take(R * c.Et);
+    w.d_h0 = take(B * H); w.d_ctx = take(mm ? B * C : 0); w.d_im = take(mm ? B * S : 0); w.d_txt = take(mm ? B * S : 0);
+    w.scr_dec = take(vag_cgru_bwd_scratch_floats(B, Ts, Tt, c.Et, H)); w.scr_head = take(R * c.Et); w.scr_ini = take(B * C);
+    w.total = o;
+    return w;
+}
+
+bool cfg_ok(const vag_step_cfg* c) {
+    return c && c->B > 0 && c->Ts > 0 && c->Tt > 0 && c->Es > 0 && c->Et > 0 && c->H > 0 && c->V > 0 && c->Es % 4 == 0 &&
+           c->Et % 4 == 0 && c->H % 4 == 0 && c->ldl >= c->V && c->ldl % 4 == 0 &&
+           (!c->multimodal || (c->S > 0 && c->S % 4 == 0 && c->I > 0 && (c->attn_method == 0 || c->attn_method == 1) &&
+                               c->rank_kind >= -1 && c->rank_kind <= 1));
+}
+
+// rng step counter, the two loss-mix constants, the decoder's input token matrix (row 0 = SOS, row t+1 = target word t:
+// V11.py:117,146), the per-sentence token counts -- one launch for the step's scalar bookkeeping.
+__global__ __launch_bounds__(256) void step_prologue_kernel(uint64_t* rng, const int64_t* __restrict__ tgt, int B, int Tt,
+                                                            int64_t* __restrict__ tok, float* __restrict__ consts,
+                                                            float* __restrict__ inv_cnt, float w_mt, float w_vse) {
+    const int64_t gid = blockIdx.x * 256ll + threadIdx.x;
+    if (gid < B) {                          // inv_cnt[b] = 1 / #(tgt[b,:] != 0)   (V11.py:164)
+        int c = 0;
+        for (int t = 0; t < Tt; ++t) c += tgt[gid * Tt + t] != 0;
+        inv_cnt[gid] = 1.f / (float)c;
+    }
+    if (gid == 0) {
+        if (rng) rng[1] += 1;
+        consts[0] = w_mt; consts[1] = w_vse; consts[2] = 0.f; consts[3] = 0.f;
+    }
+    const int64_t total = (int64_t)(Tt + 1) * B;
+    for (int64_t i = gid; i < total; i += (int64_t)gridDim.x * 256) {
+        const int t = (int)(i / B), b = (int)(i - (int64_t)t * B);
+        tok[i] = t == 0 ? 2 : tgt[(int64_t)b * Tt + (t - 1)];
+    }
+}
+
+struct DerivedScope {       // points the operators at the driver's derived weights for the duration of one call
+    explicit DerivedScope(const float* d) { vag_set_derived_override(d); }
+    ~DerivedScope() { vag_set_derived_override(nullptr); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int64_t vag_step_ws_floats(const vag_step_cfg* cfg) {
+    if (!cfg_ok(cfg)) return VAG_EINVAL;
+    return step_ws(nullptr, *cfg).total;
+}
+
+// float offset of a workspace tensor, for tests and diagnostics: 0 enc (B,Ts,C), 1 alpha_vse (B,Ts), 2 hseq (Tt+1,B,H),
+// 3 logits (Tt*B,ldl), 4 decoder workspace (see vag_cgru_ws_offset), 5 d_enc (B,Ts,C), 6 im_emb, 7 txt_emb, 8 tok (int64)
+int64_t vag_step_ws_offset(const vag_step_cfg* cfg, int which) {
+    if (!cfg_ok(cfg)) return VAG_EINVAL;
+    static float base[1];
+    StepWs w = step_ws(base, *cfg);
+    const float* p = nullptr;
+    switch (which) {
+        case 0: p = w.enc; break;
+        case 1: p = w.alpha_v; break;
+        case 2: p = w.hseq; break;
+        case 3: p = w.logits; break;
+        case 4: p = w.ws_dec; break;
+        case 5: p = w.d_enc; break;
+        case 6: p = w.im_emb; break;
+        case 7: p = w.txt_emb; break;
+        case 8: p = reinterpret_cast<const float*>(w.tok); break;
+        default: return VAG_EINVAL;
+    }
+    return (int64_t)(p - base);
+}
+
+int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_model_g* gp, const int64_t* src,
+                   const int32_t* lengths, const int64_t* tgt, const float* im, const float* vocab_weight, uint64_t* rng,
+                   const float* derived, float* ws, float* losses, int phases, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(cfg_ok(cfg) && wp && gp && src && lengths && tgt && vocab_weight && ws && losses && aligned16(ws));
+    const vag_step_cfg& c = *cfg;
+    const vag_model_w& w = *wp;
+    const vag_model_g& g = *gp;
+    const bool mm = c.multimodal != 0;
+    VAG_CHECK_ARG(!mm || (im && w.im_w && w.im_b && w.txt_w && w.txt_b && w.ctx2ctx && w.emb2ctx &&
+                          (c.attn_method == 0 || w.mlp_w)));
+    VAG_CHECK_ARG(w.enc_emb && w.ini_w && w.ini_b && w.attn_e && (phases & 7) != 0);
+    const int64_t B = c.B, Ts = c.Ts, Tt = c.Tt, H = c.H, C = 2 * H, S = c.S, V = c.V, Et = c.Et;
+    StepWs k = step_ws(ws, c);
+    DerivedScope scope(derived);
+    const bool has_vse = mm && c.rank_kind >= 0;
+    const float w_mt = mm ? c.loss_w : 1.f, w_vse = mm ? 1.f - c.loss_w : 0.f;
+    float* h0 = k.hseq;                    // [h0, h2_0 .. h2_{Tt-1}] in one buffer: the W_hh1 gradient is one product
+    float* h2_all = k.hseq + B * H;
+    const uint64_t* crng = rng;
+
+    if (phases & 1) {
+        {
+            int64_t nb = cdiv64((Tt + 1) * B, 256);
+            if (nb > 1024) nb = 1024;
+            hipLaunchKernelGGL(step_prologue_kernel, dim3((unsigned)nb), dim3(256), 0, s, rng, tgt, (int)B, (int)Tt, k.tok,
+                               k.consts, k.inv_cnt, w_mt, w_vse);
+            VAG_LAUNCH_CHECK();
+        }
+        VAG_TRY(vag_bigru_seq_fwd(src, lengths, w.enc_emb, w.enc_fw, w.enc_bw, c.p_emb, c.p_ctx, crng, B, Ts, c.Es, H, k.enc,
+                                  k.mask, k.ws_enc, stream));                                           // V11.py:111
+        if (mm) {                                                                                       // V11.py:114
+            VAG_TRY(vag_img_proj_l2_fwd(im, w.im_w, w.im_b, B, c.I, S, c.activation_vse, k.y_im, k.nrm_im, k.im_emb, stream));
+            VAG_TRY(vag_imagine_attn_ctx_fwd(k.im_emb, k.enc, k.mask, w.ctx2ctx, w.emb2ctx, w.mlp_w, c.attn_method, B, Ts, C, S,
+                                             k.alpha_v, k.ctx, k.ws_img, stream));
+            VAG_TRY(vag_img_proj_l2_fwd(k.ctx, w.txt_w, w.txt_b, B, C, S, c.activation_vse, k.y_txt, k.nrm_txt, k.txt_emb,
+                                        stream));
+            if (has_vse)
+                VAG_TRY(vag_rank_loss_fwd(k.im_emb, k.txt_emb, B, S, c.margin, c.rank_kind, k.rscores, k.G, losses + 2, stream));
+        }
+        VAG_TRY(vag_dec_init_fwd(k.enc, k.mask, mm ? k.ctx : nullptr, mm ? c.init_split : 0.f, w.ini_w, w.ini_b, B, Ts, C, H,
+                                 k.xmix, h0, stream));                                                  // V11.py:118
+        VAG_TRY(vag_attn_keys_proj(k.enc, w.attn_e, B * Ts, C, k.pe, stream));                          // NMT_Decoder.py:47
+        VAG_TRY(vag_cgru_attn_decode_seq_fwd(k.enc, k.pe, k.mask, h0, k.tok, w.dec, B, Ts, Tt, Et, H, V, h2_all, k.c_all,
+                                             k.e_all, k.ws_dec, c.free_run, &w.head, c.p_out, crng, k.tmid, k.logits, c.ldl,
+                                             stream));                                                  // V11.py:138-160
+        VAG_TRY(vag_head_ce_seq_fwd_impl(h2_all, k.c_all, k.e_all, w.head, tgt, vocab_weight, B, Tt, Et, H, V, c.p_out, crng,
+                                         c.free_run ? 1 : 0, k.tmid, k.logits, c.ldl, k.lse, k.nll, k.inv_cnt, 1, nullptr,
+                                         losses, w_mt, w_vse, has_vse ? 1 : 0, s));                     // V11.py:140,164-166
+    }
+    if (phases & 2) {
+        VAG_TRY(vag_head_ce_seq_bwd(h2_all, k.c_all, k.e_all, w.head, tgt, vocab_weight, B, Tt, Et, H, V, c.p_out, crng, k.tmid,
+                                    k.logits, c.ldl, k.lse, k.inv_cnt, k.consts + 0, k.d_h2, k.d_c, k.d_e, g.head, k.scr_head,
+                                    stream));
+        VAG_TRY(vag_cgru_attn_decode_seq_bwd(k.enc, k.pe, k.mask, h0, k.tok, w.dec, B, Ts, Tt, Et, H, V, h2_all, k.c_all,
+                                             k.e_all, k.d_h2, k.d_c, k.d_e, k.ws_dec, k.d_enc, 0, k.d_pe, k.d_h0, g.dec,
+                                             k.scr_dec, stream));
+        VAG_TRY(vag_attn_keys_proj_bwd(k.enc, w.attn_e, k.d_pe, B * Ts, C, k.d_enc, 1, g.attn_e, stream));
+        if (mm) {
+            if (has_vse) {
+                VAG_TRY(vag_rank_loss_bwd(k.im_emb, k.txt_emb, k.G, k.consts + 1, B, S, k.d_im, k.d_txt, stream));
+            } else {
+                VAG_TRY(vag_axpy_launch(0.f, k.d_im, k.d_im, B * S, 2, s));
+                VAG_TRY(vag_axpy_launch(0.f, k.d_txt, k.d_txt, B * S, 2, s));
+            }
+            VAG_TRY(vag_img_proj_l2_bwd(k.ctx, w.txt_w, k.y_txt, k.nrm_txt, k.txt_emb, k.d_txt, B, C, S, c.activation_vse,
+                                        k.d_ctx, g.txt_w, g.txt_b, stream));
+        }
+        VAG_TRY(vag_dec_init_bwd_impl(k.mask, k.xmix, h0, mm ? c.init_split : 0.f, w.ini_w, k.d_h0, B, Ts, C, H, k.d_enc, 1,
+                                      mm ? k.d_ctx : nullptr, 1, g.ini_w, g.ini_b, k.scr_ini, s));
+        if (mm) {
+            VAG_TRY(vag_imagine_attn_ctx_bwd_impl(k.im_emb, k.enc, k.mask, w.ctx2ctx, w.emb2ctx, w.mlp_w, c.attn_method, B, Ts,
+                                                  C, S, k.alpha_v, k.d_ctx, k.ws_img, k.d_enc, 1, k.d_im, 1, g.ctx2ctx,
+                                                  g.emb2ctx, g.mlp_w, s));
+            VAG_TRY(vag_img_proj_l2_bwd(im, w.im_w, k.y_im, k.nrm_im, k.im_emb, k.d_im, B, c.I, S, c.activation_vse, nullptr,
+                                        g.im_w, g.im_b, stream));
+        }
+    }
+    if (phases & 4) {
+        VAG_TRY(vag_bigru_seq_bwd(src, lengths, w.enc_fw, w.enc_bw, c.p_emb, c.p_ctx, crng, B, Ts, c.Es, H, k.d_enc, k.ws_enc,
+                                  g.enc_emb, g.enc_fw, g.enc_bw, stream));
+    }
+    return VAG_OK;
+}
+
+}  // extern "C"

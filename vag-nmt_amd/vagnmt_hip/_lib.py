@@ -31,6 +31,20 @@ class HeadW(C.Structure):
     _fields_ = [("w1", P), ("b1", P), ("w2", P), ("b2", P), ("w3", P), ("b3", P), ("out_w", P), ("out_b", P)]
 
 
+class ModelW(C.Structure):
+    """vag_model_w / vag_model_g (identical layout: one pointer per parameter)."""
+    _fields_ = [("enc_emb", P), ("enc_fw", GruW), ("enc_bw", GruW),
+                ("im_w", P), ("im_b", P), ("txt_w", P), ("txt_b", P), ("ctx2ctx", P), ("emb2ctx", P), ("mlp_w", P),
+                ("ini_w", P), ("ini_b", P), ("attn_e", P), ("dec", DecW), ("head", HeadW)]
+
+
+class StepCfg(C.Structure):
+    """vag_step_cfg"""
+    _fields_ = [(n, I64) for n in ("B", "Ts", "Tt", "Es", "Et", "H", "S", "I", "V", "ldl")] + \
+               [(n, I32) for n in ("multimodal", "attn_method", "activation_vse", "rank_kind", "free_run", "reserved")] + \
+               [(n, F) for n in ("margin", "loss_w", "init_split", "p_emb", "p_ctx", "p_out")]
+
+
 # name -> (restype, argtypes); mirrors include/vag_nmt.h declaration by declaration
 PROTOS = {
     "vag_version": (I32, []),
@@ -85,8 +99,15 @@ PROTOS = {
     "vag_beam_step": (I32, [P, I64, P, P, I64, I64, P, P, I64, I64, I64, I64, P, P, P]),
     "vag_beam_step_dev": (I32, [P, I64, P, P, P, I64, P, P, P, I64, I64, I64, I64, P, P, P]),
     "vag_beam_finish": (I32, [P, P, I64, I64, I64, I64, P, P, P]),
-    "vag_clip_adam_flat": (I32, [P, P, P, P, I64, I32, C.POINTER(I64), C.POINTER(F), C.POINTER(F), F, F, F, F, F, P, P,
-                                 P, P]),
+    "vag_clip_adam_flat": (I32, [P, P, P, P, I64, I32, C.POINTER(I64), C.POINTER(F), C.POINTER(F), F, F, F, F, F, I32, P,
+                                 P, P, P]),
+    "vag_step_ws_floats": (I64, [C.POINTER(StepCfg)]),
+    "vag_step_ws_offset": (I64, [C.POINTER(StepCfg), I32]),
+    "vag_train_step": (I32, [C.POINTER(StepCfg), C.POINTER(ModelW), C.POINTER(ModelW), P, P, P, P, P, P, P, P, P, I32, P]),
+    "vag_copy4": (I32, [C.POINTER(P), C.POINTER(P), C.POINTER(I64), I32, P]),
+    "vag_derived_floats": (I64, [I64]),
+    "vag_derive_weights": (I32, [DecW, P, P, I64, P, P]),
+    "vag_cgru_ws_offset": (I64, [I64, I64, I64, I64, I64, I32]),
     "vag_dropout_mask": (I32, [P, I32, I64, F, P, P]),
     "vag_rng_advance": (I32, [P, P]),
 }

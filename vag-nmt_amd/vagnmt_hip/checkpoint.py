@@ -44,8 +44,9 @@ def load_checkpoint(path, model, train_step=None, map_location="cpu"):
     if unexpected or not set(missing) <= {"decoder.out.weight"}:
         raise RuntimeError("checkpoint does not match the model: missing %s unexpected %s" % (missing, unexpected))
     if "dropout_rng" in ckpt:
-        dev = next(model.parameters()).device
-        model._vag_rng = ckpt["dropout_rng"].to(dev)
+        # in place: captured step graphs hold the device address of these two words
+        from .state import dropout_rng
+        dropout_rng(model, next(model.parameters()).device).copy_(ckpt["dropout_rng"])
     if train_step is not None and "optimizer" in ckpt:
         opt, fp = ckpt["optimizer"], train_step.fp
         with torch.no_grad():
@@ -55,4 +56,6 @@ def load_checkpoint(path, model, train_step=None, map_location="cpu"):
                 fp.v[o:o + k].copy_(opt["v"][name].reshape(-1))
             train_step.step_count.fill_(int(opt["step"]))
         train_step.lr = opt["lr"]
+    if train_step is not None and hasattr(train_step.backend, "after_optimizer"):
+        train_step.backend.after_optimizer()      # derived weights follow the restored parameters
     return ckpt

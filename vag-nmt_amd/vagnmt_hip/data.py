@@ -57,9 +57,29 @@ class DeviceCorpus:
         return bx, by, bim, x_len_sorted, y_len_sorted
 
 
-def data_generator_tl_mtv(corpus, batch_size, rank=0, world_size=1):
-    """Same contract as preprocessing.data_generator_tl_mtv, over a DeviceCorpus; batches of equal target length."""
-    sampler = BucketBatchSampler(corpus.y_len, batch_size)
-    for i, bidx in enumerate(sampler):
-        if i % world_size == rank:
-            yield corpus.batch(bidx)
+def shard_batches(batches, rank, world_size):
+    """Rank r takes batches r, r+world, ... of the common order, truncated to a multiple of world_size so that every
+    rank runs the same number of optimiser steps (each step ends in a collective; an extra batch on some ranks would
+    leave them waiting in it forever).  At most world_size-1 batches per epoch are skipped; the per-epoch reshuffle of
+    the sampler rotates which ones."""
+    n = len(batches) // world_size * world_size
+    return [batches[i] for i in range(rank, n, world_size)]
+
+
+def data_generator_tl_mtv(corpus, batch_size, rank=0, world_size=1, seed=None):
+    """Same contract as preprocessing.data_generator_tl_mtv, over a DeviceCorpus; batches of equal target length.
+    Data parallel: pass the same ``seed`` (e.g. base_seed + epoch) on every rank -- the sampler shuffles with numpy's
+    global generator, which is seeded here for the duration of the shuffle only and restored afterwards."""
+    if world_size > 1 and seed is None:
+        raise ValueError("data-parallel batch streams need a common seed (every rank must walk the same batch order)")
+    state = None
+    if seed is not None:
+        state = np.random.get_state()
+        np.random.seed(seed)
+    try:
+        batches = [np.asarray(b) for b in BucketBatchSampler(corpus.y_len, batch_size)]
+    finally:
+        if state is not None:
+            np.random.set_state(state)
+    for bidx in shard_batches(batches, rank, world_size):
+        yield corpus.batch(bidx)

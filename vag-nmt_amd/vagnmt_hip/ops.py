@@ -19,45 +19,6 @@ from ._lib import DecW, GruW, HeadW, call, gru_w, ptr, stream
 I64 = torch.int64
 
 
-class _SideStream:
-    """Optional second stream for work nothing on the critical path waits for (the weight-gradient products of the head
-    and of the decoder): it runs beside the backward recurrences, which leave most CUs idle.  Off by default; the step
-    driver enables it and joins before the optimiser.  Buffers handed to the side stream are kept alive until join()."""
-
-    def __init__(self):
-        self.stream = None
-        self.keep = []
-        self.forked = False
-
-    def enable(self, stream):
-        self.stream = stream
-
-    def disable(self):
-        self.join()
-        self.stream = None
-
-    @property
-    def enabled(self):
-        return self.stream is not None
-
-    def run(self, fn, keep):
-        main = torch.cuda.current_stream()
-        self.stream.wait_stream(main)
-        with torch.cuda.stream(self.stream):
-            fn()
-        self.keep.extend(keep)
-        self.forked = True
-
-    def join(self):
-        if self.stream is not None and self.forked:
-            torch.cuda.current_stream().wait_stream(self.stream)
-        self.keep = []
-        self.forked = False
-
-
-SIDE = _SideStream()
-
-
 def _f32(*shape, like):
     return torch.empty(*shape, dtype=torch.float32, device=like.device)
 
@@ -267,17 +228,9 @@ class _CGRUDecodeSeq(Function):
         g = [x[0] for x in t]
         gdec = DecW(ptr(g[0]), gru_w(g[1], g[2], g[3], g[4]), ptr(g[5]), ptr(g[6]), ptr(g[7]),
                     gru_w(g[8], g[9], g[10], g[11]))
-        if SIDE.enabled:
-            call("vag_cgru_attn_decode_seq_bwd_loop", ptr(enc), ptr(pe), ptr(mask), ptr(h0), ptr(tok, I64), _dec_w(emb, dec),
-                 B, Ts, Tt, E, H, V, ptr(h2), ptr(c), ptr(e), ptr(d_h2), ptr(d_c), ptr(d_e), ptr(ws), ptr(d_enc), 0,
-                 ptr(d_pe), ptr(d_h0), ptr(scratch), stream())
-            SIDE.run(lambda: call("vag_cgru_attn_decode_seq_bwd_weights", ptr(h0), ptr(tok, I64), _dec_w(emb, dec), B, Ts, Tt,
-                                  E, H, ptr(h2), ptr(c), ptr(e), ptr(d_e), ptr(ws), gdec, ptr(scratch), stream()),
-                     [h0, tok, emb, ws, h2, c, e, d_e, d_c, scratch, g] + list(dec))
-        else:
-            call("vag_cgru_attn_decode_seq_bwd", ptr(enc), ptr(pe), ptr(mask), ptr(h0), ptr(tok, I64), _dec_w(emb, dec),
-                 B, Ts, Tt, E, H, V, ptr(h2), ptr(c), ptr(e), ptr(d_h2), ptr(d_c), ptr(d_e), ptr(ws), ptr(d_enc), 0,
-                 ptr(d_pe), ptr(d_h0), gdec, ptr(scratch), stream())
+        call("vag_cgru_attn_decode_seq_bwd", ptr(enc), ptr(pe), ptr(mask), ptr(h0), ptr(tok, I64), _dec_w(emb, dec),
+             B, Ts, Tt, E, H, V, ptr(h2), ptr(c), ptr(e), ptr(d_h2), ptr(d_c), ptr(d_e), ptr(ws), ptr(d_enc), 0,
+             ptr(d_pe), ptr(d_h0), gdec, ptr(scratch), stream())
         r = _ret(t)
         return (d_enc, d_pe, None, d_h0, None, r[0], None, None, None, None, None, None) + tuple(r[1:]) + \
             (None,) * (ctx.nrest - ctx.ndec)
@@ -332,16 +285,9 @@ class HeadCE(Function):
         g = [x[0] for x in t]
         # tied embeddings: out_w and the decoder embedding are the same Parameter, so g[6] is its gradient buffer
         rp = ptr(rng, torch.int64) if rng is not None else None
-        if SIDE.enabled:
-            call("vag_head_ce_seq_bwd_data", _head_w(head), ptr(tgt, I64), ptr(vw), B, Tt, E, H, V, p_out, rp, ptr(tmid),
-                 ptr(logits), ldl, ptr(lse), ptr(inv_cnt), ptr(d_loss), ptr(d_h2), ptr(d_c), ptr(d_e), ptr(scratch), stream())
-            SIDE.run(lambda: call("vag_head_bwd_weights", ptr(h2), ptr(c), ptr(e), Tt * B, E, H, V, ptr(tmid), ptr(logits), ldl,
-                                  ptr(scratch), HeadW(*[ptr(x) for x in g]), stream()),
-                     [h2, c, e, tmid, logits, scratch, g])
-        else:
-            call("vag_head_ce_seq_bwd", ptr(h2), ptr(c), ptr(e), _head_w(head), ptr(tgt, I64), ptr(vw), B, Tt, E, H, V, p_out,
-                 rp, ptr(tmid), ptr(logits), ldl, ptr(lse), ptr(inv_cnt), ptr(d_loss), ptr(d_h2), ptr(d_c), ptr(d_e),
-                 HeadW(*[ptr(x) for x in g]), ptr(scratch), stream())
+        call("vag_head_ce_seq_bwd", ptr(h2), ptr(c), ptr(e), _head_w(head), ptr(tgt, I64), ptr(vw), B, Tt, E, H, V, p_out,
+             rp, ptr(tmid), ptr(logits), ldl, ptr(lse), ptr(inv_cnt), ptr(d_loss), ptr(d_h2), ptr(d_c), ptr(d_e),
+             HeadW(*[ptr(x) for x in g]), ptr(scratch), stream())
         return (d_h2, d_c, d_e, None, None, None, None, None, None, None) + _ret(t)
 
 

@@ -2,17 +2,21 @@
 
     model.train(); zero_grad(); loss = model(...); loss.backward(); clip_grad_norm_(params, clip); optimizer.step()
 
-with three changes in mechanism, none in arithmetic:
-  * every parameter lives in ONE flat fp32 buffer ordered like the reference's Adam param groups
-    (nmt_multimodal_beam_DE.py:303-332: names without 'bias' get L2 weight decay, names with 'bias' do not;
-    optional half-learning-rate groups for 'vse_imagine'), with a matching flat gradient buffer the HIP backward
-    kernels accumulate into directly;
-  * global-norm clipping and Adam are one fused pass over that buffer (vag_clip_adam_flat);
-  * zero-grad + forward + backward are captured once per batch shape into a HIP graph and replayed, so the ~1.5k
-    kernel launches of a step cost one graph launch on the host;
-and, for data parallelism (one process per GPU), one RCCL sum all-reduce of the flat gradient buffer between
-backward and the optimiser (clipping acts on the averaged gradient, exactly what a single-GPU step on the global
-batch's mean gradient would do)."""
+with these changes in mechanism, none in arithmetic:
+  * every parameter lives in ONE flat fp32 buffer laid out by the reference's Adam param groups
+    (nmt_multimodal_beam_DE.py:303-332: names without 'bias' get L2 weight decay, names with 'bias' do not; optional
+    half-learning-rate groups for 'vse_imagine'), with a matching flat gradient buffer the HIP backward kernels
+    accumulate into directly.  Inside the buffer the segments are ordered by the moment their gradients become final
+    in backward: everything except the encoder first, the encoder's parameters last, so a data-parallel run
+    all-reduces the first bucket while the encoder's backward recurrence is still running;
+  * forward + backward of a mini-batch is ONE call into the library (vag_train_step) on one static workspace, captured
+    once per batch shape into a HIP graph and replayed;
+  * global-norm clipping and Adam are one fused pass over the flat buffer (vag_clip_adam_flat, two launches) that also
+    leaves the gradient buffer zeroed for the next step, followed by the refresh of the derived weights;
+and, for data parallelism (one process per GPU over torch.distributed, backend "nccl" = RCCL), bucketed sum all-reduces
+of the flat gradient between the backward phases and the optimiser (clipping acts on the averaged gradient, exactly what
+a single-GPU step on the global batch's mean gradient would do)."""
+import collections
 import ctypes as C
 import random
 
@@ -33,27 +37,44 @@ def param_groups(named_params, vse_separate=False):
             ("vse_bias", [n for n in names if "bias" in n and "vse_imagine" in n], False, 0.5)]
 
 
+def is_late(name):
+    """Gradients that are only final after the encoder's backward recurrence (the last thing backward does)."""
+    return name.startswith("encoder.")
+
+
 def flat_layout(named_params, vse_separate=False):
-    """Offsets of every parameter in the flat buffer: groups are contiguous segments, slots 16-byte aligned.
-    Returns (groups, offsets dict, segment boundaries, total floats).  Pure host logic (no GPU needed)."""
+    """Offsets of every parameter in the flat buffer.  Each optimiser group is split into an early and a late part
+    (see is_late); all early segments come first.  Segments are contiguous, slots 256-byte aligned.
+    Returns (segments [(name, [param names], wd?, lr_mult)], offsets dict, segment boundaries, total floats);
+    the early bucket is [0, boundary of the first late segment).  Pure host logic (no GPU needed)."""
     byname = dict(named_params)
-    groups = param_groups(named_params, vse_separate)
+    early, late = [], []
+    for gname, names, wd, mult in param_groups(named_params, vse_separate):
+        e = [n for n in names if not is_late(n)]
+        la = [n for n in names if is_late(n)]
+        if e:
+            early.append((gname, e, wd, mult))
+        if la:
+            late.append((gname + "/encoder", la, wd, mult))
+    segs = early + late
     offs, seg_off, o = {}, [0], 0
-    for _, names, _, _ in groups:
+    for _, names, _, _ in segs:
         for n in names:
             offs[n] = o
-            o += (byname[n].numel() + 3) // 4 * 4
+            o += (byname[n].numel() + 63) // 64 * 64          # 256-byte slots: matrix rows start on cache-line boundaries
         seg_off.append(o)
-    return groups, offs, seg_off, o
+    return segs, offs, seg_off, o
 
 
 class FlatParams:
     """Re-homes a module's parameters into one flat buffer (+ gradient, Adam m/v buffers)."""
 
     def __init__(self, model, vse_separate=False):
-        named = list(model.named_parameters())          # tied weights appear once
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]      # tied weights appear once
         dev = named[0][1].device
         self.groups, self.offsets, self.seg_off, self.n = flat_layout(named, vse_separate)
+        n_early = sum(1 for g in self.groups if not g[0].endswith("/encoder"))
+        self.early_end = self.seg_off[n_early]              # [0, early_end): final before the encoder's backward
         self.flat = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.m = torch.zeros(self.n, dtype=torch.float32, device=dev)
@@ -68,15 +89,19 @@ class FlatParams:
                 p.grad = p._vag_grad
         self.named = named
 
+    def buckets(self):
+        """Gradient buckets in the order backward finishes them."""
+        return [(0, self.early_end), (self.early_end, self.n)]
+
 
 class TrainStep:
     """One optimiser step per call.  ``step(src, lengths, tgt, im)`` returns (loss, loss_mt, loss_vse) as device
-    tensors (no host sync); call ``.item()`` on them only when a number is needed (the reference syncs every step,
-    train.py:51)."""
+    tensors of this step (no host sync); call ``.item()`` on them only when a number is needed (the reference syncs
+    every step, train.py:51)."""
 
     def __init__(self, model, criterion_mt, criterion_vse=None, lr=4e-4, weight_decay=1e-5, clip=1.0,
                  teacher_force_ratio=0.8, betas=(0.9, 0.999), eps=1e-8, vse_separate=False, use_graph=True,
-                 process_group=None, world_size=1, overlap=False):
+                 process_group=None, world_size=1, max_graphs=48, pad_src=4, fused=None, backend=None):
         self.model = model
         self.criterion_mt = criterion_mt
         self.criterion_vse = criterion_vse
@@ -86,6 +111,8 @@ class TrainStep:
         self.betas, self.eps = betas, eps
         self.use_graph = use_graph
         self.pg, self.world = process_group, world_size
+        self.max_graphs = max_graphs
+        self.pad_src = max(1, int(pad_src))
         self.fp = FlatParams(model, vse_separate)
         dev = self.fp.flat.device
         if world_size > 1:
@@ -96,49 +123,60 @@ class TrainStep:
         self._seg_wd = (C.c_float * ns)(*[weight_decay if g[2] else 0.0 for g in self.fp.groups])
         self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._scratch = torch.zeros(512, dtype=torch.float32, device=dev)        # VAG_ADAM_SCRATCH_BYTES
-        self._graphs = {}
-        self._eager_done = set()
-        # optional second stream for the weight-gradient products.  Measured (round 1): no gain -- the products' blocks
-        # fill every CU and the recurrence's small kernels queue behind them -- so it is off by default.
-        self._side = torch.cuda.Stream(device=dev) if overlap and dev.type == "cuda" else None
+        self._scratch = torch.zeros(512, dtype=torch.float32, device=dev)        # VAG_ADAM_SCRATCH_BYTES, zero once
+        self._graphs = collections.OrderedDict()      # LRU: (B,Ts,Tt,teacher) -> dict(graphs, generation)
+        self._seen = collections.OrderedDict()        # shapes run once eagerly (captured on the second visit)
+        self._opt_graphs = {}
+        self.stats = {"captures": 0, "evictions": 0, "eager_steps": 0, "replays": 0}
+        # the compute back end: the fused HIP step when the criteria are the reference's own, else the per-operator
+        # autograd path; tests inject a CPU stand-in to exercise the data-parallel bookkeeping without a GPU
+        self.backend = backend
+        if backend is None and criterion_mt is not None and dev.type == "cuda":
+            from .fused import FusedStep, fusable
+            if (fused is None or fused) and fusable(model, criterion_mt, criterion_vse):
+                self.backend = _FusedBackend(self, FusedStep(model, criterion_mt, criterion_vse))
+            else:
+                self.backend = _AutogradBackend(self)
 
     def set_lr(self, lr):
         """ReduceLROnPlateau equivalent hook (nmt_multimodal_beam_DE.py:335,469): lr is a host scalar per call."""
         self.lr = lr
 
-    # ---- pieces ----
-    def _fwd_bwd(self, src, lengths, tgt, im, teacher):
-        self.fp.grad.zero_()
-        tfr = 1.0 if teacher else 0.0       # the coin is drawn by the caller so each captured graph is one fixed path
-        if self.multimodal:
-            loss, loss_mt, loss_vse = self.model(src, lengths, tgt, im, tfr, criterion_mt=self.criterion_mt,
-                                                 criterion_vse=self.criterion_vse)
-        else:
-            loss = self.model(src, lengths, tgt, tfr, criterion=self.criterion_mt)
-            loss_mt, loss_vse = loss, None
-        from . import ops
-        if self._side is not None:
-            ops.SIDE.enable(self._side)
-        try:
-            loss.backward()
-        finally:
-            if self._side is not None:
-                ops.SIDE.disable()        # joins: the gradients are complete on the current stream after this
-        return loss, loss_mt, loss_vse
-
+    # ---- optimiser + collectives ----
     def _optimizer(self):
+        if hasattr(self.backend, "optimizer"):
+            return self.backend.optimizer()
         fp = self.fp
         ns = len(fp.groups)
         seg_lr = (C.c_float * ns)(*[self.lr * g[3] for g in fp.groups])
         call("vag_clip_adam_flat", ptr(fp.flat), ptr(fp.grad), ptr(fp.m), ptr(fp.v), fp.n, ns, self._seg_off, seg_lr,
-             self._seg_wd, float(self.clip), 1.0 / self.world, self.betas[0], self.betas[1], self.eps,
+             self._seg_wd, float(self.clip), 1.0 / self.world, self.betas[0], self.betas[1], self.eps, 1,
              ptr(self.step_count, torch.int32), ptr(self.grad_norm), self._scratch.data_ptr(), stream())
+        if hasattr(self.backend, "after_optimizer"):
+            self.backend.after_optimizer()
 
-    def _allreduce(self):
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM, group=self.pg)
+    def _run_optimizer(self):
+        """Clip + Adam (+ derived-weight refresh) replayed from a small graph of its own, keyed by the learning rate."""
+        if not (self.use_graph and self.fp.flat.is_cuda) or hasattr(self.backend, "optimizer"):
+            return self._optimizer()
+        key = ("opt", float(self.lr))
+        g = self._opt_graphs.get(key)
+        if g is None:
+            if len(self._opt_graphs) >= 4:
+                self._opt_graphs.clear()
+            if key not in self._seen:
+                self._seen[key] = True
+                return self._optimizer()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._optimizer()
+            self._opt_graphs[key] = g
+        g.replay()
+
+    def _allreduce_async(self, lo, hi):
+        import torch.distributed as dist
+        return dist.all_reduce(self.fp.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     # ---- public ----
     def step(self, src, lengths, tgt, im=None, teacher=None):
@@ -147,37 +185,121 @@ class TrainStep:
             teacher = random.random() < self.tfr                     # models/...V11.py:136
         if not torch.is_tensor(lengths):
             lengths = torch.tensor(list(lengths), dtype=torch.int32, device=src.device)
-        key = (tuple(src.shape), tuple(tgt.shape), bool(teacher))
-        if not self.use_graph:
-            out = self._fwd_bwd(src, lengths, tgt, im, teacher)
-        elif key not in self._graphs:
-            if key not in self._eager_done:
-                # first visit of a shape: run eagerly (loads code objects, sizes the allocator), capture on the next
-                self._eager_done.add(key)
-                out = self._fwd_bwd(src, lengths, tgt, im, teacher)
-            else:
-                out = self._capture(key, src, lengths, tgt, im, teacher)
+        lengths = lengths.to(torch.int32)
+        be = self.backend
+        if be is None:
+            raise RuntimeError("TrainStep needs HIP tensors and criteria (or an injected backend) to run a step")
+        (bk0, bk1) = self.fp.buckets()
+        if self.world > 1 and getattr(be, "phased", False):
+            # backward in two phases; the first bucket's all-reduce runs beside the encoder's backward
+            be.run(src, lengths, tgt, im, teacher, 3)
+            w0 = self._allreduce_async(*bk0)
+            be.run(src, lengths, tgt, im, teacher, 4, reuse=True)
+            w1 = self._allreduce_async(*bk1)
+            w0.wait()
+            w1.wait()
         else:
-            g = self._graphs[key]
-            g["src"].copy_(src)
-            g["len"].copy_(lengths)
-            g["tgt"].copy_(tgt)
-            if im is not None:
-                g["im"].copy_(im)
-            g["graph"].replay()
-            out = g["out"]
-        self._allreduce()
-        self._optimizer()
+            be.run(src, lengths, tgt, im, teacher, 7)
+            if self.world > 1:
+                w0 = self._allreduce_async(0, self.fp.n)
+                w0.wait()
+        out = be.outputs()
+        self._run_optimizer()
         return out
 
-    def _capture(self, key, src, lengths, tgt, im, teacher):
-        st = {"src": src.clone(), "len": lengths.clone().to(torch.int32), "tgt": tgt.clone(),
-              "im": im.clone() if im is not None else None}
-        graph = torch.cuda.CUDAGraph()
-        torch.cuda.synchronize()
-        with torch.cuda.graph(graph):
-            out = self._fwd_bwd(st["src"], st["len"], st["tgt"], st["im"], teacher)
-        st["graph"], st["out"] = graph, out
-        self._graphs[key] = st
-        graph.replay()
-        return out
+
+class _FusedBackend:
+    """vag_train_step replayed from HIP graphs: one LRU-bounded entry per (B, padded Ts, Tt, teacher) holding the captured
+    phase graphs; all entries share the FusedStep's static workspace and input buffers."""
+    phased = True
+
+    def __init__(self, ts, fused):
+        self.ts, self.f = ts, fused
+
+    @property
+    def generation(self):
+        return self.f.generation
+
+    def _pad(self, src, lengths):
+        """Source length up to a multiple of pad_src: padded positions carry token 0 / mask 0 and are exact no-ops
+        (zero attention weight, zero encoder state), so fewer distinct shapes need a captured graph."""
+        B, Ts = src.shape
+        p = self.ts.pad_src
+        Tp = (Ts + p - 1) // p * p
+        if Tp != Ts:
+            src = torch.nn.functional.pad(src, (0, Tp - Ts))
+        return src
+
+    def run(self, src, lengths, tgt, im, teacher, phases, reuse=False):
+        ts, f = self.ts, self.f
+        if not reuse:
+            src = self._pad(src, lengths)
+            B, Ts = src.shape
+            Tt = tgt.shape[1]
+            if f.reserve(B, Ts, Tt):
+                ts._graphs.clear()                    # static buffers moved: every captured graph is stale
+                ts._opt_graphs.clear()
+            f.load_batch(src, lengths, tgt, im)
+            self._cur = (B, Ts, Tt, bool(teacher))
+        B, Ts, Tt, teacher = self._cur
+        key = self._cur
+        if not ts.use_graph:
+            ts.stats["eager_steps"] += 1
+            return f.run(B, Ts, Tt, teacher, phases)
+        ent = ts._graphs.get(key)
+        if ent is not None:
+            ts._graphs.move_to_end(key)
+        if ent is None or phases not in ent:
+            if (key, phases) not in ts._seen:
+                # first visit of a shape: run eagerly (rare shapes never pay for a capture), capture on the next visit
+                ts._seen[(key, phases)] = True
+                while len(ts._seen) > 8192:
+                    ts._seen.popitem(last=False)
+                ts.stats["eager_steps"] += 1
+                return f.run(B, Ts, Tt, teacher, phases)
+            if ent is None:
+                ent = {}
+                ts._graphs[key] = ent
+                while len(ts._graphs) > ts.max_graphs:
+                    ts._graphs.popitem(last=False)
+                    ts.stats["evictions"] += 1
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                f.run(B, Ts, Tt, teacher, phases)
+            ent[phases] = g
+            ts.stats["captures"] += 1
+        ts.stats["replays"] += 1
+        ent[phases].replay()
+
+    def outputs(self):
+        out = self.f.losses.clone()               # the static result words are overwritten by the next step
+        return out[0], out[1], out[2]
+
+    def after_optimizer(self):
+        self.f.refresh_derived()
+
+
+class _AutogradBackend:
+    """Per-operator path through torch.autograd (criteria other than the reference's own): eager, one all-reduce."""
+    phased = False
+
+    def __init__(self, ts):
+        self.ts = ts
+        self._out = None
+
+    def run(self, src, lengths, tgt, im, teacher, phases, reuse=False):
+        ts = self.ts
+        tfr = 1.0 if teacher else 0.0       # the coin is drawn by the caller
+        if ts.multimodal:
+            loss, loss_mt, loss_vse = ts.model(src, lengths, tgt, im, tfr, criterion_mt=ts.criterion_mt,
+                                               criterion_vse=ts.criterion_vse)
+        else:
+            loss = ts.model(src, lengths, tgt, tfr, criterion=ts.criterion_mt)
+            loss_mt, loss_vse = loss, None
+        loss.backward()
+        zero = torch.zeros((), device=loss.device)
+        self._out = (loss.detach(), loss_mt.detach(), loss_vse.detach() if torch.is_tensor(loss_vse) else zero)
+
+    def outputs(self):
+        return self._out
