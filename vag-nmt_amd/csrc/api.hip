@@ -481,6 +481,17 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
         a.s[0].A = hprev; a.s[0].W = w.gru1.w_hh; a.s[0].bias = w.gru1.b_hh; a.s[0].other = k.xp1 + t * B * 3 * H;
         a.s[0].hprev = hprev; a.s[0].hout = h1; a.s[0].out2 = nullptr; a.s[0].save = k.g1 + t * 4 * BH; a.s[0].t = 0;
         VAG_TRY(vag_gru_step_launch(a, 1, s));                                                              // gru_1 :121
+        // Experiment kept for the record: 3 launches per step with the attention half in ONE kernel.  Measured
+        // slower (27.7 vs 23.7 us per step): without a cross-workgroup exchange every workgroup of a row recomputes all its
+        // scores, and the 4x tanh work (3.2 us per workgroup) costs more than the launch it saves.  Off unless VAG_CGRU_FUSE=1.
+        static const bool opt_fused = getenv("VAG_CGRU_FUSE") != nullptr;
+        if (opt_fused && vag_attn_fused_fwd_ok(Ts, H, Q, Q)) {
+            // [q | W_hh2 h1 + b] in one product, then scores + softmax + projected context + gru_2 in one kernel
+            VAG_TRY(vag_skinny_launch(B, Q, H, h1, H, p.wcat, H, p.bcat, nullptr, 0, qhp, Q, 0, s));         // :47 | gru_2 hidden side
+            VAG_TRY(vag_attn_fused_fwd_launch(pe, qhp, Q, w.attn_v, mask, k.encwp, w.gru2.b_ih, qhp + C, Q, h1, B, Ts, H,
+                                              k.alpha + t * B * Ts, h2_all + t * BH, k.g2 + t * 4 * BH, s));  // :41-51, :124-129
+            continue;
+        }
         static const bool opt_side = getenv("VAG_CGRU_NOSIDE") == nullptr;
         if (opt_side && Ts * B < (1ll << 28)) {
             // q = attn_h h1, then the scores with W_hh2 h1 + b_hh2 (not needed before the cell) in the same grid

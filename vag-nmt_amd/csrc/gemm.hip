@@ -31,6 +31,38 @@ struct GemmArgs {
 
 constexpr int BK = 32;      // k-depth of one LDS stage (one barrier per 32 of K)
 
+// Epilogue of one 32x32 accumulator (this lane: 16 rows row0 + (r&3) + 8*(r>>2) of one column; rows_left = M - row0).
+// The beta path requests all 16 old values BEFORE using any of them (a per-element load-use-store sequence costs one
+// memory round trip per element: ~15 us for a 64x64-tile product however small it is).
+__device__ __forceinline__ void gemm_epilogue16(const f32x16& acc, float* __restrict__ cbase, int64_t ldc, int rows_left,
+                                                float alpha, float beta, float bv, int act, bool atomic) {
+    if (rows_left <= 0) return;
+    if (atomic) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            if (dr < rows_left) atomicAdd(cbase + (int64_t)dr * ldc, alpha * acc[r] + bv);
+        }
+        return;
+    }
+    float old[16];
+    if (beta != 0.f) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            old[r] = cbase[(int64_t)min(dr, rows_left - 1) * ldc];       // clamped: no branch around the load
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        float v = alpha * acc[r] + bv;
+        if (beta != 0.f) v += beta * old[r];
+        if (act == VAG_ACT_TANH) v = vag_tanh(v);
+        if (dr < rows_left) cbase[(int64_t)dr * ldc] = v;
+    }
+}
+
 // Load a (BT outer) x (BK k) operand tile into registers.  KC: k is the contiguous dimension.  NTH threads.
 template <int BT, bool KC, bool VEC, int NTH>
 __device__ __forceinline__ void tile_load(const float* __restrict__ P, int64_t so, int64_t sk, int o0, int k0,
@@ -165,20 +197,9 @@ __global__ __launch_bounds__(NTH) void gemm_tiled_kernel(GemmArgs a) {
             const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
             if (col >= a.N) continue;
             const float bv = (a.bias && first) ? a.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= a.M) continue;
-                float* cp = a.C + (int64_t)row * a.ldc + col;
-                float v = a.alpha * acc[i][j][r] + bv;
-                if (atomic) {
-                    atomicAdd(cp, v);
-                } else {
-                    if (a.beta != 0.f) v += a.beta * (*cp);
-                    if (a.act == VAG_ACT_TANH) v = vag_tanh(v);
-                    *cp = v;
-                }
-            }
+            const int row0 = m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5);
+            float* cbase = a.C + (int64_t)row0 * a.ldc + col;
+            gemm_epilogue16(acc[i][j], cbase, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, atomic);
         }
 }
 
@@ -300,7 +321,33 @@ __device__ __forceinline__ bf16x8 sp_frag(const __bf16* p) {      // 8 consecuti
     return __builtin_bit_cast(bf16x8, q);
 }
 
-template <bool AKC, bool BKC, bool VEC>
+// One k-tile of MFMA work from the LDS planes: 2 k-steps of 16, six bf16 products each (smallest terms first).
+__device__ __forceinline__ void sp_compute(const __bf16* Af, const __bf16* Bf, f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[2][3], bf[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            bf[p] = sp_frag(Bf + p * SP_PLANE + ks * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                af[i][p] = sp_frag(Af + p * SP_PLANE + i * 32 * SP_LD + ks * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[2], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[1], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[0], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[1], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[0], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i], 0, 0, 0);
+        }
+    }
+}
+
+// PF2: two k-tiles of global loads in flight (two register sets, loop unrolled by two) instead of one: a tile's loads
+// then have a whole iteration more to land before the split needs them.
+template <bool AKC, bool BKC, bool VEC, bool PF2 = false>
 __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem, int bx, int by, int bz) {
     __bf16* As = smem;
     __bf16* Bs = smem + 3 * SP_PLANE;
@@ -316,44 +363,54 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    SpRegs ra, rb;
-    sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, kbeg, a.M, kend, ra);
-    sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, kbeg, a.N, kend, rb);
-
     // fragment addresses: lane (r = lane&31, h = lane>>5) holds 8 consecutive k (8h..8h+7) of row r
     const __bf16* Af = As + (wm * 64 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
     const __bf16* Bf = Bs + (wn * 32 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
 
-    for (int k0 = kbeg; k0 < kend; k0 += SP_BK) {
-        sp_store<AKC>(As, ra);
-        sp_store<BKC>(Bs, rb);
-        __syncthreads();
-        if (k0 + SP_BK < kend) {
-            sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, k0 + SP_BK, a.M, kend, ra);
-            sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, k0 + SP_BK, a.N, kend, rb);
+    if (PF2) {
+        SpRegs ra0, rb0, ra1, rb1;
+        sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, kbeg, a.M, kend, ra0);
+        sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, kbeg, a.N, kend, rb0);
+        if (kbeg + SP_BK < kend) {
+            sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, kbeg + SP_BK, a.M, kend, ra1);
+            sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, kbeg + SP_BK, a.N, kend, rb1);
         }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2][3], bf[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                bf[p] = sp_frag(Bf + p * SP_PLANE + ks * 16);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    af[i][p] = sp_frag(Af + p * SP_PLANE + i * 32 * SP_LD + ks * 16);
+        for (int k0 = kbeg; k0 < kend; k0 += 2 * SP_BK) {
+            sp_store<AKC>(As, ra0);
+            sp_store<BKC>(Bs, rb0);
+            __syncthreads();
+            if (k0 + 2 * SP_BK < kend) {
+                sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, k0 + 2 * SP_BK, a.M, kend, ra0);
+                sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, k0 + 2 * SP_BK, a.N, kend, rb0);
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                // smallest terms first
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[2], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[1], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[0], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[1], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[0], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i], 0, 0, 0);
+            sp_compute(Af, Bf, acc);
+            __syncthreads();
+            if (k0 + SP_BK >= kend) break;
+            sp_store<AKC>(As, ra1);
+            sp_store<BKC>(Bs, rb1);
+            __syncthreads();
+            if (k0 + 3 * SP_BK < kend) {
+                sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, k0 + 3 * SP_BK, a.M, kend, ra1);
+                sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, k0 + 3 * SP_BK, a.N, kend, rb1);
             }
+            sp_compute(Af, Bf, acc);
+            __syncthreads();
         }
-        __syncthreads();
+    } else {
+        SpRegs ra, rb;
+        sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, kbeg, a.M, kend, ra);
+        sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, kbeg, a.N, kend, rb);
+        for (int k0 = kbeg; k0 < kend; k0 += SP_BK) {
+            sp_store<AKC>(As, ra);
+            sp_store<BKC>(Bs, rb);
+            __syncthreads();
+            if (k0 + SP_BK < kend) {
+                sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, k0 + SP_BK, a.M, kend, ra);
+                sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, k0 + SP_BK, a.N, kend, rb);
+            }
+            sp_compute(Af, Bf, acc);
+            __syncthreads();
+        }
     }
 
     // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -363,27 +420,16 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
     if (col >= a.N) return;
     const float bv = (a.bias && first) ? a.bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row >= a.M) continue;
-            float* cp = a.C + (int64_t)row * a.ldc + col;
-            float v = a.alpha * acc[i][r] + bv;
-            if (atomic) {
-                atomicAdd(cp, v);
-            } else {
-                if (a.beta != 0.f) v += a.beta * (*cp);
-                if (a.act == VAG_ACT_TANH) v = vag_tanh(v);
-                *cp = v;
-            }
-        }
+    for (int i = 0; i < 2; ++i) {
+        const int row0 = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+        gemm_epilogue16(acc[i], a.C + (int64_t)row0 * a.ldc + col, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, atomic);
+    }
 }
 
-template <bool AKC, bool BKC, bool VEC>
+template <bool AKC, bool BKC, bool VEC, bool PF2 = false, int PAD = 0>
 __global__ __launch_bounds__(512) void gemm_split_kernel(GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) __bf16 smem[6 * SP_PLANE];
-    gemm_split_body<AKC, BKC, VEC>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    __shared__ __attribute__((aligned(16))) __bf16 smem[6 * SP_PLANE + PAD];      // PAD: experiment (forces one block per CU)
+    gemm_split_body<AKC, BKC, VEC, PF2>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Grouped launch: the blocks of up to GROUP_MAX independent products of one operand layout (e.g. all "TN": both operands
@@ -415,6 +461,29 @@ __global__ __launch_bounds__(512) void gemm_split_group_kernel(GemmGroupArgs G) 
 // block per CU).  Reference points: PMC on this kernel shows MFMA 31 %, LDS 39 %, VALU 26 % busy; a pure MFMA loop
 // (tools/mfma_probe.hip) sustains 1.9-2.1 PFLOP/s bf16, i.e. 315-350 TFLOP/s fp32-equivalent at six products.)
 static int gemm_split_dispatch(const GemmArgs& g, bool akc, bool bkc, bool vec, dim3 grid, hipStream_t s) {
+    // experiment switch (tools/exp_gemm2.py): VAG_GEMM_VARIANT = 1 two k-tiles of loads in flight, 2 one block per CU
+    const char* ev = getenv("VAG_GEMM_VARIANT");
+    const int variant = ev ? atoi(ev) : 0;
+    if (vec && variant == 1) {
+#define VAG_SPLIT_V1(AK, BKc)                                                                         \
+    if (akc == AK && bkc == BKc) {                                                                    \
+        hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, true, true>), grid, dim3(512), 0, s, g);       \
+        VAG_LAUNCH_CHECK();                                                                           \
+        return VAG_OK;                                                                                \
+    }
+        VAG_SPLIT_V1(true, true) VAG_SPLIT_V1(true, false) VAG_SPLIT_V1(false, true) VAG_SPLIT_V1(false, false)
+#undef VAG_SPLIT_V1
+    }
+    if (vec && variant == 2) {
+#define VAG_SPLIT_V2(AK, BKc)                                                                         \
+    if (akc == AK && bkc == BKc) {                                                                    \
+        hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, true, false, 14000>), grid, dim3(512), 0, s, g); \
+        VAG_LAUNCH_CHECK();                                                                           \
+        return VAG_OK;                                                                                \
+    }
+        VAG_SPLIT_V2(true, true) VAG_SPLIT_V2(true, false) VAG_SPLIT_V2(false, true) VAG_SPLIT_V2(false, false)
+#undef VAG_SPLIT_V2
+    }
 #define VAG_SPLIT_CASE(AK, BKc, V)                                                                    \
     if (akc == AK && bkc == BKc && vec == V) {                                                        \
         hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V>), grid, dim3(512), 0, s, g);                \

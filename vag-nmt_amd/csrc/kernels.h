@@ -80,6 +80,11 @@ int vag_attn_scores_ex_launch(int mode, const float* pe, const float* q, int64_t
 int vag_attn_ctx_gru_launch(const float* scores, const float* encwp, int64_t N, int64_t rps, int64_t Ts, int64_t H,
                             const float* b_ih, const float* hp, int64_t ldhp, const float* hprev, float* alpha, float* hout,
                             float* save, hipStream_t s);
+// scores + softmax + projected context + gru_2 cell in one launch (training sizes: see vag_attn_fused_fwd_ok)
+bool vag_attn_fused_fwd_ok(int64_t Ts, int64_t H, int64_t ldq, int64_t ldhp);
+int vag_attn_fused_fwd_launch(const float* pe, const float* q, int64_t ldq, const float* v, const float* mask,
+                              const float* encwp, const float* b_ih, const float* hp, int64_t ldhp, const float* hprev,
+                              int64_t N, int64_t Ts, int64_t H, float* alpha, float* hout, float* save, hipStream_t s);
 int vag_attn_wsum_launch(int over_src, const float* a, const float* x, int64_t B, int64_t Ts, int64_t T, int64_t W, float* out,
                          hipStream_t s);
 // softmax=1: alpha[n,:] = softmax(scores[n,:]) (written to alpha), ctx[n,c] = sum_s alpha[n,s] enc[b,s,c]

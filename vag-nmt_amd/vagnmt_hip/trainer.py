@@ -198,6 +198,10 @@ class TrainStep:
             w1 = self._allreduce_async(*bk1)
             w0.wait()
             w1.wait()
+        elif self.world == 1 and getattr(be, "with_optimizer", False) and self.use_graph:
+            # single GPU: forward, backward and the optimiser in ONE captured graph per (shape, learning rate)
+            be.run(src, lengths, tgt, im, teacher, 7, optimizer=True)
+            return be.outputs()
         else:
             be.run(src, lengths, tgt, im, teacher, 7)
             if self.world > 1:
@@ -212,6 +216,7 @@ class _FusedBackend:
     """vag_train_step replayed from HIP graphs: one LRU-bounded entry per (B, padded Ts, Tt, teacher) holding the captured
     phase graphs; all entries share the FusedStep's static workspace and input buffers."""
     phased = True
+    with_optimizer = True
 
     def __init__(self, ts, fused):
         self.ts, self.f = ts, fused
@@ -230,7 +235,7 @@ class _FusedBackend:
             src = torch.nn.functional.pad(src, (0, Tp - Ts))
         return src
 
-    def run(self, src, lengths, tgt, im, teacher, phases, reuse=False):
+    def run(self, src, lengths, tgt, im, teacher, phases, reuse=False, optimizer=False):
         ts, f = self.ts, self.f
         if not reuse:
             src = self._pad(src, lengths)
@@ -243,9 +248,16 @@ class _FusedBackend:
             self._cur = (B, Ts, Tt, bool(teacher))
         B, Ts, Tt, teacher = self._cur
         key = self._cur
+
+        def launch():
+            f.run(B, Ts, Tt, teacher, phases)
+            if optimizer:
+                ts._optimizer()
+        if optimizer:
+            key = key + (float(ts.lr),)                 # the learning rate is baked into the captured Adam launch
         if not ts.use_graph:
             ts.stats["eager_steps"] += 1
-            return f.run(B, Ts, Tt, teacher, phases)
+            return launch()
         ent = ts._graphs.get(key)
         if ent is not None:
             ts._graphs.move_to_end(key)
@@ -256,7 +268,7 @@ class _FusedBackend:
                 while len(ts._seen) > 8192:
                     ts._seen.popitem(last=False)
                 ts.stats["eager_steps"] += 1
-                return f.run(B, Ts, Tt, teacher, phases)
+                return launch()
             if ent is None:
                 ent = {}
                 ts._graphs[key] = ent
@@ -266,14 +278,16 @@ class _FusedBackend:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                f.run(B, Ts, Tt, teacher, phases)
+                launch()
             ent[phases] = g
             ts.stats["captures"] += 1
         ts.stats["replays"] += 1
         ent[phases].replay()
 
     def outputs(self):
-        out = self.f.losses.clone()               # the static result words are overwritten by the next step
+        """(loss, loss_mt, loss_vse) of the step just enqueued, as a copy (the static result words are overwritten by the
+        next step; a caller may keep these tensors and read them later)."""
+        out = self.f.losses.clone()
         return out[0], out[1], out[2]
 
     def after_optimizer(self):
