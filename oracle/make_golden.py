@@ -13,6 +13,8 @@ shims let it run on torch 2.x CPU:
      (losses/PairwiseRankingLoss.py:16,18)
   3. integer ``/`` meant floor-division in torch 0.4 -> trunc-div for integral
      operands (models/...V11.py:242,245,303)
+  4. (batch fixture only) ``nltk.tokenize`` stubbed in sys.modules: preprocessing.py:9
+     imports it for sent_tokenize, which data_generator_tl_mtv never calls
 The fixtures are plain arrays: parameters, inputs, and what the reference
 computed from them (losses, intermediates, gradients, post-Adam parameters,
 decoded token lists).
@@ -236,6 +238,46 @@ def run_sampler():
     print("sampler.npz written")
 
 
+def run_batches():
+    """Batches produced by the reference's own generator (preprocessing.data_generator_tl_mtv, :308-384) for a seeded toy
+    corpus.  preprocessing.py imports nltk at module level (:9) only for sent_tokenize, which the generator never calls:
+    a stub module stands in for it (4th shim; nltk is not installed here)."""
+    import types
+    stub = types.ModuleType("nltk")
+    tok = types.ModuleType("nltk.tokenize")
+    tok.sent_tokenize = lambda s: [s]
+    stub.tokenize = tok
+    sys.modules.setdefault("nltk", stub)
+    sys.modules.setdefault("nltk.tokenize", tok)
+    import preprocessing as PP
+    rs = np.random.RandomState(0)
+    N = 150
+    pairs = [[[int(t) for t in rs.randint(4, 50, size=rs.randint(1, 9))] + [3],
+              [int(t) for t in rs.randint(4, 60, size=rs.randint(1, 7))] + [3]] for _ in range(N)]
+    feats = rs.rand(N, 24).astype(np.float32)
+    out = {"feats": feats, "x_len": np.array([len(p[0]) for p in pairs]), "y_len": np.array([len(p[1]) for p in pairs])}
+    lx, ly = out["x_len"].max(), out["y_len"].max()
+    X = np.zeros((N, lx), dtype=np.int64)
+    Y = np.zeros((N, ly), dtype=np.int64)
+    for i, (a, b) in enumerate(pairs):
+        X[i, :len(a)] = a
+        Y[i, :len(b)] = b
+    out["x"], out["y"] = X, Y
+    for bs in (16, 5):
+        np.random.seed(11)
+        nb = 0
+        for k, (bx, by, bim, xl, yl) in enumerate(PP.data_generator_tl_mtv(pairs, feats, bs)):
+            out["bs%d/%d/x" % (bs, k)] = bx.detach().cpu().numpy()
+            out["bs%d/%d/y" % (bs, k)] = by.detach().cpu().numpy()
+            out["bs%d/%d/im" % (bs, k)] = bim.detach().cpu().numpy()
+            out["bs%d/%d/xl" % (bs, k)] = np.array(xl)
+            out["bs%d/%d/yl" % (bs, k)] = np.array(yl)
+            nb += 1
+        out["bs%d/n" % bs] = np.array([nb])
+    np.savez_compressed(os.path.join(OUT, "batches.npz"), **out)
+    print("batches.npz written")
+
+
 def main():
     sys.path.insert(0, REF)
     sys.dont_write_bytecode = True
@@ -256,6 +298,7 @@ def main():
              ragged=False, beams=(3,), max_len=8)
     run_losses()
     run_sampler()
+    run_batches()
 
 
 if __name__ == "__main__":

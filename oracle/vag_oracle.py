@@ -461,8 +461,8 @@ def i2t(images, captions):
 
 
 # --------------------------------------------------------------------------
-# batch assembly  (preprocessing.py:308-384 data_generator_tl_mtv; restated from the source text -- the module
-# itself cannot be imported here (it needs nltk), so this function is NOT pinned by a reference run)
+# batch assembly  (preprocessing.py:308-384 data_generator_tl_mtv).  Pinned: tests/golden/batches.npz holds the batches the
+# reference's own generator produced for a seeded toy corpus (oracle/make_golden.py:run_batches, nltk stubbed)
 # --------------------------------------------------------------------------
 def assemble_batch(data_pairs, data_im, bidx):
     import numpy as np

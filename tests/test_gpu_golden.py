@@ -168,25 +168,28 @@ def test_retrieval_metrics_t2i_i2t():
 
 
 def test_device_resident_batch_pipeline():
-    """vagnmt_hip.data: batches assembled on the device equal the host restatement of preprocessing.py:308-384."""
+    """vagnmt_hip.data: batches assembled on the device equal the batches the reference's own generator produced
+    (preprocessing.py:308-384; tests/golden/batches.npz from oracle/make_golden.py:run_batches)."""
+    import os
+    from conftest import GOLDEN
     from vagnmt_hip.data import DeviceCorpus, data_generator_tl_mtv
-    from oracle import vag_oracle as O
-    rs = np.random.RandomState(0)
-    N = 150
-    pairs = [[list(rs.randint(4, 50, size=rs.randint(1, 9))) + [3], list(rs.randint(4, 60, size=rs.randint(1, 7))) + [3]]
-             for _ in range(N)]
-    feats = rs.rand(N, 24).astype(np.float32)
+    z = dict(np.load(os.path.join(GOLDEN, "batches.npz")))
+    N = z["x"].shape[0]
+    pairs = [[[int(v) for v in z["x"][i, :z["x_len"][i]]], [int(v) for v in z["y"][i, :z["y_len"][i]]]] for i in range(N)]
+    feats = z["feats"]
     corpus = DeviceCorpus(pairs, feats, torch.device("cuda:0"))
+    for bs in (16, 5):
+        np.random.seed(11)
+        got = list(data_generator_tl_mtv(corpus, bs))
+        assert len(got) == int(z["bs%d/n" % bs][0]) and sum(g[0].shape[0] for g in got) == N
+        for k, g in enumerate(got):
+            assert np.array_equal(g[0].cpu().numpy(), z["bs%d/%d/x" % (bs, k)])
+            assert np.array_equal(g[1].cpu().numpy(), z["bs%d/%d/y" % (bs, k)])
+            assert np.array_equal(g[2].cpu().numpy(), z["bs%d/%d/im" % (bs, k)])
+            assert g[3] == list(z["bs%d/%d/xl" % (bs, k)]) and g[4] == list(z["bs%d/%d/yl" % (bs, k)])
+            assert g[3] == sorted(g[3], reverse=True) and len(set(g[4])) == 1
     np.random.seed(11)
     got = list(data_generator_tl_mtv(corpus, 16))
-    np.random.seed(11)
-    from machine_translation_vision.samplers import BucketBatchSampler
-    want = [O.assemble_batch(pairs, feats, b) for b in BucketBatchSampler([len(p[1]) for p in pairs], 16)]
-    assert len(got) == len(want) and sum(g[0].shape[0] for g in got) == N
-    for g, w in zip(got, want):
-        assert torch.equal(g[0].cpu(), w[0]) and torch.equal(g[1].cpu(), w[1]) and torch.equal(g[2].cpu(), w[2])
-        assert g[3] == w[3] and g[4] == w[4]
-        assert g[3] == sorted(g[3], reverse=True) and len(set(g[4])) == 1
     # data-parallel sharding: a common seed, disjoint batches, the same number of batches on every rank
     np.random.seed(11)
     state = np.random.get_state()[1].copy()

@@ -102,3 +102,26 @@ def test_retrieval_metrics():
         im, cap = torch.from_numpy(z["retr%d/im" % N]), torch.from_numpy(z["retr%d/cap" % N])
         assert list(O.t2i(im, cap)) == list(z["retr%d/t2i" % N])
         assert list(O.i2t(im, cap)) == list(z["retr%d/i2t" % N])
+
+
+def _toy_corpus(z):
+    pairs = [[[int(v) for v in z["x"][i, :z["x_len"][i]]], [int(v) for v in z["y"][i, :z["y_len"][i]]]]
+             for i in range(z["x"].shape[0])]
+    return pairs, z["feats"]
+
+
+def test_batch_assembly_equals_the_reference_generator():
+    """tests/golden/batches.npz: batches of preprocessing.data_generator_tl_mtv itself (:308-384) under numpy seed 11."""
+    import os
+    from conftest import GOLDEN
+    from machine_translation_vision.samplers import BucketBatchSampler
+    z = dict(np.load(os.path.join(GOLDEN, "batches.npz")))
+    pairs, feats = _toy_corpus(z)
+    for bs in (16, 5):
+        np.random.seed(11)
+        got = [O.assemble_batch(pairs, feats, b) for b in BucketBatchSampler([len(p[1]) for p in pairs], bs)]
+        assert len(got) == int(z["bs%d/n" % bs][0])
+        for k, (bx, by, bim, xl, yl) in enumerate(got):
+            assert np.array_equal(bx.numpy(), z["bs%d/%d/x" % (bs, k)]) and np.array_equal(by.numpy(), z["bs%d/%d/y" % (bs, k)])
+            assert np.array_equal(bim.numpy(), z["bs%d/%d/im" % (bs, k)])
+            assert list(xl) == list(z["bs%d/%d/xl" % (bs, k)]) and list(yl) == list(z["bs%d/%d/yl" % (bs, k)])

@@ -3,6 +3,7 @@ import torch
 import torch.nn as nn
 
 from vagnmt_hip import ops
+from vagnmt_hip._lib import call, ptr, stream
 from vagnmt_hip.state import dropout_rng, lengths_tensor
 
 
@@ -32,7 +33,12 @@ class LIUMCVC_Encoder(nn.Module):
         """Batch-major result used inside the models: enc (B,Ts,2H), mask (B,Ts)."""
         g = self.gru
         train = self.training
-        rng = dropout_rng(self, input_var.device) if train and (self.dropout_emb > 0 or self.dropout_ctx > 0) else None
+        rng = None
+        if train and (self.dropout_emb > 0 or self.dropout_ctx > 0):
+            # stand-alone layer call: this module owns the generator, so it draws fresh masks per call like the reference
+            # (inside the models the step counter is advanced once per forward by Seq2SeqBase._train_rng)
+            rng = dropout_rng(self, input_var.device)
+            call("vag_rng_advance", ptr(rng, torch.int64), stream())
         return ops.BiGRUEncode.apply(
             input_var, lengths_tensor(input_lengths, input_var.device), self.embedding.weight,
             g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0,

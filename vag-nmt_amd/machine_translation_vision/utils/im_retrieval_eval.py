@@ -19,11 +19,9 @@ def _ranks(queries, keys):
 
 
 def _metrics(ranks):
-    r1 = 100.0 * len(np.where(ranks < 1)[0]) / len(ranks)
-    r5 = 100.0 * len(np.where(ranks < 5)[0]) / len(ranks)
-    r10 = 100.0 * len(np.where(ranks < 10)[0]) / len(ranks)
-    medr = np.floor(np.median(ranks)) + 1
-    return (r1, r5, r10, medr)
+    """Recall@{1,5,10} in percent and the 1-based median rank (utils/im_retrieval_eval.py:25-30)."""
+    recall = [100.0 * int(np.count_nonzero(ranks < k)) / len(ranks) for k in (1, 5, 10)]
+    return (recall[0], recall[1], recall[2], float(np.floor(np.median(ranks))) + 1)
 
 
 def t2i(images, captions):
