@@ -67,31 +67,57 @@ def build_model(c, dev, seed=1234, dropout=True):
     return m.to(dev)
 
 
-def cpu_baseline(c, steps=2):
-    """The oracle (reference op order: per-step attn_e, per-step head) timed on this host's cores, full step
-    (fwd + bwd + clip + Adam), same synthetic shapes."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(c, warmup=3, steps=10):
+    """The oracle timed on this host's cores: full optimiser step (fwd + bwd + clip + Adam) on the same synthetic batch,
+    train mode (dropout masks drawn per step, as the GPU run), median of `steps` after `warmup`.  Two operation orders:
+    the reference's own (attn_e(enc) recomputed at every decoder step, NMT_Decoder.py:47 -- this row stands for "the
+    reference CPU path") and the hoisted one (same arithmetic, the product taken once per batch)."""
     from oracle import vag_oracle as O
     torch.manual_seed(1234)
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = min(cores, 32)
-    torch.set_num_threads(cores)
+    threads = min(cores, 32)
+    torch.set_num_threads(threads)
     m = build_model(c, torch.device("cpu"))
-    P = {n: p.detach().clone() for n, p in m.named_parameters()}
     src, lens, tgt, im = make_batch(c, 0, torch.device("cpu"))
-    state = {}
-    times = []
-    for i in range(steps + 1):
-        t0 = time.time()
-        _, _, _, P, state = O.train_step(P, src, lens, tgt, im, teacher=True, state=state)
-        times.append(time.time() - t0)
-    dt = sum(times[1:]) / steps
-    return dict(value=c["B"] / dt, unit="sentence-pairs/s", cores=cores, kind="port",
-                sample="%d full optimiser steps (after 1 warm-up) of the same B=%d x T=%d batch, torch CPU threads=%d, "
-                       "eval-mode oracle in the reference's op order" % (steps, c["B"], c["Tt"], cores),
-                s_per_step=dt)
+    B, Ts, Tt, E, H = c["B"], c["Ts"], c["Tt"], c["E"], c["H"]
+    g = torch.Generator().manual_seed(7)
+
+    def masks():
+        def mk(shape, p):
+            return (torch.rand(shape, generator=g) >= p).float() / (1.0 - p)
+        return {"emb": mk((Ts, B, E), 0.3), "ctx": mk((Ts, B, 2 * H), 0.5), "out": mk((Tt, B, E), 0.5)}
+    rows = {}
+    for name, hoist in (("reference_order", False), ("hoisted", True)):
+        P = {n: p.detach().clone() for n, p in m.named_parameters()}
+        state, times = {}, []
+        for i in range(warmup + steps):
+            t0 = time.time()
+            _, _, _, P, state = O.train_step(P, src, lens, tgt, im, teacher=True, state=state, masks=masks(), hoist=hoist)
+            times.append(time.time() - t0)
+        ts_ = sorted(times[warmup:])
+        med = ts_[len(ts_) // 2]
+        rows[name] = {"s_per_step_median": med, "pairs_per_s": c["B"] / med, "min_s": ts_[0], "max_s": ts_[-1]}
+    ref = rows["reference_order"]
+    return dict(value=ref["pairs_per_s"], unit="sentence-pairs/s", cores=threads, kind="port",
+                sample="%d full optimiser steps (median, after %d warm-up) of the same B=%d x T=%d batch, train mode "
+                       "(dropout 0.3/0.5/0.5), oracle in the reference's op order; torch CPU threads=%d of %d cores"
+                       % (steps, warmup, c["B"], c["Tt"], threads, cores),
+                s_per_step=ref["s_per_step_median"], cpu_model=_cpu_model(), host_cores=cores,
+                hoisted={"value": rows["hoisted"]["pairs_per_s"], "s_per_step": rows["hoisted"]["s_per_step_median"]},
+                spread_s={k: [v["min_s"], v["max_s"]] for k, v in rows.items()})
 
 
 def _time_graph(fn, reps=20):
@@ -167,15 +193,130 @@ def measure_operators(c, dev):
     return out
 
 
+def measure_dense(c, dev):
+    """Live MFMA-side numbers for the dense contractions BASELINE.json names (image projection, BxB similarity) and the
+    three largest products of the step, through the same entry points the step uses; HIP events around graph replays."""
+    from vagnmt_hip import _lib as L
+    B, I, S, V, E = c["B"], c["I"], c["S"], c["V"], c["E"]
+    R = c["B"] * c["Tt"]
+    rows = []
+
+    def gemm(name, M, N, K, a_kc, b_kc, beta):
+        A = torch.randn((M, K) if a_kc else (K, M), device=dev)
+        Bm = torch.randn((N, K) if b_kc else (K, N), device=dev)
+        ldc = (N + 3) // 4 * 4
+        C = torch.zeros(M, ldc, device=dev)
+        sa = (K, 1) if a_kc else (1, M)
+        sb = (1, K) if b_kc else (N, 1)
+        t = _time_graph(lambda: L.call("vag_gemm_f32", M, N, K, 1.0, L.ptr(A), sa[0], sa[1], L.ptr(Bm), sb[0], sb[1],
+                                       float(beta), L.ptr(C), ldc, None, 0, L.stream()), reps=10)
+        rows.append({"product": name, "M": M, "N": N, "K": K, "us": t * 1e6, "tflops": 2.0 * M * N * K / t / 1e12})
+
+    def linear(name, M, N, K):
+        x = torch.randn(M, K, device=dev)
+        W = torch.randn(N, K, device=dev)
+        y = torch.empty(M, N, device=dev)
+        t = _time_graph(lambda: L.call("vag_linear_fwd", M, N, K, L.ptr(x), L.ptr(W), None, 0, L.ptr(y), L.stream()), reps=10)
+        rows.append({"product": name, "M": M, "N": N, "K": K, "us": t * 1e6, "tflops": 2.0 * M * N * K / t / 1e12})
+    linear("image projection (B,I)x(S,I)^T, VSE_Imagine_Enc.py:123", B, S, I)
+    linear("BxB similarity, PairwiseRankingLoss.py:12", B, B, S)
+    gemm("head logits (Tt*B,E)x(V,E)^T, NMT_Decoder.py:143", R, V, E, True, True, 0)
+    gemm("attention keys (B*Ts,C)x(C,C)^T, NMT_Decoder.py:47 hoisted", c["B"] * c["Ts"], 2 * c["H"], 2 * c["H"], True, True, 0)
+    gemm("d out.weight = dlogits^T tmid", V, E, R, False, False, 1)
+    big = [r for r in rows if r["M"] > 64]
+    flops = sum(2.0 * r["M"] * r["N"] * r["K"] for r in big)
+    secs = sum(r["us"] for r in big) * 1e-6
+    return {"bound": "mfma", "unit": "TFLOP/s", "achieved": flops / secs / 1e12, "peak": MFMA_F32_PEAK / 1e12,
+            "frac": flops / secs / MFMA_F32_PEAK,
+            "peak_bf16x6": 2500.0 / 6.0, "frac_of_bf16x6_ceiling": flops / secs / (2500.0e12 / 6.0),
+            "note": "fp32-equivalent FLOP/s of the products with M > 64 (bf16x6 on v_mfma_f32_32x32x16_bf16: 6 bf16 MFMAs per "
+                    "fp32 product, so the matrix pipes do 6x these FLOPs); peak = f32-input MFMA 157.3, bf16 dense 2500/6 as the "
+                    "ceiling of the split; the two M = B products are launch-bound and listed for the record",
+            "products": rows}
+
+
+def measure_copy_bandwidth(dev, mib=1024):
+    """Device-to-device copy rate of a plain 16-byte-per-lane kernel (vag_copy4): read + write bytes per second."""
+    import ctypes as C
+    from vagnmt_hip import _lib as L
+    n = mib * (1 << 20) // 4
+    a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    sp = (C.c_void_p * 4)(a.data_ptr(), 0, 0, 0)
+    dp = (C.c_void_p * 4)(b.data_ptr(), 0, 0, 0)
+    nb = (C.c_int64 * 4)(n * 4, 0, 0, 0)
+    t = _time_graph(lambda: L.call("vag_copy4", sp, dp, nb, 1, L.stream()), reps=5)
+    return {"GBps": 2.0 * n * 4 / t / 1e9, "MiB": mib, "frac_of_nominal": 2.0 * n * 4 / t / HBM_PEAK}
+
+
+def measure_extras(c, dev, ts, args):
+    """Rows SURVEY 8(d) asks for beside the headline: ragged source lengths, the reference's default teacher-forcing ratio
+    0.8 (V11.py:136: a python coin per batch picks the teacher-forced or the free-running graph), and configs[3]: beam-12
+    decode of an eval batch of 16 (test_multimodal.py) in sentences per second."""
+    import random
+    out = {}
+
+    def run(n, batch, lens_t, teacher=None):
+        for _ in range(4):
+            ts.step(batch[0], lens_t, batch[2], batch[3], teacher=teacher)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ts.step(batch[0], lens_t, batch[2], batch[3], teacher=teacher)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    rb = make_batch(c, 0, dev, ragged=True)
+    lt = torch.tensor(rb[1], dtype=torch.int32, device=dev)
+    ms = run(30, rb, lt, teacher=True)
+    out["ragged_lengths"] = {"ms_per_step": ms, "pairs_per_s": c["B"] / ms * 1e3, "mean_src_len": sum(rb[1]) / len(rb[1])}
+    fb = make_batch(c, 0, dev)
+    ltf = torch.tensor(fb[1], dtype=torch.int32, device=dev)
+    for _ in range(3):                       # capture the free-running graph too
+        ts.step(fb[0], ltf, fb[2], fb[3], teacher=False)
+    ms_free = run(20, fb, ltf, teacher=False)
+    random.seed(99)
+    old = ts.tfr
+    ts.tfr = 0.8
+    ms08 = run(60, fb, ltf, teacher=None)
+    ts.tfr = old
+    out["teacher_force_ratio_0.8"] = {"ms_per_step": ms08, "pairs_per_s": c["B"] / ms08 * 1e3}
+    out["free_running"] = {"ms_per_step": ms_free, "pairs_per_s": c["B"] / ms_free * 1e3}
+    # configs[3]
+    c4 = dict(c)
+    c4["B"] = 16
+    m4 = ts.model
+    was = m4.training
+    m4.eval()
+    src, lens, _, im = make_batch(c4, 0, dev, ragged=True)
+    for k, key in ((12, "beam12_decode"), (1, "greedy_decode")):
+        for _ in range(2):
+            m4.beamsearch_decode(src, lens, im, k, 80)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 3
+        for _ in range(n):
+            hyp = m4.beamsearch_decode(src, lens, im, k, 80)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        out[key] = {"sentences_per_s": 16 / dt, "ms_per_batch": dt * 1e3, "eval_batch": 16, "max_length": 80,
+                    "mean_hyp_len": sum(len(h) for h in hyp) / 16.0,
+                    "note": "beam search stops once every hypothesis has emitted EOS (V11.py:266-269)"}
+    m4.train(was)
+    return out
+
+
 def pmc_traffic():
-    """HBM traffic per launch of the dominant kernel from rocprofv3 PMC passes (profiles/r01_pmc.json, produced by
-    tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs, FETCH doubled as MI355X_MICROARCH.md prescribes)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
-    if os.path.exists(path):
+    """HBM traffic per launch of the dominant kernel from rocprofv3 PMC passes (profiles/rNN_pmc.json, produced by
+    tools/profile_round.sh -> tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs, FETCH doubled as
+    MI355X_MICROARCH.md prescribes)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):      # latest round first
         try:
-            return json.load(open(path))
+            d = json.load(open(path))
+            d["file"] = os.path.relpath(path, ROOT)
+            return d
         except Exception:
-            return None
+            continue
     return None
 
 
@@ -186,6 +327,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the ragged / tfr 0.8 / decode rows and the dense-product block")
     ap.add_argument("--no-operators", action="store_true",
                     help="profiling runs: skip the isolated operator timings so kernel counts in a trace are per step")
     ap.add_argument("--tfr", type=float, default=1.0, help="teacher forcing ratio (headline: 1.0)")
@@ -211,6 +353,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL prints its ring / tree / channel choice over xGMI once at communicator creation (rank 0's stderr)
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
         if smoke_dp:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -262,6 +407,35 @@ def main():
     loss = float(out[0].item())
 
     log("timed region done: %.3f ms/step" % (dt / args.steps * 1e3))
+    dp_info = None
+    if world > 1:
+        # per-rank step time with and without the collectives (same phases, all-reduces skipped): the difference is the
+        # communication time the overlap did not hide
+        import torch.distributed as dist
+        n = max(10, min(50, args.steps))
+
+        def timed(comm):
+            ts.comm_enabled = comm
+            for _ in range(3):
+                ts.step(src, lens_t, tgt, im)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                ts.step(src, lens_t, tgt, im)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        t_comm = timed(True)
+        t_nocomm = timed(False)
+        ts.comm_enabled = True
+        ts.resync()                       # replicas diverged while the all-reduces were skipped
+        v = torch.tensor([t_comm, t_nocomm], device=dev, dtype=torch.float64)
+        allv = [torch.zeros_like(v) for _ in range(world)]
+        dist.all_gather(allv, v)
+        dp_info = {"per_rank_ms_per_step": [float(x[0]) for x in allv],
+                   "per_rank_ms_per_step_without_allreduce": [float(x[1]) for x in allv],
+                   "exposed_comm_ms": max(float(x[0]) for x in allv) - max(float(x[1]) for x in allv),
+                   "gradient_bytes": ts.fp.n * 4, "buckets_bytes": [(hi - lo) * 4 for lo, hi in ts.fp.buckets()],
+                   "backend": dist.get_backend(), "steps": n}
     if rank == 0:
         ab = algorithmic_bytes(c)
         if args.no_operators:
@@ -313,7 +487,7 @@ def main():
                                       "traffic": pmc.get("gru_step_kernel_bytes_per_launch"),
                                       "algorithmic_bytes_per_launch": cell_bytes, "us_per_launch": fam["gru_cell"] * 1e6},
             # the BASELINE.json target quantity: one GRU+attention decoder step against the HBM streaming model
-            "roofline_decoder_step": {"bound": "hbm", "kernel": "vag_cgru_attn_decode_seq_fwd / Tt (4 kernels per step + per-batch projections)",
+            "roofline_decoder_step": {"bound": "hbm", "kernel": "vag_cgru_attn_decode_seq_fwd / Tt (4 kernels per step + per-batch products)",
                                       "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                       "frac": achieved / HBM_PEAK,
                                       "traffic": pmc.get("decoder_step_bytes"),
@@ -324,6 +498,22 @@ def main():
         if args.config != "cfg2":
             res["roofline"]["traffic"] = res["roofline_decoder_step"]["traffic"] = None     # PMC passes were taken at cfg2
             res["roofline_gru_cell_fwd"]["traffic"] = None
+        whole = ab["F_enc"] * 2 * c["Ts"] + ab["F_dec"] * c["Tt"] + ab["Bk_enc"] * 2 * c["Ts"] + ab["Bk_dec"] * c["Tt"]
+        if args.config == "cfg2":
+            whole = 6.150e9            # chains + once-per-batch products (fwd, 2x bwd) + Adam, evaluated at cfg2
+        step_s = dt / args.steps
+        res["roofline_whole_step"] = {"bound": "hbm", "kernel": "zero-grad + forward + backward + clip + Adam (SURVEY 8d streaming model)",
+                                      "achieved": whole / step_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                      "frac": whole / step_s / HBM_PEAK, "algorithmic_bytes_per_step": whole,
+                                      "target_frac": 0.40}
+        if dp_info is not None:
+            res["dp"] = dp_info
+        if world == 1 and not args.no_extras:
+            res["copy_bandwidth"] = measure_copy_bandwidth(dev)
+            res["mfma"] = measure_dense(c, dev)
+            if args.config == "cfg2" and not args.no_graph and not args.no_fused:
+                res["extra"] = measure_extras(c, dev, ts, args)
+            log("extras done")
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
             res["cpu_baseline"] = cpu_baseline(c)
         print(json.dumps(res))

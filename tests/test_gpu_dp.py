@@ -99,3 +99,43 @@ def test_two_ranks_on_one_gpu_equal_single_process_mean_gradient(use_graph):
     torch.cuda.synchronize()
     ref = ts.fp.flat.cpu().numpy()
     assert np.allclose(flat_a, ref, rtol=2e-4, atol=2e-6), np.abs(flat_a - ref).max()
+
+
+def _rccl_worker(port, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from vagnmt_hip.trainer import TrainStep
+    res = {}
+    for name, kw in (("phased", dict(process_group=dist.group.WORLD, force_phased=True)), ("single", {})):
+        m = _model(100)
+        cm, cv = _criteria()
+        ts = TrainStep(m, cm, cv, use_graph=True, **kw)
+        losses = [float(ts.step(*_batch(1000 + 10 * (s % 2)), teacher=True)[0]) for s in range(6)]
+        torch.cuda.synchronize()
+        res[name] = (ts.fp.flat.cpu().numpy().copy(), losses, dict(ts.stats))
+    q.put(res)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_phased_sequence_with_rccl_collectives_world1():
+    """The data-parallel sequence -- phase graph, async all-reduce of the first bucket on RCCL's stream, encoder-phase graph,
+    second all-reduce, optimiser -- on the real "nccl" (= RCCL) backend with one rank: what can be rehearsed of the
+    multi-GPU path on a one-GPU box (graph capture next to RCCL's watchdog thread, stream ordering of the async work)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(29700 + os.getpid() % 2000, q))
+    p.start()
+    res = q.get(timeout=500)
+    p.join(120)
+    assert p.exitcode == 0
+    (fa, la, sa), (fb, lb, sb) = res["phased"], res["single"]
+    assert sa["captures"] >= 2 and sa["replays"] >= 4, sa
+    assert np.allclose(la, lb, rtol=2e-4), (la, lb)
+    assert np.allclose(fa, fb, rtol=2e-4, atol=2e-6), np.abs(fa - fb).max()

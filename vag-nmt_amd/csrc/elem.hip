@@ -360,9 +360,16 @@ __global__ __launch_bounds__(256) void copy4_kernel(Copy4 c) {
     unsigned char* d = c.d[k];
     if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
         const int64_t n16 = n >> 4;
-        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256)
-            reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
-        for (int64_t i = (n16 << 4) + blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+        const uint4* s4 = reinterpret_cast<const uint4*>(s);
+        uint4* d4 = reinterpret_cast<uint4*>(d);
+        const int64_t stride = (int64_t)gridDim.x * 256;
+        int64_t i = blockIdx.x * 256ll + threadIdx.x;
+        for (; i + 3 * stride < n16; i += 4 * stride) {          // four 16-byte loads in flight per thread
+            const uint4 a = s4[i], b = s4[i + stride], c2 = s4[i + 2 * stride], e = s4[i + 3 * stride];
+            d4[i] = a; d4[i + stride] = b; d4[i + 2 * stride] = c2; d4[i + 3 * stride] = e;
+        }
+        for (; i < n16; i += stride) d4[i] = s4[i];
+        for (int64_t j = (n16 << 4) + blockIdx.x * 256ll + threadIdx.x; j < n; j += stride) d[j] = s[j];
     } else {
         for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = s[i];
     }
@@ -379,8 +386,8 @@ int vag_copy4_launch(const void* const* src, void* const* dst, const int64_t* by
         if (c.n[i] > mx) mx = c.n[i];
     }
     if (mx == 0) return VAG_OK;
-    int64_t nb = cdiv64(mx, 256 * 16);
-    if (nb > 1024) nb = 1024;
+    int64_t nb = cdiv64(mx, 256 * 16 * 4);
+    if (nb > 8192) nb = 8192;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(copy4_kernel, dim3((unsigned)nb, (unsigned)n), dim3(256), 0, s, c);
     VAG_LAUNCH_CHECK();

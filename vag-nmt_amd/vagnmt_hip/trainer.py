@@ -101,7 +101,8 @@ class TrainStep:
 
     def __init__(self, model, criterion_mt, criterion_vse=None, lr=4e-4, weight_decay=1e-5, clip=1.0,
                  teacher_force_ratio=0.8, betas=(0.9, 0.999), eps=1e-8, vse_separate=False, use_graph=True,
-                 process_group=None, world_size=1, max_graphs=48, pad_src=4, fused=None, backend=None):
+                 process_group=None, world_size=1, max_graphs=48, pad_src=4, fused=None, backend=None,
+                 force_phased=False):
         self.model = model
         self.criterion_mt = criterion_mt
         self.criterion_vse = criterion_vse
@@ -111,6 +112,8 @@ class TrainStep:
         self.betas, self.eps = betas, eps
         self.use_graph = use_graph
         self.pg, self.world = process_group, world_size
+        self.comm_enabled = True              # False: keep the phases but skip the all-reduces (measurement only)
+        self.force_phased = force_phased      # tests: the data-parallel sequence (two phases, two buckets) at world_size 1
         self.max_graphs = max_graphs
         self.pad_src = max(1, int(pad_src))
         self.fp = FlatParams(model, vse_separate)
@@ -169,14 +172,26 @@ class TrainStep:
                 return self._optimizer()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._optimizer()
             self._opt_graphs[key] = g
         g.replay()
 
     def _allreduce_async(self, lo, hi):
         import torch.distributed as dist
+        if not self.comm_enabled:
+            return _NoWork()
         return dist.all_reduce(self.fp.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def resync(self):
+        """Make the replicas identical again (rank 0's parameters and optimiser state), e.g. after a measurement that ran
+        steps without the all-reduces."""
+        if self.world > 1:
+            import torch.distributed as dist
+            for t in (self.fp.flat, self.fp.m, self.fp.v):
+                dist.broadcast(t, src=0, group=self.pg)
+            if hasattr(self.backend, "after_optimizer"):
+                self.backend.after_optimizer()
 
     # ---- public ----
     def step(self, src, lengths, tgt, im=None, teacher=None):
@@ -190,7 +205,7 @@ class TrainStep:
         if be is None:
             raise RuntimeError("TrainStep needs HIP tensors and criteria (or an injected backend) to run a step")
         (bk0, bk1) = self.fp.buckets()
-        if self.world > 1 and getattr(be, "phased", False):
+        if (self.world > 1 or (self.force_phased and self.pg is not None)) and getattr(be, "phased", False):
             # backward in two phases; the first bucket's all-reduce runs beside the encoder's backward
             be.run(src, lengths, tgt, im, teacher, 3)
             w0 = self._allreduce_async(*bk0)
@@ -210,6 +225,11 @@ class TrainStep:
         out = be.outputs()
         self._run_optimizer()
         return out
+
+
+class _NoWork:
+    def wait(self):
+        return True
 
 
 class _FusedBackend:
@@ -277,7 +297,7 @@ class _FusedBackend:
                     ts.stats["evictions"] += 1
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 launch()
             ent[phases] = g
             ts.stats["captures"] += 1
