@@ -315,7 +315,7 @@ int vag_beam_finish(const float* nll, const int64_t* beam, int64_t max_len, int6
  * incremented here.  norm_out (1): total gradient norm before clipping.  scratch: VAG_ADAM_SCRATCH_BYTES, 8-byte aligned. */
 #define VAG_ADAM_SCRATCH_BYTES 2048
 /* zero_grad != 0: g is left zeroed (the next step's backward accumulates into it; no separate fill pass).
- * scratch must be zero before the FIRST call; every call leaves it ready for the next one.  Two launches. */
+ * scratch must be zero before the FIRST call; every call leaves it ready for the next one.  Three launches. */
 int vag_clip_adam_flat(float* p, float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
                        const float* seg_lr, const float* seg_wd, float clip, float grad_scale, float beta1,
                        float beta2, float eps, int zero_grad, int32_t* step, float* norm_out, void* scratch,

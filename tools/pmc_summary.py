@@ -1,4 +1,5 @@
-"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_decoder_fwd.py into profiles/r01_pmc.json.
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_decoder_fwd.py into a JSON file
+(usage: pmc_summary.py <fetch dir> <write dir> <out.json>; tools/profile_round.sh copies it to profiles/rNN_pmc.json).
 FETCH_SIZE / WRITE_SIZE are in KiB... per dispatch; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced
 reads (MI355X_MICROARCH.md, HBM section) and is doubled here; WRITE_SIZE is taken as is."""
 import csv, glob, json, os, sys
@@ -44,5 +45,6 @@ res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
        "gru_bwd_step_kernel_bytes_per_launch": kib(2 * bwd_fetch + bwd_write),
        "gru_bwd_step_kernel_fetch_bytes": kib(2 * bwd_fetch), "gru_bwd_step_kernel_write_bytes": kib(bwd_write),
        "decoder_step_bytes": kib(2 * dec_fetch + dec_write) / (NSEQ * Tt)}
-json.dump(res, open(os.path.join(ROOT, "profiles", "r01_pmc.json"), "w"), indent=1)
+out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "pmc.json")
+json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -447,49 +447,73 @@ int vag_attn_dq_launch(const float* pe, const float* q, int64_t ldq, const float
 // ------------------------------------------------------------------ after the time loop: d_pe, dv partials, d_enc
 // grid (ceil(C/256), B); thread owns one c and walks source positions in chunks of SC, all Tt steps per chunk.
 constexpr int SC = VAG_POST_SC;
+constexpr int POST_TMAX = 96;           // steps whose (ds, alpha) rows are staged in LDS per pass
 __global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restrict__ pe, const float* __restrict__ q_all,
                                                             const float* __restrict__ v, const float* __restrict__ ds_all,
                                                             const float* __restrict__ alpha_all,
                                                             const float* __restrict__ dc_all, int B, int Ts, int Tt, int C,
                                                             int64_t ldq, float* __restrict__ d_pe, float* __restrict__ dvp,
                                                             float* __restrict__ d_enc, int acc_enc) {
+    // the block's (ds, alpha) values -- Tt x SC of each, the same for every thread -- are staged in LDS once instead of being
+    // fetched step by step inside the loop; the per-step query / context-gradient loads run four steps ahead
+    __shared__ float sd[POST_TMAX][SC], sa[POST_TMAX][SC];
     const int b = blockIdx.y;
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const float vc = v[c];
+    const bool cok = c < C;
+    const int s0 = blockIdx.z * SC;          // one chunk of SC source positions per block (grid.z chunks)
+    const float vc = cok ? v[c] : 0.f;
     float dv = 0.f;
-    {
-        const int s0 = blockIdx.z * SC;          // one chunk of SC source positions per block (grid.z chunks)
-        float pv[SC], ape[SC], aen[SC];
+    float pv[SC], ape[SC], aen[SC];
 #pragma unroll
-        for (int i = 0; i < SC; ++i) {
-            const int s = min(s0 + i, Ts - 1);
-            pv[i] = pe[((int64_t)b * Ts + s) * C + c];
-            ape[i] = 0.f; aen[i] = 0.f;
+    for (int i = 0; i < SC; ++i) {
+        const int s = min(s0 + i, Ts - 1);
+        pv[i] = cok ? pe[((int64_t)b * Ts + s) * C + c] : 0.f;
+        ape[i] = 0.f; aen[i] = 0.f;
+    }
+    for (int t0 = 0; t0 < Tt; t0 += POST_TMAX) {
+        const int nt = min(POST_TMAX, Tt - t0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nt * SC; i += 256) {
+            const int t = i / SC, k = i - t * SC;
+            const int s = min(s0 + k, Ts - 1);
+            const int64_t o = ((int64_t)(t0 + t) * B + b) * Ts + s;
+            sd[t][k] = (s0 + k < Ts) ? ds_all[o] : 0.f;           // positions past the end contribute nothing
+            sa[t][k] = alpha_all[o];
         }
-        for (int t = 0; t < Tt; ++t) {
-            const float qv = q_all[((int64_t)t * B + b) * ldq + c];
-            const float dcv = dc_all ? dc_all[((int64_t)t * B + b) * C + c] : 0.f;
-            const float* dsr = ds_all + ((int64_t)t * B + b) * Ts;
-            const float* alr = alpha_all + ((int64_t)t * B + b) * Ts;
+        __syncthreads();
+        if (!cok) continue;
+        constexpr int U = 4;
+        for (int t = 0; t < nt; t += U) {
+            float qv[U], dcv[U];
 #pragma unroll
-            for (int i = 0; i < SC; ++i) {
-                const int s = min(s0 + i, Ts - 1);
-                const float d = dsr[s];
-                const float th = vag_tanh(pv[i] + qv);
-                ape[i] += d * (1.f - th * th);
-                if (s0 + i < Ts) dv += d * th;
-                aen[i] += alr[s] * dcv;
+            for (int u = 0; u < U; ++u) {
+                const int tt = min(t + u, nt - 1) + t0;
+                qv[u] = q_all[((int64_t)tt * B + b) * ldq + c];
+                dcv[u] = dc_all ? dc_all[((int64_t)tt * B + b) * C + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (t + u < nt) {
+#pragma unroll
+                    for (int i = 0; i < SC; ++i) {
+                        const float d = sd[t + u][i];
+                        const float th = vag_tanh(pv[i] + qv[u]);
+                        ape[i] += d * (1.f - th * th);
+                        dv += d * th;
+                        aen[i] += sa[t + u][i] * dcv[u];
+                    }
+                }
             }
         }
+    }
+    if (!cok) return;
 #pragma unroll
-        for (int i = 0; i < SC; ++i) {
-            const int s = s0 + i;
-            if (s < Ts) {
-                const int64_t o = ((int64_t)b * Ts + s) * C + c;
-                d_pe[o] = vc * ape[i];
-                if (d_enc && dc_all) d_enc[o] = acc_enc ? d_enc[o] + aen[i] : aen[i];
-            }
+    for (int i = 0; i < SC; ++i) {
+        const int s = s0 + i;
+        if (s < Ts) {
+            const int64_t o = ((int64_t)b * Ts + s) * C + c;
+            d_pe[o] = vc * ape[i];
+            if (d_enc && dc_all) d_enc[o] = acc_enc ? d_enc[o] + aen[i] : aen[i];
         }
     }
     if (dvp) dvp[((int64_t)blockIdx.z * B + b) * C + c] = dv;      // partial per chunk: rows z*B + b

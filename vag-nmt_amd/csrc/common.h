@@ -88,16 +88,17 @@ int vag_skinny_batched_launch(int64_t nb, int64_t M, int64_t N, int64_t K, const
                               hipStream_t stream);
 int vag_skinny_nn_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                          float beta, float* C, int64_t ldc, hipStream_t stream);
-// queue the qualifying (weight-gradient shaped) products issued between begin and end into one grouped launch;
-// nothing queued may be read or overwritten by work enqueued before vag_gemm_group_end
+// queue the qualifying products issued between begin and end, one queue per operand layout, each launched as one grouped
+// grid at end; nothing queued may be read or overwritten by work enqueued before vag_gemm_group_end.  Brackets nest: an
+// inner end flushes everything queued so far
 void vag_gemm_group_begin();
 int vag_gemm_group_end(hipStream_t stream);
 void vag_gemm_group_abort();
 // scope guard: an early error return inside a bracket must not leave the queue open
 struct VagGemmGroup {
     bool open = true;
-    VagGemmGroup() { vag_gemm_group_begin(); }
-    int end(hipStream_t s) { open = false; return vag_gemm_group_end(s); }
+    explicit VagGemmGroup(bool enable = true) : open(enable) { if (enable) vag_gemm_group_begin(); }
+    int end(hipStream_t s) { if (!open) return VAG_OK; open = false; return vag_gemm_group_end(s); }
     ~VagGemmGroup() { if (open) vag_gemm_group_abort(); }
     VagGemmGroup(const VagGemmGroup&) = delete;
     VagGemmGroup& operator=(const VagGemmGroup&) = delete;

@@ -535,25 +535,40 @@ __global__ __launch_bounds__(256) void fill2d_kernel(float* __restrict__ C, int6
 // deep-K products (every weight gradient: K = Tt*B) are split along K and accumulated with fp32 atomics.
 // ---- grouped launch queue (host side; the library is driven by one host thread per process) ----
 // thread_local: forward runs on the caller's thread, backward on the autograd engine's; a bracket never spans threads
-static thread_local bool g_group_on = false;
-static thread_local int g_group_n = 0;
-static thread_local bool g_group_akc = false, g_group_bkc = false;   // layout of the queued products (set by the first one)
-static thread_local GemmArgs g_group[GROUP_MAX];
+// One queue per operand layout (index akc*2 + bkc).  Brackets nest: an inner end() flushes everything queued so far (its
+// caller is about to consume those results) and the outer bracket keeps collecting afterwards.
+static thread_local int g_group_depth = 0;
+static thread_local int g_qn[4] = {0, 0, 0, 0};
+static thread_local GemmArgs g_q[4][GROUP_MAX];
 static int vag_gemm_launch_now(const GemmArgs& q, hipStream_t stream);
 void vag_colsum_queue_begin();
-int vag_colsum_queue_end(hipStream_t stream);
+int vag_colsum_queue_flush(hipStream_t stream);
 void vag_colsum_queue_abort();
-void vag_gemm_group_begin() { g_group_on = true; g_group_n = 0; vag_colsum_queue_begin(); }
-void vag_gemm_group_abort() { g_group_on = false; g_group_n = 0; vag_colsum_queue_abort(); }   // error path: drop the queue
-int vag_gemm_group_end(hipStream_t stream) {
-    VAG_TRY(vag_colsum_queue_end(stream));
-    g_group_on = false;
-    const int n = g_group_n;
-    g_group_n = 0;
+void vag_gemm_group_begin() {
+    if (g_group_depth++ == 0) {
+        for (int l = 0; l < 4; ++l) g_qn[l] = 0;
+        vag_colsum_queue_begin();
+    }
+}
+void vag_gemm_group_abort() {        // error path: drop the queues
+    g_group_depth = 0;
+    for (int l = 0; l < 4; ++l) g_qn[l] = 0;
+    vag_colsum_queue_abort();
+}
+static int gemm_group_flush_layout(int lay, hipStream_t stream) {
+    const int n = g_qn[lay];
+    g_qn[lay] = 0;
     if (n == 0) return VAG_OK;
-    if (n == 1) return vag_gemm_launch_now(g_group[0], stream);
+    if (n == 1) {
+        const int depth = g_group_depth;       // launch directly, not back into the queue
+        g_group_depth = 0;
+        const int rc = vag_gemm_launch_now(g_q[lay][0], stream);
+        g_group_depth = depth;
+        return rc;
+    }
+    const GemmArgs* q = g_q[lay];
     int64_t tiles = 0;
-    for (int i = 0; i < n; ++i) tiles += cdiv64(g_group[i].M, 128) * cdiv64(g_group[i].N, 128);
+    for (int i = 0; i < n; ++i) tiles += cdiv64(q[i].M, 128) * cdiv64(q[i].N, 128);
     // two co-resident blocks per CU: aim at ~512 blocks; only accumulating (beta = 1) products may be split, and no
     // k-slice shorter than 256
     int sp = (int)((512 + tiles / 2) / tiles);
@@ -564,7 +579,7 @@ int vag_gemm_group_end(hipStream_t stream) {
     int total = 0;
     for (int i = 0; i < n; ++i) {
         GemmArgs& a = G.p[i];
-        a = g_group[i];
+        a = q[i];
         int s_i = a.beta != 0.f ? sp : 1;
         if (s_i > a.K / 256) s_i = a.K / 256 > 0 ? a.K / 256 : 1;
         int kchunk = (int)(cdiv64(cdiv64(a.K, s_i), SP_BK) * SP_BK);
@@ -577,16 +592,27 @@ int vag_gemm_group_end(hipStream_t stream) {
         total += (int)(cdiv64(a.M, 128) * cdiv64(a.N, 128)) * s_i;
     }
     G.start[n] = total;
-    if (!g_group_akc && !g_group_bkc)
+    const bool akc = (lay & 2) != 0, bkc = (lay & 1) != 0;
+    if (!akc && !bkc)
         hipLaunchKernelGGL((gemm_split_group_kernel<false, false>), dim3((unsigned)total), dim3(512), 0, stream, G);
-    else if (g_group_akc && !g_group_bkc)
+    else if (akc && !bkc)
         hipLaunchKernelGGL((gemm_split_group_kernel<true, false>), dim3((unsigned)total), dim3(512), 0, stream, G);
-    else if (g_group_akc && g_group_bkc)
+    else if (akc && bkc)
         hipLaunchKernelGGL((gemm_split_group_kernel<true, true>), dim3((unsigned)total), dim3(512), 0, stream, G);
     else
         hipLaunchKernelGGL((gemm_split_group_kernel<false, true>), dim3((unsigned)total), dim3(512), 0, stream, G);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
+}
+int vag_gemm_group_end(hipStream_t stream) {
+    if (g_group_depth <= 0) return VAG_OK;
+    int rc = vag_colsum_queue_flush(stream);
+    for (int lay = 0; lay < 4 && rc == VAG_OK; ++lay) rc = gemm_group_flush_layout(lay, stream);
+    if (--g_group_depth == 0 || rc != VAG_OK) {
+        if (rc != VAG_OK) vag_gemm_group_abort();
+        else vag_colsum_queue_abort();           // bracket closed: later column sums launch at once
+    }
+    return rc;
 }
 
 int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
@@ -608,12 +634,11 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     g.alpha = alpha; g.beta = beta; g.act = act;
     const int64_t lda = akc ? sam : sak, ldb = bkc ? sbn : sbk;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
-    if (g_group_on && g_group_n < GROUP_MAX && vec && alpha == 1.f && (beta == 0.f || beta == 1.f) &&
-        act == VAG_ACT_NONE && M > 64 && N > 64 && K >= 256 && (g_group_n == 0 || (akc == g_group_akc && bkc == g_group_bkc)) &&
-        !opt_nogroup) {
-        if (g_group_n == 0) { g_group_akc = akc; g_group_bkc = bkc; }
+    const int lay = (akc ? 2 : 0) + (bkc ? 1 : 0);
+    if (g_group_depth > 0 && g_qn[lay] < GROUP_MAX && vec && alpha == 1.f && (beta == 0.f || beta == 1.f) &&
+        act == VAG_ACT_NONE && M > 64 && N > 64 && K >= 256 && !opt_f32mfma && !opt_nogroup) {
         g.kchunk = (int)K; g.splitk = 1;
-        g_group[g_group_n++] = g;
+        g_q[lay][g_qn[lay]++] = g;
         return VAG_OK;
     }
     // cost model (microseconds) over tile in {64,128} x split-K: MFMA time of the busiest CU + output traffic
@@ -1307,12 +1332,13 @@ static thread_local ColsumTasks g_colsum;
 static thread_local unsigned g_colsum_gx = 0, g_colsum_gy = 0;
 void vag_colsum_queue_begin() { g_colsum_queue_on = true; g_colsum_n = 0; g_colsum_gx = g_colsum_gy = 0; }
 void vag_colsum_queue_abort() { g_colsum_queue_on = false; g_colsum_n = 0; }
-int vag_colsum_queue_end(hipStream_t stream) {
-    g_colsum_queue_on = false;
+int vag_colsum_queue_flush(hipStream_t stream) {       // launches what is queued; the queue stays open
     const int n = g_colsum_n;
     g_colsum_n = 0;
+    const unsigned gx = g_colsum_gx, gy = g_colsum_gy;
+    g_colsum_gx = g_colsum_gy = 0;
     if (n == 0) return VAG_OK;
-    hipLaunchKernelGGL(colsum_multi_kernel, dim3(g_colsum_gx, g_colsum_gy, (unsigned)n), dim3(256), 0, stream, g_colsum);
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3(gx, gy, (unsigned)n), dim3(256), 0, stream, g_colsum);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

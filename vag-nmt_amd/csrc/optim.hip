@@ -1,6 +1,7 @@
 // Fused global-norm clip + Adam over one flat fp32 parameter buffer (train.py:46-49).
-// Two launches: sum of squares (per-block partials; the last block to finish does the scalar work: norm, clip
-// coefficient, bias corrections in double, step counter) and the streaming update (7 x 4 B per parameter).
+// Three launches: sum of squares (per-block partials into 128 slots), scalar prep (norm, clip coefficient, bias
+// corrections in double, step counter; re-zeroes the slots) and the streaming update of every param group in one grid
+// (7 x 4 B per parameter), which also leaves the gradient buffer zeroed for the next step.
 #include "kernels.h"
 
 constexpr int SUMSQ_SLOTS = 128;
@@ -9,21 +10,18 @@ struct AdamScalars {          // lives in the caller's scratch (VAG_ADAM_SCRATCH
     float coef;               // grad_scale * min(1, clip / (norm + 1e-6))
     float bc1;                // 1 - beta1^t
     float bc2_sqrt;           // sqrt(1 - beta2^t)
-    unsigned ticket;          // blocks of the norm pass that have delivered their partial sum
+    float pad;
     // the blocks' partial sums land in 128 slots (2048 double atomics on ONE address serialise in L2: ~25 of the
     // pass's 31 us); the last block to arrive adds the slots up in a fixed order
     double part[SUMSQ_SLOTS];
 };
 static_assert(sizeof(AdamScalars) <= 2048, "vag_clip_adam_flat scratch contract");
 
-// Pass 1: sum of squares of the gradient.  The block whose ticket is the last one also does the scalar work (norm, clip
-// coefficient, bias corrections in double, step counter) and leaves the slots and the ticket zeroed for the next call,
-// so the optimiser step is two launches.
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, AdamScalars* sc, float clip,
-                                                    float grad_scale, float beta1, float beta2, int32_t* step,
-                                                    float* norm_out) {
+// Pass 1: sum of squares of the gradient into 128 slots (plain relaxed atomics, no fences: an in-kernel "last block does the
+// scalar work" variant needs a device-scope fence per block, and 2048 of them cost 80 us -- measured -- against 2 us for
+// the tiny kernel below).
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, AdamScalars* sc) {
     __shared__ double sh[4];
-    __shared__ unsigned last;
     double acc = 0.0;
     const int64_t n4 = n >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -50,20 +48,19 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&sc->part[blockIdx.x % SUMSQ_SLOTS], sh[0] + sh[1] + sh[2] + sh[3]);    // device-scope, memory side
-        __threadfence();
-        last = (atomicAdd(&sc->ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!last || threadIdx.x != 0) return;
-    __threadfence();
+    if (threadIdx.x == 0) atomicAdd(&sc->part[blockIdx.x % SUMSQ_SLOTS], sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// Scalar work between the passes (norm, clip coefficient, bias corrections in double, step counter); leaves the slots zeroed
+// for the next call, so no separate zeroing launch is needed.
+__global__ void adam_prep_kernel(AdamScalars* sc, float clip, float grad_scale, float beta1, float beta2, int32_t* step,
+                                 float* norm_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double ss = 0.0;
     for (int k = 0; k < SUMSQ_SLOTS; ++k) {                        // fixed order
-        ss += __hip_atomic_load(&sc->part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ss += sc->part[k];
         sc->part[k] = 0.0;
     }
-    sc->ticket = 0u;
     sc->sumsq = ss;
     const double norm = sqrt(ss) * (double)grad_scale;             // norm of the scaled (averaged) gradient
     double c = (double)clip / (norm + 1e-6);                        // torch.nn.utils.clip_grad_norm_
@@ -116,13 +113,11 @@ int vag_clip_adam_launch(float* p, float* g, float* m, float* v, int64_t n, int 
                   scratch);
     VAG_CHECK_ARG(aligned16(g) && seg_off[0] == 0 && seg_off[nseg] == n);
     AdamScalars* sc = reinterpret_cast<AdamScalars*>(scratch);
-    // few enough blocks that the arrival tickets (one address) do not serialise the pass: 512 x 256 threads x 4 loads of
-    // 16 B in flight = 8 MB outstanding
-    int64_t blocks = cdiv64(n / 4 + 1, 256 * 4);
-    if (blocks > 512) blocks = 512;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, n, sc, clip, grad_scale, beta1, beta2, step,
-                       norm_out);
+    int64_t blocks = cdiv64(n / 4 + 1, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, n, sc);
+    VAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, sc, clip, grad_scale, beta1, beta2, step, norm_out);
     VAG_LAUNCH_CHECK();
     AdamSegs sg;
     int64_t maxcnt = 0;

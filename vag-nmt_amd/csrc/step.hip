@@ -154,10 +154,18 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
         }
         VAG_TRY(vag_dec_init_fwd(k.enc, k.mask, mm ? k.ctx : nullptr, mm ? c.init_split : 0.f, w.ini_w, w.ini_b, B, Ts, C, H,
                                  k.xmix, h0, stream));                                                  // V11.py:118
-        VAG_TRY(vag_attn_keys_proj(k.enc, w.attn_e, B * Ts, C, k.pe, stream));                          // NMT_Decoder.py:47
-        VAG_TRY(vag_cgru_attn_decode_seq_fwd(k.enc, k.pe, k.mask, h0, k.tok, w.dec, B, Ts, Tt, Et, H, V, h2_all, k.c_all,
-                                             k.e_all, k.ws_dec, c.free_run, &w.head, c.p_out, crng, k.tmid, k.logits, c.ldl,
-                                             stream));                                                  // V11.py:138-160
+        {
+            // the key projection joins the decoder's per-batch products (projected keys, input projection of every step) in
+            // one grouped launch: the bracket is flushed by the decoder operator's own bracket before its time loop starts.
+            // (Only with the driver's derived weights: otherwise the operator first builds W_ih2 W_c2h, which the queue
+            // would hold back.)
+            VagGemmGroup outer(derived != nullptr);
+            VAG_TRY(vag_attn_keys_proj(k.enc, w.attn_e, B * Ts, C, k.pe, stream));                      // NMT_Decoder.py:47
+            VAG_TRY(vag_cgru_attn_decode_seq_fwd(k.enc, k.pe, k.mask, h0, k.tok, w.dec, B, Ts, Tt, Et, H, V, h2_all, k.c_all,
+                                                 k.e_all, k.ws_dec, c.free_run, &w.head, c.p_out, crng, k.tmid, k.logits,
+                                                 c.ldl, stream));                                       // V11.py:138-160
+            VAG_TRY(outer.end(s));
+        }
         VAG_TRY(vag_head_ce_seq_fwd_impl(h2_all, k.c_all, k.e_all, w.head, tgt, vocab_weight, B, Tt, Et, H, V, c.p_out, crng,
                                          c.free_run ? 1 : 0, k.tmid, k.logits, c.ldl, k.lse, k.nll, k.inv_cnt, 1, nullptr,
                                          losses, w_mt, w_vse, has_vse ? 1 : 0, s));                     // V11.py:140,164-166
@@ -166,10 +174,18 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
         VAG_TRY(vag_head_ce_seq_bwd(h2_all, k.c_all, k.e_all, w.head, tgt, vocab_weight, B, Tt, Et, H, V, c.p_out, crng, k.tmid,
                                     k.logits, c.ldl, k.lse, k.inv_cnt, k.consts + 0, k.d_h2, k.d_c, k.d_e, g.head, k.scr_head,
                                     stream));
-        VAG_TRY(vag_cgru_attn_decode_seq_bwd(k.enc, k.pe, k.mask, h0, k.tok, w.dec, B, Ts, Tt, Et, H, V, h2_all, k.c_all,
-                                             k.e_all, k.d_h2, k.d_c, k.d_e, k.ws_dec, k.d_enc, 0, k.d_pe, k.d_h0, g.dec,
-                                             k.scr_dec, stream));
-        VAG_TRY(vag_attn_keys_proj_bwd(k.enc, w.attn_e, k.d_pe, B * Ts, C, k.d_enc, 1, g.attn_e, stream));
+        {
+            // after the backward recurrence: the products that add into d_enc (projected keys, attention keys) and the weight
+            // gradients of the decoder and of attn_e are queued by layout and go out as two grouped launches
+            VagGemmGroup outer(true);
+            VAG_TRY(vag_cgru_attn_decode_seq_bwd_loop(k.enc, k.pe, k.mask, h0, k.tok, w.dec, B, Ts, Tt, Et, H, V, h2_all, k.c_all,
+                                                      k.e_all, k.d_h2, k.d_c, k.d_e, k.ws_dec, k.d_enc, 0, k.d_pe, k.d_h0,
+                                                      k.scr_dec, stream));
+            VAG_TRY(vag_attn_keys_proj_bwd(k.enc, w.attn_e, k.d_pe, B * Ts, C, k.d_enc, 1, g.attn_e, stream));
+            VAG_TRY(vag_cgru_attn_decode_seq_bwd_weights(h0, k.tok, w.dec, B, Ts, Tt, Et, H, h2_all, k.c_all, k.e_all, k.d_e,
+                                                         k.ws_dec, g.dec, k.scr_dec, stream));
+            VAG_TRY(outer.end(s));
+        }
         if (mm) {
             if (has_vse) {
                 VAG_TRY(vag_rank_loss_bwd(k.im_emb, k.txt_emb, k.G, k.consts + 1, B, S, k.d_im, k.d_txt, stream));

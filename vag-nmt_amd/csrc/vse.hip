@@ -2,24 +2,32 @@
 // max-margin ranking loss over the BxB similarity matrix (loss value and d loss / d scores in one pass).
 #include "kernels.h"
 
-// one wave per row
+// one 256-thread block per row (rows are a mini-batch: few of them, so a wave per row leaves the chip idle and pays a
+// dependent load round per 64 elements)
+__device__ __forceinline__ float vse_block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return r;
+}
 __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ y, int64_t B, int S,
                                                          float* __restrict__ nrm, float* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = blockIdx.x * 4ll + (threadIdx.x >> 6);
-    if (b >= B) return;
+    __shared__ float sh[4];
+    const int64_t b = blockIdx.x;
     const float* r = y + b * S;
     float ss = 0.f;
-    for (int j = lane; j < S; j += 64) ss += r[j] * r[j];
-    ss = wave_sum(ss);
+    for (int j = threadIdx.x; j < S; j += 256) ss += r[j] * r[j];
+    ss = vse_block_sum(ss, sh);
     const float n = fmaxf(sqrtf(ss), 1e-12f);       // utils/utils.py:10  clamp(min=eps)
-    if (lane == 0) nrm[b] = n;
+    if (threadIdx.x == 0) nrm[b] = n;
     const float inv = 1.f / n;
-    for (int j = lane; j < S; j += 64) out[b * S + j] = r[j] * inv;
+    for (int j = threadIdx.x; j < S; j += 256) out[b * S + j] = r[j] * inv;
 }
 int vag_l2norm_fwd_launch(const float* y, int64_t B, int64_t S, float* nrm, float* out, hipStream_t s) {
     VAG_CHECK_ARG(y && nrm && out && B > 0 && S > 0);
-    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)cdiv64(B, 4)), dim3(256), 0, s, y, B, (int)S, nrm, out);
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)B), dim3(256), 0, s, y, B, (int)S, nrm, out);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
@@ -28,16 +36,15 @@ int vag_l2norm_fwd_launch(const float* y, int64_t B, int64_t S, float* nrm, floa
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ nrm,
                                                          const float* __restrict__ out, const float* __restrict__ d_out,
                                                          int64_t B, int S, int act, float* __restrict__ dy) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = blockIdx.x * 4ll + (threadIdx.x >> 6);
-    if (b >= B) return;
+    __shared__ float sh[4];
+    const int64_t b = blockIdx.x;
     const float n = nrm[b];
     float dot = 0.f;
-    for (int j = lane; j < S; j += 64) dot += out[b * S + j] * d_out[b * S + j];
-    dot = wave_sum(dot);
+    for (int j = threadIdx.x; j < S; j += 256) dot += out[b * S + j] * d_out[b * S + j];
+    dot = vse_block_sum(dot, sh);
     if (!(n > 1e-12f)) dot = 0.f;
     const float inv = 1.f / n;
-    for (int j = lane; j < S; j += 64) {
+    for (int j = threadIdx.x; j < S; j += 256) {
         float g = (d_out[b * S + j] - out[b * S + j] * dot) * inv;
         if (act) {
             const float yy = y[b * S + j];
@@ -49,8 +56,7 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 int vag_l2norm_bwd_launch(const float* y, const float* nrm, const float* out, const float* d_out, int64_t B, int64_t S,
                           int act, float* dy, hipStream_t s) {
     VAG_CHECK_ARG(y && nrm && out && d_out && dy && B > 0 && S > 0);
-    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)cdiv64(B, 4)), dim3(256), 0, s, y, nrm, out, d_out, B, (int)S,
-                       act, dy);
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)B), dim3(256), 0, s, y, nrm, out, d_out, B, (int)S, act, dy);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

@@ -11,7 +11,7 @@ with these changes in mechanism, none in arithmetic:
     all-reduces the first bucket while the encoder's backward recurrence is still running;
   * forward + backward of a mini-batch is ONE call into the library (vag_train_step) on one static workspace, captured
     once per batch shape into a HIP graph and replayed;
-  * global-norm clipping and Adam are one fused pass over the flat buffer (vag_clip_adam_flat, two launches) that also
+  * global-norm clipping and Adam are one fused pass over the flat buffer (vag_clip_adam_flat, three launches) that also
     leaves the gradient buffer zeroed for the next step, followed by the refresh of the derived weights;
 and, for data parallelism (one process per GPU over torch.distributed, backend "nccl" = RCCL), bucketed sum all-reduces
 of the flat gradient between the backward phases and the optimiser (clipping acts on the averaged gradient, exactly what
