@@ -140,7 +140,7 @@ def _time_graph(fn, reps=20):
     return s.elapsed_time(e) / reps * 1e-3
 
 
-def measure_operators(c, dev):
+def measure_operators(c, dev, storage16=False):
     """Live timings for the roofline block:
       decoder_seq_fwd : one vag_cgru_attn_decode_seq_fwd call = Tt GRU+attention steps (4 kernels each) + the per-batch
                         key projection and context products around the loop
@@ -152,6 +152,27 @@ def measure_operators(c, dev):
     src, lens, tgt, im = make_batch(c, 0, dev)
     lens_t = torch.tensor(lens, dtype=torch.int32, device=dev)
     out = {}
+    B, H = c["B"], c["H"]
+    derived = None
+    if storage16:
+        # operator-level access to the 2-byte storage mode: fp16 copies of the recurrent weights in a derived buffer, and the
+        # per-operator entry points switched to it on this thread for the measurements below
+        from vagnmt_hip.ops import _dec_w
+        g = m.encoder.gru
+        derived = torch.empty(_lib.lib().vag_derived_floats(H), dtype=torch.float32, device=dev)
+        call("vag_derive_weights", _dec_w(m.decoder.embedding.weight, m.decoder.dec_params()), ptr(g.weight_hh_l0),
+             ptr(g.weight_hh_l0_reverse), H, 1, ptr(derived), stream())
+        call("vag_set_operator_context", ptr(derived), 1)
+    try:
+        return _measure_operators(c, dev, m, src, lens_t, tgt, im, out)
+    finally:
+        if storage16:
+            call("vag_set_operator_context", None, 0)
+
+
+def _measure_operators(c, dev, m, src, lens_t, tgt, im, out):
+    from vagnmt_hip import ops
+    from vagnmt_hip._lib import ptr, call, stream
     B, H = c["B"], c["H"]
     with torch.no_grad():
         enc, mask = m._encode(src, lens_t, None)
@@ -334,8 +355,9 @@ def main():
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="debug: disable the reference dropouts")
     ap.add_argument("--no-fused", action="store_true", help="debug: per-operator autograd path instead of vag_train_step")
-    ap.add_argument("--config", choices=["cfg2", "cfg5-f32"], default="cfg2",
-                    help="cfg2 = BASELINE configs[1] (the metric's configuration); cfg5-f32 = configs[4] sizes in fp32")
+    ap.add_argument("--config", choices=["cfg2", "cfg5", "cfg5-f32"], default="cfg2",
+                    help="cfg2 = BASELINE configs[1] (the metric's configuration); cfg5 = configs[4] (H=1024, T=80, B=256, "
+                         "V=40k) with fp16 storage of the per-step streams; cfg5-f32 = the same sizes, fp32 storage")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -372,7 +394,8 @@ def main():
     crit_mt = torch.nn.NLLLoss(weight=vw, reduction="none")
     crit_vse = PairwiseRankingLoss(margin=0.1)
     ts = TrainStep(model, crit_mt, crit_vse, lr=4e-4, weight_decay=1e-5, clip=1.0, teacher_force_ratio=args.tfr,
-                   use_graph=not args.no_graph, process_group=pg, world_size=world, fused=not args.no_fused)
+                   use_graph=not args.no_graph, process_group=pg, world_size=world, fused=not args.no_fused,
+                   storage="f16" if args.config == "cfg5" else "f32")
     src, lens, tgt, im = make_batch(c, rank, dev, ragged=args.ragged)
     lens_t = torch.tensor(lens, dtype=torch.int32, device=dev)
 
@@ -437,11 +460,12 @@ def main():
                    "gradient_bytes": ts.fp.n * 4, "buckets_bytes": [(hi - lo) * 4 for lo, hi in ts.fp.buckets()],
                    "backend": dist.get_backend(), "steps": n}
     if rank == 0:
-        ab = algorithmic_bytes(c)
+        # configs[4] prices every streamed element at 2 bytes (F_dec = 199.3 MB)
+        ab = algorithmic_bytes(c, w=2 if args.config == "cfg5" else 4)
         if args.no_operators:
             print(json.dumps({"ms_per_step": dt / args.steps * 1e3, "final_loss": loss}))
             return
-        fam = measure_operators(c, dev)
+        fam = measure_operators(c, dev, storage16=(args.config == "cfg5"))
         log("operator timings: %s" % fam)
         B, H = c["B"], c["H"]
         t_dec_step = fam["decoder_seq_fwd"] / c["Tt"]
@@ -461,11 +485,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f16" if args.config == "cfg5" else "f32",
             "data": "synthetic",
             "config": {"workload": "%s: multimodal en->de train step, B=%d/GPU, Ts=Tt=%d, E=%d, H=%d, S=%d, "
                                    "I=%d, Vs=%d, V=%d, dropout 0.3/0.5/0.5, tied emb, teacher_force_ratio=%g%s"
-                                   % ("configs[1]" if args.config == "cfg2" else "configs[4] sizes, fp32 storage",
+                                   % ("configs[1]" if args.config == "cfg2" else
+                                      ("configs[4] (fp16 storage of recurrent weights and attention keys, fp32 accumulate)"
+                                       if args.config == "cfg5" else "configs[4] sizes, fp32 storage"),
                                       c["B"], c["Ts"], c["E"], c["H"], c["S"], c["I"], c["Vs"], c["V"],
                                       args.tfr, ", ragged source lengths" if args.ragged else ""),
                        "global_batch": c["B"] * world, "parallelism": "dp%d" % world,

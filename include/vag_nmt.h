@@ -352,7 +352,11 @@ typedef struct {
     int32_t activation_vse;               /* tanh on the shared-space projections */
     int32_t rank_kind;                    /* 0 pairwise, 1 image retrieval, -1 no criterion_vse (loss_vse = 0) */
     int32_t free_run;                     /* 0 teacher forcing, 1 feed back the argmax (V11.py:148-160) */
-    int32_t reserved;
+    int32_t storage;                      /* 0: everything fp32.  1 (BASELINE configs[4], "fp16"): what the recurrences stream at
+                                           * every time step -- their weights and the attention keys / projected keys -- is
+                                           * kept as fp16 in HBM; accumulation, master weights, recurrent state, saved gates and
+                                           * all gradients stay fp32.  Teacher-forced steps only; needs `derived` built with
+                                           * with_fp16 and H % 8 == 0 */
     float margin, loss_w, init_split, p_emb, p_ctx, p_out;
 } vag_step_cfg;
 /* phases: bit 0 forward (losses[0..2] = loss, loss_mt, loss_vse), bit 1 backward down to the encoder states (final for
@@ -365,14 +369,20 @@ int64_t vag_step_ws_offset(const vag_step_cfg* cfg, int which);
 int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* w, const vag_model_g* g, const int64_t* src,
                    const int32_t* lengths, const int64_t* tgt, const float* im, const float* vocab_weight, uint64_t* rng,
                    const float* derived, float* ws, float* losses, int phases, vag_stream_t stream);
+/* The per-operator entry points (vag_bigru_seq_*, vag_attn_keys_proj, vag_cgru_attn_decode_seq_*) normally rebuild the
+ * derived weights inside their workspaces and use fp32 storage.  This sets, for the CALLING THREAD until changed, the
+ * driver-owned derived buffer they should read instead and the storage mode (vag_step_cfg.storage); vag_train_step does the
+ * same for the duration of its call.  derived = NULL, storage = 0 restores the defaults. */
+int vag_set_operator_context(const float* derived, int storage);
 /* Up to four contiguous device byte ranges copied by one launch (src[i] -> dst[i], bytes[i]; host arrays): a batch's
  * src / lengths / tgt / image rows into the step driver's static input buffers. */
 int vag_copy4(const void* const* src, void* const* dst, const int64_t* bytes, int n, vag_stream_t stream);
 /* Weights derived from the parameters alone ([attn_h; gru_2.w_hh] stacked and transposed, gru_2.w_ih . context2hid,
- * gru_1.w_hh^T, both encoder w_hh^T): per optimiser step, not per training step. */
+ * gru_1.w_hh^T, both encoder w_hh^T): per optimiser step, not per training step.  with_fp16: also the fp16 copies of the
+ * recurrent matrices the 2-byte storage mode reads (vag_step_cfg.storage = 1; H % 8 == 0). */
 int64_t vag_derived_floats(int64_t H);
-int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_whh_bw, int64_t H, float* derived,
-                       vag_stream_t stream);
+int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_whh_bw, int64_t H, int with_fp16,
+                       float* derived, vag_stream_t stream);
 
 /* ---- dropout helpers ---------------------------------------------------------------------------------- */
 /* which: 1 encoder-embedding (Ts,B,E), 2 encoder-context (B,Ts,2H), 3 decoder-output (Tt,B,E). */

@@ -341,3 +341,76 @@ def test_beam12_at_config_size_matches_oracle():
     assert np.allclose(scores, want_scores.numpy(), rtol=2e-4, atol=2e-4), np.abs(scores - want_scores.numpy()).max()
     assert sum(a == b for a, b in zip(got, want)) >= 15, [i for i, (a, b) in enumerate(zip(got, want)) if a != b]
     assert sum(a == b for a, b in zip(got_g, want_g)) >= 15
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: 2-byte ("fp16") storage of what the recurrences stream per time step, fp32 accumulation
+# ------------------------------------------------------------------------------------------------------------------
+def _fp16_case(name):
+    if name == "mid":
+        meta, P, z = load_golden("mm_dot_tied_mid_f32")            # H = 64, B = 16, Ts = Tt = 12, ragged
+        m_of = lambda: build(meta, P)                               # noqa: E731
+        src, lens, tgt, im = _inputs(meta, z)
+        cm, cv = criteria(meta)
+        return m_of, (src, lens, tgt, im), cm, cv
+    # "wide": configs[4] widths (H=1024, B=256, 2048-d features) at reduced length / vocabulary -- the fp16 twin of
+    # test_edge_shapes[wide]
+    lens = sorted([int(x) for x in torch.randint(1, 7, (256,), generator=torch.Generator().manual_seed(9))], reverse=True)
+    lens[0] = 6
+    m0, src, tgt, im = make(700, 1003, 2048, 256, 1024, 512, 256, 6, 5, lens, seed=7)
+    state = {k: v.clone() for k, v in m0.state_dict().items()}
+
+    def m_of():
+        m, _, _, _ = make(700, 1003, 2048, 256, 1024, 512, 256, 6, 5, lens, seed=7)
+        m.load_state_dict(state)
+        return m.cuda()
+    from machine_translation_vision.losses import PairwiseRankingLoss
+    vw = torch.ones(1003, device="cuda")
+    vw[0] = 0
+    return m_of, (src.cuda(), lens, tgt.cuda(), im.cuda()), torch.nn.NLLLoss(weight=vw, reduction="none"), PairwiseRankingLoss(0.1)
+
+
+@pytest.mark.parametrize("name", ["mid", "wide"])
+def test_fp16_storage_step_against_fp32(name):
+    """fp16 storage changes what is READ per time step (weights, keys), not the arithmetic: losses within 2e-3 of the fp32
+    path (itself within 1e-4 of the reference), gradients within 1e-2 of each tensor's largest entry; and the mode is
+    really on (the keys in the workspace are fp16 bit patterns, the loss differs from the fp32 one)."""
+    from vagnmt_hip import _lib as L
+    from vagnmt_hip.trainer import TrainStep
+    m_of, (src, lens, tgt, im), cm, cv = _fp16_case(name)
+    lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    out = {}
+    for storage in ("f32", "f16"):
+        m = m_of()
+        ts = TrainStep(m, cm, cv, use_graph=False, storage=storage, pad_src=1)
+        m.eval()
+        ts.backend.run(src, lt, tgt, im, True, 7)
+        losses = [float(x) for x in ts.backend.outputs()]
+        grads = {n: p._vag_grad.detach().clone() for n, p in m.named_parameters()}
+        f = ts.backend.f
+        B, Ts = src.shape
+        c = f.cfg(B, Ts, tgt.shape[1], True, False)
+        # pe sits right after enc, mask and the encoder workspace: read its first words as stored
+        off_enc = L.lib().vag_step_ws_offset(C.byref(c), 0)
+        out[storage] = (losses, grads, int(c.storage), off_enc)
+        if storage == "f16":
+            ts._optimizer()          # the optimiser refreshes the fp16 weight copies: a second step must still work
+            ts.backend.run(src, lt, tgt, im, True, 7)
+            assert np.isfinite([float(x) for x in ts.backend.outputs()]).all()
+    (l32, g32, s32, _), (l16, g16, s16, _) = out["f32"], out["f16"]
+    assert s32 == 0 and s16 == 1
+    assert np.allclose(l16, l32, rtol=2e-3, atol=2e-4), (l16, l32)
+    assert l16 != l32                                   # not silently the fp32 path
+    for n in g32:
+        scale = max(g32[n].abs().max().item(), 1e-6)
+        err = (g16[n] - g32[n]).abs().max().item()
+        assert err <= 1e-2 * scale, (n, err, scale)
+
+
+def test_fp16_storage_trains_and_free_running_steps_fall_back_to_fp32_storage():
+    from vagnmt_hip.trainer import TrainStep
+    m_of, (src, lens, tgt, im), cm, cv = _fp16_case("mid")
+    m = m_of()
+    ts = TrainStep(m, cm, cv, use_graph=True, storage="f16")
+    losses = [float(ts.step(src, lens, tgt, im, teacher=(i % 3 != 2))[0]) for i in range(9)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses

@@ -41,10 +41,25 @@ static int gemm_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
 // call through this thread-local (same pattern as the grouped-GEMM bracket: one host thread drives a stream).
 static thread_local const float* g_derived = nullptr;
 void vag_set_derived_override(const float* d) { g_derived = d; }
+// 2-byte storage mode of the step driver (vag_step_cfg.storage = 1): the tensors the recurrences stream at every time step
+// -- their weights (fp16 copies in the derived buffer) and the attention keys pe / projected keys encwp -- are fp16 in
+// memory; every product still accumulates in fp32, master weights, recurrent state, saved gates and all gradients stay fp32.
+static thread_local bool g_store16 = false;
+void vag_set_store16(bool on) { g_store16 = on; vag_gemm_set_planes(on ? 2 : 3); }
+static inline const float* as_f(const vag_half* p) { return reinterpret_cast<const float*>(p); }
 
 extern "C" {
 
 int vag_version(void) { return 200; }
+
+// Operator-level access to what vag_train_step sets up for itself: the derived-weights buffer and the storage mode the
+// per-operator entry points use ON THE CALLING THREAD until changed (derived NULL / storage 0 = the defaults).
+int vag_set_operator_context(const float* derived, int storage) {
+    VAG_CHECK_ARG(storage == 0 || (storage == 1 && derived));
+    g_derived = derived;
+    vag_set_store16(storage == 1);
+    return VAG_OK;
+}
 
 int vag_gemm_f32(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak, const float* B,
                  int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc, const float* bias, int act,
@@ -81,6 +96,9 @@ int vag_embed_bwd(const int64_t* idx, int64_t n, const float* d_out, int64_t E, 
 // read: wcatT (H, C+3H), whh1T (H, 3H), encT (2 x (H, 3H): forward / reverse encoder W_hh^T).
 struct DerivedW {
     float *prep, *wcatT, *whh1T, *encT;
+    // fp16 copies for the 2-byte storage mode (element counts in halves; each region starts 256-byte aligned):
+    // wcat16 (Q,H), wcatT16 (H,Q), whh1_16 (3H,H), whh1T16 (H,3H), enc16 (2 x (3H,H)), encT16 (2 x (H,3H))
+    vag_half *wcat16, *wcatT16, *whh1_16, *whh1T16, *enc16, *encT16;
     int64_t total;
 };
 static int64_t cgru_prep_total(int64_t H);
@@ -89,7 +107,10 @@ static DerivedW derived_layout(float* p, int64_t H) {
     const int64_t C = 2 * H, Q = C + 3 * H;
     int64_t o = 0;
     auto take = [&](int64_t n) { float* q = p ? p + o : nullptr; o += (n + 63) & ~63ll; return q; };
+    auto take16 = [&](int64_t nh) { return reinterpret_cast<vag_half*>(take((nh + 1) / 2)); };
     w.prep = take(cgru_prep_total(H)); w.wcatT = take(Q * H); w.whh1T = take(3 * H * H); w.encT = take(2 * 3 * H * H);
+    w.wcat16 = take16(Q * H); w.wcatT16 = take16(Q * H); w.whh1_16 = take16(3 * H * H); w.whh1T16 = take16(3 * H * H);
+    w.enc16 = take16(2 * 3 * H * H); w.encT16 = take16(2 * 3 * H * H);
     w.total = o;
     return w;
 }
@@ -141,20 +162,23 @@ int vag_bigru_seq_fwd(const int64_t* src, const int32_t* lengths, const float* e
     GruStepArgs a = {};
     a.lda = H; a.ldw = H; a.ldother = 6 * H; a.ldh = H; a.ld2 = Ts * 2 * H;
     a.M = (int)B; a.K = (int)H; a.H = (int)H; a.lengths = lengths; a.comp_hidden = 1;
+    const bool s16 = g_store16 && g_derived;
+    VAG_CHECK_ARG(!g_store16 || (g_derived && H % 8 == 0));
+    const vag_half* w16 = s16 ? derived_layout(const_cast<float*>(g_derived), H).enc16 : nullptr;
     for (int64_t k = 0; k < Ts; ++k) {
         for (int d = 0; d < 2; ++d) {
             const int64_t t = d == 0 ? k : Ts - 1 - k;
             const vag_gru_w& g = d == 0 ? fw : bw;
             float* hs = w.hst + d * (Ts + 1) * BH;
             GruSide& sd = a.s[d];
-            sd.A = hs + k * BH; sd.W = g.w_hh; sd.bias = g.b_hh;
+            sd.A = hs + k * BH; sd.W = s16 ? as_f(w16 + d * 3 * H * H) : g.w_hh; sd.bias = g.b_hh;
             sd.other = w.xp + t * B * 6 * H + d * 3 * H;
             sd.hprev = hs + k * BH; sd.hout = hs + (k + 1) * BH;
             sd.out2 = enc + t * 2 * H + d * H;
             sd.save = w.gates + (d * Ts + k) * 4 * BH;
             sd.t = (int)t;
         }
-        VAG_TRY(vag_gru_step_launch(a, 2, s));
+        VAG_TRY(vag_gru_step_launch(a, 2, s, s16));
     }
     VAG_TRY(vag_dropout_apply_launch(enc, B * Ts * 2 * H, 0, rng, VAG_DROP_ENC_CTX, p_ctx, s));
     return VAG_OK;
@@ -169,7 +193,11 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
     const int64_t R = Ts * B, BH = B * H;
     float* d_xp = w.xp;      // forward input projections are no longer needed (gates are saved)
     const float* whhT = w.whhT;
-    if (g_derived) {
+    const bool s16 = g_store16 && g_derived;
+    VAG_CHECK_ARG(!g_store16 || (g_derived && H % 8 == 0));
+    if (s16) {
+        whhT = as_f(derived_layout(const_cast<float*>(g_derived), H).encT16);
+    } else if (g_derived) {
         whhT = derived_layout(const_cast<float*>(g_derived), H).encT;
     } else {
         for (int d = 0; d < 2; ++d) {
@@ -210,7 +238,7 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
             const int64_t t1 = d == 0 ? k1 : Ts - 1 - k1;
             GruBwdStepSide& sd = f.s[d];
             sd.A = w.dgh + (d * Ts + k) * B * 3 * H;
-            sd.WT = whhT + d * 3 * H * H;
+            sd.WT = s16 ? as_f(reinterpret_cast<const vag_half*>(whhT) + d * 3 * H * H) : whhT + d * 3 * H * H;
             sd.addend = w.carry + (d * 2 + cur) * BH;
             sd.dh_add = d_enc + t1 * 2 * H + d * H;
             sd.drop_idx0 = t1 * 2 * H + d * H;
@@ -222,7 +250,7 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
             sd.dh_out = nullptr;
             sd.t = (int)t1;
         }
-        VAG_TRY(vag_gru_bwd_step_launch(f, 2, s));
+        VAG_TRY(vag_gru_bwd_step_launch(f, 2, s, s16));
         cur ^= 1;
     }
     VagGemmGroup grp1;      // the four weight gradients (both directions) go out as one grouped launch
@@ -282,6 +310,8 @@ int vag_gru_cell_bwd(const float* dgh_next, const float* w_hh_t, const float* ca
 // =====================================================================================================
 int vag_attn_keys_proj(const float* enc, const float* attn_e, int64_t rows, int64_t C, float* pe, vag_stream_t stream) {
     VAG_CHECK_ARG(enc && attn_e && pe && rows > 0 && C > 0);
+    if (g_store16)      // 2-byte storage mode: the keys are written as fp16
+        return vag_gemm_launch(rows, C, C, 1.f, enc, C, 1, attn_e, 1, C, 0.f, pe, C, nullptr, 0, S_(stream), 1);
     return linear_fwd(rows, C, C, enc, C, attn_e, nullptr, 0, pe, C, S_(stream));
 }
 // a4 stand-alone (inference): alpha = softmax_s(v . tanh(pe_s + q)), ctx = sum_s alpha_s enc_s
@@ -346,8 +376,8 @@ int vag_cgru_prepare(vag_dec_w w, int64_t H, float* prep, vag_stream_t stream) {
 // Everything the recurrences read that is a function of the parameters alone, refreshed once per optimiser step by a
 // step driver (the stand-alone operators rebuild their share per call): [attn_h; W_hh2] stacked and transposed, the
 // folded W_ih2 W_c2h, W_hh1^T, both encoder W_hh^T.  derived: vag_derived_floats(H) floats.
-int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_whh_bw, int64_t H, float* derived,
-                       vag_stream_t stream) {
+int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_whh_bw, int64_t H, int with_fp16,
+                       float* derived, vag_stream_t stream) {
     hipStream_t s = S_(stream);
     VAG_CHECK_ARG(dec_w_ok(w) && enc_whh_fw && enc_whh_bw && derived && H > 0 && H % 4 == 0 && aligned16(derived));
     const int64_t C = 2 * H, Q = C + 3 * H;
@@ -365,6 +395,23 @@ int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_wh
         {enc_whh_bw, d.encT + 3 * H * H, 3 * H, H, H, 3 * H, 2},
     };
     VAG_TRY(vag_jobs_launch(jobs, 9, s));
+    if (with_fp16) {        // fp16 copies of what the recurrences re-read every time step (2-byte storage mode)
+        VAG_CHECK_ARG(H % 8 == 0);
+        auto h = [&](vag_half* q) { return reinterpret_cast<float*>(q); };
+            const VagJob j16[10] = {
+            {w.attn_h, h(d.wcat16), C, H, H, H, 3},
+            {w.gru2.w_hh, h(d.wcat16 + C * H), 3 * H, H, H, H, 3},
+            {w.attn_h, h(d.wcatT16), C, H, H, Q, 4},
+            {w.gru2.w_hh, h(d.wcatT16 + C), 3 * H, H, H, Q, 4},
+            {w.gru1.w_hh, h(d.whh1_16), 3 * H, H, H, H, 3},
+            {w.gru1.w_hh, h(d.whh1T16), 3 * H, H, H, 3 * H, 4},
+            {enc_whh_fw, h(d.enc16), 3 * H, H, H, H, 3},
+            {enc_whh_bw, h(d.enc16 + 3 * H * H), 3 * H, H, H, H, 3},
+            {enc_whh_fw, h(d.encT16), 3 * H, H, H, 3 * H, 4},
+            {enc_whh_bw, h(d.encT16 + 3 * H * H), 3 * H, H, H, 3 * H, 4},
+        };
+        VAG_TRY(vag_jobs_launch(j16, 10, s));
+    }
     return gemm_nn(3 * H, C, H, w.gru2.w_ih, H, w.c2h, C, 0.f, p.wp, C, s);      // Wp = W_ih2 W_c2h
 }
 
@@ -461,6 +508,11 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
     // and always works on the projected keys.
     static const bool opt_hoist = getenv("VAG_CGRU_NOHOIST") == nullptr;
     const bool hoist = opt_hoist && !free_run;
+    // 2-byte storage mode: teacher-forced (hoisted) path only, weights from the driver's derived buffer
+    const bool s16 = g_store16;
+    VAG_CHECK_ARG(!s16 || (hoist && g_derived && H % 8 == 0 && Ts * B < (1ll << 28)));
+    DerivedW dw16 = {};
+    if (s16) dw16 = derived_layout(const_cast<float*>(g_derived), H);
     {
         VagGemmGroup grp;
         if (!free_run) {
@@ -468,7 +520,7 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
             VAG_TRY(vag_embed_gather_launch(tok, B, 1, Tt, B, w.emb, E, e_all, nullptr, 0, 0.f, s));
             VAG_TRY(vag_gemm_launch(Tt * B, 3 * H, E, 1.f, e_all, E, 1, w.gru1.w_ih, 1, E, 0.f, k.xp1, 3 * H, w.gru1.b_ih, 0, s));
         }
-        VAG_TRY(vag_gemm_launch(B * Ts, 3 * H, C, 1.f, enc, C, 1, p.wp, 1, C, 0.f, k.encwp, 3 * H, nullptr, 0, s));
+        VAG_TRY(vag_gemm_launch(B * Ts, 3 * H, C, 1.f, enc, C, 1, p.wp, 1, C, 0.f, k.encwp, 3 * H, nullptr, 0, s, s16 ? 1 : 0));
         VAG_TRY(grp.end(s));
     }
     for (int64_t t = 0; hoist && t < Tt; ++t) {
@@ -478,9 +530,18 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
         GruStepArgs a = {};
         a.lda = H; a.ldw = H; a.ldother = 3 * H; a.ldh = H; a.ld2 = 0;
         a.M = (int)B; a.K = (int)H; a.H = (int)H; a.lengths = nullptr; a.comp_hidden = 1;
-        a.s[0].A = hprev; a.s[0].W = w.gru1.w_hh; a.s[0].bias = w.gru1.b_hh; a.s[0].other = k.xp1 + t * B * 3 * H;
+        a.s[0].A = hprev; a.s[0].W = s16 ? as_f(dw16.whh1_16) : w.gru1.w_hh; a.s[0].bias = w.gru1.b_hh;
+        a.s[0].other = k.xp1 + t * B * 3 * H;
         a.s[0].hprev = hprev; a.s[0].hout = h1; a.s[0].out2 = nullptr; a.s[0].save = k.g1 + t * 4 * BH; a.s[0].t = 0;
-        VAG_TRY(vag_gru_step_launch(a, 1, s));                                                              // gru_1 :121
+        VAG_TRY(vag_gru_step_launch(a, 1, s, s16));                                                         // gru_1 :121
+        if (s16) {
+            VAG_TRY(vag_skinny_launch(B, C, H, h1, H, as_f(dw16.wcat16), H, nullptr, nullptr, 0, qhp, Q, 0, s, true));  // :47
+            VAG_TRY(vag_attn_dot_side_launch(0, pe, qhp, Q, w.attn_v, mask, nullptr, B, Ts, C, k.scores, B, 3 * H, H, h1, H,
+                                             as_f(dw16.wcat16 + C * H), H, p.bcat + C, nullptr, qhp + C, Q, s, true));
+            VAG_TRY(vag_attn_ctx_gru_launch(k.scores, k.encwp, B, 1, Ts, H, w.gru2.b_ih, qhp + C, Q, h1, k.alpha + t * B * Ts,
+                                            h2_all + t * BH, k.g2 + t * 4 * BH, s, true));
+            continue;
+        }
         // Experiment kept for the record: 3 launches per step with the attention half in ONE kernel.  Measured
         // slower (27.7 vs 23.7 us per step): without a cross-workgroup exchange every workgroup of a row recomputes all its
         // scores, and the 4x tanh work (3.2 us per workgroup) costs more than the launch it saves.  Off unless VAG_CGRU_FUSE=1.
@@ -569,10 +630,15 @@ int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const f
     CgruWs k = cgru_ws(ws, B, Ts, Tt, E, H);
     CgruPrep p = cgru_prep(k.prep, H);          // Wcat / Wp from the forward call are still in the workspace
     CgruBwdScratch z = cgru_bwd_scratch(scratch, B, Ts, Tt, E, H);
+    const bool s16 = g_store16;
+    VAG_CHECK_ARG(!s16 || (g_derived && H % 8 == 0));
     if (g_derived) {
         DerivedW dw = derived_layout(const_cast<float*>(g_derived), H);
         p = cgru_prep(dw.prep, H);
         z.wcatT = dw.wcatT; z.whh1T = dw.whh1T;
+        if (s16) {      // the same two transposes as fp16 (element strides are unchanged)
+            z.wcatT = const_cast<float*>(as_f(dw.wcatT16)); z.whh1T = const_cast<float*>(as_f(dw.whh1T16));
+        }
     } else {
         // per-step products are written as x W^T, so transpose the (derived) weights once per call
         VAG_TRY(vag_transpose_launch(p.wcat, Q, H, z.wcatT, s));            // (H, C+3H) = [attn_h^T | W_hh2^T]
@@ -604,17 +670,18 @@ int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const f
         float* dqgh = z.dqgh + t * B * Q;
         // attention backward: d alpha ; softmax backward ; dq = sum_s ds v (1 - tanh^2)
         // ... in one grid with the hidden-side half of dh1 (dgh2 W_hh2 + z2*dh2), whose operand is already known
+        const float* wside = s16 ? as_f(reinterpret_cast<const vag_half*>(z.wcatT) + C) : z.wcatT + C;
         VAG_TRY(vag_attn_dot_side_launch(1, k.encwp, dgi2, 3 * H, nullptr, nullptr, z.dah + t * B * Ts, B, Ts, 3 * H, z.dalpha,
-                                         B, H, 3 * H, dqgh + C, Q, z.wcatT + C, Q, nullptr, z.dh1d, z.pbuf, H, s));
+                                         B, H, 3 * H, dqgh + C, Q, wside, Q, nullptr, z.dh1d, z.pbuf, H, s, s16));
         VAG_TRY(vag_attn_dq_launch(pe, k.qhp + t * B * Q, Q, w.attn_v, k.alpha + t * B * Ts, z.dalpha, z.ds + t * B * Ts, B,
-                                   Ts, C, dqgh, Q, s));
+                                   Ts, C, dqgh, Q, s, s16));
         // dh1 = dq attn_h + (dgh2 W_hh2 + z2*dh2)   -> gru_1 cell backward of this step
         f.lda = Q; f.ldw = Q; f.K = (int)C; f.ldgi = 3 * H; f.ldgh = 3 * H; f.has_cell = 1;
         GruBwdStepSide& sd = f.s[0];
         sd.A = dqgh; sd.WT = z.wcatT; sd.addend = z.pbuf; sd.dh_add = nullptr; sd.drop_idx0 = 0;
         sd.save = k.g1 + t * 4 * BH; sd.hprev = (t == 0) ? h0 : h2_all + (t - 1) * BH;
         sd.dgi = z.dgi1 + t * B * 3 * H; sd.dgh = z.dgh1 + t * B * 3 * H; sd.dh_direct = z.carry; sd.dh_out = nullptr; sd.t = 0;
-        VAG_TRY(vag_gru_bwd_step_launch(f, 1, s));
+        VAG_TRY(vag_gru_bwd_step_launch(f, 1, s, s16));
         // d h2[t-1] = dgh1 W_hh1 + z1*dh1 (+ head's d_h2[t-1])   -> gru_2 cell backward of step t-1 (or d_h0 at t = 0)
         f.lda = 3 * H; f.ldw = 3 * H; f.K = (int)(3 * H);
         sd.A = z.dgh1 + t * B * 3 * H; sd.WT = z.whh1T; sd.addend = z.carry;
@@ -629,11 +696,11 @@ int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const f
             sd.dh_add = nullptr; sd.save = nullptr; sd.hprev = nullptr; sd.dgi = nullptr; sd.dgh = nullptr;
             sd.dh_direct = nullptr; sd.dh_out = d_h0;
         }
-        VAG_TRY(vag_gru_bwd_step_launch(f, 1, s));
+        VAG_TRY(vag_gru_bwd_step_launch(f, 1, s, s16));
     }
     // after the loop: everything that does not sit on the recurrence's critical path, as large products
     VAG_TRY(vag_attn_post_bwd_launch(pe, k.qhp, Q, w.attn_v, z.ds, k.alpha, d_c_all, B, Ts, Tt, C, d_pe, z.dvp, d_enc_out,
-                                     accumulate_enc, s));
+                                     accumulate_enc, s, s16));
     // d_enc += (sum_t alpha_t dgi2_t) (W_ih2 W_c2h): gru_2's share, through the projected keys
     VAG_TRY(vag_attn_wsum_launch(0, k.alpha, z.dgi2, B, Ts, Tt, 3 * H, z.dencwp, s));
     return gemm_nn(B * Ts, C, 3 * H, z.dencwp, 3 * H, p.wp, C, 1.f, d_enc_out, C, s);

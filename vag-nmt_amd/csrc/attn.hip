@@ -153,6 +153,7 @@ int vag_attn_ctx_launch(int softmax, const float* scores, const float* enc, int6
 // the positions s = w, w + CG_WAVES, ...; partial sums meet in LDS, wave 0 finishes the cell.
 // hp (N, ldhp) = W_hh2 h1 + b_hh2 (three gate blocks of H), save = [4][N][H] (r, z, n, hp_n) or NULL.
 constexpr int CG_WAVES = 8;
+template <bool XH>
 __global__ __launch_bounds__(64 * CG_WAVES) void attn_ctx_gru_kernel(const float* __restrict__ scores,
                                                                      const float* __restrict__ encwp, int rps, int Ts, int H,
                                                                      const float* __restrict__ b_ih,
@@ -171,13 +172,13 @@ __global__ __launch_bounds__(64 * CG_WAVES) void attn_ctx_gru_kernel(const float
     // Everything that does not depend on the softmax is requested first -- the first U value rows of this wave and, for
     // wave 0, the cell's other operands -- so that the weights cost no extra round of memory latency.
     constexpr int U = 5;
-    const float* e = encwp + b * Ts * 3 * H + (uok ? u : 0);
+    const int64_t e0 = b * Ts * 3 * H + (uok ? u : 0);       // element offset into encwp (fp32 or fp16)
     float4 ev[U][3];
 #pragma unroll
     for (int i = 0; i < U; ++i) {
         const int s = min(wave + i * CG_WAVES, Ts - 1);
 #pragma unroll
-        for (int g = 0; g < 3; ++g) ev[i][g] = *reinterpret_cast<const float4*>(e + (int64_t)s * 3 * H + g * H);
+        for (int g = 0; g < 3; ++g) ev[i][g] = ld4_any<XH>(encwp, e0 + (int64_t)s * 3 * H + g * H);
     }
     float4 bb[3], hg[3], h1 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (wave == 0 && uok) {
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(64 * CG_WAVES) void attn_ctx_gru_kernel(const float
                 for (int i = 0; i < U; ++i) {
                     const int s = min(s0 + i * CG_WAVES, Ts - 1);
 #pragma unroll
-                    for (int g = 0; g < 3; ++g) ev[i][g] = *reinterpret_cast<const float4*>(e + (int64_t)s * 3 * H + g * H);
+                    for (int g = 0; g < 3; ++g) ev[i][g] = ld4_any<XH>(encwp, e0 + (int64_t)s * 3 * H + g * H);
                 }
             }
 #pragma unroll
@@ -265,14 +266,18 @@ __global__ __launch_bounds__(64 * CG_WAVES) void attn_ctx_gru_kernel(const float
 }
 int vag_attn_ctx_gru_launch(const float* scores, const float* encwp, int64_t N, int64_t rps, int64_t Ts, int64_t H,
                             const float* b_ih, const float* hp, int64_t ldhp, const float* hprev, float* alpha, float* hout,
-                            float* save, hipStream_t s) {
+                            float* save, hipStream_t s, bool x16) {
     VAG_CHECK_ARG(scores && encwp && b_ih && hp && hprev && hout && N > 0 && N < 65536 && Ts > 0 && H > 0 && H % 4 == 0);
     VAG_CHECK_ARG(ldhp % 4 == 0 && rps >= 1 && aligned16(encwp) && aligned16(hp) && aligned16(hprev) && aligned16(hout) &&
                   aligned16(b_ih) && (!save || aligned16(save)));
     dim3 grid((unsigned)cdiv64(H, 256), (unsigned)N);
     const size_t lds = (size_t)((Ts + 3) & ~3) * sizeof(float) + (size_t)CG_WAVES * 3 * 64 * 16;
-    hipLaunchKernelGGL(attn_ctx_gru_kernel, grid, dim3(64 * CG_WAVES), lds, s, scores, encwp, (int)rps, (int)Ts, (int)H, b_ih,
-                       hp, ldhp, hprev, N, alpha, hout, save);
+    if (x16)
+        hipLaunchKernelGGL(attn_ctx_gru_kernel<true>, grid, dim3(64 * CG_WAVES), lds, s, scores, encwp, (int)rps, (int)Ts,
+                           (int)H, b_ih, hp, ldhp, hprev, N, alpha, hout, save);
+    else
+        hipLaunchKernelGGL(attn_ctx_gru_kernel<false>, grid, dim3(64 * CG_WAVES), lds, s, scores, encwp, (int)rps, (int)Ts,
+                           (int)H, b_ih, hp, ldhp, hprev, N, alpha, hout, save);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
@@ -362,6 +367,7 @@ int vag_softmax_bwd_launch(const float* alpha, const float* dalpha, int64_t N, i
 // ds = alpha * (dalpha - sum alpha dalpha) is done in the prologue (the first column block stores it for the post-loop
 // kernel).
 constexpr int DQ_WAVES = 4;
+template <bool XH>
 __global__ __launch_bounds__(64 * DQ_WAVES) void attn_dq_kernel(const float* __restrict__ pe, const float* __restrict__ q,
                                                      int64_t ldq, const float* __restrict__ v,
                                                      const float* __restrict__ alpha, const float* __restrict__ dalpha,
@@ -375,10 +381,10 @@ __global__ __launch_bounds__(64 * DQ_WAVES) void attn_dq_kernel(const float* __r
     constexpr int DQ_U = 10;
     const int c = (blockIdx.x * 64 + lane) * 4;
     const bool cok = c < C;
-    const float* p = pe + n * Ts * C + (cok ? c : 0);
+    const int64_t p0 = n * Ts * C + (cok ? c : 0);              // element offset into pe (fp32 or fp16)
     float4 pv[DQ_U];
 #pragma unroll
-    for (int i = 0; i < DQ_U; ++i) pv[i] = *reinterpret_cast<const float4*>(p + (int64_t)min(wave + i * DQ_WAVES, Ts - 1) * C);
+    for (int i = 0; i < DQ_U; ++i) pv[i] = ld4_any<XH>(pe, p0 + (int64_t)min(wave + i * DQ_WAVES, Ts - 1) * C);
     const float4 qv = cok ? *reinterpret_cast<const float4*>(q + n * ldq + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (alpha) {
         float dot = 0.f;
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(64 * DQ_WAVES) void attn_dq_kernel(const float* __r
 #pragma unroll
                 for (int i = 0; i < DQ_U; ++i) {
                     const int s = min(s0 + i * DQ_WAVES, Ts - 1);
-                    pv[i] = *reinterpret_cast<const float4*>(p + (int64_t)s * C);
+                    pv[i] = ld4_any<XH>(pe, p0 + (int64_t)s * C);
                 }
             }
 #pragma unroll
@@ -433,13 +439,17 @@ __global__ __launch_bounds__(64 * DQ_WAVES) void attn_dq_kernel(const float* __r
 }
 int vag_attn_dq_launch(const float* pe, const float* q, int64_t ldq, const float* v, const float* alpha,
                        const float* dalpha, float* dscore, int64_t N, int64_t Ts, int64_t C, float* dq, int64_t lddq,
-                       hipStream_t s) {
+                       hipStream_t s, bool x16) {
     VAG_CHECK_ARG(pe && q && v && dscore && dq && N > 0 && Ts > 0 && C > 0 && C % 4 == 0 && ldq % 4 == 0 && lddq % 4 == 0);
     VAG_CHECK_ARG((alpha == nullptr) == (dalpha == nullptr));
     dim3 grid((unsigned)cdiv64(C, 256), (unsigned)N);
     const size_t lds = (size_t)((Ts + 3) & ~3) * sizeof(float) + (size_t)DQ_WAVES * 64 * 16;
-    hipLaunchKernelGGL(attn_dq_kernel, grid, dim3(64 * DQ_WAVES), lds, s, pe, q, ldq, v, alpha, dalpha, dscore,
-                       (int)Ts, (int)C, dq, lddq);
+    if (x16)
+        hipLaunchKernelGGL(attn_dq_kernel<true>, grid, dim3(64 * DQ_WAVES), lds, s, pe, q, ldq, v, alpha, dalpha, dscore,
+                           (int)Ts, (int)C, dq, lddq);
+    else
+        hipLaunchKernelGGL(attn_dq_kernel<false>, grid, dim3(64 * DQ_WAVES), lds, s, pe, q, ldq, v, alpha, dalpha, dscore,
+                           (int)Ts, (int)C, dq, lddq);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
@@ -448,6 +458,7 @@ int vag_attn_dq_launch(const float* pe, const float* q, int64_t ldq, const float
 // grid (ceil(C/256), B); thread owns one c and walks source positions in chunks of SC, all Tt steps per chunk.
 constexpr int SC = VAG_POST_SC;
 constexpr int POST_TMAX = 96;           // steps whose (ds, alpha) rows are staged in LDS per pass
+template <bool XH>
 __global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restrict__ pe, const float* __restrict__ q_all,
                                                             const float* __restrict__ v, const float* __restrict__ ds_all,
                                                             const float* __restrict__ alpha_all,
@@ -467,7 +478,7 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < SC; ++i) {
         const int s = min(s0 + i, Ts - 1);
-        pv[i] = cok ? pe[((int64_t)b * Ts + s) * C + c] : 0.f;
+        pv[i] = cok ? ld1_any<XH>(pe, ((int64_t)b * Ts + s) * C + c) : 0.f;
         ape[i] = 0.f; aen[i] = 0.f;
     }
     for (int t0 = 0; t0 < Tt; t0 += POST_TMAX) {
@@ -520,11 +531,15 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restr
 }
 int vag_attn_post_bwd_launch(const float* pe, const float* q_all, int64_t ldq, const float* v, const float* ds_all,
                              const float* alpha_all, const float* dc_all, int64_t B, int64_t Ts, int64_t Tt,
-                             int64_t C, float* d_pe, float* dvp, float* d_enc, int accumulate_enc, hipStream_t s) {
+                             int64_t C, float* d_pe, float* dvp, float* d_enc, int accumulate_enc, hipStream_t s, bool x16) {
     VAG_CHECK_ARG(pe && q_all && v && ds_all && alpha_all && d_pe && B > 0 && Ts > 0 && Tt > 0 && C > 0);
     dim3 grid((unsigned)cdiv64(C, 256), (unsigned)B, (unsigned)cdiv64(Ts, SC));
-    hipLaunchKernelGGL(attn_post_bwd_kernel, grid, dim3(256), 0, s, pe, q_all, v, ds_all, alpha_all, dc_all, (int)B,
-                       (int)Ts, (int)Tt, (int)C, ldq, d_pe, dvp, d_enc, accumulate_enc);
+    if (x16)
+        hipLaunchKernelGGL(attn_post_bwd_kernel<true>, grid, dim3(256), 0, s, pe, q_all, v, ds_all, alpha_all, dc_all, (int)B,
+                           (int)Ts, (int)Tt, (int)C, ldq, d_pe, dvp, d_enc, accumulate_enc);
+    else
+        hipLaunchKernelGGL(attn_post_bwd_kernel<false>, grid, dim3(256), 0, s, pe, q_all, v, ds_all, alpha_all, dc_all, (int)B,
+                           (int)Ts, (int)Tt, (int)C, ldq, d_pe, dvp, d_enc, accumulate_enc);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

@@ -66,6 +66,25 @@ __device__ __forceinline__ float vag_drop_mul(const uint64_t* rng, uint32_t stre
     return (u >= p) ? 1.0f / (1.0f - p) : 0.0f;
 }
 
+// ---- 2-byte storage mode: tensors the recurrences stream at every time step (their weights, the attention keys) may be
+// kept as fp16 in memory; arithmetic and accumulation stay fp32.  Pointers keep the type `const float*` in the argument
+// structs and are re-cast where the template flag says fp16.
+typedef _Float16 vag_half;
+__device__ __forceinline__ float h16_lo(unsigned p) { return (float)__builtin_bit_cast(vag_half, (unsigned short)(p & 0xffffu)); }
+__device__ __forceinline__ float h16_hi(unsigned p) { return (float)__builtin_bit_cast(vag_half, (unsigned short)(p >> 16)); }
+// 4 consecutive elements (index `elem` .. `elem`+3, elem % 4 == 0) of a tensor stored as fp32 or fp16
+template <bool XH> __device__ __forceinline__ float4 ld4_any(const float* base, int64_t elem) {
+    if (XH) {
+        const uint2 p = *reinterpret_cast<const uint2*>(reinterpret_cast<const vag_half*>(base) + elem);
+        return make_float4(h16_lo(p.x), h16_hi(p.x), h16_lo(p.y), h16_hi(p.y));
+    }
+    return *reinterpret_cast<const float4*>(base + elem);
+}
+template <bool XH> __device__ __forceinline__ float ld1_any(const float* base, int64_t elem) {
+    if (XH) return (float)reinterpret_cast<const vag_half*>(base)[elem];
+    return base[elem];
+}
+
 enum { VAG_ACT_NONE = 0, VAG_ACT_TANH = 1 };
 enum { VAG_DROP_ENC_EMB = 1, VAG_DROP_ENC_CTX = 2, VAG_DROP_DEC_OUT = 3 };
 
@@ -73,16 +92,17 @@ enum { VAG_DROP_ENC_EMB = 1, VAG_DROP_ENC_CTX = 2, VAG_DROP_DEC_OUT = 3 };
 // C[M,N] = act(alpha * op(A) op(B) + beta * C + bias[n]);  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn].
 int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
                     const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc,
-                    const float* bias, int act, hipStream_t stream);
+                    const float* bias, int act, hipStream_t stream, int c_half = 0);   // c_half: C stored as fp16 (beta = 0)
 // out[m,n] = act(sum_k A[m,k] W[n,k] + bias[n] + addend[m,n]);  M small (decode/recurrent steps).
+void vag_gemm_set_planes(int planes);      // 3: bf16x6 (default), 2: bf16x3 (2-byte storage mode), calling thread
 int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
                       const float* bias, const float* addend, int64_t ldadd, float* out, int64_t ldo, int act,
-                      hipStream_t stream);
+                      hipStream_t stream, bool w16 = false);      // w16: W is stored as fp16 (2-byte storage mode)
 // out[n] += sum_m X[m*ld + n]
 int vag_attn_dot_side_launch(int mode, const float* x, const float* q, int64_t ldq, const float* v, const float* mask,
                              const float* addend, int64_t N, int64_t Ts, int64_t W, float* out, int64_t M, int64_t Np,
                              int64_t K, const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* pbias,
-                             const float* padd, float* P, int64_t ldp, hipStream_t stream);
+                             const float* padd, float* P, int64_t ldp, hipStream_t stream, bool s16 = false);   // s16: x and Wt fp16
 int vag_skinny_batched_launch(int64_t nb, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t bsA,
                               const float* W, int64_t ldw, int64_t bsW, float* out, int64_t ldo, int64_t bsO,
                               hipStream_t stream);
@@ -128,7 +148,7 @@ struct GruStepArgs {
     const int* lengths;  // device int32[M] or NULL
     int comp_hidden;     // 1: computed projection is the hidden one (W_hh h), 0: the input one (W_ih x)
 };
-int vag_gru_step_launch(const GruStepArgs& a, int nz, hipStream_t stream);
+int vag_gru_step_launch(const GruStepArgs& a, int nz, hipStream_t stream, bool w16 = false);      // w16: s[].W is fp16
 
 // ---- fused "gradient w.r.t. a hidden state, then the GRU cell backward it feeds" (gemm.hip) ----
 // dh[m,j] = sum_k A[m,k] WT[j,k] + addend[m,j]   (WT = transposed weights, one row per hidden unit)
@@ -157,4 +177,4 @@ struct GruBwdStepArgs {
     const uint64_t* rng; int sid; float p;
     int has_cell;
 };
-int vag_gru_bwd_step_launch(const GruBwdStepArgs& a, int nz, hipStream_t stream);
+int vag_gru_bwd_step_launch(const GruBwdStepArgs& a, int nz, hipStream_t stream, bool w16 = false);   // w16: s[].WT is fp16

@@ -299,7 +299,8 @@ int vag_gather_rows_i64_launch(const int64_t* in, int64_t ld, const int64_t* idx
 
 
 // ------------------------------------------------------------------ several small fills / copies / transposes, one launch
-// Each job covers a (rows x cols) fp32 matrix: kind 0 zero-fill, 1 copy, 2 transpose (dst[c*ld_dst + r] = src[r*ld_src + c]).
+// Each job covers a (rows x cols) fp32 matrix: kind 0 zero-fill, 1 copy, 2 transpose (dst[c*ld_dst + r] = src[r*ld_src + c]),
+// 3 / 4 = copy / transpose into an fp16 destination (ld_dst in halves).
 // A block handles one 32x32 tile of one job.  Used for the per-optimiser-step derived weights and the zero rows of the
 // recurrent state buffers: a handful of tiny dependent-free operations that would otherwise be a launch each.
 __global__ __launch_bounds__(256) void jobs_kernel(VagJobs J) {
@@ -311,11 +312,17 @@ __global__ __launch_bounds__(256) void jobs_kernel(VagJobs J) {
     const int tc = (int)((j.cols + 31) / 32);
     const int64_t r0 = (int64_t)(id / tc) * 32, c0 = (int64_t)(id % tc) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
-    if (j.kind != 2) {
+    const bool to_half = j.kind >= 3;                            // kinds 3 / 4: copy / transpose into an fp16 destination
+    vag_half* dh = reinterpret_cast<vag_half*>(j.dst);
+    if (j.kind != 2 && j.kind != 4) {
 #pragma unroll
         for (int i = 0; i < 32; i += 8) {
             const int64_t r = r0 + ty + i, c = c0 + tx;
-            if (r < j.rows && c < j.cols) j.dst[r * j.ld_dst + c] = j.kind == 0 ? 0.f : j.src[r * j.ld_src + c];
+            if (r < j.rows && c < j.cols) {
+                const float v = j.kind == 0 ? 0.f : j.src[r * j.ld_src + c];
+                if (to_half) dh[r * j.ld_dst + c] = (vag_half)v;
+                else j.dst[r * j.ld_dst + c] = v;
+            }
         }
         return;
     }
@@ -328,7 +335,10 @@ __global__ __launch_bounds__(256) void jobs_kernel(VagJobs J) {
 #pragma unroll
     for (int i = 0; i < 32; i += 8) {
         const int64_t c = c0 + ty + i, r = r0 + tx;
-        if (r < j.rows && c < j.cols) j.dst[c * j.ld_dst + r] = tile[tx][ty + i];
+        if (r < j.rows && c < j.cols) {
+            if (to_half) dh[c * j.ld_dst + r] = (vag_half)tile[tx][ty + i];
+            else j.dst[c * j.ld_dst + r] = tile[tx][ty + i];
+        }
     }
 }
 int vag_jobs_launch(const VagJob* jobs, int n, hipStream_t s) {

@@ -27,6 +27,7 @@ struct GemmArgs {
     int M, N, K, kchunk;
     float alpha, beta;
     int act, splitk;
+    int c_half;           // 1: C is stored as fp16 (outputs that the recurrences re-read every step); needs beta == 0, no split-K
 };
 
 constexpr int BK = 32;      // k-depth of one LDS stage (one barrier per 32 of K)
@@ -35,8 +36,20 @@ constexpr int BK = 32;      // k-depth of one LDS stage (one barrier per 32 of K
 // The beta path requests all 16 old values BEFORE using any of them (a per-element load-use-store sequence costs one
 // memory round trip per element: ~15 us for a 64x64-tile product however small it is).
 __device__ __forceinline__ void gemm_epilogue16(const f32x16& acc, float* __restrict__ cbase, int64_t ldc, int rows_left,
-                                                float alpha, float beta, float bv, int act, bool atomic) {
+                                                float alpha, float beta, float bv, int act, bool atomic, int c_half = 0,
+                                                int64_t c_elem0 = 0) {
     if (rows_left <= 0) return;
+    if (c_half) {          // fp16 output: cbase is the matrix base, c_elem0 the element index of (row0, col)
+        vag_half* ch = reinterpret_cast<vag_half*>(cbase) + c_elem0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            float v = alpha * acc[r] + bv;
+            if (act == VAG_ACT_TANH) v = vag_tanh(v);
+            if (dr < rows_left) ch[(int64_t)dr * ldc] = (vag_half)v;
+        }
+        return;
+    }
     if (atomic) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -282,8 +295,8 @@ __device__ __forceinline__ void sp_load(const float* __restrict__ P, int64_t so,
     }
 }
 
-// registers -> three bf16 planes in LDS, image [outer][k] per plane
-template <bool KC>
+// registers -> PL (3 or 2) bf16 planes in LDS, image [outer][k] per plane
+template <bool KC, int PL = 3>
 __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r) {
     const int tid = threadIdx.x;
     if (KC) {
@@ -297,7 +310,7 @@ __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r
             __bf16* d = S + o * SP_LD + k;
             *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
             *reinterpret_cast<uint2*>(d + SP_PLANE) = make_uint2(a2, b2);
-            *reinterpret_cast<uint2*>(d + 2 * SP_PLANE) = make_uint2(a3, b3);
+            if (PL == 3) *reinterpret_cast<uint2*>(d + 2 * SP_PLANE) = make_uint2(a3, b3);
         }
     } else {
         const int o = tid & 127, kq = tid >> 7;
@@ -308,7 +321,7 @@ __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r
             __bf16* d = S + o * SP_LD + 2 * (kq + 4 * i);
             *reinterpret_cast<unsigned*>(d) = p1;
             *reinterpret_cast<unsigned*>(d + SP_PLANE) = p2;
-            *reinterpret_cast<unsigned*>(d + 2 * SP_PLANE) = p3;
+            if (PL == 3) *reinterpret_cast<unsigned*>(d + 2 * SP_PLANE) = p3;
         }
     }
 }
@@ -321,13 +334,15 @@ __device__ __forceinline__ bf16x8 sp_frag(const __bf16* p) {      // 8 consecuti
     return __builtin_bit_cast(bf16x8, q);
 }
 
-// One k-tile of MFMA work from the LDS planes: 2 k-steps of 16, six bf16 products each (smallest terms first).
+// One k-tile of MFMA work from the LDS planes: 2 k-steps of 16; PL = 3: six bf16 products (fp32-grade), PL = 2: three
+// (x = x1 + x2 exactly to 16 significand bits: the 2-byte storage mode, whose operands carry no more than that).
+template <int PL>
 __device__ __forceinline__ void sp_compute(const __bf16* Af, const __bf16* Bf, f32x16 (&acc)[2]) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 af[2][3], bf[3];
+        bf16x8 af[2][PL], bf[PL];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < PL; ++p) {
             bf[p] = sp_frag(Bf + p * SP_PLANE + ks * 16);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -335,9 +350,12 @@ __device__ __forceinline__ void sp_compute(const __bf16* Af, const __bf16* Bf, f
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[2], acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[1], acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[0], acc[i], 0, 0, 0);
+            // smallest terms first
+            if (PL == 3) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[PL - 1], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[1], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PL - 1], bf[0], acc[i], 0, 0, 0);
+            }
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[1], acc[i], 0, 0, 0);
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[0], acc[i], 0, 0, 0);
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i], 0, 0, 0);
@@ -345,9 +363,7 @@ __device__ __forceinline__ void sp_compute(const __bf16* Af, const __bf16* Bf, f
     }
 }
 
-// PF2: two k-tiles of global loads in flight (two register sets, loop unrolled by two) instead of one: a tile's loads
-// then have a whole iteration more to land before the split needs them.
-template <bool AKC, bool BKC, bool VEC, bool PF2 = false>
+template <bool AKC, bool BKC, bool VEC, int PL = 3>
 __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem, int bx, int by, int bz) {
     __bf16* As = smem;
     __bf16* Bs = smem + 3 * SP_PLANE;
@@ -367,50 +383,19 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
     const __bf16* Af = As + (wm * 64 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
     const __bf16* Bf = Bs + (wn * 32 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
 
-    if (PF2) {
-        SpRegs ra0, rb0, ra1, rb1;
-        sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, kbeg, a.M, kend, ra0);
-        sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, kbeg, a.N, kend, rb0);
-        if (kbeg + SP_BK < kend) {
-            sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, kbeg + SP_BK, a.M, kend, ra1);
-            sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, kbeg + SP_BK, a.N, kend, rb1);
+    SpRegs ra, rb;
+    sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, kbeg, a.M, kend, ra);
+    sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, kbeg, a.N, kend, rb);
+    for (int k0 = kbeg; k0 < kend; k0 += SP_BK) {
+        sp_store<AKC, PL>(As, ra);
+        sp_store<BKC, PL>(Bs, rb);
+        __syncthreads();
+        if (k0 + SP_BK < kend) {
+            sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, k0 + SP_BK, a.M, kend, ra);
+            sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, k0 + SP_BK, a.N, kend, rb);
         }
-        for (int k0 = kbeg; k0 < kend; k0 += 2 * SP_BK) {
-            sp_store<AKC>(As, ra0);
-            sp_store<BKC>(Bs, rb0);
-            __syncthreads();
-            if (k0 + 2 * SP_BK < kend) {
-                sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, k0 + 2 * SP_BK, a.M, kend, ra0);
-                sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, k0 + 2 * SP_BK, a.N, kend, rb0);
-            }
-            sp_compute(Af, Bf, acc);
-            __syncthreads();
-            if (k0 + SP_BK >= kend) break;
-            sp_store<AKC>(As, ra1);
-            sp_store<BKC>(Bs, rb1);
-            __syncthreads();
-            if (k0 + 3 * SP_BK < kend) {
-                sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, k0 + 3 * SP_BK, a.M, kend, ra1);
-                sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, k0 + 3 * SP_BK, a.N, kend, rb1);
-            }
-            sp_compute(Af, Bf, acc);
-            __syncthreads();
-        }
-    } else {
-        SpRegs ra, rb;
-        sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, kbeg, a.M, kend, ra);
-        sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, kbeg, a.N, kend, rb);
-        for (int k0 = kbeg; k0 < kend; k0 += SP_BK) {
-            sp_store<AKC>(As, ra);
-            sp_store<BKC>(Bs, rb);
-            __syncthreads();
-            if (k0 + SP_BK < kend) {
-                sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, k0 + SP_BK, a.M, kend, ra);
-                sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, k0 + SP_BK, a.N, kend, rb);
-            }
-            sp_compute(Af, Bf, acc);
-            __syncthreads();
-        }
+        sp_compute<PL>(Af, Bf, acc);
+        __syncthreads();
     }
 
     // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -422,14 +407,15 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row0 = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
-        gemm_epilogue16(acc[i], a.C + (int64_t)row0 * a.ldc + col, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, atomic);
+        if (a.c_half) gemm_epilogue16(acc[i], a.C, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, atomic, 1, (int64_t)row0 * a.ldc + col);
+        else gemm_epilogue16(acc[i], a.C + (int64_t)row0 * a.ldc + col, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, atomic);
     }
 }
 
-template <bool AKC, bool BKC, bool VEC, bool PF2 = false, int PAD = 0>
+template <bool AKC, bool BKC, bool VEC, int PL = 3>
 __global__ __launch_bounds__(512) void gemm_split_kernel(GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) __bf16 smem[6 * SP_PLANE + PAD];      // PAD: experiment (forces one block per CU)
-    gemm_split_body<AKC, BKC, VEC, PF2>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    __shared__ __attribute__((aligned(16))) __bf16 smem[6 * SP_PLANE];
+    gemm_split_body<AKC, BKC, VEC, PL>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Grouped launch: the blocks of up to GROUP_MAX independent products of one operand layout (e.g. all "TN": both operands
@@ -442,7 +428,7 @@ struct GemmGroupArgs {
     int start[GROUP_MAX + 1];      // first block of each product
     int n;
 };
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, int PL = 3>
 __global__ __launch_bounds__(512) void gemm_split_group_kernel(GemmGroupArgs G) {
     __shared__ __attribute__((aligned(16))) __bf16 smem[6 * SP_PLANE];
     int p = 0;
@@ -451,7 +437,7 @@ __global__ __launch_bounds__(512) void gemm_split_group_kernel(GemmGroupArgs G) 
     const int id = blockIdx.x - G.start[p];
     const int tn = (a.N + 127) / 128, tm = (a.M + 127) / 128;
     const int bx = id % tn, by = (id / tn) % tm, bz = id / (tn * tm);
-    gemm_split_body<AKC, BKC, true>(a, smem, bx, by, bz);
+    gemm_split_body<AKC, BKC, true, PL>(a, smem, bx, by, bz);
 }
 
 // (A double-buffered variant -- 110 KB of LDS, one block per CU, split/store of tile t+1 issued between the k-halves of
@@ -460,33 +446,16 @@ __global__ __launch_bounds__(512) void gemm_split_group_kernel(GemmGroupArgs G) 
 // tiles: 128 vs 138 TFLOP/s at 4096^3, up to 35 % slower at K = 256 -- and a 3-tile register prefetch (154 VGPRs, one
 // block per CU).  Reference points: PMC on this kernel shows MFMA 31 %, LDS 39 %, VALU 26 % busy; a pure MFMA loop
 // (tools/mfma_probe.hip) sustains 1.9-2.1 PFLOP/s bf16, i.e. 315-350 TFLOP/s fp32-equivalent at six products.)
+// Planes per operand of the bf16 split on the calling thread: 3 (default: six products, fp32-grade) or 2 (three products:
+// the 2-byte storage mode, set by the step driver for the duration of a call).
+static thread_local int g_gemm_planes = 3;
+void vag_gemm_set_planes(int planes) { g_gemm_planes = planes == 2 ? 2 : 3; }
+
 static int gemm_split_dispatch(const GemmArgs& g, bool akc, bool bkc, bool vec, dim3 grid, hipStream_t s) {
-    // experiment switch (tools/exp_gemm2.py): VAG_GEMM_VARIANT = 1 two k-tiles of loads in flight, 2 one block per CU
-    const char* ev = getenv("VAG_GEMM_VARIANT");
-    const int variant = ev ? atoi(ev) : 0;
-    if (vec && variant == 1) {
-#define VAG_SPLIT_V1(AK, BKc)                                                                         \
-    if (akc == AK && bkc == BKc) {                                                                    \
-        hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, true, true>), grid, dim3(512), 0, s, g);       \
-        VAG_LAUNCH_CHECK();                                                                           \
-        return VAG_OK;                                                                                \
-    }
-        VAG_SPLIT_V1(true, true) VAG_SPLIT_V1(true, false) VAG_SPLIT_V1(false, true) VAG_SPLIT_V1(false, false)
-#undef VAG_SPLIT_V1
-    }
-    if (vec && variant == 2) {
-#define VAG_SPLIT_V2(AK, BKc)                                                                         \
-    if (akc == AK && bkc == BKc) {                                                                    \
-        hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, true, false, 14000>), grid, dim3(512), 0, s, g); \
-        VAG_LAUNCH_CHECK();                                                                           \
-        return VAG_OK;                                                                                \
-    }
-        VAG_SPLIT_V2(true, true) VAG_SPLIT_V2(true, false) VAG_SPLIT_V2(false, true) VAG_SPLIT_V2(false, false)
-#undef VAG_SPLIT_V2
-    }
 #define VAG_SPLIT_CASE(AK, BKc, V)                                                                    \
     if (akc == AK && bkc == BKc && vec == V) {                                                        \
-        hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V>), grid, dim3(512), 0, s, g);                \
+        if (g_gemm_planes == 2) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 2>), grid, dim3(512), 0, s, g);   \
+        else hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 3>), grid, dim3(512), 0, s, g);        \
         VAG_LAUNCH_CHECK();                                                                           \
         return VAG_OK;                                                                                \
     }
@@ -593,14 +562,17 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
     }
     G.start[n] = total;
     const bool akc = (lay & 2) != 0, bkc = (lay & 1) != 0;
-    if (!akc && !bkc)
-        hipLaunchKernelGGL((gemm_split_group_kernel<false, false>), dim3((unsigned)total), dim3(512), 0, stream, G);
-    else if (akc && !bkc)
-        hipLaunchKernelGGL((gemm_split_group_kernel<true, false>), dim3((unsigned)total), dim3(512), 0, stream, G);
-    else if (akc && bkc)
-        hipLaunchKernelGGL((gemm_split_group_kernel<true, true>), dim3((unsigned)total), dim3(512), 0, stream, G);
-    else
-        hipLaunchKernelGGL((gemm_split_group_kernel<false, true>), dim3((unsigned)total), dim3(512), 0, stream, G);
+#define VAG_GROUP_GO(PLN)                                                                                                     \
+    if (!akc && !bkc)                                                                                                         \
+        hipLaunchKernelGGL((gemm_split_group_kernel<false, false, PLN>), dim3((unsigned)total), dim3(512), 0, stream, G);     \
+    else if (akc && !bkc)                                                                                                     \
+        hipLaunchKernelGGL((gemm_split_group_kernel<true, false, PLN>), dim3((unsigned)total), dim3(512), 0, stream, G);      \
+    else if (akc && bkc)                                                                                                      \
+        hipLaunchKernelGGL((gemm_split_group_kernel<true, true, PLN>), dim3((unsigned)total), dim3(512), 0, stream, G);       \
+    else                                                                                                                      \
+        hipLaunchKernelGGL((gemm_split_group_kernel<false, true, PLN>), dim3((unsigned)total), dim3(512), 0, stream, G);
+    if (g_gemm_planes == 2) { VAG_GROUP_GO(2) } else { VAG_GROUP_GO(3) }
+#undef VAG_GROUP_GO
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
@@ -617,7 +589,7 @@ int vag_gemm_group_end(hipStream_t stream) {
 
 int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
                     const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc,
-                    const float* bias, int act, hipStream_t stream) {
+                    const float* bias, int act, hipStream_t stream, int c_half) {
     const bool opt_f32mfma = getenv("VAG_GEMM_F32MFMA") != nullptr;      // read per call: the parity tests flip it
     static const bool opt_nogroup = getenv("VAG_GEMM_NOGROUP") != nullptr;
     VAG_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && A && B && C);
@@ -631,7 +603,8 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     const bool bkc = (sbk == 1);        // B: k contiguous
     g.sa_o = sam; g.sa_k = sak; g.sb_o = sbn; g.sb_k = sbk;
     g.ldc = ldc; g.M = (int)M; g.N = (int)N; g.K = (int)K;
-    g.alpha = alpha; g.beta = beta; g.act = act;
+    g.alpha = alpha; g.beta = beta; g.act = act; g.c_half = c_half;
+    VAG_CHECK_ARG(!c_half || (beta == 0.f && M > 64 && N > 64 && !opt_f32mfma));      // fp16 output: bf16x6 kernels only
     const int64_t lda = akc ? sam : sak, ldb = bkc ? sbn : sbk;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     const int lay = (akc ? 2 : 0) + (bkc ? 1 : 0);
@@ -643,12 +616,12 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     }
     // cost model (microseconds) over tile in {64,128} x split-K: MFMA time of the busiest CU + output traffic
     // (split-K partial sums as fp32 atomics ~3 TB/s chip-wide, plain stores ~4 TB/s) -- constants fitted to measured launches.
-    const bool can_split = (act == VAG_ACT_NONE) && (beta == 0.f || beta == 1.f);
+    const bool can_split = (act == VAG_ACT_NONE) && (beta == 0.f || beta == 1.f) && !c_half;
     double best = 1e30;
     int64_t T = 64, splitk = 1;
     // bytes/us of split-K partial sums landing as fp32 atomics (fitted: tools/exp_gemm_sweep.py; 1e6 was too pessimistic)
     static const double atomic_rate = getenv("VAG_GEMM_ATOMIC") ? atof(getenv("VAG_GEMM_ATOMIC")) : 3.0e6;
-    for (int64_t t = 64; t <= 128; t *= 2) {
+    for (int64_t t = (c_half ? 128 : 64); t <= 128; t *= 2) {
         if (t == 128 && (M <= 64 || N <= 64)) continue;
         const double eff = (t == 128) ? (opt_f32mfma ? 0.62 : 0.64) : 0.42;   // fraction of the f32-MFMA peak
         const int64_t base = cdiv64(M, t) * cdiv64(N, t);
@@ -701,7 +674,7 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
 
 static int vag_gemm_launch_now(const GemmArgs& q, hipStream_t stream) {
     return vag_gemm_launch(q.M, q.N, q.K, q.alpha, q.A, q.sa_o, q.sa_k, q.B, q.sb_k, q.sb_o, q.beta, q.C, q.ldc, q.bias, q.act,
-                           stream);
+                           stream, q.c_half);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -803,6 +776,103 @@ __device__ __forceinline__ void skinny_mma(const float* const (&ap)[MT], const f
     __syncthreads();
 }
 
+// The same product with the W operand stored as fp16 (the 2-byte storage mode: weights the recurrences re-read at every
+// time step).  Chunks are 32 of K: lane (row r, segment g) loads 8 consecutive halves of W (one 16-byte request: quads
+// still read 64 contiguous bytes) and the matching 8 floats of A as two float4 (k = 8g..8g+3, 8g+4..8g+7); both go through
+// the same lane permutation and feed eight K=4 MFMAs in the same k order, so products are exact fp32 x fp16->fp32.
+// ap/wp are already offset by 8*skinny_ldseg(lane) elements.  K % 8 == 0.
+template <int WAVES, int MT, int NT, int U = 2>
+__device__ __forceinline__ void skinny_mma_h16(const float* const (&ap)[MT], const vag_half* const (&wp)[NT], int K, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = skinny_ldseg(lane);
+    const int src4 = 4 * (16 * (lane & 3) + (lane & 12) + (lane >> 4));
+    const int kper = ((K + WAVES - 1) / WAVES + 31) & ~31;
+    const int kbeg = wave * kper;
+    const int kend = min(K, kbeg + kper);
+    f32x4 acc[MT][NT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            acc[i][j][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[i][j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    for (int c0 = kbeg; c0 < kend; c0 += 32 * U) {
+        float4 a0[MT][U], a1[MT][U];
+        uint4 wq[NT][U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = c0 + 32 * u + 8 * g;
+            const bool ok = k < kend;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                a0[i][u] = ok ? *reinterpret_cast<const float4*>(ap[i] + c0 + 32 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+                a1[i][u] = ok ? *reinterpret_cast<const float4*>(ap[i] + c0 + 32 * u + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                wq[j][u] = (ok && wp[j]) ? *reinterpret_cast<const uint4*>(wp[j] + c0 + 32 * u) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) { a0[i][u] = skinny_xpose(a0[i][u], src4); a1[i][u] = skinny_xpose(a1[i][u], src4); }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                uint4 q = wq[j][u];
+                q.x = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)q.x);
+                q.y = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)q.y);
+                q.z = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)q.z);
+                q.w = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)q.w);
+                wq[j][u] = q;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const uint4 q = wq[j][u];
+                    acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][u].x, h16_lo(q.x), acc[i][j][0], 0, 0, 0);
+                    acc[i][j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][u].y, h16_hi(q.x), acc[i][j][1], 0, 0, 0);
+                    acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][u].z, h16_lo(q.y), acc[i][j][0], 0, 0, 0);
+                    acc[i][j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][u].w, h16_hi(q.y), acc[i][j][1], 0, 0, 0);
+                    acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][u].x, h16_lo(q.z), acc[i][j][0], 0, 0, 0);
+                    acc[i][j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][u].y, h16_hi(q.z), acc[i][j][1], 0, 0, 0);
+                    acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][u].z, h16_lo(q.w), acc[i][j][0], 0, 0, 0);
+                    acc[i][j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][u].w, h16_hi(q.w), acc[i][j][1], 0, 0, 0);
+                }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            f32x4 s = acc[i][j][0] + acc[i][j][1];
+            *reinterpret_cast<f32x4*>(&red[((wave * (MT * NT) + i * NT + j) * 64 + lane) * 4]) = s;
+        }
+    __syncthreads();
+}
+// Dispatch on the W storage type.  koff = this lane's element offset inside a chunk (4g for fp32 W, 8g for fp16 W).
+template <bool WH> __device__ __forceinline__ int skinny_koff(int g) { return WH ? 8 * g : 4 * g; }
+template <int WAVES, int MT, int NT, int U, bool WH>
+__device__ __forceinline__ void skinny_mma_any(const float* const (&ap)[MT], const float* const (&wp)[NT], int K, float* red) {
+    if constexpr (WH) {
+        const vag_half* wh[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wh[j] = reinterpret_cast<const vag_half*>(wp[j]);
+        skinny_mma_h16<WAVES, MT, NT, (U + 1) / 2>(ap, wh, K, red);
+    } else {
+        skinny_mma<WAVES, MT, NT, U>(ap, wp, K, red);
+    }
+}
+// address of element (row, col) of a W matrix stored as fp32 or fp16 (returned as const float* either way: the half
+// version is re-cast inside skinny_mma_any)
+template <bool WH> __device__ __forceinline__ const float* skinny_wptr(const float* W, int64_t row, int64_t ldw, int col) {
+    if (WH) return reinterpret_cast<const float*>(reinterpret_cast<const vag_half*>(W) + row * ldw + col);
+    return W + row * ldw + col;
+}
+
 // sum over the waves of tile `tile`, for this lane's 4 accumulator rows
 template <int WAVES, int TILES>
 __device__ __forceinline__ f32x4 skinny_sum(const float* red, int tile, int lane) {
@@ -823,7 +893,7 @@ __device__ __forceinline__ float skinny_sum1(const float* red, int tile, int mro
 
 // One 16x16 output tile per workgroup; the 256 outputs are finished by the first 256 threads (bias / addend requested
 // before the product).
-template <int WAVES, int U = 4>
+template <int WAVES, int U = 4, bool WH = false>
 __device__ __forceinline__ void skinny_plain_body(const SkinnyArgs& a, float* red, int bx, int by) {
     const int lane = threadIdx.x & 63;
     const int r = skinny_ldrow(lane), g = skinny_ldseg(lane);
@@ -838,22 +908,23 @@ __device__ __forceinline__ void skinny_plain_body(const SkinnyArgs& a, float* re
     }
     const float* ap[1];
     const float* wp[1];
-    ap[0] = a.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + 4 * g;
-    wp[0] = a.W + (int64_t)min(nb + r, a.N - 1) * a.ldw + 4 * g;
-    skinny_mma<WAVES, 1, 1, U>(ap, wp, a.K, red);
+    ap[0] = a.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + skinny_koff<WH>(g);
+    wp[0] = skinny_wptr<WH>(a.W, min(nb + r, a.N - 1), a.ldw, skinny_koff<WH>(g));
+    skinny_mma_any<WAVES, 1, 1, U, WH>(ap, wp, a.K, red);
     if (!eok) return;
     float v = skinny_sum1<WAVES, 1>(red, 0, erow, ecol) + pre;
     if (a.act == VAG_ACT_TANH) v = vag_tanh(v);
     a.out[(int64_t)em * a.ldo + ej] = v;
 }
-template <int WAVES>
+// WH: the W operand is stored as fp16 (batched launches, blockIdx.z, are fp32-only)
+template <int WAVES, bool WH = false>
 __global__ __launch_bounds__(WAVES * 64) void skinny_plain_kernel(SkinnyArgs a) {
     __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4];
     if (blockIdx.z) {
         a.A += blockIdx.z * a.bsA; a.W += blockIdx.z * a.bsW; a.out += blockIdx.z * a.bsO;
         if (a.addend) a.addend += blockIdx.z * a.bsO;
     }
-    skinny_plain_body<WAVES>(a, red, blockIdx.x, blockIdx.y);
+    skinny_plain_body<WAVES, 4, WH>(a, red, blockIdx.x, blockIdx.y);
 }
 
 // Horizontal fusion for the decoder steps: an attention dot-product pass (a streaming dot per (row, position), latency
@@ -870,24 +941,26 @@ struct DotArgs {
     int Ts, W, gx, nscore;
 };
 // DS_WAVES waves per block: that many (row, position) pairs, or the K split of one product tile
-template <int MODE, int DS_WAVES>
+// S16: 2-byte storage mode -- the streamed operand x (attention keys / projected keys) and the side product's weights
+// are fp16 in memory
+template <int MODE, int DS_WAVES, bool S16 = false>
 __global__ __launch_bounds__(64 * DS_WAVES) void attn_dot_side_kernel(DotArgs d, SkinnyArgs a, int tiles_x) {
     __shared__ __attribute__((aligned(16))) float red[DS_WAVES * 64 * 4];
     const int id = blockIdx.x;
     if (id >= d.nscore) {
         const int t = id - d.nscore;
-        skinny_plain_body<DS_WAVES, (MODE == 1 ? 6 : 4)>(a, red, t % tiles_x, t / tiles_x);
+        skinny_plain_body<DS_WAVES, (MODE == 1 ? 6 : 4), S16>(a, red, t % tiles_x, t / tiles_x);
         return;
     }
     const int lane = threadIdx.x & 63;
     const int s = (id % d.gx) * DS_WAVES + (threadIdx.x >> 6);
     if (s >= d.Ts) return;
     const int64_t n = id / d.gx;
-    const float* xr = d.x + (n * d.Ts + s) * d.W;
+    const int64_t xrow = (n * d.Ts + s) * d.W;
     const float* qr = d.q + n * d.ldq;
     float acc = 0.f;
     for (int c = lane * 4; c < d.W; c += 256) {
-        const float4 pv = *reinterpret_cast<const float4*>(xr + c);
+        const float4 pv = ld4_any<S16>(d.x, xrow + c);
         const float4 qv = *reinterpret_cast<const float4*>(qr + c);
         if (MODE == 0) {
             const float4 vv = *reinterpret_cast<const float4*>(d.v + c);
@@ -912,7 +985,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void attn_dot_side_kernel(DotArgs d,
 int vag_attn_dot_side_launch(int mode, const float* x, const float* q, int64_t ldq, const float* v, const float* mask,
                              const float* addend, int64_t N, int64_t Ts, int64_t W, float* out, int64_t M, int64_t Np,
                              int64_t K, const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* pbias,
-                             const float* padd, float* P, int64_t ldp, hipStream_t stream) {
+                             const float* padd, float* P, int64_t ldp, hipStream_t stream, bool s16) {
     VAG_CHECK_ARG(x && q && out && N > 0 && Ts > 0 && W > 0 && W % 4 == 0 && ldq % 4 == 0 && aligned16(x) && aligned16(q));
     VAG_CHECK_ARG((mode == 1 || (mode == 0 && v && aligned16(v))) && A && Wt && P && M > 0 && Np > 0 &&
                   skinny_ok(A, lda, Wt, ldw, K));
@@ -927,8 +1000,14 @@ int vag_attn_dot_side_launch(int mode, const float* x, const float* q, int64_t l
     a.bias = pbias; a.addend = padd; a.ldadd = Np; a.out = P; a.ldo = ldp; a.act = VAG_ACT_NONE;
     const int tiles_x = (int)cdiv64(Np, 16), tiles_y = (int)cdiv64(M, 16);
     const dim3 grid((unsigned)(d.nscore + tiles_x * tiles_y));
-    if (mode == 0) hipLaunchKernelGGL((attn_dot_side_kernel<0, 8>), grid, dim3(512), 0, stream, d, a, tiles_x);
-    else hipLaunchKernelGGL((attn_dot_side_kernel<1, 16>), grid, dim3(1024), 0, stream, d, a, tiles_x);
+    if (s16) {
+        VAG_CHECK_ARG(K % 8 == 0 && W % 4 == 0);
+        if (mode == 0) hipLaunchKernelGGL((attn_dot_side_kernel<0, 8, true>), grid, dim3(512), 0, stream, d, a, tiles_x);
+        else hipLaunchKernelGGL((attn_dot_side_kernel<1, 16, true>), grid, dim3(1024), 0, stream, d, a, tiles_x);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL((attn_dot_side_kernel<0, 8>), grid, dim3(512), 0, stream, d, a, tiles_x);
+        else hipLaunchKernelGGL((attn_dot_side_kernel<1, 16>), grid, dim3(1024), 0, stream, d, a, tiles_x);
+    }
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
@@ -985,7 +1064,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_bt_kernel(SkinnyArgs a) {
 // Fused GRU cell: 16 rows x 16 hidden units x 3 gates per workgroup.  The 256 (row, unit) outputs are finished by the
 // first 256 threads, one each; their epilogue operands (the other projection, h_prev, bias) are requested BEFORE the
 // product so that they arrive under it instead of costing a second memory round trip.
-template <int WAVES>
+template <int WAVES, bool WH = false>
 __global__ __launch_bounds__(WAVES * 64) void gru_step_kernel(GruStepArgs a) {
     constexpr int NT = 3;
     __shared__ __attribute__((aligned(16))) float red[WAVES * NT * 64 * 4];
@@ -1009,10 +1088,10 @@ __global__ __launch_bounds__(WAVES * 64) void gru_step_kernel(GruStepArgs a) {
     }
     const float* ap[1];
     const float* wp[NT];
-    ap[0] = sd.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + 4 * g;
+    ap[0] = sd.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + skinny_koff<WH>(g);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) wp[j] = sd.W + (int64_t)min(j * H + u0 + r, 3 * H - 1) * a.ldw + 4 * g;
-    skinny_mma<WAVES, 1, NT>(ap, wp, a.K, red);
+    for (int j = 0; j < NT; ++j) wp[j] = skinny_wptr<WH>(sd.W, min(j * H + u0 + r, 3 * H - 1), a.ldw, skinny_koff<WH>(g));
+    skinny_mma_any<WAVES, 1, NT, 4, WH>(ap, wp, a.K, red);
     if (!eok) return;
     const float c_r = skinny_sum1<WAVES, NT>(red, 0, erow, ecol) + b_r;
     const float c_z = skinny_sum1<WAVES, NT>(red, 1, erow, ecol) + b_z;
@@ -1036,7 +1115,7 @@ __global__ __launch_bounds__(WAVES * 64) void gru_step_kernel(GruStepArgs a) {
 // the 8 units, tile 1 [n | unused]; UNITS = 4: one tile [r | z | n | unused].  For single-direction launches with
 // M <= 64 rows this puts a workgroup on every CU instead of every other one, with less MFMA time and fewer bytes per
 // workgroup (unused tile rows issue no loads).
-template <int WAVES, int UNITS>
+template <int WAVES, int UNITS, bool WH = false>
 __global__ __launch_bounds__(WAVES * 64) void gru_step_small_kernel(GruStepArgs a) {
     constexpr int NT = UNITS == 8 ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float red[WAVES * NT * 64 * 4];
@@ -1060,16 +1139,17 @@ __global__ __launch_bounds__(WAVES * 64) void gru_step_small_kernel(GruStepArgs 
     }
     const float* ap[1];
     const float* wp[NT];
-    ap[0] = sd.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + 4 * g;
+    ap[0] = sd.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + skinny_koff<WH>(g);
     const int unit = min(u0 + (r % UNITS), H - 1);
     const int gate = r / UNITS;                                   // gate of tile 0's row r
+    const int ko = skinny_koff<WH>(g);
     if (UNITS == 8) {
-        wp[0] = sd.W + (int64_t)(gate * H + unit) * a.ldw + 4 * g;                                  // r | z
-        wp[NT - 1] = r < 8 ? sd.W + (int64_t)(2 * H + unit) * a.ldw + 4 * g : nullptr;              // n | -
+        wp[0] = skinny_wptr<WH>(sd.W, gate * H + unit, a.ldw, ko);                                  // r | z
+        wp[NT - 1] = r < 8 ? skinny_wptr<WH>(sd.W, 2 * H + unit, a.ldw, ko) : nullptr;              // n | -
     } else {
-        wp[0] = gate < 3 ? sd.W + (int64_t)(gate * H + unit) * a.ldw + 4 * g : nullptr;             // r | z | n | -
+        wp[0] = gate < 3 ? skinny_wptr<WH>(sd.W, gate * H + unit, a.ldw, ko) : nullptr;             // r | z | n | -
     }
-    skinny_mma<WAVES, 1, NT>(ap, wp, a.K, red);
+    skinny_mma_any<WAVES, 1, NT, 4, WH>(ap, wp, a.K, red);
     if (!eok) return;
     const float c_r = skinny_sum1<WAVES, NT>(red, 0, erow, ecol) + b_r;
     const float c_z = skinny_sum1<WAVES, NT>(red, 0, erow, UNITS + ecol) + b_z;
@@ -1094,7 +1174,7 @@ __global__ __launch_bounds__(WAVES * 64) void gru_step_small_kernel(GruStepArgs 
 // Same structure: 256 outputs finished by 256 threads, epilogue operands prefetched under the product.
 // (A half-tile variant -- 8 output columns per workgroup on twice the workgroups, as gru_step_small_kernel does for the
 // forward cell -- measured no gain here: the MFMA count per workgroup stays that of a full tile.)
-template <int WAVES, int U>
+template <int WAVES, int U, bool WH = false>
 __global__ __launch_bounds__(WAVES * 64) void gru_bwd_step_kernel(GruBwdStepArgs a) {
     __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4];
     const GruBwdStepSide& sd = a.s[blockIdx.z];
@@ -1123,9 +1203,9 @@ __global__ __launch_bounds__(WAVES * 64) void gru_bwd_step_kernel(GruBwdStepArgs
     }
     const float* ap[1];
     const float* wp[1];
-    ap[0] = sd.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + 4 * g;
-    wp[0] = sd.WT + (int64_t)min(nb + r, H - 1) * a.ldw + 4 * g;
-    skinny_mma<WAVES, 1, 1, U>(ap, wp, a.K, red);
+    ap[0] = sd.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + skinny_koff<WH>(g);
+    wp[0] = skinny_wptr<WH>(sd.WT, min(nb + r, H - 1), a.ldw, skinny_koff<WH>(g));
+    skinny_mma_any<WAVES, 1, 1, U, WH>(ap, wp, a.K, red);
     if (!eok) return;
     float dh = skinny_sum1<WAVES, 1>(red, 0, erow, ecol) + add;
     if (!a.has_cell) {
@@ -1153,8 +1233,14 @@ static bool skinny_ok(const float* A, int64_t lda, const float* W, int64_t ldw, 
     return aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && K % 4 == 0 && K >= 4;
 }
 
-static void skinny_plain_go(const SkinnyArgs& a, hipStream_t stream) {
+static void skinny_plain_go(const SkinnyArgs& a, hipStream_t stream, bool w16 = false) {
     dim3 grid((unsigned)cdiv64(a.N, 16), (unsigned)cdiv64(a.M, 16), 1);
+    if (w16) {
+        if (a.K <= 256) hipLaunchKernelGGL((skinny_plain_kernel<4, true>), grid, dim3(256), 0, stream, a);
+        else if (a.K <= 1024) hipLaunchKernelGGL((skinny_plain_kernel<8, true>), grid, dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((skinny_plain_kernel<16, true>), grid, dim3(1024), 0, stream, a);
+        return;
+    }
     if (a.K <= 256) hipLaunchKernelGGL((skinny_plain_kernel<4>), grid, dim3(256), 0, stream, a);
     else if (a.K <= 1024) hipLaunchKernelGGL((skinny_plain_kernel<8>), grid, dim3(512), 0, stream, a);
     else hipLaunchKernelGGL((skinny_plain_kernel<16>), grid, dim3(1024), 0, stream, a);
@@ -1162,9 +1248,18 @@ static void skinny_plain_go(const SkinnyArgs& a, hipStream_t stream) {
 
 int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
                       const float* bias, const float* addend, int64_t ldadd, float* out, int64_t ldo, int act,
-                      hipStream_t stream) {
+                      hipStream_t stream, bool w16) {
     VAG_CHECK_ARG(M >= 0 && N >= 0 && K > 0 && A && W && out);
     if (M == 0 || N == 0) return VAG_OK;
+    if (w16) {      // W stored as fp16: skinny kernels only (the per-time-step products of the 2-byte storage mode)
+        VAG_CHECK_ARG(M <= 256 && K % 8 == 0 && lda % 4 == 0 && ldw % 8 == 0 && aligned16(A) && aligned16(W));
+        SkinnyArgs a;
+        a.A = A; a.W = W; a.lda = lda; a.ldw = ldw; a.M = (int)M; a.N = (int)N; a.K = (int)K;
+        a.bias = bias; a.addend = addend; a.ldadd = ldadd; a.out = out; a.ldo = ldo; a.act = act;
+        skinny_plain_go(a, stream, true);
+        VAG_LAUNCH_CHECK();
+        return VAG_OK;
+    }
     // every 16x16 output tile re-reads its operand rows: M*N*K/2 bytes requested in all.  Measured at the beam-decode
     // shape (B*k = 192 rows): the 192x2560x512 query/gate product (126 MB) is still faster here (5 vs 16 us), the
     // 192x9391x256 vocabulary product (230 MB) is faster on the LDS-tiled kernel (19 vs 38 us).
@@ -1222,12 +1317,13 @@ int vag_skinny_batched_launch(int64_t nb, int64_t M, int64_t N, int64_t K, const
     return VAG_OK;
 }
 
-int vag_gru_step_launch(const GruStepArgs& a, int nz, hipStream_t stream) {
+int vag_gru_step_launch(const GruStepArgs& a, int nz, hipStream_t stream, bool w16) {
     VAG_CHECK_ARG(a.H > 0 && a.M > 0 && a.K > 0 && (nz == 1 || nz == 2));
     for (int z = 0; z < nz; ++z) {
         VAG_CHECK_ARG(a.s[z].A && a.s[z].W && a.s[z].other && a.s[z].hprev && a.s[z].hout);
         VAG_CHECK_ARG(skinny_ok(a.s[z].A, a.lda, a.s[z].W, a.ldw, a.K));
     }
+    VAG_CHECK_ARG(!w16 || (a.K % 8 == 0 && a.ldw % 8 == 0));
     // tile choice from measurements (tools/exp_tiles.py, tools/skinny_probe.hip): 16 units x 16 rows; half tiles on
     // twice the CUs were no faster (the launch is paced by load requests issued chip-wide, duplicates included).
     dim3 grid((unsigned)cdiv64(a.H, 16), (unsigned)cdiv64(a.M, 16), (unsigned)nz);
@@ -1236,36 +1332,46 @@ int vag_gru_step_launch(const GruStepArgs& a, int nz, hipStream_t stream) {
     static const int64_t maxwg = getenv("VAG_GRU_SMALL_MAXWG") ? atoi(getenv("VAG_GRU_SMALL_MAXWG")) : 160;
     if (a.K > 256 && wgs <= maxwg && (small == 8 || small == 4)) {
         // fewer than ~2/3 of the CUs would get a workgroup: fewer units each on more workgroups
+        const dim3 g8((unsigned)cdiv64(a.H, 8), grid.y, grid.z), g4((unsigned)cdiv64(a.H, 4), grid.y, grid.z);
         if (small == 8) {
-            hipLaunchKernelGGL((gru_step_small_kernel<8, 8>), dim3((unsigned)cdiv64(a.H, 8), grid.y, grid.z), dim3(512), 0,
-                               stream, a);
+            if (w16) hipLaunchKernelGGL((gru_step_small_kernel<8, 8, true>), g8, dim3(512), 0, stream, a);
+            else hipLaunchKernelGGL((gru_step_small_kernel<8, 8>), g8, dim3(512), 0, stream, a);
         } else {
-            hipLaunchKernelGGL((gru_step_small_kernel<8, 4>), dim3((unsigned)cdiv64(a.H, 4), grid.y, grid.z), dim3(512), 0,
-                               stream, a);
+            if (w16) hipLaunchKernelGGL((gru_step_small_kernel<8, 4, true>), g4, dim3(512), 0, stream, a);
+            else hipLaunchKernelGGL((gru_step_small_kernel<8, 4>), g4, dim3(512), 0, stream, a);
         }
         VAG_LAUNCH_CHECK();
         return VAG_OK;
     }
-    if (a.K <= 256) hipLaunchKernelGGL((gru_step_kernel<4>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((gru_step_kernel<8>), grid, dim3(512), 0, stream, a);
+    if (w16) {
+        if (a.K <= 256) hipLaunchKernelGGL((gru_step_kernel<4, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((gru_step_kernel<8, true>), grid, dim3(512), 0, stream, a);
+    } else {
+        if (a.K <= 256) hipLaunchKernelGGL((gru_step_kernel<4>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((gru_step_kernel<8>), grid, dim3(512), 0, stream, a);
+    }
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
 
-int vag_gru_bwd_step_launch(const GruBwdStepArgs& a, int nz, hipStream_t stream) {
+int vag_gru_bwd_step_launch(const GruBwdStepArgs& a, int nz, hipStream_t stream, bool w16) {
     VAG_CHECK_ARG(a.H > 0 && a.M > 0 && a.K > 0 && (nz == 1 || nz == 2));
     for (int z = 0; z < nz; ++z) {
         VAG_CHECK_ARG(a.s[z].A && a.s[z].WT && skinny_ok(a.s[z].A, a.lda, a.s[z].WT, a.ldw, a.K));
         if (a.has_cell) VAG_CHECK_ARG(a.s[z].save && a.s[z].hprev && a.s[z].dgi && a.s[z].dgh && a.s[z].dh_direct);
         else VAG_CHECK_ARG(a.s[z].dh_out != nullptr);
     }
+    VAG_CHECK_ARG(!w16 || (a.K % 8 == 0 && a.ldw % 8 == 0));
     dim3 grid((unsigned)cdiv64(a.H, 16), (unsigned)cdiv64(a.M, 16), (unsigned)nz);
     // waves by K; chunks in flight so that a wave's K share (K / waves, in 16s) is one round of requests when it fits
-    if (a.K <= 256) hipLaunchKernelGGL((gru_bwd_step_kernel<4, 4>), grid, dim3(256), 0, stream, a);
-    else if (a.K <= 512) hipLaunchKernelGGL((gru_bwd_step_kernel<8, 4>), grid, dim3(512), 0, stream, a);
-    else if (a.K <= 1024) hipLaunchKernelGGL((gru_bwd_step_kernel<8, 8>), grid, dim3(512), 0, stream, a);
-    else if (a.K <= 1536) hipLaunchKernelGGL((gru_bwd_step_kernel<16, 6>), grid, dim3(1024), 0, stream, a);
-    else hipLaunchKernelGGL((gru_bwd_step_kernel<16, 4>), grid, dim3(1024), 0, stream, a);
+#define VAG_BWD_GO(WH)                                                                                                \
+    if (a.K <= 256) hipLaunchKernelGGL((gru_bwd_step_kernel<4, 4, WH>), grid, dim3(256), 0, stream, a);               \
+    else if (a.K <= 512) hipLaunchKernelGGL((gru_bwd_step_kernel<8, 4, WH>), grid, dim3(512), 0, stream, a);          \
+    else if (a.K <= 1024) hipLaunchKernelGGL((gru_bwd_step_kernel<8, 8, WH>), grid, dim3(512), 0, stream, a);         \
+    else if (a.K <= 1536) hipLaunchKernelGGL((gru_bwd_step_kernel<16, 6, WH>), grid, dim3(1024), 0, stream, a);       \
+    else hipLaunchKernelGGL((gru_bwd_step_kernel<16, 4, WH>), grid, dim3(1024), 0, stream, a);
+    if (w16) { VAG_BWD_GO(true) } else { VAG_BWD_GO(false) }
+#undef VAG_BWD_GO
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

@@ -79,7 +79,7 @@ int vag_attn_scores_ex_launch(int mode, const float* pe, const float* q, int64_t
                               float* scores, hipStream_t s);
 int vag_attn_ctx_gru_launch(const float* scores, const float* encwp, int64_t N, int64_t rps, int64_t Ts, int64_t H,
                             const float* b_ih, const float* hp, int64_t ldhp, const float* hprev, float* alpha, float* hout,
-                            float* save, hipStream_t s);
+                            float* save, hipStream_t s, bool x16 = false);      // x16: encwp is fp16
 // scores + softmax + projected context + gru_2 cell in one launch (training sizes: see vag_attn_fused_fwd_ok)
 bool vag_attn_fused_fwd_ok(int64_t Ts, int64_t H, int64_t ldq, int64_t ldhp);
 int vag_attn_fused_fwd_launch(const float* pe, const float* q, int64_t ldq, const float* v, const float* mask,
@@ -97,13 +97,14 @@ int vag_softmax_bwd_launch(const float* alpha, const float* dalpha, int64_t N, i
 // alpha/dalpha given: dscore is first computed (softmax backward) and stored; NULL: dscore is an input.
 int vag_attn_dq_launch(const float* pe, const float* q, int64_t ldq, const float* v, const float* alpha,
                        const float* dalpha, float* dscore, int64_t N, int64_t Ts, int64_t C, float* dq, int64_t lddq,
-                       hipStream_t s);
+                       hipStream_t s, bool x16 = false);                       // x16: pe is fp16
 // After the time loop: d_pe[b,s,c] = v[c] sum_t ds[t,b,s] (1-th^2);  dvp[(z*B+b),c] = sum_{t, s in chunk z} ds*th
 // (VAG_POST_CHUNKS(Ts) = ceil(Ts/8) chunk rows per batch row; column-sum all rows for dv);
 // d_enc[b,s,c] (+)= sum_t alpha[t,b,s] dc[t,b,c]   (skipped when dc == NULL)
 int vag_attn_post_bwd_launch(const float* pe, const float* q_all, int64_t ldq, const float* v, const float* ds_all,
                              const float* alpha_all, const float* dc_all, int64_t B, int64_t Ts, int64_t Tt,
-                             int64_t C, float* d_pe, float* dvp, float* d_enc, int accumulate_enc, hipStream_t s);
+                             int64_t C, float* d_pe, float* dvp, float* d_enc, int accumulate_enc, hipStream_t s,
+                             bool x16 = false);                                // x16: pe is fp16
 // out[b,t,c] (+)= a1[b,t]*x1[b,c] + a2[b,t]*x2[b,c]
 int vag_outer2_launch(const float* a1, const float* x1, const float* a2, const float* x2, int64_t B, int64_t Ts,
                       int64_t C, float* out, int accumulate, hipStream_t s);
@@ -155,6 +156,7 @@ int vag_beam_finish_launch(const float* nll, const int64_t* beam, int64_t max_le
 
 // ---------------- api.hip internals shared with step.hip ----------------
 void vag_set_derived_override(const float* d);
+void vag_set_store16(bool on);
 int vag_dec_init_bwd_impl(const float* mask, const float* xmix, const float* h0, float split, const float* W, float* d_h0,
                           int64_t B, int64_t Ts, int64_t C, int64_t H, float* d_enc, int accumulate_enc, float* d_ctx,
                           int accumulate_ctx, float* g_W, float* g_b, float* scratch, hipStream_t s);

@@ -76,9 +76,9 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(uint64_t* rng, const
     }
 }
 
-struct DerivedScope {       // points the operators at the driver's derived weights for the duration of one call
-    explicit DerivedScope(const float* d) { vag_set_derived_override(d); }
-    ~DerivedScope() { vag_set_derived_override(nullptr); }
+struct DerivedScope {       // points the operators at the driver's derived weights (and storage mode) for the duration of one call
+    DerivedScope(const float* d, bool store16) { vag_set_derived_override(d); vag_set_store16(store16); }
+    ~DerivedScope() { vag_set_derived_override(nullptr); vag_set_store16(false); }
 };
 
 }  // namespace
@@ -126,7 +126,8 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     VAG_CHECK_ARG(w.enc_emb && w.ini_w && w.ini_b && w.attn_e && (phases & 7) != 0);
     const int64_t B = c.B, Ts = c.Ts, Tt = c.Tt, H = c.H, C = 2 * H, S = c.S, V = c.V, Et = c.Et;
     StepWs k = step_ws(ws, c);
-    DerivedScope scope(derived);
+    VAG_CHECK_ARG(c.storage == 0 || (c.storage == 1 && derived && !c.free_run && H % 8 == 0));
+    DerivedScope scope(derived, c.storage == 1);
     const bool has_vse = mm && c.rank_kind >= 0;
     const float w_mt = mm ? c.loss_w : 1.f, w_vse = mm ? 1.f - c.loss_w : 0.f;
     float* h0 = k.hseq;                    // [h0, h2_0 .. h2_{Tt-1}] in one buffer: the W_hh1 gradient is one product

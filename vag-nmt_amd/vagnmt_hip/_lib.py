@@ -41,7 +41,7 @@ class ModelW(C.Structure):
 class StepCfg(C.Structure):
     """vag_step_cfg"""
     _fields_ = [(n, I64) for n in ("B", "Ts", "Tt", "Es", "Et", "H", "S", "I", "V", "ldl")] + \
-               [(n, I32) for n in ("multimodal", "attn_method", "activation_vse", "rank_kind", "free_run", "reserved")] + \
+               [(n, I32) for n in ("multimodal", "attn_method", "activation_vse", "rank_kind", "free_run", "storage")] + \
                [(n, F) for n in ("margin", "loss_w", "init_split", "p_emb", "p_ctx", "p_out")]
 
 
@@ -105,8 +105,9 @@ PROTOS = {
     "vag_step_ws_offset": (I64, [C.POINTER(StepCfg), I32]),
     "vag_train_step": (I32, [C.POINTER(StepCfg), C.POINTER(ModelW), C.POINTER(ModelW), P, P, P, P, P, P, P, P, P, I32, P]),
     "vag_copy4": (I32, [C.POINTER(P), C.POINTER(P), C.POINTER(I64), I32, P]),
+    "vag_set_operator_context": (I32, [P, I32]),
     "vag_derived_floats": (I64, [I64]),
-    "vag_derive_weights": (I32, [DecW, P, P, I64, P, P]),
+    "vag_derive_weights": (I32, [DecW, P, P, I64, I32, P, P]),
     "vag_cgru_ws_offset": (I64, [I64, I64, I64, I64, I64, I32]),
     "vag_dropout_mask": (I32, [P, I32, I64, F, P, P]),
     "vag_rng_advance": (I32, [P, P]),

@@ -55,7 +55,12 @@ def model_struct(model, grad=False):
 
 
 class FusedStep:
-    def __init__(self, model, criterion_mt, criterion_vse):
+    def __init__(self, model, criterion_mt, criterion_vse, storage="f32"):
+        """storage: "f32", or "f16" = BASELINE configs[4]'s 2-byte storage: the recurrences' weights and the attention keys
+        are kept as fp16 in HBM on teacher-forced steps (free-running steps of the same driver use fp32 storage)."""
+        if storage not in ("f32", "f16"):
+            raise ValueError("storage must be 'f32' or 'f16'")
+        self.storage16 = storage == "f16"
         self.model = model
         self.mm = hasattr(model, "vse_imagine")
         self.vw = criterion_mt.weight
@@ -66,6 +71,8 @@ class FusedStep:
         self.ldl = (self.V + 3) // 4 * 4
         self.Es = enc.embedding.weight.shape[1]
         self.Et = dec.embedding.weight.shape[1]
+        if self.storage16 and self.H % 8 != 0:
+            raise ValueError("fp16 storage needs hidden_size % 8 == 0")
         self.S = model.vse_imagine.shared_embedding_size if self.mm else 0
         self.I = model.vse_imagine.im_size if self.mm else 0
         self.rank_kind, self.margin = -1, 0.0
@@ -93,6 +100,7 @@ class FusedStep:
         c.activation_vse = 1 if (self.mm and m.vse_imagine.activation_vse) else 0
         c.rank_kind = self.rank_kind
         c.free_run = 0 if teacher else 1
+        c.storage = 1 if (self.storage16 and teacher) else 0
         c.margin = self.margin
         c.loss_w = float(m.loss_w) if self.mm else 1.0
         c.init_split = float(m.init_split) if self.mm else 0.0
@@ -146,8 +154,8 @@ class FusedStep:
     def refresh_derived(self):
         """Per optimiser step: the stacked / folded / transposed weights the recurrences read."""
         g = self.model.encoder.gru
-        call("vag_derive_weights", self.w.dec, ptr(g.weight_hh_l0), ptr(g.weight_hh_l0_reverse), self.H, ptr(self.derived),
-             stream())
+        call("vag_derive_weights", self.w.dec, ptr(g.weight_hh_l0), ptr(g.weight_hh_l0_reverse), self.H,
+             1 if self.storage16 else 0, ptr(self.derived), stream())
 
     def run(self, B, Ts, Tt, teacher, phases):
         m = self.model

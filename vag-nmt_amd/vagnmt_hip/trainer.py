@@ -102,7 +102,7 @@ class TrainStep:
     def __init__(self, model, criterion_mt, criterion_vse=None, lr=4e-4, weight_decay=1e-5, clip=1.0,
                  teacher_force_ratio=0.8, betas=(0.9, 0.999), eps=1e-8, vse_separate=False, use_graph=True,
                  process_group=None, world_size=1, max_graphs=48, pad_src=4, fused=None, backend=None,
-                 force_phased=False):
+                 force_phased=False, storage="f32"):
         self.model = model
         self.criterion_mt = criterion_mt
         self.criterion_vse = criterion_vse
@@ -137,8 +137,10 @@ class TrainStep:
         if backend is None and criterion_mt is not None and dev.type == "cuda":
             from .fused import FusedStep, fusable
             if (fused is None or fused) and fusable(model, criterion_mt, criterion_vse):
-                self.backend = _FusedBackend(self, FusedStep(model, criterion_mt, criterion_vse))
+                self.backend = _FusedBackend(self, FusedStep(model, criterion_mt, criterion_vse, storage=storage))
             else:
+                if storage != "f32":
+                    raise ValueError("fp16 storage is a mode of the fused step (vag_train_step)")
                 self.backend = _AutogradBackend(self)
 
     def set_lr(self, lr):
