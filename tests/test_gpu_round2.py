@@ -414,3 +414,39 @@ def test_fp16_storage_trains_and_free_running_steps_fall_back_to_fp32_storage():
     ts = TrainStep(m, cm, cv, use_graph=True, storage="f16")
     losses = [float(ts.step(src, lens, tgt, im, teacher=(i % 3 != 2))[0]) for i in range(9)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# output head in row chunks: the (Tt*B, V) logits are never formed as a whole (forward per chunk, backward recomputes)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+@pytest.mark.parametrize("chunk_steps", [1, 5])           # 5 does not divide Tt = 12: a ragged last chunk
+@pytest.mark.parametrize("mode", ["fused", "recompute", "split_phases"])
+def test_chunked_head_equals_whole_sequence_head(monkeypatch, storage, chunk_steps, mode):
+    """fused: forward+backward in one call -- each chunk is finished (d(logits) and its three products) in the forward.
+    recompute / split_phases: the backward builds each chunk's logits again (forced by the switch, or because the
+    backward is a separate call)."""
+    from vagnmt_hip.trainer import TrainStep
+    m_of, (src, lens, tgt, im), cm, cv = _fp16_case("mid")
+    lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    B = src.shape[0]
+    out = []
+    for chunk in (0, chunk_steps * B):
+        monkeypatch.setenv("VAG_HEAD_CHUNK", str(chunk))
+        monkeypatch.setenv("VAG_HEAD_FUSE", "0" if mode == "recompute" else "1")
+        m = m_of()
+        ts = TrainStep(m, cm, cv, use_graph=False, storage=storage, pad_src=1)
+        m.train()                                   # dropout on: the recomputation must see the same masks
+        if mode == "split_phases" and chunk:
+            ts.backend.run(src, lt, tgt, im, True, 1)
+            ts.backend.run(src, lt, tgt, im, True, 6)
+        else:
+            ts.backend.run(src, lt, tgt, im, True, 7)
+        out.append(([float(x) for x in ts.backend.outputs()], ts.fp.grad.detach().clone()))
+    (l0, g0), (l1, g1) = out
+    assert np.allclose(l0, l1, rtol=1e-6, atol=1e-7), (l0, l1)
+    # same products on the same operands chunk by chunk; only the summation order of the weight-gradient sums over rows
+    # (and the split-K atomics) differs
+    scale = g0.abs().max().item()
+    assert (g0 - g1).abs().max().item() <= 2e-5 * scale, ((g0 - g1).abs().max().item(), scale)
+    assert g0.abs().sum().item() > 0

@@ -47,6 +47,19 @@ void vag_set_derived_override(const float* d) { g_derived = d; }
 static thread_local bool g_store16 = false;
 void vag_set_store16(bool on) { g_store16 = on; vag_gemm_set_planes(on ? 2 : 3); }
 static inline const float* as_f(const vag_half* p) { return reinterpret_cast<const float*>(p); }
+// Row chunk of the output head (0 = whole sequence at once).  With a chunk set the (Tt*B, V) logits are never formed as a
+// whole: forward computes them chunk by chunk for the log-sum-exp / NLL, backward RECOMPUTES each chunk, turns it into
+// d(logits) in place and consumes it with the two products that need it -- the chunk (sized to stay inside the 256 MB
+// Infinity Cache) is the only logits storage that is touched.  Set by the step driver for large Tt*B*V (configs[4]).
+static thread_local int64_t g_head_chunk = 0;
+void vag_set_head_chunk(int64_t rows) { g_head_chunk = rows > 0 ? rows : 0; }
+// With a chunk set AND a backward that is known to follow in the same call (the step driver with phases 1|2), the forward
+// finishes each chunk completely: a row's log-sum-exp needs only that row, and d(loss)/d(loss_mt) = w_mt and 1/count are
+// known before the step starts, so d(logits) of the chunk, its share of d(tmid), of g(out.weight) and of g(out.bias) are
+// produced while the chunk is still on the die -- nothing is recomputed and the backward starts at d(tmid).
+struct HeadFuse { const vag_head_g* g; const float* d_loss; float* dt; bool done; };
+static thread_local HeadFuse g_head_fuse = {nullptr, nullptr, nullptr, false};
+void vag_set_head_fuse(const vag_head_g* g, const float* d_loss, float* dt) { g_head_fuse = HeadFuse{g, d_loss, dt, false}; }
 
 extern "C" {
 
@@ -821,12 +834,31 @@ int vag_head_ce_seq_fwd_impl(const float* h2_all, const float* c_all, const floa
     VAG_CHECK_ARG(w.w1 && w.b1 && w.w2 && w.b2 && w.w3 && w.b3 && w.out_w && w.out_b);
     VAG_CHECK_ARG(B > 0 && Tt > 0 && E % 4 == 0 && H % 4 == 0 && V > 0 && ldl >= V && ldl % 4 == 0);
     const int64_t R = Tt * B;
-    if (!logits_ready) {
-        VAG_TRY(head_pre_seq(h2_all, c_all, e_all, w, R, E, H, p_out, rng, tmid, s));
-        VAG_TRY(vag_gemm_launch(R, V, E, 1.f, tmid, E, 1, w.out_w, 1, E, 0.f, logits, ldl, w.out_b, 0, s));
-    }
     if (!inv_cnt_ready) VAG_TRY(vag_inv_cnt_launch(tgt, B, Tt, inv_cnt, s));
-    VAG_TRY(vag_lse_nll_launch(logits, ldl, R, V, tgt, B, Tt, vocab_weight, lse, nll, nullptr, 0, nullptr, 0, s));
+    const int64_t CH = (!logits_ready && g_head_chunk > 0 && g_head_chunk < R) ? (g_head_chunk + B - 1) / B * B : 0;
+    if (CH > 0) {
+        VAG_TRY(head_pre_seq(h2_all, c_all, e_all, w, R, E, H, p_out, rng, tmid, s));
+        for (int64_t r0 = 0; r0 < R; r0 += CH) {        // chunks start on a time-step boundary: row r0 = step r0 / B
+            const int64_t rows = R - r0 < CH ? R - r0 : CH;
+            VAG_TRY(vag_gemm_launch(rows, V, E, 1.f, tmid + r0 * E, E, 1, w.out_w, 1, E, 0.f, logits, ldl, w.out_b, 0, s));
+            VAG_TRY(vag_lse_nll_launch(logits, ldl, rows, V, tgt + r0 / B, B, Tt, vocab_weight, lse + r0, nll + r0, nullptr, 0,
+                                       nullptr, 0, s));
+            if (g_head_fuse.g) {
+                const vag_head_g& g = *g_head_fuse.g;
+                VAG_TRY(vag_ce_bwd_colsum_launch(logits, ldl, rows, V, tgt + r0 / B, B, Tt, vocab_weight, lse + r0, inv_cnt,
+                                                 g_head_fuse.d_loss, g.out_b, s));
+                VAG_TRY(gemm_nn(rows, E, V, logits, ldl, w.out_w, E, 0.f, g_head_fuse.dt + r0 * E, E, s));
+                VAG_TRY(gemm_tn_acc(V, E, rows, logits, ldl, tmid + r0 * E, E, g.out_w, E, s));
+            }
+        }
+        if (g_head_fuse.g) g_head_fuse.done = true;
+    } else {
+        if (!logits_ready) {
+            VAG_TRY(head_pre_seq(h2_all, c_all, e_all, w, R, E, H, p_out, rng, tmid, s));
+            VAG_TRY(vag_gemm_launch(R, V, E, 1.f, tmid, E, 1, w.out_w, 1, E, 0.f, logits, ldl, w.out_b, 0, s));
+        }
+        VAG_TRY(vag_lse_nll_launch(logits, ldl, R, V, tgt, B, Tt, vocab_weight, lse, nll, nullptr, 0, nullptr, 0, s));
+    }
     if (losses) return vag_loss_mt_mix_launch(nll, inv_cnt, B, Tt, losses, w_mt, w_vse, has_vse, s);
     return vag_loss_mt_launch(nll, inv_cnt, B, Tt, loss_mt, s);
 }
@@ -835,9 +867,9 @@ extern "C" {
 // d(logits) -> d(tmid) -> through dropout+tanh -> input gradients.  dt (R,E) is left holding d(pre-activation).
 static int head_bwd_data(const vag_head_w& w, int64_t R, int64_t E, int64_t H, int64_t V, float p_out, const uint64_t* rng,
                          const float* tmid, const float* dlogits, int64_t ldl, float* d_h2_all, float* d_c_all,
-                         float* d_e_all, float* dt, hipStream_t s) {
+                         float* d_e_all, float* dt, hipStream_t s, bool dt_ready = false) {
     const int64_t C = 2 * H;
-    VAG_TRY(gemm_nn(R, E, V, dlogits, ldl, w.out_w, E, 0.f, dt, E, s));
+    if (!dt_ready) VAG_TRY(gemm_nn(R, E, V, dlogits, ldl, w.out_w, E, 0.f, dt, E, s));
     VAG_TRY(vag_tanh_bwd_launch(tmid, dt, dt, R * E, rng, VAG_DROP_DEC_OUT, p_out, s));   // tmid holds tanh(.)*mul
     VagGemmGroup grp5;              // three independent products of d(pre-activation): one grouped launch
     VAG_TRY(gemm_nn(R, H, E, dt, E, w.w1, H, 0.f, d_h2_all, H, s));
@@ -849,10 +881,10 @@ static int head_bwd_data(const vag_head_w& w, int64_t R, int64_t E, int64_t H, i
 // so they may run on a side stream beside the decoder's backward recurrence.
 static int head_bwd_weights(const float* h2_all, const float* c_all, const float* e_all, int64_t R, int64_t E, int64_t H,
                             int64_t V, const float* tmid, const float* dlogits, int64_t ldl, const float* dt,
-                            const vag_head_g& g, hipStream_t s, bool out_b_done = false) {
+                            const vag_head_g& g, hipStream_t s, bool out_b_done = false, bool out_w_done = false) {
     const int64_t C = 2 * H;
     VagGemmGroup grp6;
-    VAG_TRY(gemm_tn_acc(V, E, R, dlogits, ldl, tmid, E, g.out_w, E, s));
+    if (!out_w_done) VAG_TRY(gemm_tn_acc(V, E, R, dlogits, ldl, tmid, E, g.out_w, E, s));
     if (!out_b_done) VAG_TRY(vag_colsum_launch(dlogits, R, V, ldl, g.out_b, s));
     VAG_TRY(gemm_tn_acc(E, H, R, dt, E, h2_all, H, g.w1, H, s));
     VAG_TRY(gemm_tn_acc(E, C, R, dt, E, c_all, C, g.w2, C, s));
@@ -894,6 +926,23 @@ int vag_head_ce_seq_bwd(const float* h2_all, const float* c_all, const float* e_
     VAG_CHECK_ARG(w.w1 && w.w2 && w.w3 && w.out_w);
     VAG_CHECK_ARG(B > 0 && Tt > 0 && E % 4 == 0 && H % 4 == 0 && V > 0 && ldl >= V && ldl % 4 == 0);
     const int64_t R = Tt * B;
+    const int64_t CH = (g_head_chunk > 0 && g_head_chunk < R) ? (g_head_chunk + B - 1) / B * B : 0;
+    if (CH > 0) {
+        // chunked head (see g_head_chunk): per chunk, logits again -> d(logits) in place (+ bias gradient) -> its share of
+        // d(tmid) and of the out.weight gradient; then everything that no longer needs the logits, as in the unchunked path
+        VAG_CHECK_ARG(w.out_b != nullptr);
+        const bool fused = g_head_fuse.done && g_head_fuse.dt == scratch;       // the forward of this call did it all
+        for (int64_t r0 = 0; r0 < R && !fused; r0 += CH) {
+            const int64_t rows = R - r0 < CH ? R - r0 : CH;
+            VAG_TRY(vag_gemm_launch(rows, V, E, 1.f, tmid + r0 * E, E, 1, w.out_w, 1, E, 0.f, logits, ldl, w.out_b, 0, s));
+            VAG_TRY(vag_ce_bwd_colsum_launch(logits, ldl, rows, V, tgt + r0 / B, B, Tt, vocab_weight, lse + r0, inv_cnt, d_loss,
+                                             g.out_b, s));
+            VAG_TRY(gemm_nn(rows, E, V, logits, ldl, w.out_w, E, 0.f, scratch + r0 * E, E, s));
+            VAG_TRY(gemm_tn_acc(V, E, rows, logits, ldl, tmid + r0 * E, E, g.out_w, E, s));
+        }
+        VAG_TRY(head_bwd_data(w, R, E, H, V, p_out, rng, tmid, logits, ldl, d_h2_all, d_c_all, d_e_all, scratch, s, true));
+        return head_bwd_weights(h2_all, c_all, e_all, R, E, H, V, tmid, logits, ldl, scratch, g, s, true, true);
+    }
     // d(logits) and the output-bias gradient in one pass over the logits
     VAG_TRY(vag_ce_bwd_colsum_launch(logits, ldl, R, V, tgt, B, Tt, vocab_weight, lse, inv_cnt, d_loss, g.out_b, s));
     VAG_TRY(head_bwd_data(w, R, E, H, V, p_out, rng, tmid, logits, ldl, d_h2_all, d_c_all, d_e_all, scratch, s));

@@ -157,6 +157,8 @@ int vag_beam_finish_launch(const float* nll, const int64_t* beam, int64_t max_le
 // ---------------- api.hip internals shared with step.hip ----------------
 void vag_set_derived_override(const float* d);
 void vag_set_store16(bool on);
+void vag_set_head_chunk(int64_t rows);
+void vag_set_head_fuse(const vag_head_g* g, const float* d_loss, float* dt);
 int vag_dec_init_bwd_impl(const float* mask, const float* xmix, const float* h0, float split, const float* W, float* d_h0,
                           int64_t B, int64_t Ts, int64_t C, int64_t H, float* d_enc, int accumulate_enc, float* d_ctx,
                           int accumulate_ctx, float* g_W, float* g_b, float* scratch, hipStream_t s);

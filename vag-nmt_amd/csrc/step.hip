@@ -7,6 +7,7 @@
 // data-parallel driver cut it where a gradient bucket becomes final (after the decoder side: everything but the encoder's
 // parameters; after the encoder's backward recurrence: the rest).
 #include "../../include/vag_nmt.h"
+#include <cstdlib>
 #include "kernels.h"
 
 #define S_(x) reinterpret_cast<hipStream_t>(x)
@@ -76,9 +77,13 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(uint64_t* rng, const
     }
 }
 
-struct DerivedScope {       // points the operators at the driver's derived weights (and storage mode) for the duration of one call
-    DerivedScope(const float* d, bool store16) { vag_set_derived_override(d); vag_set_store16(store16); }
-    ~DerivedScope() { vag_set_derived_override(nullptr); vag_set_store16(false); }
+struct DerivedScope {       // points the operators at the driver's derived weights, storage mode and head chunk for one call
+    DerivedScope(const float* d, bool store16, int64_t chunk) {
+        vag_set_derived_override(d); vag_set_store16(store16); vag_set_head_chunk(chunk);
+    }
+    ~DerivedScope() {
+        vag_set_derived_override(nullptr); vag_set_store16(false); vag_set_head_chunk(0); vag_set_head_fuse(nullptr, nullptr, nullptr);
+    }
 };
 
 }  // namespace
@@ -127,7 +132,24 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     const int64_t B = c.B, Ts = c.Ts, Tt = c.Tt, H = c.H, C = 2 * H, S = c.S, V = c.V, Et = c.Et;
     StepWs k = step_ws(ws, c);
     VAG_CHECK_ARG(c.storage == 0 || (c.storage == 1 && derived && !c.free_run && H % 8 == 0));
-    DerivedScope scope(derived, c.storage == 1);
+    // output head in row chunks once the logits would exceed 1 GiB (configs[4]: 3.3 GB): the (Tt*B, V) logits are then never
+    // formed -- one chunk buffer (<= 640 MiB) is reused.  Measured at configs[4] (fp16 storage, ms per step): whole 46.80;
+    // chunks finished in the forward 4096 rows 46.84, 2048 47.7, 1024 48.2, 512 (96 MB, Infinity-Cache sized) 55.7 -- the
+    // head is bound by its three products, not by the logits' traffic, and short chunks make those inefficient
+    // (d(tmid) = 512 x 512 x K=40000 is 16 tiles); so chunks are as long as the buffer bound allows.
+    int64_t chunk = 0;
+    if (!c.free_run && (double)c.Tt * (double)c.B * (double)c.ldl * 4.0 > 1073741824.0) {
+        chunk = (int64_t)(671088640.0 / ((double)c.ldl * 4.0)) / c.B * c.B;
+        if (chunk < c.B) chunk = c.B;
+    }
+    if (const char* e = getenv("VAG_HEAD_CHUNK")) {      // rows per chunk (0 = never chunk); tests and experiments
+        chunk = c.free_run ? 0 : atoll(e);
+    }
+    DerivedScope scope(derived, c.storage == 1, chunk);
+    // forward and backward in one call: the chunked head finishes each chunk (d(logits) and its products) in the forward;
+    // a backward called on its own (phases = 2 after an earlier phases = 1) recomputes the chunks instead
+    if (chunk > 0 && (phases & 3) == 3 && !(getenv("VAG_HEAD_FUSE") && atoi(getenv("VAG_HEAD_FUSE")) == 0))
+        vag_set_head_fuse(&g.head, k.consts + 0, k.scr_head);
     const bool has_vse = mm && c.rank_kind >= 0;
     const float w_mt = mm ? c.loss_w : 1.f, w_vse = mm ? 1.f - c.loss_w : 0.f;
     float* h0 = k.hseq;                    // [h0, h2_0 .. h2_{Tt-1}] in one buffer: the W_hh1 gradient is one product
