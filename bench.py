@@ -354,6 +354,7 @@ def main():
     ap.add_argument("--tfr", type=float, default=1.0, help="teacher forcing ratio (headline: 1.0)")
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="debug: disable the reference dropouts")
+    ap.add_argument("--overlap", action="store_true", help="CU-partitioned streams inside the step (eager launches)")
     ap.add_argument("--no-fused", action="store_true", help="debug: per-operator autograd path instead of vag_train_step")
     ap.add_argument("--config", choices=["cfg2", "cfg5", "cfg5-f32"], default="cfg2",
                     help="cfg2 = BASELINE configs[1] (the metric's configuration); cfg5 = configs[4] (H=1024, T=80, B=256, "
@@ -395,7 +396,7 @@ def main():
     crit_vse = PairwiseRankingLoss(margin=0.1)
     ts = TrainStep(model, crit_mt, crit_vse, lr=4e-4, weight_decay=1e-5, clip=1.0, teacher_force_ratio=args.tfr,
                    use_graph=not args.no_graph, process_group=pg, world_size=world, fused=not args.no_fused,
-                   storage="f16" if args.config == "cfg5" else "f32")
+                   storage="f16" if args.config == "cfg5" else "f32", overlap=args.overlap)
     src, lens, tgt, im = make_batch(c, rank, dev, ragged=args.ragged)
     lens_t = torch.tensor(lens, dtype=torch.int32, device=dev)
 

@@ -357,6 +357,10 @@ typedef struct {
                                            * kept as fp16 in HBM; accumulation, master weights, recurrent state, saved gates and
                                            * all gradients stay fp32.  Teacher-forced steps only; needs `derived` built with
                                            * with_fp16 and H % 8 == 0 */
+    int32_t overlap;                      /* 1: teacher-forced calls with phases 1|2 run the recurrences and the dense work beside
+                                           * them on two library-owned streams with disjoint compute-unit masks (forked from and
+                                           * joined to `stream`).  Such a call must NOT be captured into a graph (a captured
+                                           * fork/join is replayed without the masks); needs `derived` */
     float margin, loss_w, init_split, p_emb, p_ctx, p_out;
 } vag_step_cfg;
 /* phases: bit 0 forward (losses[0..2] = loss, loss_mt, loss_vse), bit 1 backward down to the encoder states (final for

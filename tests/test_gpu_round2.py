@@ -450,3 +450,47 @@ def test_chunked_head_equals_whole_sequence_head(monkeypatch, storage, chunk_ste
     scale = g0.abs().max().item()
     assert (g0 - g1).abs().max().item() <= 2e-5 * scale, ((g0 - g1).abs().max().item(), scale)
     assert g0.abs().sum().item() > 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# overlapped schedule: recurrences and the dense work beside them on two CU-masked streams
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+@pytest.mark.parametrize("steps", ["1", "5", "8"])          # chunk length in time steps (Tt = 12: ragged last chunk / single chunk)
+def test_overlapped_step_equals_single_stream_step(monkeypatch, storage, steps):
+    from vagnmt_hip.trainer import TrainStep
+    m_of, (src, lens, tgt, im), cm, cv = _fp16_case("mid")
+    lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    monkeypatch.setenv("VAG_OVERLAP_STEPS", steps)
+    out = []
+    for overlap in (False, True):
+        m = m_of()
+        ts = TrainStep(m, cm, cv, use_graph=False, storage=storage, pad_src=1, overlap=overlap)
+        m.train()
+        for _ in range(2):                      # twice: the second call meets the streams of the first
+            ts.fp.grad.zero_()
+            ts.backend.run(src, lt, tgt, im, True, 7)
+        torch.cuda.synchronize()
+        out.append(([float(x) for x in ts.backend.outputs()], ts.fp.grad.detach().clone()))
+    (l0, g0), (l1, g1) = out
+    assert np.allclose(l0, l1, rtol=1e-6, atol=1e-7), (l0, l1)
+    scale = g0.abs().max().item()
+    assert (g0 - g1).abs().max().item() <= 2e-5 * scale, ((g0 - g1).abs().max().item(), scale)
+
+
+def test_overlapped_training_matches_graph_training():
+    """Whole optimiser steps (clip + Adam, derived-weight refresh, teacher-forced and free-running steps mixed): the
+    overlapped eager schedule against the captured single-stream one."""
+    from vagnmt_hip.trainer import TrainStep
+    m_of, (src, lens, tgt, im), cm, cv = _fp16_case("mid")
+    res = []
+    for overlap in (False, True):
+        m = m_of()
+        ts = TrainStep(m, cm, cv, use_graph=True, overlap=overlap)
+        losses = [float(ts.step(src, lens, tgt, im, teacher=(i % 3 != 2))[0]) for i in range(9)]
+        torch.cuda.synchronize()
+        res.append((losses, ts.fp.flat.detach().clone(), dict(ts.stats)))
+    (la, fa, _), (lb, fb, sb) = res
+    assert sb["eager_steps"] >= 6, sb
+    assert np.allclose(la, lb, rtol=2e-4), (la, lb)
+    assert torch.allclose(fa, fb, rtol=2e-3, atol=2e-5), (fa - fb).abs().max().item()

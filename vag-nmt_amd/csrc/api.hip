@@ -536,7 +536,11 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
         VAG_TRY(vag_gemm_launch(B * Ts, 3 * H, C, 1.f, enc, C, 1, p.wp, 1, C, 0.f, k.encwp, 3 * H, nullptr, 0, s, s16 ? 1 : 0));
         VAG_TRY(grp.end(s));
     }
-    for (int64_t t = 0; hoist && t < Tt; ++t) {
+    // overlapped step driver (sched.hip): the loop's launches go to the chain stream, hooks run around every step
+    const VagLoopHooks* hk = hoist ? vag_loop_hooks() : nullptr;
+    const hipStream_t s_op = s;
+    if (hk && hk->chain) { VAG_TRY(vag_sched_order(s_op, hk->chain)); s = hk->chain; }
+    auto hoisted_step = [&](int64_t t) -> int {
         const float* hprev = t == 0 ? h0 : h2_all + (t - 1) * BH;
         float* h1 = k.h1 + t * BH;
         float* qhp = k.qhp + t * B * Q;
@@ -553,7 +557,7 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
                                              as_f(dw16.wcat16 + C * H), H, p.bcat + C, nullptr, qhp + C, Q, s, true));
             VAG_TRY(vag_attn_ctx_gru_launch(k.scores, k.encwp, B, 1, Ts, H, w.gru2.b_ih, qhp + C, Q, h1, k.alpha + t * B * Ts,
                                             h2_all + t * BH, k.g2 + t * 4 * BH, s, true));
-            continue;
+            return VAG_OK;
         }
         // Experiment kept for the record: 3 launches per step with the attention half in ONE kernel.  Measured
         // slower (27.7 vs 23.7 us per step): without a cross-workgroup exchange every workgroup of a row recomputes all its
@@ -564,7 +568,7 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
             VAG_TRY(vag_skinny_launch(B, Q, H, h1, H, p.wcat, H, p.bcat, nullptr, 0, qhp, Q, 0, s));         // :47 | gru_2 hidden side
             VAG_TRY(vag_attn_fused_fwd_launch(pe, qhp, Q, w.attn_v, mask, k.encwp, w.gru2.b_ih, qhp + C, Q, h1, B, Ts, H,
                                               k.alpha + t * B * Ts, h2_all + t * BH, k.g2 + t * 4 * BH, s));  // :41-51, :124-129
-            continue;
+            return VAG_OK;
         }
         static const bool opt_side = getenv("VAG_CGRU_NOSIDE") == nullptr;
         if (opt_side && Ts * B < (1ll << 28)) {
@@ -578,7 +582,15 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
         }
         VAG_TRY(vag_attn_ctx_gru_launch(k.scores, k.encwp, B, 1, Ts, H, w.gru2.b_ih, qhp + C, Q, h1, k.alpha + t * B * Ts,
                                         h2_all + t * BH, k.g2 + t * 4 * BH, s));                            // :44, :126-129
+        return VAG_OK;
+    };
+    for (int64_t t = 0; hoist && t < Tt; ++t) {
+        if (hk && hk->before) VAG_TRY(hk->before(t));
+        VAG_TRY(hoisted_step(t));
+        if (hk && hk->after) VAG_TRY(hk->after(t));
     }
+    if (hk && hk->chain) { VAG_TRY(vag_sched_order(s, s_op)); s = s_op; }
+    if (hoist && hk && hk->skip_bulk) return VAG_OK;          // the hooks form the contexts chunk by chunk
     if (hoist) return vag_attn_wsum_launch(1, k.alpha, enc, B, Ts, Tt, C, c_all, s);                       // all contexts :126
     for (int64_t t = 0; t < Tt; ++t) {
         if (free_run) {
@@ -674,11 +686,17 @@ int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const f
     // d alpha does not depend on the recurrence: all steps at once, before the loop.  The second is taken on the
     // projected keys, d alpha[b,s] += encwp[b,s,:] . dgi2[b,:], so no per-step product dc = dgi2 W is needed.
     // per sentence b: dah[:, b, :] (Tt,Ts) = d_c_all[:, b, :] (Tt,C) enc[b]^T (C,Ts): B small products in one launch
-    if (C % 4 == 0 && aligned16(enc) && aligned16(d_c_all) && B < 65536)
+    const VagLoopHooks* hk = vag_loop_hooks();
+    if (hk && hk->skip_bulk) {
+        // the hooks have filled z.dah chunk by chunk (vag_head_chunk_data)
+    } else if (C % 4 == 0 && aligned16(enc) && aligned16(d_c_all) && B < 65536)
         VAG_TRY(vag_skinny_batched_launch(B, Tt, Ts, C, d_c_all, B * C, C, enc, C, Ts * C, z.dah, B * Ts, Ts, s));
     else
         VAG_TRY(vag_attn_scores_ex_launch(1, enc, d_c_all, C, nullptr, nullptr, Tt * B, 1, B, Ts, C, nullptr, z.dah, s));
+    const hipStream_t s_op = s;
+    if (hk && hk->chain) { VAG_TRY(vag_sched_order(s_op, hk->chain)); s = hk->chain; }
     for (int64_t t = Tt - 1; t >= 0; --t) {
+        if (hk && hk->before) VAG_TRY(hk->before(t));
         float* dgi2 = z.dgi2 + t * B * 3 * H;
         float* dqgh = z.dqgh + t * B * Q;
         // attention backward: d alpha ; softmax backward ; dq = sum_s ds v (1 - tanh^2)
@@ -710,7 +728,9 @@ int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const f
             sd.dh_direct = nullptr; sd.dh_out = d_h0;
         }
         VAG_TRY(vag_gru_bwd_step_launch(f, 1, s, s16));
+        if (hk && hk->after) VAG_TRY(hk->after(t));
     }
+    if (hk && hk->chain) { VAG_TRY(vag_sched_order(s, s_op)); s = s_op; }
     // after the loop: everything that does not sit on the recurrence's critical path, as large products
     VAG_TRY(vag_attn_post_bwd_launch(pe, k.qhp, Q, w.attn_v, z.ds, k.alpha, d_c_all, B, Ts, Tt, C, d_pe, z.dvp, d_enc_out,
                                      accumulate_enc, s, s16));
@@ -728,37 +748,80 @@ int vag_cgru_attn_decode_seq_bwd_weights(const float* h0, const int64_t* tok, va
     VAG_CHECK_ARG(h0 && tok && h2_all && c_all && e_all && ws && scratch && dec_w_ok(w));
     VAG_CHECK_ARG(g.emb && g.gru1.w_ih && g.gru1.w_hh && g.gru1.b_ih && g.gru1.b_hh && g.attn_h && g.attn_v && g.c2h &&
                   g.gru2.w_ih && g.gru2.w_hh && g.gru2.b_ih && g.gru2.b_hh);
-    const int64_t C = 2 * H, Q = C + 3 * H, R = Tt * B;
-    CgruWs k = cgru_ws(ws, B, Ts, Tt, E, H);
+    const int64_t C = 2 * H;
     CgruBwdScratch z = cgru_bwd_scratch(scratch, B, Ts, Tt, E, H);
-    const float* dgh2 = z.dqgh + C;      // (R,3H) row stride Q
     VagGemmGroup grp3;              // the independent K = Tt*B weight gradients go out as one grouped launch,
     VAG_TRY(vag_colsum_launch(z.dvp, VAG_POST_CHUNKS(Ts) * B, C, C, g.attn_v, s));      // the bias sums as another
-    VAG_TRY(gemm_tn_acc(3 * H, H, R, dgh2, Q, k.h1, H, g.gru2.w_hh, H, s));
-    VAG_TRY(vag_colsum_launch(dgh2, R, 3 * H, Q, g.gru2.b_hh, s));
-    VAG_TRY(gemm_tn_acc(C, H, R, z.dqgh, Q, k.h1, H, g.attn_h, H, s));
-    // d(W_ih2 W_c2h) = dgi2^T c, then the chain rule through the folded product
-    VAG_TRY(vag_gemm_launch(3 * H, C, R, 1.f, z.dgi2, 1, 3 * H, c_all, C, 1, 0.f, z.dwp, C, nullptr, 0, s));
+    VAG_TRY(vag_cgru_bwd_weights_chunk(h0, tok, w, B, Ts, Tt, E, H, h2_all, c_all, e_all, d_e_all, ws, g, scratch, 0, Tt, true,
+                                       s));
+    VAG_TRY(grp3.end(s));      // z.dwp and z.de are complete from here on
+    VAG_TRY(vag_cgru_bwd_weights_scatter(tok, B, Ts, Tt, E, H, g, scratch, 0, Tt, s));
+    return vag_cgru_bwd_weights_finish(w, B, Ts, Tt, E, H, g, scratch, false, s);
+}
+}  // extern "C"
+
+// Rows of the time steps [t0, t1).  The products are queued when the caller holds a group bracket; the embedding-gradient
+// tail (d(embedded inputs) -> scatter) reads nothing the queued products write.
+int vag_cgru_bwd_weights_chunk(const float* h0, const int64_t* tok, vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt, int64_t E,
+                               int64_t H, const float* h2_all, const float* c_all, const float* e_all, const float* d_e_all,
+                               float* ws, vag_dec_g g, float* scratch, int64_t t0, int64_t t1, bool first, hipStream_t s) {
+    VAG_CHECK_ARG(0 <= t0 && t0 < t1 && t1 <= Tt);
+    const int64_t C = 2 * H, Q = C + 3 * H, r0 = t0 * B, n = (t1 - t0) * B;
+    CgruWs k = cgru_ws(ws, B, Ts, Tt, E, H);
+    CgruBwdScratch z = cgru_bwd_scratch(scratch, B, Ts, Tt, E, H);
+    const float* dqgh = z.dqgh + r0 * Q;
+    const float* dgh2 = dqgh + C;        // (n,3H) row stride Q
+    const float* dgi2 = z.dgi2 + r0 * 3 * H;
+    const float* dgi1 = z.dgi1 + r0 * 3 * H;
+    const float* dgh1 = z.dgh1 + r0 * 3 * H;
+    const float* h1 = k.h1 + r0 * H;
+    VAG_TRY(gemm_tn_acc(3 * H, H, n, dgh2, Q, h1, H, g.gru2.w_hh, H, s));
+    VAG_TRY(vag_colsum_launch(dgh2, n, 3 * H, Q, g.gru2.b_hh, s));
+    VAG_TRY(gemm_tn_acc(C, H, n, dqgh, Q, h1, H, g.attn_h, H, s));
+    // d(W_ih2 W_c2h) = dgi2^T c, then (vag_cgru_bwd_weights_finish) the chain rule through the folded product
+    VAG_TRY(vag_gemm_launch(3 * H, C, n, 1.f, dgi2, 1, 3 * H, c_all + r0 * C, C, 1, first ? 0.f : 1.f, z.dwp, C, nullptr, 0, s));
     if (h0 + B * H == h2_all) {
         // caller keeps [h0, h2_all] in one buffer: the previous states of all steps are one (R,H) operand
-        VAG_TRY(gemm_tn_acc(3 * H, H, R, z.dgh1, 3 * H, h0, H, g.gru1.w_hh, H, s));
+        VAG_TRY(gemm_tn_acc(3 * H, H, n, dgh1, 3 * H, h0 + r0 * H, H, g.gru1.w_hh, H, s));
     } else {
-        VAG_TRY(gemm_tn_acc(3 * H, H, B, z.dgh1, 3 * H, h0, H, g.gru1.w_hh, H, s));
-        VAG_TRY(gemm_tn_acc(3 * H, H, R - B, z.dgh1 + B * 3 * H, 3 * H, h2_all, H, g.gru1.w_hh, H, s));
+        if (t0 == 0) VAG_TRY(gemm_tn_acc(3 * H, H, B, dgh1, 3 * H, h0, H, g.gru1.w_hh, H, s));
+        const int64_t skip = t0 == 0 ? B : 0;
+        if (n > skip)
+            VAG_TRY(gemm_tn_acc(3 * H, H, n - skip, dgh1 + skip * 3 * H, 3 * H, h2_all + (r0 + skip - B) * H, H, g.gru1.w_hh, H,
+                                s));
     }
-    VAG_TRY(gemm_tn_acc(3 * H, E, R, z.dgi1, 3 * H, e_all, E, g.gru1.w_ih, E, s));
-    VAG_TRY(vag_colsum_launch(z.dgi2, R, 3 * H, 3 * H, g.gru2.b_ih, s));
-    VAG_TRY(vag_colsum_launch(z.dgh1, R, 3 * H, 3 * H, g.gru1.b_hh, s));
-    VAG_TRY(vag_colsum_launch(z.dgi1, R, 3 * H, 3 * H, g.gru1.b_ih, s));
-    VAG_TRY(grp3.end(s));      // z.dwp is complete from here on
-    VAG_TRY(vag_gemm_launch(3 * H, H, C, 1.f, z.dwp, C, 1, w.c2h, 1, C, 1.f, g.gru2.w_ih, H, nullptr, 0, s));
-    VAG_TRY(vag_gemm_launch(H, C, 3 * H, 1.f, w.gru2.w_ih, 1, H, z.dwp, C, 1, 1.f, g.c2h, C, nullptr, 0, s));
+    VAG_TRY(gemm_tn_acc(3 * H, E, n, dgi1, 3 * H, e_all + r0 * E, E, g.gru1.w_ih, E, s));
+    VAG_TRY(vag_colsum_launch(dgi2, n, 3 * H, 3 * H, g.gru2.b_ih, s));
+    VAG_TRY(vag_colsum_launch(dgh1, n, 3 * H, 3 * H, g.gru1.b_hh, s));
+    VAG_TRY(vag_colsum_launch(dgi1, n, 3 * H, 3 * H, g.gru1.b_ih, s));
     // d(embedded inputs) = dgi1 W_ih1 (+ the head's W3 path), scattered into the embedding gradient
-    if (d_e_all) VAG_TRY(copy_async(z.de, d_e_all, R * E * sizeof(float), s));
-    VAG_TRY(gemm_nn(R, E, 3 * H, z.dgi1, 3 * H, w.gru1.w_ih, E, d_e_all ? 1.f : 0.f, z.de, E, s));
-    VAG_TRY(vag_embed_scatter_launch(tok, B, 1, Tt, B, z.de, E, g.emb, nullptr, 0, 0.f, s));
+    float* de = z.de + r0 * E;
+    if (d_e_all) VAG_TRY(copy_async(de, d_e_all + r0 * E, n * E * sizeof(float), s));
+    VAG_TRY(gemm_nn(n, E, 3 * H, dgi1, 3 * H, w.gru1.w_ih, E, d_e_all ? 1.f : 0.f, de, E, s));
     return VAG_OK;
 }
+// After every chunk's products have been LAUNCHED (group brackets closed): the embedding scatter of [t0, t1) ...
+int vag_cgru_bwd_weights_scatter(const int64_t* tok, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, vag_dec_g g,
+                                 float* scratch, int64_t t0, int64_t t1, hipStream_t s) {
+    CgruBwdScratch z = cgru_bwd_scratch(scratch, B, Ts, Tt, E, H);
+    return vag_embed_scatter_launch(tok + t0 * B, B, 1, t1 - t0, B, z.de + t0 * B * E, E, g.emb, nullptr, 0, 0.f, s);
+}
+// ... and, once all chunks are in: the attention vector's gradient and the chain rule through the folded product.
+int vag_cgru_bwd_weights_finish(vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, vag_dec_g g,
+                                float* scratch, bool with_attn_v, hipStream_t s) {
+    const int64_t C = 2 * H;
+    CgruBwdScratch z = cgru_bwd_scratch(scratch, B, Ts, Tt, E, H);
+    if (with_attn_v) VAG_TRY(vag_colsum_launch(z.dvp, VAG_POST_CHUNKS(Ts) * B, C, C, g.attn_v, s));
+    VAG_TRY(vag_gemm_launch(3 * H, H, C, 1.f, z.dwp, C, 1, w.c2h, 1, C, 1.f, g.gru2.w_ih, H, nullptr, 0, s));
+    return vag_gemm_launch(H, C, 3 * H, 1.f, w.gru2.w_ih, 1, H, z.dwp, C, 1, 1.f, g.c2h, C, nullptr, 0, s);
+}
+float* vag_cgru_ws_alpha(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
+    return cgru_ws(ws, B, Ts, Tt, E, H).alpha;
+}
+float* vag_cgru_scratch_dah(float* scratch, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
+    return cgru_bwd_scratch(scratch, B, Ts, Tt, E, H).dah;
+}
+extern "C" {
 
 int vag_cgru_attn_decode_seq_bwd(const float* enc, const float* pe, const float* mask, const float* h0, const int64_t* tok,
                                  vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, int64_t V,
@@ -948,6 +1011,52 @@ int vag_head_ce_seq_bwd(const float* h2_all, const float* c_all, const float* e_
     VAG_TRY(head_bwd_data(w, R, E, H, V, p_out, rng, tmid, logits, ldl, d_h2_all, d_c_all, d_e_all, scratch, s));
     return head_bwd_weights(h2_all, c_all, e_all, R, E, H, V, tmid, logits, ldl, scratch, g, s, true);
 }
+
+}  // extern "C"
+
+// ---- the head by time chunks, for the overlapped step driver (kernels.h: VagHeadChunk) ----
+int vag_head_chunk_data(const VagHeadChunk& k, int64_t t0, int64_t t1, hipStream_t s) {
+    VAG_CHECK_ARG(0 <= t0 && t0 < t1 && t1 <= k.Tt);
+    const int64_t B = k.B, E = k.E, H = k.H, C = 2 * H, V = k.V, Ts = k.Ts, ldl = k.ldl, r0 = t0 * B, n = (t1 - t0) * B;
+    float* c = k.c_all + r0 * C;
+    float* tmid = k.tmid + r0 * E;
+    float* dt = k.dt + r0 * E;
+    VAG_TRY(vag_attn_wsum_launch(1, k.alpha + r0 * Ts, k.enc, B, Ts, t1 - t0, C, c, s));                    // contexts :126
+    VAG_TRY(zero_async(tmid, n * E * sizeof(float), s));
+    {
+        VagGemmGroup grp;
+        VAG_TRY(vag_gemm_launch(n, E, H, 1.f, k.h2_all + r0 * H, H, 1, k.w.w1, 1, H, 1.f, tmid, E, k.w.b1, 0, s));
+        VAG_TRY(vag_gemm_launch(n, E, C, 1.f, c, C, 1, k.w.w2, 1, C, 1.f, tmid, E, k.w.b2, 0, s));
+        VAG_TRY(vag_gemm_launch(n, E, E, 1.f, k.e_all + r0 * E, E, 1, k.w.w3, 1, E, 1.f, tmid, E, k.w.b3, 0, s));
+        VAG_TRY(grp.end(s));
+    }
+    VAG_TRY(vag_tanh_dropout_launch(tmid, n * E, r0 * E, k.rng, VAG_DROP_DEC_OUT, k.p_out, s));
+    VAG_TRY(vag_gemm_launch(n, V, E, 1.f, tmid, E, 1, k.w.out_w, 1, E, 0.f, k.logits, ldl, k.w.out_b, 0, s));
+    VAG_TRY(vag_lse_nll_launch(k.logits, ldl, n, V, k.tgt + t0, B, k.Tt, k.vw, k.lse + r0, k.nll + r0, nullptr, 0, nullptr, 0, s));
+    VAG_TRY(vag_ce_bwd_colsum_launch(k.logits, ldl, n, V, k.tgt + t0, B, k.Tt, k.vw, k.lse + r0, k.inv_cnt, k.d_loss, k.g.out_b,
+                                     s));
+    VAG_TRY(gemm_nn(n, E, V, k.logits, ldl, k.w.out_w, E, 0.f, dt, E, s));
+    VAG_TRY(vag_tanh_bwd_launch(tmid, dt, dt, n * E, k.rng, VAG_DROP_DEC_OUT, k.p_out, s, r0 * E));
+    {
+        VagGemmGroup grp;
+        VAG_TRY(gemm_nn(n, H, E, dt, E, k.w.w1, H, 0.f, k.d_h2 + r0 * H, H, s));
+        VAG_TRY(gemm_nn(n, C, E, dt, E, k.w.w2, C, 0.f, k.d_c + r0 * C, C, s));
+        VAG_TRY(gemm_nn(n, E, E, dt, E, k.w.w3, E, 0.f, k.d_e + r0 * E, E, s));
+        VAG_TRY(grp.end(s));
+    }
+    // d alpha through the head's use of the context, rows of this chunk (see vag_cgru_attn_decode_seq_bwd_loop)
+    if (C % 4 == 0 && aligned16(k.enc) && aligned16(k.d_c) && B < 65536)
+        return vag_skinny_batched_launch(B, t1 - t0, Ts, C, k.d_c + r0 * C, B * C, C, k.enc, C, Ts * C, k.dah + r0 * Ts, B * Ts,
+                                         Ts, s);
+    return vag_attn_scores_ex_launch(1, k.enc, k.d_c + r0 * C, C, nullptr, nullptr, n, 1, B, Ts, C, nullptr, k.dah + r0 * Ts, s);
+}
+// k.logits must still hold the chunk's d(logits)
+int vag_head_chunk_weights(const VagHeadChunk& k, int64_t t0, int64_t t1, hipStream_t s) {
+    const int64_t B = k.B, r0 = t0 * B, n = (t1 - t0) * B, E = k.E, H = k.H, C = 2 * H;
+    return head_bwd_weights(k.h2_all + r0 * H, k.c_all + r0 * C, k.e_all + r0 * E, n, E, H, k.V, k.tmid + r0 * E, k.logits, k.ldl,
+                            k.dt + r0 * E, k.g, s, true);
+}
+extern "C" {
 
 int vag_head_logp_seq_fwd(const float* h2, const float* c, const float* e, vag_head_w w, int64_t R, int64_t E, int64_t H,
                           int64_t V, float p_out, const uint64_t* rng, float* tmid, float* logp, int64_t ldl,

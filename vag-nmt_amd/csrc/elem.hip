@@ -128,12 +128,12 @@ int vag_gru_bwd_elem_launch(const GruBwdArgs& a, int nz, hipStream_t s) {
 // ------------------------------------------------------------------ small elementwise kernels
 __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
                                                        float* __restrict__ dx, int64_t n, const uint64_t* rng,
-                                                       int sid, float p) {
+                                                       int sid, float p, int64_t idx0) {
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float yy = y[i];
         float d = dy[i];
         if (rng && p > 0.f) {
-            const float mlt = vag_drop_mul(rng, sid, (uint64_t)i, p);
+            const float mlt = vag_drop_mul(rng, sid, (uint64_t)(idx0 + i), p);
             d *= mlt;
             yy = mlt > 0.f ? yy / mlt : 0.f;     // y holds tanh(.)*mul; undo the scale for kept elements
         }
@@ -141,9 +141,9 @@ __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__
     }
 }
 int vag_tanh_bwd_launch(const float* y, const float* dy, float* dx, int64_t n, const uint64_t* rng, int sid, float p,
-                        hipStream_t s) {
+                        hipStream_t s, int64_t idx0) {
     if (n == 0) return VAG_OK;
-    hipLaunchKernelGGL(tanh_bwd_kernel, grid1d(n), dim3(256), 0, s, y, dy, dx, n, rng, sid, p);
+    hipLaunchKernelGGL(tanh_bwd_kernel, grid1d(n), dim3(256), 0, s, y, dy, dx, n, rng, sid, p, idx0);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

@@ -625,7 +625,7 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
         if (t == 128 && (M <= 64 || N <= 64)) continue;
         const double eff = (t == 128) ? (opt_f32mfma ? 0.62 : 0.64) : 0.42;   // fraction of the f32-MFMA peak
         const int64_t base = cdiv64(M, t) * cdiv64(N, t);
-        for (int64_t sp = 1; sp <= 16; ++sp) {
+        for (int64_t sp = 1; sp <= 64; sp += (sp < 16 ? 1 : sp < 32 ? 4 : 8)) {      // few tiles, long K (a row chunk of d(tmid)): up to 64
             if (sp > 1 && (!can_split || K / sp < 128)) break;
             const int64_t kper = cdiv64(cdiv64(K, sp), BK) * BK;
             const int64_t blocks = base * sp;

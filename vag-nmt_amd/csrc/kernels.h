@@ -34,7 +34,7 @@ int vag_gru_bwd_elem_launch(const GruBwdArgs& a, int nz, hipStream_t s);
 // dx = dy * dropout(i) * (1 - t*t)   (in place allowed).  With dropout, y is the post-dropout value t*mul;
 // t is recovered from it (dropped elements have zero gradient).
 int vag_tanh_bwd_launch(const float* y, const float* dy, float* dx, int64_t n, const uint64_t* rng, int sid, float p,
-                        hipStream_t s);
+                        hipStream_t s, int64_t idx0 = 0);      // idx0: dropout index of element 0 (a row chunk of a larger array)
 // x[i] *= dropout(idx0 + i)
 int vag_dropout_apply_launch(float* x, int64_t n, int64_t idx0, const uint64_t* rng, int sid, float p, hipStream_t s);
 int vag_tanh_dropout_launch(float* x, int64_t n, int64_t idx0, const uint64_t* rng, int sid, float p, hipStream_t s);
@@ -172,3 +172,61 @@ int vag_head_ce_seq_fwd_impl(const float* h2_all, const float* c_all, const floa
                              const uint64_t* rng, int logits_ready, float* tmid, float* logits, int64_t ldl, float* lse,
                              float* nll, float* inv_cnt, int inv_cnt_ready, float* loss_mt, float* losses, float w_mt,
                              float w_vse, int has_vse, hipStream_t s);
+
+// ---------------- sched.hip: CU-partitioned streams for the overlapped step ----------------
+#include <functional>
+int vag_sched_streams(hipStream_t* chain, hipStream_t* side);
+int vag_sched_order(hipStream_t from, hipStream_t to);
+int vag_sched_mark(hipStream_t from, hipEvent_t* out);
+int vag_sched_wait(hipStream_t to, hipEvent_t e);
+bool vag_sched_tracing();
+void vag_sched_trace(hipStream_t s, const char* label, int64_t idx = -1);
+void vag_sched_trace_dump();
+// Hooks of the time loops (decoder forward, decoder backward, encoder forward/backward), set by the overlapped step driver
+// for the calling thread: the loop's launches go to `chain` (forked from the operator's stream before the first step and
+// joined to it after the last), `before(t)` / `after(t)` run on the host around each time step's launches (they record /
+// wait events and enqueue the side stream's work).  skip_bulk: the loop's operator leaves out the all-steps work that the
+// hooks do chunk by chunk instead (decoder forward: the contexts; decoder backward: d alpha through the head).
+struct VagLoopHooks {
+    hipStream_t chain = nullptr;
+    std::function<int(int64_t)> before, after;
+    bool skip_bulk = false;
+};
+void vag_set_loop_hooks(const VagLoopHooks* h);
+const VagLoopHooks* vag_loop_hooks();
+struct VagHooksScope {
+    explicit VagHooksScope(const VagLoopHooks* h) { vag_set_loop_hooks(h); }
+    ~VagHooksScope() { vag_set_loop_hooks(nullptr); }
+};
+
+// The output head for the time steps [t0, t1) of a teacher-forced sequence, complete: contexts from the saved attention
+// weights, pre-activation, logits (into the chunk buffer), log-sum-exp / NLL, d(logits), the gradients w.r.t. h2 / c / e
+// and d alpha through the head's use of the context (vag_head_chunk_data); then the chunk's share of the head's parameter
+// gradients (vag_head_chunk_weights), which nothing on the backward recurrence waits for.
+struct VagHeadChunk {
+    const float *h2_all, *e_all, *enc, *alpha;
+    float* c_all;
+    vag_head_w w;
+    vag_head_g g;
+    const int64_t* tgt;
+    const float* vw;
+    int64_t B, Ts, Tt, E, H, V, ldl;
+    float p_out;
+    const uint64_t* rng;
+    float *tmid, *logits, *lse, *nll;
+    const float *inv_cnt, *d_loss;
+    float *dt, *d_h2, *d_c, *d_e, *dah;
+};
+int vag_head_chunk_data(const VagHeadChunk& k, int64_t t0, int64_t t1, hipStream_t s);
+int vag_head_chunk_weights(const VagHeadChunk& k, int64_t t0, int64_t t1, hipStream_t s);
+float* vag_cgru_ws_alpha(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H);
+float* vag_cgru_scratch_dah(float* scratch, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H);
+// decoder parameter gradients from the rows of time steps [t0, t1) (first: this chunk initialises the folded-product
+// gradient instead of adding to it), and what remains once every chunk is in
+int vag_cgru_bwd_weights_chunk(const float* h0, const int64_t* tok, vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt, int64_t E,
+                               int64_t H, const float* h2_all, const float* c_all, const float* e_all, const float* d_e_all,
+                               float* ws, vag_dec_g g, float* scratch, int64_t t0, int64_t t1, bool first, hipStream_t s);
+int vag_cgru_bwd_weights_scatter(const int64_t* tok, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, vag_dec_g g,
+                                 float* scratch, int64_t t0, int64_t t1, hipStream_t s);
+int vag_cgru_bwd_weights_finish(vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, vag_dec_g g,
+                                float* scratch, bool with_attn_v, hipStream_t s);
