@@ -494,3 +494,26 @@ def test_overlapped_training_matches_graph_training():
     assert sb["eager_steps"] >= 6, sb
     assert np.allclose(la, lb, rtol=2e-4), (la, lb)
     assert torch.allclose(fa, fb, rtol=2e-3, atol=2e-5), (fa - fb).abs().max().item()
+
+
+def test_three_launch_decoder_step_experiment_keeps_parity(monkeypatch):
+    """VAG_CGRU_QSCORE=1 (scores as per-column-tile partial sums behind the query product): same losses and gradients
+    as the shipped 4-launch step, fp32 and fp16 storage."""
+    from vagnmt_hip.trainer import TrainStep
+    for storage in ("f32", "f16"):
+        m_of, (src, lens, tgt, im), cm, cv = _fp16_case("mid")
+        lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+        out = []
+        for on in (False, True):
+            if on:
+                monkeypatch.setenv("VAG_CGRU_QSCORE", "1")
+            else:
+                monkeypatch.delenv("VAG_CGRU_QSCORE", raising=False)
+            m = m_of()
+            ts = TrainStep(m, cm, cv, use_graph=False, storage=storage, pad_src=1)
+            m.train()
+            ts.backend.run(src, lt, tgt, im, True, 7)
+            out.append(([float(x) for x in ts.backend.outputs()], ts.fp.grad.detach().clone()))
+        (l0, g0), (l1, g1) = out
+        assert np.allclose(l0, l1, rtol=2e-6, atol=1e-7), (l0, l1)
+        assert (g0 - g1).abs().max().item() <= 2e-5 * g0.abs().max().item()

@@ -429,7 +429,7 @@ int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_wh
 }
 
 struct CgruWs {
-    float *xp1, *h1, *g1, *g2, *qhp, *scores, *alpha, *tmp, *prep, *encwp;
+    float *xp1, *h1, *g1, *g2, *qhp, *scores, *alpha, *tmp, *prep, *encwp, *spart;
     int64_t total;
 };
 static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
@@ -447,6 +447,7 @@ static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, i
     w.tmp = take(B * E);
     w.prep = take(cgru_prep(nullptr, H).total);
     w.encwp = take(B * Ts * 3 * H);         // (W_ih2 W_c2h) enc[b,s,:]: the keys as gru_2 sees them, once per batch
+    w.spart = take(B * ((C + 15) / 16) * Ts);   // attention scores of one step as per-column-tile partial sums
     w.total = o;
     return w;
 }
@@ -551,6 +552,21 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
         a.s[0].other = k.xp1 + t * B * 3 * H;
         a.s[0].hprev = hprev; a.s[0].hout = h1; a.s[0].out2 = nullptr; a.s[0].save = k.g1 + t * 4 * BH; a.s[0].t = 0;
         VAG_TRY(vag_gru_step_launch(a, 1, s, s16));                                                         // gru_1 :121
+        // Experiment kept for the record, VAG_CGRU_QSCORE=1: 3 launches per step -- cell 1 | q = attn_h h1
+        // with the scores as per-column-tile partial sums (+ W_hh2 h1 + b_hh2 in the same grid) | softmax, projected context,
+        // cell 2.  No redundant work, parity green, and still slower than the 4-launch step (24.97 vs 23.95 us per step
+        // in a graph): a removed boundary is worth 1.45 us, and the fused kernel's phases (product -> LDS reduction ->
+        // tanh over 64-byte key pieces) run one after the other in every workgroup.  Read per call (tests flip it).
+        const bool opt_qscore = getenv("VAG_CGRU_QSCORE") != nullptr;
+        if (opt_qscore && Ts <= 768 && Ts * B < (1ll << 28)) {
+            const float* wq = s16 ? as_f(dw16.wcat16) : p.wcat;
+            const float* wt = s16 ? as_f(dw16.wcat16 + C * H) : p.wcat + C * H;
+            VAG_TRY(vag_attn_qscore_side_launch(pe, w.attn_v, Ts, h1, H, B, H, wq, H, C, qhp, Q, k.spart, wt, H, 3 * H,
+                                                p.bcat + C, qhp + C, Q, s, s16));                           // :47-51
+            VAG_TRY(vag_attn_ctx_gru_launch(nullptr, k.encwp, B, 1, Ts, H, w.gru2.b_ih, qhp + C, Q, h1, k.alpha + t * B * Ts,
+                                            h2_all + t * BH, k.g2 + t * 4 * BH, s, s16, k.spart, (C + 15) / 16, mask));  // :41-44, :126-129
+            return VAG_OK;
+        }
         if (s16) {
             VAG_TRY(vag_skinny_launch(B, C, H, h1, H, as_f(dw16.wcat16), H, nullptr, nullptr, 0, qhp, Q, 0, s, true));  // :47
             VAG_TRY(vag_attn_dot_side_launch(0, pe, qhp, Q, w.attn_v, mask, nullptr, B, Ts, C, k.scores, B, 3 * H, H, h1, H,

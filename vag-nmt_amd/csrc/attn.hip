@@ -160,13 +160,27 @@ __global__ __launch_bounds__(64 * CG_WAVES) void attn_ctx_gru_kernel(const float
                                                                      const float* __restrict__ hp, int64_t ldhp,
                                                                      const float* __restrict__ hprev, int64_t N,
                                                                      float* __restrict__ alpha, float* __restrict__ hout,
-                                                                     float* __restrict__ save) {
-    extern __shared__ __attribute__((aligned(16))) float w[];   // Ts weights, then CG_WAVES x 3 x 64 float4 partials
+                                                                     float* __restrict__ save,
+                                                                     const float* __restrict__ spart, int ntile,
+                                                                     const float* __restrict__ mask) {
+    extern __shared__ __attribute__((aligned(16))) float w[];   // Ts weights, CG_WAVES x 3 x 64 float4 partials, [Ts scores]
     float4* part = reinterpret_cast<float4*>(w + ((Ts + 3) & ~3));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t n = blockIdx.y;
     const int64_t b = rps == 1 ? n : (int64_t)((int)blockIdx.y / rps);
-    const float* sc = scores + n * Ts;
+    const float* sc = scores ? scores + n * Ts : nullptr;
+    // scores handed over as per-column-tile partial sums (attn_qscore_side_kernel): wave k requests tiles k, k+8, ... of
+    // every position now, and adds them up after the value rows below have been requested too
+    float* ssum = reinterpret_cast<float*>(part + CG_WAVES * 3 * 64);     // Ts floats, only with spart
+    constexpr int SP = 8;                           // tiles per wave in flight (ntile <= 64 in one round at 8 waves)
+    float pv[SP];
+    if (spart) {
+#pragma unroll
+        for (int i = 0; i < SP; ++i) {
+            const int t = wave + i * CG_WAVES;
+            pv[i] = (lane < Ts && t < ntile) ? spart[(n * ntile + t) * Ts + lane] : 0.f;
+        }
+    }
     const int u = (blockIdx.x * 64 + lane) * 4;
     const bool uok = u < H;
     // Everything that does not depend on the softmax is requested first -- the first U value rows of this wave and, for
@@ -188,6 +202,33 @@ __global__ __launch_bounds__(64 * CG_WAVES) void attn_ctx_gru_kernel(const float
             hg[g] = *reinterpret_cast<const float4*>(hp + n * ldhp + g * H + u);
         }
         h1 = *reinterpret_cast<const float4*>(hprev + n * H + u);
+    }
+    if (spart) {
+        // general shape: positions in rounds of 64, tiles in rounds of SP * CG_WAVES; the first round is in registers
+        float* pw = reinterpret_cast<float*>(part);           // CG_WAVES x Ts partial sums (the float4 area is free until later)
+        for (int s0 = 0; s0 < Ts; s0 += 64) {
+            const int s = s0 + lane;
+            float acc = 0.f;
+            for (int t0 = 0; t0 < ntile; t0 += SP * CG_WAVES) {
+#pragma unroll
+                for (int i = 0; i < SP; ++i) {
+                    const int t = t0 + wave + i * CG_WAVES;
+                    if (s0 == 0 && t0 == 0) acc += pv[i];
+                    else if (s < Ts && t < ntile) acc += spart[(n * ntile + t) * Ts + s];
+                }
+            }
+            if (s < Ts) pw[wave * Ts + s] = acc;
+        }
+        __syncthreads();
+        for (int s = threadIdx.x; s < Ts; s += 64 * CG_WAVES) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < CG_WAVES; ++k) t += pw[k * Ts + s];
+            if (mask && mask[b * Ts + s] == 0.f) t = -INFINITY;
+            ssum[s] = t;
+        }
+        __syncthreads();
+        sc = ssum;
     }
     {
         float mx = -INFINITY;
@@ -266,18 +307,21 @@ __global__ __launch_bounds__(64 * CG_WAVES) void attn_ctx_gru_kernel(const float
 }
 int vag_attn_ctx_gru_launch(const float* scores, const float* encwp, int64_t N, int64_t rps, int64_t Ts, int64_t H,
                             const float* b_ih, const float* hp, int64_t ldhp, const float* hprev, float* alpha, float* hout,
-                            float* save, hipStream_t s, bool x16) {
-    VAG_CHECK_ARG(scores && encwp && b_ih && hp && hprev && hout && N > 0 && N < 65536 && Ts > 0 && H > 0 && H % 4 == 0);
+                            float* save, hipStream_t s, bool x16, const float* spart, int64_t ntile, const float* mask) {
+    VAG_CHECK_ARG((scores || (spart && ntile > 0 && rps == 1)) && encwp && b_ih && hp && hprev && hout && N > 0 && N < 65536 &&
+                  Ts > 0 && H > 0 && H % 4 == 0);
+    VAG_CHECK_ARG(!spart || (int64_t)CG_WAVES * Ts <= (int64_t)CG_WAVES * 3 * 64 * 4);        // partial sums fit the float4 area
     VAG_CHECK_ARG(ldhp % 4 == 0 && rps >= 1 && aligned16(encwp) && aligned16(hp) && aligned16(hprev) && aligned16(hout) &&
                   aligned16(b_ih) && (!save || aligned16(save)));
     dim3 grid((unsigned)cdiv64(H, 256), (unsigned)N);
-    const size_t lds = (size_t)((Ts + 3) & ~3) * sizeof(float) + (size_t)CG_WAVES * 3 * 64 * 16;
+    const size_t lds = (size_t)((Ts + 3) & ~3) * sizeof(float) + (size_t)CG_WAVES * 3 * 64 * 16 +
+                       (spart ? (size_t)((Ts + 3) & ~3) * sizeof(float) : 0);
     if (x16)
         hipLaunchKernelGGL(attn_ctx_gru_kernel<true>, grid, dim3(64 * CG_WAVES), lds, s, scores, encwp, (int)rps, (int)Ts,
-                           (int)H, b_ih, hp, ldhp, hprev, N, alpha, hout, save);
+                           (int)H, b_ih, hp, ldhp, hprev, N, alpha, hout, save, spart, (int)ntile, mask);
     else
         hipLaunchKernelGGL(attn_ctx_gru_kernel<false>, grid, dim3(64 * CG_WAVES), lds, s, scores, encwp, (int)rps, (int)Ts,
-                           (int)H, b_ih, hp, ldhp, hprev, N, alpha, hout, save);
+                           (int)H, b_ih, hp, ldhp, hprev, N, alpha, hout, save, spart, (int)ntile, mask);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

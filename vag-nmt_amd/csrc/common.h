@@ -103,6 +103,10 @@ int vag_attn_dot_side_launch(int mode, const float* x, const float* q, int64_t l
                              const float* addend, int64_t N, int64_t Ts, int64_t W, float* out, int64_t M, int64_t Np,
                              int64_t K, const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* pbias,
                              const float* padd, float* P, int64_t ldp, hipStream_t stream, bool s16 = false);   // s16: x and Wt fp16
+int vag_attn_qscore_side_launch(const float* x, const float* v, int64_t Ts, const float* A, int64_t lda, int64_t M, int64_t K,
+                                const float* Wq, int64_t ldwq, int64_t Nq, float* qout, int64_t ldq, float* spart,
+                                const float* Wt, int64_t ldwt, int64_t Np, const float* pbias, float* P, int64_t ldp,
+                                hipStream_t stream, bool s16 = false);
 int vag_skinny_batched_launch(int64_t nb, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t bsA,
                               const float* W, int64_t ldw, int64_t bsW, float* out, int64_t ldo, int64_t bsO,
                               hipStream_t stream);

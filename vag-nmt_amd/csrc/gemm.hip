@@ -1012,6 +1012,119 @@ int vag_attn_dot_side_launch(int mode, const float* x, const float* q, int64_t l
     return VAG_OK;
 }
 
+// Forward decoder step, launch 2 of 3: the attention query q = attn_h h1 and the attention scores in ONE grid.
+// A score is a sum over the C key columns, score[b,s] = sum_c v_c tanh(pe[b,s,c] + q[b,c]), so the workgroup that has just
+// finished a 16-row x 16-column tile of q can add up ITS 16 columns' share of the scores of its 16 rows at once -- no
+// workgroup has to wait for a whole row of q, which is what used to cost a kernel boundary between the two.  The C/16
+// partial sums per score are added by the consumer (attn_ctx_gru_kernel) while its value rows are in flight.  The side
+// product of the old scores launch (W_hh2 h1 + b_hh2, not needed before the cell) rides in the same grid as before.
+// Blocks [0, nq) are the q tiles (tile x = column tile, y = row tile), the rest are 16x16 tiles of the side product.
+// spart (N, ntile, Ts): partial score of row n, column tile, position s.  Masking is the consumer's.
+#ifndef VAG_QSCORE_XCD
+#define VAG_QSCORE_XCD 1
+#endif
+struct QScoreArgs {
+    const float* x; const float* v; float* spart;     // x (B,Ts,W) keys (fp32 or fp16), v (W)
+    int Ts, W, nq, qtiles_x;
+};
+template <int WAVES, bool S16>
+__global__ __launch_bounds__(64 * WAVES) void attn_qscore_side_kernel(QScoreArgs d, SkinnyArgs q, SkinnyArgs a, int tiles_x) {
+    __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4];
+    __shared__ float qs[16][17];
+    const int id = blockIdx.x;
+    if (id >= d.nq) {
+        const int t = id - d.nq;
+        skinny_plain_body<WAVES, 4, S16>(a, red, t % tiles_x, t / tiles_x);
+        return;
+    }
+    // Neighbouring column tiles read the two halves of the same 128-byte key lines: keep them on one XCD (workgroup i runs
+    // on XCD i % 8) so that the second half is an L2 hit instead of a second fetch into another XCD's L2.
+    int f = id;
+    if ((d.nq & 7) == 0 && VAG_QSCORE_XCD) f = (id & 7) * (d.nq >> 3) + (id >> 3);
+    const int bx = f % d.qtiles_x, by = f / d.qtiles_x;
+    const int lane = threadIdx.x & 63;
+    const int r = skinny_ldrow(lane), g = skinny_ldseg(lane);
+    const int m0 = by * 16, nb = bx * 16;
+    // this thread's (row, position) pairs and 4 of the tile's 16 columns: requested before the product, used after it
+    constexpr int PAIRS = WAVES * 16;              // pairs per pass of the block
+    constexpr int PRE = 6;                          // passes kept in registers (Ts <= PRE * PAIRS / 16 = 48 at 8 waves)
+    const int c4 = threadIdx.x & 3, pr = threadIdx.x >> 2;
+    const int col = nb + 4 * c4;
+    const bool cok = col < d.W;
+    const int npair = 16 * d.Ts;
+    float4 xv[PRE];
+#pragma unroll
+    for (int i = 0; i < PRE; ++i) {
+        const int p = pr + i * PAIRS;
+        xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < npair && cok) {
+            const int rr = p / d.Ts, s = p - rr * d.Ts;
+            const int64_t row = min(m0 + rr, q.M - 1);
+            xv[i] = ld4_any<S16>(d.x, (row * d.Ts + s) * (int64_t)d.W + col);
+        }
+    }
+    const float4 vv = cok ? *reinterpret_cast<const float4*>(d.v + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* ap[1];
+    const float* wp[1];
+    ap[0] = q.A + (int64_t)min(m0 + r, q.M - 1) * q.lda + skinny_koff<S16>(g);
+    wp[0] = skinny_wptr<S16>(q.W, min(nb + r, q.N - 1), q.ldw, skinny_koff<S16>(g));
+    skinny_mma_any<WAVES, 1, 1, 4, S16>(ap, wp, q.K, red);
+    if (threadIdx.x < 256) {
+        const int erow = (threadIdx.x >> 4) & 15, ecol = threadIdx.x & 15;
+        const float val = skinny_sum1<WAVES, 1>(red, 0, erow, ecol);
+        qs[erow][ecol] = val;
+        if (m0 + erow < q.M && nb + ecol < q.N) q.out[(int64_t)(m0 + erow) * q.ldo + nb + ecol] = val;      // saved for the backward
+    }
+    __syncthreads();
+    for (int p0 = 0; p0 < npair; p0 += PAIRS * PRE) {
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) {
+            const int p = p0 + pr + i * PAIRS;
+            const int rr = min(p, npair - 1) / d.Ts, s = min(p, npair - 1) - rr * d.Ts;
+            float4 x = xv[i];
+            if (p0 > 0) {        // positions beyond the preloaded passes (long sources)
+                x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p < npair && cok) x = ld4_any<S16>(d.x, ((int64_t)min(m0 + rr, q.M - 1) * d.Ts + s) * (int64_t)d.W + col);
+            }
+            const float* qr = &qs[rr][4 * c4];
+            float acc = vv.x * vag_tanh(x.x + qr[0]) + vv.y * vag_tanh(x.y + qr[1]) + vv.z * vag_tanh(x.z + qr[2]) +
+                        vv.w * vag_tanh(x.w + qr[3]);
+            if (!cok) acc = 0.f;
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            if (c4 == 0 && p < npair && m0 + rr < q.M)
+                d.spart[((int64_t)(m0 + rr) * d.qtiles_x + bx) * d.Ts + s] = acc;
+        }
+    }
+}
+// q (M, Nq) = A (M,K) Wq^T -> qout (row stride ldq), spart (M, ceil(Nq/16), Ts) partial scores against the keys x (M,Ts,Nq);
+// side product P (M,Np) = A Wt^T + pbias (row stride ldp).  One source row per query row.
+int vag_attn_qscore_side_launch(const float* x, const float* v, int64_t Ts, const float* A, int64_t lda, int64_t M, int64_t K,
+                                const float* Wq, int64_t ldwq, int64_t Nq, float* qout, int64_t ldq, float* spart,
+                                const float* Wt, int64_t ldwt, int64_t Np, const float* pbias, float* P, int64_t ldp,
+                                hipStream_t stream, bool s16) {
+    VAG_CHECK_ARG(x && v && A && Wq && qout && spart && Wt && P && M > 0 && Ts > 0 && Nq > 0 && Np > 0 && Nq % 4 == 0);
+    VAG_CHECK_ARG(aligned16(x) && aligned16(v) && skinny_ok(A, lda, Wq, ldwq, K) && skinny_ok(A, lda, Wt, ldwt, K));
+    VAG_CHECK_ARG(!s16 || K % 8 == 0);
+    QScoreArgs d;
+    d.x = x; d.v = v; d.spart = spart; d.Ts = (int)Ts; d.W = (int)Nq;
+    d.qtiles_x = (int)cdiv64(Nq, 16);
+    const int64_t qtiles_y = cdiv64(M, 16);
+    VAG_CHECK_ARG(d.qtiles_x * qtiles_y < (1ll << 30));
+    d.nq = (int)(d.qtiles_x * qtiles_y);
+    SkinnyArgs q;
+    q.A = A; q.W = Wq; q.lda = lda; q.ldw = ldwq; q.M = (int)M; q.N = (int)Nq; q.K = (int)K;
+    q.bias = nullptr; q.addend = nullptr; q.ldadd = 0; q.out = qout; q.ldo = ldq; q.act = VAG_ACT_NONE;
+    SkinnyArgs a = q;
+    a.W = Wt; a.ldw = ldwt; a.N = (int)Np; a.bias = pbias; a.out = P; a.ldo = ldp;
+    const int tiles_x = (int)cdiv64(Np, 16), tiles_y = (int)cdiv64(M, 16);
+    const dim3 grid((unsigned)(d.nq + tiles_x * tiles_y));
+    if (s16) hipLaunchKernelGGL((attn_qscore_side_kernel<8, true>), grid, dim3(512), 0, stream, d, q, a, tiles_x);
+    else hipLaunchKernelGGL((attn_qscore_side_kernel<8, false>), grid, dim3(512), 0, stream, d, q, a, tiles_x);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
 // out[m,n] = sum_k A[m,k] B[k,n] with B stored (K,N) row-major (data gradients dX = dY W of the once-per-batch
 // M <= 128-row operators: the LDS-tiled kernels need ~14 us for these however small they are).  A is loaded as in
 // skinny_mma; B is read directly in MFMA layout, one dword per lane and k (16 consecutive n = 64 contiguous bytes).

@@ -79,7 +79,8 @@ int vag_attn_scores_ex_launch(int mode, const float* pe, const float* q, int64_t
                               float* scores, hipStream_t s);
 int vag_attn_ctx_gru_launch(const float* scores, const float* encwp, int64_t N, int64_t rps, int64_t Ts, int64_t H,
                             const float* b_ih, const float* hp, int64_t ldhp, const float* hprev, float* alpha, float* hout,
-                            float* save, hipStream_t s, bool x16 = false);      // x16: encwp is fp16
+                            float* save, hipStream_t s, bool x16 = false, const float* spart = nullptr, int64_t ntile = 0,
+                            const float* mask = nullptr);      // spart: scores as (N, ntile, Ts) partial sums, masked here      // x16: encwp is fp16
 // scores + softmax + projected context + gru_2 cell in one launch (training sizes: see vag_attn_fused_fwd_ok)
 bool vag_attn_fused_fwd_ok(int64_t Ts, int64_t H, int64_t ldq, int64_t ldhp);
 int vag_attn_fused_fwd_launch(const float* pe, const float* q, int64_t ldq, const float* v, const float* mask,
