@@ -1,4 +1,6 @@
-"""Experiment: the cfg2 training step's dense products (shapes from the round-2 step timeline, grouped ones listed singly)
+"""[historic: the experiment builds this script switched between (VAG_GEMM_VARIANT) were removed after the
+measurement in profiles/r02_exp_gemm_variants.txt; it now times the shipped kernel only]
+Experiment: the cfg2 training step's dense products (shapes from the round-2 step timeline, grouped ones listed singly)
 timed one by one through vag_gemm_f32 for each kernel variant (VAG_GEMM_VARIANT) -- interleaved in ONE process."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
