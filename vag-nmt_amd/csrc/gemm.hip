@@ -1177,51 +1177,65 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_bt_kernel(SkinnyArgs a) {
 // Fused GRU cell: 16 rows x 16 hidden units x 3 gates per workgroup.  The 256 (row, unit) outputs are finished by the
 // first 256 threads, one each; their epilogue operands (the other projection, h_prev, bias) are requested BEFORE the
 // product so that they arrive under it instead of costing a second memory round trip.
-template <int WAVES, bool WH = false>
+// MT 16-row tiles per workgroup (2 for wide batches: the three gate rows of W are then re-read by half as many workgroups).
+template <int WAVES, bool WH = false, int MT = 1>
 __global__ __launch_bounds__(WAVES * 64) void gru_step_kernel(GruStepArgs a) {
     constexpr int NT = 3;
-    __shared__ __attribute__((aligned(16))) float red[WAVES * NT * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float red[WAVES * MT * NT * 64 * 4];
     const GruSide& sd = a.s[blockIdx.z];
     const int lane = threadIdx.x & 63;
     const int r = skinny_ldrow(lane), g = skinny_ldseg(lane);
-    const int m0 = blockIdx.y * 16, u0 = blockIdx.x * 16;
+    const int m0 = blockIdx.y * 16 * MT, u0 = blockIdx.x * 16;
     const int H = a.H;
-    // epilogue operands of thread t < 256: output (row m0 + t/16, unit u0 + t%16)
-    const int erow = (threadIdx.x >> 4) & 15, ecol = threadIdx.x & 15;
-    const int em = m0 + erow, ej = u0 + ecol;
-    const bool eok = threadIdx.x < 256 && em < a.M && ej < H;
-    float o_r = 0.f, o_z = 0.f, o_n = 0.f, hp = 0.f, b_r = 0.f, b_z = 0.f, b_n = 0.f;
-    bool active = true;
-    if (eok) {
-        const float* op = sd.other + (int64_t)em * a.ldother + ej;
-        o_r = op[0]; o_z = op[H]; o_n = op[2 * H];
-        hp = sd.hprev[(int64_t)em * a.ldh + ej];
-        if (sd.bias) { b_r = sd.bias[ej]; b_z = sd.bias[H + ej]; b_n = sd.bias[2 * H + ej]; }
-        if (a.lengths) active = sd.t < a.lengths[em];
+    // epilogue operands: output q of thread t is (row m0 + 16*(t'/256) + (t'%256)/16, unit u0 + t'%16), t' = t + q*threads
+    constexpr int OUTS = (MT * 256 + WAVES * 64 - 1) / (WAVES * 64);
+    float o_r[OUTS], o_z[OUTS], o_n[OUTS], hp[OUTS], b_r[OUTS], b_z[OUTS], b_n[OUTS];
+    bool active[OUTS], eok[OUTS];
+#pragma unroll
+    for (int q = 0; q < OUTS; ++q) {
+        const int t = threadIdx.x + q * WAVES * 64;
+        const int em = m0 + 16 * (t >> 8) + ((t >> 4) & 15), ej = u0 + (t & 15);
+        eok[q] = t < MT * 256 && em < a.M && ej < H;
+        o_r[q] = o_z[q] = o_n[q] = hp[q] = b_r[q] = b_z[q] = b_n[q] = 0.f;
+        active[q] = true;
+        if (eok[q]) {
+            const float* op = sd.other + (int64_t)em * a.ldother + ej;
+            o_r[q] = op[0]; o_z[q] = op[H]; o_n[q] = op[2 * H];
+            hp[q] = sd.hprev[(int64_t)em * a.ldh + ej];
+            if (sd.bias) { b_r[q] = sd.bias[ej]; b_z[q] = sd.bias[H + ej]; b_n[q] = sd.bias[2 * H + ej]; }
+            if (a.lengths) active[q] = sd.t < a.lengths[em];
+        }
     }
-    const float* ap[1];
+    const float* ap[MT];
     const float* wp[NT];
-    ap[0] = sd.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + skinny_koff<WH>(g);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) ap[i] = sd.A + (int64_t)min(m0 + 16 * i + r, a.M - 1) * a.lda + skinny_koff<WH>(g);
 #pragma unroll
     for (int j = 0; j < NT; ++j) wp[j] = skinny_wptr<WH>(sd.W, min(j * H + u0 + r, 3 * H - 1), a.ldw, skinny_koff<WH>(g));
-    skinny_mma_any<WAVES, 1, NT, 4, WH>(ap, wp, a.K, red);
-    if (!eok) return;
-    const float c_r = skinny_sum1<WAVES, NT>(red, 0, erow, ecol) + b_r;
-    const float c_z = skinny_sum1<WAVES, NT>(red, 1, erow, ecol) + b_z;
-    const float c_n = skinny_sum1<WAVES, NT>(red, 2, erow, ecol) + b_n;
-    const float gi_n = a.comp_hidden ? o_n : c_n;
-    const float gh_n = a.comp_hidden ? c_n : o_n;
-    const float rr = vag_sigmoid(c_r + o_r);
-    const float zz = vag_sigmoid(c_z + o_z);
-    const float nn = vag_tanh(gi_n + rr * gh_n);
-    const float hn = (1.f - zz) * nn + zz * hp;
-    const int64_t o = (int64_t)em * H + ej;
-    if (sd.save) {
-        const int64_t MH = (int64_t)a.M * H;
-        sd.save[o] = rr; sd.save[MH + o] = zz; sd.save[2 * MH + o] = nn; sd.save[3 * MH + o] = gh_n;
+    skinny_mma_any<WAVES, MT, NT, 4, WH>(ap, wp, a.K, red);
+#pragma unroll
+    for (int q = 0; q < OUTS; ++q) {
+        if (!eok[q]) continue;
+        const int t = threadIdx.x + q * WAVES * 64;
+        const int mt = t >> 8, erow = (t >> 4) & 15, ecol = t & 15;
+        const int em = m0 + 16 * mt + erow, ej = u0 + ecol;
+        const float c_r = skinny_sum1<WAVES, MT * NT>(red, mt * NT + 0, erow, ecol) + b_r[q];
+        const float c_z = skinny_sum1<WAVES, MT * NT>(red, mt * NT + 1, erow, ecol) + b_z[q];
+        const float c_n = skinny_sum1<WAVES, MT * NT>(red, mt * NT + 2, erow, ecol) + b_n[q];
+        const float gi_n = a.comp_hidden ? o_n[q] : c_n;
+        const float gh_n = a.comp_hidden ? c_n : o_n[q];
+        const float rr = vag_sigmoid(c_r + o_r[q]);
+        const float zz = vag_sigmoid(c_z + o_z[q]);
+        const float nn = vag_tanh(gi_n + rr * gh_n);
+        const float hn = (1.f - zz) * nn + zz * hp[q];
+        const int64_t o = (int64_t)em * H + ej;
+        if (sd.save) {
+            const int64_t MH = (int64_t)a.M * H;
+            sd.save[o] = rr; sd.save[MH + o] = zz; sd.save[2 * MH + o] = nn; sd.save[3 * MH + o] = gh_n;
+        }
+        sd.hout[o] = active[q] ? hn : hp[q];
+        if (sd.out2) sd.out2[(int64_t)em * a.ld2 + ej] = active[q] ? hn : 0.f;
     }
-    sd.hout[o] = active ? hn : hp;
-    if (sd.out2) sd.out2[(int64_t)em * a.ld2 + ej] = active ? hn : 0.f;
 }
 
 // The same cell with 8 or 4 hidden units per workgroup (2x / 4x the workgroups).  UNITS = 8: tile 0 holds [r | z] of
@@ -1287,59 +1301,79 @@ __global__ __launch_bounds__(WAVES * 64) void gru_step_small_kernel(GruStepArgs 
 // Same structure: 256 outputs finished by 256 threads, epilogue operands prefetched under the product.
 // (A half-tile variant -- 8 output columns per workgroup on twice the workgroups, as gru_step_small_kernel does for the
 // forward cell -- measured no gain here: the MFMA count per workgroup stays that of a full tile.)
-template <int WAVES, int U, bool WH = false>
+// MT x NT 16x16 tiles per workgroup (1 x 1 for M <= 64 rows: one workgroup per CU matters more there; 2 x 2 for the wide
+// configuration, where each launch is bound by operand re-reads out of L2: 300 MB -> 150 MB at M = 256, H = 1024).
+template <int WAVES, int U, bool WH = false, int MT = 1, int NT = 1>
 __global__ __launch_bounds__(WAVES * 64) void gru_bwd_step_kernel(GruBwdStepArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4];
+    constexpr int TILES = MT * NT;
+    __shared__ __attribute__((aligned(16))) float red[WAVES * TILES * 64 * 4];
     const GruBwdStepSide& sd = a.s[blockIdx.z];
     const int lane = threadIdx.x & 63;
     const int r = skinny_ldrow(lane), g = skinny_ldseg(lane);
-    const int m0 = blockIdx.y * 16, nb = blockIdx.x * 16;
+    const int m0 = blockIdx.y * 16 * MT, nb = blockIdx.x * 16 * NT;
     const int H = a.H;
-    const int erow = (threadIdx.x >> 4) & 15, ecol = threadIdx.x & 15;
-    const int em = m0 + erow, ej = nb + ecol;
-    const bool eok = threadIdx.x < 256 && em < a.M && ej < H;
-    const int64_t o = (int64_t)em * H + ej;
     const int64_t MH = (int64_t)a.M * H;
-    float add = 0.f, e = 0.f, rr = 0.f, zz = 0.f, nn = 0.f, hn = 0.f, hp = 0.f;
-    bool active = true;
-    if (eok) {
-        if (sd.addend) add = sd.addend[o];
-        if (a.has_cell) {
-            if (a.lengths) active = sd.t < a.lengths[em];
-            if (sd.dh_add) {
-                e = sd.dh_add[(int64_t)em * a.ld_add + ej];
-                if (a.rng && a.p > 0.f) e *= vag_drop_mul(a.rng, a.sid, (uint64_t)em * a.ld_add + sd.drop_idx0 + ej, a.p);
+    constexpr int OUTS = (TILES * 256 + WAVES * 64 - 1) / (WAVES * 64);      // outputs per thread
+    float add[OUTS], e[OUTS], rr[OUTS], zz[OUTS], nn[OUTS], hn[OUTS], hp[OUTS];
+    bool active[OUTS], eok[OUTS];
+    int64_t oo[OUTS];
+#pragma unroll
+    for (int q = 0; q < OUTS; ++q) {
+        const int t = threadIdx.x + q * WAVES * 64;
+        const int tile = t >> 8, erow = (t >> 4) & 15, ecol = t & 15;
+        const int em = m0 + 16 * (tile / NT) + erow, ej = nb + 16 * (tile % NT) + ecol;
+        eok[q] = tile < TILES && em < a.M && ej < H;
+        oo[q] = (int64_t)em * H + ej;
+        add[q] = e[q] = rr[q] = zz[q] = nn[q] = hn[q] = hp[q] = 0.f;
+        active[q] = true;
+        if (eok[q]) {
+            if (sd.addend) add[q] = sd.addend[oo[q]];
+            if (a.has_cell) {
+                if (a.lengths) active[q] = sd.t < a.lengths[em];
+                if (sd.dh_add) {
+                    e[q] = sd.dh_add[(int64_t)em * a.ld_add + ej];
+                    if (a.rng && a.p > 0.f) e[q] *= vag_drop_mul(a.rng, a.sid, (uint64_t)em * a.ld_add + sd.drop_idx0 + ej, a.p);
+                }
+                rr[q] = sd.save[oo[q]]; zz[q] = sd.save[MH + oo[q]]; nn[q] = sd.save[2 * MH + oo[q]]; hn[q] = sd.save[3 * MH + oo[q]];
+                hp[q] = sd.hprev[(int64_t)em * a.ldh + ej];
             }
-            rr = sd.save[o]; zz = sd.save[MH + o]; nn = sd.save[2 * MH + o]; hn = sd.save[3 * MH + o];
-            hp = sd.hprev[(int64_t)em * a.ldh + ej];
         }
     }
-    const float* ap[1];
-    const float* wp[1];
-    ap[0] = sd.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + skinny_koff<WH>(g);
-    wp[0] = skinny_wptr<WH>(sd.WT, min(nb + r, H - 1), a.ldw, skinny_koff<WH>(g));
-    skinny_mma_any<WAVES, 1, 1, U, WH>(ap, wp, a.K, red);
-    if (!eok) return;
-    float dh = skinny_sum1<WAVES, 1>(red, 0, erow, ecol) + add;
-    if (!a.has_cell) {
-        sd.dh_out[o] = dh;
-        return;
+    const float* ap[MT];
+    const float* wp[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) ap[i] = sd.A + (int64_t)min(m0 + 16 * i + r, a.M - 1) * a.lda + skinny_koff<WH>(g);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wp[j] = skinny_wptr<WH>(sd.WT, min(nb + 16 * j + r, H - 1), a.ldw, skinny_koff<WH>(g));
+    skinny_mma_any<WAVES, MT, NT, U, WH>(ap, wp, a.K, red);
+#pragma unroll
+    for (int q = 0; q < OUTS; ++q) {
+        if (!eok[q]) continue;
+        const int t = threadIdx.x + q * WAVES * 64;
+        const int tile = t >> 8, erow = (t >> 4) & 15, ecol = t & 15;
+        const int em = m0 + 16 * (tile / NT) + erow, ej = nb + 16 * (tile % NT) + ecol;
+        const int64_t o = oo[q];
+        float dh = skinny_sum1<WAVES, TILES>(red, tile, erow, ecol) + add[q];
+        if (!a.has_cell) {
+            sd.dh_out[o] = dh;
+            continue;
+        }
+        float* gi = sd.dgi + (int64_t)em * a.ldgi + ej;
+        float* gh = sd.dgh + (int64_t)em * a.ldgh + ej;
+        if (!active[q]) {
+            gi[0] = 0.f; gi[H] = 0.f; gi[2 * H] = 0.f;
+            gh[0] = 0.f; gh[H] = 0.f; gh[2 * H] = 0.f;
+            sd.dh_direct[o] = dh;
+            continue;
+        }
+        dh += e[q];
+        const float dn_pre = dh * (1.f - zz[q]) * (1.f - nn[q] * nn[q]);
+        const float dz_pre = dh * (hp[q] - nn[q]) * zz[q] * (1.f - zz[q]);
+        const float dr_pre = dn_pre * hn[q] * rr[q] * (1.f - rr[q]);
+        gi[0] = dr_pre; gi[H] = dz_pre; gi[2 * H] = dn_pre;
+        gh[0] = dr_pre; gh[H] = dz_pre; gh[2 * H] = dn_pre * rr[q];
+        sd.dh_direct[o] = dh * zz[q];
     }
-    float* gi = sd.dgi + (int64_t)em * a.ldgi + ej;
-    float* gh = sd.dgh + (int64_t)em * a.ldgh + ej;
-    if (!active) {
-        gi[0] = 0.f; gi[H] = 0.f; gi[2 * H] = 0.f;
-        gh[0] = 0.f; gh[H] = 0.f; gh[2 * H] = 0.f;
-        sd.dh_direct[o] = dh;
-        return;
-    }
-    dh += e;
-    const float dn_pre = dh * (1.f - zz) * (1.f - nn * nn);
-    const float dz_pre = dh * (hp - nn) * zz * (1.f - zz);
-    const float dr_pre = dn_pre * hn * rr * (1.f - rr);
-    gi[0] = dr_pre; gi[H] = dz_pre; gi[2 * H] = dn_pre;
-    gh[0] = dr_pre; gh[H] = dz_pre; gh[2 * H] = dn_pre * rr;
-    sd.dh_direct[o] = dh * zz;
 }
 
 static bool skinny_ok(const float* A, int64_t lda, const float* W, int64_t ldw, int64_t K) {
@@ -1456,6 +1490,15 @@ int vag_gru_step_launch(const GruStepArgs& a, int nz, hipStream_t stream, bool w
         VAG_LAUNCH_CHECK();
         return VAG_OK;
     }
+    // wide batches: two row tiles per workgroup (half the W re-reads) as long as >= 256 workgroups remain
+    static const int opt_wide = getenv("VAG_GRU_FWD_WIDE") ? atoi(getenv("VAG_GRU_FWD_WIDE")) : 1;
+    if (opt_wide && a.M >= 128 && a.K > 256 && (int64_t)grid.x * cdiv64(a.M, 32) * nz >= 256) {
+        const dim3 gw(grid.x, (unsigned)cdiv64(a.M, 32), grid.z);
+        if (w16) hipLaunchKernelGGL((gru_step_kernel<8, true, 2>), gw, dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((gru_step_kernel<8, false, 2>), gw, dim3(512), 0, stream, a);
+        VAG_LAUNCH_CHECK();
+        return VAG_OK;
+    }
     if (w16) {
         if (a.K <= 256) hipLaunchKernelGGL((gru_step_kernel<4, true>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((gru_step_kernel<8, true>), grid, dim3(512), 0, stream, a);
@@ -1475,6 +1518,15 @@ int vag_gru_bwd_step_launch(const GruBwdStepArgs& a, int nz, hipStream_t stream,
         else VAG_CHECK_ARG(a.s[z].dh_out != nullptr);
     }
     VAG_CHECK_ARG(!w16 || (a.K % 8 == 0 && a.ldw % 8 == 0));
+    // wide shapes (M >= 128 rows and still >= 256 workgroups): 2 x 2 tiles per workgroup halve the operand re-reads
+    static const int opt_wide = getenv("VAG_GRU_BWD_WIDE") ? atoi(getenv("VAG_GRU_BWD_WIDE")) : 1;
+    if (opt_wide && a.M >= 128 && a.K > 1024 && cdiv64(a.H, 32) * cdiv64(a.M, 32) * nz >= 256) {
+        dim3 gw((unsigned)cdiv64(a.H, 32), (unsigned)cdiv64(a.M, 32), (unsigned)nz);
+        if (w16) hipLaunchKernelGGL((gru_bwd_step_kernel<16, 4, true, 2, 2>), gw, dim3(1024), 0, stream, a);
+        else hipLaunchKernelGGL((gru_bwd_step_kernel<16, 2, false, 2, 2>), gw, dim3(1024), 0, stream, a);
+        VAG_LAUNCH_CHECK();
+        return VAG_OK;
+    }
     dim3 grid((unsigned)cdiv64(a.H, 16), (unsigned)cdiv64(a.M, 16), (unsigned)nz);
     // waves by K; chunks in flight so that a wave's K share (K / waves, in 16s) is one round of requests when it fits
 #define VAG_BWD_GO(WH)                                                                                                \
