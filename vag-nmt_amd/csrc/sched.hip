@@ -116,6 +116,8 @@ bool vag_sched_tracing() {
 }
 void vag_sched_trace(hipStream_t s, const char* label, int64_t idx) {
     if (!vag_sched_tracing()) return;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return;      // timing events cannot be captured
     hipEvent_t e;
     if (!g_trace_pool.empty()) { e = g_trace_pool.back(); g_trace_pool.pop_back(); }
     else if (hipEventCreate(&e) != hipSuccess) return;

@@ -163,7 +163,12 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
         if (const char* e = getenv("VAG_OVERLAP_STEPS")) cs = atoll(e);
         if (chunk > 0) { defer = false; if (cs > chunk / c.B) cs = chunk / c.B; }
         if (cs < 1) cs = 1;
-        for (int64_t t = 0; t < c.Tt; t += cs) bound.push_back(t);
+        // the last chunk's head is exposed (the backward recurrence starts with its gradients): keep it short
+        int64_t tail = 0;       // measured: a short last chunk costs more (small products, one more hand-off) than it exposes less
+        if (const char* e = getenv("VAG_OVERLAP_TAIL")) tail = atoll(e);
+        if (tail < 0 || tail >= c.Tt || tail > cs) tail = 0;
+        for (int64_t t = 0; t < c.Tt - tail; t += cs) bound.push_back(t);
+        if (tail > 0) bound.push_back(c.Tt - tail);
         bound.push_back(c.Tt);
         ev_data.resize(bound.size() - 1);
         chunk = 0;                 // the operators' own chunking is not used on this path
@@ -191,7 +196,8 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     auto chunk_of_top = [&](int64_t t) { for (int i = 0; i < nch; ++i) if (bound[i + 1] - 1 == t) return i; return -1; };
     auto chunk_of_bottom = [&](int64_t t) { for (int i = 0; i < nch; ++i) if (bound[i] == t) return i; return -1; };
 
-    if (ov) vag_sched_trace(s, "step start");
+    const bool tr = vag_sched_tracing();       // eager launches only (timing events cannot be captured)
+    if (tr) vag_sched_trace(s, "step start");
     if (phases & 1) {
         {
             int64_t nb = cdiv64((Tt + 1) * B, 256);
@@ -238,6 +244,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
                                                  k.e_all, k.ws_dec, 0, &w.head, c.p_out, crng, k.tmid, k.logits, c.ldl,
                                                  stream));                                              // V11.py:138-146
         } else {
+            if (tr) vag_sched_trace(s, "decoder fwd op start");
             // the key projection joins the decoder's per-batch products (projected keys, input projection of every step) in
             // one grouped launch: the bracket is flushed by the decoder operator's own bracket before its time loop starts.
             // (Only with the driver's derived weights: otherwise the operator first builds W_ih2 W_c2h, which the queue
@@ -249,6 +256,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
                                                  c.ldl, stream));                                       // V11.py:138-160
             VAG_TRY(outer.end(s));
         }
+        if (tr && !ov) vag_sched_trace(s, "main: fwd joined");
         if (!ov)
         VAG_TRY(vag_head_ce_seq_fwd_impl(h2_all, k.c_all, k.e_all, w.head, tgt, vocab_weight, B, Tt, Et, H, V, c.p_out, crng,
                                          c.free_run ? 1 : 0, k.tmid, k.logits, c.ldl, k.lse, k.nll, k.inv_cnt, 1, nullptr,
@@ -298,6 +306,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
         VAG_TRY(vag_head_ce_seq_bwd(h2_all, k.c_all, k.e_all, w.head, tgt, vocab_weight, B, Tt, Et, H, V, c.p_out, crng, k.tmid,
                                     k.logits, c.ldl, k.lse, k.inv_cnt, k.consts + 0, k.d_h2, k.d_c, k.d_e, g.head, k.scr_head,
                                     stream));
+        if (tr && !ov) vag_sched_trace(s, "main: last head chunk arrived, bwd starts");
         if (!ov) {
             // after the backward recurrence: the products that add into d_enc (projected keys, attention keys) and the weight
             // gradients of the decoder and of attn_e are queued by layout and go out as two grouped launches
@@ -305,10 +314,12 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
             VAG_TRY(vag_cgru_attn_decode_seq_bwd_loop(k.enc, k.pe, k.mask, h0, k.tok, w.dec, B, Ts, Tt, Et, H, V, h2_all, k.c_all,
                                                       k.e_all, k.d_h2, k.d_c, k.d_e, k.ws_dec, k.d_enc, 0, k.d_pe, k.d_h0,
                                                       k.scr_dec, stream));
+            if (tr) vag_sched_trace(s, "main: bwd loop op done (its post-loop products still queued)");
             VAG_TRY(vag_attn_keys_proj_bwd(k.enc, w.attn_e, k.d_pe, B * Ts, C, k.d_enc, 1, g.attn_e, stream));
             VAG_TRY(vag_cgru_attn_decode_seq_bwd_weights(h0, k.tok, w.dec, B, Ts, Tt, Et, H, h2_all, k.c_all, k.e_all, k.d_e,
                                                          k.ws_dec, g.dec, k.scr_dec, stream));
             VAG_TRY(outer.end(s));
+            if (tr) vag_sched_trace(s, "main: decoder weight gradients done");
         }
         if (mm) {
             if (has_vse) {
@@ -334,6 +345,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
         VAG_TRY(vag_bigru_seq_bwd(src, lengths, w.enc_fw, w.enc_bw, c.p_emb, c.p_ctx, crng, B, Ts, c.Es, H, k.d_enc, k.ws_enc,
                                   g.enc_emb, g.enc_fw, g.enc_bw, stream));
     }
+    if (tr && !ov) { vag_sched_trace(s, "step end"); vag_sched_trace_dump(); }
     if (ov) {
         vag_sched_trace(s, "main: all phases enqueued");
         vag_sched_trace(sb, "side: done");
