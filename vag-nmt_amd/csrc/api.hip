@@ -61,6 +61,26 @@ struct HeadFuse { const vag_head_g* g; const float* d_loss; float* dt; bool done
 static thread_local HeadFuse g_head_fuse = {nullptr, nullptr, nullptr, false};
 void vag_set_head_fuse(const vag_head_g* g, const float* d_loss, float* dt) { g_head_fuse = HeadFuse{g, d_loss, dt, false}; }
 
+// The two vocabulary-sized gradient products of the head, d(tmid) = d(logits) out.weight and g(out.weight) += d(logits)^T
+// tmid.  2-byte storage mode: plain bf16 operands, one MFMA product instead of three (fp32 accumulation) -- gradients of
+// a softmax over V classes are sums of thousands of small terms whose 2^-9 rounding errors average out; the forward
+// logits keep the two-plane product.  VAG_HEAD_BF16_GRADS=0 keeps two planes here too.
+static bool head_grads_one_plane() {
+    static const bool on = !(getenv("VAG_HEAD_BF16_GRADS") && atoi(getenv("VAG_HEAD_BF16_GRADS")) == 0);
+    return on && g_store16;
+}
+static int head_dt_gemm(int64_t R, int64_t E, int64_t V, const float* dlogits, int64_t ldl, const float* out_w, float* dt,
+                        hipStream_t s) {
+    if (head_grads_one_plane() && R > 128) return vag_gemm_launch_planes(1, R, E, V, 1.f, dlogits, ldl, 1, out_w, E, 1, 0.f, dt, E, s);
+    return gemm_nn(R, E, V, dlogits, ldl, out_w, E, 0.f, dt, E, s);
+}
+static int head_outw_gemm(int64_t V, int64_t E, int64_t R, const float* dlogits, int64_t ldl, const float* tmid, float* g_out_w,
+                          hipStream_t s) {
+    if (R == 0) return VAG_OK;
+    if (head_grads_one_plane() && R > 128) return vag_gemm_launch_planes(1, V, E, R, 1.f, dlogits, 1, ldl, tmid, E, 1, 1.f, g_out_w, E, s);
+    return gemm_tn_acc(V, E, R, dlogits, ldl, tmid, E, g_out_w, E, s);
+}
+
 extern "C" {
 
 int vag_version(void) { return 200; }
@@ -926,8 +946,8 @@ int vag_head_ce_seq_fwd_impl(const float* h2_all, const float* c_all, const floa
                 const vag_head_g& g = *g_head_fuse.g;
                 VAG_TRY(vag_ce_bwd_colsum_launch(logits, ldl, rows, V, tgt + r0 / B, B, Tt, vocab_weight, lse + r0, inv_cnt,
                                                  g_head_fuse.d_loss, g.out_b, s));
-                VAG_TRY(gemm_nn(rows, E, V, logits, ldl, w.out_w, E, 0.f, g_head_fuse.dt + r0 * E, E, s));
-                VAG_TRY(gemm_tn_acc(V, E, rows, logits, ldl, tmid + r0 * E, E, g.out_w, E, s));
+                VAG_TRY(head_dt_gemm(rows, E, V, logits, ldl, w.out_w, g_head_fuse.dt + r0 * E, s));
+                VAG_TRY(head_outw_gemm(V, E, rows, logits, ldl, tmid + r0 * E, g.out_w, s));
             }
         }
         if (g_head_fuse.g) g_head_fuse.done = true;
@@ -948,7 +968,7 @@ static int head_bwd_data(const vag_head_w& w, int64_t R, int64_t E, int64_t H, i
                          const float* tmid, const float* dlogits, int64_t ldl, float* d_h2_all, float* d_c_all,
                          float* d_e_all, float* dt, hipStream_t s, bool dt_ready = false) {
     const int64_t C = 2 * H;
-    if (!dt_ready) VAG_TRY(gemm_nn(R, E, V, dlogits, ldl, w.out_w, E, 0.f, dt, E, s));
+    if (!dt_ready) VAG_TRY(head_dt_gemm(R, E, V, dlogits, ldl, w.out_w, dt, s));
     VAG_TRY(vag_tanh_bwd_launch(tmid, dt, dt, R * E, rng, VAG_DROP_DEC_OUT, p_out, s));   // tmid holds tanh(.)*mul
     VagGemmGroup grp5;              // three independent products of d(pre-activation): one grouped launch
     VAG_TRY(gemm_nn(R, H, E, dt, E, w.w1, H, 0.f, d_h2_all, H, s));
@@ -963,7 +983,7 @@ static int head_bwd_weights(const float* h2_all, const float* c_all, const float
                             const vag_head_g& g, hipStream_t s, bool out_b_done = false, bool out_w_done = false) {
     const int64_t C = 2 * H;
     VagGemmGroup grp6;
-    if (!out_w_done) VAG_TRY(gemm_tn_acc(V, E, R, dlogits, ldl, tmid, E, g.out_w, E, s));
+    if (!out_w_done) VAG_TRY(head_outw_gemm(V, E, R, dlogits, ldl, tmid, g.out_w, s));
     if (!out_b_done) VAG_TRY(vag_colsum_launch(dlogits, R, V, ldl, g.out_b, s));
     VAG_TRY(gemm_tn_acc(E, H, R, dt, E, h2_all, H, g.w1, H, s));
     VAG_TRY(gemm_tn_acc(E, C, R, dt, E, c_all, C, g.w2, C, s));
@@ -1016,8 +1036,8 @@ int vag_head_ce_seq_bwd(const float* h2_all, const float* c_all, const float* e_
             VAG_TRY(vag_gemm_launch(rows, V, E, 1.f, tmid + r0 * E, E, 1, w.out_w, 1, E, 0.f, logits, ldl, w.out_b, 0, s));
             VAG_TRY(vag_ce_bwd_colsum_launch(logits, ldl, rows, V, tgt + r0 / B, B, Tt, vocab_weight, lse + r0, inv_cnt, d_loss,
                                              g.out_b, s));
-            VAG_TRY(gemm_nn(rows, E, V, logits, ldl, w.out_w, E, 0.f, scratch + r0 * E, E, s));
-            VAG_TRY(gemm_tn_acc(V, E, rows, logits, ldl, tmid + r0 * E, E, g.out_w, E, s));
+            VAG_TRY(head_dt_gemm(rows, E, V, logits, ldl, w.out_w, scratch + r0 * E, s));
+            VAG_TRY(head_outw_gemm(V, E, rows, logits, ldl, tmid + r0 * E, g.out_w, s));
         }
         VAG_TRY(head_bwd_data(w, R, E, H, V, p_out, rng, tmid, logits, ldl, d_h2_all, d_c_all, d_e_all, scratch, s, true));
         return head_bwd_weights(h2_all, c_all, e_all, R, E, H, V, tmid, logits, ldl, scratch, g, s, true, true);
@@ -1051,7 +1071,7 @@ int vag_head_chunk_data(const VagHeadChunk& k, int64_t t0, int64_t t1, hipStream
     VAG_TRY(vag_lse_nll_launch(k.logits, ldl, n, V, k.tgt + t0, B, k.Tt, k.vw, k.lse + r0, k.nll + r0, nullptr, 0, nullptr, 0, s));
     VAG_TRY(vag_ce_bwd_colsum_launch(k.logits, ldl, n, V, k.tgt + t0, B, k.Tt, k.vw, k.lse + r0, k.inv_cnt, k.d_loss, k.g.out_b,
                                      s));
-    VAG_TRY(gemm_nn(n, E, V, k.logits, ldl, k.w.out_w, E, 0.f, dt, E, s));
+    VAG_TRY(head_dt_gemm(n, E, V, k.logits, ldl, k.w.out_w, dt, s));
     VAG_TRY(vag_tanh_bwd_launch(tmid, dt, dt, n * E, k.rng, VAG_DROP_DEC_OUT, k.p_out, s, r0 * E));
     {
         VagGemmGroup grp;

@@ -309,7 +309,7 @@ __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r
             split3(r.v[4 * i + 2], r.v[4 * i + 3], b1, b2, b3);
             __bf16* d = S + o * SP_LD + k;
             *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
-            *reinterpret_cast<uint2*>(d + SP_PLANE) = make_uint2(a2, b2);
+            if (PL >= 2) *reinterpret_cast<uint2*>(d + SP_PLANE) = make_uint2(a2, b2);
             if (PL == 3) *reinterpret_cast<uint2*>(d + 2 * SP_PLANE) = make_uint2(a3, b3);
         }
     } else {
@@ -320,7 +320,7 @@ __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r
             split3(r.v[2 * i], r.v[2 * i + 1], p1, p2, p3);       // (k, k+1) packed into one dword
             __bf16* d = S + o * SP_LD + 2 * (kq + 4 * i);
             *reinterpret_cast<unsigned*>(d) = p1;
-            *reinterpret_cast<unsigned*>(d + SP_PLANE) = p2;
+            if (PL >= 2) *reinterpret_cast<unsigned*>(d + SP_PLANE) = p2;
             if (PL == 3) *reinterpret_cast<unsigned*>(d + 2 * SP_PLANE) = p3;
         }
     }
@@ -335,7 +335,8 @@ __device__ __forceinline__ bf16x8 sp_frag(const __bf16* p) {      // 8 consecuti
 }
 
 // One k-tile of MFMA work from the LDS planes: 2 k-steps of 16; PL = 3: six bf16 products (fp32-grade), PL = 2: three
-// (x = x1 + x2 exactly to 16 significand bits: the 2-byte storage mode, whose operands carry no more than that).
+// (x = x1 + x2 exactly to 16 significand bits: the 2-byte storage mode, whose operands carry no more than that), PL = 1:
+// plain bf16 operands, one product (2-byte mode, the two vocabulary-sized gradient products of the head only).
 template <int PL>
 __device__ __forceinline__ void sp_compute(const __bf16* Af, const __bf16* Bf, f32x16 (&acc)[2]) {
 #pragma unroll
@@ -356,8 +357,10 @@ __device__ __forceinline__ void sp_compute(const __bf16* Af, const __bf16* Bf, f
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[1], acc[i], 0, 0, 0);
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PL - 1], bf[0], acc[i], 0, 0, 0);
             }
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[1], acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[0], acc[i], 0, 0, 0);
+            if (PL >= 2) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[PL >= 2 ? 1 : 0], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PL >= 2 ? 1 : 0], bf[0], acc[i], 0, 0, 0);
+            }
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i], 0, 0, 0);
         }
     }
@@ -449,12 +452,13 @@ __global__ __launch_bounds__(512) void gemm_split_group_kernel(GemmGroupArgs G) 
 // Planes per operand of the bf16 split on the calling thread: 3 (default: six products, fp32-grade) or 2 (three products:
 // the 2-byte storage mode, set by the step driver for the duration of a call).
 static thread_local int g_gemm_planes = 3;
-void vag_gemm_set_planes(int planes) { g_gemm_planes = planes == 2 ? 2 : 3; }
+void vag_gemm_set_planes(int planes) { g_gemm_planes = (planes == 2 || planes == 1) ? planes : 3; }
 
 static int gemm_split_dispatch(const GemmArgs& g, bool akc, bool bkc, bool vec, dim3 grid, hipStream_t s) {
 #define VAG_SPLIT_CASE(AK, BKc, V)                                                                    \
     if (akc == AK && bkc == BKc && vec == V) {                                                        \
         if (g_gemm_planes == 2) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 2>), grid, dim3(512), 0, s, g);   \
+        else if (g_gemm_planes == 1) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 1>), grid, dim3(512), 0, s, g);   \
         else hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 3>), grid, dim3(512), 0, s, g);        \
         VAG_LAUNCH_CHECK();                                                                           \
         return VAG_OK;                                                                                \
@@ -571,7 +575,7 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
         hipLaunchKernelGGL((gemm_split_group_kernel<true, true, PLN>), dim3((unsigned)total), dim3(512), 0, stream, G);       \
     else                                                                                                                      \
         hipLaunchKernelGGL((gemm_split_group_kernel<false, true, PLN>), dim3((unsigned)total), dim3(512), 0, stream, G);
-    if (g_gemm_planes == 2) { VAG_GROUP_GO(2) } else { VAG_GROUP_GO(3) }
+    if (g_gemm_planes <= 2) { VAG_GROUP_GO(2) } else { VAG_GROUP_GO(3) }      // one-plane products are never grouped
 #undef VAG_GROUP_GO
     VAG_LAUNCH_CHECK();
     return VAG_OK;
@@ -672,6 +676,17 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     return gemm_dispatch<64, 64, 256>(g, akc, bkc, vec, grid, stream);
 }
 
+// One product launched at once (not queued into an open group bracket) with `planes` bf16 planes per operand.
+int vag_gemm_launch_planes(int planes, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
+                           const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc, hipStream_t stream) {
+    const int depth = g_group_depth, pl = g_gemm_planes;
+    g_group_depth = 0;
+    g_gemm_planes = planes;
+    const int rc = vag_gemm_launch(M, N, K, alpha, A, sam, sak, B, sbk, sbn, beta, C, ldc, nullptr, 0, stream, 0);
+    g_group_depth = depth;
+    g_gemm_planes = pl;
+    return rc;
+}
 static int vag_gemm_launch_now(const GemmArgs& q, hipStream_t stream) {
     return vag_gemm_launch(q.M, q.N, q.K, q.alpha, q.A, q.sa_o, q.sa_k, q.B, q.sb_k, q.sb_o, q.beta, q.C, q.ldc, q.bias, q.act,
                            stream, q.c_half);
