@@ -327,6 +327,51 @@ def measure_extras(c, dev, ts, args):
                     "mean_hyp_len": sum(len(h) for h in hyp) / 16.0,
                     "note": "beam search stops once every hypothesis has emitted EOS (V11.py:266-269)"}
     m4.train(was)
+    # the overlapped schedule (CU-masked streams, eager) and configs[4] in its 2-byte storage mode, each on a driver of its
+    # own; a failure here must not take the headline line down
+    from vagnmt_hip.trainer import TrainStep
+    from machine_translation_vision.losses import PairwiseRankingLoss
+
+    def fresh(cc, **kw):
+        mm_ = build_model(cc, dev)
+        vw = torch.ones(cc["V"], device=dev)
+        vw[0] = 0
+        t2 = TrainStep(mm_, torch.nn.NLLLoss(weight=vw, reduction="none"), PairwiseRankingLoss(margin=0.1), lr=4e-4,
+                       weight_decay=1e-5, clip=1.0, teacher_force_ratio=1.0, **kw)
+        b2 = make_batch(cc, 0, dev)
+        return t2, b2, torch.tensor(b2[1], dtype=torch.int32, device=dev)
+
+    def timed(t2, b2, l2, n):
+        for _ in range(4):
+            t2.step(b2[0], l2, b2[2], b2[3], teacher=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            t2.step(b2[0], l2, b2[2], b2[3], teacher=True)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    try:
+        with torch.cuda.stream(torch.cuda.Stream()):
+            t2, b2, l2 = fresh(c, overlap=True)
+            ms_ov = timed(t2, b2, l2, 30)
+        out["overlapped_schedule"] = {"ms_per_step": ms_ov, "pairs_per_s": c["B"] / ms_ov * 1e3,
+                                      "note": "recurrences on 160 CUs, head and decoder weight gradients on 96 (CU-masked "
+                                              "streams, eager launches); off by default, DESIGN section 7 item 3"}
+        del t2, b2, l2
+    except Exception as e:       # noqa: BLE001
+        out["overlapped_schedule"] = {"error": repr(e)[:200]}
+    if c is CFG2 and not args.no_cfg5_row:
+        try:
+            torch.cuda.empty_cache()
+            t2, b2, l2 = fresh(CFG5, storage="f16")
+            ms5 = timed(t2, b2, l2, 6)
+            out["configs4_fp16_storage"] = {"ms_per_step": ms5, "pairs_per_s": CFG5["B"] / ms5 * 1e3, "dtype": "f16",
+                                            "workload": "H=1024, Ts=Tt=80, B=256, V=40000; python bench.py --config cfg5 "
+                                                        "prints its full line"}
+            del t2, b2, l2
+            torch.cuda.empty_cache()
+        except Exception as e:   # noqa: BLE001
+            out["configs4_fp16_storage"] = {"error": repr(e)[:200]}
     return out
 
 
@@ -358,6 +403,7 @@ def main():
     ap.add_argument("--tfr", type=float, default=1.0, help="teacher forcing ratio (headline: 1.0)")
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="debug: disable the reference dropouts")
+    ap.add_argument("--no-cfg5-row", action="store_true", help="skip the configs[4] row of the extras")
     ap.add_argument("--overlap", action="store_true", help="CU-partitioned streams inside the step (eager launches)")
     ap.add_argument("--no-fused", action="store_true", help="debug: per-operator autograd path instead of vag_train_step")
     ap.add_argument("--config", choices=["cfg2", "cfg5", "cfg5-f32"], default="cfg2",
