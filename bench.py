@@ -426,9 +426,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL prints its ring / tree / channel choice over xGMI once at communicator creation (rank 0's stderr)
+        # RCCL logs its ring / tree / channel choice over xGMI once at communicator creation.  It would print to STDOUT,
+        # where the one JSON line must stay alone: send it to a file per process and quote an excerpt in the `dp` block.
         os.environ.setdefault("NCCL_DEBUG", "INFO")
         os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/vag_rccl_%h_%p.log")
         if smoke_dp:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -510,6 +512,16 @@ def main():
                    "exposed_comm_ms": max(float(x[0]) for x in allv) - max(float(x[1]) for x in allv),
                    "gradient_bytes": ts.fp.n * 4, "buckets_bytes": [(hi - lo) * 4 for lo, hi in ts.fp.buckets()],
                    "backend": dist.get_backend(), "steps": n}
+        if rank == 0:
+            import glob
+            lines = []
+            for f in glob.glob("/tmp/vag_rccl_*_%d.log" % os.getpid()):
+                try:
+                    lines += [ln.strip()[:200] for ln in open(f, errors="replace")
+                              if any(k in ln for k in ("Ring", "Tree", "Channel", "channels", "xGMI", "XGMI", "comm 0x"))]
+                except OSError:
+                    pass
+            dp_info["rccl_log_excerpt"] = lines[:16]
     if rank == 0:
         # configs[4] prices every streamed element at 2 bytes (F_dec = 199.3 MB)
         ab = algorithmic_bytes(c, w=2 if args.config == "cfg5" else 4)
