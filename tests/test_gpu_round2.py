@@ -456,14 +456,23 @@ def test_chunked_head_equals_whole_sequence_head(monkeypatch, storage, chunk_ste
 # overlapped schedule: recurrences and the dense work beside them on two CU-masked streams
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("storage", ["f32", "f16"])
-@pytest.mark.parametrize("steps", ["1", "5", "8"])          # chunk length in time steps (Tt = 12: ragged last chunk / single chunk)
+@pytest.mark.parametrize("steps", ["1", "5", "8", "5+chunkbuf", "8+tail3"])   # chunk length in time steps (Tt = 12: ragged last chunk / single chunk)
 def test_overlapped_step_equals_single_stream_step(monkeypatch, storage, steps):
+    """+chunkbuf: the large-vocabulary variant of the schedule (one reused logits chunk buffer, each chunk's parameter
+    gradients taken before the next chunk overwrites it); +tail3: a short last chunk."""
     from vagnmt_hip.trainer import TrainStep
     m_of, (src, lens, tgt, im), cm, cv = _fp16_case("mid")
     lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
-    monkeypatch.setenv("VAG_OVERLAP_STEPS", steps)
+    monkeypatch.setenv("VAG_OVERLAP_STEPS", steps.split("+")[0])
+    if steps.endswith("tail3"):
+        monkeypatch.setenv("VAG_OVERLAP_TAIL", "3")
     out = []
     for overlap in (False, True):
+        if steps.endswith("chunkbuf"):
+            if overlap:
+                monkeypatch.setenv("VAG_HEAD_CHUNK", str(5 * src.shape[0]))
+            else:
+                monkeypatch.delenv("VAG_HEAD_CHUNK", raising=False)
         m = m_of()
         ts = TrainStep(m, cm, cv, use_graph=False, storage=storage, pad_src=1, overlap=overlap)
         m.train()
