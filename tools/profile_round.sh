@@ -17,7 +17,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ps && rocprofv3 --kernel-trace --stats -d /tmp/ps -o s --output-format csv -- \
-    python3 $ROOT/bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-operators > $OUT/bench_prof.log 2>&1
+    python3 $ROOT/bench.py --steps 60 --warmup 20 --no-cpu-baseline --no-operators --no-extras > $OUT/bench_prof.log 2>&1
 cp /tmp/ps/s_kernel_stats.csv $OUT/kernel_stats.csv
 python3 $ROOT/tools/step_timeline.py /tmp/ps --full > $OUT/step_timeline.txt
 python3 $ROOT/tools/kernel_by_shape.py /tmp/ps $OUT/kernel_by_shape.json > $OUT/kernel_by_shape.txt
