@@ -27,7 +27,6 @@ struct GemmArgs {
     int M, N, K, kchunk;
     float alpha, beta;
     int act, splitk;
-    int stagger;          // experiment: odd "dispatch rounds" of blocks sleep this many x 512 cycles before their first tile
     int c_half;           // 1: C is stored as fp16 (outputs that the recurrences re-read every step); needs beta == 0, no split-K
 };
 
@@ -387,14 +386,6 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
     const __bf16* Af = As + (wm * 64 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
     const __bf16* Bf = Bs + (wn * 32 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
 
-    if (a.stagger > 0) {
-        // two blocks share a CU and, started together, run their split / MFMA phases in lockstep (each phase then takes twice
-        // as long); the block of the second dispatch round starts half a period late so that one splits while the other
-        // multiplies
-        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        if ((lin >> 8) & 1)
-            for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(8);
-    }
     SpRegs ra, rb;
     sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, kbeg, a.M, kend, ra);
     sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, kbeg, a.N, kend, rb);
@@ -617,7 +608,6 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     g.sa_o = sam; g.sa_k = sak; g.sb_o = sbn; g.sb_k = sbk;
     g.ldc = ldc; g.M = (int)M; g.N = (int)N; g.K = (int)K;
     g.alpha = alpha; g.beta = beta; g.act = act; g.c_half = c_half;
-    g.stagger = getenv("VAG_GEMM_STAGGER") ? atoi(getenv("VAG_GEMM_STAGGER")) : 0;
     VAG_CHECK_ARG(!c_half || (beta == 0.f && M > 64 && N > 64 && !opt_f32mfma));      // fp16 output: bf16x6 kernels only
     const int64_t lda = akc ? sam : sak, ldb = bkc ? sbn : sbk;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
