@@ -37,7 +37,131 @@ __device__ __forceinline__ Cand block_best(Cand c, Cand* sh) {
     return r;
 }
 
-// Selection in both stages: every thread caches the best of the candidates it owns; a round is one block-wide argmax
+// ---- selection by radix search (round 2) ----
+// The k best of the candidates one WAVE holds in registers (E per lane), under the same total order (value desc, flat index
+// asc), without any cross-lane data movement: the k-th largest key is found bit by bit from ballots and population counts
+// (32 x E ballots, no LDS round trips; the former k rounds of a shuffle-tree argmax cost ~12 dependent ds_bpermute each).
+// Ties on the k-th value are broken by index in a (rare) slow loop.  The winners come out as an unordered set; the one place
+// that needs them ordered (stage 2's output) ranks its k entries afterwards.
+__device__ __forceinline__ unsigned fkey(float v) {       // order-preserving float -> uint (larger float, larger key)
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+template <int E>
+__device__ __forceinline__ void wave_select(const float (&val)[E], const int (&idx)[E], int k, bool (&sel)[E]) {
+    unsigned key[E];
+    int nvalid = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool ok = idx[e] != 0x7fffffff;
+        key[e] = ok ? fkey(val[e]) : 0u;          // fkey(-inf) = 0x007fffff > 0: a real candidate always beats a hole
+        nvalid += __popcll(__ballot(ok));
+        sel[e] = false;
+    }
+    const int kk = min(k, nvalid);
+    if (kk == 0) return;
+    unsigned prefix = 0;
+    int need = kk;
+    for (int b = 31; b >= 0; --b) {
+        const unsigned test = prefix | (1u << b);
+        const unsigned himask = ~((1u << b) - 1u);
+        int c = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) c += __popcll(__ballot((key[e] & himask) == test && idx[e] != 0x7fffffff));
+        if (c >= need) prefix = test;
+        else need -= c;
+    }
+    // prefix = key of the kk-th best; `need` of the candidates equal to it are taken, smallest index first
+    int neq = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool ok = idx[e] != 0x7fffffff;
+        sel[e] = ok && key[e] > prefix;
+        neq += __popcll(__ballot(ok && key[e] == prefix));
+    }
+    if (neq == need) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) sel[e] = sel[e] || (idx[e] != 0x7fffffff && key[e] == prefix);
+        return;
+    }
+    for (int r = 0; r < need; ++r) {              // exact ties across candidates: rare
+        int best = 0x7fffffff;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (idx[e] != 0x7fffffff && key[e] == prefix && !sel[e]) best = min(best, idx[e]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (idx[e] == best && key[e] == prefix) sel[e] = true;
+    }
+}
+// Writes the selected candidates of a wave densely to (ov, oi)[0 .. count): returns count (uniform over the wave).
+template <int E>
+__device__ __forceinline__ int wave_compact(const float (&val)[E], const int (&idx)[E], const bool (&sel)[E], float* ov, int* oi) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    int n = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const unsigned long long m = __ballot(sel[e]);
+        if (sel[e]) {
+            const int pos = n + __popcll(m & lt);
+            ov[pos] = val[e]; oi[pos] = idx[e];
+        }
+        n += __popcll(m);
+    }
+    return n;
+}
+
+// The k best of a wave's candidates, RANKED (ov/oi[0..n): best first), n = min(k, #valid) returned.  Most candidates are
+// discarded by a bound that costs 32 ballots whatever E is: the k-th largest of the 64 lane-local maxima is a lower
+// bound of the k-th largest overall (those k lane maxima are k distinct candidates), so only candidates >= it can be
+// winners -- typically k to 2k survive.  Survivors (<= 64: one per lane) are ranked by counting who beats them; with more
+// survivors (heavy ties) the exact radix search over all E takes over.  sv/si: 64 entries of LDS scratch of this wave.
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+template <int E>
+__device__ __forceinline__ int wave_topk(const float (&val)[E], const int (&idx)[E], int k, float* sv, int* si, float* ov, int* oi) {
+    const int lane = threadIdx.x & 63;
+    unsigned kb = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (idx[e] != 0x7fffffff) kb = max(kb, fkey(val[e]));
+    unsigned t0 = 1u;                                   // every valid key is >= fkey(-inf) > 1
+    if (__popcll(__ballot(kb != 0u)) >= k) {            // k-th largest of the lane maxima
+        unsigned prefix = 0;
+        int need = k;
+        for (int b = 31; b >= 0; --b) {
+            const unsigned test = prefix | (1u << b);
+            const int c = __popcll(__ballot((kb & ~((1u << b) - 1u)) == test));
+            if (c >= need) prefix = test;
+            else need -= c;
+        }
+        t0 = prefix;
+    }
+    bool sel[E];
+    int n = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        sel[e] = idx[e] != 0x7fffffff && fkey(val[e]) >= t0;
+        n += __popcll(__ballot(sel[e]));
+    }
+    if (n > 64) {                                       // heavy ties: exact search over everything
+        wave_select<E>(val, idx, k, sel);
+    }
+    n = wave_compact<E>(val, idx, sel, sv, si);
+    wave_lds_fence();
+    if (lane < n) {
+        const float mv = sv[lane];
+        const int mi = si[lane];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += better(sv[j], si[j], mv, mi) ? 1 : 0;
+        if (rank < k) { ov[rank] = mv; oi[rank] = mi; }
+    }
+    return min(n, k);
+}
+
+// Selection in both stages (fallback path): every thread caches the best of the candidates it owns; a round is one block-wide argmax
 // of the cached bests, and only the winner's owner rescans its (register- or LDS-resident) candidates.
 // The step index comes from the host (di_host) or, for launches replayed from a HIP graph, from device memory
 // (di_state[0], advanced by stage 2; such launches are always steps >= 1, i.e. k_in == k).
@@ -46,7 +170,6 @@ __global__ __launch_bounds__(256) void beam_stage1_kernel(const float* __restric
                                                           const int32_t* di_state, int di_host, int max_len, int B,
                                                           int k_in, int k, int V, float* __restrict__ cval,
                                                           int* __restrict__ cidx, int32_t* __restrict__ n_alive) {
-    __shared__ Cand sh[4];
     const int di = di_state ? __atomic_load_n(di_state, __ATOMIC_RELAXED) : di_host;
     if (di >= max_len || (di_state && di < 1)) return;                          // replayed past the end: nothing to do
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *n_alive = 0;   // stage 2 (next launch) counts into it
@@ -75,28 +198,25 @@ __global__ __launch_bounds__(256) void beam_stage1_kernel(const float* __restric
         else if (w == pt) lp = NEG_PEN;                           // V11.py:279-280
         val[e] = f < total ? base + lp : -INFINITY;               // V11.py:297
     }
-    unsigned taken = 0;
-    auto scan = [&]() {
-        Cand c = {-INFINITY, 0x7fffffff};
+    // each wave ranks the k best of its 512 candidates; wave 0 then ranks the k best of those 4k
+    __shared__ float wv[4 * 64], sv[4 * 64];
+    __shared__ int wi[4 * 64], si[4 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int idx[EPT];
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const int f = f0 + e * 256;
-            if (!((taken >> e) & 1u) && f < total && better(val[e], f, c.v, c.idx)) { c.v = val[e]; c.idx = f; }
-        }
-        return c;
-    };
-    Cand mine = scan();
-    for (int r = 0; r < k; ++r) {
-        const Cand c = block_best(mine, sh);
-        if (threadIdx.x == 0) {
-            const int64_t o = ((int64_t)b * chunks + chunk) * k + r;
-            cval[o] = c.v; cidx[o] = c.idx;
-        }
-        if (c.idx != 0x7fffffff && mine.idx == c.idx) {
-            taken |= 1u << ((c.idx - f0) >> 8);
-            mine = scan();
-        }
-    }
+    for (int e = 0; e < EPT; ++e) idx[e] = (f0 + e * 256 < total) ? f0 + e * 256 : 0x7fffffff;
+    wv[wave * 64 + lane] = -INFINITY; wi[wave * 64 + lane] = 0x7fffffff;
+    wave_lds_fence();
+    wave_topk<EPT>(val, idx, k, sv + wave * 64, si + wave * 64, wv + wave * 64, wi + wave * 64);
+    __syncthreads();
+    if (wave != 0) return;
+    float v2[4];
+    int i2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v2[e] = wv[e * 64 + lane]; i2[e] = wi[e * 64 + lane]; }
+    const int64_t o = ((int64_t)b * chunks + chunk) * k;
+    const int n = wave_topk<4>(v2, i2, k, sv, si, cval + o, cidx + o);
+    for (int r = n + lane; r < k; r += 64) { cval[o + r] = -INFINITY; cidx[o + r] = 0x7fffffff; }
 }
 
 constexpr int S2_LDS = 4096;             // candidates kept in LDS by stage 2 (more: selection works on the scratch copy)
@@ -123,6 +243,24 @@ __global__ __launch_bounds__(256) void beam_stage2_kernel(float* __restrict__ cv
         pv = lv; pi = li;
         __syncthreads();
     }
+    constexpr int E2 = 16;                     // fast path: up to 1024 chunk winners, held by ONE wave (16 per lane)
+    if (ncand <= 64 * E2) {
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            float v2[E2];
+            int i2[E2];
+#pragma unroll
+            for (int e = 0; e < E2; ++e) {
+                const int c = e * 64 + lane;
+                v2[e] = c < ncand ? pv[c] : -INFINITY;
+                i2[e] = c < ncand ? pi[c] : 0x7fffffff;
+            }
+            __shared__ float tv[64];
+            __shared__ int ti[64];
+            const int n = wave_topk<E2>(v2, i2, k, tv, ti, sel_val, sel_idx);       // ranked: slot j = j-th best
+            for (int r = n + lane; r < k; r += 64) { sel_idx[r] = 0x7fffffff; sel_val[r] = -INFINITY; }
+        }
+    } else {
     int mine_e = -1;
     auto scan = [&]() {
         Cand c = {-INFINITY, 0x7fffffff};
@@ -141,6 +279,7 @@ __global__ __launch_bounds__(256) void beam_stage2_kernel(float* __restrict__ cv
             pi[mine_e] = 0x7fffffff;                               // taken (only its owner reads this slot again)
             mine = scan();
         }
+    }
     }
     __syncthreads();
     if (threadIdx.x < k) {
