@@ -608,6 +608,7 @@ def main():
         print(json.dumps(res))
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()                    # rank 0 is still measuring its single-GPU blocks: leave together
         dist.destroy_process_group()
 
 
