@@ -527,6 +527,10 @@ def main():
         ab = algorithmic_bytes(c, w=2 if args.config == "cfg5" else 4)
         if args.no_operators:
             print(json.dumps({"ms_per_step": dt / args.steps * 1e3, "final_loss": loss}))
+            if world > 1:
+                import torch.distributed as dist
+                dist.barrier()
+                dist.destroy_process_group()
             return
         fam = measure_operators(c, dev, storage16=(args.config == "cfg5"))
         log("operator timings: %s" % fam)
