@@ -526,3 +526,73 @@ def test_three_launch_decoder_step_experiment_keeps_parity(monkeypatch):
         (l0, g0), (l1, g1) = out
         assert np.allclose(l0, l1, rtol=2e-6, atol=1e-7), (l0, l1)
         assert (g0 - g1).abs().max().item() <= 2e-5 * g0.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# beam expansion at the kernel level: the selection (lane-maxima bound + rank counting, radix search under heavy ties)
+# against a numpy restatement of models/...V11.py:279-313 with the total order (score desc, flat index asc)
+# ------------------------------------------------------------------------------------------------------------------
+def _beam_step_reference(logp, nll, prev_tok, di, k_in, k, V):
+    B = logp.shape[0] // k_in
+    words = np.zeros((B, k), dtype=np.int64)
+    parents = np.zeros((B, k), dtype=np.int64)
+    scores = np.zeros((B, k), dtype=np.float32)
+    for b in range(B):
+        cand = np.empty(k_in * V, dtype=np.float32)
+        for j in range(k_in):
+            n = b * k_in + j
+            lp = logp[n, :V].copy()
+            base = np.float32(0.0)
+            if di > 0:
+                pt = prev_tok[n]
+                if pt == 3:
+                    lp[:] = np.float32(-1e5)
+                    lp[3] = 0.0
+                else:
+                    lp[pt] = np.float32(-1e5)
+                base = nll[n]
+            cand[j * V:(j + 1) * V] = base + lp
+        order = np.lexsort((np.arange(cand.size), -cand.astype(np.float64)))[:k]
+        words[b], parents[b], scores[b] = order % V, order // V, cand[order]
+    return words, parents, scores
+
+
+@pytest.mark.parametrize("case", ["random", "quantised", "constant", "small_vocab"])
+def test_beam_expansion_selection_matches_total_order(case):
+    from vagnmt_hip import _lib as L
+    from vagnmt_hip._lib import call, ptr
+    B, k, V, H, ML = (5, 12, 9391, 32, 10) if case != "small_vocab" else (3, 7, 37, 8, 6)
+    ldl = (V + 3) // 4 * 4
+    g = torch.Generator().manual_seed(3)
+    for di in (0, 2):
+        k_in = 1 if di == 0 else k
+        N = B * k_in
+        x = torch.randn(N, ldl, generator=g)
+        if case == "quantised":
+            x = (x * 2).round() / 2             # thousands of exact ties on every value
+        elif case == "constant":
+            x = torch.zeros(N, ldl)             # everything ties: winners are the smallest flat indices
+        logp = x.cuda().contiguous()
+        nll = (torch.randn(B * k, generator=g).round() if case != "random" else torch.randn(B * k, generator=g)).cuda()
+        beam = torch.zeros(2 * ML, B, k, dtype=torch.int64)
+        if di > 0:
+            beam[di - 1] = torch.randint(0, V, (B, k), generator=g)
+            beam[di - 1, 0, 0] = 3              # a finished hypothesis
+            beam[di - 1, 1, :] = 3              # a sentence whose hypotheses have all finished
+        beam = beam.cuda()
+        h_in = torch.randn(N, H, generator=g).cuda()
+        h_out = torch.zeros(B * k, H, device="cuda")
+        n_alive = torch.zeros(1, dtype=torch.int32, device="cuda")
+        scratch = torch.empty(L.lib().vag_beam_scratch_bytes(B, k, V, ML), dtype=torch.uint8, device="cuda")
+        nll_in = nll.clone()
+        call("vag_beam_step", ptr(logp), ldl, ptr(nll), ptr(beam, torch.int64), di, ML, ptr(h_in), ptr(h_out), B, k, V, H,
+             ptr(n_alive, torch.int32), scratch.data_ptr(), L.stream())
+        torch.cuda.synchronize()
+        prev = beam[di - 1].reshape(-1).cpu().numpy() if di > 0 else None
+        w, p, s = _beam_step_reference(logp.cpu().numpy(), nll_in.cpu().numpy(), prev, di, k_in, k, V)
+        assert np.array_equal(beam[di].cpu().numpy(), w), (case, di)
+        assert np.array_equal(beam[ML + di].cpu().numpy(), p), (case, di)
+        assert np.array_equal(nll.cpu().numpy().reshape(B, k), s), (case, di)
+        want_h = h_in.cpu().numpy().reshape(B, k_in, H)[np.arange(B)[:, None], p]
+        assert np.array_equal(h_out.cpu().numpy().reshape(B, k, H), want_h), (case, di)
+        assert int(n_alive.item()) == int((w != 3).sum()), (case, di)
