@@ -259,6 +259,15 @@ __device__ __forceinline__ void split3(float a, float b, unsigned& p1, unsigned&
 // outer dimension, at k and k+1 (round 2; before: eight scalar loads per operand and thread), giving four (k, k+1) pairs
 // whose LDS scatter writes whole dwords.
 struct SpRegs { float v[8]; };
+// k-contiguous operands: the four rows a 32-lane group writes to LDS with one 8-byte store per lane are 8 apart, not
+// consecutive: with the 72-byte row stride rows r and r+2 share banks, rows r, r+8, r+16, r+24 tile the 32 banks exactly
+// twice (PMC had 20 % of the LDS-active cycles as bank conflicts).
+__device__ __forceinline__ int sp_row(int q) { return (q & ~31) | ((q & 3) << 3) | ((q >> 2) & 7); }
+// outer-contiguous operands: lane -> (group of 4 outer indices, k pair) within a wave's 8 groups x 8 pairs.  Each 32-lane
+// half takes 4 groups x 8 pairs: rows 4 apart differ by 8 banks (72-byte stride), so 4 groups x 8 consecutive dword columns
+// tile the 32 banks exactly once per half.
+__device__ __forceinline__ int sp_oc_group(int lane) { return (lane & 3) | ((lane >> 5) << 2); }
+__device__ __forceinline__ int sp_oc_kpair(int lane) { return (lane >> 2) & 7; }
 
 template <bool KC, bool VEC>
 __device__ __forceinline__ void sp_load(const float* __restrict__ P, int64_t so, int64_t sk, int o0, int k0, int OUT,
@@ -268,7 +277,7 @@ __device__ __forceinline__ void sp_load(const float* __restrict__ P, int64_t so,
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + i * 512;
-            const int o = o0 + (idx >> 3), k = k0 + ((idx & 7) << 2);
+            const int o = o0 + sp_row(idx >> 3), k = k0 + ((idx & 7) << 2);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (o < OUT) {
                 const float* p = P + (int64_t)o * so + k;
@@ -284,12 +293,12 @@ __device__ __forceinline__ void sp_load(const float* __restrict__ P, int64_t so,
             r.v[4 * i + 0] = v.x; r.v[4 * i + 1] = v.y; r.v[4 * i + 2] = v.z; r.v[4 * i + 3] = v.w;
         }
     } else {
-        // thread = (4 consecutive outer indices o4..o4+3, one k pair): lane l of wave w takes outer group (w&3)*8 + (l&7)
-        // and k pair (w>>2)*8 + (l>>3), so a wave instruction reads eight 128-byte row segments and the LDS scatter below
-        // (one dword per row and plane) is 2-way conflicted at most.  r.v[i] = (k, o4+i), r.v[4+i] = (k+1, o4+i).
+        // thread = (4 consecutive outer indices o4..o4+3, one k pair), see sp_oc_group / sp_oc_kpair: a wave instruction reads
+        // eight 128-byte row segments and the LDS scatter below (one dword per row and plane) is free of bank conflicts.
+        // r.v[i] = (k, o4+i), r.v[4+i] = (k+1, o4+i).
         const int lane = tid & 63, w = tid >> 6;
-        const int o = o0 + 4 * ((w & 3) * 8 + (lane & 7));
-        const int k = k0 + 2 * ((w >> 2) * 8 + (lane >> 3));
+        const int o = o0 + 4 * ((w & 3) * 8 + sp_oc_group(lane));
+        const int k = k0 + 2 * ((w >> 2) * 8 + sp_oc_kpair(lane));
         const float* p = P + (int64_t)k * sk + o;
         if (VEC && o + 3 < OUT && k + 1 < KEND) {
             const float4 a = *reinterpret_cast<const float4*>(p);
@@ -314,7 +323,7 @@ __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + i * 512;
-            const int o = idx >> 3, k = (idx & 7) << 2;
+            const int o = sp_row(idx >> 3), k = (idx & 7) << 2;
             unsigned a1, a2, a3, b1, b2, b3;
             split3(r.v[4 * i + 0], r.v[4 * i + 1], a1, a2, a3);
             split3(r.v[4 * i + 2], r.v[4 * i + 3], b1, b2, b3);
@@ -325,8 +334,8 @@ __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r
         }
     } else {
         const int lane = tid & 63, w = tid >> 6;
-        const int o = 4 * ((w & 3) * 8 + (lane & 7));
-        const int k = 2 * ((w >> 2) * 8 + (lane >> 3));
+        const int o = 4 * ((w & 3) * 8 + sp_oc_group(lane));
+        const int k = 2 * ((w >> 2) * 8 + sp_oc_kpair(lane));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             unsigned p1, p2, p3;
