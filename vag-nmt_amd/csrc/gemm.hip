@@ -255,19 +255,14 @@ __device__ __forceinline__ void split3(float a, float b, unsigned& p1, unsigned&
 }
 
 // global -> registers (8 floats per thread per operand tile).
-// KC (k contiguous): two float4 = (row, 4 consecutive k) items.  OC (outer contiguous): two float4 along the contiguous
-// outer dimension, at k and k+1 (round 2; before: eight scalar loads per operand and thread), giving four (k, k+1) pairs
-// whose LDS scatter writes whole dwords.
+// KC (k contiguous): two float4 = (row, 4 consecutive k) items.  OC (outer contiguous): lanes run along the
+// contiguous outer dimension with one float each (256-B rows per wave load), four (k, k+1) pairs per thread, so that
+// the LDS scatter below writes whole dwords (2-way bank conflicts).
 struct SpRegs { float v[8]; };
 // k-contiguous operands: the four rows a 32-lane group writes to LDS with one 8-byte store per lane are 8 apart, not
 // consecutive: with the 72-byte row stride rows r and r+2 share banks, rows r, r+8, r+16, r+24 tile the 32 banks exactly
 // twice (PMC had 20 % of the LDS-active cycles as bank conflicts).
 __device__ __forceinline__ int sp_row(int q) { return (q & ~31) | ((q & 3) << 3) | ((q >> 2) & 7); }
-// outer-contiguous operands: lane -> (group of 4 outer indices, k pair) within a wave's 8 groups x 8 pairs.  Each 32-lane
-// half takes 4 groups x 8 pairs: rows 4 apart differ by 8 banks (72-byte stride), so 4 groups x 8 consecutive dword columns
-// tile the 32 banks exactly once per half.
-__device__ __forceinline__ int sp_oc_group(int lane) { return (lane & 3) | ((lane >> 5) << 2); }
-__device__ __forceinline__ int sp_oc_kpair(int lane) { return (lane >> 2) & 7; }
 
 template <bool KC, bool VEC>
 __device__ __forceinline__ void sp_load(const float* __restrict__ P, int64_t so, int64_t sk, int o0, int k0, int OUT,
@@ -293,24 +288,16 @@ __device__ __forceinline__ void sp_load(const float* __restrict__ P, int64_t so,
             r.v[4 * i + 0] = v.x; r.v[4 * i + 1] = v.y; r.v[4 * i + 2] = v.z; r.v[4 * i + 3] = v.w;
         }
     } else {
-        // thread = (4 consecutive outer indices o4..o4+3, one k pair), see sp_oc_group / sp_oc_kpair: a wave instruction reads
-        // eight 128-byte row segments and the LDS scatter below (one dword per row and plane) is free of bank conflicts.
-        // r.v[i] = (k, o4+i), r.v[4+i] = (k+1, o4+i).
-        const int lane = tid & 63, w = tid >> 6;
-        const int o = o0 + 4 * ((w & 3) * 8 + sp_oc_group(lane));
-        const int k = k0 + 2 * ((w >> 2) * 8 + sp_oc_kpair(lane));
-        const float* p = P + (int64_t)k * sk + o;
-        if (VEC && o + 3 < OUT && k + 1 < KEND) {
-            const float4 a = *reinterpret_cast<const float4*>(p);
-            const float4 b = *reinterpret_cast<const float4*>(p + sk);
-            r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-            r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-        } else {
+        // lanes run along the contiguous outer dimension with one float each (256-byte rows per wave load), four (k, k+1)
+        // pairs per thread.  (Round 2 tried two float4 along the outer dimension at k and k+1 instead of the eight scalars:
+        // +9 % at 4096^3, but 3-13 % SLOWER at the model's split-K weight-gradient shapes -- tools/exp_gemm_tn.py.)
+        const int o = o0 + (tid & 127), kq = tid >> 7;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                r.v[i] = (o + i < OUT && k < KEND) ? p[i] : 0.f;
-                r.v[4 + i] = (o + i < OUT && k + 1 < KEND) ? p[sk + i] : 0.f;
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + 2 * (kq + 4 * i);
+            const float* p = P + (int64_t)k * sk + o;
+            r.v[2 * i + 0] = (o < OUT && k < KEND) ? p[0] : 0.f;
+            r.v[2 * i + 1] = (o < OUT && k + 1 < KEND) ? p[sk] : 0.f;
         }
     }
 }
@@ -333,14 +320,12 @@ __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r
             if (PL == 3) *reinterpret_cast<uint2*>(d + 2 * SP_PLANE) = make_uint2(a3, b3);
         }
     } else {
-        const int lane = tid & 63, w = tid >> 6;
-        const int o = 4 * ((w & 3) * 8 + sp_oc_group(lane));
-        const int k = 2 * ((w >> 2) * 8 + sp_oc_kpair(lane));
+        const int o = tid & 127, kq = tid >> 7;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             unsigned p1, p2, p3;
-            split3(r.v[i], r.v[4 + i], p1, p2, p3);               // (k, k+1) packed into one dword
-            __bf16* d = S + (o + i) * SP_LD + k;
+            split3(r.v[2 * i], r.v[2 * i + 1], p1, p2, p3);       // (k, k+1) packed into one dword
+            __bf16* d = S + o * SP_LD + 2 * (kq + 4 * i);
             *reinterpret_cast<unsigned*>(d) = p1;
             if (PL >= 2) *reinterpret_cast<unsigned*>(d + SP_PLANE) = p2;
             if (PL == 3) *reinterpret_cast<unsigned*>(d + 2 * SP_PLANE) = p3;

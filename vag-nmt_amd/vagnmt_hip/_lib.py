@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)                       # .../vag-nmt_amd
 CSRC = os.path.join(PKG_ROOT, "csrc")
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libvagnmt.so")
+LIB_PATH = os.environ.get("VAG_LIB") or os.path.join(PKG_ROOT, "lib", "libvagnmt.so")      # VAG_LIB: A/B builds of the library
 
 P = C.c_void_p
 I64 = C.c_int64
