@@ -9,8 +9,14 @@ idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('adam_kernel
 # one adam_kernel launch per step (or two in older builds): take the span between the last two "step ends"
 per = 2 if len(idx) >= 4 and idx[1] - idx[0] < 5 else 1
 ends = idx[per - 1::per]
-a, b = ends[-3], ends[-2]
-step = rows[a + 1:b + 1]
+# the cleanest of the last steps (a profiled run now and then has a step with a stall in it): smallest span
+best = None
+for j in range(max(1, len(ends) - 20), len(ends) - 1):
+    cand = rows[ends[j - 1] + 1:ends[j] + 1]
+    span = max(int(r['End_Timestamp']) for r in cand) - int(cand[0]['Start_Timestamp'])
+    if best is None or span < best[0]:
+        best = (span, cand)
+step = best[1]
 t0 = int(step[0]['Start_Timestamp'])
 prev_end = t0
 agg = collections.OrderedDict()
