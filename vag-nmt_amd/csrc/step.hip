@@ -174,6 +174,9 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
         chunk = 0;                 // the operators' own chunking is not used on this path
     }
     const int nch = ov ? (int)bound.size() - 1 : 0;
+    // VAG_OVERLAP_FWD=0: only the backward half of the schedule (decoder parameter gradients beside the backward recurrence);
+    // the forward recurrence and the head run as in the single-stream step
+    const bool ov_fwd = ov && !(getenv("VAG_OVERLAP_FWD") && atoi(getenv("VAG_OVERLAP_FWD")) == 0);
     DerivedScope scope(derived, c.storage == 1, chunk);
     // forward and backward in one call: the chunked head finishes each chunk (d(logits) and its products) in the forward;
     // a backward called on its own (phases = 2 after an earlier phases = 1) recomputes the chunks instead
@@ -219,7 +222,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
         }
         VAG_TRY(vag_dec_init_fwd(k.enc, k.mask, mm ? k.ctx : nullptr, mm ? c.init_split : 0.f, w.ini_w, w.ini_b, B, Ts, C, H,
                                  k.xmix, h0, stream));                                                  // V11.py:118
-        if (ov) {
+        if (ov_fwd) {
             VAG_TRY(vag_attn_keys_proj(k.enc, w.attn_e, B * Ts, C, k.pe, stream));                      // NMT_Decoder.py:47
             VagLoopHooks hk;
             hk.chain = sa == s ? nullptr : sa;
@@ -256,25 +259,31 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
                                                  c.ldl, stream));                                       // V11.py:138-160
             VAG_TRY(outer.end(s));
         }
-        if (tr && !ov) vag_sched_trace(s, "main: fwd joined");
-        if (!ov)
+        if (tr && !ov_fwd) vag_sched_trace(s, "main: fwd joined");
+        if (!ov_fwd)
         VAG_TRY(vag_head_ce_seq_fwd_impl(h2_all, k.c_all, k.e_all, w.head, tgt, vocab_weight, B, Tt, Et, H, V, c.p_out, crng,
                                          c.free_run ? 1 : 0, k.tmid, k.logits, c.ldl, k.lse, k.nll, k.inv_cnt, 1, nullptr,
                                          losses, w_mt, w_vse, has_vse ? 1 : 0, s));                     // V11.py:140,164-166
     }
     if ((phases & 2) && ov) {
         // the head's parameter gradients (all chunks in one pass over the rows) once the last chunk's data gradients are out
-        if (defer) VAG_TRY(vag_head_chunk_weights(hc, 0, Tt, sb));
-        vag_sched_trace(sb, "side: head weights done");
-        vag_sched_trace(s, "main: fwd joined");
-        VAG_TRY(vag_sched_wait(s, ev_data[nch - 1]));
+        if (ov_fwd) {
+            if (defer) VAG_TRY(vag_head_chunk_weights(hc, 0, Tt, sb));
+            vag_sched_trace(sb, "side: head weights done");
+            vag_sched_trace(s, "main: fwd joined");
+            VAG_TRY(vag_sched_wait(s, ev_data[nch - 1]));
+        } else {
+            VAG_TRY(vag_head_ce_seq_bwd(h2_all, k.c_all, k.e_all, w.head, tgt, vocab_weight, B, Tt, Et, H, V, c.p_out, crng, k.tmid,
+                                        k.logits, c.ldl, k.lse, k.inv_cnt, k.consts + 0, k.d_h2, k.d_c, k.d_e, g.head,
+                                        k.scr_head, stream));
+        }
         vag_sched_trace(s, "main: last head chunk arrived, bwd starts");
         VagLoopHooks hk;
         hk.chain = sa == s ? nullptr : sa;
-        hk.skip_bulk = true;
+        hk.skip_bulk = ov_fwd;
         hk.before = [&](int64_t t) -> int {           // entering an earlier chunk: its head gradients (long since done)
             const int i = chunk_of_top(t);
-            return (i >= 0 && i < nch - 1) ? vag_sched_wait(sa, ev_data[i]) : VAG_OK;
+            return (ov_fwd && i >= 0 && i < nch - 1) ? vag_sched_wait(sa, ev_data[i]) : VAG_OK;
         };
         hk.after = [&](int64_t t) -> int {            // the recurrence has left a chunk: the decoder's parameter gradients of its rows
             const int i = chunk_of_bottom(t);
@@ -350,7 +359,8 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
         vag_sched_trace(s, "main: all phases enqueued");
         vag_sched_trace(sb, "side: done");
         VAG_TRY(vag_sched_order(sb, s));              // every gradient of this call is final behind this point of the caller's stream
-        VAG_TRY(vag_loss_mt_mix_launch(k.nll, k.inv_cnt, B, Tt, losses, w_mt, w_vse, has_vse ? 1 : 0, s));      // V11.py:164-166
+        if (ov_fwd)
+            VAG_TRY(vag_loss_mt_mix_launch(k.nll, k.inv_cnt, B, Tt, losses, w_mt, w_vse, has_vse ? 1 : 0, s));  // V11.py:164-166
         vag_sched_trace(s, "step end");
         vag_sched_trace_dump();
     }
