@@ -514,10 +514,19 @@ static int head_step(const float* h2, const float* c, const float* e, const vag_
                      int64_t V, float p_out, const uint64_t* rng, int64_t drop_idx0, float* tmp, float* tmid,
                      float* logits, int64_t ldl, hipStream_t s) {
     const int64_t C = 2 * H;
-    VAG_TRY(vag_skinny_launch(N, E, H, h2, H, w.w1, H, w.b1, nullptr, 0, tmp, E, 0, s));
-    VAG_TRY(vag_skinny_launch(N, E, C, c, C, w.w2, C, w.b2, tmp, E, tmp, E, 0, s));
-    VAG_TRY(vag_skinny_launch(N, E, E, e, E, w.w3, E, w.b3, tmp, E, tmid, E, VAG_ACT_TANH, s));
-    VAG_TRY(vag_dropout_apply_launch(tmid, N * E, drop_idx0, rng, VAG_DROP_DEC_OUT, p_out, s));
+    if (N <= 256 && aligned16(h2) && aligned16(c) && aligned16(e) && aligned16(w.w1) && aligned16(w.w2) && aligned16(w.w3)) {
+        // one launch: the three products, the biases, tanh and the dropout multiplier (round 2; was four launches)
+        const float* A3[3] = {h2, c, e};
+        const float* W3[3] = {w.w1, w.w2, w.w3};
+        const float* B3[3] = {w.b1, w.b2, w.b3};
+        const int64_t ld3[3] = {H, C, E}, K3[3] = {H, C, E};
+        VAG_TRY(vag_skinny3_launch(N, E, A3, ld3, W3, ld3, K3, B3, tmid, E, VAG_ACT_TANH, rng, VAG_DROP_DEC_OUT, p_out, drop_idx0, s));
+    } else {
+        VAG_TRY(vag_skinny_launch(N, E, H, h2, H, w.w1, H, w.b1, nullptr, 0, tmp, E, 0, s));
+        VAG_TRY(vag_skinny_launch(N, E, C, c, C, w.w2, C, w.b2, tmp, E, tmp, E, 0, s));
+        VAG_TRY(vag_skinny_launch(N, E, E, e, E, w.w3, E, w.b3, tmp, E, tmid, E, VAG_ACT_TANH, s));
+        VAG_TRY(vag_dropout_apply_launch(tmid, N * E, drop_idx0, rng, VAG_DROP_DEC_OUT, p_out, s));
+    }
     VAG_TRY(linear_fwd(N, V, E, tmid, E, w.out_w, w.out_b, 0, logits, ldl, s));
     return VAG_OK;
 }

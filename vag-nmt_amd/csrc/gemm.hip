@@ -949,6 +949,89 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_plain_kernel(SkinnyArgs a) 
     skinny_plain_body<WAVES, 4, WH>(a, red, blockIdx.x, blockIdx.y);
 }
 
+// out (M,N) = act(A1 W1^T + A2 W2^T + A3 W3^T + b1 + b2 + b3) [* dropout]: the pre-activation of the output head for one
+// decoding step (NMT_Decoder.py:137-141) in ONE launch instead of three products and a dropout pass.  16x16 tile per
+// workgroup; every wave takes its share of each segment's K and keeps accumulating in registers, one reduction at the end.
+struct Skinny3Args {
+    const float* A[3]; const float* W[3]; const float* bias[3];
+    int64_t lda[3], ldw[3];
+    int K[3];
+    int M, N;
+    float* out; int64_t ldo; int act;
+    const uint64_t* rng; int sid; float p; int64_t drop_idx0;      // dropout multiplier of element (m,n): index drop_idx0 + m*N + n
+};
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void skinny3_kernel(Skinny3Args a) {
+    __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = skinny_ldrow(lane), g = skinny_ldseg(lane);
+    const int m0 = blockIdx.y * 16, nb = blockIdx.x * 16;
+    const int erow = (threadIdx.x >> 4) & 15, ecol = threadIdx.x & 15;
+    const int em = m0 + erow, ej = nb + ecol;
+    const bool eok = threadIdx.x < 256 && em < a.M && ej < a.N;
+    float pre = 0.f;
+    if (eok) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (a.bias[q]) pre += a.bias[q][ej];
+    }
+    const int src4 = 4 * (16 * (lane & 3) + (lane & 12) + (lane >> 4));
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int K = a.K[q];
+        if (K <= 0) continue;
+        const float* ap = a.A[q] + (int64_t)min(m0 + r, a.M - 1) * a.lda[q] + 4 * g;
+        const float* wp = a.W[q] + (int64_t)min(nb + r, a.N - 1) * a.ldw[q] + 4 * g;
+        const int kper = ((K + WAVES - 1) / WAVES + 15) & ~15;
+        const int kbeg = wave * kper, kend = min(K, kbeg + kper);
+        constexpr int U = 4;
+        for (int c0 = kbeg; c0 < kend; c0 += 16 * U) {
+            float4 av[U], wv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = c0 + 16 * u + 4 * g < kend;
+                av[u] = ok ? *reinterpret_cast<const float4*>(ap + c0 + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+                wv[u] = ok ? *reinterpret_cast<const float4*>(wp + c0 + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { av[u] = skinny_xpose(av[u], src4); wv[u] = skinny_xpose(wv[u], src4); }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, wv[u].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, wv[u].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, wv[u].z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, wv[u].w, acc1, 0, 0, 0);
+            }
+        }
+    }
+    *reinterpret_cast<f32x4*>(&red[(wave * 64 + lane) * 4]) = acc0 + acc1;
+    __syncthreads();
+    if (!eok) return;
+    float v = skinny_sum1<WAVES, 1>(red, 0, erow, ecol) + pre;
+    if (a.act == VAG_ACT_TANH) v = vag_tanh(v);
+    if (a.rng && a.p > 0.f) v *= vag_drop_mul(a.rng, a.sid, (uint64_t)(a.drop_idx0 + (int64_t)em * a.N + ej), a.p);
+    a.out[(int64_t)em * a.ldo + ej] = v;
+}
+static bool skinny_ok(const float* A, int64_t lda, const float* W, int64_t ldw, int64_t K);
+// Three-segment product; every (A_q, W_q, K_q) must satisfy the skinny alignment rules, M <= 256.
+int vag_skinny3_launch(int64_t M, int64_t N, const float* const* A, const int64_t* lda, const float* const* W, const int64_t* ldw,
+                       const int64_t* K, const float* const* bias, float* out, int64_t ldo, int act, const uint64_t* rng, int sid,
+                       float p, int64_t drop_idx0, hipStream_t stream) {
+    VAG_CHECK_ARG(M > 0 && M <= 256 && N > 0 && out);
+    Skinny3Args a;
+    for (int q = 0; q < 3; ++q) {
+        VAG_CHECK_ARG(A[q] && W[q] && skinny_ok(A[q], lda[q], W[q], ldw[q], K[q]));
+        a.A[q] = A[q]; a.W[q] = W[q]; a.bias[q] = bias[q]; a.lda[q] = lda[q]; a.ldw[q] = ldw[q]; a.K[q] = (int)K[q];
+    }
+    a.M = (int)M; a.N = (int)N; a.out = out; a.ldo = ldo; a.act = act;
+    a.rng = rng; a.sid = sid; a.p = p; a.drop_idx0 = drop_idx0;
+    const dim3 grid((unsigned)cdiv64(N, 16), (unsigned)cdiv64(M, 16));
+    hipLaunchKernelGGL(skinny3_kernel<8>, grid, dim3(512), 0, stream, a);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
 // Horizontal fusion for the decoder steps: an attention dot-product pass (a streaming dot per (row, position), latency
 // bound, most CUs half idle) and an INDEPENDENT skinny product in one grid.  Backward: the hidden-side part dgh2 W_hh2
 // (+ carry) of the next launch's dh1 = [dq | dgh2] [attn_h; W_hh2] -- its operand is known one launch earlier than dq, so
