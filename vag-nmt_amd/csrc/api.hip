@@ -639,9 +639,15 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
     if (hoist) return vag_attn_wsum_launch(1, k.alpha, enc, B, Ts, Tt, C, c_all, s);                       // all contexts :126
     for (int64_t t = 0; t < Tt; ++t) {
         if (free_run) {
-            VAG_TRY(vag_embed_gather_launch(tok + t * B, B, 1, 1, B, w.emb, E, e_all + t * B * E, nullptr, 0, 0.f, s));
-            VAG_TRY(vag_skinny_launch(B, 3 * H, E, e_all + t * B * E, E, w.gru1.w_ih, E, w.gru1.b_ih, nullptr, 0,
-                                      k.xp1 + t * B * 3 * H, 3 * H, 0, s));
+            if (B <= 256 && aligned16(w.emb) && aligned16(w.gru1.w_ih) && aligned16(e_all)) {
+                // embedding lookup + input projection of gru_1 in one launch
+                VAG_TRY(vag_skinny_gather_launch(B, 3 * H, E, w.emb, E, tok + t * B, w.gru1.w_ih, E, w.gru1.b_ih,
+                                                 k.xp1 + t * B * 3 * H, 3 * H, e_all + t * B * E, E, s));
+            } else {
+                VAG_TRY(vag_embed_gather_launch(tok + t * B, B, 1, 1, B, w.emb, E, e_all + t * B * E, nullptr, 0, 0.f, s));
+                VAG_TRY(vag_skinny_launch(B, 3 * H, E, e_all + t * B * E, E, w.gru1.w_ih, E, w.gru1.b_ih, nullptr, 0,
+                                          k.xp1 + t * B * 3 * H, 3 * H, 0, s));
+            }
         }
         StepBufs b;
         b.xp1 = k.xp1 + t * B * 3 * H;
@@ -896,8 +902,12 @@ int vag_cgru_attn_decode_step(const float* enc, const float* pe, const float* ma
     float* h1 = q; q += N * H;
     float* qhp = q; q += N * Q;
     float* scores = q;
-    VAG_TRY(vag_embed_gather_launch(tok, 1, 0, N, 1, w.emb, E, e, nullptr, 0, 0.f, s));                   // :118
-    VAG_TRY(linear_fwd(N, 3 * H, E, e, E, w.gru1.w_ih, w.gru1.b_ih, 0, xp1, 3 * H, s));
+    if (N <= 256 && aligned16(w.emb) && aligned16(w.gru1.w_ih) && aligned16(e)) {                          // :118, one launch
+        VAG_TRY(vag_skinny_gather_launch(N, 3 * H, E, w.emb, E, tok, w.gru1.w_ih, E, w.gru1.b_ih, xp1, 3 * H, e, E, s));
+    } else {
+        VAG_TRY(vag_embed_gather_launch(tok, 1, 0, N, 1, w.emb, E, e, nullptr, 0, 0.f, s));
+        VAG_TRY(linear_fwd(N, 3 * H, E, e, E, w.gru1.w_ih, w.gru1.b_ih, 0, xp1, 3 * H, s));
+    }
     StepBufs b;
     b.xp1 = xp1; b.hprev = h_in; b.h1 = h1; b.g1 = nullptr; b.g2 = nullptr; b.qhp = qhp; b.scores = scores;
     b.alpha = alpha; b.c = c; b.h2 = h_out;

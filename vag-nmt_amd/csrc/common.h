@@ -109,6 +109,9 @@ int vag_attn_qscore_side_launch(const float* x, const float* v, int64_t Ts, cons
                                 const float* Wq, int64_t ldwq, int64_t Nq, float* qout, int64_t ldq, float* spart,
                                 const float* Wt, int64_t ldwt, int64_t Np, const float* pbias, float* P, int64_t ldp,
                                 hipStream_t stream, bool s16 = false);
+int vag_skinny_gather_launch(int64_t M, int64_t N, int64_t K, const float* table, int64_t ldt, const int64_t* idx, const float* W,
+                             int64_t ldw, const float* bias, float* out, int64_t ldo, float* gathered, int64_t ldg,
+                             hipStream_t stream);
 int vag_skinny3_launch(int64_t M, int64_t N, const float* const* A, const int64_t* lda, const float* const* W, const int64_t* ldw,
                        const int64_t* K, const float* const* bias, float* out, int64_t ldo, int act, const uint64_t* rng, int sid,
                        float p, int64_t drop_idx0, hipStream_t stream);

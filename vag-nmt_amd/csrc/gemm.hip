@@ -711,6 +711,9 @@ struct SkinnyArgs {
     int M, N, K;
     const float* bias; const float* addend; int64_t ldadd; float* out; int64_t ldo; int act;
     int64_t bsA = 0, bsW = 0, bsO = 0;     // batched launches (blockIdx.z): element strides of A, W and out/addend
+    // A rows taken through an index (A = embedding table, row m = A[row_idx[m]]); the column-tile-0 workgroups also write
+    // the gathered rows out (the embedded inputs are needed again by the head and by the backward pass)
+    const int64_t* row_idx = nullptr; float* gather_out = nullptr; int64_t ld_gather = 0;
 };
 
 // Load pattern.  The MFMA wants lane l to hold row l&15, k-group l>>4, but a wave request whose lane QUADS each touch
@@ -930,8 +933,18 @@ __device__ __forceinline__ void skinny_plain_body(const SkinnyArgs& a, float* re
     }
     const float* ap[1];
     const float* wp[1];
-    ap[0] = a.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + skinny_koff<WH>(g);
+    const int64_t arow = a.row_idx ? a.row_idx[min(m0 + r, a.M - 1)] : (int64_t)min(m0 + r, a.M - 1);
+    ap[0] = a.A + arow * a.lda + skinny_koff<WH>(g);
     wp[0] = skinny_wptr<WH>(a.W, min(nb + r, a.N - 1), a.ldw, skinny_koff<WH>(g));
+    if (a.gather_out && bx == 0) {
+        const int k4 = a.K >> 2;
+        for (int i = threadIdx.x; i < 16 * k4; i += WAVES * 64) {
+            const int row = i / k4, c4 = i - row * k4;
+            if (m0 + row < a.M)
+                reinterpret_cast<float4*>(a.gather_out + (int64_t)(m0 + row) * a.ld_gather)[c4] =
+                    reinterpret_cast<const float4*>(a.A + a.row_idx[m0 + row] * a.lda)[c4];
+        }
+    }
     skinny_mma_any<WAVES, 1, 1, U, WH>(ap, wp, a.K, red);
     if (!eok) return;
     float v = skinny_sum1<WAVES, 1>(red, 0, erow, ecol) + pre;
@@ -1496,6 +1509,22 @@ static void skinny_plain_go(const SkinnyArgs& a, hipStream_t stream, bool w16 = 
     if (a.K <= 256) hipLaunchKernelGGL((skinny_plain_kernel<4>), grid, dim3(256), 0, stream, a);
     else if (a.K <= 1024) hipLaunchKernelGGL((skinny_plain_kernel<8>), grid, dim3(512), 0, stream, a);
     else hipLaunchKernelGGL((skinny_plain_kernel<16>), grid, dim3(1024), 0, stream, a);
+}
+
+// out (M,N) = table[idx[m], :] W^T + bias, and gathered (M,K) = table[idx[m], :]: embedding lookup and input projection of one
+// decoding step in one launch.  M <= 256, K % 4 == 0.
+int vag_skinny_gather_launch(int64_t M, int64_t N, int64_t K, const float* table, int64_t ldt, const int64_t* idx, const float* W,
+                             int64_t ldw, const float* bias, float* out, int64_t ldo, float* gathered, int64_t ldg,
+                             hipStream_t stream) {
+    VAG_CHECK_ARG(M > 0 && M <= 256 && N > 0 && table && idx && W && out && gathered && skinny_ok(table, ldt, W, ldw, K) &&
+                  aligned16(gathered) && ldg % 4 == 0);
+    SkinnyArgs a;
+    a.A = table; a.W = W; a.lda = ldt; a.ldw = ldw; a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.bias = bias; a.addend = nullptr; a.ldadd = 0; a.out = out; a.ldo = ldo; a.act = VAG_ACT_NONE;
+    a.row_idx = idx; a.gather_out = gathered; a.ld_gather = ldg;
+    skinny_plain_go(a, stream);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
 }
 
 int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
