@@ -255,10 +255,22 @@ __device__ __forceinline__ void split3(float a, float b, unsigned& p1, unsigned&
 }
 
 // global -> registers (8 floats per thread per operand tile).
-// KC (k contiguous): two float4 = (row, 4 consecutive k) items.  OC (outer contiguous): lanes run along the
-// contiguous outer dimension with one float each (256-B rows per wave load), four (k, k+1) pairs per thread, so that
-// the LDS scatter below writes whole dwords (2-way bank conflicts).
+// KC (k contiguous): two float4 = (row, 4 consecutive k) items.  OC (outer contiguous): two float4 = (k row, 4 consecutive
+// outer) items, stored as they come into the [k][outer] image (sp_oc_off) and transposed by the fragment reads.
 struct SpRegs { float v[8]; };
+// ---- outer-contiguous operands (round 2): LDS image [k][outer], 32 rows of 128 bf16 (256 B), filled with 8-byte stores of
+// four consecutive outer elements and read back TRANSPOSED by gfx950's ds_read_b64_tr_b16 (a 16-lane group fetches a
+// 4 (k) x 16 (outer) block and each lane receives one outer column's four k values): the MFMA operand's eight consecutive
+// k of one row are two such reads.  Before: eight scalar global loads per thread and operand and twelve 4-byte LDS
+// stores scattering (k, k+1) pairs into an [outer][k] image.  16-byte chunks of a row are XOR-swizzled with the row
+// (cdna_hip_programming.md T10 image (b)): without it the four rows of a transposed read hit the same banks.
+// Element offset of columns col..col+3 (col % 4 == 0) of row `row` inside a plane:
+__device__ __forceinline__ int sp_oc_off(int row, int col) {
+    const int ch = col >> 3;
+    return (256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 8 * ((col >> 2) & 1)) >> 1;
+}
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+typedef bf16x4v __attribute__((address_space(3))) lds_bf16x4v;
 // k-contiguous operands: the four rows a 32-lane group writes to LDS with one 8-byte store per lane are 8 apart, not
 // consecutive: with the 72-byte row stride rows r and r+2 share banks, rows r, r+8, r+16, r+24 tile the 32 banks exactly
 // twice (PMC had 20 % of the LDS-active cycles as bank conflicts).
@@ -288,16 +300,25 @@ __device__ __forceinline__ void sp_load(const float* __restrict__ P, int64_t so,
             r.v[4 * i + 0] = v.x; r.v[4 * i + 1] = v.y; r.v[4 * i + 2] = v.z; r.v[4 * i + 3] = v.w;
         }
     } else {
-        // lanes run along the contiguous outer dimension with one float each (256-byte rows per wave load), four (k, k+1)
-        // pairs per thread.  (Round 2 tried two float4 along the outer dimension at k and k+1 instead of the eight scalars:
-        // +9 % at 4096^3, but 3-13 % SLOWER at the model's split-K weight-gradient shapes -- tools/exp_gemm_tn.py.)
-        const int o = o0 + (tid & 127), kq = tid >> 7;
+        // two float4 along the outer dimension per thread: item idx -> k row idx>>5, outer group (idx&31)*4; a wave reads two
+        // 512-byte row segments per instruction.  r.v[4i..4i+3] = the four outer elements of item i.
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = k0 + 2 * (kq + 4 * i);
-            const float* p = P + (int64_t)k * sk + o;
-            r.v[2 * i + 0] = (o < OUT && k < KEND) ? p[0] : 0.f;
-            r.v[2 * i + 1] = (o < OUT && k + 1 < KEND) ? p[sk] : 0.f;
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 512;
+            const int k = k0 + (idx >> 5), o = o0 + ((idx & 31) << 2);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < KEND) {
+                const float* p = P + (int64_t)k * sk + o;
+                if (VEC && o + 3 < OUT) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (o + 0 < OUT) v.x = p[0];
+                    if (o + 1 < OUT) v.y = p[1];
+                    if (o + 2 < OUT) v.z = p[2];
+                    if (o + 3 < OUT) v.w = p[3];
+                }
+            }
+            r.v[4 * i + 0] = v.x; r.v[4 * i + 1] = v.y; r.v[4 * i + 2] = v.z; r.v[4 * i + 3] = v.w;
         }
     }
 }
@@ -320,15 +341,16 @@ __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r
             if (PL == 3) *reinterpret_cast<uint2*>(d + 2 * SP_PLANE) = make_uint2(a3, b3);
         }
     } else {
-        const int o = tid & 127, kq = tid >> 7;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned p1, p2, p3;
-            split3(r.v[2 * i], r.v[2 * i + 1], p1, p2, p3);       // (k, k+1) packed into one dword
-            __bf16* d = S + o * SP_LD + 2 * (kq + 4 * i);
-            *reinterpret_cast<unsigned*>(d) = p1;
-            if (PL >= 2) *reinterpret_cast<unsigned*>(d + SP_PLANE) = p2;
-            if (PL == 3) *reinterpret_cast<unsigned*>(d + 2 * SP_PLANE) = p3;
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 512;
+            unsigned a1, a2, a3, b1, b2, b3;
+            split3(r.v[4 * i + 0], r.v[4 * i + 1], a1, a2, a3);
+            split3(r.v[4 * i + 2], r.v[4 * i + 3], b1, b2, b3);
+            __bf16* d = S + sp_oc_off(idx >> 5, (idx & 31) << 2);
+            *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
+            if (PL >= 2) *reinterpret_cast<uint2*>(d + SP_PLANE) = make_uint2(a2, b2);
+            if (PL == 3) *reinterpret_cast<uint2*>(d + 2 * SP_PLANE) = make_uint2(a3, b3);
         }
     }
 }
@@ -344,17 +366,28 @@ __device__ __forceinline__ bf16x8 sp_frag(const __bf16* p) {      // 8 consecuti
 // One k-tile of MFMA work from the LDS planes: 2 k-steps of 16; PL = 3: six bf16 products (fp32-grade), PL = 2: three
 // (x = x1 + x2 exactly to 16 significand bits: the 2-byte storage mode, whose operands carry no more than that), PL = 1:
 // plain bf16 operands, one product (2-byte mode, the two vocabulary-sized gradient products of the head only).
-template <int PL>
-__device__ __forceinline__ void sp_compute(const __bf16* Af, const __bf16* Bf, f32x16 (&acc)[2]) {
+// fragment of an outer-contiguous operand: rows (outer) ob + (lane & 31), k = ks*16 + 8*(lane >> 5) .. + 7
+__device__ __forceinline__ bf16x8 sp_frag_tr(const __bf16* plane, int ob, int ks) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+    const int col = ob + 16 * (g & 1) + 4 * pp, kb = ks * 16 + 8 * (g >> 1);
+    const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4v*)(plane + sp_oc_off(kb + q, col)));
+    const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4v*)(plane + sp_oc_off(kb + 4 + q, col)));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// Af / Bf: fragment base of a k-contiguous operand; As / Bs + (oa, obn): plane base and first outer index of this wave's
+// rows for an outer-contiguous one.
+template <int PL, bool AKC, bool BKC>
+__device__ __forceinline__ void sp_compute(const __bf16* Af, const __bf16* Bf, const __bf16* As, const __bf16* Bs, int oa, int obn,
+                                           f32x16 (&acc)[2]) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         bf16x8 af[2][PL], bf[PL];
 #pragma unroll
         for (int p = 0; p < PL; ++p) {
-            bf[p] = sp_frag(Bf + p * SP_PLANE + ks * 16);
+            bf[p] = BKC ? sp_frag(Bf + p * SP_PLANE + ks * 16) : sp_frag_tr(Bs + p * SP_PLANE, obn, ks);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                af[i][p] = sp_frag(Af + p * SP_PLANE + i * 32 * SP_LD + ks * 16);
+                af[i][p] = AKC ? sp_frag(Af + p * SP_PLANE + i * 32 * SP_LD + ks * 16) : sp_frag_tr(As + p * SP_PLANE, oa + 32 * i, ks);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -404,7 +437,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
             sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, k0 + SP_BK, a.M, kend, ra);
             sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, k0 + SP_BK, a.N, kend, rb);
         }
-        sp_compute<PL>(Af, Bf, acc);
+        sp_compute<PL, AKC, BKC>(Af, Bf, As, Bs, wm * 64, wn * 32, acc);
         __syncthreads();
     }
 
