@@ -232,8 +232,10 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int SP_BK = 32;
-constexpr int SP_LD = SP_BK + 4;            // bf16 elements per LDS row: 72 B = 18 dwords.  Fragments are read as two
-                                            // ds_read_b64 (conflict-free over 32 rows); k-pair dword writes are 2-way at most
+constexpr int SP_LD = SP_BK + 8;            // bf16 elements per LDS row of a k-contiguous operand: 80 B = 20 dwords, 16-byte aligned:
+                                            // a fragment (8 consecutive k) is ONE ds_read_b128, and 16 consecutive rows tile the 64
+                                            // banks exactly once (20 r mod 64 are 16 distinct multiples of 4).  (72-byte rows made the
+                                            // compiler pair the two 8-byte halves into ds_read2_b64, which is banked over 32.)
 constexpr int SP_PLANE = 128 * SP_LD;       // bf16 elements per plane
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -271,10 +273,10 @@ __device__ __forceinline__ int sp_oc_off(int row, int col) {
 }
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 typedef bf16x4v __attribute__((address_space(3))) lds_bf16x4v;
-// k-contiguous operands: the four rows a 32-lane group writes to LDS with one 8-byte store per lane are 8 apart, not
-// consecutive: with the 72-byte row stride rows r and r+2 share banks, rows r, r+8, r+16, r+24 tile the 32 banks exactly
-// twice (PMC had 20 % of the LDS-active cycles as bank conflicts).
-__device__ __forceinline__ int sp_row(int q) { return (q & ~31) | ((q & 3) << 3) | ((q >> 2) & 7); }
+// k-contiguous operands: the four rows a 32-lane group writes to LDS with one 8-byte store per lane are 4 apart, not
+// consecutive: with the 80-byte row stride rows r, r+4, r+8, r+12 start at banks 0, 16, 0, 16 (mod 32) and tile the 32 banks
+// exactly twice (consecutive rows: PMC had 20 % of the LDS-active cycles as bank conflicts).
+__device__ __forceinline__ int sp_row(int q) { return (q & ~15) | ((q & 3) << 2) | ((q >> 2) & 3); }
 
 template <bool KC, bool VEC>
 __device__ __forceinline__ void sp_load(const float* __restrict__ P, int64_t so, int64_t sk, int o0, int k0, int OUT,
@@ -356,10 +358,9 @@ __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 sp_frag(const __bf16* p) {      // 8 consecutive k of one row, as two 8-byte LDS reads
-    const uint2 lo = *reinterpret_cast<const uint2*>(p);
-    const uint2 hi = *reinterpret_cast<const uint2*>(p + 4);
-    const u32x4 q = {lo.x, lo.y, hi.x, hi.y};
+__device__ __forceinline__ bf16x8 sp_frag(const __bf16* p) {      // 8 consecutive k of one row: one 16-byte LDS read
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    const u32x4 q = {v.x, v.y, v.z, v.w};
     return __builtin_bit_cast(bf16x8, q);
 }
 
