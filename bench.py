@@ -227,12 +227,14 @@ def measure_dense(c, dev):
     rows = []
 
     def gemm(name, M, N, K, a_kc, b_kc, beta):
-        A = torch.randn((M, K) if a_kc else (K, M), device=dev)
-        Bm = torch.randn((N, K) if b_kc else (K, N), device=dev)
+        # outer-contiguous operands with the row stride the step gives them (d logits: ldl = ceil4(V))
+        lda, ldb = (M + 3) // 4 * 4, (N + 3) // 4 * 4
+        A = torch.randn((M, K) if a_kc else (K, lda), device=dev)
+        Bm = torch.randn((N, K) if b_kc else (K, ldb), device=dev)
         ldc = (N + 3) // 4 * 4
         C = torch.zeros(M, ldc, device=dev)
-        sa = (K, 1) if a_kc else (1, M)
-        sb = (1, K) if b_kc else (N, 1)
+        sa = (K, 1) if a_kc else (1, lda)
+        sb = (1, K) if b_kc else (ldb, 1)
         t = _time_graph(lambda: L.call("vag_gemm_f32", M, N, K, 1.0, L.ptr(A), sa[0], sa[1], L.ptr(Bm), sb[0], sb[1],
                                        float(beta), L.ptr(C), ldc, None, 0, L.stream()), reps=10)
         rows.append({"product": name, "M": M, "N": N, "K": K, "us": t * 1e6, "tflops": 2.0 * M * N * K / t / 1e12})
