@@ -329,8 +329,7 @@ def measure_extras(c, dev, ts, args):
                     "mean_hyp_len": sum(len(h) for h in hyp) / 16.0,
                     "note": "beam search stops once every hypothesis has emitted EOS (V11.py:266-269)"}
     m4.train(was)
-    # the overlapped schedule (CU-masked streams, eager) and configs[4] in its 2-byte storage mode, each on a driver of its
-    # own; a failure here must not take the headline line down
+    # configs[4] in its 2-byte storage mode on a driver of its own; a failure here must not take the headline line down
     from vagnmt_hip.trainer import TrainStep
     from machine_translation_vision.losses import PairwiseRankingLoss
 
@@ -352,16 +351,6 @@ def measure_extras(c, dev, ts, args):
             t2.step(b2[0], l2, b2[2], b2[3], teacher=True)
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
-    try:
-        with torch.cuda.stream(torch.cuda.Stream()):
-            t2, b2, l2 = fresh(c, overlap=True)
-            ms_ov = timed(t2, b2, l2, 30)
-        out["overlapped_schedule"] = {"ms_per_step": ms_ov, "pairs_per_s": c["B"] / ms_ov * 1e3,
-                                      "note": "recurrences on 160 CUs, head and decoder weight gradients on 96 (CU-masked "
-                                              "streams, eager launches); off by default, DESIGN section 7 item 3"}
-        del t2, b2, l2
-    except Exception as e:       # noqa: BLE001
-        out["overlapped_schedule"] = {"error": repr(e)[:200]}
     if c is CFG2 and not args.no_cfg5_row:
         try:
             torch.cuda.empty_cache()
@@ -406,7 +395,6 @@ def main():
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="debug: disable the reference dropouts")
     ap.add_argument("--no-cfg5-row", action="store_true", help="skip the configs[4] row of the extras")
-    ap.add_argument("--overlap", action="store_true", help="CU-partitioned streams inside the step (eager launches)")
     ap.add_argument("--no-fused", action="store_true", help="debug: per-operator autograd path instead of vag_train_step")
     ap.add_argument("--config", choices=["cfg2", "cfg5", "cfg5-f32"], default="cfg2",
                     help="cfg2 = BASELINE configs[1] (the metric's configuration); cfg5 = configs[4] (H=1024, T=80, B=256, "
@@ -450,7 +438,7 @@ def main():
     crit_vse = PairwiseRankingLoss(margin=0.1)
     ts = TrainStep(model, crit_mt, crit_vse, lr=4e-4, weight_decay=1e-5, clip=1.0, teacher_force_ratio=args.tfr,
                    use_graph=not args.no_graph, process_group=pg, world_size=world, fused=not args.no_fused,
-                   storage="f16" if args.config == "cfg5" else "f32", overlap=args.overlap)
+                   storage="f16" if args.config == "cfg5" else "f32")
     src, lens, tgt, im = make_batch(c, rank, dev, ragged=args.ragged)
     lens_t = torch.tensor(lens, dtype=torch.int32, device=dev)
 

@@ -357,10 +357,6 @@ typedef struct {
                                            * kept as fp16 in HBM; accumulation, master weights, recurrent state, saved gates and
                                            * all gradients stay fp32.  Teacher-forced steps only; needs `derived` built with
                                            * with_fp16 and H % 8 == 0 */
-    int32_t overlap;                      /* 1: teacher-forced calls with phases 1|2 run the recurrences and the dense work beside
-                                           * them on two library-owned streams with disjoint compute-unit masks (forked from and
-                                           * joined to `stream`).  Such a call must NOT be captured into a graph (a captured
-                                           * fork/join is replayed without the masks); needs `derived` */
     float margin, loss_w, init_split, p_emb, p_ctx, p_out;
 } vag_step_cfg;
 /* phases: bit 0 forward (losses[0..2] = loss, loss_mt, loss_vse), bit 1 backward down to the encoder states (final for
@@ -378,6 +374,11 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* w, const vag_mode
  * driver-owned derived buffer they should read instead and the storage mode (vag_step_cfg.storage); vag_train_step does the
  * same for the duration of its call.  derived = NULL, storage = 0 restores the defaults. */
 int vag_set_operator_context(const float* derived, int storage);
+/* Process-wide debug / tuning options by name, for the parity tests and tuning scripts (none is needed in normal use):
+ * "gemm_f32mfma" (1: every product on the exact f32-input MFMA kernels), "gemm_nogroup", "gemm_force_tile" +
+ * "gemm_force_splitk", "gemm_debug", "head_chunk" (rows per chunk of the output head; -1 automatic, 0 never),
+ * "head_fuse", "head_bf16_grads".  Returns VAG_EINVAL for an unknown name. */
+int vag_set_option(const char* name, int64_t value);
 /* Up to four contiguous device byte ranges copied by one launch (src[i] -> dst[i], bytes[i]; host arrays): a batch's
  * src / lengths / tgt / image rows into the step driver's static input buffers. */
 int vag_copy4(const void* const* src, void* const* dst, const int64_t* bytes, int n, vag_stream_t stream);

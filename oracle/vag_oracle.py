@@ -215,11 +215,13 @@ def decoder_init(P, enc, mask, ctx=None, init_split=0.5):
 # --------------------------------------------------------------------------
 def model_forward(P, src, lengths, tgt, im=None, *, teacher=True, vocab_weight=None,
                   loss_w=0.99, init_split=0.5, attn="dot", activation=True,
-                  vse_loss="pairwise", margin=0.1, masks=None, hoist=False, keep=False):
+                  vse_loss="pairwise", margin=0.1, masks=None, hoist=False, keep=False, ckpt=False):
     """Training/validation forward.  ``im is None`` = text-only model (a12).
 
     masks: optional dict of dropout multipliers {'emb' (Ts,B,E), 'ctx' (Ts,B,2H),
     'out' (Tt,B,E)} (already scaled by 1/(1-p)); None = eval mode.
+    ckpt: recompute each decoder step in backward instead of keeping its activations (same values; bounds
+    the memory of the configs[4]-size parity test: a step's (Ts,B,2H) attention tensors are 168 MB there).
     Returns dict(loss, loss_mt, loss_vse, + intermediates if keep).
     """
     masks = masks or {}
@@ -254,7 +256,13 @@ def model_forward(P, src, lengths, tgt, im=None, *, teacher=True, vocab_weight=N
     steps = []
     for di in range(Tt):
         od = masks["out"][di] if "out" in masks else None
-        logp, h, aux = decoder_step(P, tok, h, enc, mask, od, pe=pe)
+        if ckpt and not keep:
+            from torch.utils.checkpoint import checkpoint
+            logp, h = checkpoint(lambda t_, h_, od_=od: decoder_step(P, t_, h_, enc, mask, od_, pe=pe)[:2], tok, h,
+                                 use_reentrant=False)
+            aux = {}
+        else:
+            logp, h, aux = decoder_step(P, tok, h, enc, mask, od, pe=pe)
         tg = tgt[:, di]
         L = L + (-vocab_weight[tg] * logp.gather(1, tg.unsqueeze(1)).squeeze(1))   # NLLLoss(weight, reduce=False)
         if teacher:

@@ -112,8 +112,7 @@ def _rccl_worker(port, q):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     from vagnmt_hip.trainer import TrainStep
     res = {}
-    for name, kw in (("phased", dict(process_group=dist.group.WORLD, force_phased=True)),
-                     ("phased_overlap", dict(process_group=dist.group.WORLD, force_phased=True, overlap=True)), ("single", {})):
+    for name, kw in (("phased", dict(process_group=dist.group.WORLD, force_phased=True)), ("single", {})):
         m = _model(100)
         cm, cv = _criteria()
         ts = TrainStep(m, cm, cv, use_graph=True, **kw)
@@ -140,8 +139,3 @@ def test_phased_sequence_with_rccl_collectives_world1():
     assert sa["captures"] >= 2 and sa["replays"] >= 4, sa
     assert np.allclose(la, lb, rtol=2e-4), (la, lb)
     assert np.allclose(fa, fb, rtol=2e-4, atol=2e-6), np.abs(fa - fb).max()
-    # the same with the overlapped schedule inside the first phase (eager, CU-masked streams) and the encoder phase replayed
-    fo, lo, so = res["phased_overlap"]
-    assert so["eager_steps"] >= 6 and so["replays"] >= 2, so
-    assert np.allclose(lo, lb, rtol=2e-4), (lo, lb)
-    assert np.allclose(fo, fb, rtol=2e-4, atol=2e-6), np.abs(fo - fb).max()

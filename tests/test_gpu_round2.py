@@ -157,15 +157,14 @@ def test_bf16x6_error_is_bounded_by_the_exact_f32_kernel(shape, wide):
     mag = np.abs(A).astype(np.float64) @ np.abs(Bm).astype(np.float64)
     errs = {}
     for mode in ("bf16x6", "f32"):
-        if mode == "f32":
-            os.environ["VAG_GEMM_F32MFMA"] = "1"
+        L.set_option("gemm_f32mfma", 1 if mode == "f32" else 0)
         try:
             Ct = torch.zeros(M, N, device="cuda")
             L.call("vag_gemm_f32", M, N, K, 1.0, L.ptr(At), sam, sak, L.ptr(Bt), sbk, sbn, 0.0, L.ptr(Ct), N, None, 0,
                    L.stream())
             got = Ct.cpu().numpy().astype(np.float64)
         finally:
-            os.environ.pop("VAG_GEMM_F32MFMA", None)
+            L.set_option("gemm_f32mfma", 0)
         errs[mode] = float((np.abs(got - ref) / mag).max())
     # fp32-grade: a few ulp of the magnitude sum, and no worse than twice the f32-input MFMA kernel on the same data
     assert errs["f32"] < 4e-6 and errs["bf16x6"] < 4e-6, errs
@@ -422,18 +421,19 @@ def test_fp16_storage_trains_and_free_running_steps_fall_back_to_fp32_storage():
 @pytest.mark.parametrize("storage", ["f32", "f16"])
 @pytest.mark.parametrize("chunk_steps", [1, 5])           # 5 does not divide Tt = 12: a ragged last chunk
 @pytest.mark.parametrize("mode", ["fused", "recompute", "split_phases"])
-def test_chunked_head_equals_whole_sequence_head(monkeypatch, storage, chunk_steps, mode):
+def test_chunked_head_equals_whole_sequence_head(storage, chunk_steps, mode):
     """fused: forward+backward in one call -- each chunk is finished (d(logits) and its three products) in the forward.
     recompute / split_phases: the backward builds each chunk's logits again (forced by the switch, or because the
     backward is a separate call)."""
     from vagnmt_hip.trainer import TrainStep
+    from vagnmt_hip import _lib as L
     m_of, (src, lens, tgt, im), cm, cv = _fp16_case("mid")
     lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
     B = src.shape[0]
     out = []
     for chunk in (0, chunk_steps * B):
-        monkeypatch.setenv("VAG_HEAD_CHUNK", str(chunk))
-        monkeypatch.setenv("VAG_HEAD_FUSE", "0" if mode == "recompute" else "1")
+        L.set_option("head_chunk", chunk)
+        L.set_option("head_fuse", 0 if mode == "recompute" else 1)
         m = m_of()
         ts = TrainStep(m, cm, cv, use_graph=False, storage=storage, pad_src=1)
         m.train()                                   # dropout on: the recomputation must see the same masks
@@ -443,6 +443,8 @@ def test_chunked_head_equals_whole_sequence_head(monkeypatch, storage, chunk_ste
         else:
             ts.backend.run(src, lt, tgt, im, True, 7)
         out.append(([float(x) for x in ts.backend.outputs()], ts.fp.grad.detach().clone()))
+    L.set_option("head_chunk", -1)
+    L.set_option("head_fuse", 1)
     (l0, g0), (l1, g1) = out
     assert np.allclose(l0, l1, rtol=1e-6, atol=1e-7), (l0, l1)
     # same products on the same operands chunk by chunk; only the summation order of the weight-gradient sums over rows
@@ -450,82 +452,6 @@ def test_chunked_head_equals_whole_sequence_head(monkeypatch, storage, chunk_ste
     scale = g0.abs().max().item()
     assert (g0 - g1).abs().max().item() <= 2e-5 * scale, ((g0 - g1).abs().max().item(), scale)
     assert g0.abs().sum().item() > 0
-
-
-# ------------------------------------------------------------------------------------------------------------------
-# overlapped schedule: recurrences and the dense work beside them on two CU-masked streams
-# ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("storage", ["f32", "f16"])
-@pytest.mark.parametrize("steps", ["1", "5", "8", "5+chunkbuf", "8+tail3"])   # chunk length in time steps (Tt = 12: ragged last chunk / single chunk)
-def test_overlapped_step_equals_single_stream_step(monkeypatch, storage, steps):
-    """+chunkbuf: the large-vocabulary variant of the schedule (one reused logits chunk buffer, each chunk's parameter
-    gradients taken before the next chunk overwrites it); +tail3: a short last chunk."""
-    from vagnmt_hip.trainer import TrainStep
-    m_of, (src, lens, tgt, im), cm, cv = _fp16_case("mid")
-    lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
-    monkeypatch.setenv("VAG_OVERLAP_STEPS", steps.split("+")[0])
-    if steps.endswith("tail3"):
-        monkeypatch.setenv("VAG_OVERLAP_TAIL", "3")
-    out = []
-    for overlap in (False, True):
-        if steps.endswith("chunkbuf"):
-            if overlap:
-                monkeypatch.setenv("VAG_HEAD_CHUNK", str(5 * src.shape[0]))
-            else:
-                monkeypatch.delenv("VAG_HEAD_CHUNK", raising=False)
-        m = m_of()
-        ts = TrainStep(m, cm, cv, use_graph=False, storage=storage, pad_src=1, overlap=overlap)
-        m.train()
-        for _ in range(2):                      # twice: the second call meets the streams of the first
-            ts.fp.grad.zero_()
-            ts.backend.run(src, lt, tgt, im, True, 7)
-        torch.cuda.synchronize()
-        out.append(([float(x) for x in ts.backend.outputs()], ts.fp.grad.detach().clone()))
-    (l0, g0), (l1, g1) = out
-    assert np.allclose(l0, l1, rtol=1e-6, atol=1e-7), (l0, l1)
-    scale = g0.abs().max().item()
-    assert (g0 - g1).abs().max().item() <= 2e-5 * scale, ((g0 - g1).abs().max().item(), scale)
-
-
-def test_overlapped_training_matches_graph_training():
-    """Whole optimiser steps (clip + Adam, derived-weight refresh, teacher-forced and free-running steps mixed): the
-    overlapped eager schedule against the captured single-stream one."""
-    from vagnmt_hip.trainer import TrainStep
-    m_of, (src, lens, tgt, im), cm, cv = _fp16_case("mid")
-    res = []
-    for overlap in (False, True):
-        m = m_of()
-        ts = TrainStep(m, cm, cv, use_graph=True, overlap=overlap)
-        losses = [float(ts.step(src, lens, tgt, im, teacher=(i % 3 != 2))[0]) for i in range(9)]
-        torch.cuda.synchronize()
-        res.append((losses, ts.fp.flat.detach().clone(), dict(ts.stats)))
-    (la, fa, _), (lb, fb, sb) = res
-    assert sb["eager_steps"] >= 6, sb
-    assert np.allclose(la, lb, rtol=2e-4), (la, lb)
-    assert torch.allclose(fa, fb, rtol=2e-3, atol=2e-5), (fa - fb).abs().max().item()
-
-
-def test_three_launch_decoder_step_experiment_keeps_parity(monkeypatch):
-    """VAG_CGRU_QSCORE=1 (scores as per-column-tile partial sums behind the query product): same losses and gradients
-    as the shipped 4-launch step, fp32 and fp16 storage."""
-    from vagnmt_hip.trainer import TrainStep
-    for storage in ("f32", "f16"):
-        m_of, (src, lens, tgt, im), cm, cv = _fp16_case("mid")
-        lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
-        out = []
-        for on in (False, True):
-            if on:
-                monkeypatch.setenv("VAG_CGRU_QSCORE", "1")
-            else:
-                monkeypatch.delenv("VAG_CGRU_QSCORE", raising=False)
-            m = m_of()
-            ts = TrainStep(m, cm, cv, use_graph=False, storage=storage, pad_src=1)
-            m.train()
-            ts.backend.run(src, lt, tgt, im, True, 7)
-            out.append(([float(x) for x in ts.backend.outputs()], ts.fp.grad.detach().clone()))
-        (l0, g0), (l1, g1) = out
-        assert np.allclose(l0, l1, rtol=2e-6, atol=1e-7), (l0, l1)
-        assert (g0 - g1).abs().max().item() <= 2e-5 * g0.abs().max().item()
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -1,8 +1,8 @@
-"""Print every vag_gemm launch of one cfg2 training step (VAG_GEMM_DEBUG) with the cost model's estimate."""
+"""Print every vag_gemm launch of one cfg2 training step (vag_set_option("gemm_debug")) with the cost model's estimate."""
 import os, sys, re, subprocess, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if os.environ.get("VAG_GEMM_DEBUG") != "1":
-    env = dict(os.environ, VAG_GEMM_DEBUG="1")
+if os.environ.get("LIST_GEMMS_CHILD") != "1":
+    env = dict(os.environ, LIST_GEMMS_CHILD="1")
     out = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True).stderr
     lines = [l for l in out.splitlines() if l.startswith("[vag_gemm]")]
     # the second step's launches: split on the marker printed between steps
@@ -19,6 +19,8 @@ if os.environ.get("VAG_GEMM_DEBUG") != "1":
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "vag-nmt_amd"))
 import torch, bench
 from vagnmt_hip.trainer import TrainStep
+from vagnmt_hip import _lib
+_lib.set_option("gemm_debug", 1)
 from machine_translation_vision.losses import PairwiseRankingLoss
 c = bench.CFG2
 dev = torch.device("cuda:0")

@@ -3,7 +3,7 @@
 // work on the caller's stream, so whole training steps can be captured into a HIP graph.
 #include "../../include/vag_nmt.h"
 #include "kernels.h"
-#include <cstdlib>
+#include <cstring>
 
 #define S_(x) reinterpret_cast<hipStream_t>(x)
 
@@ -46,6 +46,8 @@ void vag_set_derived_override(const float* d) { g_derived = d; }
 // memory; every product still accumulates in fp32, master weights, recurrent state, saved gates and all gradients stay fp32.
 static thread_local bool g_store16 = false;
 void vag_set_store16(bool on) { g_store16 = on; vag_gemm_set_planes(on ? 2 : 3); }
+const float* vag_get_derived_override() { return g_derived; }
+bool vag_get_store16() { return g_store16; }
 static inline const float* as_f(const vag_half* p) { return reinterpret_cast<const float*>(p); }
 // Row chunk of the output head (0 = whole sequence at once).  With a chunk set the (Tt*B, V) logits are never formed as a
 // whole: forward computes them chunk by chunk for the log-sum-exp / NLL, backward RECOMPUTES each chunk, turns it into
@@ -66,8 +68,7 @@ void vag_set_head_fuse(const vag_head_g* g, const float* d_loss, float* dt) { g_
 // a softmax over V classes are sums of thousands of small terms whose 2^-9 rounding errors average out; the forward
 // logits keep the two-plane product.  VAG_HEAD_BF16_GRADS=0 keeps two planes here too.
 static bool head_grads_one_plane() {
-    static const bool on = !(getenv("VAG_HEAD_BF16_GRADS") && atoi(getenv("VAG_HEAD_BF16_GRADS")) == 0);
-    return on && g_store16;
+    return vag_opt().head_bf16_grads != 0 && g_store16;
 }
 static int head_dt_gemm(int64_t R, int64_t E, int64_t V, const float* dlogits, int64_t ldl, const float* out_w, float* dt,
                         hipStream_t s) {
@@ -81,9 +82,28 @@ static int head_outw_gemm(int64_t V, int64_t E, int64_t R, const float* dlogits,
     return gemm_tn_acc(V, E, R, dlogits, ldl, tmid, E, g_out_w, E, s);
 }
 
+VagOptions& vag_opt() {
+    static VagOptions o;
+    return o;
+}
+
 extern "C" {
 
-int vag_version(void) { return 200; }
+int vag_version(void) { return 300; }
+
+// Debug / tuning options by name (common.h: VagOptions); process-wide, takes effect for calls enqueued afterwards.
+int vag_set_option(const char* name, int64_t value) {
+    VAG_CHECK_ARG(name != nullptr);
+    VagOptions& o = vag_opt();
+    const struct { const char* n; int* p; } ints[] = {
+        {"gemm_f32mfma", &o.gemm_f32mfma}, {"gemm_nogroup", &o.gemm_nogroup}, {"gemm_force_tile", &o.gemm_force_tile},
+        {"gemm_force_splitk", &o.gemm_force_splitk}, {"gemm_debug", &o.gemm_debug}, {"head_fuse", &o.head_fuse},
+        {"head_bf16_grads", &o.head_bf16_grads}};
+    for (const auto& e : ints)
+        if (strcmp(name, e.n) == 0) { *e.p = (int)value; return VAG_OK; }
+    if (strcmp(name, "head_chunk") == 0) { o.head_chunk = value; return VAG_OK; }
+    return VAG_EINVAL;
+}
 
 // Operator-level access to what vag_train_step sets up for itself: the derived-weights buffer and the storage mode the
 // per-operator entry points use ON THE CALLING THREAD until changed (derived NULL / storage 0 = the defaults).
@@ -449,7 +469,7 @@ int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_wh
 }
 
 struct CgruWs {
-    float *xp1, *h1, *g1, *g2, *qhp, *scores, *alpha, *tmp, *prep, *encwp, *spart;
+    float *xp1, *h1, *g1, *g2, *qhp, *scores, *alpha, *tmp, *prep, *encwp;
     int64_t total;
 };
 static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
@@ -467,7 +487,6 @@ static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, i
     w.tmp = take(B * E);
     w.prep = take(cgru_prep(nullptr, H).total);
     w.encwp = take(B * Ts * 3 * H);         // (W_ih2 W_c2h) enc[b,s,:]: the keys as gru_2 sees them, once per batch
-    w.spart = take(B * ((C + 15) / 16) * Ts);   // attention scores of one step as per-column-tile partial sums
     w.total = o;
     return w;
 }
@@ -549,8 +568,7 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
     // only needs sum_s alpha_s (W_ih2 W_c2h enc_s), the contexts themselves are formed for all steps after the loop.
     // Free running needs each context at once for the head, so it keeps the 5-launch step; backward is common to both
     // and always works on the projected keys.
-    static const bool opt_hoist = getenv("VAG_CGRU_NOHOIST") == nullptr;
-    const bool hoist = opt_hoist && !free_run;
+    const bool hoist = !free_run;
     // 2-byte storage mode: teacher-forced (hoisted) path only, weights from the driver's derived buffer
     const bool s16 = g_store16;
     VAG_CHECK_ARG(!s16 || (hoist && g_derived && H % 8 == 0 && Ts * B < (1ll << 28)));
@@ -566,10 +584,6 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
         VAG_TRY(vag_gemm_launch(B * Ts, 3 * H, C, 1.f, enc, C, 1, p.wp, 1, C, 0.f, k.encwp, 3 * H, nullptr, 0, s, s16 ? 1 : 0));
         VAG_TRY(grp.end(s));
     }
-    // overlapped step driver (sched.hip): the loop's launches go to the chain stream, hooks run around every step
-    const VagLoopHooks* hk = hoist ? vag_loop_hooks() : nullptr;
-    const hipStream_t s_op = s;
-    if (hk && hk->chain) { VAG_TRY(vag_sched_order(s_op, hk->chain)); s = hk->chain; }
     auto hoisted_step = [&](int64_t t) -> int {
         const float* hprev = t == 0 ? h0 : h2_all + (t - 1) * BH;
         float* h1 = k.h1 + t * BH;
@@ -581,21 +595,6 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
         a.s[0].other = k.xp1 + t * B * 3 * H;
         a.s[0].hprev = hprev; a.s[0].hout = h1; a.s[0].out2 = nullptr; a.s[0].save = k.g1 + t * 4 * BH; a.s[0].t = 0;
         VAG_TRY(vag_gru_step_launch(a, 1, s, s16));                                                         // gru_1 :121
-        // Experiment kept for the record, VAG_CGRU_QSCORE=1: 3 launches per step -- cell 1 | q = attn_h h1
-        // with the scores as per-column-tile partial sums (+ W_hh2 h1 + b_hh2 in the same grid) | softmax, projected context,
-        // cell 2.  No redundant work, parity green, and still slower than the 4-launch step (24.97 vs 23.95 us per step
-        // in a graph): a removed boundary is worth 1.45 us, and the fused kernel's phases (product -> LDS reduction ->
-        // tanh over 64-byte key pieces) run one after the other in every workgroup.  Read per call (tests flip it).
-        const bool opt_qscore = getenv("VAG_CGRU_QSCORE") != nullptr;
-        if (opt_qscore && Ts <= 768 && Ts * B < (1ll << 28)) {
-            const float* wq = s16 ? as_f(dw16.wcat16) : p.wcat;
-            const float* wt = s16 ? as_f(dw16.wcat16 + C * H) : p.wcat + C * H;
-            VAG_TRY(vag_attn_qscore_side_launch(pe, w.attn_v, Ts, h1, H, B, H, wq, H, C, qhp, Q, k.spart, wt, H, 3 * H,
-                                                p.bcat + C, qhp + C, Q, s, s16));                           // :47-51
-            VAG_TRY(vag_attn_ctx_gru_launch(nullptr, k.encwp, B, 1, Ts, H, w.gru2.b_ih, qhp + C, Q, h1, k.alpha + t * B * Ts,
-                                            h2_all + t * BH, k.g2 + t * 4 * BH, s, s16, k.spart, (C + 15) / 16, mask));  // :41-44, :126-129
-            return VAG_OK;
-        }
         if (s16) {
             VAG_TRY(vag_skinny_launch(B, C, H, h1, H, as_f(dw16.wcat16), H, nullptr, nullptr, 0, qhp, Q, 0, s, true));  // :47
             VAG_TRY(vag_attn_dot_side_launch(0, pe, qhp, Q, w.attn_v, mask, nullptr, B, Ts, C, k.scores, B, 3 * H, H, h1, H,
@@ -604,19 +603,7 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
                                             h2_all + t * BH, k.g2 + t * 4 * BH, s, true));
             return VAG_OK;
         }
-        // Experiment kept for the record: 3 launches per step with the attention half in ONE kernel.  Measured
-        // slower (27.7 vs 23.7 us per step): without a cross-workgroup exchange every workgroup of a row recomputes all its
-        // scores, and the 4x tanh work (3.2 us per workgroup) costs more than the launch it saves.  Off unless VAG_CGRU_FUSE=1.
-        static const bool opt_fused = getenv("VAG_CGRU_FUSE") != nullptr;
-        if (opt_fused && vag_attn_fused_fwd_ok(Ts, H, Q, Q)) {
-            // [q | W_hh2 h1 + b] in one product, then scores + softmax + projected context + gru_2 in one kernel
-            VAG_TRY(vag_skinny_launch(B, Q, H, h1, H, p.wcat, H, p.bcat, nullptr, 0, qhp, Q, 0, s));         // :47 | gru_2 hidden side
-            VAG_TRY(vag_attn_fused_fwd_launch(pe, qhp, Q, w.attn_v, mask, k.encwp, w.gru2.b_ih, qhp + C, Q, h1, B, Ts, H,
-                                              k.alpha + t * B * Ts, h2_all + t * BH, k.g2 + t * 4 * BH, s));  // :41-51, :124-129
-            return VAG_OK;
-        }
-        static const bool opt_side = getenv("VAG_CGRU_NOSIDE") == nullptr;
-        if (opt_side && Ts * B < (1ll << 28)) {
+        if (Ts * B < (1ll << 28)) {
             // q = attn_h h1, then the scores with W_hh2 h1 + b_hh2 (not needed before the cell) in the same grid
             VAG_TRY(vag_skinny_launch(B, C, H, h1, H, p.wcat, H, nullptr, nullptr, 0, qhp, Q, 0, s));                  // :47
             VAG_TRY(vag_attn_dot_side_launch(0, pe, qhp, Q, w.attn_v, mask, nullptr, B, Ts, C, k.scores, B, 3 * H, H, h1, H,
@@ -629,13 +616,7 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
                                         h2_all + t * BH, k.g2 + t * 4 * BH, s));                            // :44, :126-129
         return VAG_OK;
     };
-    for (int64_t t = 0; hoist && t < Tt; ++t) {
-        if (hk && hk->before) VAG_TRY(hk->before(t));
-        VAG_TRY(hoisted_step(t));
-        if (hk && hk->after) VAG_TRY(hk->after(t));
-    }
-    if (hk && hk->chain) { VAG_TRY(vag_sched_order(s, s_op)); s = s_op; }
-    if (hoist && hk && hk->skip_bulk) return VAG_OK;          // the hooks form the contexts chunk by chunk
+    for (int64_t t = 0; hoist && t < Tt; ++t) VAG_TRY(hoisted_step(t));
     if (hoist) return vag_attn_wsum_launch(1, k.alpha, enc, B, Ts, Tt, C, c_all, s);                       // all contexts :126
     for (int64_t t = 0; t < Tt; ++t) {
         if (free_run) {
@@ -737,17 +718,11 @@ int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const f
     // d alpha does not depend on the recurrence: all steps at once, before the loop.  The second is taken on the
     // projected keys, d alpha[b,s] += encwp[b,s,:] . dgi2[b,:], so no per-step product dc = dgi2 W is needed.
     // per sentence b: dah[:, b, :] (Tt,Ts) = d_c_all[:, b, :] (Tt,C) enc[b]^T (C,Ts): B small products in one launch
-    const VagLoopHooks* hk = vag_loop_hooks();
-    if (hk && hk->skip_bulk) {
-        // the hooks have filled z.dah chunk by chunk (vag_head_chunk_data)
-    } else if (C % 4 == 0 && aligned16(enc) && aligned16(d_c_all) && B < 65536)
+    if (C % 4 == 0 && aligned16(enc) && aligned16(d_c_all) && B < 65536)
         VAG_TRY(vag_skinny_batched_launch(B, Tt, Ts, C, d_c_all, B * C, C, enc, C, Ts * C, z.dah, B * Ts, Ts, s));
     else
         VAG_TRY(vag_attn_scores_ex_launch(1, enc, d_c_all, C, nullptr, nullptr, Tt * B, 1, B, Ts, C, nullptr, z.dah, s));
-    const hipStream_t s_op = s;
-    if (hk && hk->chain) { VAG_TRY(vag_sched_order(s_op, hk->chain)); s = hk->chain; }
     for (int64_t t = Tt - 1; t >= 0; --t) {
-        if (hk && hk->before) VAG_TRY(hk->before(t));
         float* dgi2 = z.dgi2 + t * B * 3 * H;
         float* dqgh = z.dqgh + t * B * Q;
         // attention backward: d alpha ; softmax backward ; dq = sum_s ds v (1 - tanh^2)
@@ -779,9 +754,7 @@ int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const f
             sd.dh_direct = nullptr; sd.dh_out = d_h0;
         }
         VAG_TRY(vag_gru_bwd_step_launch(f, 1, s, s16));
-        if (hk && hk->after) VAG_TRY(hk->after(t));
     }
-    if (hk && hk->chain) { VAG_TRY(vag_sched_order(s, s_op)); s = s_op; }
     // after the loop: everything that does not sit on the recurrence's critical path, as large products
     VAG_TRY(vag_attn_post_bwd_launch(pe, k.qhp, Q, w.attn_v, z.ds, k.alpha, d_c_all, B, Ts, Tt, C, d_pe, z.dvp, d_enc_out,
                                      accumulate_enc, s, s16));
@@ -865,12 +838,6 @@ int vag_cgru_bwd_weights_finish(vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt, 
     if (with_attn_v) VAG_TRY(vag_colsum_launch(z.dvp, VAG_POST_CHUNKS(Ts) * B, C, C, g.attn_v, s));
     VAG_TRY(vag_gemm_launch(3 * H, H, C, 1.f, z.dwp, C, 1, w.c2h, 1, C, 1.f, g.gru2.w_ih, H, nullptr, 0, s));
     return vag_gemm_launch(H, C, 3 * H, 1.f, w.gru2.w_ih, 1, H, z.dwp, C, 1, 1.f, g.c2h, C, nullptr, 0, s);
-}
-float* vag_cgru_ws_alpha(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
-    return cgru_ws(ws, B, Ts, Tt, E, H).alpha;
-}
-float* vag_cgru_scratch_dah(float* scratch, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
-    return cgru_bwd_scratch(scratch, B, Ts, Tt, E, H).dah;
 }
 extern "C" {
 
@@ -1069,48 +1036,6 @@ int vag_head_ce_seq_bwd(const float* h2_all, const float* c_all, const float* e_
 
 }  // extern "C"
 
-// ---- the head by time chunks, for the overlapped step driver (kernels.h: VagHeadChunk) ----
-int vag_head_chunk_data(const VagHeadChunk& k, int64_t t0, int64_t t1, hipStream_t s) {
-    VAG_CHECK_ARG(0 <= t0 && t0 < t1 && t1 <= k.Tt);
-    const int64_t B = k.B, E = k.E, H = k.H, C = 2 * H, V = k.V, Ts = k.Ts, ldl = k.ldl, r0 = t0 * B, n = (t1 - t0) * B;
-    float* c = k.c_all + r0 * C;
-    float* tmid = k.tmid + r0 * E;
-    float* dt = k.dt + r0 * E;
-    VAG_TRY(vag_attn_wsum_launch(1, k.alpha + r0 * Ts, k.enc, B, Ts, t1 - t0, C, c, s));                    // contexts :126
-    VAG_TRY(zero_async(tmid, n * E * sizeof(float), s));
-    {
-        VagGemmGroup grp;
-        VAG_TRY(vag_gemm_launch(n, E, H, 1.f, k.h2_all + r0 * H, H, 1, k.w.w1, 1, H, 1.f, tmid, E, k.w.b1, 0, s));
-        VAG_TRY(vag_gemm_launch(n, E, C, 1.f, c, C, 1, k.w.w2, 1, C, 1.f, tmid, E, k.w.b2, 0, s));
-        VAG_TRY(vag_gemm_launch(n, E, E, 1.f, k.e_all + r0 * E, E, 1, k.w.w3, 1, E, 1.f, tmid, E, k.w.b3, 0, s));
-        VAG_TRY(grp.end(s));
-    }
-    VAG_TRY(vag_tanh_dropout_launch(tmid, n * E, r0 * E, k.rng, VAG_DROP_DEC_OUT, k.p_out, s));
-    VAG_TRY(vag_gemm_launch(n, V, E, 1.f, tmid, E, 1, k.w.out_w, 1, E, 0.f, k.logits, ldl, k.w.out_b, 0, s));
-    VAG_TRY(vag_lse_nll_launch(k.logits, ldl, n, V, k.tgt + t0, B, k.Tt, k.vw, k.lse + r0, k.nll + r0, nullptr, 0, nullptr, 0, s));
-    VAG_TRY(vag_ce_bwd_colsum_launch(k.logits, ldl, n, V, k.tgt + t0, B, k.Tt, k.vw, k.lse + r0, k.inv_cnt, k.d_loss, k.g.out_b,
-                                     s));
-    VAG_TRY(head_dt_gemm(n, E, V, k.logits, ldl, k.w.out_w, dt, s));
-    VAG_TRY(vag_tanh_bwd_launch(tmid, dt, dt, n * E, k.rng, VAG_DROP_DEC_OUT, k.p_out, s, r0 * E));
-    {
-        VagGemmGroup grp;
-        VAG_TRY(gemm_nn(n, H, E, dt, E, k.w.w1, H, 0.f, k.d_h2 + r0 * H, H, s));
-        VAG_TRY(gemm_nn(n, C, E, dt, E, k.w.w2, C, 0.f, k.d_c + r0 * C, C, s));
-        VAG_TRY(gemm_nn(n, E, E, dt, E, k.w.w3, E, 0.f, k.d_e + r0 * E, E, s));
-        VAG_TRY(grp.end(s));
-    }
-    // d alpha through the head's use of the context, rows of this chunk (see vag_cgru_attn_decode_seq_bwd_loop)
-    if (C % 4 == 0 && aligned16(k.enc) && aligned16(k.d_c) && B < 65536)
-        return vag_skinny_batched_launch(B, t1 - t0, Ts, C, k.d_c + r0 * C, B * C, C, k.enc, C, Ts * C, k.dah + r0 * Ts, B * Ts,
-                                         Ts, s);
-    return vag_attn_scores_ex_launch(1, k.enc, k.d_c + r0 * C, C, nullptr, nullptr, n, 1, B, Ts, C, nullptr, k.dah + r0 * Ts, s);
-}
-// k.logits must still hold the chunk's d(logits)
-int vag_head_chunk_weights(const VagHeadChunk& k, int64_t t0, int64_t t1, hipStream_t s) {
-    const int64_t B = k.B, r0 = t0 * B, n = (t1 - t0) * B, E = k.E, H = k.H, C = 2 * H;
-    return head_bwd_weights(k.h2_all + r0 * H, k.c_all + r0 * C, k.e_all + r0 * E, n, E, H, k.V, k.tmid + r0 * E, k.logits, k.ldl,
-                            k.dt + r0 * E, k.g, s, true);
-}
 extern "C" {
 
 int vag_head_logp_seq_fwd(const float* h2, const float* c, const float* e, vag_head_w w, int64_t R, int64_t E, int64_t H,

@@ -160,27 +160,13 @@ __global__ __launch_bounds__(64 * CG_WAVES) void attn_ctx_gru_kernel(const float
                                                                      const float* __restrict__ hp, int64_t ldhp,
                                                                      const float* __restrict__ hprev, int64_t N,
                                                                      float* __restrict__ alpha, float* __restrict__ hout,
-                                                                     float* __restrict__ save,
-                                                                     const float* __restrict__ spart, int ntile,
-                                                                     const float* __restrict__ mask) {
-    extern __shared__ __attribute__((aligned(16))) float w[];   // Ts weights, CG_WAVES x 3 x 64 float4 partials, [Ts scores]
+                                                                     float* __restrict__ save) {
+    extern __shared__ __attribute__((aligned(16))) float w[];   // Ts weights, CG_WAVES x 3 x 64 float4 partials
     float4* part = reinterpret_cast<float4*>(w + ((Ts + 3) & ~3));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t n = blockIdx.y;
     const int64_t b = rps == 1 ? n : (int64_t)((int)blockIdx.y / rps);
-    const float* sc = scores ? scores + n * Ts : nullptr;
-    // scores handed over as per-column-tile partial sums (attn_qscore_side_kernel): wave k requests tiles k, k+8, ... of
-    // every position now, and adds them up after the value rows below have been requested too
-    float* ssum = reinterpret_cast<float*>(part + CG_WAVES * 3 * 64);     // Ts floats, only with spart
-    constexpr int SP = 8;                           // tiles per wave in flight (ntile <= 64 in one round at 8 waves)
-    float pv[SP];
-    if (spart) {
-#pragma unroll
-        for (int i = 0; i < SP; ++i) {
-            const int t = wave + i * CG_WAVES;
-            pv[i] = (lane < Ts && t < ntile) ? spart[(n * ntile + t) * Ts + lane] : 0.f;
-        }
-    }
+    const float* sc = scores + n * Ts;
     const int u = (blockIdx.x * 64 + lane) * 4;
     const bool uok = u < H;
     // Everything that does not depend on the softmax is requested first -- the first U value rows of this wave and, for
@@ -202,33 +188,6 @@ __global__ __launch_bounds__(64 * CG_WAVES) void attn_ctx_gru_kernel(const float
             hg[g] = *reinterpret_cast<const float4*>(hp + n * ldhp + g * H + u);
         }
         h1 = *reinterpret_cast<const float4*>(hprev + n * H + u);
-    }
-    if (spart) {
-        // general shape: positions in rounds of 64, tiles in rounds of SP * CG_WAVES; the first round is in registers
-        float* pw = reinterpret_cast<float*>(part);           // CG_WAVES x Ts partial sums (the float4 area is free until later)
-        for (int s0 = 0; s0 < Ts; s0 += 64) {
-            const int s = s0 + lane;
-            float acc = 0.f;
-            for (int t0 = 0; t0 < ntile; t0 += SP * CG_WAVES) {
-#pragma unroll
-                for (int i = 0; i < SP; ++i) {
-                    const int t = t0 + wave + i * CG_WAVES;
-                    if (s0 == 0 && t0 == 0) acc += pv[i];
-                    else if (s < Ts && t < ntile) acc += spart[(n * ntile + t) * Ts + s];
-                }
-            }
-            if (s < Ts) pw[wave * Ts + s] = acc;
-        }
-        __syncthreads();
-        for (int s = threadIdx.x; s < Ts; s += 64 * CG_WAVES) {
-            float t = 0.f;
-#pragma unroll
-            for (int k = 0; k < CG_WAVES; ++k) t += pw[k * Ts + s];
-            if (mask && mask[b * Ts + s] == 0.f) t = -INFINITY;
-            ssum[s] = t;
-        }
-        __syncthreads();
-        sc = ssum;
     }
     {
         float mx = -INFINITY;
@@ -307,21 +266,18 @@ __global__ __launch_bounds__(64 * CG_WAVES) void attn_ctx_gru_kernel(const float
 }
 int vag_attn_ctx_gru_launch(const float* scores, const float* encwp, int64_t N, int64_t rps, int64_t Ts, int64_t H,
                             const float* b_ih, const float* hp, int64_t ldhp, const float* hprev, float* alpha, float* hout,
-                            float* save, hipStream_t s, bool x16, const float* spart, int64_t ntile, const float* mask) {
-    VAG_CHECK_ARG((scores || (spart && ntile > 0 && rps == 1)) && encwp && b_ih && hp && hprev && hout && N > 0 && N < 65536 &&
-                  Ts > 0 && H > 0 && H % 4 == 0);
-    VAG_CHECK_ARG(!spart || (int64_t)CG_WAVES * Ts <= (int64_t)CG_WAVES * 3 * 64 * 4);        // partial sums fit the float4 area
+                            float* save, hipStream_t s, bool x16) {
+    VAG_CHECK_ARG(scores && encwp && b_ih && hp && hprev && hout && N > 0 && N < 65536 && Ts > 0 && H > 0 && H % 4 == 0);
     VAG_CHECK_ARG(ldhp % 4 == 0 && rps >= 1 && aligned16(encwp) && aligned16(hp) && aligned16(hprev) && aligned16(hout) &&
                   aligned16(b_ih) && (!save || aligned16(save)));
     dim3 grid((unsigned)cdiv64(H, 256), (unsigned)N);
-    const size_t lds = (size_t)((Ts + 3) & ~3) * sizeof(float) + (size_t)CG_WAVES * 3 * 64 * 16 +
-                       (spart ? (size_t)((Ts + 3) & ~3) * sizeof(float) : 0);
+    const size_t lds = (size_t)((Ts + 3) & ~3) * sizeof(float) + (size_t)CG_WAVES * 3 * 64 * 16;
     if (x16)
         hipLaunchKernelGGL(attn_ctx_gru_kernel<true>, grid, dim3(64 * CG_WAVES), lds, s, scores, encwp, (int)rps, (int)Ts,
-                           (int)H, b_ih, hp, ldhp, hprev, N, alpha, hout, save, spart, (int)ntile, mask);
+                           (int)H, b_ih, hp, ldhp, hprev, N, alpha, hout, save);
     else
         hipLaunchKernelGGL(attn_ctx_gru_kernel<false>, grid, dim3(64 * CG_WAVES), lds, s, scores, encwp, (int)rps, (int)Ts,
-                           (int)H, b_ih, hp, ldhp, hprev, N, alpha, hout, save, spart, (int)ntile, mask);
+                           (int)H, b_ih, hp, ldhp, hprev, N, alpha, hout, save);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
@@ -614,147 +570,6 @@ int vag_outer2_launch(const float* a1, const float* x1, const float* a2, const f
     VAG_CHECK_ARG(a1 && x1 && out && B > 0 && Ts > 0 && C > 0 && C % 4 == 0);
     dim3 grid((unsigned)cdiv64(C, 1024), (unsigned)B);
     hipLaunchKernelGGL(outer2_kernel, grid, dim3(256), 0, s, a1, x1, a2, x2, (int)Ts, (int)C, out, accumulate);
-    VAG_LAUNCH_CHECK();
-    return VAG_OK;
-}
-
-// ------------------------------------------------------------------ one launch for the attention half of a decoder step
-// scores -> softmax -> projected context -> gru_2 cell (NMT_Decoder.py:124-129) for teacher-forced training at the sizes
-// where a query row's work fits one pass of registers (C = 1024, Ts <= 48): the two launches above become one, i.e. one
-// kernel boundary and one ramp less on the critical path of every decoder step.
-// Grid (H / FU, N): workgroup (j, n) owns hidden units [j*FU, (j+1)*FU) of row n.  All 16 waves first score the row --
-// EVERY workgroup of a row computes all Ts scores (the 4x redundant key reads and tanh evaluations are cheaper than a
-// cross-workgroup exchange of the 40 scores, which costs a grid-visible hand-off per step: MI355X_MICROARCH.md, hand-off
-// price list) -- then the softmax, then the weighted sum of this workgroup's 3*FU projected-key columns (position groups
-// meet in LDS), then the cell.  All global loads of the key rows, the projected keys and the cell's operands are requested
-// before the first use of any of them: one round of memory latency per launch.
-constexpr int FU = 128;                 // hidden units per workgroup
-constexpr int F_WAVES = 16;
-constexpr int F_TC = 3 * FU / 4;        // float4 columns of the projected keys per workgroup (96)
-constexpr int F_NG = F_WAVES * 64 / F_TC;   // position groups in the weighted sum (10; threads >= F_NG*F_TC idle there)
-constexpr int F_PS = 3;                 // key positions per wave in flight (Ts <= 48)
-constexpr int F_PC = 5;                 // projected-key positions per thread in flight (Ts <= 50)
-__global__ __launch_bounds__(64 * F_WAVES) void attn_fused_fwd_kernel(
-    const float* __restrict__ pe, const float* __restrict__ q, int64_t ldq, const float* __restrict__ v,
-    const float* __restrict__ mask, const float* __restrict__ encwp, const float* __restrict__ b_ih,
-    const float* __restrict__ hp, int64_t ldhp, const float* __restrict__ hprev, int Ts, int H, int64_t N,
-    float* __restrict__ alpha, float* __restrict__ hout, float* __restrict__ save) {
-    constexpr int C = 1024;
-    __shared__ __attribute__((aligned(16))) float sc[64];
-    __shared__ __attribute__((aligned(16))) float4 part[F_NG * F_TC];
-    __shared__ __attribute__((aligned(16))) float gsum[3 * FU];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t n = blockIdx.y;
-    const int u0 = blockIdx.x * FU;
-    // ---- requests: key rows of this wave's positions, query, v
-    const float* pr = pe + n * Ts * C + lane * 4;
-    float4 pv[F_PS][4];
-#pragma unroll
-    for (int i = 0; i < F_PS; ++i) {
-        const int s = min(wave + i * F_WAVES, Ts - 1);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pv[i][k] = *reinterpret_cast<const float4*>(pr + (int64_t)s * C + 256 * k);
-    }
-    float4 qv[4], vv[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        qv[k] = *reinterpret_cast<const float4*>(q + n * ldq + lane * 4 + 256 * k);
-        vv[k] = *reinterpret_cast<const float4*>(v + lane * 4 + 256 * k);
-    }
-    // ---- requests: this thread's projected-key columns (gate g, 4 units) of positions grp, grp + F_NG, ...
-    const int tc = threadIdx.x % F_TC, grp = threadIdx.x / F_TC;
-    const bool cact = grp < F_NG;
-    const int gate = tc / (FU / 4), within = tc % (FU / 4);
-    const float* er = encwp + n * Ts * 3 * H + gate * H + u0 + 4 * within;
-    float4 ev[F_PC];
-#pragma unroll
-    for (int i = 0; i < F_PC; ++i) {
-        const int s = min(grp + i * F_NG, Ts - 1);
-        ev[i] = cact ? *reinterpret_cast<const float4*>(er + (int64_t)s * 3 * H) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // ---- requests: the cell's operands (threads < FU: one hidden unit each)
-    const int u = u0 + threadIdx.x;
-    const bool uact = threadIdx.x < FU;
-    float bi[3] = {0.f, 0.f, 0.f}, hg[3] = {0.f, 0.f, 0.f}, h1 = 0.f;
-    if (uact) {
-#pragma unroll
-        for (int g = 0; g < 3; ++g) { bi[g] = b_ih[g * H + u]; hg[g] = hp[n * ldhp + g * H + u]; }
-        h1 = hprev[n * H + u];
-    }
-    // ---- scores (NMT_Decoder.py:47-51), masked positions at -inf (:41-43)
-#pragma unroll
-    for (int i = 0; i < F_PS; ++i) {
-        const int s = wave + i * F_WAVES;
-        if (s < Ts) {                                       // wave-uniform
-            float acc = 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                acc += vv[k].x * vag_tanh(pv[i][k].x + qv[k].x);
-                acc += vv[k].y * vag_tanh(pv[i][k].y + qv[k].y);
-                acc += vv[k].z * vag_tanh(pv[i][k].z + qv[k].z);
-                acc += vv[k].w * vag_tanh(pv[i][k].w + qv[k].w);
-            }
-            acc = wave_sum(acc);
-            if (lane == 0) sc[s] = (mask && mask[n * Ts + s] == 0.f) ? -INFINITY : acc;
-        }
-    }
-    __syncthreads();
-    // ---- softmax (:44): every wave reduces the Ts scores itself
-    float mx = -INFINITY;
-    for (int s = lane; s < Ts; s += 64) mx = fmaxf(mx, sc[s]);
-    mx = wave_max(mx);
-    float sum = 0.f;
-    for (int s = lane; s < Ts; s += 64) sum += __expf(sc[s] - mx);
-    sum = wave_sum(sum);
-    const float inv = 1.f / sum;
-    if (blockIdx.x == 0 && alpha)
-        for (int s = threadIdx.x; s < Ts; s += 64 * F_WAVES) alpha[n * Ts + s] = __expf(sc[s] - mx) * inv;
-    // ---- weighted sum of the projected keys: sum_s alpha_s (W_ih2 W_c2h enc_s)   (:126-129 with context2hid folded in)
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cact) {
-#pragma unroll
-        for (int i = 0; i < F_PC; ++i) {
-            const int s = grp + i * F_NG;
-            const float a = s < Ts ? __expf(sc[s] - mx) * inv : 0.f;
-            acc.x += a * ev[i].x; acc.y += a * ev[i].y; acc.z += a * ev[i].z; acc.w += a * ev[i].w;
-        }
-        part[grp * F_TC + tc] = acc;
-    }
-    __syncthreads();
-    if (threadIdx.x < F_TC) {
-        float4 t = part[threadIdx.x];
-#pragma unroll
-        for (int g = 1; g < F_NG; ++g) {
-            const float4 o = part[g * F_TC + threadIdx.x];
-            t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
-        }
-        *reinterpret_cast<float4*>(&gsum[4 * threadIdx.x]) = t;      // [gate][unit] order: 4*tc = gate*FU + 4*within
-    }
-    __syncthreads();
-    if (!uact) return;
-    // ---- gru_2 cell (:129)
-    const float gi_r = gsum[threadIdx.x] + bi[0], gi_z = gsum[FU + threadIdx.x] + bi[1], gi_n = gsum[2 * FU + threadIdx.x] + bi[2];
-    const float rr = vag_sigmoid(gi_r + hg[0]);
-    const float zz = vag_sigmoid(gi_z + hg[1]);
-    const float nn = vag_tanh(gi_n + rr * hg[2]);
-    const int64_t o = n * H + u;
-    hout[o] = (1.f - zz) * nn + zz * h1;
-    if (save) {
-        const int64_t NH = N * H;
-        save[o] = rr; save[NH + o] = zz; save[2 * NH + o] = nn; save[3 * NH + o] = hg[2];
-    }
-}
-// Applicable when C == 1024 (H == 512), Ts <= 48, one source row per query row and every pointer 16-byte aligned.
-bool vag_attn_fused_fwd_ok(int64_t Ts, int64_t H, int64_t ldq, int64_t ldhp) {
-    return H == 512 && Ts >= 1 && Ts <= F_PS * F_WAVES && Ts <= F_PC * F_NG && ldq % 4 == 0 && ldhp % 4 == 0;
-}
-int vag_attn_fused_fwd_launch(const float* pe, const float* q, int64_t ldq, const float* v, const float* mask,
-                              const float* encwp, const float* b_ih, const float* hp, int64_t ldhp, const float* hprev,
-                              int64_t N, int64_t Ts, int64_t H, float* alpha, float* hout, float* save, hipStream_t s) {
-    VAG_CHECK_ARG(pe && q && v && encwp && b_ih && hp && hprev && hout && N > 0 && N < 65536);
-    VAG_CHECK_ARG(vag_attn_fused_fwd_ok(Ts, H, ldq, ldhp) && aligned16(pe) && aligned16(q) && aligned16(v) && aligned16(encwp));
-    hipLaunchKernelGGL(attn_fused_fwd_kernel, dim3((unsigned)(H / FU), (unsigned)N), dim3(64 * F_WAVES), 0, s, pe, q, ldq, v,
-                       mask, encwp, b_ih, hp, ldhp, hprev, (int)Ts, (int)H, N, alpha, hout, save);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

@@ -85,6 +85,20 @@ template <bool XH> __device__ __forceinline__ float ld1_any(const float* base, i
     return base[elem];
 }
 
+// Process-wide debug / tuning options (api.hip: vag_set_option).  Defaults are what ships; the parity tests flip
+// gemm_f32mfma (exact-f32 reference products), head_chunk / head_fuse (chunked output head at small sizes).
+struct VagOptions {
+    int gemm_f32mfma = 0;        // 1: every product on the f32-input MFMA kernels (no bf16 split)
+    int gemm_nogroup = 0;        // 1: products inside a group bracket are launched one by one
+    int gemm_force_tile = 0;     // 64 / 128 together with gemm_force_splitk >= 1: override the tile / split-K choice
+    int gemm_force_splitk = 0;
+    int gemm_debug = 0;          // 1: print the choice per product
+    int64_t head_chunk = -1;     // rows per chunk of the output head (-1: automatic, 0: never chunk)
+    int head_fuse = 1;           // 0: the chunked head recomputes its chunks in backward instead of finishing them in forward
+    int head_bf16_grads = 1;     // 2-byte storage mode: one bf16 plane in the head's two vocabulary-sized gradient products
+};
+VagOptions& vag_opt();
+
 enum { VAG_ACT_NONE = 0, VAG_ACT_TANH = 1 };
 enum { VAG_DROP_ENC_EMB = 1, VAG_DROP_ENC_CTX = 2, VAG_DROP_DEC_OUT = 3 };
 
@@ -105,10 +119,6 @@ int vag_attn_dot_side_launch(int mode, const float* x, const float* q, int64_t l
                              const float* addend, int64_t N, int64_t Ts, int64_t W, float* out, int64_t M, int64_t Np,
                              int64_t K, const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* pbias,
                              const float* padd, float* P, int64_t ldp, hipStream_t stream, bool s16 = false);   // s16: x and Wt fp16
-int vag_attn_qscore_side_launch(const float* x, const float* v, int64_t Ts, const float* A, int64_t lda, int64_t M, int64_t K,
-                                const float* Wq, int64_t ldwq, int64_t Nq, float* qout, int64_t ldq, float* spart,
-                                const float* Wt, int64_t ldwt, int64_t Np, const float* pbias, float* P, int64_t ldp,
-                                hipStream_t stream, bool s16 = false);
 int vag_skinny_gather_launch(int64_t M, int64_t N, int64_t K, const float* table, int64_t ldt, const int64_t* idx, const float* W,
                              int64_t ldw, const float* bias, float* out, int64_t ldo, float* gathered, int64_t ldg,
                              hipStream_t stream);

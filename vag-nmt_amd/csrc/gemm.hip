@@ -212,7 +212,8 @@ __global__ __launch_bounds__(NTH) void gemm_tiled_kernel(GemmArgs a) {
             const float bv = (a.bias && first) ? a.bias[col] : 0.f;
             const int row0 = m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5);
             float* cbase = a.C + (int64_t)row0 * a.ldc + col;
-            gemm_epilogue16(acc[i][j], cbase, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, atomic);
+            if (a.c_half) gemm_epilogue16(acc[i][j], a.C, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, false, 1, (int64_t)row0 * a.ldc + col);
+            else gemm_epilogue16(acc[i][j], cbase, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, atomic);
         }
 }
 
@@ -254,9 +255,6 @@ __device__ __forceinline__ float sub_f32(float a, float b) {
 }
 // split two floats into three packed bf16 pairs (low half = first element)
 __device__ __forceinline__ void split3(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
-#ifdef VAG_EXP_NO_SPLIT      // timing experiment only (wrong results): what the VALU side of the split costs
-    p1 = pack_bf16(a, b); p2 = p1; p3 = p1; return;
-#endif
     p1 = pack_bf16(a, b);
     const float a1 = __builtin_bit_cast(float, p1 << 16), b1 = __builtin_bit_cast(float, p1 & 0xffff0000u);
     const float ra = sub_f32(a, a1), rb = sub_f32(b, b1);
@@ -644,8 +642,8 @@ int vag_gemm_group_end(hipStream_t stream) {
 int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
                     const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc,
                     const float* bias, int act, hipStream_t stream, int c_half) {
-    const bool opt_f32mfma = getenv("VAG_GEMM_F32MFMA") != nullptr;      // read per call: the parity tests flip it
-    static const bool opt_nogroup = getenv("VAG_GEMM_NOGROUP") != nullptr;
+    const bool opt_f32mfma = vag_opt().gemm_f32mfma != 0;      // vag_set_option("gemm_f32mfma"): the bf16x6 bound test flips it
+    const bool opt_nogroup = vag_opt().gemm_nogroup != 0;
     VAG_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && A && B && C);
     if (M == 0 || N == 0) return VAG_OK;
     VAG_CHECK_ARG(M < (1ll << 30) && N < (1ll << 30) && K < (1ll << 30));
@@ -658,7 +656,7 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     g.sa_o = sam; g.sa_k = sak; g.sb_o = sbn; g.sb_k = sbk;
     g.ldc = ldc; g.M = (int)M; g.N = (int)N; g.K = (int)K;
     g.alpha = alpha; g.beta = beta; g.act = act; g.c_half = c_half;
-    VAG_CHECK_ARG(!c_half || (beta == 0.f && M > 64 && N > 64 && !opt_f32mfma));      // fp16 output: bf16x6 kernels only
+    VAG_CHECK_ARG(!c_half || beta == 0.f);      // fp16 output: plain stores only (no split-K, no accumulation)
     const int64_t lda = akc ? sam : sak, ldb = bkc ? sbn : sbk;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     const int lay = (akc ? 2 : 0) + (bkc ? 1 : 0);
@@ -674,8 +672,8 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     double best = 1e30;
     int64_t T = 64, splitk = 1;
     // bytes/us of split-K partial sums landing as fp32 atomics (fitted: tools/exp_gemm_sweep.py; 1e6 was too pessimistic)
-    static const double atomic_rate = getenv("VAG_GEMM_ATOMIC") ? atof(getenv("VAG_GEMM_ATOMIC")) : 3.0e6;
-    for (int64_t t = (c_half ? 128 : 64); t <= 128; t *= 2) {
+    const double atomic_rate = 3.0e6;
+    for (int64_t t = 64; t <= 128; t *= 2) {
         if (t == 128 && (M <= 64 || N <= 64)) continue;
         const double eff = (t == 128) ? (opt_f32mfma ? 0.62 : 0.64) : 0.42;   // fraction of the f32-MFMA peak
         const int64_t base = cdiv64(M, t) * cdiv64(N, t);
@@ -700,11 +698,11 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
             if (cost < best) { best = cost; T = t; splitk = sp; }
         }
     }
-    if (const char* f = getenv("VAG_GEMM_FORCE")) {          // tuning hook: "T,splitk"
-        int ft = 0, fs = 0;
-        if (sscanf(f, "%d,%d", &ft, &fs) == 2 && (ft == 64 || ft == 128) && fs >= 1 && (fs == 1 || can_split)) { T = ft; splitk = fs; }
+    {          // tuning hook: vag_set_option("gemm_force_tile" / "gemm_force_splitk")
+        const int ft = vag_opt().gemm_force_tile, fs = vag_opt().gemm_force_splitk;
+        if ((ft == 64 || ft == 128) && fs >= 1 && (fs == 1 || can_split)) { T = ft; splitk = fs; }
     }
-    if (getenv("VAG_GEMM_DEBUG"))
+    if (vag_opt().gemm_debug)
         fprintf(stderr, "[vag_gemm] M=%lld N=%lld K=%lld akc=%d bkc=%d beta=%g -> T=%lld splitk=%lld model=%.1f us\n",
                 (long long)M, (long long)N, (long long)K, (int)akc, (int)bkc, (double)beta, (long long)T, (long long)splitk, best);
     const bool big = (T == 128);
@@ -824,14 +822,10 @@ __device__ __forceinline__ void skinny_mma(const float* const (&ap)[MT], const f
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     // lane group g supplies k = 4g+e to MFMA e; A and W use the same k order, so the sum is exact.
-#ifdef VAG_EXP_NO_MFMA      // timing experiment only (wrong results): how much of a chain launch is matrix-pipe time
-                    acc[i][j][0][0] += av[i][u].x + wv[j][u].x + av[i][u].y + wv[j][u].y + av[i][u].z + wv[j][u].z + av[i][u].w + wv[j][u].w;
-#else
                     acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][u].x, wv[j][u].x, acc[i][j][0], 0, 0, 0);
                     acc[i][j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][u].y, wv[j][u].y, acc[i][j][1], 0, 0, 0);
                     acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][u].z, wv[j][u].z, acc[i][j][0], 0, 0, 0);
                     acc[i][j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][u].w, wv[j][u].w, acc[i][j][1], 0, 0, 0);
-#endif
                 }
     }
 #pragma unroll
@@ -1169,119 +1163,6 @@ int vag_attn_dot_side_launch(int mode, const float* x, const float* q, int64_t l
         if (mode == 0) hipLaunchKernelGGL((attn_dot_side_kernel<0, 8>), grid, dim3(512), 0, stream, d, a, tiles_x);
         else hipLaunchKernelGGL((attn_dot_side_kernel<1, 16>), grid, dim3(1024), 0, stream, d, a, tiles_x);
     }
-    VAG_LAUNCH_CHECK();
-    return VAG_OK;
-}
-
-// Forward decoder step, launch 2 of 3: the attention query q = attn_h h1 and the attention scores in ONE grid.
-// A score is a sum over the C key columns, score[b,s] = sum_c v_c tanh(pe[b,s,c] + q[b,c]), so the workgroup that has just
-// finished a 16-row x 16-column tile of q can add up ITS 16 columns' share of the scores of its 16 rows at once -- no
-// workgroup has to wait for a whole row of q, which is what used to cost a kernel boundary between the two.  The C/16
-// partial sums per score are added by the consumer (attn_ctx_gru_kernel) while its value rows are in flight.  The side
-// product of the old scores launch (W_hh2 h1 + b_hh2, not needed before the cell) rides in the same grid as before.
-// Blocks [0, nq) are the q tiles (tile x = column tile, y = row tile), the rest are 16x16 tiles of the side product.
-// spart (N, ntile, Ts): partial score of row n, column tile, position s.  Masking is the consumer's.
-#ifndef VAG_QSCORE_XCD
-#define VAG_QSCORE_XCD 1
-#endif
-struct QScoreArgs {
-    const float* x; const float* v; float* spart;     // x (B,Ts,W) keys (fp32 or fp16), v (W)
-    int Ts, W, nq, qtiles_x;
-};
-template <int WAVES, bool S16>
-__global__ __launch_bounds__(64 * WAVES) void attn_qscore_side_kernel(QScoreArgs d, SkinnyArgs q, SkinnyArgs a, int tiles_x) {
-    __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4];
-    __shared__ float qs[16][17];
-    const int id = blockIdx.x;
-    if (id >= d.nq) {
-        const int t = id - d.nq;
-        skinny_plain_body<WAVES, 4, S16>(a, red, t % tiles_x, t / tiles_x);
-        return;
-    }
-    // Neighbouring column tiles read the two halves of the same 128-byte key lines: keep them on one XCD (workgroup i runs
-    // on XCD i % 8) so that the second half is an L2 hit instead of a second fetch into another XCD's L2.
-    int f = id;
-    if ((d.nq & 7) == 0 && VAG_QSCORE_XCD) f = (id & 7) * (d.nq >> 3) + (id >> 3);
-    const int bx = f % d.qtiles_x, by = f / d.qtiles_x;
-    const int lane = threadIdx.x & 63;
-    const int r = skinny_ldrow(lane), g = skinny_ldseg(lane);
-    const int m0 = by * 16, nb = bx * 16;
-    // this thread's (row, position) pairs and 4 of the tile's 16 columns: requested before the product, used after it
-    constexpr int PAIRS = WAVES * 16;              // pairs per pass of the block
-    constexpr int PRE = 6;                          // passes kept in registers (Ts <= PRE * PAIRS / 16 = 48 at 8 waves)
-    const int c4 = threadIdx.x & 3, pr = threadIdx.x >> 2;
-    const int col = nb + 4 * c4;
-    const bool cok = col < d.W;
-    const int npair = 16 * d.Ts;
-    float4 xv[PRE];
-#pragma unroll
-    for (int i = 0; i < PRE; ++i) {
-        const int p = pr + i * PAIRS;
-        xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p < npair && cok) {
-            const int rr = p / d.Ts, s = p - rr * d.Ts;
-            const int64_t row = min(m0 + rr, q.M - 1);
-            xv[i] = ld4_any<S16>(d.x, (row * d.Ts + s) * (int64_t)d.W + col);
-        }
-    }
-    const float4 vv = cok ? *reinterpret_cast<const float4*>(d.v + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* ap[1];
-    const float* wp[1];
-    ap[0] = q.A + (int64_t)min(m0 + r, q.M - 1) * q.lda + skinny_koff<S16>(g);
-    wp[0] = skinny_wptr<S16>(q.W, min(nb + r, q.N - 1), q.ldw, skinny_koff<S16>(g));
-    skinny_mma_any<WAVES, 1, 1, 4, S16>(ap, wp, q.K, red);
-    if (threadIdx.x < 256) {
-        const int erow = (threadIdx.x >> 4) & 15, ecol = threadIdx.x & 15;
-        const float val = skinny_sum1<WAVES, 1>(red, 0, erow, ecol);
-        qs[erow][ecol] = val;
-        if (m0 + erow < q.M && nb + ecol < q.N) q.out[(int64_t)(m0 + erow) * q.ldo + nb + ecol] = val;      // saved for the backward
-    }
-    __syncthreads();
-    for (int p0 = 0; p0 < npair; p0 += PAIRS * PRE) {
-#pragma unroll
-        for (int i = 0; i < PRE; ++i) {
-            const int p = p0 + pr + i * PAIRS;
-            const int rr = min(p, npair - 1) / d.Ts, s = min(p, npair - 1) - rr * d.Ts;
-            float4 x = xv[i];
-            if (p0 > 0) {        // positions beyond the preloaded passes (long sources)
-                x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p < npair && cok) x = ld4_any<S16>(d.x, ((int64_t)min(m0 + rr, q.M - 1) * d.Ts + s) * (int64_t)d.W + col);
-            }
-            const float* qr = &qs[rr][4 * c4];
-            float acc = vv.x * vag_tanh(x.x + qr[0]) + vv.y * vag_tanh(x.y + qr[1]) + vv.z * vag_tanh(x.z + qr[2]) +
-                        vv.w * vag_tanh(x.w + qr[3]);
-            if (!cok) acc = 0.f;
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            if (c4 == 0 && p < npair && m0 + rr < q.M)
-                d.spart[((int64_t)(m0 + rr) * d.qtiles_x + bx) * d.Ts + s] = acc;
-        }
-    }
-}
-// q (M, Nq) = A (M,K) Wq^T -> qout (row stride ldq), spart (M, ceil(Nq/16), Ts) partial scores against the keys x (M,Ts,Nq);
-// side product P (M,Np) = A Wt^T + pbias (row stride ldp).  One source row per query row.
-int vag_attn_qscore_side_launch(const float* x, const float* v, int64_t Ts, const float* A, int64_t lda, int64_t M, int64_t K,
-                                const float* Wq, int64_t ldwq, int64_t Nq, float* qout, int64_t ldq, float* spart,
-                                const float* Wt, int64_t ldwt, int64_t Np, const float* pbias, float* P, int64_t ldp,
-                                hipStream_t stream, bool s16) {
-    VAG_CHECK_ARG(x && v && A && Wq && qout && spart && Wt && P && M > 0 && Ts > 0 && Nq > 0 && Np > 0 && Nq % 4 == 0);
-    VAG_CHECK_ARG(aligned16(x) && aligned16(v) && skinny_ok(A, lda, Wq, ldwq, K) && skinny_ok(A, lda, Wt, ldwt, K));
-    VAG_CHECK_ARG(!s16 || K % 8 == 0);
-    QScoreArgs d;
-    d.x = x; d.v = v; d.spart = spart; d.Ts = (int)Ts; d.W = (int)Nq;
-    d.qtiles_x = (int)cdiv64(Nq, 16);
-    const int64_t qtiles_y = cdiv64(M, 16);
-    VAG_CHECK_ARG(d.qtiles_x * qtiles_y < (1ll << 30));
-    d.nq = (int)(d.qtiles_x * qtiles_y);
-    SkinnyArgs q;
-    q.A = A; q.W = Wq; q.lda = lda; q.ldw = ldwq; q.M = (int)M; q.N = (int)Nq; q.K = (int)K;
-    q.bias = nullptr; q.addend = nullptr; q.ldadd = 0; q.out = qout; q.ldo = ldq; q.act = VAG_ACT_NONE;
-    SkinnyArgs a = q;
-    a.W = Wt; a.ldw = ldwt; a.N = (int)Np; a.bias = pbias; a.out = P; a.ldo = ldp;
-    const int tiles_x = (int)cdiv64(Np, 16), tiles_y = (int)cdiv64(M, 16);
-    const dim3 grid((unsigned)(d.nq + tiles_x * tiles_y));
-    if (s16) hipLaunchKernelGGL((attn_qscore_side_kernel<8, true>), grid, dim3(512), 0, stream, d, q, a, tiles_x);
-    else hipLaunchKernelGGL((attn_qscore_side_kernel<8, false>), grid, dim3(512), 0, stream, d, q, a, tiles_x);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
@@ -1651,9 +1532,9 @@ int vag_gru_step_launch(const GruStepArgs& a, int nz, hipStream_t stream, bool w
     // tile choice from measurements (tools/exp_tiles.py, tools/skinny_probe.hip): 16 units x 16 rows; half tiles on
     // twice the CUs were no faster (the launch is paced by load requests issued chip-wide, duplicates included).
     dim3 grid((unsigned)cdiv64(a.H, 16), (unsigned)cdiv64(a.M, 16), (unsigned)nz);
-    static const int small = getenv("VAG_GRU_UNITS") ? atoi(getenv("VAG_GRU_UNITS")) : 8;
+    constexpr int small = 8;
     const int64_t wgs = (int64_t)grid.x * grid.y * grid.z;
-    static const int64_t maxwg = getenv("VAG_GRU_SMALL_MAXWG") ? atoi(getenv("VAG_GRU_SMALL_MAXWG")) : 160;
+    constexpr int64_t maxwg = 160;
     if (a.K > 256 && wgs <= maxwg && (small == 8 || small == 4)) {
         // fewer than ~2/3 of the CUs would get a workgroup: fewer units each on more workgroups
         const dim3 g8((unsigned)cdiv64(a.H, 8), grid.y, grid.z), g4((unsigned)cdiv64(a.H, 4), grid.y, grid.z);
@@ -1668,7 +1549,7 @@ int vag_gru_step_launch(const GruStepArgs& a, int nz, hipStream_t stream, bool w
         return VAG_OK;
     }
     // wide batches: two row tiles per workgroup (half the W re-reads) as long as >= 256 workgroups remain
-    static const int opt_wide = getenv("VAG_GRU_FWD_WIDE") ? atoi(getenv("VAG_GRU_FWD_WIDE")) : 1;
+    constexpr int opt_wide = 1;
     if (opt_wide && a.M >= 128 && a.K > 256 && (int64_t)grid.x * cdiv64(a.M, 32) * nz >= 256) {
         const dim3 gw(grid.x, (unsigned)cdiv64(a.M, 32), grid.z);
         if (w16) hipLaunchKernelGGL((gru_step_kernel<8, true, 2>), gw, dim3(512), 0, stream, a);
@@ -1696,7 +1577,7 @@ int vag_gru_bwd_step_launch(const GruBwdStepArgs& a, int nz, hipStream_t stream,
     }
     VAG_CHECK_ARG(!w16 || (a.K % 8 == 0 && a.ldw % 8 == 0));
     // wide shapes (M >= 128 rows and still >= 256 workgroups): 2 x 2 tiles per workgroup halve the operand re-reads
-    static const int opt_wide = getenv("VAG_GRU_BWD_WIDE") ? atoi(getenv("VAG_GRU_BWD_WIDE")) : 1;
+    constexpr int opt_wide = 1;
     if (opt_wide && a.M >= 128 && a.K > 1024 && cdiv64(a.H, 32) * cdiv64(a.M, 32) * nz >= 256) {
         dim3 gw((unsigned)cdiv64(a.H, 32), (unsigned)cdiv64(a.M, 32), (unsigned)nz);
         if (w16) hipLaunchKernelGGL((gru_bwd_step_kernel<16, 4, true, 2, 2>), gw, dim3(1024), 0, stream, a);

@@ -79,13 +79,7 @@ int vag_attn_scores_ex_launch(int mode, const float* pe, const float* q, int64_t
                               float* scores, hipStream_t s);
 int vag_attn_ctx_gru_launch(const float* scores, const float* encwp, int64_t N, int64_t rps, int64_t Ts, int64_t H,
                             const float* b_ih, const float* hp, int64_t ldhp, const float* hprev, float* alpha, float* hout,
-                            float* save, hipStream_t s, bool x16 = false, const float* spart = nullptr, int64_t ntile = 0,
-                            const float* mask = nullptr);      // spart: scores as (N, ntile, Ts) partial sums, masked here      // x16: encwp is fp16
-// scores + softmax + projected context + gru_2 cell in one launch (training sizes: see vag_attn_fused_fwd_ok)
-bool vag_attn_fused_fwd_ok(int64_t Ts, int64_t H, int64_t ldq, int64_t ldhp);
-int vag_attn_fused_fwd_launch(const float* pe, const float* q, int64_t ldq, const float* v, const float* mask,
-                              const float* encwp, const float* b_ih, const float* hp, int64_t ldhp, const float* hprev,
-                              int64_t N, int64_t Ts, int64_t H, float* alpha, float* hout, float* save, hipStream_t s);
+                            float* save, hipStream_t s, bool x16 = false);      // x16: encwp is fp16
 int vag_attn_wsum_launch(int over_src, const float* a, const float* x, int64_t B, int64_t Ts, int64_t T, int64_t W, float* out,
                          hipStream_t s);
 // softmax=1: alpha[n,:] = softmax(scores[n,:]) (written to alpha), ctx[n,c] = sum_s alpha[n,s] enc[b,s,c]
@@ -158,6 +152,8 @@ int vag_beam_finish_launch(const float* nll, const int64_t* beam, int64_t max_le
 // ---------------- api.hip internals shared with step.hip ----------------
 void vag_set_derived_override(const float* d);
 void vag_set_store16(bool on);
+const float* vag_get_derived_override();
+bool vag_get_store16();
 void vag_set_head_chunk(int64_t rows);
 void vag_set_head_fuse(const vag_head_g* g, const float* d_loss, float* dt);
 int vag_dec_init_bwd_impl(const float* mask, const float* xmix, const float* h0, float split, const float* W, float* d_h0,
@@ -174,54 +170,6 @@ int vag_head_ce_seq_fwd_impl(const float* h2_all, const float* c_all, const floa
                              float* nll, float* inv_cnt, int inv_cnt_ready, float* loss_mt, float* losses, float w_mt,
                              float w_vse, int has_vse, hipStream_t s);
 
-// ---------------- sched.hip: CU-partitioned streams for the overlapped step ----------------
-#include <functional>
-int vag_sched_streams(hipStream_t* chain, hipStream_t* side);
-int vag_sched_order(hipStream_t from, hipStream_t to);
-int vag_sched_mark(hipStream_t from, hipEvent_t* out);
-int vag_sched_wait(hipStream_t to, hipEvent_t e);
-bool vag_sched_tracing();
-void vag_sched_trace(hipStream_t s, const char* label, int64_t idx = -1);
-void vag_sched_trace_dump();
-// Hooks of the time loops (decoder forward, decoder backward, encoder forward/backward), set by the overlapped step driver
-// for the calling thread: the loop's launches go to `chain` (forked from the operator's stream before the first step and
-// joined to it after the last), `before(t)` / `after(t)` run on the host around each time step's launches (they record /
-// wait events and enqueue the side stream's work).  skip_bulk: the loop's operator leaves out the all-steps work that the
-// hooks do chunk by chunk instead (decoder forward: the contexts; decoder backward: d alpha through the head).
-struct VagLoopHooks {
-    hipStream_t chain = nullptr;
-    std::function<int(int64_t)> before, after;
-    bool skip_bulk = false;
-};
-void vag_set_loop_hooks(const VagLoopHooks* h);
-const VagLoopHooks* vag_loop_hooks();
-struct VagHooksScope {
-    explicit VagHooksScope(const VagLoopHooks* h) { vag_set_loop_hooks(h); }
-    ~VagHooksScope() { vag_set_loop_hooks(nullptr); }
-};
-
-// The output head for the time steps [t0, t1) of a teacher-forced sequence, complete: contexts from the saved attention
-// weights, pre-activation, logits (into the chunk buffer), log-sum-exp / NLL, d(logits), the gradients w.r.t. h2 / c / e
-// and d alpha through the head's use of the context (vag_head_chunk_data); then the chunk's share of the head's parameter
-// gradients (vag_head_chunk_weights), which nothing on the backward recurrence waits for.
-struct VagHeadChunk {
-    const float *h2_all, *e_all, *enc, *alpha;
-    float* c_all;
-    vag_head_w w;
-    vag_head_g g;
-    const int64_t* tgt;
-    const float* vw;
-    int64_t B, Ts, Tt, E, H, V, ldl;
-    float p_out;
-    const uint64_t* rng;
-    float *tmid, *logits, *lse, *nll;
-    const float *inv_cnt, *d_loss;
-    float *dt, *d_h2, *d_c, *d_e, *dah;
-};
-int vag_head_chunk_data(const VagHeadChunk& k, int64_t t0, int64_t t1, hipStream_t s);
-int vag_head_chunk_weights(const VagHeadChunk& k, int64_t t0, int64_t t1, hipStream_t s);
-float* vag_cgru_ws_alpha(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H);
-float* vag_cgru_scratch_dah(float* scratch, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H);
 // decoder parameter gradients from the rows of time steps [t0, t1) (first: this chunk initialises the folded-product
 // gradient instead of adding to it), and what remains once every chunk is in
 int vag_cgru_bwd_weights_chunk(const float* h0, const int64_t* tok, vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt, int64_t E,

@@ -7,7 +7,6 @@
 // data-parallel driver cut it where a gradient bucket becomes final (after the decoder side: everything but the encoder's
 // parameters; after the encoder's backward recurrence: the rest).
 #include "../../include/vag_nmt.h"
-#include <cstdlib>
 #include <vector>
 #include "kernels.h"
 
@@ -79,11 +78,13 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(uint64_t* rng, const
 }
 
 struct DerivedScope {       // points the operators at the driver's derived weights, storage mode and head chunk for one call
-    DerivedScope(const float* d, bool store16, int64_t chunk) {
+    const float* prev_d;    // ... and puts back what the caller had set with vag_set_operator_context ("until changed")
+    bool prev16;
+    DerivedScope(const float* d, bool store16, int64_t chunk) : prev_d(vag_get_derived_override()), prev16(vag_get_store16()) {
         vag_set_derived_override(d); vag_set_store16(store16); vag_set_head_chunk(chunk);
     }
     ~DerivedScope() {
-        vag_set_derived_override(nullptr); vag_set_store16(false); vag_set_head_chunk(0); vag_set_head_fuse(nullptr, nullptr, nullptr);
+        vag_set_derived_override(prev_d); vag_set_store16(prev16); vag_set_head_chunk(0); vag_set_head_fuse(nullptr, nullptr, nullptr);
     }
 };
 
@@ -143,64 +144,18 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
         chunk = (int64_t)(671088640.0 / ((double)c.ldl * 4.0)) / c.B * c.B;
         if (chunk < c.B) chunk = c.B;
     }
-    if (const char* e = getenv("VAG_HEAD_CHUNK")) {      // rows per chunk (0 = never chunk); tests and experiments
-        chunk = c.free_run ? 0 : atoll(e);
-    }
-    // Overlapped schedule (cfg.overlap, sched.hip): the recurrences run on a stream confined to 5/8 of the CUs, the dense
-    // work that does not sit on them -- the whole output head, forward AND backward, by chunks of time steps behind the
-    // decoder's forward recurrence; the decoder's parameter gradients by chunks behind its backward recurrence -- on a
-    // stream confined to the other 3/8.  Teacher-forced steps with forward and backward in one call; must be launched
-    // eagerly (a captured fork/join loses the CU masks).
-    const bool ov = c.overlap != 0 && !c.free_run && (phases & 3) == 3 && derived != nullptr;
-    hipStream_t sa = nullptr, sb = nullptr;
-    std::vector<int64_t> bound;
-    std::vector<hipEvent_t> ev_data;
-    bool defer = true;             // head parameter gradients: all chunks at once after the last chunk (needs the full logits buffer)
-    if (ov) {
-        VAG_TRY(vag_sched_streams(&sa, &sb));
-        if (getenv("VAG_OVERLAP_MAINCHAIN")) sa = s;       // experiment: recurrences stay on the caller's (unmasked) stream
-        int64_t cs = 8;
-        if (const char* e = getenv("VAG_OVERLAP_STEPS")) cs = atoll(e);
-        if (chunk > 0) { defer = false; if (cs > chunk / c.B) cs = chunk / c.B; }
-        if (cs < 1) cs = 1;
-        // the last chunk's head is exposed (the backward recurrence starts with its gradients): keep it short
-        int64_t tail = 0;       // measured: a short last chunk costs more (small products, one more hand-off) than it exposes less
-        if (const char* e = getenv("VAG_OVERLAP_TAIL")) tail = atoll(e);
-        if (tail < 0 || tail >= c.Tt || tail > cs) tail = 0;
-        for (int64_t t = 0; t < c.Tt - tail; t += cs) bound.push_back(t);
-        if (tail > 0) bound.push_back(c.Tt - tail);
-        bound.push_back(c.Tt);
-        ev_data.resize(bound.size() - 1);
-        chunk = 0;                 // the operators' own chunking is not used on this path
-    }
-    const int nch = ov ? (int)bound.size() - 1 : 0;
-    // VAG_OVERLAP_FWD=0: only the backward half of the schedule (decoder parameter gradients beside the backward recurrence);
-    // the forward recurrence and the head run as in the single-stream step
-    const bool ov_fwd = ov && !(getenv("VAG_OVERLAP_FWD") && atoi(getenv("VAG_OVERLAP_FWD")) == 0);
+    if (vag_opt().head_chunk >= 0)      // vag_set_option("head_chunk", rows): rows per chunk (0 = never chunk); tests
+        chunk = c.free_run ? 0 : vag_opt().head_chunk;
     DerivedScope scope(derived, c.storage == 1, chunk);
     // forward and backward in one call: the chunked head finishes each chunk (d(logits) and its products) in the forward;
     // a backward called on its own (phases = 2 after an earlier phases = 1) recomputes the chunks instead
-    if (chunk > 0 && (phases & 3) == 3 && !(getenv("VAG_HEAD_FUSE") && atoi(getenv("VAG_HEAD_FUSE")) == 0))
+    if (chunk > 0 && (phases & 3) == 3 && vag_opt().head_fuse != 0)
         vag_set_head_fuse(&g.head, k.consts + 0, k.scr_head);
     const bool has_vse = mm && c.rank_kind >= 0;
     const float w_mt = mm ? c.loss_w : 1.f, w_vse = mm ? 1.f - c.loss_w : 0.f;
     float* h0 = k.hseq;                    // [h0, h2_0 .. h2_{Tt-1}] in one buffer: the W_hh1 gradient is one product
     float* h2_all = k.hseq + B * H;
     const uint64_t* crng = rng;
-    VagHeadChunk hc = {};
-    if (ov) {
-        hc.h2_all = h2_all; hc.e_all = k.e_all; hc.enc = k.enc; hc.alpha = vag_cgru_ws_alpha(k.ws_dec, B, Ts, Tt, Et, H);
-        hc.c_all = k.c_all; hc.w = w.head; hc.g = g.head; hc.tgt = tgt; hc.vw = vocab_weight;
-        hc.B = B; hc.Ts = Ts; hc.Tt = Tt; hc.E = Et; hc.H = H; hc.V = V; hc.ldl = c.ldl; hc.p_out = c.p_out; hc.rng = crng;
-        hc.tmid = k.tmid; hc.logits = k.logits; hc.lse = k.lse; hc.nll = k.nll; hc.inv_cnt = k.inv_cnt; hc.d_loss = k.consts + 0;
-        hc.dt = k.scr_head; hc.d_h2 = k.d_h2; hc.d_c = k.d_c; hc.d_e = k.d_e;
-        hc.dah = vag_cgru_scratch_dah(k.scr_dec, B, Ts, Tt, Et, H);
-    }
-    auto chunk_of_top = [&](int64_t t) { for (int i = 0; i < nch; ++i) if (bound[i + 1] - 1 == t) return i; return -1; };
-    auto chunk_of_bottom = [&](int64_t t) { for (int i = 0; i < nch; ++i) if (bound[i] == t) return i; return -1; };
-
-    const bool tr = vag_sched_tracing();       // eager launches only (timing events cannot be captured)
-    if (tr) vag_sched_trace(s, "step start");
     if (phases & 1) {
         {
             int64_t nb = cdiv64((Tt + 1) * B, 256);
@@ -222,32 +177,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
         }
         VAG_TRY(vag_dec_init_fwd(k.enc, k.mask, mm ? k.ctx : nullptr, mm ? c.init_split : 0.f, w.ini_w, w.ini_b, B, Ts, C, H,
                                  k.xmix, h0, stream));                                                  // V11.py:118
-        if (ov_fwd) {
-            VAG_TRY(vag_attn_keys_proj(k.enc, w.attn_e, B * Ts, C, k.pe, stream));                      // NMT_Decoder.py:47
-            VagLoopHooks hk;
-            hk.chain = sa == s ? nullptr : sa;
-            hk.skip_bulk = true;
-            hk.after = [&](int64_t t) -> int {          // the recurrence has finished a chunk's last step: its head, complete
-                const int i = chunk_of_top(t);
-                if (i < 0) return VAG_OK;
-                vag_sched_trace(sa, "fwd chain: chunk done", i);
-                VAG_TRY(vag_sched_order(sa, sb));
-                vag_sched_trace(sb, "side: head chunk start", i);
-                VagHeadChunk h = hc;
-                if (defer) h.logits = hc.logits + bound[i] * B * c.ldl;
-                VAG_TRY(vag_head_chunk_data(h, bound[i], bound[i + 1], sb));
-                VAG_TRY(vag_sched_mark(sb, &ev_data[i]));
-                vag_sched_trace(sb, "side: head chunk data done", i);
-                if (!defer) VAG_TRY(vag_head_chunk_weights(h, bound[i], bound[i + 1], sb));
-                return VAG_OK;
-            };
-            VagHooksScope hs(&hk);
-            vag_sched_trace(s, "decoder fwd op start");
-            VAG_TRY(vag_cgru_attn_decode_seq_fwd(k.enc, k.pe, k.mask, h0, k.tok, w.dec, B, Ts, Tt, Et, H, V, h2_all, k.c_all,
-                                                 k.e_all, k.ws_dec, 0, &w.head, c.p_out, crng, k.tmid, k.logits, c.ldl,
-                                                 stream));                                              // V11.py:138-146
-        } else {
-            if (tr) vag_sched_trace(s, "decoder fwd op start");
+        {
             // the key projection joins the decoder's per-batch products (projected keys, input projection of every step) in
             // one grouped launch: the bracket is flushed by the decoder operator's own bracket before its time loop starts.
             // (Only with the driver's derived weights: otherwise the operator first builds W_ih2 W_c2h, which the queue
@@ -259,76 +189,25 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
                                                  c.ldl, stream));                                       // V11.py:138-160
             VAG_TRY(outer.end(s));
         }
-        if (tr && !ov_fwd) vag_sched_trace(s, "main: fwd joined");
-        if (!ov_fwd)
         VAG_TRY(vag_head_ce_seq_fwd_impl(h2_all, k.c_all, k.e_all, w.head, tgt, vocab_weight, B, Tt, Et, H, V, c.p_out, crng,
                                          c.free_run ? 1 : 0, k.tmid, k.logits, c.ldl, k.lse, k.nll, k.inv_cnt, 1, nullptr,
                                          losses, w_mt, w_vse, has_vse ? 1 : 0, s));                     // V11.py:140,164-166
     }
-    if ((phases & 2) && ov) {
-        // the head's parameter gradients (all chunks in one pass over the rows) once the last chunk's data gradients are out
-        if (ov_fwd) {
-            if (defer) VAG_TRY(vag_head_chunk_weights(hc, 0, Tt, sb));
-            vag_sched_trace(sb, "side: head weights done");
-            vag_sched_trace(s, "main: fwd joined");
-            VAG_TRY(vag_sched_wait(s, ev_data[nch - 1]));
-        } else {
-            VAG_TRY(vag_head_ce_seq_bwd(h2_all, k.c_all, k.e_all, w.head, tgt, vocab_weight, B, Tt, Et, H, V, c.p_out, crng, k.tmid,
-                                        k.logits, c.ldl, k.lse, k.inv_cnt, k.consts + 0, k.d_h2, k.d_c, k.d_e, g.head,
-                                        k.scr_head, stream));
-        }
-        vag_sched_trace(s, "main: last head chunk arrived, bwd starts");
-        VagLoopHooks hk;
-        hk.chain = sa == s ? nullptr : sa;
-        hk.skip_bulk = ov_fwd;
-        hk.before = [&](int64_t t) -> int {           // entering an earlier chunk: its head gradients (long since done)
-            const int i = chunk_of_top(t);
-            return (ov_fwd && i >= 0 && i < nch - 1) ? vag_sched_wait(sa, ev_data[i]) : VAG_OK;
-        };
-        hk.after = [&](int64_t t) -> int {            // the recurrence has left a chunk: the decoder's parameter gradients of its rows
-            const int i = chunk_of_bottom(t);
-            if (i < 0) return VAG_OK;
-            vag_sched_trace(sa, "bwd chain: chunk done", i);
-            VAG_TRY(vag_sched_order(sa, sb));
-            vag_sched_trace(sb, "side: dec weights chunk start", i);
-            VagGemmGroup grp;
-            VAG_TRY(vag_cgru_bwd_weights_chunk(h0, k.tok, w.dec, B, Ts, Tt, Et, H, h2_all, k.c_all, k.e_all, k.d_e, k.ws_dec, g.dec,
-                                               k.scr_dec, bound[i], bound[i + 1], i == nch - 1, sb));
-            VAG_TRY(grp.end(sb));
-            VAG_TRY(vag_cgru_bwd_weights_scatter(k.tok, B, Ts, Tt, Et, H, g.dec, k.scr_dec, bound[i], bound[i + 1], sb));
-            vag_sched_trace(sb, "side: dec weights chunk done", i);
-            return VAG_OK;
-        };
-        {
-            VagHooksScope hs(&hk);
-            VAG_TRY(vag_cgru_attn_decode_seq_bwd_loop(k.enc, k.pe, k.mask, h0, k.tok, w.dec, B, Ts, Tt, Et, H, V, h2_all, k.c_all,
-                                                      k.e_all, k.d_h2, k.d_c, k.d_e, k.ws_dec, k.d_enc, 0, k.d_pe, k.d_h0,
-                                                      k.scr_dec, stream));
-        }
-        vag_sched_trace(s, "main: bwd loop op done");
-        VAG_TRY(vag_attn_keys_proj_bwd(k.enc, w.attn_e, k.d_pe, B * Ts, C, k.d_enc, 1, g.attn_e, stream));
-        VAG_TRY(vag_sched_order(s, sb));              // the attention vector's gradient needs the post-loop pass
-        VAG_TRY(vag_cgru_bwd_weights_finish(w.dec, B, Ts, Tt, Et, H, g.dec, k.scr_dec, true, sb));
-    }
     if (phases & 2) {
-        if (!ov)
         VAG_TRY(vag_head_ce_seq_bwd(h2_all, k.c_all, k.e_all, w.head, tgt, vocab_weight, B, Tt, Et, H, V, c.p_out, crng, k.tmid,
                                     k.logits, c.ldl, k.lse, k.inv_cnt, k.consts + 0, k.d_h2, k.d_c, k.d_e, g.head, k.scr_head,
                                     stream));
-        if (tr && !ov) vag_sched_trace(s, "main: last head chunk arrived, bwd starts");
-        if (!ov) {
+        {
             // after the backward recurrence: the products that add into d_enc (projected keys, attention keys) and the weight
             // gradients of the decoder and of attn_e are queued by layout and go out as two grouped launches
             VagGemmGroup outer(true);
             VAG_TRY(vag_cgru_attn_decode_seq_bwd_loop(k.enc, k.pe, k.mask, h0, k.tok, w.dec, B, Ts, Tt, Et, H, V, h2_all, k.c_all,
                                                       k.e_all, k.d_h2, k.d_c, k.d_e, k.ws_dec, k.d_enc, 0, k.d_pe, k.d_h0,
                                                       k.scr_dec, stream));
-            if (tr) vag_sched_trace(s, "main: bwd loop op done (its post-loop products still queued)");
             VAG_TRY(vag_attn_keys_proj_bwd(k.enc, w.attn_e, k.d_pe, B * Ts, C, k.d_enc, 1, g.attn_e, stream));
             VAG_TRY(vag_cgru_attn_decode_seq_bwd_weights(h0, k.tok, w.dec, B, Ts, Tt, Et, H, h2_all, k.c_all, k.e_all, k.d_e,
                                                          k.ws_dec, g.dec, k.scr_dec, stream));
             VAG_TRY(outer.end(s));
-            if (tr) vag_sched_trace(s, "main: decoder weight gradients done");
         }
         if (mm) {
             if (has_vse) {
@@ -353,16 +232,6 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     if (phases & 4) {
         VAG_TRY(vag_bigru_seq_bwd(src, lengths, w.enc_fw, w.enc_bw, c.p_emb, c.p_ctx, crng, B, Ts, c.Es, H, k.d_enc, k.ws_enc,
                                   g.enc_emb, g.enc_fw, g.enc_bw, stream));
-    }
-    if (tr && !ov) { vag_sched_trace(s, "step end"); vag_sched_trace_dump(); }
-    if (ov) {
-        vag_sched_trace(s, "main: all phases enqueued");
-        vag_sched_trace(sb, "side: done");
-        VAG_TRY(vag_sched_order(sb, s));              // every gradient of this call is final behind this point of the caller's stream
-        if (ov_fwd)
-            VAG_TRY(vag_loss_mt_mix_launch(k.nll, k.inv_cnt, B, Tt, losses, w_mt, w_vse, has_vse ? 1 : 0, s));  // V11.py:164-166
-        vag_sched_trace(s, "step end");
-        vag_sched_trace_dump();
     }
     return VAG_OK;
 }

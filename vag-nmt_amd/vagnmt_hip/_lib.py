@@ -41,7 +41,7 @@ class ModelW(C.Structure):
 class StepCfg(C.Structure):
     """vag_step_cfg"""
     _fields_ = [(n, I64) for n in ("B", "Ts", "Tt", "Es", "Et", "H", "S", "I", "V", "ldl")] + \
-               [(n, I32) for n in ("multimodal", "attn_method", "activation_vse", "rank_kind", "free_run", "storage", "overlap")] + \
+               [(n, I32) for n in ("multimodal", "attn_method", "activation_vse", "rank_kind", "free_run", "storage")] + \
                [(n, F) for n in ("margin", "loss_w", "init_split", "p_emb", "p_ctx", "p_out")]
 
 
@@ -106,6 +106,7 @@ PROTOS = {
     "vag_train_step": (I32, [C.POINTER(StepCfg), C.POINTER(ModelW), C.POINTER(ModelW), P, P, P, P, P, P, P, P, P, I32, P]),
     "vag_copy4": (I32, [C.POINTER(P), C.POINTER(P), C.POINTER(I64), I32, P]),
     "vag_set_operator_context": (I32, [P, I32]),
+    "vag_set_option": (I32, [C.c_char_p, I64]),
     "vag_derived_floats": (I64, [I64]),
     "vag_derive_weights": (I32, [DecW, P, P, I64, I32, P, P]),
     "vag_cgru_ws_offset": (I64, [I64, I64, I64, I64, I64, I32]),
@@ -177,3 +178,8 @@ def gru_w(w_ih, w_hh, b_ih, b_hh):
 
 def call(name, *args):
     check(getattr(lib(), name)(*args), name)
+
+
+def set_option(name, value):
+    """Debug / tuning option of the library by name (include/vag_nmt.h: vag_set_option)."""
+    check(lib().vag_set_option(name.encode(), int(value)), "vag_set_option(%s)" % name)

@@ -55,15 +55,12 @@ def model_struct(model, grad=False):
 
 
 class FusedStep:
-    def __init__(self, model, criterion_mt, criterion_vse, storage="f32", overlap=False):
-        """overlap: teacher-forced steps run the recurrences and the dense work beside them on two compute-unit-partitioned
-        streams inside the library (vag_step_cfg.overlap); such steps are launched eagerly, never captured.
-        storage: "f32", or "f16" = BASELINE configs[4]'s 2-byte storage: the recurrences' weights and the attention keys
+    def __init__(self, model, criterion_mt, criterion_vse, storage="f32"):
+        """storage: "f32", or "f16" = BASELINE configs[4]'s 2-byte storage: the recurrences' weights and the attention keys
         are kept as fp16 in HBM on teacher-forced steps (free-running steps of the same driver use fp32 storage)."""
         if storage not in ("f32", "f16"):
             raise ValueError("storage must be 'f32' or 'f16'")
         self.storage16 = storage == "f16"
-        self.overlap = bool(overlap)
         self.model = model
         self.mm = hasattr(model, "vse_imagine")
         self.vw = criterion_mt.weight
@@ -104,7 +101,6 @@ class FusedStep:
         c.rank_kind = self.rank_kind
         c.free_run = 0 if teacher else 1
         c.storage = 1 if (self.storage16 and teacher) else 0
-        c.overlap = 1 if (self.overlap and teacher) else 0
         c.margin = self.margin
         c.loss_w = float(m.loss_w) if self.mm else 1.0
         c.init_split = float(m.init_split) if self.mm else 0.0

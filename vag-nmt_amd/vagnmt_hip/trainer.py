@@ -102,7 +102,7 @@ class TrainStep:
     def __init__(self, model, criterion_mt, criterion_vse=None, lr=4e-4, weight_decay=1e-5, clip=1.0,
                  teacher_force_ratio=0.8, betas=(0.9, 0.999), eps=1e-8, vse_separate=False, use_graph=True,
                  process_group=None, world_size=1, max_graphs=48, pad_src=4, fused=None, backend=None,
-                 force_phased=False, storage="f32", overlap=False):
+                 force_phased=False, storage="f32"):
         self.model = model
         self.criterion_mt = criterion_mt
         self.criterion_vse = criterion_vse
@@ -137,11 +137,10 @@ class TrainStep:
         if backend is None and criterion_mt is not None and dev.type == "cuda":
             from .fused import FusedStep, fusable
             if (fused is None or fused) and fusable(model, criterion_mt, criterion_vse):
-                self.backend = _FusedBackend(self, FusedStep(model, criterion_mt, criterion_vse, storage=storage,
-                                                                  overlap=overlap))
+                self.backend = _FusedBackend(self, FusedStep(model, criterion_mt, criterion_vse, storage=storage))
             else:
-                if storage != "f32" or overlap:
-                    raise ValueError("fp16 storage / overlap are modes of the fused step (vag_train_step)")
+                if storage != "f32":
+                    raise ValueError("fp16 storage is a mode of the fused step (vag_train_step)")
                 self.backend = _AutogradBackend(self)
 
     def set_lr(self, lr):
@@ -198,24 +197,6 @@ class TrainStep:
 
     # ---- public ----
     def step(self, src, lengths, tgt, im=None, teacher=None):
-        f = getattr(self.backend, "f", None)
-        cur = torch.cuda.current_stream() if (f is not None and getattr(f, "overlap", False)) else None
-        if cur is not None and cur.cuda_stream == 0:
-            # The library's CU-masked streams are ordinary ("blocking") streams -- hipExtStreamCreateWithCUMask takes no
-            # flags -- so they synchronise implicitly with the NULL stream: an overlapped step driven from it is serialised
-            # (measured 9.4 ms instead of 4.7).  Run it on a stream of our own, ordered after / before the caller's.
-            if not hasattr(self, "_ov_stream"):
-                self._ov_stream = torch.cuda.Stream()
-            self._ov_stream.wait_stream(cur)
-            with torch.cuda.stream(self._ov_stream):
-                out = self._step(src, lengths, tgt, im, teacher)
-            cur.wait_stream(self._ov_stream)
-            for o in out:
-                o.record_stream(cur)
-            return out
-        return self._step(src, lengths, tgt, im, teacher)
-
-    def _step(self, src, lengths, tgt, im=None, teacher=None):
         self.model.train()
         if teacher is None:
             teacher = random.random() < self.tfr                     # models/...V11.py:136
@@ -296,8 +277,7 @@ class _FusedBackend:
                 ts._optimizer()
         if optimizer:
             key = key + (float(ts.lr),)                 # the learning rate is baked into the captured Adam launch
-        if not ts.use_graph or (f.overlap and teacher and (phases & 3) == 3):
-            # the overlapped schedule forks onto CU-masked streams, which a captured graph would not keep: always eager
+        if not ts.use_graph:
             ts.stats["eager_steps"] += 1
             return launch()
         ent = ts._graphs.get(key)
