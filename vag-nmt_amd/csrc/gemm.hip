@@ -9,7 +9,7 @@
 //                        layout (no LDS staging: each weight element is used once per workgroup),
 //                        v_mfma_f32_16x16x4_f32, LDS only for the cross-wave reduction.  Epilogues: plain
 //                        (bias/addend/tanh) and the fused GRU cell.
-#include "common.h"
+#include "gemm_shared.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstdio>
@@ -19,63 +19,6 @@ int vag_copy2d_launch(const float* in, int64_t ldi, float* out, int64_t ldo, int
 // ------------------------------------------------------------------------------------------------
 // tiled GEMM
 // ------------------------------------------------------------------------------------------------
-struct GemmArgs {
-    const float* A; const float* B; float* C; const float* bias;
-    int64_t sa_o, sa_k;   // A(m,k) = A[m*sa_o + k*sa_k]
-    int64_t sb_o, sb_k;   // B(k,n) = B[n*sb_o + k*sb_k]
-    int64_t ldc;
-    int M, N, K, kchunk;
-    float alpha, beta;
-    int act, splitk;
-    int c_half;           // 1: C is stored as fp16 (outputs that the recurrences re-read every step); needs beta == 0, no split-K
-};
-
-constexpr int BK = 32;      // k-depth of one LDS stage (one barrier per 32 of K)
-
-// Epilogue of one 32x32 accumulator (this lane: 16 rows row0 + (r&3) + 8*(r>>2) of one column; rows_left = M - row0).
-// The beta path requests all 16 old values BEFORE using any of them (a per-element load-use-store sequence costs one
-// memory round trip per element: ~15 us for a 64x64-tile product however small it is).
-__device__ __forceinline__ void gemm_epilogue16(const f32x16& acc, float* __restrict__ cbase, int64_t ldc, int rows_left,
-                                                float alpha, float beta, float bv, int act, bool atomic, int c_half = 0,
-                                                int64_t c_elem0 = 0) {
-    if (rows_left <= 0) return;
-    if (c_half) {          // fp16 output: cbase is the matrix base, c_elem0 the element index of (row0, col)
-        vag_half* ch = reinterpret_cast<vag_half*>(cbase) + c_elem0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int dr = (r & 3) + 8 * (r >> 2);
-            float v = alpha * acc[r] + bv;
-            if (act == VAG_ACT_TANH) v = vag_tanh(v);
-            if (dr < rows_left) ch[(int64_t)dr * ldc] = (vag_half)v;
-        }
-        return;
-    }
-    if (atomic) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int dr = (r & 3) + 8 * (r >> 2);
-            if (dr < rows_left) atomicAdd(cbase + (int64_t)dr * ldc, alpha * acc[r] + bv);
-        }
-        return;
-    }
-    float old[16];
-    if (beta != 0.f) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int dr = (r & 3) + 8 * (r >> 2);
-            old[r] = cbase[(int64_t)min(dr, rows_left - 1) * ldc];       // clamped: no branch around the load
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int dr = (r & 3) + 8 * (r >> 2);
-        float v = alpha * acc[r] + bv;
-        if (beta != 0.f) v += beta * old[r];
-        if (act == VAG_ACT_TANH) v = vag_tanh(v);
-        if (dr < rows_left) cbase[(int64_t)dr * ldc] = v;
-    }
-}
-
 // Load a (BT outer) x (BK k) operand tile into registers.  KC: k is the contiguous dimension.  NTH threads.
 template <int BT, bool KC, bool VEC, int NTH>
 __device__ __forceinline__ void tile_load(const float* __restrict__ P, int64_t so, int64_t sk, int o0, int k0,
@@ -228,58 +171,10 @@ __global__ __launch_bounds__(NTH) void gemm_tiled_kernel(GemmArgs a) {
 // global memory into LDS (three bf16 planes per operand), so global traffic is unchanged.
 // Block 128x128x32, 8 waves (2x4, 64x32 each), LDS single-staged (61 KB: two blocks per CU), register prefetch.
 // ------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int SP_BK = 32;
-constexpr int SP_LD = SP_BK + 8;            // bf16 elements per LDS row of a k-contiguous operand: 80 B = 20 dwords, 16-byte aligned:
-                                            // a fragment (8 consecutive k) is ONE ds_read_b128, and 16 consecutive rows tile the 64
-                                            // banks exactly once (20 r mod 64 are 16 distinct multiples of 4).  (72-byte rows made the
-                                            // compiler pair the two 8-byte halves into ds_read2_b64, which is banked over 32.)
-constexpr int SP_PLANE = 128 * SP_LD;       // bf16 elements per plane
-
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-    f32x2 v = {a, b};
-    bf16x2 h = __builtin_convertvector(v, bf16x2);     // v_cvt_pk_bf16_f32 (round to nearest even)
-    return __builtin_bit_cast(unsigned, h);
-}
-// a - b as ONE scalar v_sub_f32: under -O3 the SLP vectoriser pairs the two residuals of a split into v_pk_add_f32, and
-// packed f32 VALU beside MFMAs is an anti-lever on gfx950 (MI355X_MICROARCH.md price list: +13 cycles each): measured
-// +8-10 % on the k-contiguous products (4096^3 NT 147 -> 160 TF/s, d out.weight 96 -> 88 us).  Inline asm keeps it scalar
-// here without switching SLP off for the rest of the file (that cost the recurrent-step kernels more than it gained).
-__device__ __forceinline__ float sub_f32(float a, float b) {
-    float r;
-    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// split two floats into three packed bf16 pairs (low half = first element)
-__device__ __forceinline__ void split3(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
-    p1 = pack_bf16(a, b);
-    const float a1 = __builtin_bit_cast(float, p1 << 16), b1 = __builtin_bit_cast(float, p1 & 0xffff0000u);
-    const float ra = sub_f32(a, a1), rb = sub_f32(b, b1);
-    p2 = pack_bf16(ra, rb);
-    const float a2 = __builtin_bit_cast(float, p2 << 16), b2 = __builtin_bit_cast(float, p2 & 0xffff0000u);
-    p3 = pack_bf16(sub_f32(ra, a2), sub_f32(rb, b2));
-}
-
 // global -> registers (8 floats per thread per operand tile).
 // KC (k contiguous): two float4 = (row, 4 consecutive k) items.  OC (outer contiguous): two float4 = (k row, 4 consecutive
 // outer) items, stored as they come into the [k][outer] image (sp_oc_off) and transposed by the fragment reads.
 struct SpRegs { float v[8]; };
-// ---- outer-contiguous operands (round 2): LDS image [k][outer], 32 rows of 128 bf16 (256 B), filled with 8-byte stores of
-// four consecutive outer elements and read back TRANSPOSED by gfx950's ds_read_b64_tr_b16 (a 16-lane group fetches a
-// 4 (k) x 16 (outer) block and each lane receives one outer column's four k values): the MFMA operand's eight consecutive
-// k of one row are two such reads.  Before: eight scalar global loads per thread and operand and twelve 4-byte LDS
-// stores scattering (k, k+1) pairs into an [outer][k] image.  16-byte chunks of a row are XOR-swizzled with the row
-// (cdna_hip_programming.md T10 image (b)): without it the four rows of a transposed read hit the same banks.
-// Element offset of columns col..col+3 (col % 4 == 0) of row `row` inside a plane:
-__device__ __forceinline__ int sp_oc_off(int row, int col) {
-    const int ch = col >> 3;
-    return (256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 8 * ((col >> 2) & 1)) >> 1;
-}
-typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
-typedef bf16x4v __attribute__((address_space(3))) lds_bf16x4v;
 // k-contiguous operands: the four rows a 32-lane group writes to LDS with one 8-byte store per lane are 4 apart, not
 // consecutive: with the 80-byte row stride rows r, r+4, r+8, r+12 start at banks 0, 16, 0, 16 (mod 32) and tile the 32 banks
 // exactly twice (consecutive rows: PMC had 20 % of the LDS-active cycles as bank conflicts).
@@ -364,24 +259,6 @@ __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r
     }
 }
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 sp_frag(const __bf16* p) {      // 8 consecutive k of one row: one 16-byte LDS read
-    const uint4 v = *reinterpret_cast<const uint4*>(p);
-    const u32x4 q = {v.x, v.y, v.z, v.w};
-    return __builtin_bit_cast(bf16x8, q);
-}
-
-// One k-tile of MFMA work from the LDS planes: 2 k-steps of 16; PL = 3: six bf16 products (fp32-grade), PL = 2: three
-// (x = x1 + x2 exactly to 16 significand bits: the 2-byte storage mode, whose operands carry no more than that), PL = 1:
-// plain bf16 operands, one product (2-byte mode, the two vocabulary-sized gradient products of the head only).
-// fragment of an outer-contiguous operand: rows (outer) ob + (lane & 31), k = ks*16 + 8*(lane >> 5) .. + 7
-__device__ __forceinline__ bf16x8 sp_frag_tr(const __bf16* plane, int ob, int ks) {
-    const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
-    const int col = ob + 16 * (g & 1) + 4 * pp, kb = ks * 16 + 8 * (g >> 1);
-    const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4v*)(plane + sp_oc_off(kb + q, col)));
-    const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4v*)(plane + sp_oc_off(kb + 4 + q, col)));
-    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
 // Af / Bf: fragment base of a k-contiguous operand; As / Bs + (oa, obn): plane base and first outer index of this wave's
 // rows for an outer-contiguous one.
 template <int PL, bool AKC, bool BKC>
@@ -473,12 +350,6 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(GemmArgs a) {
 // outer-contiguous, the weight gradients g_W += dY^T X of one operator) in ONE grid.  Each of these products alone is a few dozen 128x128 tiles
 // with K = Tt*B: launched one by one they need split-K by 5-10 (atomics) to fill the chip and still pay a ramp and a
 // partial last wave each; together they fill it with split-K 1-2.
-constexpr int GROUP_MAX = 12;
-struct GemmGroupArgs {
-    GemmArgs p[GROUP_MAX];
-    int start[GROUP_MAX + 1];      // first block of each product
-    int n;
-};
 template <bool AKC, bool BKC, int PL = 3>
 __global__ __launch_bounds__(512) void gemm_split_group_kernel(GemmGroupArgs G) {
     __shared__ __attribute__((aligned(16))) __bf16 smem[6 * SP_PLANE];
@@ -562,6 +433,7 @@ static thread_local int g_group_depth = 0;
 static thread_local int g_qn[4] = {0, 0, 0, 0};
 static thread_local GemmArgs g_q[4][GROUP_MAX];
 static int vag_gemm_launch_now(const GemmArgs& q, hipStream_t stream);
+static int gemm_group_launch(const GemmArgs* q, int n, int lay, bool plane_form, hipStream_t stream);
 void vag_colsum_queue_begin();
 int vag_colsum_queue_flush(hipStream_t stream);
 void vag_colsum_queue_abort();
@@ -572,6 +444,7 @@ void vag_gemm_group_begin() {
     }
 }
 void vag_gemm_group_abort() {        // error path: drop the queues
+    vag_planes_release(true);
     g_group_depth = 0;
     for (int l = 0; l < 4; ++l) g_qn[l] = 0;
     vag_colsum_queue_abort();
@@ -580,14 +453,24 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
     const int n = g_qn[lay];
     g_qn[lay] = 0;
     if (n == 0) return VAG_OK;
-    if (n == 1) {
+    // plane-form products (gemm_planes.hip) and products that split inside the kernel go out as separate grids
+    GemmArgs part[2][GROUP_MAX];
+    int np[2] = {0, 0};
+    for (int i = 0; i < n; ++i) { const int w = g_q[lay][i].Ap ? 1 : 0; part[w][np[w]++] = g_q[lay][i]; }
+    for (int w = 0; w < 2; ++w) {
+        if (np[w] == 0) continue;
+        VAG_TRY(gemm_group_launch(part[w], np[w], lay, w == 1, stream));
+    }
+    return VAG_OK;
+}
+static int gemm_group_launch(const GemmArgs* q, int n, int lay, bool plane_form, hipStream_t stream) {
+    if (n == 1 && !plane_form) {
         const int depth = g_group_depth;       // launch directly, not back into the queue
         g_group_depth = 0;
-        const int rc = vag_gemm_launch_now(g_q[lay][0], stream);
+        const int rc = vag_gemm_launch_now(q[0], stream);
         g_group_depth = depth;
         return rc;
     }
-    const GemmArgs* q = g_q[lay];
     int64_t tiles = 0;
     for (int i = 0; i < n; ++i) tiles += cdiv64(q[i].M, 128) * cdiv64(q[i].N, 128);
     // two co-resident blocks per CU: aim at ~512 blocks; only accumulating (beta = 1) products may be split, and no
@@ -614,6 +497,7 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
     }
     G.start[n] = total;
     const bool akc = (lay & 2) != 0, bkc = (lay & 1) != 0;
+    if (plane_form) return vag_gemm_planes_group_dispatch(G, akc, bkc, g_gemm_planes, total, stream);
 #define VAG_GROUP_GO(PLN)                                                                                                     \
     if (!akc && !bkc)                                                                                                         \
         hipLaunchKernelGGL((gemm_split_group_kernel<false, false, PLN>), dim3((unsigned)total), dim3(512), 0, stream, G);     \
@@ -631,7 +515,9 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
 int vag_gemm_group_end(hipStream_t stream) {
     if (g_group_depth <= 0) return VAG_OK;
     int rc = vag_colsum_queue_flush(stream);
+    if (rc == VAG_OK) rc = vag_planes_flush_jobs(stream);        // one streaming launch splits the queued products' operands
     for (int lay = 0; lay < 4 && rc == VAG_OK; ++lay) rc = gemm_group_flush_layout(lay, stream);
+    vag_planes_release(true);                                    // every product reading the arena has been launched
     if (--g_group_depth == 0 || rc != VAG_OK) {
         if (rc != VAG_OK) vag_gemm_group_abort();
         else vag_colsum_queue_abort();           // bracket closed: later column sums launch at once
@@ -663,6 +549,7 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     if (g_group_depth > 0 && g_qn[lay] < GROUP_MAX && vec && alpha == 1.f && (beta == 0.f || beta == 1.f) &&
         act == VAG_ACT_NONE && M > 64 && N > 64 && K >= 256 && !opt_f32mfma && !opt_nogroup) {
         g.kchunk = (int)K; g.splitk = 1;
+        if (vag_opt().gemm_planes) vag_planes_attach(g, akc, bkc, g_gemm_planes, true);       // else: split inside the kernel
         g_q[lay][g_qn[lay]++] = g;
         return VAG_OK;
     }
@@ -717,6 +604,14 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     }
     dim3 grid((unsigned)cdiv64(N, T), (unsigned)cdiv64(M, T), (unsigned)splitk);
     if (big) {
+        if (!opt_f32mfma && vag_opt().gemm_planes && vag_planes_attach(g, akc, bkc, g_gemm_planes, false)) {
+            VAG_TRY(vag_planes_flush_jobs(stream));
+            const int rc = vag_gemm_planes_dispatch(g, akc, bkc, g_gemm_planes, grid, stream);
+            int queued = 0;
+            for (int l = 0; l < 4; ++l) queued += g_qn[l];
+            vag_planes_release(queued == 0);       // nothing queued reads the arena: start over; else keep the queued products' planes
+            return rc;
+        }
         if (!opt_f32mfma) return gemm_split_dispatch(g, akc, bkc, vec, grid, stream);
         // f32-input MFMA path (v_mfma_f32_32x32x2_f32), 8 waves (2 per SIMD)
         return gemm_dispatch<128, 128, 512>(g, akc, bkc, vec, grid, stream);

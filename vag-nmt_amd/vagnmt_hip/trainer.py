@@ -137,7 +137,8 @@ class TrainStep:
         if backend is None and criterion_mt is not None and dev.type == "cuda":
             from .fused import FusedStep, fusable
             if (fused is None or fused) and fusable(model, criterion_mt, criterion_vse):
-                self.backend = _FusedBackend(self, FusedStep(model, criterion_mt, criterion_vse, storage=storage))
+                self.backend = _FusedBackend(self, FusedStep(model, criterion_mt, criterion_vse, storage=storage,
+                                                             flat=self.fp.flat))
             else:
                 if storage != "f32":
                     raise ValueError("fp16 storage is a mode of the fused step (vag_train_step)")
