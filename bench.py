@@ -165,7 +165,7 @@ def measure_operators(c, dev, storage16=False):
         g = m.encoder.gru
         derived = torch.empty(_lib.lib().vag_derived_floats(H), dtype=torch.float32, device=dev)
         call("vag_derive_weights", _dec_w(m.decoder.embedding.weight, m.decoder.dec_params()), ptr(g.weight_hh_l0),
-             ptr(g.weight_hh_l0_reverse), H, 1, ptr(derived), None, stream())
+             ptr(g.weight_hh_l0_reverse), H, 1, ptr(derived), stream())
         call("vag_set_operator_context", ptr(derived), 1)
     try:
         return _measure_operators(c, dev, m, src, lens_t, tgt, im, out)

@@ -69,12 +69,6 @@ int vag_version(void);
 int vag_gemm_f32(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
                  const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc,
                  const float* bias, int act, vag_stream_t stream);
-/* The same product with a caller-owned scratch range: products with M, N > 64 then run in plane form (both operands are
- * first split into three bf16 planes inside `scratch` by one streaming pass, the main loop is LDS-DMA + MFMA only).  A
- * product whose planes do not fit (6 bytes per operand element + 1 KiB) splits inside the kernel as vag_gemm_f32 does. */
-int vag_gemm_f32_ws(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak, const float* B,
-                    int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc, const float* bias, int act, void* scratch,
-                    int64_t scratch_bytes, vag_stream_t stream);
 /* y[M,N] = act(x[M,K] W[N,K]^T + bias)  -- nn.Linear forward; picks the small-M kernel for M <= 128. */
 int vag_linear_fwd(int64_t M, int64_t N, int64_t K, const float* x, const float* W, const float* bias, int act,
                    float* y, vag_stream_t stream);
@@ -321,11 +315,13 @@ int vag_beam_finish(const float* nll, const int64_t* beam, int64_t max_len, int6
  * incremented here.  norm_out (1): total gradient norm before clipping.  scratch: VAG_ADAM_SCRATCH_BYTES, 8-byte aligned. */
 #define VAG_ADAM_SCRATCH_BYTES 2048
 /* zero_grad != 0: g is left zeroed (the next step's backward accumulates into it; no separate fill pass).
- * scratch must be zero before the FIRST call; every call leaves it ready for the next one.  Three launches. */
+ * scratch must be zero before the FIRST call; every call leaves it ready for the next one.  Three launches.
+ * lr_dev: NULL, or one DEVICE float that multiplies every seg_lr when the kernels run: with seg_lr = the groups' relative
+ * rates and *lr_dev = the current learning rate, a captured graph of this call serves every learning rate. */
 int vag_clip_adam_flat(float* p, float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
                        const float* seg_lr, const float* seg_wd, float clip, float grad_scale, float beta1,
                        float beta2, float eps, int zero_grad, int32_t* step, float* norm_out, void* scratch,
-                       vag_stream_t stream);
+                       const float* lr_dev, vag_stream_t stream);
 
 /* ---- a2 + a13: the whole training step (train.py:36-51 around models/...V11.py:82-168 and
  * NMT_Seq2Seq_Beam_V2.py:58-113) as ONE call: every operator above in the order autograd would run them, on one
@@ -370,23 +366,11 @@ typedef struct {
  * gradient bucket while phase 4 runs.  rng: {seed, step} (step is advanced by the forward phase) or NULL (no dropout).
  * derived: vag_derived_floats(H) floats kept current with vag_derive_weights() after every optimiser step, or NULL
  * (derived weights are then rebuilt inside the call).  ws: vag_step_ws_floats(cfg) floats, kept between phases. */
-/* Plane form of the parameters (round 3): the large products run on operands held as three bf16 planes (x = x1 + x2 + x3
- * exactly; six bf16 MFMA products per fp32 product, fp32-grade).  Activations are split on demand into a part of `ws`;
- * the parameters -- the caller's ONE flat fp32 buffer holding every weight -- and the derived weights are split once per
- * optimiser step by vag_derive_weights into `planes` (vag_param_plane_bytes(n_flat, H) bytes, caller-owned).  NULL
- * (or flat == NULL): weight operands are split per use like activations. */
-typedef struct {
-    const float* flat;          /* base of the flat parameter buffer (every vag_model_w pointer lies inside) */
-    int64_t n_flat;             /* its length in floats */
-    void* planes;
-} vag_param_planes;
-int64_t vag_param_plane_bytes(int64_t n_flat, int64_t H);
 int64_t vag_step_ws_floats(const vag_step_cfg* cfg);
 int64_t vag_step_ws_offset(const vag_step_cfg* cfg, int which);
 int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* w, const vag_model_g* g, const int64_t* src,
                    const int32_t* lengths, const int64_t* tgt, const float* im, const float* vocab_weight, uint64_t* rng,
-                   const float* derived, const vag_param_planes* pp, float* ws, float* losses, int phases,
-                   vag_stream_t stream);
+                   const float* derived, float* ws, float* losses, int phases, vag_stream_t stream);
 /* The per-operator entry points (vag_bigru_seq_*, vag_attn_keys_proj, vag_cgru_attn_decode_seq_*) normally rebuild the
  * derived weights inside their workspaces and use fp32 storage.  This sets, for the CALLING THREAD until changed, the
  * driver-owned derived buffer they should read instead and the storage mode (vag_step_cfg.storage); vag_train_step does the
@@ -405,7 +389,7 @@ int vag_copy4(const void* const* src, void* const* dst, const int64_t* bytes, in
  * recurrent matrices the 2-byte storage mode reads (vag_step_cfg.storage = 1; H % 8 == 0). */
 int64_t vag_derived_floats(int64_t H);
 int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_whh_bw, int64_t H, int with_fp16,
-                       float* derived, const vag_param_planes* pp, vag_stream_t stream);
+                       float* derived, vag_stream_t stream);
 
 /* ---- dropout helpers ---------------------------------------------------------------------------------- */
 /* which: 1 encoder-embedding (Ts,B,E), 2 encoder-context (B,Ts,2H), 3 decoder-output (Tt,B,E). */

@@ -1,45 +1,38 @@
-"""Experiment: TFLOP/s of vag_gemm_f32 on every large product of a cfg2 training step."""
-import sys, os
+"""The step's product shapes through vag_gemm_f32 (whole calls replayed from a graph, hot operands)."""
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "vag-nmt_amd"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "vag-nmt_amd"))
 import torch
+import bench
 from vagnmt_hip import _lib as L
+
 dev = torch.device("cuda:0")
-R = 2560
-# (name, M, N, K, layout, beta)  layout: NT = A(M,K) k-contig, B stored (N,K);  NN = B stored (K,N);  TN = A stored (K,M), B (K,N)
-SHAPES = [("enc/dec in-proj", R, 1536, 256, "NT", 0), ("attn keys pe", R, 1024, 1024, "NT", 0),
-          ("head W2", R, 256, 1024, "NT", 1), ("head W1", R, 256, 512, "NT", 0), ("logits", R, 9391, 256, "NT", 0),
-          ("dW_out", 9391, 256, R, "TN", 1), ("d tmid", R, 256, 9391, "NN", 0), ("dW2", 256, 1024, R, "TN", 1),
-          ("d_c head", R, 1024, 256, "NN", 0), ("d_h2 head", R, 512, 256, "NN", 0),
-          ("dW_hh (3HxH)", 1536, 512, R, "TN", 1), ("dW_h (CxH)", 1024, 512, R, "TN", 1), ("dWp (3HxC)", 1536, 1024, R, "TN", 0),
-          ("dW_ih2 chain", 1536, 512, 1024, "NT", 1), ("dW_c2h chain", 512, 1024, 1536, "TN", 1),
-          ("dW_ih1 (3HxE)", 1536, 256, R, "TN", 1), ("de", R, 256, 1536, "NN", 0), ("d_enc pe", R, 1024, 1024, "NN", 1),
-          ("dW_e", 1024, 1024, R, "TN", 1), ("Wp fold", 1536, 1024, 512, "NN", 0)]
-tot_t = tot_f = 0.0
-for name, M, N, K, lay, beta in SHAPES:
-    if lay == "NT":
-        A = torch.randn(M, K, device=dev); B = torch.randn(N, K, device=dev); sa = (K, 1); sb = (1, K)
-    elif lay == "NN":
-        A = torch.randn(M, K, device=dev); B = torch.randn(K, N, device=dev); sa = (K, 1); sb = (N, 1)
-    else:
-        A = torch.randn(K, M, device=dev); B = torch.randn(K, N, device=dev); sa = (1, M); sb = (N, 1)
+SHAPES = [  # name, M, N, K, a_kc, b_kc, beta
+    ("head logits", 2560, 9391, 256, True, True, 0),
+    ("attn keys", 2560, 1024, 1024, True, True, 0),
+    ("enc in-proj", 2560, 1536, 256, True, True, 0),
+    ("encwp", 2560, 1536, 1024, True, True, 0),
+    ("d tmid", 2560, 256, 9391, True, False, 0),
+    ("d out.weight", 9391, 256, 2560, False, False, 1),
+    ("g W_hh", 1536, 512, 2560, False, False, 1),
+    ("g wcat", 2560, 512, 2560, False, False, 1),
+    ("g attn_e", 1024, 1024, 2560, False, False, 1),
+    ("d_enc += d_pe attn_e", 2560, 1024, 1024, True, False, 1),
+    ("4096^3 NT", 4096, 4096, 4096, True, True, 0),
+    ("4096^3 TN", 4096, 4096, 4096, False, False, 0),
+    ("cfg5 logits chunk", 4096, 40000, 256, True, True, 0),
+    ("cfg5 keys", 20480, 2048, 2048, True, True, 0),
+]
+for name, M, N, K, a_kc, b_kc, beta in SHAPES:
+    lda, ldb = (M + 3) // 4 * 4, (N + 3) // 4 * 4
+    A = torch.randn((M, K) if a_kc else (K, lda), device=dev)
+    Bm = torch.randn((N, K) if b_kc else (K, ldb), device=dev)
     ldc = (N + 3) // 4 * 4
-    C = torch.zeros(M, ldc, device=dev)
-    def run():
-        L.call("vag_gemm_f32", M, N, K, 1.0, L.ptr(A), sa[0], sa[1], L.ptr(B), sb[0], sb[1], float(beta), L.ptr(C), ldc, None, 0, L.stream())
-    run(); torch.cuda.synchronize()
-    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
-    reps = 20
-    g = torch.cuda.CUDAGraph()           # graph replay: eager ctypes launches cost ~20 us of host time each
-    with torch.cuda.graph(g):
-        for _ in range(reps):
-            run()
-    g.replay(); torch.cuda.synchronize()
-    s.record()
-    g.replay()
-    e.record(); torch.cuda.synchronize()
-    us = s.elapsed_time(e) / reps * 1e3
+    Cm = torch.zeros(M, ldc, device=dev)
+    sa = (K, 1) if a_kc else (1, lda)
+    sb = (1, K) if b_kc else (ldb, 1)
+    fn = lambda: L.call("vag_gemm_f32", M, N, K, 1.0, L.ptr(A), sa[0], sa[1], L.ptr(Bm), sb[0], sb[1], float(beta),
+                        L.ptr(Cm), ldc, None, 0, L.stream())
+    t = bench._time_graph(fn, reps=10)
     fl = 2.0 * M * N * K
-    tot_t += us; tot_f += fl
-    print("%-16s %5dx%5dx%5d %s b%d  %8.1f us  %6.1f TF/s" % (name, M, N, K, lay, beta, us, fl / us / 1e6), flush=True)
-print("sum %.1f us, %.1f GF -> %.1f TF/s" % (tot_t, tot_f / 1e9, tot_f / tot_t / 1e6))
+    print("%-22s M=%5d N=%5d K=%5d  %8.1f us %6.1f TF" % (name, M, N, K, t * 1e6, fl / t / 1e12), flush=True)

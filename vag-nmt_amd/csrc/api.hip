@@ -98,7 +98,7 @@ int vag_set_option(const char* name, int64_t value) {
     const struct { const char* n; int* p; } ints[] = {
         {"gemm_f32mfma", &o.gemm_f32mfma}, {"gemm_nogroup", &o.gemm_nogroup}, {"gemm_force_tile", &o.gemm_force_tile},
         {"gemm_force_splitk", &o.gemm_force_splitk}, {"gemm_debug", &o.gemm_debug}, {"head_fuse", &o.head_fuse},
-        {"head_bf16_grads", &o.head_bf16_grads}, {"gemm_planes", &o.gemm_planes}, {"gemm_plane_stages", &o.gemm_plane_stages}};
+        {"head_bf16_grads", &o.head_bf16_grads}};
     for (const auto& e : ints)
         if (strcmp(name, e.n) == 0) { *e.p = (int)value; return VAG_OK; }
     if (strcmp(name, "head_chunk") == 0) { o.head_chunk = value; return VAG_OK; }
@@ -118,16 +118,6 @@ int vag_gemm_f32(int64_t M, int64_t N, int64_t K, float alpha, const float* A, i
                  int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc, const float* bias, int act,
                  vag_stream_t stream) {
     return vag_gemm_launch(M, N, K, alpha, A, sam, sak, B, sbk, sbn, beta, C, ldc, bias, act, S_(stream));
-}
-
-int vag_gemm_f32_ws(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak, const float* B,
-                    int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc, const float* bias, int act, void* scratch,
-                    int64_t scratch_bytes, vag_stream_t stream) {
-    VAG_CHECK_ARG(scratch == nullptr || (aligned16(scratch) && scratch_bytes >= 0));
-    vag_planes_set_arena(scratch, scratch_bytes);
-    const int rc = vag_gemm_launch(M, N, K, alpha, A, sam, sak, B, sbk, sbn, beta, C, ldc, bias, act, S_(stream));
-    vag_planes_set_arena(nullptr, 0);
-    return rc;
 }
 
 int vag_linear_fwd(int64_t M, int64_t N, int64_t K, const float* x, const float* W, const float* bias, int act, float* y,
@@ -159,7 +149,6 @@ int vag_embed_bwd(const int64_t* idx, int64_t n, const float* d_out, int64_t E, 
 // read: wcatT (H, C+3H), whh1T (H, 3H), encT (2 x (H, 3H): forward / reverse encoder W_hh^T).
 struct DerivedW {
     float *prep, *wcatT, *whh1T, *encT;
-    int64_t f32_total;      // floats of the fp32 part (what the plane form of the derived weights covers)
     // fp16 copies for the 2-byte storage mode (element counts in halves; each region starts 256-byte aligned):
     // wcat16 (Q,H), wcatT16 (H,Q), whh1_16 (3H,H), whh1T16 (H,3H), enc16 (2 x (3H,H)), encT16 (2 x (H,3H))
     vag_half *wcat16, *wcatT16, *whh1_16, *whh1T16, *enc16, *encT16;
@@ -173,7 +162,6 @@ static DerivedW derived_layout(float* p, int64_t H) {
     auto take = [&](int64_t n) { float* q = p ? p + o : nullptr; o += (n + 63) & ~63ll; return q; };
     auto take16 = [&](int64_t nh) { return reinterpret_cast<vag_half*>(take((nh + 1) / 2)); };
     w.prep = take(cgru_prep_total(H)); w.wcatT = take(Q * H); w.whh1T = take(3 * H * H); w.encT = take(2 * 3 * H * H);
-    w.f32_total = o;
     w.wcat16 = take16(Q * H); w.wcatT16 = take16(Q * H); w.whh1_16 = take16(3 * H * H); w.whh1T16 = take16(3 * H * H);
     w.enc16 = take16(2 * 3 * H * H); w.encT16 = take16(2 * 3 * H * H);
     w.total = o;
@@ -441,27 +429,8 @@ int vag_cgru_prepare(vag_dec_w w, int64_t H, float* prep, vag_stream_t stream) {
 // Everything the recurrences read that is a function of the parameters alone, refreshed once per optimiser step by a
 // step driver (the stand-alone operators rebuild their share per call): [attn_h; W_hh2] stacked and transposed, the
 // folded W_ih2 W_c2h, W_hh1^T, both encoder W_hh^T.  derived: vag_derived_floats(H) floats.
-// plane-form buffer of a driver: [flat parameters: 3 planes x psf][derived weights (fp32 part): 3 planes x psd] bf16
-static inline int64_t plane_stride(int64_t n) { return (n + 127) & ~127ll; }
-int64_t vag_param_plane_bytes(int64_t n_flat, int64_t H) {
-    if (n_flat <= 0 || H <= 0) return VAG_EINVAL;
-    return 3 * 2 * (plane_stride(n_flat) + plane_stride(derived_layout(nullptr, H).f32_total)) + 1024;
-}
-}  // extern "C"
-// registers the driver's plane-form regions for the calling thread (see gemm_planes.hip)
-void vag_param_planes_register(const vag_param_planes* pp, const float* derived, int64_t H) {
-    vag_planes_registry_clear();
-    if (!pp || !pp->flat || !pp->planes || pp->n_flat <= 0) return;
-    const int64_t psf = plane_stride(pp->n_flat);
-    vag_planes_register(pp->flat, pp->n_flat, pp->planes, psf);
-    if (derived) {
-        const int64_t nd = derived_layout(nullptr, H).f32_total;
-        vag_planes_register(derived, nd, reinterpret_cast<const __bf16*>(pp->planes) + 3 * psf, plane_stride(nd));
-    }
-}
-extern "C" {
 int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_whh_bw, int64_t H, int with_fp16,
-                       float* derived, const vag_param_planes* pp, vag_stream_t stream) {
+                       float* derived, vag_stream_t stream) {
     hipStream_t s = S_(stream);
     VAG_CHECK_ARG(dec_w_ok(w) && enc_whh_fw && enc_whh_bw && derived && H > 0 && H % 4 == 0 && aligned16(derived));
     const int64_t C = 2 * H, Q = C + 3 * H;
@@ -496,15 +465,7 @@ int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_wh
         };
         VAG_TRY(vag_jobs_launch(j16, 10, s));
     }
-    VAG_TRY(gemm_nn(3 * H, C, H, w.gru2.w_ih, H, w.c2h, C, 0.f, p.wp, C, s));      // Wp = W_ih2 W_c2h
-    if (pp && pp->flat && pp->planes && pp->n_flat > 0) {
-        // plane form of every parameter and of the derived weights: two streaming passes per optimiser step
-        VAG_CHECK_ARG(aligned16(pp->flat) && aligned16(pp->planes));
-        const int64_t psf = plane_stride(pp->n_flat), nd = d.f32_total;
-        VAG_TRY(vag_planes_split_region(pp->flat, pp->n_flat, pp->planes, psf, s));
-        VAG_TRY(vag_planes_split_region(derived, nd, reinterpret_cast<__bf16*>(pp->planes) + 3 * psf, plane_stride(nd), s));
-    }
-    return VAG_OK;
+    return gemm_nn(3 * H, C, H, w.gru2.w_ih, H, w.c2h, C, 0.f, p.wp, C, s);      // Wp = W_ih2 W_c2h
 }
 
 struct CgruWs {
@@ -1319,9 +1280,10 @@ int vag_beam_finish(const float* nll, const int64_t* beam, int64_t max_len, int6
 
 int vag_clip_adam_flat(float* p, float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
                        const float* seg_lr, const float* seg_wd, float clip, float grad_scale, float beta1, float beta2,
-                       float eps, int zero_grad, int32_t* step, float* norm_out, void* scratch, vag_stream_t stream) {
+                       float eps, int zero_grad, int32_t* step, float* norm_out, void* scratch, const float* lr_dev,
+                       vag_stream_t stream) {
     return vag_clip_adam_launch(p, g, m, v, n, nseg, seg_off, seg_lr, seg_wd, clip, grad_scale, beta1, beta2, eps, zero_grad,
-                                step, norm_out, scratch, S_(stream));
+                                step, norm_out, scratch, lr_dev, S_(stream));
 }
 
 int vag_copy4(const void* const* src, void* const* dst, const int64_t* bytes, int n, vag_stream_t stream) {

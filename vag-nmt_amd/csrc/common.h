@@ -96,8 +96,6 @@ struct VagOptions {
     int64_t head_chunk = -1;     // rows per chunk of the output head (-1: automatic, 0: never chunk)
     int head_fuse = 1;           // 0: the chunked head recomputes its chunks in backward instead of finishing them in forward
     int head_bf16_grads = 1;     // 2-byte storage mode: one bf16 plane in the head's two vocabulary-sized gradient products
-    int gemm_planes = 1;         // 0: never use plane-form operands (gemm_planes.hip); every product splits in the kernel
-    int gemm_plane_stages = 2;   // LDS stages of the plane-form kernel: 2 (96 KB, one block per CU) or 1 (48 KB, three)
 };
 VagOptions& vag_opt();
 
@@ -111,12 +109,6 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
                     const float* bias, int act, hipStream_t stream, int c_half = 0);   // c_half: C stored as fp16 (beta = 0)
 // out[m,n] = act(sum_k A[m,k] W[n,k] + bias[n] + addend[m,n]);  M small (decode/recurrent steps).
 void vag_gemm_set_planes(int planes);
-// plane-form operands (gemm_planes.hip), per host thread: a scratch arena for operands split on demand, and regions whose
-// owner keeps an element-wise bf16x3 split of the whole region up to date (planes[p * ps + i] = plane p of base[i])
-void vag_planes_set_arena(void* p, int64_t bytes);
-void vag_planes_registry_clear();
-void vag_planes_register(const float* base, int64_t n, const void* planes, int64_t ps);
-int vag_planes_split_region(const float* src, int64_t n, void* planes, int64_t ps, hipStream_t s);
 int vag_gemm_launch_planes(int planes, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
                            const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc, hipStream_t stream);      // 3: bf16x6 (default), 2: bf16x3 (2-byte storage mode), calling thread
 int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,

@@ -340,10 +340,36 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
     }
 }
 
+// Block -> tile mapping (round 3).  Workgroup i runs on XCD i % 8, each XCD has its own 4 MB L2, and at 128x128 fp32 tiles
+// the products sit below the L2-fill ridge (32 flop per operand byte against ~40 for six bf16 MFMA products per fp32
+// product at ~10 TB/s of fabric): what one block fetches must be shared by its L2 neighbours.  (1) every XCD gets a
+// CONTIGUOUS range of tile indices (T1, bijective form) instead of every 8th tile; (2) inside a k-slice the tiles are
+// walked in panels of 8 tile columns, row by row, so the ~64 blocks an XCD has in flight cover an ~8 x 8 patch (16 operand
+// panels for 64 tiles) instead of two full rows (34).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+__device__ __forceinline__ void tile_of(int id, int tn, int tm, int& bx, int& by, int& bz) {
+    constexpr int PW = 8;
+    const int per = tn * tm;
+    bz = id / per;
+    const int t = id - bz * per;
+    const int panel = t / (PW * tm), first = panel * PW;
+    const int w = min(PW, tn - first);
+    const int r = t - panel * PW * tm;
+    by = r / w;
+    bx = first + (r - by * w);
+}
+
 template <bool AKC, bool BKC, bool VEC, int PL = 3>
 __global__ __launch_bounds__(512) void gemm_split_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) __bf16 smem[6 * SP_PLANE];
-    gemm_split_body<AKC, BKC, VEC, PL>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    const int nwg = gridDim.x * gridDim.y * gridDim.z;
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    int bx, by, bz;
+    tile_of(xcd_remap(lin, nwg), gridDim.x, gridDim.y, bx, by, bz);
+    gemm_split_body<AKC, BKC, VEC, PL>(a, smem, bx, by, bz);
 }
 
 // Grouped launch: the blocks of up to GROUP_MAX independent products of one operand layout (e.g. all "TN": both operands
@@ -353,12 +379,13 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(GemmArgs a) {
 template <bool AKC, bool BKC, int PL = 3>
 __global__ __launch_bounds__(512) void gemm_split_group_kernel(GemmGroupArgs G) {
     __shared__ __attribute__((aligned(16))) __bf16 smem[6 * SP_PLANE];
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
     int p = 0;
-    while (p + 1 < G.n && (int)blockIdx.x >= G.start[p + 1]) ++p;
+    while (p + 1 < G.n && bid >= G.start[p + 1]) ++p;
     const GemmArgs& a = G.p[p];
-    const int id = blockIdx.x - G.start[p];
     const int tn = (a.N + 127) / 128, tm = (a.M + 127) / 128;
-    const int bx = id % tn, by = (id / tn) % tm, bz = id / (tn * tm);
+    int bx, by, bz;
+    tile_of(bid - G.start[p], tn, tm, bx, by, bz);
     gemm_split_body<AKC, BKC, true, PL>(a, smem, bx, by, bz);
 }
 
@@ -433,7 +460,6 @@ static thread_local int g_group_depth = 0;
 static thread_local int g_qn[4] = {0, 0, 0, 0};
 static thread_local GemmArgs g_q[4][GROUP_MAX];
 static int vag_gemm_launch_now(const GemmArgs& q, hipStream_t stream);
-static int gemm_group_launch(const GemmArgs* q, int n, int lay, bool plane_form, hipStream_t stream);
 void vag_colsum_queue_begin();
 int vag_colsum_queue_flush(hipStream_t stream);
 void vag_colsum_queue_abort();
@@ -444,7 +470,6 @@ void vag_gemm_group_begin() {
     }
 }
 void vag_gemm_group_abort() {        // error path: drop the queues
-    vag_planes_release(true);
     g_group_depth = 0;
     for (int l = 0; l < 4; ++l) g_qn[l] = 0;
     vag_colsum_queue_abort();
@@ -453,24 +478,14 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
     const int n = g_qn[lay];
     g_qn[lay] = 0;
     if (n == 0) return VAG_OK;
-    // plane-form products (gemm_planes.hip) and products that split inside the kernel go out as separate grids
-    GemmArgs part[2][GROUP_MAX];
-    int np[2] = {0, 0};
-    for (int i = 0; i < n; ++i) { const int w = g_q[lay][i].Ap ? 1 : 0; part[w][np[w]++] = g_q[lay][i]; }
-    for (int w = 0; w < 2; ++w) {
-        if (np[w] == 0) continue;
-        VAG_TRY(gemm_group_launch(part[w], np[w], lay, w == 1, stream));
-    }
-    return VAG_OK;
-}
-static int gemm_group_launch(const GemmArgs* q, int n, int lay, bool plane_form, hipStream_t stream) {
-    if (n == 1 && !plane_form) {
+    if (n == 1) {
         const int depth = g_group_depth;       // launch directly, not back into the queue
         g_group_depth = 0;
-        const int rc = vag_gemm_launch_now(q[0], stream);
+        const int rc = vag_gemm_launch_now(g_q[lay][0], stream);
         g_group_depth = depth;
         return rc;
     }
+    const GemmArgs* q = g_q[lay];
     int64_t tiles = 0;
     for (int i = 0; i < n; ++i) tiles += cdiv64(q[i].M, 128) * cdiv64(q[i].N, 128);
     // two co-resident blocks per CU: aim at ~512 blocks; only accumulating (beta = 1) products may be split, and no
@@ -497,7 +512,6 @@ static int gemm_group_launch(const GemmArgs* q, int n, int lay, bool plane_form,
     }
     G.start[n] = total;
     const bool akc = (lay & 2) != 0, bkc = (lay & 1) != 0;
-    if (plane_form) return vag_gemm_planes_group_dispatch(G, akc, bkc, g_gemm_planes, total, stream);
 #define VAG_GROUP_GO(PLN)                                                                                                     \
     if (!akc && !bkc)                                                                                                         \
         hipLaunchKernelGGL((gemm_split_group_kernel<false, false, PLN>), dim3((unsigned)total), dim3(512), 0, stream, G);     \
@@ -515,9 +529,7 @@ static int gemm_group_launch(const GemmArgs* q, int n, int lay, bool plane_form,
 int vag_gemm_group_end(hipStream_t stream) {
     if (g_group_depth <= 0) return VAG_OK;
     int rc = vag_colsum_queue_flush(stream);
-    if (rc == VAG_OK) rc = vag_planes_flush_jobs(stream);        // one streaming launch splits the queued products' operands
     for (int lay = 0; lay < 4 && rc == VAG_OK; ++lay) rc = gemm_group_flush_layout(lay, stream);
-    vag_planes_release(true);                                    // every product reading the arena has been launched
     if (--g_group_depth == 0 || rc != VAG_OK) {
         if (rc != VAG_OK) vag_gemm_group_abort();
         else vag_colsum_queue_abort();           // bracket closed: later column sums launch at once
@@ -549,7 +561,6 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     if (g_group_depth > 0 && g_qn[lay] < GROUP_MAX && vec && alpha == 1.f && (beta == 0.f || beta == 1.f) &&
         act == VAG_ACT_NONE && M > 64 && N > 64 && K >= 256 && !opt_f32mfma && !opt_nogroup) {
         g.kchunk = (int)K; g.splitk = 1;
-        if (vag_opt().gemm_planes) vag_planes_attach(g, akc, bkc, g_gemm_planes, true);       // else: split inside the kernel
         g_q[lay][g_qn[lay]++] = g;
         return VAG_OK;
     }
@@ -604,14 +615,6 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     }
     dim3 grid((unsigned)cdiv64(N, T), (unsigned)cdiv64(M, T), (unsigned)splitk);
     if (big) {
-        if (!opt_f32mfma && vag_opt().gemm_planes && vag_planes_attach(g, akc, bkc, g_gemm_planes, false)) {
-            VAG_TRY(vag_planes_flush_jobs(stream));
-            const int rc = vag_gemm_planes_dispatch(g, akc, bkc, g_gemm_planes, grid, stream);
-            int queued = 0;
-            for (int l = 0; l < 4; ++l) queued += g_qn[l];
-            vag_planes_release(queued == 0);       // nothing queued reads the arena: start over; else keep the queued products' planes
-            return rc;
-        }
         if (!opt_f32mfma) return gemm_split_dispatch(g, akc, bkc, vec, grid, stream);
         // f32-input MFMA path (v_mfma_f32_32x32x2_f32), 8 waves (2 per SIMD)
         return gemm_dispatch<128, 128, 512>(g, akc, bkc, vec, grid, stream);

@@ -1,5 +1,5 @@
-// Shared between gemm.hip (operands split into bf16 planes inside the kernel) and gemm_planes.hip (operands already held as
-// bf16 planes in memory): argument structs, the epilogue, the exact 3-way bf16 split and the LDS fragment reads.
+// Declarations of the LDS-tiled products of gemm.hip: argument structs, the epilogue, the exact 3-way bf16 split and the LDS
+// fragment reads (kept apart so that probes under tools/ can build against the same pieces).
 #pragma once
 #include "common.h"
 
@@ -12,10 +12,6 @@ struct GemmArgs {
     float alpha, beta;
     int act, splitk;
     int c_half;           // 1: C is stored as fp16 (outputs that the recurrences re-read every step); needs beta == 0, no split-K
-    // plane form (gemm_planes.hip): both operands already split into bf16 planes in memory -- plane p of the operand's
-    // storage element (row, col) is at Xp[p * ps + row * ld + col]; A/B above are then unused by the kernel
-    const __bf16* Ap = nullptr; const __bf16* Bp = nullptr;
-    int64_t a_ps = 0, a_ld = 0, b_ps = 0, b_ld = 0;
 };
 
 
@@ -141,11 +137,3 @@ struct GemmGroupArgs {
     int start[GROUP_MAX + 1];      // first block of each product
     int n;
 };
-
-// ---- gemm_planes.hip: products on operands held as bf16 planes (no split arithmetic in the main loop) ----
-bool vag_planes_active();
-bool vag_planes_attach(GemmArgs& g, bool akc, bool bkc, int planes, bool queued);
-int vag_planes_flush_jobs(hipStream_t s);
-void vag_planes_release(bool all);
-int vag_gemm_planes_dispatch(const GemmArgs& g, bool akc, bool bkc, int planes, dim3 grid, hipStream_t s);
-int vag_gemm_planes_group_dispatch(const GemmGroupArgs& G, bool akc, bool bkc, int planes, int total, hipStream_t s);

@@ -138,7 +138,7 @@ int vag_scale_by_dev_launch(float* x, int64_t n, const float* scalar, hipStream_
 // ---------------- optim.hip ----------------
 int vag_clip_adam_launch(float* p, float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
                          const float* seg_lr, const float* seg_wd, float clip, float grad_scale, float beta1,
-                         float beta2, float eps, int zero_grad, int32_t* step, float* norm_out, void* scratch,
+                         float beta2, float eps, int zero_grad, int32_t* step, float* norm_out, void* scratch, const float* lr_dev,
                          hipStream_t s);
 
 // ---------------- beam.hip ----------------
@@ -155,7 +155,6 @@ void vag_set_store16(bool on);
 const float* vag_get_derived_override();
 bool vag_get_store16();
 void vag_set_head_chunk(int64_t rows);
-void vag_param_planes_register(const vag_param_planes* pp, const float* derived, int64_t H);
 void vag_set_head_fuse(const vag_head_g* g, const float* d_loss, float* dt);
 int vag_dec_init_bwd_impl(const float* mask, const float* xmix, const float* h0, float split, const float* W, float* d_h0,
                           int64_t B, int64_t Ts, int64_t C, int64_t H, float* d_enc, int accumulate_enc, float* d_ctx,

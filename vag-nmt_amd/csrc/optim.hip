@@ -10,7 +10,7 @@ struct AdamScalars {          // lives in the caller's scratch (VAG_ADAM_SCRATCH
     float coef;               // grad_scale * min(1, clip / (norm + 1e-6))
     float bc1;                // 1 - beta1^t
     float bc2_sqrt;           // sqrt(1 - beta2^t)
-    float pad;
+    float lr_base;            // multiplies every segment's learning rate: *lr_dev, or 1
     // the blocks' partial sums land in 128 slots (2048 double atomics on ONE address serialise in L2: ~25 of the
     // pass's 31 us); the last block to arrive adds the slots up in a fixed order
     double part[SUMSQ_SLOTS];
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 // Scalar work between the passes (norm, clip coefficient, bias corrections in double, step counter); leaves the slots zeroed
 // for the next call, so no separate zeroing launch is needed.
 __global__ void adam_prep_kernel(AdamScalars* sc, float clip, float grad_scale, float beta1, float beta2, int32_t* step,
-                                 float* norm_out) {
+                                 float* norm_out, const float* lr_dev) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double ss = 0.0;
     for (int k = 0; k < SUMSQ_SLOTS; ++k) {                        // fixed order
@@ -71,6 +71,7 @@ __global__ void adam_prep_kernel(AdamScalars* sc, float clip, float grad_scale, 
     sc->coef = (float)(c * (double)grad_scale);
     sc->bc1 = (float)(1.0 - pow((double)beta1, (double)t));
     sc->bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)t));
+    sc->lr_base = lr_dev ? lr_dev[0] : 1.f;
     if (norm_out) norm_out[0] = (float)norm;
 }
 
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     const int64_t off = sg.off[seg], cnt = sg.cnt[seg];
     const float lr = sg.lr[seg], wd = sg.wd[seg];
     const float coef = sc->coef;
-    const float step_size = lr / sc->bc1;
+    const float step_size = lr * sc->lr_base / sc->bc1;
     const float inv_bc2s = 1.f / sc->bc2_sqrt;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) {
         const int64_t k = off + i;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 int vag_clip_adam_launch(float* p, float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
                          const float* seg_lr, const float* seg_wd, float clip, float grad_scale, float beta1,
                          float beta2, float eps, int zero_grad, int32_t* step, float* norm_out, void* scratch,
-                         hipStream_t s) {
+                         const float* lr_dev, hipStream_t s) {
     VAG_CHECK_ARG(p && g && m && v && n > 0 && nseg >= 1 && nseg <= ADAM_MAX_SEG && seg_off && seg_lr && seg_wd && step &&
                   scratch);
     VAG_CHECK_ARG(aligned16(g) && seg_off[0] == 0 && seg_off[nseg] == n);
@@ -117,7 +118,7 @@ int vag_clip_adam_launch(float* p, float* g, float* m, float* v, int64_t n, int 
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, n, sc);
     VAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, sc, clip, grad_scale, beta1, beta2, step, norm_out);
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, sc, clip, grad_scale, beta1, beta2, step, norm_out, lr_dev);
     VAG_LAUNCH_CHECK();
     AdamSegs sg;
     int64_t maxcnt = 0;

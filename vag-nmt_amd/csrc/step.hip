@@ -20,8 +20,6 @@ struct StepWs {
     float *xmix, *hseq, *c_all, *e_all, *ws_dec, *tmid, *logits, *lse, *nll, *inv_cnt, *consts;
     int64_t* tok;
     float *d_enc, *d_pe, *d_h2, *d_c, *d_e, *d_h0, *d_ctx, *d_im, *d_txt, *scr_dec, *scr_head, *scr_ini;
-    float* arena;           // plane-form operands split on demand (gemm_planes.hip)
-    int64_t arena_floats;
     int64_t total;
 };
 
@@ -46,19 +44,6 @@ StepWs step_ws(float* p, const vag_step_cfg& c) {
     w.d_enc = take(B * Ts * C); w.d_pe = take(B * Ts * C); w.d_h2 = take(R * H); w.d_c = take(R * C); w.d_e = take(R * c.Et);
     w.d_h0 = take(B * H); w.d_ctx = take(mm ? B * C : 0); w.d_im = take(mm ? B * S : 0); w.d_txt = take(mm ? B * S : 0);
     w.scr_dec = take(vag_cgru_bwd_scratch_floats(B, Ts, Tt, c.Et, H)); w.scr_head = take(R * c.Et); w.scr_ini = take(B * C);
-    // Arena of the plane-form products: the largest product group's operands as three bf16 planes (6 bytes per element).
-    // Decoder backward group: d gates (3 x 3H), [dq | dgh2] (C + 3H), d_pe / enc / c (3 x C), h1 / h_prev (2 x H), e (E) per
-    // row; the head's d(logits) (chunk rows x ldl) is the largest single operand.  Too small only costs speed: a product
-    // whose operands do not fit splits inside the kernel instead.
-    {
-        const int64_t Rm = (B * Ts > R ? B * Ts : R);
-        const int64_t per_row = 12 * H + (C + 3 * H) + 3 * C + 2 * H + 2 * c.Et + c.Es;
-        int64_t head_rows = R;
-        if ((double)R * (double)c.ldl * 4.0 > 1073741824.0) head_rows = (int64_t)(671088640.0 / ((double)c.ldl * 4.0)) + B;
-        const int64_t elems = Rm * per_row + head_rows * (c.ldl + 2 * c.Et) + (1 << 20);
-        w.arena_floats = (elems * 6 + 3) / 4;
-        w.arena = take(w.arena_floats);
-    }
     w.total = o;
     return w;
 }
@@ -95,17 +80,11 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(uint64_t* rng, const
 struct DerivedScope {       // points the operators at the driver's derived weights, storage mode and head chunk for one call
     const float* prev_d;    // ... and puts back what the caller had set with vag_set_operator_context ("until changed")
     bool prev16;
-    DerivedScope(const float* d, bool store16, int64_t chunk, const vag_param_planes* pp, int64_t H, float* arena,
-                 int64_t arena_floats)
-        : prev_d(vag_get_derived_override()), prev16(vag_get_store16()) {
+    DerivedScope(const float* d, bool store16, int64_t chunk) : prev_d(vag_get_derived_override()), prev16(vag_get_store16()) {
         vag_set_derived_override(d); vag_set_store16(store16); vag_set_head_chunk(chunk);
-        vag_param_planes_register(pp, d, H);
-        vag_planes_set_arena(arena, arena_floats * 4);
     }
     ~DerivedScope() {
         vag_set_derived_override(prev_d); vag_set_store16(prev16); vag_set_head_chunk(0); vag_set_head_fuse(nullptr, nullptr, nullptr);
-        vag_planes_registry_clear();
-        vag_planes_set_arena(nullptr, 0);
     }
 };
 
@@ -142,8 +121,7 @@ int64_t vag_step_ws_offset(const vag_step_cfg* cfg, int which) {
 
 int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_model_g* gp, const int64_t* src,
                    const int32_t* lengths, const int64_t* tgt, const float* im, const float* vocab_weight, uint64_t* rng,
-                   const float* derived, const vag_param_planes* pp, float* ws, float* losses, int phases,
-                   vag_stream_t stream) {
+                   const float* derived, float* ws, float* losses, int phases, vag_stream_t stream) {
     hipStream_t s = S_(stream);
     VAG_CHECK_ARG(cfg_ok(cfg) && wp && gp && src && lengths && tgt && vocab_weight && ws && losses && aligned16(ws));
     const vag_step_cfg& c = *cfg;
@@ -168,7 +146,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     }
     if (vag_opt().head_chunk >= 0)      // vag_set_option("head_chunk", rows): rows per chunk (0 = never chunk); tests
         chunk = c.free_run ? 0 : vag_opt().head_chunk;
-    DerivedScope scope(derived, c.storage == 1, chunk, pp, H, k.arena, k.arena_floats);
+    DerivedScope scope(derived, c.storage == 1, chunk);
     // forward and backward in one call: the chunked head finishes each chunk (d(logits) and its products) in the forward;
     // a backward called on its own (phases = 2 after an earlier phases = 1) recomputes the chunks instead
     if (chunk > 0 && (phases & 3) == 3 && vag_opt().head_fuse != 0)

@@ -38,11 +38,6 @@ class ModelW(C.Structure):
                 ("ini_w", P), ("ini_b", P), ("attn_e", P), ("dec", DecW), ("head", HeadW)]
 
 
-class ParamPlanes(C.Structure):
-    """vag_param_planes"""
-    _fields_ = [("flat", P), ("n_flat", I64), ("planes", P)]
-
-
 class StepCfg(C.Structure):
     """vag_step_cfg"""
     _fields_ = [(n, I64) for n in ("B", "Ts", "Tt", "Es", "Et", "H", "S", "I", "V", "ldl")] + \
@@ -54,7 +49,6 @@ class StepCfg(C.Structure):
 PROTOS = {
     "vag_version": (I32, []),
     "vag_gemm_f32": (I32, [I64, I64, I64, F, P, I64, I64, P, I64, I64, F, P, I64, P, I32, P]),
-    "vag_gemm_f32_ws": (I32, [I64, I64, I64, F, P, I64, I64, P, I64, I64, F, P, I64, P, I32, P, I64, P]),
     "vag_linear_fwd": (I32, [I64, I64, I64, P, P, P, I32, P, P]),
     "vag_linear_bwd": (I32, [I64, I64, I64, P, P, P, P, I32, P, I32, P, P, P]),
     "vag_embed_fwd": (I32, [P, I64, P, I64, P, P]),
@@ -106,17 +100,15 @@ PROTOS = {
     "vag_beam_step_dev": (I32, [P, I64, P, P, P, I64, P, P, P, I64, I64, I64, I64, P, P, P]),
     "vag_beam_finish": (I32, [P, P, I64, I64, I64, I64, P, P, P]),
     "vag_clip_adam_flat": (I32, [P, P, P, P, I64, I32, C.POINTER(I64), C.POINTER(F), C.POINTER(F), F, F, F, F, F, I32, P,
-                                 P, P, P]),
+                                 P, P, P, P]),
     "vag_step_ws_floats": (I64, [C.POINTER(StepCfg)]),
     "vag_step_ws_offset": (I64, [C.POINTER(StepCfg), I32]),
-    "vag_train_step": (I32, [C.POINTER(StepCfg), C.POINTER(ModelW), C.POINTER(ModelW), P, P, P, P, P, P, P,
-                             C.POINTER(ParamPlanes), P, P, I32, P]),
+    "vag_train_step": (I32, [C.POINTER(StepCfg), C.POINTER(ModelW), C.POINTER(ModelW), P, P, P, P, P, P, P, P, P, I32, P]),
     "vag_copy4": (I32, [C.POINTER(P), C.POINTER(P), C.POINTER(I64), I32, P]),
     "vag_set_operator_context": (I32, [P, I32]),
     "vag_set_option": (I32, [C.c_char_p, I64]),
     "vag_derived_floats": (I64, [I64]),
-    "vag_derive_weights": (I32, [DecW, P, P, I64, I32, P, C.POINTER(ParamPlanes), P]),
-    "vag_param_plane_bytes": (I64, [I64, I64]),
+    "vag_derive_weights": (I32, [DecW, P, P, I64, I32, P, P]),
     "vag_cgru_ws_offset": (I64, [I64, I64, I64, I64, I64, I32]),
     "vag_dropout_mask": (I32, [P, I32, I64, F, P, P]),
     "vag_rng_advance": (I32, [P, P]),

@@ -55,7 +55,7 @@ def load_checkpoint(path, model, train_step=None, map_location="cpu"):
                 fp.m[o:o + k].copy_(opt["m"][name].reshape(-1))
                 fp.v[o:o + k].copy_(opt["v"][name].reshape(-1))
             train_step.step_count.fill_(int(opt["step"]))
-        train_step.lr = opt["lr"]
+        train_step.set_lr(opt["lr"])
     if train_step is not None and hasattr(train_step.backend, "after_optimizer"):
         train_step.backend.after_optimizer()      # derived weights follow the restored parameters
     return ckpt

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from ._lib import DecW, GruW, HeadW, ModelW, ParamPlanes, StepCfg, call, gru_w, ptr, stream
+from ._lib import DecW, GruW, HeadW, ModelW, StepCfg, call, gru_w, ptr, stream
 from .state import dropout_rng
 
 
@@ -55,7 +55,7 @@ def model_struct(model, grad=False):
 
 
 class FusedStep:
-    def __init__(self, model, criterion_mt, criterion_vse, storage="f32", flat=None):
+    def __init__(self, model, criterion_mt, criterion_vse, storage="f32"):
         """storage: "f32", or "f16" = BASELINE configs[4]'s 2-byte storage: the recurrences' weights and the attention keys
         are kept as fp16 in HBM on teacher-forced steps (free-running steps of the same driver use fp32 storage)."""
         if storage not in ("f32", "f16"):
@@ -83,12 +83,6 @@ class FusedStep:
         self.w = model_struct(model, grad=False)
         self.g = model_struct(model, grad=True)
         self.derived = torch.empty(L.lib().vag_derived_floats(self.H), dtype=torch.float32, device=self.dev)
-        self.pp = None
-        if flat is not None:
-            self._flat = flat
-            nb = L.lib().vag_param_plane_bytes(flat.numel(), self.H)
-            self._planes = torch.zeros((nb + 3) // 4, dtype=torch.int32, device=self.dev)
-            self.pp = ParamPlanes(flat.data_ptr(), flat.numel(), self._planes.data_ptr())
         self.losses = torch.zeros(4, dtype=torch.float32, device=self.dev)
         self.ws = None
         self.cap = (0, 0, 0)          # (B*Ts, B*Tt, B) capacity of the static input buffers
@@ -161,7 +155,7 @@ class FusedStep:
         """Per optimiser step: the stacked / folded / transposed weights the recurrences read."""
         g = self.model.encoder.gru
         call("vag_derive_weights", self.w.dec, ptr(g.weight_hh_l0), ptr(g.weight_hh_l0_reverse), self.H,
-             1 if self.storage16 else 0, ptr(self.derived), C.byref(self.pp) if self.pp is not None else None, stream())
+             1 if self.storage16 else 0, ptr(self.derived), stream())
 
     def run(self, B, Ts, Tt, teacher, phases):
         m = self.model
@@ -172,5 +166,5 @@ class FusedStep:
             rng = dropout_rng(m, self.dev)
         call("vag_train_step", C.byref(c), C.byref(self.w), C.byref(self.g), ptr(self.src, torch.int64),
              ptr(self.lens, torch.int32), ptr(self.tgt, torch.int64), ptr(self.im) if self.mm else None, ptr(self.vw),
-             ptr(rng, torch.int64) if rng is not None else None, ptr(self.derived),
-             C.byref(self.pp) if self.pp is not None else None, ptr(self.ws), ptr(self.losses), int(phases), stream())
+             ptr(rng, torch.int64) if rng is not None else None, ptr(self.derived), ptr(self.ws), ptr(self.losses),
+             int(phases), stream())

@@ -124,6 +124,8 @@ class TrainStep:
         ns = len(self.fp.groups)
         self._seg_off = (C.c_int64 * (ns + 1))(*self.fp.seg_off)
         self._seg_wd = (C.c_float * ns)(*[weight_decay if g[2] else 0.0 for g in self.fp.groups])
+        self._seg_lr = (C.c_float * ns)(*[g[3] for g in self.fp.groups])       # relative rates; the rate itself is on the device
+        self._lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
         self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._scratch = torch.zeros(512, dtype=torch.float32, device=dev)        # VAG_ADAM_SCRATCH_BYTES, zero once
@@ -137,16 +139,19 @@ class TrainStep:
         if backend is None and criterion_mt is not None and dev.type == "cuda":
             from .fused import FusedStep, fusable
             if (fused is None or fused) and fusable(model, criterion_mt, criterion_vse):
-                self.backend = _FusedBackend(self, FusedStep(model, criterion_mt, criterion_vse, storage=storage,
-                                                             flat=self.fp.flat))
+                self.backend = _FusedBackend(self, FusedStep(model, criterion_mt, criterion_vse, storage=storage))
             else:
                 if storage != "f32":
                     raise ValueError("fp16 storage is a mode of the fused step (vag_train_step)")
                 self.backend = _AutogradBackend(self)
 
     def set_lr(self, lr):
-        """ReduceLROnPlateau equivalent hook (nmt_multimodal_beam_DE.py:335,469): lr is a host scalar per call."""
-        self.lr = lr
+        """ReduceLROnPlateau equivalent hook (nmt_multimodal_beam_DE.py:335,469).  The rate lives in a device word the
+        optimiser kernels read, so captured graphs serve every rate (a per-step schedule costs one 4-byte fill per step,
+        no re-capture)."""
+        if float(lr) != self.lr:
+            self.lr = float(lr)
+            self._lr_dev.fill_(self.lr)
 
     # ---- optimiser + collectives ----
     def _optimizer(self):
@@ -154,22 +159,19 @@ class TrainStep:
             return self.backend.optimizer()
         fp = self.fp
         ns = len(fp.groups)
-        seg_lr = (C.c_float * ns)(*[self.lr * g[3] for g in fp.groups])
-        call("vag_clip_adam_flat", ptr(fp.flat), ptr(fp.grad), ptr(fp.m), ptr(fp.v), fp.n, ns, self._seg_off, seg_lr,
+        call("vag_clip_adam_flat", ptr(fp.flat), ptr(fp.grad), ptr(fp.m), ptr(fp.v), fp.n, ns, self._seg_off, self._seg_lr,
              self._seg_wd, float(self.clip), 1.0 / self.world, self.betas[0], self.betas[1], self.eps, 1,
-             ptr(self.step_count, torch.int32), ptr(self.grad_norm), self._scratch.data_ptr(), stream())
+             ptr(self.step_count, torch.int32), ptr(self.grad_norm), self._scratch.data_ptr(), ptr(self._lr_dev), stream())
         if hasattr(self.backend, "after_optimizer"):
             self.backend.after_optimizer()
 
     def _run_optimizer(self):
-        """Clip + Adam (+ derived-weight refresh) replayed from a small graph of its own, keyed by the learning rate."""
+        """Clip + Adam (+ derived-weight refresh) replayed from a small graph of its own (one graph: the rate is a device word)."""
         if not (self.use_graph and self.fp.flat.is_cuda) or hasattr(self.backend, "optimizer"):
             return self._optimizer()
-        key = ("opt", float(self.lr))
+        key = ("opt",)
         g = self._opt_graphs.get(key)
         if g is None:
-            if len(self._opt_graphs) >= 4:
-                self._opt_graphs.clear()
             if key not in self._seen:
                 self._seen[key] = True
                 return self._optimizer()
@@ -217,7 +219,7 @@ class TrainStep:
             w0.wait()
             w1.wait()
         elif self.world == 1 and getattr(be, "with_optimizer", False) and self.use_graph:
-            # single GPU: forward, backward and the optimiser in ONE captured graph per (shape, learning rate)
+            # single GPU: forward, backward and the optimiser in ONE captured graph per shape
             be.run(src, lengths, tgt, im, teacher, 7, optimizer=True)
             return be.outputs()
         else:
@@ -277,7 +279,7 @@ class _FusedBackend:
             if optimizer:
                 ts._optimizer()
         if optimizer:
-            key = key + (float(ts.lr),)                 # the learning rate is baked into the captured Adam launch
+            key = key + ("opt",)
         if not ts.use_graph:
             ts.stats["eager_steps"] += 1
             return launch()
