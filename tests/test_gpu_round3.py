@@ -1,0 +1,63 @@
+"""GPU, round 3: the persistent recurrence kernels (persist.hip) against the per-step launch chains they replace."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(H, Vs=300, Vt=333, I=64, E=32, S=48, seed=0):
+    from machine_translation_vision.models import NMT_AttentionImagine_Seq2Seq_Beam_V11
+    torch.manual_seed(seed)
+    return NMT_AttentionImagine_Seq2Seq_Beam_V11(Vs, Vt, I, E, E, H, S, 0.99, tied_emb=True).cuda().eval()
+
+
+def _batch(B, Ts, Tt, Vs=300, Vt=333, I=64, seed=1, full=False):
+    g = torch.Generator().manual_seed(seed)
+    lens = sorted([int(x) for x in torch.randint(1, Ts + 1, (B,), generator=g)], reverse=True)
+    lens[0] = Ts
+    if full:
+        lens = [Ts] * B
+    src = torch.zeros(B, Ts, dtype=torch.long)
+    for b, L in enumerate(lens):
+        src[b, :L] = torch.randint(4, Vs, (L,), generator=g)
+    tgt = torch.randint(4, Vt, (B, Tt), generator=g)
+    tgt[:, -1] = 3
+    im = torch.randn(B, I, generator=g).abs()
+    return src.cuda(), lens, tgt.cuda(), im.cuda()
+
+
+@pytest.mark.parametrize("H,B,Ts", [(256, 64, 9), (256, 20, 5), (512, 64, 40), (512, 37, 7), (256, 1, 3), (1024, 16, 6)])
+def test_persistent_encoder_equals_launch_chain(H, B, Ts):
+    """Forward: encoder states (zeros past each row's length) and, through the saved gates / hidden states, every
+    gradient -- the persistent kernel (W_hh as bf16x3 planes in registers, six products) against the chain of per-step
+    launches (exact f32-input MFMA).  Ragged lengths, batches that are not a multiple of the 16-row tile."""
+    from vagnmt_hip import _lib as L
+    from machine_translation_vision.losses import PairwiseRankingLoss
+    src, lens, tgt, im = _batch(B, Ts, 4)
+    vw = torch.ones(333, device="cuda")
+    vw[0] = 0
+    crit = torch.nn.NLLLoss(weight=vw, reduction="none")
+    res = {}
+    for mode in (0, 1):
+        L.set_option("persistent", mode)
+        try:
+            m = _model(H)
+            enc, mask = m.encoder(src, lens)
+            loss, _, _ = m(src, lens, tgt, im, 1.0, criterion_mt=crit, criterion_vse=PairwiseRankingLoss(0.1))
+            loss.backward()
+            torch.cuda.synchronize()
+            res[mode] = (enc.detach().clone(), float(loss), {n: p.grad.detach().clone() for n, p in m.named_parameters()})
+        finally:
+            L.set_option("persistent", 1)
+    e0, l0, g0 = res[0]
+    e1, l1, g1 = res[1]
+    assert torch.isfinite(e1).all()
+    assert (e0 - e1).abs().max().item() <= 2e-6, (e0 - e1).abs().max().item()
+    for b, Lb in enumerate(lens):
+        if Lb < Ts:
+            assert float(e1[Lb:, b].abs().max()) == 0.0
+    assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0))
+    for n in g0:
+        scale = max(g0[n].abs().max().item(), 1e-3)
+        assert (g0[n] - g1[n]).abs().max().item() <= 2e-5 * scale, n

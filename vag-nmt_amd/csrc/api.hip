@@ -98,7 +98,7 @@ int vag_set_option(const char* name, int64_t value) {
     const struct { const char* n; int* p; } ints[] = {
         {"gemm_f32mfma", &o.gemm_f32mfma}, {"gemm_nogroup", &o.gemm_nogroup}, {"gemm_force_tile", &o.gemm_force_tile},
         {"gemm_force_splitk", &o.gemm_force_splitk}, {"gemm_debug", &o.gemm_debug}, {"head_fuse", &o.head_fuse},
-        {"head_bf16_grads", &o.head_bf16_grads}};
+        {"head_bf16_grads", &o.head_bf16_grads}, {"persistent", &o.persistent}};
     for (const auto& e : ints)
         if (strcmp(name, e.n) == 0) { *e.p = (int)value; return VAG_OK; }
     if (strcmp(name, "head_chunk") == 0) { o.head_chunk = value; return VAG_OK; }
@@ -173,6 +173,7 @@ static DerivedW derived_layout(float* p, int64_t H) {
 // =====================================================================================================
 struct BiGruWs {
     float *x, *xp, *hst, *gates, *dgh, *carry, *dx, *whhT;
+    unsigned* sync;                      // counters of the persistent recurrence kernels (persist.hip)
     int64_t total;
 };
 static BiGruWs bigru_ws(float* ws, int64_t B, int64_t Ts, int64_t E, int64_t H) {
@@ -187,6 +188,7 @@ static BiGruWs bigru_ws(float* ws, int64_t B, int64_t Ts, int64_t E, int64_t H) 
     w.carry = take(4 * B * H);           // backward: [dir][2][B][H]
     w.dx = take(Ts * B * E);             // backward: d(embedded input)
     w.whhT = take(2 * 3 * H * H);        // backward: W_hh^T per direction (H,3H)
+    w.sync = reinterpret_cast<unsigned*>(take(vag_enc_persistent_sync_words(B, Ts)));
     w.total = o;
     return w;
 }
@@ -212,11 +214,17 @@ int vag_bigru_seq_fwd(const int64_t* src, const int32_t* lengths, const float* e
         const VagJob zj[2] = {{nullptr, w.hst, B, H, H, H, 0}, {nullptr, w.hst + (Ts + 1) * BH, B, H, H, H, 0}};
         VAG_TRY(vag_jobs_launch(zj, 2, s));          // initial states of both directions
     }
+    const bool s16 = g_store16 && g_derived;
+    VAG_CHECK_ARG(!g_store16 || (g_derived && H % 8 == 0));
+    if (!s16 && vag_opt().persistent && vag_enc_persistent_ok(B, Ts, H)) {
+        // the whole recurrence, both directions, in ONE launch (persist.hip): W_hh stays in registers for all Ts steps
+        VAG_TRY(vag_enc_fwd_persistent_launch(w.xp, fw.w_hh, bw.w_hh, fw.b_hh, bw.b_hh, lengths, w.hst, w.gates, enc, w.sync, B,
+                                              Ts, H, s));
+        return vag_dropout_apply_launch(enc, B * Ts * 2 * H, 0, rng, VAG_DROP_ENC_CTX, p_ctx, s);
+    }
     GruStepArgs a = {};
     a.lda = H; a.ldw = H; a.ldother = 6 * H; a.ldh = H; a.ld2 = Ts * 2 * H;
     a.M = (int)B; a.K = (int)H; a.H = (int)H; a.lengths = lengths; a.comp_hidden = 1;
-    const bool s16 = g_store16 && g_derived;
-    VAG_CHECK_ARG(!g_store16 || (g_derived && H % 8 == 0));
     const vag_half* w16 = s16 ? derived_layout(const_cast<float*>(g_derived), H).enc16 : nullptr;
     for (int64_t k = 0; k < Ts; ++k) {
         for (int d = 0; d < 2; ++d) {

@@ -96,6 +96,7 @@ struct VagOptions {
     int64_t head_chunk = -1;     // rows per chunk of the output head (-1: automatic, 0: never chunk)
     int head_fuse = 1;           // 0: the chunked head recomputes its chunks in backward instead of finishing them in forward
     int head_bf16_grads = 1;     // 2-byte storage mode: one bf16 plane in the head's two vocabulary-sized gradient products
+    int persistent = 1;          // 0: the recurrences always run as chains of per-step launches (persist.hip off)
 };
 VagOptions& vag_opt();
 

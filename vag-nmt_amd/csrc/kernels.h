@@ -141,6 +141,13 @@ int vag_clip_adam_launch(float* p, float* g, float* m, float* v, int64_t n, int 
                          float beta2, float eps, int zero_grad, int32_t* step, float* norm_out, void* scratch, const float* lr_dev,
                          hipStream_t s);
 
+// ---------------- persist.hip: whole recurrences in one launch ----------------
+bool vag_enc_persistent_ok(int64_t B, int64_t Ts, int64_t H);
+int64_t vag_enc_persistent_sync_words(int64_t B, int64_t Ts);
+int vag_enc_fwd_persistent_launch(const float* xp, const float* w_fw, const float* w_bw, const float* b_fw, const float* b_bw,
+                                  const int* lengths, float* hst, float* gates, float* enc, unsigned* sync, int64_t B, int64_t Ts,
+                                  int64_t H, hipStream_t s);
+
 // ---------------- beam.hip ----------------
 int64_t vag_beam_scratch_bytes_impl(int64_t B, int64_t k, int64_t V);
 int vag_beam_step_launch(float* logp, int64_t ldl, float* nll, int64_t* beam, int64_t di, int32_t* di_state,
