@@ -26,7 +26,7 @@ namespace {
 typedef unsigned __attribute__((address_space(1))) gu32;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-constexpr unsigned SPIN_LIMIT = 1u << 22;       // polls before giving up (seconds; a healthy wait is a few hundred)
+constexpr unsigned SPIN_LIMIT = 1u << 19;       // polls before giving up (~a second; a healthy wait is a few hundred polls)
 
 struct EncPArgs {
     const float* xp;            // (Ts, B, 6H): input projections [fwd r z n | rev r z n], biases included
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_persistent_kernel(EncPArgs a) 
     gu32* cnt = (gu32*)(a.cnt + ((int64_t)d * a.RT + rt) * Ts);
     const int arow = min(m0 + fr, B - 1);                  // batch row of this lane's B-operand fragment (clamped past the edge)
     float4* red = reinterpret_cast<float4*>(lds);          // [wave][gate][lane]
+    bool dead = false;                                      // a wait gave up: stop waiting (results are void, the grid drains)
 
     for (int k = 0; k < Ts; ++k) {
         const int t = d == 0 ? k : Ts - 1 - k;
@@ -128,10 +129,10 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_persistent_kernel(EncPArgs a) 
             for (int j = 0; j < 3; ++j) xo[j] = *reinterpret_cast<const float4*>(xp + j * H);
         }
         if (k > 0) {
-            if (threadIdx.x == 0) {
+            if (threadIdx.x == 0 && !dead) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(cnt + (k - 1), RLX_AGENT) < (unsigned)a.CS) {
-                    if (++spins > SPIN_LIMIT) { __hip_atomic_store((gu32*)a.err, 1u, RLX_AGENT); break; }
+                    if (++spins > SPIN_LIMIT) { __hip_atomic_store((gu32*)a.err, 1u, RLX_AGENT); dead = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
