@@ -41,14 +41,33 @@ struct EncPArgs {
     int B, Ts, H, RT, CS;
 };
 
-__device__ __forceinline__ float4 ld_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    const __attribute__((ext_vector_type(4))) unsigned v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);
-    return make_float4(__builtin_bit_cast(float, v[0]), __builtin_bit_cast(float, v[1]), __builtin_bit_cast(float, v[2]),
-                       __builtin_bit_cast(float, v[3]));
+// N x 32 floats of one row read back from another workgroup's sc1 stores: 2 N sc1 loads of 16 bytes (k-step s: floats
+// [32 s, 32 s + 8) of p) and their wait in ONE asm statement (cdna_hip_programming.md 5.7 item 1, form (i)).  Inline asm
+// because __builtin_amdgcn_raw_buffer_load_b128 / _b64 come out as ONE buffer_load_dword whose value is used for every
+// element with this toolchain (ROCm 7.2 hipcc, gfx950; checked in the .s), and __hip_atomic_load stops at 8 bytes.
+template <int N> __device__ __forceinline__ void ld_rows_sc1(const float* p, float4 (&a)[N], float4 (&b)[N]);
+template <> __device__ __forceinline__ void ld_rows_sc1<1>(const float* p, float4 (&a)[1], float4 (&b)[1]) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a[0]), "=&v"(b[0]) : "v"(p) : "memory");
+}
+template <> __device__ __forceinline__ void ld_rows_sc1<2>(const float* p, float4 (&a)[2], float4 (&b)[2]) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:128 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:144 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a[0]), "=&v"(b[0]), "=&v"(a[1]), "=&v"(b[1]) : "v"(p) : "memory");
+}
+template <> __device__ __forceinline__ void ld_rows_sc1<4>(const float* p, float4 (&a)[4], float4 (&b)[4]) {
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %8, off offset:128 sc1\n\tglobal_load_dwordx4 %3, %8, off offset:144 sc1\n\t"
+                 "global_load_dwordx4 %4, %8, off offset:256 sc1\n\tglobal_load_dwordx4 %5, %8, off offset:272 sc1\n\t"
+                 "global_load_dwordx4 %6, %8, off offset:384 sc1\n\tglobal_load_dwordx4 %7, %8, off offset:400 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a[0]), "=&v"(b[0]), "=&v"(a[1]), "=&v"(b[1]), "=&v"(a[2]), "=&v"(b[2]), "=&v"(a[3]), "=&v"(b[3])
+                 : "v"(p) : "memory");
 }
 __device__ __forceinline__ void st_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
-    const __attribute__((ext_vector_type(4))) unsigned u = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y),
-                                                           __builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)};
+    const u32x4 u = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z),
+                     __builtin_bit_cast(unsigned, v.w)};
     __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, 16);
 }
 // 8 consecutive floats -> three bf16x8 planes
@@ -141,12 +160,7 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_persistent_kernel(EncPArgs a) 
         // ---- h_k rows of this row tile (all H columns; this wave: its K share), sc1 loads, split, six-product MFMAs
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         float4 h0[KS], h1[KS];
-        const unsigned hoff = (unsigned)((((int64_t)k * B + arow) * H + kbase + 8 * fg) * 4);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            h0[s] = ld_sc1(rs, hoff + 128 * s);
-            h1[s] = ld_sc1(rs, hoff + 128 * s + 16);
-        }
+        ld_rows_sc1<KS>(hs + ((int64_t)k * B + arow) * H + kbase + 8 * fg, h0, h1);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             bf16x8 hf[3];
