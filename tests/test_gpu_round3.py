@@ -61,3 +61,34 @@ def test_persistent_encoder_equals_launch_chain(H, B, Ts):
     for n in g0:
         scale = max(g0[n].abs().max().item(), 1e-3)
         assert (g0[n] - g1[n]).abs().max().item() <= 2e-5 * scale, n
+
+
+@pytest.mark.parametrize("B,Ts,Tt", [(64, 40, 40), (64, 12, 5), (37, 9, 7), (5, 7, 3), (16, 33, 4), (64, 50, 6)])
+def test_persistent_decoder_equals_launch_chain(B, Ts, Tt):
+    """Teacher-forced decoder forward in one launch (weights in registers, keys in LDS, four exchanges per step) against
+    the 4-launches-per-step chain: per-step outputs through the loss, the saved attention weights through every gradient
+    (the backward operators read what the forward saved).  H = 512 is the only hidden size the persistent decoder takes."""
+    from vagnmt_hip import _lib as L
+    from machine_translation_vision.losses import PairwiseRankingLoss
+    src, lens, tgt, im = _batch(B, Ts, Tt, seed=3)
+    vw = torch.ones(333, device="cuda")
+    vw[0] = 0
+    crit = torch.nn.NLLLoss(weight=vw, reduction="none")
+    res = {}
+    for mode in (0, 1):
+        L.set_option("persistent", mode)
+        try:
+            m = _model(512, seed=2)
+            loss, loss_mt, _ = m(src, lens, tgt, im, 1.0, criterion_mt=crit, criterion_vse=PairwiseRankingLoss(0.1))
+            loss.backward()
+            torch.cuda.synchronize()
+            res[mode] = (float(loss), float(loss_mt), {n: p.grad.detach().clone() for n, p in m.named_parameters()})
+        finally:
+            L.set_option("persistent", 1)
+    (l0, m0, g0), (l1, m1, g1) = res[0], res[1]
+    assert np.isfinite(l1)
+    assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0)), (l0, l1)
+    assert abs(m0 - m1) <= 2e-6 * max(1.0, abs(m0)), (m0, m1)
+    for n in g0:
+        scale = max(g0[n].abs().max().item(), 1e-3)
+        assert (g0[n] - g1[n]).abs().max().item() <= 2e-5 * scale, n

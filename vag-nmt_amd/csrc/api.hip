@@ -478,6 +478,8 @@ int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_wh
 
 struct CgruWs {
     float *xp1, *h1, *g1, *g2, *qhp, *scores, *alpha, *tmp, *prep, *encwp;
+    float* psc;                 // persistent decoder (persist.hip): the steps' scores as exchanged between workgroups (Tt,B,Ts)
+    unsigned* sync;             // ... and its counters
     int64_t total;
 };
 static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
@@ -495,6 +497,8 @@ static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, i
     w.tmp = take(B * E);
     w.prep = take(cgru_prep(nullptr, H).total);
     w.encwp = take(B * Ts * 3 * H);         // (W_ih2 W_c2h) enc[b,s,:]: the keys as gru_2 sees them, once per batch
+    w.psc = take(Tt * B * Ts);
+    w.sync = reinterpret_cast<unsigned*>(take(vag_dec_persistent_sync_words(B, Tt)));
     w.total = o;
     return w;
 }
@@ -624,6 +628,13 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
                                         h2_all + t * BH, k.g2 + t * 4 * BH, s));                            // :44, :126-129
         return VAG_OK;
     };
+    if (hoist && !s16 && vag_opt().persistent && vag_dec_persistent_ok(B, Ts, Tt, H)) {
+        // all Tt steps in ONE launch (persist.hip): weights in registers, keys in LDS, four exchanges per step
+        VAG_TRY(vag_dec_fwd_persistent_launch(pe, mask, h0, k.xp1, w.gru1.w_hh, w.gru1.b_hh, p.wcat, p.bcat, w.attn_v, k.encwp,
+                                              w.gru2.b_ih, k.h1, k.g1, k.qhp, k.alpha, h2_all, k.g2, k.psc, k.sync, B, Ts, Tt, H,
+                                              s));
+        return vag_attn_wsum_launch(1, k.alpha, enc, B, Ts, Tt, C, c_all, s);                              // all contexts :126
+    }
     for (int64_t t = 0; hoist && t < Tt; ++t) VAG_TRY(hoisted_step(t));
     if (hoist) return vag_attn_wsum_launch(1, k.alpha, enc, B, Ts, Tt, C, c_all, s);                       // all contexts :126
     for (int64_t t = 0; t < Tt; ++t) {

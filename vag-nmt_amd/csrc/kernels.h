@@ -147,6 +147,12 @@ int64_t vag_enc_persistent_sync_words(int64_t B, int64_t Ts);
 int vag_enc_fwd_persistent_launch(const float* xp, const float* w_fw, const float* w_bw, const float* b_fw, const float* b_bw,
                                   const int* lengths, float* hst, float* gates, float* enc, unsigned* sync, int64_t B, int64_t Ts,
                                   int64_t H, hipStream_t s);
+bool vag_dec_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H);
+int64_t vag_dec_persistent_sync_words(int64_t B, int64_t Tt);
+int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const float* h0, const float* xp1, const float* W1,
+                                  const float* b1, const float* wcat, const float* bcat, const float* v, const float* encwp,
+                                  const float* b_ih2, float* h1, float* g1, float* qhp, float* alpha, float* h2_all, float* g2,
+                                  float* psc, unsigned* sync, int64_t B, int64_t Ts, int64_t Tt, int64_t H, hipStream_t s);
 
 // ---------------- beam.hip ----------------
 int64_t vag_beam_scratch_bytes_impl(int64_t B, int64_t k, int64_t V);

@@ -152,7 +152,6 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_persistent_kernel(EncPArgs a) 
                 unsigned spins = 0;
                 while (__hip_atomic_load(cnt + (k - 1), RLX_AGENT) < (unsigned)a.CS) {
                     if (++spins > SPIN_LIMIT) { __hip_atomic_store((gu32*)a.err, 1u, RLX_AGENT); dead = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
                 }
             }
             __syncthreads();
@@ -204,6 +203,10 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_persistent_kernel(EncPArgs a) 
                 hp = make_float4(ho[0], ho[1], ho[2], ho[3]);
                 const int64_t o = (int64_t)em * H + eu;
                 st_sc1(rs, (unsigned)((((int64_t)(k + 1) * B) * H + o) * 4), hp);                  // h_{k+1}: read by other workgroups
+                // publish before the saves below (nobody in this launch reads those): this wave is the only one that stored
+                // h; drain, then ONE lane signals for the workgroup
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(cnt + k, 1u, RLX_AGENT);      // (lane 0 is row m0: always a valid row)
                 float* sv = a.gates + ((int64_t)(d * Ts + k) * 4) * BH + o;
                 *reinterpret_cast<float4*>(sv) = make_float4(rr[0], rr[1], rr[2], rr[3]);
                 *reinterpret_cast<float4*>(sv + BH) = make_float4(zz[0], zz[1], zz[2], zz[3]);
@@ -211,11 +214,357 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_persistent_kernel(EncPArgs a) 
                 *reinterpret_cast<float4*>(sv + 3 * BH) = c[2];
                 *reinterpret_cast<float4*>(a.enc + ((int64_t)em * Ts + t) * 2 * H + d * H + eu) = make_float4(o2[0], o2[1], o2[2], o2[3]);
             }
-            // publish: this wave is the only one that stored; drain, then ONE lane signals for the workgroup
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(cnt + k, 1u, RLX_AGENT);
         }
         // (the barrier behind the next step's wait separates wave 0's LDS reads of this step from the next step's writes)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Decoder forward recurrence, teacher forced (layers/NMT_Decoder.py:109-129 x the loop of models/...V11.py:138-146), in ONE
+// launch.  As a chain of launches a step is 4 kernels and ~24 us; every one of them re-reads, per workgroup, weights that
+// never change and keys that never change.  Here everything that is constant over the steps lives on chip:
+//   * grid = ceil(B/16) row tiles x 64 workgroups (256 at B = 64), one per CU.  Workgroup i of a row tile owns hidden units
+//     [8i, 8i+8) of both cells and attention-query columns [16i, 16i+16) for the tile's 16 batch rows;
+//   * registers: its rows of W_hh1 (24), attn_h (16) and W_hh2 (24) as bf16x3 planes in MFMA operand layout;
+//   * LDS: the attention keys pe of its share of the tile's (row, position) pairs (Ts/4 pairs x C floats) and its 24 gate
+//     columns of the projected keys encwp for all 16 x Ts pairs -- the 21 MB per step that the launch chain streams from
+//     L2 / the Infinity Cache at every step are read from memory ONCE per sequence;
+//   * a step = 4 phases with an exchange between them, each exchange = sc1 stores + counter + sc1 loads as in the encoder
+//     kernel above:   h2[t-1] -> (gru_1 cell) -> h1 -> (q = attn_h h1, hp2 = W_hh2 h1 + b) -> q -> (scores of own pairs)
+//                     -> scores -> (softmax, projected context of own columns, gru_2 cell) -> h2[t].
+// Everything the backward pass needs (h1, both cells' gates, [q | hp2], alpha, h2) is saved in the launch chain's own
+// layout, so the backward operators are unchanged.
+struct DecPArgs {
+    const float *pe, *mask, *h0, *xp1, *W1, *b1, *wcat, *bcat, *v, *encwp, *b_ih2;
+    float *h1, *g1, *qhp, *alpha, *h2_all, *g2, *psc;
+    unsigned* cnt;              // [4 phases][RT][Tt], zero on entry
+    unsigned* err;
+    int B, Ts, Tt, H, RT, np;   // np: (row, position) pairs per workgroup = ceil(16 Ts / 64)
+};
+
+__device__ __forceinline__ void st_sc1_f4(float* p, float4 v) {
+    const f32x4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ void st_sc1_f1(float* p, float v) {
+    asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+// one relaxed agent-scope poll loop by thread 0, then the workgroup's barrier
+__device__ __forceinline__ void wait_count(gu32* c, unsigned want, unsigned* err, bool& dead) {
+    if (threadIdx.x == 0 && !dead) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(c, RLX_AGENT) < want) {
+            if (++spins > SPIN_LIMIT) { __hip_atomic_store((gu32*)err, 1u, RLX_AGENT); dead = true; break; }
+        }
+    }
+    __syncthreads();
+}
+
+constexpr int DEC_WGS = 64;          // workgroups per row tile
+constexpr int DEC_U = 8;             // hidden units per workgroup (H = 512)
+
+__global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float dlds[];
+    constexpr int H = DEC_WGS * DEC_U, C = 2 * H, Q = C + 3 * H, KS = 2;       // K share of a wave: H / 8 = 64 = 2 k-steps
+    const int i = blockIdx.x % DEC_WGS, rt = blockIdx.x / DEC_WGS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int B = a.B, Ts = a.Ts, Tt = a.Tt, np = a.np;
+    const int m0 = rt * 16, u0 = i * DEC_U;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int kbase = wave * (H >> 3);
+    const int64_t BH = (int64_t)B * H;
+    // LDS carve-up (floats)
+    float4* red = reinterpret_cast<float4*>(dlds);                  // [8 waves][3 tiles][64 lanes]
+    float* pe_s = dlds + 6144;                                       // [np][C]
+    float* ew_s = pe_s + (int64_t)np * C;                            // [16 rows][Ts][24]
+    float* sc_s = ew_s + 16 * Ts * 24;                               // [16][Ts] scores -> alpha
+    float* gi_s = sc_s + 16 * Ts;                                    // [16][24] projected context of own columns
+    float* hp_s = gi_s + 16 * 24;                                    // [16][24] hidden-side projection of gru_2 (own units)
+    float* bs_s = hp_s + 16 * 24;                                    // [3 kinds][3 gates][8]: b_hh1, b_hh2, b_ih2 of the own units
+    float* hs_s = bs_s + 80;                                         // [2][16][8]: own units of h1 (this step) and h2 (previous step)
+    float* v_s = hs_s + 256;                                         // [C] attention vector
+
+    // ---- weights as bf16 planes in registers (A operands: rows = output columns).  Row of a tile held by lane fr:
+    //   cell tiles: tile 0 = [r | z] of the 8 own units (fr < 8: gate r, unit fr; else gate z, unit fr - 8), tile 1 = [n | n again]
+    bf16x8 w1[KS][2][3], w2[KS][3][3];
+    {
+        const int ur = fr & 7, g01 = fr >> 3;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int ko = kbase + 32 * s + 8 * fg;
+            const float* p0 = a.W1 + (int64_t)(g01 * H + u0 + ur) * H + ko;
+            const float* p1 = a.W1 + (int64_t)(2 * H + u0 + ur) * H + ko;
+            split8(*reinterpret_cast<const float4*>(p0), *reinterpret_cast<const float4*>(p0 + 4), w1[s][0]);
+            split8(*reinterpret_cast<const float4*>(p1), *reinterpret_cast<const float4*>(p1 + 4), w1[s][1]);
+            const float* q0 = a.wcat + (int64_t)(16 * i + fr) * H + ko;                         // attn_h rows = query columns
+            const float* q1 = a.wcat + (int64_t)(C + g01 * H + u0 + ur) * H + ko;               // W_hh2 [r | z]
+            const float* q2 = a.wcat + (int64_t)(C + 2 * H + u0 + ur) * H + ko;                 // W_hh2 [n | n]
+            split8(*reinterpret_cast<const float4*>(q0), *reinterpret_cast<const float4*>(q0 + 4), w2[s][0]);
+            split8(*reinterpret_cast<const float4*>(q1), *reinterpret_cast<const float4*>(q1 + 4), w2[s][1]);
+            split8(*reinterpret_cast<const float4*>(q2), *reinterpret_cast<const float4*>(q2 + 4), w2[s][2]);
+        }
+    }
+    // ---- keys of the own pairs and own columns of the projected keys -> LDS (read from memory once per sequence)
+    const int P0 = np * i;                                           // first pair (index r * Ts + s inside the tile)
+    for (int x = threadIdx.x; x < np * (C / 4); x += 512) {
+        const int j = x / (C / 4), c4 = x - j * (C / 4);
+        const int P = min(P0 + j, 16 * Ts - 1);
+        const int r = P / Ts, sp = P - r * Ts, b = min(m0 + r, B - 1);
+        reinterpret_cast<float4*>(pe_s)[x] = reinterpret_cast<const float4*>(a.pe + ((int64_t)b * Ts + sp) * C)[c4];
+    }
+    for (int x = threadIdx.x; x < 16 * Ts * 6; x += 512) {           // (row, position, gate, half) -> one float4
+        const int hf = x & 1, g = (x >> 1) % 3, rs_ = x / 6;
+        const int r = rs_ / Ts, sp = rs_ - r * Ts, b = min(m0 + r, B - 1);
+        reinterpret_cast<float4*>(ew_s)[rs_ * 6 + g * 2 + hf] =
+            *reinterpret_cast<const float4*>(a.encwp + ((int64_t)b * Ts + sp) * 3 * H + g * H + u0 + 4 * hf);
+    }
+    // ---- epilogue threads: e = threadIdx.x < 32: batch row fr, unit quad hq: units u0 + 4 hq .. + 3
+    const int hq = (threadIdx.x >> 4) & 1;
+    const int em = m0 + fr, eu = u0 + 4 * hq;
+    const bool ep = threadIdx.x < 32, eok = ep && em < B;
+    if (threadIdx.x < 72) {
+        const int kind = threadIdx.x / 24, g = (threadIdx.x / 8) % 3, u = threadIdx.x & 7;
+        const float* src = kind == 0 ? a.b1 : (kind == 1 ? a.bcat + C : a.b_ih2);
+        bs_s[threadIdx.x] = src[g * H + u0 + u];
+    }
+    for (int x = threadIdx.x; x < C / 4; x += 512) reinterpret_cast<float4*>(v_s)[x] = reinterpret_cast<const float4*>(a.v)[x];
+    if (ep) *reinterpret_cast<float4*>(hs_s + 128 + fr * 8 + 4 * hq) = eok ? *reinterpret_cast<const float4*>(a.h0 + (int64_t)em * H + eu)
+                                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int arow = min(m0 + fr, B - 1);
+    gu32* c1 = (gu32*)(a.cnt + ((int64_t)0 * a.RT + rt) * Tt);       // h2[t] published (waited on by step t + 1)
+    gu32* c2 = (gu32*)(a.cnt + ((int64_t)1 * a.RT + rt) * Tt);       // h1
+    gu32* c3 = (gu32*)(a.cnt + ((int64_t)2 * a.RT + rt) * Tt);       // q
+    gu32* c4 = (gu32*)(a.cnt + ((int64_t)3 * a.RT + rt) * Tt);       // scores
+    bool dead = false;
+    __syncthreads();
+
+    for (int t = 0; t < Tt; ++t) {
+        // ================= phase 1: gru_1 cell (NMT_Decoder.py:121) =================
+        float4 ha[KS], hb[KS];
+        if (t == 0) {
+            const float* hp = a.h0 + (int64_t)arow * H + kbase + 8 * fg;          // written before this launch: plain loads
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { ha[s] = *reinterpret_cast<const float4*>(hp + 32 * s); hb[s] = *reinterpret_cast<const float4*>(hp + 32 * s + 4); }
+        } else {
+            wait_count(c1 + (t - 1), DEC_WGS, a.err, dead);
+            ld_rows_sc1<KS>(a.h2_all + ((int64_t)(t - 1) * B + arow) * H + kbase + 8 * fg, ha, hb);
+        }
+        {
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bf16x8 hf[3];
+                split8(ha[s], hb[s], hf);
+                acc[0] = mma6(w1[s][0], hf, acc[0]);
+                acc[1] = mma6(w1[s][1], hf, acc[1]);
+            }
+            red[(wave * 3 + 0) * 64 + lane] = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+            red[(wave * 3 + 1) * 64 + lane] = make_float4(acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
+        }
+        float4 xo[3];                                   // the input projection of this step: arrives under the barrier + reduction
+        if (eok) {
+            const float* xp = a.xp1 + ((int64_t)t * B + em) * 3 * H + eu;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) xo[g] = *reinterpret_cast<const float4*>(xp + g * H);
+        }
+        __syncthreads();
+        if (ep) {
+            // D[tile row][batch row]: lane (fr, fg) of a tile holds rows 4 fg + i.  r of units 4 hq + i: tile 0, fg = hq;
+            // z: tile 0, fg = 2 + hq; n: tile 1, fg = hq
+            float4 cr = make_float4(0, 0, 0, 0), cz = cr, cn = cr;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const float4 x0 = red[(w * 3 + 0) * 64 + hq * 16 + fr], x1 = red[(w * 3 + 0) * 64 + (2 + hq) * 16 + fr];
+                const float4 x2 = red[(w * 3 + 1) * 64 + hq * 16 + fr];
+                cr.x += x0.x; cr.y += x0.y; cr.z += x0.z; cr.w += x0.w;
+                cz.x += x1.x; cz.y += x1.y; cz.z += x1.z; cz.w += x1.w;
+                cn.x += x2.x; cn.y += x2.y; cn.z += x2.z; cn.w += x2.w;
+            }
+            if (eok) {
+                const float4 b0 = *reinterpret_cast<const float4*>(bs_s + 0 * 8 + 4 * hq), b1_ = *reinterpret_cast<const float4*>(bs_s + 1 * 8 + 4 * hq);
+                const float4 b2_ = *reinterpret_cast<const float4*>(bs_s + 2 * 8 + 4 * hq);
+                const float r_[4] = {cr.x + b0.x + xo[0].x, cr.y + b0.y + xo[0].y, cr.z + b0.z + xo[0].z, cr.w + b0.w + xo[0].w};
+                const float z_[4] = {cz.x + b1_.x + xo[1].x, cz.y + b1_.y + xo[1].y, cz.z + b1_.z + xo[1].z, cz.w + b1_.w + xo[1].w};
+                const float gh[4] = {cn.x + b2_.x, cn.y + b2_.y, cn.z + b2_.z, cn.w + b2_.w};
+                const float xn[4] = {xo[2].x, xo[2].y, xo[2].z, xo[2].w};
+                const float4 hprev = *reinterpret_cast<const float4*>(hs_s + 128 + fr * 8 + 4 * hq);
+                const float hpv[4] = {hprev.x, hprev.y, hprev.z, hprev.w};
+                float rr[4], zz[4], nn[4], ho[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    rr[q] = vag_sigmoid(r_[q]);
+                    zz[q] = vag_sigmoid(z_[q]);
+                    nn[q] = vag_tanh(xn[q] + rr[q] * gh[q]);
+                    ho[q] = (1.f - zz[q]) * nn[q] + zz[q] * hpv[q];
+                }
+                const float4 h1v = make_float4(ho[0], ho[1], ho[2], ho[3]);
+                *reinterpret_cast<float4*>(hs_s + fr * 8 + 4 * hq) = h1v;
+                const int64_t o = (int64_t)em * H + eu;
+                st_sc1_f4(a.h1 + (int64_t)t * BH + o, h1v);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                float* sv = a.g1 + (int64_t)t * 4 * BH + o;
+                *reinterpret_cast<float4*>(sv) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+                *reinterpret_cast<float4*>(sv + BH) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+                *reinterpret_cast<float4*>(sv + 2 * BH) = make_float4(nn[0], nn[1], nn[2], nn[3]);
+                *reinterpret_cast<float4*>(sv + 3 * BH) = make_float4(gh[0], gh[1], gh[2], gh[3]);
+            }
+            // (threads 0..31 are half of wave 0: the drain above covered every storing lane of the wave)
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(c2 + t, 1u, RLX_AGENT);
+        }
+        // ================= phase 2: q = attn_h h1 (:47), hp2 = W_hh2 h1 + b_hh2 (hidden side of gru_2, :129) =================
+        wait_count(c2 + t, DEC_WGS, a.err, dead);
+        ld_rows_sc1<KS>(a.h1 + ((int64_t)t * B + arow) * H + kbase + 8 * fg, ha, hb);
+        {
+            f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bf16x8 hf[3];
+                split8(ha[s], hb[s], hf);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[j] = mma6(w2[s][j], hf, acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) red[(wave * 3 + j) * 64 + lane] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // q: lane (fr, fg) -> batch row fr, columns 16 i + 4 fg .. + 3
+            float4 qv = make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const float4 x0 = red[(w * 3 + 0) * 64 + lane];
+                qv.x += x0.x; qv.y += x0.y; qv.z += x0.z; qv.w += x0.w;
+            }
+            if (m0 + fr < B) st_sc1_f4(a.qhp + ((int64_t)t * B + m0 + fr) * Q + 16 * i + 4 * fg, qv);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(c3 + t, 1u, RLX_AGENT);
+            if (ep) {
+                float4 hp2[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    const float4 x0 = red[(w * 3 + 1) * 64 + hq * 16 + fr], x1 = red[(w * 3 + 1) * 64 + (2 + hq) * 16 + fr];
+                    const float4 x2 = red[(w * 3 + 2) * 64 + hq * 16 + fr];
+                    hp2[0].x += x0.x; hp2[0].y += x0.y; hp2[0].z += x0.z; hp2[0].w += x0.w;
+                    hp2[1].x += x1.x; hp2[1].y += x1.y; hp2[1].z += x1.z; hp2[1].w += x1.w;
+                    hp2[2].x += x2.x; hp2[2].y += x2.y; hp2[2].z += x2.z; hp2[2].w += x2.w;
+                }
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const float4 bb = *reinterpret_cast<const float4*>(bs_s + 24 + g * 8 + 4 * hq);
+                    hp2[g].x += bb.x; hp2[g].y += bb.y; hp2[g].z += bb.z; hp2[g].w += bb.w;
+                    *reinterpret_cast<float4*>(hp_s + fr * 24 + g * 8 + 4 * hq) = hp2[g];      // read back by the same thread in phase 4
+                    if (eok) *reinterpret_cast<float4*>(a.qhp + ((int64_t)t * B + em) * Q + C + g * H + eu) = hp2[g];     // saved for backward
+                }
+            }
+        }
+        // ================= phase 3: scores of the own (row, position) pairs (:47-51, mask :41-43) =================
+        wait_count(c3 + t, DEC_WGS, a.err, dead);
+        for (int j = wave; j < np; j += 8) {
+            const int P = P0 + j;
+            if (P >= 16 * Ts) break;
+            const int r = P / Ts, sp = P - r * Ts, b = m0 + r;
+            if (b >= B) break;
+            float4 qa[2], qb[2];
+            // q row b: columns 4 lane + 256 jj, jj = 0..3  (two statements of two sc1 loads each: offsets 0 / 1024 bytes)
+            const float* qrow = a.qhp + ((int64_t)t * B + b) * Q + 4 * lane;
+            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:3072 sc1\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(qa[0]), "=&v"(qa[1]), "=&v"(qb[0]), "=&v"(qb[1]) : "v"(qrow) : "memory");
+            const float4 qq[4] = {qa[0], qa[1], qb[0], qb[1]};
+            const float4* pr = reinterpret_cast<const float4*>(pe_s + (int64_t)j * C);
+            float acc = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float4 pv = pr[lane + 64 * jj];
+                const float4 vq = reinterpret_cast<const float4*>(v_s)[lane + 64 * jj];
+                acc += vq.x * vag_tanh(pv.x + qq[jj].x);
+                acc += vq.y * vag_tanh(pv.y + qq[jj].y);
+                acc += vq.z * vag_tanh(pv.z + qq[jj].z);
+                acc += vq.w * vag_tanh(pv.w + qq[jj].w);
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) {
+                if (a.mask[(int64_t)b * Ts + sp] == 0.f) acc = -INFINITY;
+                st_sc1_f1(a.psc + ((int64_t)t * B + b) * Ts + sp, acc);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains ...
+        __syncthreads();                                       // ... before the one lane that signals for all of them
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(c4 + t, 1u, RLX_AGENT);
+        // ================= phase 4: softmax (:44), projected context of own columns, gru_2 cell (:126-129) =================
+        wait_count(c4 + t, DEC_WGS, a.err, dead);
+        for (int x = threadIdx.x; x < 16 * Ts; x += 512) {
+            const int r = x / Ts, sp = x - r * Ts, b = min(m0 + r, B - 1);
+            sc_s[x] = __hip_atomic_load(a.psc + ((int64_t)t * B + b) * Ts + sp, RLX_AGENT);      // 4-byte sc1 load
+        }
+        __syncthreads();
+        for (int r = wave; r < 16; r += 8) {
+            float mx = -INFINITY;
+            for (int sp = lane; sp < Ts; sp += 64) mx = fmaxf(mx, sc_s[r * Ts + sp]);
+            mx = wave_max(mx);
+            float sum = 0.f;
+            for (int sp = lane; sp < Ts; sp += 64) sum += __expf(sc_s[r * Ts + sp] - mx);
+            sum = wave_sum(sum);
+            const float inv = 1.f / sum;
+            for (int sp = lane; sp < Ts; sp += 64) {
+                const float al = __expf(sc_s[r * Ts + sp] - mx) * inv;
+                sc_s[r * Ts + sp] = al;
+                if (i == 0 && m0 + r < B) a.alpha[((int64_t)t * B + m0 + r) * Ts + sp] = al;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 16 * 24) {
+            const int r = threadIdx.x / 24, col = threadIdx.x - r * 24;
+            const float* al = sc_s + r * Ts;
+            const float* ew = ew_s + (int64_t)r * Ts * 24 + col;
+            float s0 = 0.f, s1 = 0.f;
+            int sp = 0;
+            for (; sp + 1 < Ts; sp += 2) { s0 += al[sp] * ew[sp * 24]; s1 += al[sp + 1] * ew[(sp + 1) * 24]; }
+            if (sp < Ts) s0 += al[sp] * ew[sp * 24];
+            gi_s[threadIdx.x] = s0 + s1;
+        }
+        __syncthreads();
+        if (eok) {
+            float gi[3][4];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const float4 x = *reinterpret_cast<const float4*>(gi_s + fr * 24 + g * 8 + 4 * hq);
+                gi[g][0] = x.x; gi[g][1] = x.y; gi[g][2] = x.z; gi[g][3] = x.w;
+            }
+            float bi[3][4], hh[3][4];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const float4 x = *reinterpret_cast<const float4*>(bs_s + 48 + g * 8 + 4 * hq);
+                const float4 y = *reinterpret_cast<const float4*>(hp_s + fr * 24 + g * 8 + 4 * hq);
+                bi[g][0] = x.x; bi[g][1] = x.y; bi[g][2] = x.z; bi[g][3] = x.w;
+                hh[g][0] = y.x; hh[g][1] = y.y; hh[g][2] = y.z; hh[g][3] = y.w;
+            }
+            const float* hr = hh[0];
+            const float* hz = hh[1];
+            const float* hn = hh[2];
+            const float4 h1v = *reinterpret_cast<const float4*>(hs_s + fr * 8 + 4 * hq);
+            const float h1a[4] = {h1v.x, h1v.y, h1v.z, h1v.w};
+            float rr[4], zz[4], nn[4], ho[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                rr[q] = vag_sigmoid(gi[0][q] + bi[0][q] + hr[q]);
+                zz[q] = vag_sigmoid(gi[1][q] + bi[1][q] + hz[q]);
+                nn[q] = vag_tanh(gi[2][q] + bi[2][q] + rr[q] * hn[q]);
+                ho[q] = (1.f - zz[q]) * nn[q] + zz[q] * h1a[q];
+            }
+            const float4 h2v = make_float4(ho[0], ho[1], ho[2], ho[3]);
+            *reinterpret_cast<float4*>(hs_s + 128 + fr * 8 + 4 * hq) = h2v;
+            const int64_t o = (int64_t)em * H + eu;
+            st_sc1_f4(a.h2_all + (int64_t)t * BH + o, h2v);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            float* sv = a.g2 + (int64_t)t * 4 * BH + o;
+            *reinterpret_cast<float4*>(sv) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+            *reinterpret_cast<float4*>(sv + BH) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+            *reinterpret_cast<float4*>(sv + 2 * BH) = make_float4(nn[0], nn[1], nn[2], nn[3]);
+            *reinterpret_cast<float4*>(sv + 3 * BH) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+        }
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(c1 + t, 1u, RLX_AGENT);
     }
 }
 
@@ -259,6 +608,55 @@ int vag_enc_fwd_persistent_launch(const float* xp, const float* w_fw, const floa
     if (H == 256) hipLaunchKernelGGL(enc_fwd_persistent_kernel<1>, grid, dim3(512), 0, s, a);
     else if (H == 512) hipLaunchKernelGGL(enc_fwd_persistent_kernel<2>, grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL(enc_fwd_persistent_kernel<4>, grid, dim3(512), 0, s, a);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+// Eligibility of the persistent decoder: H = 512 (8 units per workgroup x 64 workgroups per row tile), at most 4 row tiles
+// (B <= 64: 256 workgroups, one per CU), keys of a row tile fit the LDS, 4-float alignment of the row strides.
+static int64_t dec_persistent_lds_bytes(int64_t Ts) {
+    const int64_t np = cdiv64(16 * Ts, DEC_WGS);
+    return 4 * (6144 + np * 1024 + 16 * Ts * 24 + 16 * Ts + 16 * 24 + 16 * 24 + 80 + 256 + 1024);
+}
+bool vag_dec_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H) {
+    if (H != 512 || B <= 0 || B > 64 || Ts <= 0 || Tt <= 0 || Ts > 512) return false;
+    if (!vag_enc_persistent_ok(16, 1, 512)) return false;            // a GPU with >= 64 CUs is present (CU count query)
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        cus = n;
+    }
+    return cdiv64(B, 16) * DEC_WGS <= cus && dec_persistent_lds_bytes(Ts) <= 160 * 1024;
+}
+int64_t vag_dec_persistent_sync_words(int64_t B, int64_t Tt) { return 4 * cdiv64(B, 16) * Tt + 64; }
+
+int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const float* h0, const float* xp1, const float* W1,
+                                  const float* b1, const float* wcat, const float* bcat, const float* v, const float* encwp,
+                                  const float* b_ih2, float* h1, float* g1, float* qhp, float* alpha, float* h2_all, float* g2,
+                                  float* psc, unsigned* sync, int64_t B, int64_t Ts, int64_t Tt, int64_t H, hipStream_t s) {
+    VAG_CHECK_ARG(pe && mask && h0 && xp1 && W1 && b1 && wcat && bcat && v && encwp && b_ih2 && h1 && g1 && qhp && alpha && h2_all &&
+                  g2 && psc && sync && vag_dec_persistent_ok(B, Ts, Tt, H));
+    VAG_CHECK_ARG(aligned16(pe) && aligned16(h0) && aligned16(xp1) && aligned16(W1) && aligned16(b1) && aligned16(wcat) &&
+                  aligned16(bcat) && aligned16(v) && aligned16(encwp) && aligned16(b_ih2) && aligned16(h1) && aligned16(g1) &&
+                  aligned16(qhp) && aligned16(h2_all) && aligned16(g2));
+    DecPArgs a;
+    a.pe = pe; a.mask = mask; a.h0 = h0; a.xp1 = xp1; a.W1 = W1; a.b1 = b1; a.wcat = wcat; a.bcat = bcat; a.v = v; a.encwp = encwp;
+    a.b_ih2 = b_ih2; a.h1 = h1; a.g1 = g1; a.qhp = qhp; a.alpha = alpha; a.h2_all = h2_all; a.g2 = g2; a.psc = psc;
+    a.B = (int)B; a.Ts = (int)Ts; a.Tt = (int)Tt; a.H = (int)H; a.RT = (int)cdiv64(B, 16); a.np = (int)cdiv64(16 * Ts, DEC_WGS);
+    const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
+    a.cnt = sync; a.err = sync + (nwords - 64);
+    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
+    VAG_LAUNCH_CHECK();
+    int64_t lds = dec_persistent_lds_bytes(Ts);
+    if (lds < 84 * 1024) lds = 84 * 1024;                            // never two workgroups on one CU
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fwd_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess) return VAG_EINVAL;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(dec_fwd_persistent_kernel, dim3((unsigned)(a.RT * DEC_WGS)), dim3(512), (size_t)lds, s, a);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
