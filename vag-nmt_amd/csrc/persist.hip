@@ -249,12 +249,19 @@ __device__ __forceinline__ void st_sc1_f4(float* p, float4 v) {
 __device__ __forceinline__ void st_sc1_f1(float* p, float v) {
     asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
 }
-// one relaxed agent-scope poll loop by thread 0, then the workgroup's barrier
-__device__ __forceinline__ void wait_count(gu32* c, unsigned want, unsigned* err, bool& dead) {
-    if (threadIdx.x == 0 && !dead) {
+// A counter of the decoder kernel is 4 shards, 64 bytes apart (64 arrivals on ONE word serialise at the memory side, ~12 ns
+// each: MI355X_MICROARCH.md, fanin): workgroup i arrives on shard i & 3; lanes 0-3 of wave 0 poll one shard each with relaxed
+// agent-scope loads until every shard holds its 16 arrivals, then the workgroup's barrier.
+constexpr int SHARDS = 4, SHARD_STRIDE = 16, CNT_WORDS = SHARDS * SHARD_STRIDE;
+__device__ __forceinline__ void arrive(gu32* c, int i) { __hip_atomic_fetch_add(c + (i & (SHARDS - 1)) * SHARD_STRIDE, 1u, RLX_AGENT); }
+__device__ __forceinline__ void wait_count(gu32* c, unsigned want_per_shard, unsigned* err, bool& dead) {
+    if (threadIdx.x < 64 && !dead) {
+        const int lane = threadIdx.x;
         unsigned spins = 0;
-        while (__hip_atomic_load(c, RLX_AGENT) < want) {
-            if (++spins > SPIN_LIMIT) { __hip_atomic_store((gu32*)err, 1u, RLX_AGENT); dead = true; break; }
+        for (;;) {
+            const bool ok = lane >= SHARDS || __hip_atomic_load(c + lane * SHARD_STRIDE, RLX_AGENT) >= want_per_shard;
+            if (__all(ok)) break;
+            if (++spins > SPIN_LIMIT) { if (lane == 0) __hip_atomic_store((gu32*)err, 1u, RLX_AGENT); dead = true; break; }
         }
     }
     __syncthreads();
@@ -283,6 +290,8 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
     float* bs_s = hp_s + 16 * 24;                                    // [3 kinds][3 gates][8]: b_hh1, b_hh2, b_ih2 of the own units
     float* hs_s = bs_s + 80;                                         // [2][16][8]: own units of h1 (this step) and h2 (previous step)
     float* v_s = hs_s + 256;                                         // [C] attention vector
+    float* mk_s = v_s + C;                                           // [np] source mask of the own pairs
+    float* q_s = mk_s + ((np + 3) & ~3);                             // [2][C] the (at most two) query rows the own pairs belong to
 
     // ---- weights as bf16 planes in registers (A operands: rows = output columns).  Row of a tile held by lane fr:
     //   cell tiles: tile 0 = [r | z] of the 8 own units (fr < 8: gate r, unit fr; else gate z, unit fr - 8), tile 1 = [n | n again]
@@ -328,13 +337,19 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
         bs_s[threadIdx.x] = src[g * H + u0 + u];
     }
     for (int x = threadIdx.x; x < C / 4; x += 512) reinterpret_cast<float4*>(v_s)[x] = reinterpret_cast<const float4*>(a.v)[x];
+    if (threadIdx.x < np) {
+        const int P = min(P0 + (int)threadIdx.x, 16 * Ts - 1);
+        const int r = P / Ts, sp = P - r * Ts;
+        mk_s[threadIdx.x] = a.mask[(int64_t)min(m0 + r, B - 1) * Ts + sp];
+    }
     if (ep) *reinterpret_cast<float4*>(hs_s + 128 + fr * 8 + 4 * hq) = eok ? *reinterpret_cast<const float4*>(a.h0 + (int64_t)em * H + eu)
                                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
     const int arow = min(m0 + fr, B - 1);
-    gu32* c1 = (gu32*)(a.cnt + ((int64_t)0 * a.RT + rt) * Tt);       // h2[t] published (waited on by step t + 1)
-    gu32* c2 = (gu32*)(a.cnt + ((int64_t)1 * a.RT + rt) * Tt);       // h1
-    gu32* c3 = (gu32*)(a.cnt + ((int64_t)2 * a.RT + rt) * Tt);       // q
-    gu32* c4 = (gu32*)(a.cnt + ((int64_t)3 * a.RT + rt) * Tt);       // scores
+    gu32* c1 = (gu32*)(a.cnt + ((int64_t)0 * a.RT + rt) * Tt * CNT_WORDS);       // h2[t] published (waited on by step t + 1)
+    gu32* c2 = (gu32*)(a.cnt + ((int64_t)1 * a.RT + rt) * Tt * CNT_WORDS);       // h1
+    gu32* c3 = (gu32*)(a.cnt + ((int64_t)2 * a.RT + rt) * Tt * CNT_WORDS);       // q
+    gu32* c4 = (gu32*)(a.cnt + ((int64_t)3 * a.RT + rt) * Tt * CNT_WORDS);       // scores
+    constexpr unsigned PER_SHARD = DEC_WGS / SHARDS;
     bool dead = false;
     __syncthreads();
 
@@ -346,7 +361,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
 #pragma unroll
             for (int s = 0; s < KS; ++s) { ha[s] = *reinterpret_cast<const float4*>(hp + 32 * s); hb[s] = *reinterpret_cast<const float4*>(hp + 32 * s + 4); }
         } else {
-            wait_count(c1 + (t - 1), DEC_WGS, a.err, dead);
+            wait_count(c1 + (t - 1) * CNT_WORDS, PER_SHARD, a.err, dead);
             ld_rows_sc1<KS>(a.h2_all + ((int64_t)(t - 1) * B + arow) * H + kbase + 8 * fg, ha, hb);
         }
         {
@@ -409,10 +424,10 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
                 *reinterpret_cast<float4*>(sv + 3 * BH) = make_float4(gh[0], gh[1], gh[2], gh[3]);
             }
             // (threads 0..31 are half of wave 0: the drain above covered every storing lane of the wave)
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(c2 + t, 1u, RLX_AGENT);
+            if (threadIdx.x == 0) arrive(c2 + t * CNT_WORDS, i);
         }
         // ================= phase 2: q = attn_h h1 (:47), hp2 = W_hh2 h1 + b_hh2 (hidden side of gru_2, :129) =================
-        wait_count(c2 + t, DEC_WGS, a.err, dead);
+        wait_count(c2 + t * CNT_WORDS, PER_SHARD, a.err, dead);
         ld_rows_sc1<KS>(a.h1 + ((int64_t)t * B + arow) * H + kbase + 8 * fg, ha, hb);
         {
             f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -437,7 +452,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
             }
             if (m0 + fr < B) st_sc1_f4(a.qhp + ((int64_t)t * B + m0 + fr) * Q + 16 * i + 4 * fg, qv);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(c3 + t, 1u, RLX_AGENT);
+            if (lane == 0) arrive(c3 + t * CNT_WORDS, i);
             if (ep) {
                 float4 hp2[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
 #pragma unroll
@@ -458,45 +473,56 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
             }
         }
         // ================= phase 3: scores of the own (row, position) pairs (:47-51, mask :41-43) =================
-        wait_count(c3 + t, DEC_WGS, a.err, dead);
-        for (int j = wave; j < np; j += 8) {
-            const int P = P0 + j;
-            if (P >= 16 * Ts) break;
-            const int r = P / Ts, sp = P - r * Ts, b = m0 + r;
-            if (b >= B) break;
-            float4 qa[2], qb[2];
-            // q row b: columns 4 lane + 256 jj, jj = 0..3  (two statements of two sc1 loads each: offsets 0 / 1024 bytes)
-            const float* qrow = a.qhp + ((int64_t)t * B + b) * Q + 4 * lane;
-            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
-                         "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:3072 sc1\n\t"
-                         "s_waitcnt vmcnt(0)"
-                         : "=&v"(qa[0]), "=&v"(qa[1]), "=&v"(qb[0]), "=&v"(qb[1]) : "v"(qrow) : "memory");
-            const float4 qq[4] = {qa[0], qa[1], qb[0], qb[1]};
-            const float4* pr = reinterpret_cast<const float4*>(pe_s + (int64_t)j * C);
-            float acc = 0.f;
+        wait_count(c3 + t * CNT_WORDS, PER_SHARD, a.err, dead);
+        {
+            // the own pairs lie in at most two batch rows (np <= Ts): their query rows, one 16-byte sc1 load per thread -> LDS
+            const int r_lo = P0 / Ts;
+            const int rr_ = r_lo + (threadIdx.x >> 8);
+            const float* qp = a.qhp + ((int64_t)t * B + min(m0 + min(rr_, 15), B - 1)) * Q + 4 * (threadIdx.x & 255);
+            float4 qv;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(qv) : "v"(qp) : "memory");
+            reinterpret_cast<float4*>(q_s)[threadIdx.x] = qv;
+            __syncthreads();
+            for (int j = wave; j < np; j += 8) {
+                const int P = P0 + j;
+                if (P >= 16 * Ts) break;
+                const int r = P / Ts, sp = P - r * Ts;
+                if (m0 + r >= B) break;
+                const float4* pr = reinterpret_cast<const float4*>(pe_s + (int64_t)j * C);
+                const float4* qr = reinterpret_cast<const float4*>(q_s + (r - r_lo) * C);
+                float acc = 0.f;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const float4 pv = pr[lane + 64 * jj];
-                const float4 vq = reinterpret_cast<const float4*>(v_s)[lane + 64 * jj];
-                acc += vq.x * vag_tanh(pv.x + qq[jj].x);
-                acc += vq.y * vag_tanh(pv.y + qq[jj].y);
-                acc += vq.z * vag_tanh(pv.z + qq[jj].z);
-                acc += vq.w * vag_tanh(pv.w + qq[jj].w);
-            }
-            acc = wave_sum(acc);
-            if (lane == 0) {
-                if (a.mask[(int64_t)b * Ts + sp] == 0.f) acc = -INFINITY;
-                st_sc1_f1(a.psc + ((int64_t)t * B + b) * Ts + sp, acc);
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float4 pv = pr[lane + 64 * jj];
+                    const float4 vq = reinterpret_cast<const float4*>(v_s)[lane + 64 * jj];
+                    const float4 qq = qr[lane + 64 * jj];
+                    acc += vq.x * vag_tanh(pv.x + qq.x);
+                    acc += vq.y * vag_tanh(pv.y + qq.y);
+                    acc += vq.z * vag_tanh(pv.z + qq.z);
+                    acc += vq.w * vag_tanh(pv.w + qq.w);
+                }
+                acc = wave_sum(acc);
+                if (lane == 0) {
+                    if (mk_s[j] == 0.f) acc = -INFINITY;
+                    st_sc1_f1(a.psc + ((int64_t)t * B + m0 + r) * Ts + sp, acc);
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains ...
         __syncthreads();                                       // ... before the one lane that signals for all of them
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(c4 + t, 1u, RLX_AGENT);
+        if (threadIdx.x == 0) arrive(c4 + t * CNT_WORDS, i);
         // ================= phase 4: softmax (:44), projected context of own columns, gru_2 cell (:126-129) =================
-        wait_count(c4 + t, DEC_WGS, a.err, dead);
-        for (int x = threadIdx.x; x < 16 * Ts; x += 512) {
-            const int r = x / Ts, sp = x - r * Ts, b = min(m0 + r, B - 1);
-            sc_s[x] = __hip_atomic_load(a.psc + ((int64_t)t * B + b) * Ts + sp, RLX_AGENT);      // 4-byte sc1 load
+        wait_count(c4 + t * CNT_WORDS, PER_SHARD, a.err, dead);
+        for (int x0 = threadIdx.x; x0 < 16 * Ts; x0 += 1024) {                                // 4-byte sc1 loads, two in flight
+            const int x1 = x0 + 512;
+            const int r0 = x0 / Ts, r1 = min(x1, 16 * Ts - 1) / Ts;
+            const float* p0 = a.psc + ((int64_t)t * B + min(m0 + r0, B - 1)) * Ts + (x0 - r0 * Ts);
+            const float* p1 = a.psc + ((int64_t)t * B + min(m0 + r1, B - 1)) * Ts + (min(x1, 16 * Ts - 1) - r1 * Ts);
+            float v0, v1;
+            asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
+            sc_s[x0] = v0;
+            if (x1 < 16 * Ts) sc_s[x1] = v1;
         }
         __syncthreads();
         for (int r = wave; r < 16; r += 8) {
@@ -564,7 +590,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
             *reinterpret_cast<float4*>(sv + 2 * BH) = make_float4(nn[0], nn[1], nn[2], nn[3]);
             *reinterpret_cast<float4*>(sv + 3 * BH) = make_float4(hn[0], hn[1], hn[2], hn[3]);
         }
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(c1 + t, 1u, RLX_AGENT);
+        if (threadIdx.x == 0) arrive(c1 + t * CNT_WORDS, i);
     }
 }
 
@@ -616,7 +642,7 @@ int vag_enc_fwd_persistent_launch(const float* xp, const float* w_fw, const floa
 // (B <= 64: 256 workgroups, one per CU), keys of a row tile fit the LDS, 4-float alignment of the row strides.
 static int64_t dec_persistent_lds_bytes(int64_t Ts) {
     const int64_t np = cdiv64(16 * Ts, DEC_WGS);
-    return 4 * (6144 + np * 1024 + 16 * Ts * 24 + 16 * Ts + 16 * 24 + 16 * 24 + 80 + 256 + 1024);
+    return 4 * (6144 + np * 1024 + 16 * Ts * 24 + 16 * Ts + 16 * 24 + 16 * 24 + 80 + 256 + 1024 + ((np + 3) & ~3ll) + 2048);
 }
 bool vag_dec_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H) {
     if (H != 512 || B <= 0 || B > 64 || Ts <= 0 || Tt <= 0 || Ts > 512) return false;
@@ -629,7 +655,7 @@ bool vag_dec_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H) {
     }
     return cdiv64(B, 16) * DEC_WGS <= cus && dec_persistent_lds_bytes(Ts) <= 160 * 1024;
 }
-int64_t vag_dec_persistent_sync_words(int64_t B, int64_t Tt) { return 4 * cdiv64(B, 16) * Tt + 64; }
+int64_t vag_dec_persistent_sync_words(int64_t B, int64_t Tt) { return 4 * cdiv64(B, 16) * Tt * CNT_WORDS + 64; }
 
 int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const float* h0, const float* xp1, const float* W1,
                                   const float* b1, const float* wcat, const float* bcat, const float* v, const float* encwp,
