@@ -340,36 +340,14 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
     }
 }
 
-// Block -> tile mapping (round 3).  Workgroup i runs on XCD i % 8, each XCD has its own 4 MB L2, and at 128x128 fp32 tiles
-// the products sit below the L2-fill ridge (32 flop per operand byte against ~40 for six bf16 MFMA products per fp32
-// product at ~10 TB/s of fabric): what one block fetches must be shared by its L2 neighbours.  (1) every XCD gets a
-// CONTIGUOUS range of tile indices (T1, bijective form) instead of every 8th tile; (2) inside a k-slice the tiles are
-// walked in panels of 8 tile columns, row by row, so the ~64 blocks an XCD has in flight cover an ~8 x 8 patch (16 operand
-// panels for 64 tiles) instead of two full rows (34).
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-}
-__device__ __forceinline__ void tile_of(int id, int tn, int tm, int& bx, int& by, int& bz) {
-    constexpr int PW = 8;
-    const int per = tn * tm;
-    bz = id / per;
-    const int t = id - bz * per;
-    const int panel = t / (PW * tm), first = panel * PW;
-    const int w = min(PW, tn - first);
-    const int r = t - panel * PW * tm;
-    by = r / w;
-    bx = first + (r - by * w);
-}
-
+// (Round 3, measured and dropped: an XCD-contiguous, panel-ordered block -> tile mapping (T1 + 8-column panels).  Single
+// products: no change on hot operands (4096^3 NT 705 -> 710 us); grouped launches: SLOWER in the step (weight-gradient group
+// 150 -> 174 us, logits/keys group 67 -> 86 us) because an XCD then works through one product's blocks and the products'
+// K differ by 10x -- the round-robin dealing of blocks over the XCDs is what balances a group.)
 template <bool AKC, bool BKC, bool VEC, int PL = 3>
 __global__ __launch_bounds__(512) void gemm_split_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) __bf16 smem[6 * SP_PLANE];
-    const int nwg = gridDim.x * gridDim.y * gridDim.z;
-    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    int bx, by, bz;
-    tile_of(xcd_remap(lin, nwg), gridDim.x, gridDim.y, bx, by, bz);
-    gemm_split_body<AKC, BKC, VEC, PL>(a, smem, bx, by, bz);
+    gemm_split_body<AKC, BKC, VEC, PL>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Grouped launch: the blocks of up to GROUP_MAX independent products of one operand layout (e.g. all "TN": both operands
@@ -379,13 +357,12 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(GemmArgs a) {
 template <bool AKC, bool BKC, int PL = 3>
 __global__ __launch_bounds__(512) void gemm_split_group_kernel(GemmGroupArgs G) {
     __shared__ __attribute__((aligned(16))) __bf16 smem[6 * SP_PLANE];
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
     int p = 0;
-    while (p + 1 < G.n && bid >= G.start[p + 1]) ++p;
+    while (p + 1 < G.n && (int)blockIdx.x >= G.start[p + 1]) ++p;
     const GemmArgs& a = G.p[p];
+    const int id = blockIdx.x - G.start[p];
     const int tn = (a.N + 127) / 128, tm = (a.M + 127) / 128;
-    int bx, by, bz;
-    tile_of(bid - G.start[p], tn, tm, bx, by, bz);
+    const int bx = id % tn, by = (id / tn) % tm, bz = id / (tn * tm);
     gemm_split_body<AKC, BKC, true, PL>(a, smem, bx, by, bz);
 }
 
