@@ -266,6 +266,11 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
             VAG_TRY(vag_transpose_launch(g.w_hh, 3 * H, H, w.whhT + d * 3 * H * H, s));
         }
     }
+    const bool persist = !s16 && vag_opt().persistent && H == 512 && vag_enc_persistent_ok(B, Ts, H);
+    if (persist) {
+        // the whole backward recurrence, both directions, in ONE launch (persist.hip)
+        VAG_TRY(vag_enc_bwd_persistent_launch(whhT, d_enc, w.gates, w.hst, lengths, rng, p_ctx, d_xp, w.dgh, w.sync, B, Ts, H, s));
+    }
     // last processed step: plain elementwise cell backward (no gradient arrives from a later step)
     GruBwdArgs a = {};
     a.ld_add = Ts * 2 * H; a.ldh = H; a.ldgi = 6 * H; a.ldgh = 3 * H;
@@ -286,14 +291,14 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
             sd.dh_prev = w.carry + (d * 2 + cur) * BH;
             sd.t = (int)t;
         }
-        VAG_TRY(vag_gru_bwd_elem_launch(a, 2, s));
+        if (!persist) VAG_TRY(vag_gru_bwd_elem_launch(a, 2, s));
     }
     // every other step: dh = dgh[k] W_hh + z*dh[k]  fused with the cell backward of step k-1 (both directions / launch)
     GruBwdStepArgs f = {};
     f.lda = 3 * H; f.ldw = 3 * H; f.ld_add = Ts * 2 * H; f.ldh = H; f.ldgi = 6 * H; f.ldgh = 3 * H;
     f.M = (int)B; f.K = (int)(3 * H); f.H = (int)H; f.lengths = lengths; f.rng = rng; f.sid = VAG_DROP_ENC_CTX; f.p = p_ctx;
     f.has_cell = 1;
-    for (int64_t k = Ts - 1; k >= 1; --k) {
+    for (int64_t k = Ts - 1; k >= 1 && !persist; --k) {
         for (int d = 0; d < 2; ++d) {
             const int64_t k1 = k - 1;
             const int64_t t1 = d == 0 ? k1 : Ts - 1 - k1;

@@ -147,6 +147,9 @@ int64_t vag_enc_persistent_sync_words(int64_t B, int64_t Ts);
 int vag_enc_fwd_persistent_launch(const float* xp, const float* w_fw, const float* w_bw, const float* b_fw, const float* b_bw,
                                   const int* lengths, float* hst, float* gates, float* enc, unsigned* sync, int64_t B, int64_t Ts,
                                   int64_t H, hipStream_t s);
+int vag_enc_bwd_persistent_launch(const float* whhT, const float* d_enc, const float* gates, const float* hst, const int* lengths,
+                                  const uint64_t* rng, float p_ctx, float* d_xp, float* dgh, unsigned* sync, int64_t B, int64_t Ts,
+                                  int64_t H, hipStream_t s);
 bool vag_dec_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H);
 int64_t vag_dec_persistent_sync_words(int64_t B, int64_t Tt);
 int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const float* h0, const float* xp1, const float* W1,

@@ -65,10 +65,29 @@ template <> __device__ __forceinline__ void ld_rows_sc1<4>(const float* p, float
                  : "=&v"(a[0]), "=&v"(b[0]), "=&v"(a[1]), "=&v"(b[1]), "=&v"(a[2]), "=&v"(b[2]), "=&v"(a[3]), "=&v"(b[3])
                  : "v"(p) : "memory");
 }
+template <> __device__ __forceinline__ void ld_rows_sc1<6>(const float* p, float4 (&a)[6], float4 (&b)[6]) {
+    asm volatile("global_load_dwordx4 %0, %12, off sc1\n\tglobal_load_dwordx4 %1, %12, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %12, off offset:128 sc1\n\tglobal_load_dwordx4 %3, %12, off offset:144 sc1\n\t"
+                 "global_load_dwordx4 %4, %12, off offset:256 sc1\n\tglobal_load_dwordx4 %5, %12, off offset:272 sc1\n\t"
+                 "global_load_dwordx4 %6, %12, off offset:384 sc1\n\tglobal_load_dwordx4 %7, %12, off offset:400 sc1\n\t"
+                 "global_load_dwordx4 %8, %12, off offset:512 sc1\n\tglobal_load_dwordx4 %9, %12, off offset:528 sc1\n\t"
+                 "global_load_dwordx4 %10, %12, off offset:640 sc1\n\tglobal_load_dwordx4 %11, %12, off offset:656 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a[0]), "=&v"(b[0]), "=&v"(a[1]), "=&v"(b[1]), "=&v"(a[2]), "=&v"(b[2]), "=&v"(a[3]), "=&v"(b[3]),
+                   "=&v"(a[4]), "=&v"(b[4]), "=&v"(a[5]), "=&v"(b[5])
+                 : "v"(p) : "memory");
+}
 __device__ __forceinline__ void st_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
     const u32x4 u = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z),
                      __builtin_bit_cast(unsigned, v.w)};
     __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, 16);
+}
+__device__ __forceinline__ void st_sc1_f4(float* p, float4 v) {
+    const f32x4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ void st_sc1_f1(float* p, float v) {
+    asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
 }
 // 8 consecutive floats -> three bf16x8 planes
 __device__ __forceinline__ void split8(const float4 a, const float4 b, bf16x8 (&p)[3]) {
@@ -220,6 +239,133 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_persistent_kernel(EncPArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Encoder backward recurrence (what autograd replays for nn.GRU, layers/Encoder.py:58), both directions, in ONE launch.
+// Same decomposition and hand-off as the forward kernel: a workgroup owns 16 hidden units x 16 batch rows; its 16 rows of
+// W_hh^T (K = 3H) stay in registers as bf16x3 planes (72 VGPRs at H = 512); per step it reads the row tile's 16 x 3H gate
+// gradients of the later step (sc1), forms dh = dgh[k+1] W_hh + z*dh[k+1] for its units (36 MFMAs per wave), runs the cell
+// backward of step k in the epilogue and publishes its 16 x 48 gate gradients.  The carried z*dh of its own units never
+// leaves the registers.
+struct EncBArgs {
+    const float* WT[2];         // (H, 3H) W_hh^T per direction
+    const float* d_enc;         // (B, Ts, 2H) gradient of the encoder states (before the context dropout)
+    const float* gates;         // [2][Ts][4][B][H]
+    const float* hst;           // [2][Ts+1][B][H]
+    const int* lengths;
+    const uint64_t* rng; float p_ctx;
+    float* d_xp;                // (Ts, B, 6H): dgi of both directions
+    float* dgh;                 // [2][Ts][B][3H]
+    unsigned* cnt;              // [2][RT][Ts]
+    unsigned* err;
+    int B, Ts, H, RT, CS;
+};
+template <int KS>               // k-steps of 32 per wave: 3H / 8 / 32 (H = 512: 6)
+__global__ __launch_bounds__(512, 1) void enc_bwd_persistent_kernel(EncBArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[21504];      // 84 KB: [0, 2048) reduction; the rest keeps the CU to ourselves
+    const int wg = blockIdx.x;
+    const int cs = wg % a.CS, rt = (wg / a.CS) % a.RT, d = wg / (a.CS * a.RT);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int H = a.H, B = a.B, Ts = a.Ts, K = 3 * H;
+    const int m0 = rt * 16, u0 = cs * 16;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int kbase = wave * (K >> 3);
+    const int64_t BH = (int64_t)B * H;
+    bf16x8 wf[KS][3];
+    {
+        const float* WT = a.WT[d] + (int64_t)(u0 + fr) * K + kbase + 8 * fg;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) split8(*reinterpret_cast<const float4*>(WT + 32 * s), *reinterpret_cast<const float4*>(WT + 32 * s + 4), wf[s]);
+    }
+    const int em = m0 + fr, eu = u0 + 4 * fg;
+    const bool eok = wave == 0 && em < B;
+    const int len = eok ? a.lengths[em] : 0;
+    float4 carry = make_float4(0.f, 0.f, 0.f, 0.f);           // z * dh of the later step, own units
+    float* dghd = a.dgh + (int64_t)d * Ts * B * K;
+    gu32* cnt = (gu32*)(a.cnt + ((int64_t)d * a.RT + rt) * Ts);
+    const int arow = min(m0 + fr, B - 1);
+    float4* red = reinterpret_cast<float4*>(lds);
+    bool dead = false;
+    const int64_t ld_add = (int64_t)Ts * 2 * H;
+
+    for (int k = Ts - 1; k >= 0; --k) {
+        const int t = d == 0 ? k : Ts - 1 - k;
+        // epilogue operands of step k (independent of the recurrence): requested before the wait
+        float4 sv[4], hp, e4;
+        if (eok) {
+            const int64_t o = (int64_t)em * H + eu;
+            const float* g = a.gates + ((int64_t)(d * Ts + k) * 4) * BH + o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sv[q] = *reinterpret_cast<const float4*>(g + q * BH);
+            hp = *reinterpret_cast<const float4*>(a.hst + ((int64_t)d * (Ts + 1) + k) * BH + o);
+            e4 = *reinterpret_cast<const float4*>(a.d_enc + (int64_t)em * ld_add + (int64_t)t * 2 * H + d * H + eu);
+        }
+        float4 dh = carry;
+        if (k < Ts - 1) {
+            if (threadIdx.x == 0 && !dead) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(cnt + (k + 1), RLX_AGENT) < (unsigned)a.CS) {
+                    if (++spins > SPIN_LIMIT) { __hip_atomic_store((gu32*)a.err, 1u, RLX_AGENT); dead = true; break; }
+                }
+            }
+            __syncthreads();
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            float4 ga[KS], gb[KS];
+            ld_rows_sc1<KS>(dghd + ((int64_t)(k + 1) * B + arow) * K + kbase + 8 * fg, ga, gb);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bf16x8 hf[3];
+                split8(ga[s], gb[s], hf);
+                acc = mma6(wf[s], hf, acc);
+            }
+            red[wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    const float4 o = red[w * 64 + lane];
+                    dh.x += o.x; dh.y += o.y; dh.z += o.z; dh.w += o.w;
+                }
+            }
+        }
+        if (eok) {
+            const bool active = t < len;
+            float dhv[4] = {dh.x, dh.y, dh.z, dh.w};
+            float gi[3][4], gh[3][4], cy[4];
+            if (!active) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { gi[0][q] = gi[1][q] = gi[2][q] = gh[0][q] = gh[1][q] = gh[2][q] = 0.f; cy[q] = dhv[q]; }
+            } else {
+                const float ev[4] = {e4.x, e4.y, e4.z, e4.w};
+                const float r_[4] = {sv[0].x, sv[0].y, sv[0].z, sv[0].w}, z_[4] = {sv[1].x, sv[1].y, sv[1].z, sv[1].w};
+                const float n_[4] = {sv[2].x, sv[2].y, sv[2].z, sv[2].w}, hn[4] = {sv[3].x, sv[3].y, sv[3].z, sv[3].w};
+                const float hpv[4] = {hp.x, hp.y, hp.z, hp.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float e = ev[q];
+                    if (a.rng && a.p_ctx > 0.f)
+                        e *= vag_drop_mul(a.rng, VAG_DROP_ENC_CTX, (uint64_t)em * ld_add + (uint64_t)t * 2 * H + d * H + eu + q, a.p_ctx);
+                    const float x = dhv[q] + e;
+                    const float dn_pre = x * (1.f - z_[q]) * (1.f - n_[q] * n_[q]);
+                    const float dz_pre = x * (hpv[q] - n_[q]) * z_[q] * (1.f - z_[q]);
+                    const float dr_pre = dn_pre * hn[q] * r_[q] * (1.f - r_[q]);
+                    gi[0][q] = dr_pre; gi[1][q] = dz_pre; gi[2][q] = dn_pre;
+                    gh[0][q] = dr_pre; gh[1][q] = dz_pre; gh[2][q] = dn_pre * r_[q];
+                    cy[q] = x * z_[q];
+                }
+            }
+            carry = make_float4(cy[0], cy[1], cy[2], cy[3]);
+            float* gho = dghd + ((int64_t)k * B + em) * K + eu;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) st_sc1_f4(gho + g * H, make_float4(gh[g][0], gh[g][1], gh[g][2], gh[g][3]));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(cnt + k, 1u, RLX_AGENT);      // (lane 0 is row m0: always a valid row)
+            float* gio = a.d_xp + ((int64_t)t * B + em) * 6 * H + d * 3 * H + eu;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) *reinterpret_cast<float4*>(gio + g * H) = make_float4(gi[g][0], gi[g][1], gi[g][2], gi[g][3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Decoder forward recurrence, teacher forced (layers/NMT_Decoder.py:109-129 x the loop of models/...V11.py:138-146), in ONE
 // launch.  As a chain of launches a step is 4 kernels and ~24 us; every one of them re-reads, per workgroup, weights that
 // never change and keys that never change.  Here everything that is constant over the steps lives on chip:
@@ -242,13 +388,6 @@ struct DecPArgs {
     int B, Ts, Tt, H, RT, np;   // np: (row, position) pairs per workgroup = ceil(16 Ts / 64)
 };
 
-__device__ __forceinline__ void st_sc1_f4(float* p, float4 v) {
-    const f32x4 x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(x) : "memory");
-}
-__device__ __forceinline__ void st_sc1_f1(float* p, float v) {
-    asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
-}
 // A counter of the decoder kernel is 4 shards, 64 bytes apart (64 arrivals on ONE word serialise at the memory side, ~12 ns
 // each: MI355X_MICROARCH.md, fanin): workgroup i arrives on shard i & 3; lanes 0-3 of wave 0 poll one shard each with relaxed
 // agent-scope loads until every shard holds its 16 arrivals, then the workgroup's barrier.
@@ -683,6 +822,24 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
         attr_set = true;
     }
     hipLaunchKernelGGL(dec_fwd_persistent_kernel, dim3((unsigned)(a.RT * DEC_WGS)), dim3(512), (size_t)lds, s, a);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+int vag_enc_bwd_persistent_launch(const float* whhT, const float* d_enc, const float* gates, const float* hst, const int* lengths,
+                                  const uint64_t* rng, float p_ctx, float* d_xp, float* dgh, unsigned* sync, int64_t B, int64_t Ts,
+                                  int64_t H, hipStream_t s) {
+    VAG_CHECK_ARG(whhT && d_enc && gates && hst && lengths && d_xp && dgh && sync && H == 512 && vag_enc_persistent_ok(B, Ts, H));
+    VAG_CHECK_ARG(aligned16(whhT) && aligned16(d_enc) && aligned16(gates) && aligned16(hst) && aligned16(d_xp) && aligned16(dgh));
+    EncBArgs a;
+    a.WT[0] = whhT; a.WT[1] = whhT + 3 * H * H; a.d_enc = d_enc; a.gates = gates; a.hst = hst; a.lengths = lengths;
+    a.rng = rng; a.p_ctx = p_ctx; a.d_xp = d_xp; a.dgh = dgh;
+    a.B = (int)B; a.Ts = (int)Ts; a.H = (int)H; a.RT = (int)cdiv64(B, 16); a.CS = (int)(H / 16);
+    const int nwords = (int)vag_enc_persistent_sync_words(B, Ts);
+    a.cnt = sync; a.err = sync + (nwords - 64);
+    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
+    VAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(enc_bwd_persistent_kernel<6>, dim3((unsigned)(2 * a.RT * a.CS)), dim3(512), 0, s, a);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
