@@ -88,8 +88,6 @@ def cpu_baseline(c, warmup=3, steps=10):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    threads = min(cores, 32)
-    torch.set_num_threads(threads)
     m = build_model(c, torch.device("cpu"))
     src, lens, tgt, im = make_batch(c, 0, torch.device("cpu"))
     B, Ts, Tt, E, H = c["B"], c["Ts"], c["Tt"], c["E"], c["H"]
@@ -99,6 +97,20 @@ def cpu_baseline(c, warmup=3, steps=10):
         def mk(shape, p):
             return (torch.rand(shape, generator=g) >= p).float() / (1.0 - p)
         return {"emb": mk((Ts, B, E), 0.3), "ctx": mk((Ts, B, 2 * H), 0.5), "out": mk((Tt, B, E), 0.5)}
+    # thread sweep ("all cores"): the step is ~600 small torch CPU ops, more threads are not always faster;
+    # two steps per candidate in the reference's op order, the fastest count is used for both rows
+    sweep = {}
+    for th in sorted({min(cores, x) for x in (16, 32, 64, 128, cores)}):
+        torch.set_num_threads(th)
+        P = {n: p.detach().clone() for n, p in m.named_parameters()}
+        ts_ = []
+        for i in range(3):
+            t0 = time.time()
+            O.train_step(P, src, lens, tgt, im, teacher=True, state={}, masks=masks(), hoist=False)
+            ts_.append(time.time() - t0)
+        sweep[th] = min(ts_[1:])
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
     rows = {}
     for name, hoist in (("reference_order", False), ("hoisted", True)):
         P = {n: p.detach().clone() for n, p in m.named_parameters()}
@@ -117,6 +129,7 @@ def cpu_baseline(c, warmup=3, steps=10):
                        % (steps, warmup, c["B"], c["Tt"], threads, cores),
                 s_per_step=ref["s_per_step_median"], cpu_model=_cpu_model(), host_cores=cores,
                 hoisted={"value": rows["hoisted"]["pairs_per_s"], "s_per_step": rows["hoisted"]["s_per_step_median"]},
+                thread_sweep_s_per_step={str(k): v for k, v in sweep.items()},
                 spread_s={k: [v["min_s"], v["max_s"]] for k, v in rows.items()})
 
 
@@ -215,6 +228,31 @@ def _measure_operators(c, dev, m, src, lens_t, tgt, im, out):
                 call("vag_gru_cell_bwd", ptr(dgh_next), ptr(wt), ptr(carry), ptr(d_out), ptr(sv), ptr(hp), B, H, ptr(dgi),
                      ptr(dgh), ptr(cout), stream())
         out["gru_cell_bwd"] = _time_graph(cells_bwd) / 100
+        # the dominant kernel of the step (profiles/): the persistent decoder forward recurrence, alone
+        from vagnmt_hip import _lib as L
+        from vagnmt_hip.ops import _dec_w
+        Ts, Tt = c["Ts"], c["Tt"]
+        if L.lib().vag_recurrence_supported(1, B, Ts, Tt, H):
+            C2, Q = 2 * H, 5 * H
+            dp = dec.dec_params()
+            wcat = torch.cat([dec.attn.attn_h.weight, dec.gru_2.weight_hh_l0], 0).contiguous()
+            bcat = torch.cat([torch.zeros(C2, device=dev), dec.gru_2.bias_hh_l0], 0).contiguous()
+            xp1 = torch.randn(Tt, B, 3 * H, device=dev) * 0.1
+            encwp = torch.randn(B, Ts, 3 * H, device=dev) * 0.1
+            o_h1 = torch.empty(Tt, B, H, device=dev)
+            o_g1 = torch.empty(Tt, 4, B, H, device=dev)
+            o_g2 = torch.empty(Tt, 4, B, H, device=dev)
+            o_q = torch.empty(Tt, B, Q, device=dev)
+            o_al = torch.empty(Tt, B, Ts, device=dev)
+            o_h2 = torch.empty(Tt, B, H, device=dev)
+            psc = torch.empty(Tt, B, Ts, device=dev)
+            sync = torch.zeros(L.lib().vag_recurrence_sync_words(1, B, Tt), dtype=torch.int32, device=dev)
+            maskf = mask.contiguous()
+            pe_c = pe.contiguous()
+            out["decoder_recurrence"] = _time_graph(
+                lambda: call("vag_cgru_recurrence_fwd", ptr(pe_c), ptr(maskf), ptr(h0), ptr(xp1), _dec_w(dec.embedding.weight, dp),
+                             ptr(wcat), ptr(bcat), ptr(encwp), B, Ts, Tt, H, ptr(o_h1), ptr(o_g1), ptr(o_q), ptr(o_al), ptr(o_h2),
+                             ptr(o_g2), ptr(psc), sync.data_ptr(), stream()))
     return out
 
 
@@ -553,14 +591,13 @@ def main():
                                       args.tfr, ", ragged source lengths" if args.ragged else ""),
                        "global_batch": c["B"] * world, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph, "final_loss": loss},
-            # dominant kernel by total time per step (profiles/r01_bench_cfg2_kernel_stats.csv): the fused backward step of
-            # the GRU recurrences (dh product + cell backward), encoder / decoder gru_1 shape
-            "roofline": {"bound": "hbm", "kernel": "gru_bwd_step_kernel<16> (dh = dgh W_hh + cell backward, M=%d, H=%d, K=%d)"
-                                                   % (B, H, 3 * H),
-                         "achieved": cell_bwd_bytes / fam["gru_cell_bwd"] / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": cell_bwd_bytes / fam["gru_cell_bwd"] / HBM_PEAK,
-                         "traffic": pmc.get("gru_bwd_step_kernel_bytes_per_launch"),
-                         "algorithmic_bytes_per_launch": cell_bwd_bytes, "us_per_launch": fam["gru_cell_bwd"] * 1e6},
+            # second by total time: the fused backward step of the decoder's GRU recurrence (dh product + cell backward)
+            "roofline_gru_cell_bwd": {"bound": "hbm", "kernel": "gru_bwd_step_kernel<16,6> (dh = dgh W_hh + cell backward, M=%d, H=%d, K=%d)"
+                                                                % (B, H, 3 * H),
+                                      "achieved": cell_bwd_bytes / fam["gru_cell_bwd"] / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                      "frac": cell_bwd_bytes / fam["gru_cell_bwd"] / HBM_PEAK,
+                                      "traffic": pmc.get("gru_bwd_step_kernel_bytes_per_launch"),
+                                      "algorithmic_bytes_per_launch": cell_bwd_bytes, "us_per_launch": fam["gru_cell_bwd"] * 1e6},
             # second by total time: the fused forward GRU cell, decoder gru_1 shape
             "roofline_gru_cell_fwd": {"bound": "hbm",
                                       "kernel": "gru_step_small_kernel<8,8> / gru_step_kernel<8> (fused GRU cell, M=%d, H=%d, K=%d)"
@@ -578,9 +615,25 @@ def main():
                                       "us_per_decoder_step": t_dec_step * 1e6,
                                       "us_per_encoder_step": fam["encoder_fwd"] / c["Ts"] * 1e6},
         }
+        # `roofline` = the dominant kernel of the step by total time (profiles/rNN_bench_cfg2_kernel_stats.csv).  Round 3: the
+        # persistent decoder forward recurrence (one launch = Tt steps; algorithmic bytes = Tt x F_dec of SURVEY 8(d): the
+        # streaming model prices every step's weights and keys again, the kernel keeps them on chip, so its measured HBM
+        # traffic is far BELOW the algorithmic bytes); where that kernel does not apply (configs[4]) the backward cell kernel.
+        if "decoder_recurrence" in fam:
+            rb = ab["F_dec"] * c["Tt"]
+            res["roofline"] = {"bound": "hbm",
+                               "kernel": "dec_fwd_persistent_kernel (Tt=%d decoder steps in one launch: gru_1, attention, gru_2; "
+                                         "B=%d, Ts=%d, H=%d)" % (c["Tt"], B, c["Ts"], H),
+                               "achieved": rb / fam["decoder_recurrence"] / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                               "frac": rb / fam["decoder_recurrence"] / HBM_PEAK,
+                               "traffic": pmc.get("dec_fwd_persistent_kernel_bytes_per_launch"),
+                               "algorithmic_bytes_per_launch": rb, "us_per_launch": fam["decoder_recurrence"] * 1e6,
+                               "us_per_decoder_step": fam["decoder_recurrence"] / c["Tt"] * 1e6}
+        else:
+            res["roofline"] = dict(res["roofline_gru_cell_bwd"])
         if args.config != "cfg2":
             res["roofline"]["traffic"] = res["roofline_decoder_step"]["traffic"] = None     # PMC passes were taken at cfg2
-            res["roofline_gru_cell_fwd"]["traffic"] = None
+            res["roofline_gru_cell_fwd"]["traffic"] = res["roofline_gru_cell_bwd"]["traffic"] = None
         whole = ab["F_enc"] * 2 * c["Ts"] + ab["F_dec"] * c["Tt"] + ab["Bk_enc"] * 2 * c["Ts"] + ab["Bk_dec"] * c["Tt"]
         if args.config == "cfg2":
             whole = 6.150e9            # chains + once-per-batch products (fwd, 2x bwd) + Adam, evaluated at cfg2

@@ -391,6 +391,24 @@ int64_t vag_derived_floats(int64_t H);
 int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_whh_bw, int64_t H, int with_fp16,
                        float* derived, vag_stream_t stream);
 
+/* ---- persistent recurrences (round 3, persist.hip) -------------------------------------------------------- */
+/* The teacher-forced decoder recurrence (every step's gru_1 cell, attention query / scores / softmax, projected context and
+ * gru_2 cell: layers/NMT_Decoder.py:121-129 x models/...V11.py:138-146) as ONE launch: recurrent weights in registers as
+ * bf16x3 planes, the attention keys of a row tile in LDS, four workgroup-to-workgroup exchanges per step (write-through
+ * stores + counters + sc1 loads).  vag_cgru_attn_decode_seq_fwd uses it whenever vag_recurrence_supported(1, ...) says so
+ * (H = 512, B <= 64, keys fit the LDS); this entry point runs it alone (bench.py times it; parity: tests/test_gpu_round3.py).
+ * kind: 0 = the bi-GRU encoder kernels (H in {256, 512, 1024}, 2 * ceil(B/16) * H/16 workgroups <= CUs), 1 = the decoder.
+ * xp1 (Tt,B,3H) = W_ih1 e_t + b_ih1; wcat (C+3H,H) = [attn_h; gru_2.w_hh], bcat (C+3H) = [0; gru_2.b_hh]; encwp (B,Ts,3H) =
+ * (gru_2.w_ih context2hid) enc; outputs as vag_cgru_attn_decode_seq_fwd saves them: h1 (Tt,B,H), g1 / g2 (Tt,4,B,H),
+ * qhp (Tt,B,C+3H), alpha (Tt,B,Ts), h2_all (Tt,B,H); psc (Tt,B,Ts) floats and sync (vag_recurrence_sync_words 32-bit
+ * words) are scratch. */
+int vag_recurrence_supported(int kind, int64_t B, int64_t Ts, int64_t Tt, int64_t H);
+int64_t vag_recurrence_sync_words(int kind, int64_t B, int64_t T);
+int vag_cgru_recurrence_fwd(const float* pe, const float* mask, const float* h0, const float* xp1, vag_dec_w w, const float* wcat,
+                            const float* bcat, const float* encwp, int64_t B, int64_t Ts, int64_t Tt, int64_t H, float* h1,
+                            float* g1, float* qhp, float* alpha, float* h2_all, float* g2, float* psc, void* sync,
+                            vag_stream_t stream);
+
 /* ---- dropout helpers ---------------------------------------------------------------------------------- */
 /* which: 1 encoder-embedding (Ts,B,E), 2 encoder-context (B,Ts,2H), 3 decoder-output (Tt,B,E). */
 int vag_dropout_mask(const uint64_t* rng, int which, int64_t n, float p, float* out, vag_stream_t stream);

@@ -1314,6 +1314,24 @@ int vag_copy4(const void* const* src, void* const* dst, const int64_t* bytes, in
     return vag_copy4_launch(src, dst, bytes, n, S_(stream));
 }
 
+int vag_recurrence_supported(int kind, int64_t B, int64_t Ts, int64_t Tt, int64_t H) {
+    if (kind == 0) return vag_enc_persistent_ok(B, Ts, H) ? 1 : 0;
+    if (kind == 1) return vag_dec_persistent_ok(B, Ts, Tt, H) ? 1 : 0;
+    return 0;
+}
+int64_t vag_recurrence_sync_words(int kind, int64_t B, int64_t T) {
+    return kind == 0 ? vag_enc_persistent_sync_words(B, T) : vag_dec_persistent_sync_words(B, T);
+}
+int vag_cgru_recurrence_fwd(const float* pe, const float* mask, const float* h0, const float* xp1, vag_dec_w w, const float* wcat,
+                            const float* bcat, const float* encwp, int64_t B, int64_t Ts, int64_t Tt, int64_t H, float* h1,
+                            float* g1, float* qhp, float* alpha, float* h2_all, float* g2, float* psc, void* sync,
+                            vag_stream_t stream) {
+    VAG_CHECK_ARG(dec_w_ok(w) && vag_dec_persistent_ok(B, Ts, Tt, H));
+    return vag_dec_fwd_persistent_launch(pe, mask, h0, xp1, w.gru1.w_hh, w.gru1.b_hh, wcat, bcat, w.attn_v, encwp, w.gru2.b_ih, h1,
+                                         g1, qhp, alpha, h2_all, g2, psc, reinterpret_cast<unsigned*>(sync), B, Ts, Tt, H,
+                                         S_(stream));
+}
+
 int vag_dropout_mask(const uint64_t* rng, int which, int64_t n, float p, float* out, vag_stream_t stream) {
     VAG_CHECK_ARG(which >= 1 && which <= 3);
     return vag_dropout_mask_launch(rng, which, n, p, out, S_(stream));

@@ -372,13 +372,22 @@ __global__ __launch_bounds__(256) void copy4_kernel(Copy4 c) {
         const int64_t n16 = n >> 4;
         const uint4* s4 = reinterpret_cast<const uint4*>(s);
         uint4* d4 = reinterpret_cast<uint4*>(d);
-        const int64_t stride = (int64_t)gridDim.x * 256;
-        int64_t i = blockIdx.x * 256ll + threadIdx.x;
-        for (; i + 3 * stride < n16; i += 4 * stride) {          // four 16-byte loads in flight per thread
-            const uint4 a = s4[i], b = s4[i + stride], c2 = s4[i + 2 * stride], e = s4[i + 3 * stride];
-            d4[i] = a; d4[i + stride] = b; d4[i + 2 * stride] = c2; d4[i + 3 * stride] = e;
+        // a workgroup moves contiguous 16 KB pieces (256 threads x 4 x 16 bytes, four loads in flight per thread), pieces dealt
+        // round-robin over the grid; non-temporal both ways: every byte is touched once (round 2's four grid-strided streams
+        // per thread, default cache policy: 4.4 TB/s of the 6.3 TB/s a float4 copy reaches on this part)
+        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+        const u4v* sv = reinterpret_cast<const u4v*>(s);
+        u4v* dv = reinterpret_cast<u4v*>(d);
+        const int64_t pieces = n16 >> 10;
+        for (int64_t pc = blockIdx.x; pc < pieces; pc += gridDim.x) {
+            const int64_t i = (pc << 10) + threadIdx.x;
+            const u4v a = __builtin_nontemporal_load(sv + i), b = __builtin_nontemporal_load(sv + i + 256);
+            const u4v c2 = __builtin_nontemporal_load(sv + i + 512), e = __builtin_nontemporal_load(sv + i + 768);
+            __builtin_nontemporal_store(a, dv + i); __builtin_nontemporal_store(b, dv + i + 256);
+            __builtin_nontemporal_store(c2, dv + i + 512); __builtin_nontemporal_store(e, dv + i + 768);
         }
-        for (; i < n16; i += stride) d4[i] = s4[i];
+        const int64_t stride = (int64_t)gridDim.x * 256;
+        for (int64_t i = (pieces << 10) + blockIdx.x * 256ll + threadIdx.x; i < n16; i += stride) d4[i] = s4[i];
         for (int64_t j = (n16 << 4) + blockIdx.x * 256ll + threadIdx.x; j < n; j += stride) d[j] = s[j];
     } else {
         for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = s[i];
