@@ -1,0 +1,30 @@
+"""Where a step of the persistent decoder forward kernel spends its time: 100 MHz timestamps taken by workgroup 0 at its phase
+boundaries (vag_set_option("dec_stamps", device address)).  Columns per step: wait for h2 | phase 1 work | wait h1 | phase 2 with the
+score shares | drain of the atomics | arrive | wait scores | phase 4."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "vag-nmt_amd"))
+import numpy as np
+import torch, bench
+from vagnmt_hip import _lib as L
+c = bench.CFG2
+dev = torch.device("cuda:0")
+Tt = c["Tt"]
+st = torch.zeros(Tt * 8, dtype=torch.int64, device=dev)
+L.set_option("dec_stamps", st.data_ptr())
+fam = bench.measure_operators(c, dev)
+torch.cuda.synchronize()
+L.set_option("dec_stamps", 0)
+s = st.cpu().numpy().reshape(Tt, 8).astype(np.float64) * 0.01        # us
+rows = []
+for t in range(1, Tt - 1):
+    a = s[t]
+    nxt = s[t + 1][0]
+    rows.append([a[1] - a[0], a[2] - a[1], a[3] - a[2], a[4] - a[3], a[5] - a[4], a[6] - a[5], a[7] - a[6], nxt - a[7]])
+r = np.array(rows)
+names = ["wait h2", "phase1", "wait h1", "phase2+scores", "atomic drain", "(arrive)", "wait sc", "phase4"]
+print("per step (us), mean over steps 1..%d of workgroup 0:" % (Tt - 2))
+for n, m, md in zip(names, r.mean(0), np.median(r, 0)):
+    print("  %-8s mean %6.2f  median %6.2f" % (n, m, md))
+print("  total    %6.2f" % r.sum(1).mean())
+print("operator timings:", {k: round(v * 1e6, 1) for k, v in fam.items()})

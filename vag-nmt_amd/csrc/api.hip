@@ -102,6 +102,7 @@ int vag_set_option(const char* name, int64_t value) {
     for (const auto& e : ints)
         if (strcmp(name, e.n) == 0) { *e.p = (int)value; return VAG_OK; }
     if (strcmp(name, "head_chunk") == 0) { o.head_chunk = value; return VAG_OK; }
+    if (strcmp(name, "dec_stamps") == 0) { o.dec_stamps = value; return VAG_OK; }
     return VAG_EINVAL;
 }
 

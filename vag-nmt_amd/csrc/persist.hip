@@ -372,12 +372,12 @@ __global__ __launch_bounds__(512, 1) void enc_bwd_persistent_kernel(EncBArgs a) 
 //   * grid = ceil(B/16) row tiles x 64 workgroups (256 at B = 64), one per CU.  Workgroup i of a row tile owns hidden units
 //     [8i, 8i+8) of both cells and attention-query columns [16i, 16i+16) for the tile's 16 batch rows;
 //   * registers: its rows of W_hh1 (24), attn_h (16) and W_hh2 (24) as bf16x3 planes in MFMA operand layout;
-//   * LDS: the attention keys pe of its share of the tile's (row, position) pairs (Ts/4 pairs x C floats) and its 24 gate
-//     columns of the projected keys encwp for all 16 x Ts pairs -- the 21 MB per step that the launch chain streams from
+//   * LDS: its 16 query columns of the attention keys pe and its 24 gate columns of the projected keys encwp, for all
+//     16 x Ts (row, position) pairs of the tile -- the 21 MB per step that the launch chain streams from
 //     L2 / the Infinity Cache at every step are read from memory ONCE per sequence;
-//   * a step = 4 phases with an exchange between them, each exchange = sc1 stores + counter + sc1 loads as in the encoder
-//     kernel above:   h2[t-1] -> (gru_1 cell) -> h1 -> (q = attn_h h1, hp2 = W_hh2 h1 + b) -> q -> (scores of own pairs)
-//                     -> scores -> (softmax, projected context of own columns, gru_2 cell) -> h2[t].
+//   * a step = 3 phases with an exchange between them (sc1 stores / fp32 atomics + counter + sc1 loads, as in the encoder
+//     kernel above):   h2[t-1] -> (gru_1 cell) -> h1 -> (q = attn_h h1, hp2 = W_hh2 h1 + b, own columns' share of every score)
+//                      -> scores -> (softmax, projected context of own columns, gru_2 cell) -> h2[t].
 // Everything the backward pass needs (h1, both cells' gates, [q | hp2], alpha, h2) is saved in the launch chain's own
 // layout, so the backward operators are unchanged.
 struct DecPArgs {
@@ -385,7 +385,8 @@ struct DecPArgs {
     float *h1, *g1, *qhp, *alpha, *h2_all, *g2, *psc;
     unsigned* cnt;              // [4 phases][RT][Tt], zero on entry
     unsigned* err;
-    int B, Ts, Tt, H, RT, np;   // np: (row, position) pairs per workgroup = ceil(16 Ts / 64)
+    unsigned long long* dbg;    // NULL, or [Tt][8] 100 MHz timestamps of workgroup 0's phase boundaries (tools/exp_dec_phases.py)
+    int B, Ts, Tt, H, RT;
 };
 
 // A counter of the decoder kernel is 4 shards, 64 bytes apart (64 arrivals on ONE word serialise at the memory side, ~12 ns
@@ -414,23 +415,23 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
     constexpr int H = DEC_WGS * DEC_U, C = 2 * H, Q = C + 3 * H, KS = 2;       // K share of a wave: H / 8 = 64 = 2 k-steps
     const int i = blockIdx.x % DEC_WGS, rt = blockIdx.x / DEC_WGS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int B = a.B, Ts = a.Ts, Tt = a.Tt, np = a.np;
+    const int B = a.B, Ts = a.Ts, Tt = a.Tt;
     const int m0 = rt * 16, u0 = i * DEC_U;
     const int fr = lane & 15, fg = lane >> 4;
     const int kbase = wave * (H >> 3);
     const int64_t BH = (int64_t)B * H;
     // LDS carve-up (floats)
     float4* red = reinterpret_cast<float4*>(dlds);                  // [8 waves][3 tiles][64 lanes]
-    float* pe_s = dlds + 6144;                                       // [np][C]
-    float* ew_s = pe_s + (int64_t)np * C;                            // [16 rows][Ts][24]
+    float* pe_s = dlds + 6144;                                       // [16 Ts pairs][16 own query columns] of the keys
+    float* ew_s = pe_s + 16 * Ts * 16;                               // [16 rows][Ts][24]
     float* sc_s = ew_s + 16 * Ts * 24;                               // [16][Ts] scores -> alpha
     float* gi_s = sc_s + 16 * Ts;                                    // [16][24] projected context of own columns
     float* hp_s = gi_s + 16 * 24;                                    // [16][24] hidden-side projection of gru_2 (own units)
     float* bs_s = hp_s + 16 * 24;                                    // [3 kinds][3 gates][8]: b_hh1, b_hh2, b_ih2 of the own units
     float* hs_s = bs_s + 80;                                         // [2][16][8]: own units of h1 (this step) and h2 (previous step)
     float* v_s = hs_s + 256;                                         // [C] attention vector
-    float* mk_s = v_s + C;                                           // [np] source mask of the own pairs
-    float* q_s = mk_s + ((np + 3) & ~3);                             // [2][C] the (at most two) query rows the own pairs belong to
+    float* mk_s = v_s + C;                                           // [16][Ts] source mask of the tile's pairs
+    float* q_s = mk_s + 16 * Ts;                                     // [16][16] this step's query, own columns
 
     // ---- weights as bf16 planes in registers (A operands: rows = output columns).  Row of a tile held by lane fr:
     //   cell tiles: tile 0 = [r | z] of the 8 own units (fr < 8: gate r, unit fr; else gate z, unit fr - 8), tile 1 = [n | n again]
@@ -452,13 +453,12 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
             split8(*reinterpret_cast<const float4*>(q2), *reinterpret_cast<const float4*>(q2 + 4), w2[s][2]);
         }
     }
-    // ---- keys of the own pairs and own columns of the projected keys -> LDS (read from memory once per sequence)
-    const int P0 = np * i;                                           // first pair (index r * Ts + s inside the tile)
-    for (int x = threadIdx.x; x < np * (C / 4); x += 512) {
-        const int j = x / (C / 4), c4 = x - j * (C / 4);
-        const int P = min(P0 + j, 16 * Ts - 1);
+    // ---- own 16 query columns of the keys of all 16 x Ts pairs, own 24 gate columns of the projected keys -> LDS (read from
+    // memory once per sequence)
+    for (int x = threadIdx.x; x < 16 * Ts * 4; x += 512) {           // (pair, column quad) -> one float4
+        const int P = x >> 2, c4 = x & 3;
         const int r = P / Ts, sp = P - r * Ts, b = min(m0 + r, B - 1);
-        reinterpret_cast<float4*>(pe_s)[x] = reinterpret_cast<const float4*>(a.pe + ((int64_t)b * Ts + sp) * C)[c4];
+        reinterpret_cast<float4*>(pe_s)[x] = *reinterpret_cast<const float4*>(a.pe + ((int64_t)b * Ts + sp) * C + 16 * i + 4 * c4);
     }
     for (int x = threadIdx.x; x < 16 * Ts * 6; x += 512) {           // (row, position, gate, half) -> one float4
         const int hf = x & 1, g = (x >> 1) % 3, rs_ = x / 6;
@@ -476,23 +476,24 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
         bs_s[threadIdx.x] = src[g * H + u0 + u];
     }
     for (int x = threadIdx.x; x < C / 4; x += 512) reinterpret_cast<float4*>(v_s)[x] = reinterpret_cast<const float4*>(a.v)[x];
-    if (threadIdx.x < np) {
-        const int P = min(P0 + (int)threadIdx.x, 16 * Ts - 1);
-        const int r = P / Ts, sp = P - r * Ts;
-        mk_s[threadIdx.x] = a.mask[(int64_t)min(m0 + r, B - 1) * Ts + sp];
+    for (int x = threadIdx.x; x < 16 * Ts; x += 512) {
+        const int r = x / Ts, sp = x - r * Ts;
+        mk_s[x] = a.mask[(int64_t)min(m0 + r, B - 1) * Ts + sp];
     }
     if (ep) *reinterpret_cast<float4*>(hs_s + 128 + fr * 8 + 4 * hq) = eok ? *reinterpret_cast<const float4*>(a.h0 + (int64_t)em * H + eu)
                                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
     const int arow = min(m0 + fr, B - 1);
     gu32* c1 = (gu32*)(a.cnt + ((int64_t)0 * a.RT + rt) * Tt * CNT_WORDS);       // h2[t] published (waited on by step t + 1)
     gu32* c2 = (gu32*)(a.cnt + ((int64_t)1 * a.RT + rt) * Tt * CNT_WORDS);       // h1
-    gu32* c3 = (gu32*)(a.cnt + ((int64_t)2 * a.RT + rt) * Tt * CNT_WORDS);       // q
     gu32* c4 = (gu32*)(a.cnt + ((int64_t)3 * a.RT + rt) * Tt * CNT_WORDS);       // scores
     constexpr unsigned PER_SHARD = DEC_WGS / SHARDS;
     bool dead = false;
     __syncthreads();
+    const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+#define VAG_STAMP(k) do { if (stamp) a.dbg[t * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
     for (int t = 0; t < Tt; ++t) {
+        VAG_STAMP(0);
         // ================= phase 1: gru_1 cell (NMT_Decoder.py:121) =================
         float4 ha[KS], hb[KS];
         if (t == 0) {
@@ -501,6 +502,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
             for (int s = 0; s < KS; ++s) { ha[s] = *reinterpret_cast<const float4*>(hp + 32 * s); hb[s] = *reinterpret_cast<const float4*>(hp + 32 * s + 4); }
         } else {
             wait_count(c1 + (t - 1) * CNT_WORDS, PER_SHARD, a.err, dead);
+            VAG_STAMP(1);
             ld_rows_sc1<KS>(a.h2_all + ((int64_t)(t - 1) * B + arow) * H + kbase + 8 * fg, ha, hb);
         }
         {
@@ -566,7 +568,9 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
             if (threadIdx.x == 0) arrive(c2 + t * CNT_WORDS, i);
         }
         // ================= phase 2: q = attn_h h1 (:47), hp2 = W_hh2 h1 + b_hh2 (hidden side of gru_2, :129) =================
+        VAG_STAMP(2);
         wait_count(c2 + t * CNT_WORDS, PER_SHARD, a.err, dead);
+        VAG_STAMP(3);
         ld_rows_sc1<KS>(a.h1 + ((int64_t)t * B + arow) * H + kbase + 8 * fg, ha, hb);
         {
             f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -589,9 +593,8 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
                 const float4 x0 = red[(w * 3 + 0) * 64 + lane];
                 qv.x += x0.x; qv.y += x0.y; qv.z += x0.z; qv.w += x0.w;
             }
-            if (m0 + fr < B) st_sc1_f4(a.qhp + ((int64_t)t * B + m0 + fr) * Q + 16 * i + 4 * fg, qv);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) arrive(c3 + t * CNT_WORDS, i);
+            if (m0 + fr < B) *reinterpret_cast<float4*>(a.qhp + ((int64_t)t * B + m0 + fr) * Q + 16 * i + 4 * fg) = qv;     // saved for backward
+            *reinterpret_cast<float4*>(q_s + fr * 16 + 4 * fg) = qv;
             if (ep) {
                 float4 hp2[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
 #pragma unroll
@@ -611,47 +614,34 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
                 }
             }
         }
-        // ================= phase 3: scores of the own (row, position) pairs (:47-51, mask :41-43) =================
-        wait_count(c3 + t * CNT_WORDS, PER_SHARD, a.err, dead);
+        // ---- scores (:47-51): score[b,s] = sum_c v_c tanh(pe[b,s,c] + q[b,c]) is a sum over the query columns, so the owner
+        // of 16 columns adds ITS share for all 16 x Ts pairs of the tile (keys of those columns: LDS) into the step's score
+        // array with fp32 atomics -- no exchange of q, one hop less per step.  (The order in which the 64 shares of a score
+        // arrive is not fixed: scores are reproducible to fp32 rounding, like the split-K products of gemm.hip.)
+        __syncthreads();
         {
-            // the own pairs lie in at most two batch rows (np <= Ts): their query rows, one 16-byte sc1 load per thread -> LDS
-            const int r_lo = P0 / Ts;
-            const int rr_ = r_lo + (threadIdx.x >> 8);
-            const float* qp = a.qhp + ((int64_t)t * B + min(m0 + min(rr_, 15), B - 1)) * Q + 4 * (threadIdx.x & 255);
-            float4 qv;
-            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(qv) : "v"(qp) : "memory");
-            reinterpret_cast<float4*>(q_s)[threadIdx.x] = qv;
-            __syncthreads();
-            for (int j = wave; j < np; j += 8) {
-                const int P = P0 + j;
-                if (P >= 16 * Ts) break;
-                const int r = P / Ts, sp = P - r * Ts;
-                if (m0 + r >= B) break;
-                const float4* pr = reinterpret_cast<const float4*>(pe_s + (int64_t)j * C);
-                const float4* qr = reinterpret_cast<const float4*>(q_s + (r - r_lo) * C);
-                float acc = 0.f;
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const float4 pv = pr[lane + 64 * jj];
-                    const float4 vq = reinterpret_cast<const float4*>(v_s)[lane + 64 * jj];
-                    const float4 qq = qr[lane + 64 * jj];
-                    acc += vq.x * vag_tanh(pv.x + qq.x);
-                    acc += vq.y * vag_tanh(pv.y + qq.y);
-                    acc += vq.z * vag_tanh(pv.z + qq.z);
-                    acc += vq.w * vag_tanh(pv.w + qq.w);
-                }
-                acc = wave_sum(acc);
-                if (lane == 0) {
-                    if (mk_s[j] == 0.f) acc = -INFINITY;
-                    st_sc1_f1(a.psc + ((int64_t)t * B + m0 + r) * Ts + sp, acc);
-                }
+            const int cq = threadIdx.x & 3;
+            const float4 vq = *reinterpret_cast<const float4*>(v_s + 16 * i + 4 * cq);
+            for (int P = threadIdx.x >> 2; P < 16 * Ts; P += 128) {
+                const int r = P / Ts;
+                const float4 pv = reinterpret_cast<const float4*>(pe_s)[P * 4 + cq];
+                const float4 qq = *reinterpret_cast<const float4*>(q_s + r * 16 + 4 * cq);
+                float acc = vq.x * vag_tanh(pv.x + qq.x) + vq.y * vag_tanh(pv.y + qq.y) + vq.z * vag_tanh(pv.z + qq.z) +
+                            vq.w * vag_tanh(pv.w + qq.w);
+                acc += __shfl_xor(acc, 1, 64);
+                acc += __shfl_xor(acc, 2, 64);
+                if (cq == 0 && m0 + r < B) atomicAdd(a.psc + ((int64_t)t * B + m0 + r) * Ts + (P - r * Ts), acc);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains ...
+        VAG_STAMP(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave's atomics have been performed ...
         __syncthreads();                                       // ... before the one lane that signals for all of them
         if (threadIdx.x == 0) arrive(c4 + t * CNT_WORDS, i);
+        VAG_STAMP(5);
         // ================= phase 4: softmax (:44), projected context of own columns, gru_2 cell (:126-129) =================
+        VAG_STAMP(6);
         wait_count(c4 + t * CNT_WORDS, PER_SHARD, a.err, dead);
+        VAG_STAMP(7);
         for (int x0 = threadIdx.x; x0 < 16 * Ts; x0 += 1024) {                                // 4-byte sc1 loads, two in flight
             const int x1 = x0 + 512;
             const int r0 = x0 / Ts, r1 = min(x1, 16 * Ts - 1) / Ts;
@@ -660,8 +650,8 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
             float v0, v1;
             asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
                          : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
-            sc_s[x0] = v0;
-            if (x1 < 16 * Ts) sc_s[x1] = v1;
+            sc_s[x0] = mk_s[x0] == 0.f ? -INFINITY : v0;                                      // mask :41-43
+            if (x1 < 16 * Ts) sc_s[x1] = mk_s[x1] == 0.f ? -INFINITY : v1;
         }
         __syncthreads();
         for (int r = wave; r < 16; r += 8) {
@@ -731,6 +721,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
         }
         if (threadIdx.x == 0) arrive(c1 + t * CNT_WORDS, i);
     }
+#undef VAG_STAMP
 }
 
 __global__ __launch_bounds__(256) void zero_u32_kernel(unsigned* p, int n) {
@@ -780,8 +771,7 @@ int vag_enc_fwd_persistent_launch(const float* xp, const float* w_fw, const floa
 // Eligibility of the persistent decoder: H = 512 (8 units per workgroup x 64 workgroups per row tile), at most 4 row tiles
 // (B <= 64: 256 workgroups, one per CU), keys of a row tile fit the LDS, 4-float alignment of the row strides.
 static int64_t dec_persistent_lds_bytes(int64_t Ts) {
-    const int64_t np = cdiv64(16 * Ts, DEC_WGS);
-    return 4 * (6144 + np * 1024 + 16 * Ts * 24 + 16 * Ts + 16 * 24 + 16 * 24 + 80 + 256 + 1024 + ((np + 3) & ~3ll) + 2048);
+    return 4 * (6144 + 16 * Ts * 16 + 16 * Ts * 24 + 16 * Ts + 16 * 24 + 16 * 24 + 80 + 256 + 1024 + 16 * Ts + 256);
 }
 bool vag_dec_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H) {
     if (H != 512 || B <= 0 || B > 64 || Ts <= 0 || Tt <= 0 || Ts > 512) return false;
@@ -808,10 +798,14 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
     DecPArgs a;
     a.pe = pe; a.mask = mask; a.h0 = h0; a.xp1 = xp1; a.W1 = W1; a.b1 = b1; a.wcat = wcat; a.bcat = bcat; a.v = v; a.encwp = encwp;
     a.b_ih2 = b_ih2; a.h1 = h1; a.g1 = g1; a.qhp = qhp; a.alpha = alpha; a.h2_all = h2_all; a.g2 = g2; a.psc = psc;
-    a.B = (int)B; a.Ts = (int)Ts; a.Tt = (int)Tt; a.H = (int)H; a.RT = (int)cdiv64(B, 16); a.np = (int)cdiv64(16 * Ts, DEC_WGS);
+    a.B = (int)B; a.Ts = (int)Ts; a.Tt = (int)Tt; a.H = (int)H; a.RT = (int)cdiv64(B, 16);
     const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
     a.cnt = sync; a.err = sync + (nwords - 64);
+    a.dbg = reinterpret_cast<unsigned long long*>(vag_opt().dec_stamps);
     hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
+    VAG_LAUNCH_CHECK();
+    const int nsc = (int)(Tt * B * Ts);                              // the scores are accumulated with atomics: start from zero
+    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nsc, 256)), dim3(256), 0, s, reinterpret_cast<unsigned*>(psc), nsc);
     VAG_LAUNCH_CHECK();
     int64_t lds = dec_persistent_lds_bytes(Ts);
     if (lds < 84 * 1024) lds = 84 * 1024;                            // never two workgroups on one CU
