@@ -572,17 +572,16 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
         wait_count(c2 + t * CNT_WORDS, PER_SHARD, a.err, dead);
         VAG_STAMP(3);
         ld_rows_sc1<KS>(a.h1 + ((int64_t)t * B + arow) * H + kbase + 8 * fg, ha, hb);
+        bf16x8 hf2[KS][3];
         {
-            f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            // the query first: its score shares (fp32 atomics) are in flight while the hidden-side products follow
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                bf16x8 hf[3];
-                split8(ha[s], hb[s], hf);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) acc[j] = mma6(w2[s][j], hf, acc[j]);
+                split8(ha[s], hb[s], hf2[s]);
+                acc = mma6(w2[s][0], hf2[s], acc);
             }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) red[(wave * 3 + j) * 64 + lane] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+            red[(wave * 3 + 0) * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
         __syncthreads();
         if (wave == 0) {
@@ -595,30 +594,12 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
             }
             if (m0 + fr < B) *reinterpret_cast<float4*>(a.qhp + ((int64_t)t * B + m0 + fr) * Q + 16 * i + 4 * fg) = qv;     // saved for backward
             *reinterpret_cast<float4*>(q_s + fr * 16 + 4 * fg) = qv;
-            if (ep) {
-                float4 hp2[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
-#pragma unroll
-                for (int w = 0; w < 8; ++w) {
-                    const float4 x0 = red[(w * 3 + 1) * 64 + hq * 16 + fr], x1 = red[(w * 3 + 1) * 64 + (2 + hq) * 16 + fr];
-                    const float4 x2 = red[(w * 3 + 2) * 64 + hq * 16 + fr];
-                    hp2[0].x += x0.x; hp2[0].y += x0.y; hp2[0].z += x0.z; hp2[0].w += x0.w;
-                    hp2[1].x += x1.x; hp2[1].y += x1.y; hp2[1].z += x1.z; hp2[1].w += x1.w;
-                    hp2[2].x += x2.x; hp2[2].y += x2.y; hp2[2].z += x2.z; hp2[2].w += x2.w;
-                }
-#pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    const float4 bb = *reinterpret_cast<const float4*>(bs_s + 24 + g * 8 + 4 * hq);
-                    hp2[g].x += bb.x; hp2[g].y += bb.y; hp2[g].z += bb.z; hp2[g].w += bb.w;
-                    *reinterpret_cast<float4*>(hp_s + fr * 24 + g * 8 + 4 * hq) = hp2[g];      // read back by the same thread in phase 4
-                    if (eok) *reinterpret_cast<float4*>(a.qhp + ((int64_t)t * B + em) * Q + C + g * H + eu) = hp2[g];     // saved for backward
-                }
-            }
         }
+        __syncthreads();
         // ---- scores (:47-51): score[b,s] = sum_c v_c tanh(pe[b,s,c] + q[b,c]) is a sum over the query columns, so the owner
         // of 16 columns adds ITS share for all 16 x Ts pairs of the tile (keys of those columns: LDS) into the step's score
         // array with fp32 atomics -- no exchange of q, one hop less per step.  (The order in which the 64 shares of a score
         // arrive is not fixed: scores are reproducible to fp32 rounding, like the split-K products of gemm.hip.)
-        __syncthreads();
         {
             const int cq = threadIdx.x & 3;
             const float4 vq = *reinterpret_cast<const float4*>(v_s + 16 * i + 4 * cq);
@@ -633,11 +614,40 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
                 if (cq == 0 && m0 + r < B) atomicAdd(a.psc + ((int64_t)t * B + m0 + r) * Ts + (P - r * Ts), acc);
             }
         }
+        {
+            // hidden side of gru_2 (needed in phase 4 only): under the atomics' flight
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                acc[0] = mma6(w2[s][1], hf2[s], acc[0]);
+                acc[1] = mma6(w2[s][2], hf2[s], acc[1]);
+            }
+            red[(wave * 3 + 1) * 64 + lane] = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+            red[(wave * 3 + 2) * 64 + lane] = make_float4(acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
+        }
         VAG_STAMP(4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave's atomics have been performed ...
         __syncthreads();                                       // ... before the one lane that signals for all of them
         if (threadIdx.x == 0) arrive(c4 + t * CNT_WORDS, i);
         VAG_STAMP(5);
+        if (ep) {
+            float4 hp2[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const float4 x0 = red[(w * 3 + 1) * 64 + hq * 16 + fr], x1 = red[(w * 3 + 1) * 64 + (2 + hq) * 16 + fr];
+                const float4 x2 = red[(w * 3 + 2) * 64 + hq * 16 + fr];
+                hp2[0].x += x0.x; hp2[0].y += x0.y; hp2[0].z += x0.z; hp2[0].w += x0.w;
+                hp2[1].x += x1.x; hp2[1].y += x1.y; hp2[1].z += x1.z; hp2[1].w += x1.w;
+                hp2[2].x += x2.x; hp2[2].y += x2.y; hp2[2].z += x2.z; hp2[2].w += x2.w;
+            }
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const float4 bb = *reinterpret_cast<const float4*>(bs_s + 24 + g * 8 + 4 * hq);
+                hp2[g].x += bb.x; hp2[g].y += bb.y; hp2[g].z += bb.z; hp2[g].w += bb.w;
+                *reinterpret_cast<float4*>(hp_s + fr * 24 + g * 8 + 4 * hq) = hp2[g];      // read back by the same thread in phase 4
+                if (eok) *reinterpret_cast<float4*>(a.qhp + ((int64_t)t * B + em) * Q + C + g * H + eu) = hp2[g];     // saved for backward
+            }
+        }
         // ================= phase 4: softmax (:44), projected context of own columns, gru_2 cell (:126-129) =================
         VAG_STAMP(6);
         wait_count(c4 + t * CNT_WORDS, PER_SHARD, a.err, dead);
