@@ -432,7 +432,6 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
     float* v_s = hs_s + 256;                                         // [C] attention vector
     float* mk_s = v_s + C;                                           // [16][Ts] source mask of the tile's pairs
     float* q_s = mk_s + 16 * Ts;                                     // [16][16] this step's query, own columns
-    float* st_s = q_s + 256;                                         // [16][2] row maximum and 1 / sum of the softmax
 
     // ---- weights as bf16 planes in registers (A operands: rows = output columns).  Row of a tile held by lane fr:
     //   cell tiles: tile 0 = [r | z] of the 8 own units (fr < 8: gate r, unit fr; else gate z, unit fr - 8), tile 1 = [n | n again]
@@ -665,25 +664,30 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
             if (x1 < 16 * Ts) sc_s[x1] = mk_s[x1] == 0.f ? -INFINITY : v1;
         }
         __syncthreads();
-        // softmax (:44) fused into the weighted sum: every thread of a (row, column) normalises for itself (Ts exps each: cheaper
-        // than a softmax pass and the barrier behind it); the weights themselves are written out after the hand-off below
+        for (int r = wave; r < 16; r += 8) {
+            float mx = -INFINITY;
+            for (int sp = lane; sp < Ts; sp += 64) mx = fmaxf(mx, sc_s[r * Ts + sp]);
+            mx = wave_max(mx);
+            float sum = 0.f;
+            for (int sp = lane; sp < Ts; sp += 64) sum += __expf(sc_s[r * Ts + sp] - mx);
+            sum = wave_sum(sum);
+            const float inv = 1.f / sum;
+            for (int sp = lane; sp < Ts; sp += 64) {
+                const float al = __expf(sc_s[r * Ts + sp] - mx) * inv;
+                sc_s[r * Ts + sp] = al;
+                if (i == 0 && m0 + r < B) a.alpha[((int64_t)t * B + m0 + r) * Ts + sp] = al;
+            }
+        }
+        __syncthreads();
         if (threadIdx.x < 16 * 24) {
             const int r = threadIdx.x / 24, col = threadIdx.x - r * 24;
-            const float* sc = sc_s + r * Ts;
+            const float* al = sc_s + r * Ts;
             const float* ew = ew_s + (int64_t)r * Ts * 24 + col;
-            float mx = -INFINITY;
-            for (int sp = 0; sp < Ts; ++sp) mx = fmaxf(mx, sc[sp]);
-            float s0 = 0.f, s1 = 0.f, d0 = 0.f, d1 = 0.f;
+            float s0 = 0.f, s1 = 0.f;
             int sp = 0;
-            for (; sp + 1 < Ts; sp += 2) {
-                const float e0 = __expf(sc[sp] - mx), e1 = __expf(sc[sp + 1] - mx);
-                d0 += e0; d1 += e1;
-                s0 += e0 * ew[sp * 24]; s1 += e1 * ew[(sp + 1) * 24];
-            }
-            if (sp < Ts) { const float e0 = __expf(sc[sp] - mx); d0 += e0; s0 += e0 * ew[sp * 24]; }
-            const float inv = 1.f / (d0 + d1);
-            gi_s[threadIdx.x] = (s0 + s1) * inv;
-            if (col == 0) { st_s[2 * r] = mx; st_s[2 * r + 1] = inv; }
+            for (; sp + 1 < Ts; sp += 2) { s0 += al[sp] * ew[sp * 24]; s1 += al[sp + 1] * ew[(sp + 1) * 24]; }
+            if (sp < Ts) s0 += al[sp] * ew[sp * 24];
+            gi_s[threadIdx.x] = s0 + s1;
         }
         __syncthreads();
         if (eok) {
@@ -726,12 +730,6 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
             *reinterpret_cast<float4*>(sv + 3 * BH) = make_float4(hn[0], hn[1], hn[2], hn[3]);
         }
         if (threadIdx.x == 0) arrive(c1 + t * CNT_WORDS, i);
-        if (i == 0) {           // the attention weights of this step, saved for the backward pass (off the critical path)
-            for (int x = threadIdx.x; x < 16 * Ts; x += 512) {
-                const int r = x / Ts;
-                if (m0 + r < B) a.alpha[((int64_t)t * B + m0 + r) * Ts + (x - r * Ts)] = __expf(sc_s[x] - st_s[2 * r]) * st_s[2 * r + 1];
-            }
-        }
     }
 #undef VAG_STAMP
 }
@@ -783,7 +781,7 @@ int vag_enc_fwd_persistent_launch(const float* xp, const float* w_fw, const floa
 // Eligibility of the persistent decoder: H = 512 (8 units per workgroup x 64 workgroups per row tile), at most 4 row tiles
 // (B <= 64: 256 workgroups, one per CU), keys of a row tile fit the LDS, 4-float alignment of the row strides.
 static int64_t dec_persistent_lds_bytes(int64_t Ts) {
-    return 4 * (6144 + 16 * Ts * 16 + 16 * Ts * 24 + 16 * Ts + 16 * 24 + 16 * 24 + 80 + 256 + 1024 + 16 * Ts + 256 + 32);
+    return 4 * (6144 + 16 * Ts * 16 + 16 * Ts * 24 + 16 * Ts + 16 * 24 + 16 * 24 + 80 + 256 + 1024 + 16 * Ts + 256);
 }
 bool vag_dec_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H) {
     if (H != 512 || B <= 0 || B > 64 || Ts <= 0 || Tt <= 0 || Ts > 512) return false;
