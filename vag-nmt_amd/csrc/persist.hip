@@ -675,7 +675,8 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
             for (int sp = lane; sp < Ts; sp += 64) {
                 const float al = __expf(sc_s[r * Ts + sp] - mx) * inv;
                 sc_s[r * Ts + sp] = al;
-                if (i == 0 && m0 + r < B) a.alpha[((int64_t)t * B + m0 + r) * Ts + sp] = al;
+                // saved for the backward pass; every workgroup of the tile holds all weights: each writes 1/64 of them
+                if (((r * Ts + sp) & (DEC_WGS - 1)) == i && m0 + r < B) a.alpha[((int64_t)t * B + m0 + r) * Ts + sp] = al;
             }
         }
         __syncthreads();
