@@ -38,13 +38,23 @@ dec_write = between_markers(sys.argv[2], "WRITE_SIZE")
 b_f = [v for k, v in fetch.items() if "gru_bwd_step_kernel" in k][0]
 b_w = [v for k, v in write.items() if "gru_bwd_step_kernel" in k][0]
 bwd_fetch = sum(b_f[-200:]) / 200; bwd_write = sum(b_w[-200:]) / 200
+def per_launch(name):
+    f = [v for k, v in fetch.items() if name in k]
+    w = [v for k, v in write.items() if name in k]
+    if not f or not w:
+        return None
+    return kib(2 * sum(f[0]) / len(f[0]) + sum(w[0]) / len(w[0]))
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/prof_decoder_fwd.py",
        "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B), KiB -> bytes",
        "gru_step_kernel_bytes_per_launch": kib(2 * cell_fetch + cell_write),
        "gru_step_kernel_fetch_bytes": kib(2 * cell_fetch), "gru_step_kernel_write_bytes": kib(cell_write),
        "gru_bwd_step_kernel_bytes_per_launch": kib(2 * bwd_fetch + bwd_write),
        "gru_bwd_step_kernel_fetch_bytes": kib(2 * bwd_fetch), "gru_bwd_step_kernel_write_bytes": kib(bwd_write),
-       "decoder_step_bytes": kib(2 * dec_fetch + dec_write) / (NSEQ * Tt)}
+       "decoder_step_bytes": kib(2 * dec_fetch + dec_write) / (NSEQ * Tt),
+       # round 3: the persistent recurrences (one launch = all steps); keys and weights stay on chip, so the measured traffic
+       # is far below the streaming model's algorithmic bytes (Tt x 35.67 MB for the decoder)
+       "dec_fwd_persistent_kernel_bytes_per_launch": per_launch("dec_fwd_persistent_kernel"),
+       "enc_fwd_persistent_kernel_bytes_per_launch": per_launch("enc_fwd_persistent_kernel")}
 out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "pmc.json")
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

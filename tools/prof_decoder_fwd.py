@@ -14,6 +14,8 @@ src, lens, tgt, im = bench.make_batch(c, 0, dev)
 lens_t = torch.tensor(lens, dtype=torch.int32, device=dev)
 with torch.no_grad():
     enc, mask = m._encode(src, lens_t, None)
+    for _ in range(3):
+        m._encode(src, lens_t, None)           # the persistent encoder kernel, for its traffic per launch
     _, ctx = m.vse_imagine.forward_bm(im, enc, mask, None)
     h0 = ops.DecInit.apply(enc, mask, ctx, m.decoderini.weight, m.decoderini.bias, 0.5)
     pe = ops.KeysProj.apply(enc, m.decoder.attn.attn_e.weight)
