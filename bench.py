@@ -511,6 +511,7 @@ def main():
     loss = float(out[0].item())
 
     log("timed region done: %.3f ms/step" % (dt / args.steps * 1e3))
+    ts.check()            # no persistent-kernel wait gave up (would void the steps)
     dp_info = None
     if world > 1:
         # per-rank step time with and without the collectives (same phases, all-reduces skipped): the difference is the

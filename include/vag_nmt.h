@@ -403,6 +403,11 @@ int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_wh
  * qhp (Tt,B,C+3H), alpha (Tt,B,Ts), h2_all (Tt,B,H); psc (Tt,B,Ts) floats and sync (vag_recurrence_sync_words 32-bit
  * words) are scratch. */
 int vag_recurrence_supported(int kind, int64_t B, int64_t Ts, int64_t Tt, int64_t H);
+/* The persistent kernels wait on each other inside one launch, which needs every workgroup resident at once (one per CU;
+ * vag_recurrence_supported checks the CU count).  Their waits are bounded: on a device where that does not hold they give
+ * up after ~1 s instead of hanging, the launch's results are then void.  This returns how many waits gave up since the last
+ * call (0 in a healthy run) and resets the count; it synchronises the device -- call it at checkpoints, not per step. */
+int vag_persistent_timeouts(void);
 int64_t vag_recurrence_sync_words(int kind, int64_t B, int64_t T);
 int vag_cgru_recurrence_fwd(const float* pe, const float* mask, const float* h0, const float* xp1, vag_dec_w w, const float* wcat,
                             const float* bcat, const float* encwp, int64_t B, int64_t Ts, int64_t Tt, int64_t H, float* h1,

@@ -52,6 +52,7 @@ def test_persistent_encoder_equals_launch_chain(H, B, Ts):
             L.set_option("persistent", 1)
     e0, l0, g0 = res[0]
     e1, l1, g1 = res[1]
+    assert L.lib().vag_persistent_timeouts() == 0
     assert torch.isfinite(e1).all()
     assert (e0 - e1).abs().max().item() <= 2e-6, (e0 - e1).abs().max().item()
     for b, Lb in enumerate(lens):
@@ -86,6 +87,7 @@ def test_persistent_decoder_equals_launch_chain(B, Ts, Tt):
         finally:
             L.set_option("persistent", 1)
     (l0, m0, g0), (l1, m1, g1) = res[0], res[1]
+    assert L.lib().vag_persistent_timeouts() == 0
     assert np.isfinite(l1)
     assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0)), (l0, l1)
     assert abs(m0 - m1) <= 2e-6 * max(1.0, abs(m0)), (m0, m1)

@@ -1320,6 +1320,7 @@ int vag_recurrence_supported(int kind, int64_t B, int64_t Ts, int64_t Tt, int64_
     if (kind == 1) return vag_dec_persistent_ok(B, Ts, Tt, H) ? 1 : 0;
     return 0;
 }
+int vag_persistent_timeouts(void) { return vag_persistent_timeouts_read(); }
 int64_t vag_recurrence_sync_words(int kind, int64_t B, int64_t T) {
     return kind == 0 ? vag_enc_persistent_sync_words(B, T) : vag_dec_persistent_sync_words(B, T);
 }

@@ -150,6 +150,7 @@ int vag_enc_fwd_persistent_launch(const float* xp, const float* w_fw, const floa
 int vag_enc_bwd_persistent_launch(const float* whhT, const float* d_enc, const float* gates, const float* hst, const int* lengths,
                                   const uint64_t* rng, float p_ctx, float* d_xp, float* dgh, unsigned* sync, int64_t B, int64_t Ts,
                                   int64_t H, hipStream_t s);
+int vag_persistent_timeouts_read(void);
 bool vag_dec_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H);
 int64_t vag_dec_persistent_sync_words(int64_t B, int64_t Tt);
 int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const float* h0, const float* xp1, const float* W1,

@@ -27,6 +27,14 @@ typedef unsigned __attribute__((address_space(1))) gu32;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 constexpr unsigned SPIN_LIMIT = 1u << 19;       // polls before giving up (~a second; a healthy wait is a few hundred polls)
+// Waits that gave up since the last vag_persistent_timeouts() (results of such a launch are void): the kernels assume that
+// every workgroup of the grid is resident at once -- one per CU, checked on the host against the CU count -- and a spin is
+// bounded so that a device on which that does not hold (CU masks, a partitioned GPU) drains instead of hanging.
+__device__ unsigned g_persist_timeouts;
+__device__ __forceinline__ void note_timeout(unsigned* err) {
+    __hip_atomic_store((gu32*)err, 1u, RLX_AGENT);
+    atomicAdd(&g_persist_timeouts, 1u);
+}
 
 struct EncPArgs {
     const float* xp;            // (Ts, B, 6H): input projections [fwd r z n | rev r z n], biases included
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_persistent_kernel(EncPArgs a) 
             if (threadIdx.x == 0 && !dead) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(cnt + (k - 1), RLX_AGENT) < (unsigned)a.CS) {
-                    if (++spins > SPIN_LIMIT) { __hip_atomic_store((gu32*)a.err, 1u, RLX_AGENT); dead = true; break; }
+                    if (++spins > SPIN_LIMIT) { note_timeout(a.err); dead = true; break; }
                 }
             }
             __syncthreads();
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(512, 1) void enc_bwd_persistent_kernel(EncBArgs a) 
             if (threadIdx.x == 0 && !dead) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(cnt + (k + 1), RLX_AGENT) < (unsigned)a.CS) {
-                    if (++spins > SPIN_LIMIT) { __hip_atomic_store((gu32*)a.err, 1u, RLX_AGENT); dead = true; break; }
+                    if (++spins > SPIN_LIMIT) { note_timeout(a.err); dead = true; break; }
                 }
             }
             __syncthreads();
@@ -401,7 +409,7 @@ __device__ __forceinline__ void wait_count(gu32* c, unsigned want_per_shard, uns
         for (;;) {
             const bool ok = lane >= SHARDS || __hip_atomic_load(c + lane * SHARD_STRIDE, RLX_AGENT) >= want_per_shard;
             if (__all(ok)) break;
-            if (++spins > SPIN_LIMIT) { if (lane == 0) __hip_atomic_store((gu32*)err, 1u, RLX_AGENT); dead = true; break; }
+            if (++spins > SPIN_LIMIT) { if (lane == 0) note_timeout(err); dead = true; break; }
         }
     }
     __syncthreads();
@@ -847,4 +855,12 @@ int vag_enc_bwd_persistent_launch(const float* whhT, const float* d_enc, const f
     hipLaunchKernelGGL(enc_bwd_persistent_kernel<6>, dim3((unsigned)(2 * a.RT * a.CS)), dim3(512), 0, s, a);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
+}
+
+// Number of waits that gave up since the last call (synchronises the device).  0 in a healthy run.
+int vag_persistent_timeouts_read(void) {
+    unsigned v = 0, z = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_persist_timeouts), sizeof(v)) != hipSuccess) return -1;
+    if (v != 0 && hipMemcpyToSymbol(HIP_SYMBOL(g_persist_timeouts), &z, sizeof(z)) != hipSuccess) return -1;
+    return (int)v;
 }

@@ -14,8 +14,10 @@ with these changes in mechanism, none in arithmetic:
   * global-norm clipping and Adam are one fused pass over the flat buffer (vag_clip_adam_flat, three launches) that also
     leaves the gradient buffer zeroed for the next step, followed by the refresh of the derived weights;
 and, for data parallelism (one process per GPU over torch.distributed, backend "nccl" = RCCL), bucketed sum all-reduces
-of the flat gradient between the backward phases and the optimiser (clipping acts on the averaged gradient, exactly what
-a single-GPU step on the global batch's mean gradient would do)."""
+of the flat gradient between the backward phases and the optimiser.  Clipping acts on the average of the ranks' gradients:
+with equal batch sizes per rank (what data.shard_batches hands out; bucket remainders of different size on different ranks
+would make it a mean of per-rank means) that is a single-GPU step on the global batch's mean translation-loss gradient,
+with the ranking loss taken per shard."""
 import collections
 import ctypes as C
 import random
@@ -197,6 +199,14 @@ class TrainStep:
                 dist.broadcast(t, src=0, group=self.pg)
             if hasattr(self.backend, "after_optimizer"):
                 self.backend.after_optimizer()
+
+    def check(self):
+        """Synchronises and raises if a persistent recurrence kernel had to give up a wait since the last check (its
+        workgroups were not all resident: results of those steps are void).  For checkpoints / the end of an epoch."""
+        from ._lib import lib, VagError
+        n = lib().vag_persistent_timeouts()
+        if n != 0:
+            raise VagError("persistent recurrence kernels: %d waits gave up; disable them with set_option('persistent', 0)" % n)
 
     # ---- public ----
     def step(self, src, lengths, tgt, im=None, teacher=None):
