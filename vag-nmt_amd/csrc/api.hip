@@ -98,7 +98,7 @@ int vag_set_option(const char* name, int64_t value) {
     const struct { const char* n; int* p; } ints[] = {
         {"gemm_f32mfma", &o.gemm_f32mfma}, {"gemm_nogroup", &o.gemm_nogroup}, {"gemm_force_tile", &o.gemm_force_tile},
         {"gemm_force_splitk", &o.gemm_force_splitk}, {"gemm_debug", &o.gemm_debug}, {"head_fuse", &o.head_fuse},
-        {"head_bf16_grads", &o.head_bf16_grads}, {"persistent", &o.persistent}};
+        {"head_bf16_grads", &o.head_bf16_grads}, {"persistent", &o.persistent}, {"persistent_dec_bwd", &o.persistent_dec_bwd}};
     for (const auto& e : ints)
         if (strcmp(name, e.n) == 0) { *e.p = (int)value; return VAG_OK; }
     if (strcmp(name, "head_chunk") == 0) { o.head_chunk = value; return VAG_OK; }
@@ -726,8 +726,9 @@ int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const f
         VAG_TRY(vag_transpose_launch(p.wcat, Q, H, z.wcatT, s));            // (H, C+3H) = [attn_h^T | W_hh2^T]
         VAG_TRY(vag_transpose_launch(w.gru1.w_hh, 3 * H, H, z.whh1T, s));   // (H, 3H)
     }
+    const bool persist = !s16 && vag_opt().persistent && vag_opt().persistent_dec_bwd && vag_dec_bwd_persistent_ok(B, Ts, Tt, H);
     // gru_2 cell backward of the last step: nothing arrives from a later step
-    {
+    if (!persist) {
         GruBwdArgs a = {};
         a.ld_add = H; a.ldh = H; a.ldgi = 3 * H; a.ldgh = Q; a.M = (int)B; a.H = (int)H;
         const int64_t t = Tt - 1;
@@ -747,7 +748,13 @@ int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const f
         VAG_TRY(vag_skinny_batched_launch(B, Tt, Ts, C, d_c_all, B * C, C, enc, C, Ts * C, z.dah, B * Ts, Ts, s));
     else
         VAG_TRY(vag_attn_scores_ex_launch(1, enc, d_c_all, C, nullptr, nullptr, Tt * B, 1, B, Ts, C, nullptr, z.dah, s));
-    for (int64_t t = Tt - 1; t >= 0; --t) {
+    if (persist) {
+        // the whole backward recurrence in ONE launch (persist.hip); k.psc (the forward's score exchange) holds d alpha
+        VAG_TRY(vag_dec_bwd_persistent_launch(pe, k.encwp, w.attn_v, z.wcatT, z.whh1T, h0, h2_all, k.h1, k.g1, k.g2, k.qhp, k.alpha,
+                                              d_h2_all, z.dah, z.dgi2, z.dqgh, z.ds, z.dgi1, z.dgh1, d_h0, k.psc, k.sync, B, Ts, Tt, H,
+                                              s));
+    }
+    for (int64_t t = Tt - 1; t >= 0 && !persist; --t) {
         float* dgi2 = z.dgi2 + t * B * 3 * H;
         float* dqgh = z.dqgh + t * B * Q;
         // attention backward: d alpha ; softmax backward ; dq = sum_s ds v (1 - tanh^2)

@@ -97,6 +97,7 @@ struct VagOptions {
     int head_fuse = 1;           // 0: the chunked head recomputes its chunks in backward instead of finishing them in forward
     int head_bf16_grads = 1;     // 2-byte storage mode: one bf16 plane in the head's two vocabulary-sized gradient products
     int persistent = 1;          // 0: the recurrences always run as chains of per-step launches (persist.hip off)
+    int persistent_dec_bwd = 1;  // 0: only the decoder's backward recurrence stays a launch chain
     int64_t dec_stamps = 0;      // device address of Tt x 8 uint64 for the persistent decoder's phase timestamps (0: none)
 };
 VagOptions& vag_opt();

@@ -743,6 +743,308 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
 #undef VAG_STAMP
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Decoder backward recurrence (teacher forced), all Tt steps in ONE launch.  Same decomposition as the forward kernel:
+// 64 workgroups per 16-row tile, workgroup i owns hidden units [8i, 8i+8) of both cells, query columns [16i, 16i+16) and the
+// 24 gate columns of its units.  Per step t (descending), three hand-offs:
+//   A  (own units' gru_2 cell backward of step t is at hand: dgi2, dgh2, z2*dh2)  the own gate columns' share of every
+//      d alpha[b,s] = encwp[b,s,:] . dgi2[b,:] from the LDS-resident projected keys, added with fp32 atomics; dgh2 published
+//   B  complete d alpha (+ the head's part, dah) -> softmax backward ds -> dq for the own 16 query columns from the
+//      LDS-resident keys, published;  beside that hand-off: the hidden side dgh2 W_hh2 + z2*dh2 for the own units
+//      (W_hh2^T rows streamed from L2: the third weight slice does not fit the registers)
+//   C  dh1 = dq attn_h + hidden side -> gru_1 cell backward -> dgi1 saved, dgh1 published, z1*dh1 kept
+//   D  dh2[t-1] = dgh1 W_hh1 + z1*dh1 + head's d_h2[t-1] -> gru_2 cell backward of step t-1 -> (A) of the next step, local
+// Outputs in the launch chain's layout (dgi2, [dq | dgh2], ds, dgi1, dgh1, d_h0): the post-loop operators are unchanged.
+struct DecBArgs {
+    const float *pe, *encwp, *v, *wcatT, *whh1T;            // wcatT (H, C+3H) = [attn_h^T | W_hh2^T], whh1T (H, 3H)
+    const float *h0, *h2_all, *h1, *g1, *g2, *qhp, *alpha;  // saved by the forward pass
+    const float *d_h2_all, *dah;                            // head's gradient of h2 (Tt,B,H); d alpha through the head (Tt,B,Ts)
+    float *dgi2, *dqgh, *ds, *dgi1, *dgh1, *d_h0;
+    float* dal;                 // (Tt,B,Ts) accumulated with atomics: zero on entry
+    unsigned* cnt;              // [3 phases][RT][Tt] x CNT_WORDS, zero on entry
+    unsigned* err;
+    int B, Ts, Tt, H, RT;
+};
+
+// GRU cell backward for 4 units (see gru_bwd_elem_kernel): dh = total gradient of the cell's output
+__device__ __forceinline__ void cell_bwd4(const float (&dh)[4], const float4 (&sv)[4], const float4 hp, float (&gi)[3][4],
+                                          float (&gh)[3][4], float (&direct)[4]) {
+    const float r_[4] = {sv[0].x, sv[0].y, sv[0].z, sv[0].w}, z_[4] = {sv[1].x, sv[1].y, sv[1].z, sv[1].w};
+    const float n_[4] = {sv[2].x, sv[2].y, sv[2].z, sv[2].w}, hn[4] = {sv[3].x, sv[3].y, sv[3].z, sv[3].w};
+    const float hpv[4] = {hp.x, hp.y, hp.z, hp.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float dn_pre = dh[q] * (1.f - z_[q]) * (1.f - n_[q] * n_[q]);
+        const float dz_pre = dh[q] * (hpv[q] - n_[q]) * z_[q] * (1.f - z_[q]);
+        const float dr_pre = dn_pre * hn[q] * r_[q] * (1.f - r_[q]);
+        gi[0][q] = dr_pre; gi[1][q] = dz_pre; gi[2][q] = dn_pre;
+        gh[0][q] = dr_pre; gh[1][q] = dz_pre; gh[2][q] = dn_pre * r_[q];
+        direct[q] = dh[q] * z_[q];
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float dlds[];
+    constexpr int H = DEC_WGS * DEC_U, C = 2 * H, Q = C + 3 * H;
+    constexpr unsigned PER_SHARD = DEC_WGS / SHARDS;
+    const int i = blockIdx.x % DEC_WGS, rt = blockIdx.x / DEC_WGS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int B = a.B, Ts = a.Ts, Tt = a.Tt;
+    const int m0 = rt * 16, u0 = i * DEC_U;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int64_t BH = (int64_t)B * H;
+    const int NP = 16 * Ts;                                          // (row, position) pairs of the tile
+    float4* red = reinterpret_cast<float4*>(dlds);                   // [8 waves][64 lanes]
+    float* pe_s = dlds + 2048;                                       // [NP][16 own query columns]
+    float* ew_t = pe_s + NP * 16;                                    // [24 own gate columns][NP]  (column-major: pair-parallel reads)
+    float* da_s = ew_t + 24 * NP;                                    // [NP] d alpha -> ds
+    float* al_s = da_s + NP;                                         // [NP] alpha of this step
+    float* gi_s = al_s + NP;                                         // [16][24] dgi2 of the own columns
+    float* d1_s = gi_s + 384;                                        // [16][8] z2 * dh2: the direct path into dh1
+    float* pb_s = d1_s + 128;                                        // [16][8] dgh2 W_hh2 + z2 * dh2
+    float* c1_s = pb_s + 128;                                        // [16][8] z1 * dh1: the direct path into dh2[t-1]
+    float* dq_s = c1_s + 128;                                        // [16][16] dq of the own columns (staging for 16-byte stores)
+
+    // ---- register-resident weights (A operands, 16-row tile = the 8 own units twice): attn_h^T (K = C) and W_hh1^T (K = 3H)
+    constexpr int KB = C / 8 / 32, KC = 3 * H / 8 / 32;             // k-steps per wave: 4 and 6
+    bf16x8 wb[KB][3], wc[KC][3];
+    {
+        const float* pb = a.wcatT + (int64_t)(u0 + (fr & 7)) * Q + wave * (C >> 3) + 8 * fg;
+        const float* pc = a.whh1T + (int64_t)(u0 + (fr & 7)) * (3 * H) + wave * (3 * H >> 3) + 8 * fg;
+#pragma unroll
+        for (int s = 0; s < KB; ++s) split8(*reinterpret_cast<const float4*>(pb + 32 * s), *reinterpret_cast<const float4*>(pb + 32 * s + 4), wb[s]);
+#pragma unroll
+        for (int s = 0; s < KC; ++s) split8(*reinterpret_cast<const float4*>(pc + 32 * s), *reinterpret_cast<const float4*>(pc + 32 * s + 4), wc[s]);
+    }
+    const float* wa_row = a.wcatT + (int64_t)(u0 + (fr & 7)) * Q + C + wave * (3 * H >> 3) + 8 * fg;      // W_hh2^T, streamed per step
+    // ---- keys -> LDS
+    for (int x = threadIdx.x; x < NP * 4; x += 512) {
+        const int P = x >> 2, c4 = x & 3;
+        const int r = P / Ts, sp = P - r * Ts, b = min(m0 + r, B - 1);
+        reinterpret_cast<float4*>(pe_s)[x] = *reinterpret_cast<const float4*>(a.pe + ((int64_t)b * Ts + sp) * C + 16 * i + 4 * c4);
+    }
+    for (int x = threadIdx.x; x < NP * 6; x += 512) {                // (pair, gate, half): four columns each
+        const int hf = x & 1, g = (x >> 1) % 3, P = x / 6;
+        const int r = P / Ts, sp = P - r * Ts, b = min(m0 + r, B - 1);
+        const float4 e = *reinterpret_cast<const float4*>(a.encwp + ((int64_t)b * Ts + sp) * 3 * H + g * H + u0 + 4 * hf);
+        const int col = g * 8 + 4 * hf;
+        ew_t[(col + 0) * NP + P] = e.x; ew_t[(col + 1) * NP + P] = e.y; ew_t[(col + 2) * NP + P] = e.z; ew_t[(col + 3) * NP + P] = e.w;
+    }
+    const int hq = (threadIdx.x >> 4) & 1;
+    const int em = m0 + fr, eu = u0 + 4 * hq;
+    const bool ep = threadIdx.x < 32, eok = ep && em < B;
+    const int arow = min(m0 + fr, B - 1);
+    gu32* cA = (gu32*)(a.cnt + ((int64_t)0 * a.RT + rt) * Tt * CNT_WORDS);
+    gu32* cB = (gu32*)(a.cnt + ((int64_t)1 * a.RT + rt) * Tt * CNT_WORDS);
+    gu32* cC = (gu32*)(a.cnt + ((int64_t)2 * a.RT + rt) * Tt * CNT_WORDS);
+    bool dead = false;
+    const float vq = a.v[16 * i + (threadIdx.x & 15)];               // attention vector, this thread's query column
+
+    // gru_2 cell backward of step t for the own units (epilogue threads), given the total gradient dh2 of its output;
+    // leaves dgi2 in LDS + memory, dgh2 published (sc1), z2 * dh2 in LDS
+    auto cell2_bwd = [&](int t, const float (&dh2)[4]) {
+        const int64_t o = (int64_t)em * H + eu;
+        float4 sv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sv[q] = *reinterpret_cast<const float4*>(a.g2 + ((int64_t)t * 4 + q) * BH + o);
+        const float4 hp = *reinterpret_cast<const float4*>(a.h1 + (int64_t)t * BH + o);
+        float gi[3][4], gh[3][4], dr[4];
+        cell_bwd4(dh2, sv, hp, gi, gh, dr);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            st_sc1_f4(a.dqgh + ((int64_t)t * B + em) * Q + C + g * H + eu, make_float4(gh[g][0], gh[g][1], gh[g][2], gh[g][3]));
+            const float4 x = make_float4(gi[g][0], gi[g][1], gi[g][2], gi[g][3]);
+            *reinterpret_cast<float4*>(gi_s + fr * 24 + g * 8 + 4 * hq) = x;
+            *reinterpret_cast<float4*>(a.dgi2 + ((int64_t)t * B + em) * 3 * H + g * H + eu) = x;
+        }
+        *reinterpret_cast<float4*>(d1_s + fr * 8 + 4 * hq) = make_float4(dr[0], dr[1], dr[2], dr[3]);
+    };
+    // sum of the 8 waves' partial tiles for this epilogue thread's 4 units (tile rows 4 hq + i, batch row fr)
+    auto red4 = [&](float (&x)[4]) {
+        float4 sum = red[hq * 16 + fr];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) {
+            const float4 o = red[w * 64 + hq * 16 + fr];
+            sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
+        }
+        x[0] = sum.x; x[1] = sum.y; x[2] = sum.z; x[3] = sum.w;
+    };
+
+    // ---- step Tt-1: nothing arrives from a later step
+    if (ep) {
+        if (eok) {
+            const float4 d = *reinterpret_cast<const float4*>(a.d_h2_all + (int64_t)(Tt - 1) * BH + (int64_t)em * H + eu);
+            const float dh2[4] = {d.x, d.y, d.z, d.w};
+            cell2_bwd(Tt - 1, dh2);
+        } else {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) *reinterpret_cast<float4*>(gi_s + fr * 24 + g * 8 + 4 * hq) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(d1_s + fr * 8 + 4 * hq) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+
+    for (int t = Tt - 1; t >= 0; --t) {
+        // ================= A: d alpha shares of the own gate columns (atomics); dgh2[t] was published by cell2_bwd =================
+        for (int P = threadIdx.x; P < NP; P += 512) {
+            const int r = P / Ts;
+            const float* g = gi_s + r * 24;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 24; ++k) acc += ew_t[k * NP + P] * g[k];
+            if (m0 + r < B) atomicAdd(a.dal + ((int64_t)t * B + m0 + r) * Ts + (P - r * Ts), acc);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave's atomics and the epilogue's sc1 stores are done ...
+        __syncthreads();
+        if (threadIdx.x == 0) arrive(cA + t * CNT_WORDS, i);
+        // operands of phase B that do not depend on the hand-off
+        float al0 = 0.f, al1 = 0.f, dh0 = 0.f, dh1_ = 0.f;
+        const int x0 = threadIdx.x, x1 = threadIdx.x + 512;
+        {
+            const int r0 = min(x0, NP - 1) / Ts, r1 = min(x1, NP - 1) / Ts;
+            const int64_t o0 = ((int64_t)t * B + min(m0 + r0, B - 1)) * Ts + (min(x0, NP - 1) - r0 * Ts);
+            const int64_t o1 = ((int64_t)t * B + min(m0 + r1, B - 1)) * Ts + (min(x1, NP - 1) - r1 * Ts);
+            al0 = a.alpha[o0]; dh0 = a.dah[o0];
+            if (x1 < NP) { al1 = a.alpha[o1]; dh1_ = a.dah[o1]; }
+            const float qv = threadIdx.x < 256 ? a.qhp[((int64_t)t * B + min(m0 + (int)(threadIdx.x >> 4), B - 1)) * Q + 16 * i + (threadIdx.x & 15)] : 0.f;
+            // ================= B: complete d alpha -> ds -> dq of the own query columns =================
+            wait_count(cA + t * CNT_WORDS, PER_SHARD, a.err, dead);
+            float v0, v1;
+            const float* p0 = a.dal + o0;
+            const float* p1 = a.dal + o1;
+            asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
+            if (x0 < NP) { da_s[x0] = v0 + dh0; al_s[x0] = al0; }
+            if (x1 < NP) { da_s[x1] = v1 + dh1_; al_s[x1] = al1; }
+            __syncthreads();
+            for (int r = wave; r < 16; r += 8) {               // softmax backward, one wave per row
+                float dot = 0.f;
+                for (int sp = lane; sp < Ts; sp += 64) dot += al_s[r * Ts + sp] * da_s[r * Ts + sp];
+                dot = wave_sum(dot);
+                for (int sp = lane; sp < Ts; sp += 64) {
+                    const float d = al_s[r * Ts + sp] * (da_s[r * Ts + sp] - dot);
+                    da_s[r * Ts + sp] = d;
+                    if (((r * Ts + sp) & (DEC_WGS - 1)) == i && m0 + r < B) a.ds[((int64_t)t * B + m0 + r) * Ts + sp] = d;
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < 256) {
+                const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+                const float* pr = pe_s + (int64_t)r * Ts * 16 + c;
+                const float* dsr = da_s + r * Ts;
+                float acc0 = 0.f, acc1 = 0.f;
+                int sp = 0;
+                for (; sp + 1 < Ts; sp += 2) {
+                    const float t0 = vag_tanh(pr[sp * 16] + qv), t1 = vag_tanh(pr[(sp + 1) * 16] + qv);
+                    acc0 += dsr[sp] * (1.f - t0 * t0);
+                    acc1 += dsr[sp + 1] * (1.f - t1 * t1);
+                }
+                if (sp < Ts) { const float t0 = vag_tanh(pr[sp * 16] + qv); acc0 += dsr[sp] * (1.f - t0 * t0); }
+                dq_s[threadIdx.x] = (acc0 + acc1) * vq;
+            }
+            __syncthreads();
+            if (threadIdx.x < 64) {                             // 16 rows x 4 column quads: one 16-byte sc1 store each
+                const int r = threadIdx.x >> 2, c4 = threadIdx.x & 3;
+                if (m0 + r < B) st_sc1_f4(a.dqgh + ((int64_t)t * B + m0 + r) * Q + 16 * i + 4 * c4, *reinterpret_cast<const float4*>(dq_s + r * 16 + 4 * c4));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (threadIdx.x == 0) arrive(cB + t * CNT_WORDS, i);
+            }
+        }
+        // ---- beside that hand-off: hidden side of dh1 for the own units, dgh2[t] W_hh2 + z2 * dh2 (dgh2 rows: complete since cA)
+        {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            float4 ga[KC], gb[KC];
+            ld_rows_sc1<KC>(a.dqgh + ((int64_t)t * B + arow) * Q + C + wave * (3 * H >> 3) + 8 * fg, ga, gb);
+#pragma unroll
+            for (int s = 0; s < KC; ++s) {
+                bf16x8 wf[3], hf[3];
+                split8(*reinterpret_cast<const float4*>(wa_row + 32 * s), *reinterpret_cast<const float4*>(wa_row + 32 * s + 4), wf);
+                split8(ga[s], gb[s], hf);
+                acc = mma6(wf, hf, acc);
+            }
+            red[wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            __syncthreads();
+            if (ep) {
+                float x[4];
+                red4(x);
+                const float4 d1 = *reinterpret_cast<const float4*>(d1_s + fr * 8 + 4 * hq);
+                *reinterpret_cast<float4*>(pb_s + fr * 8 + 4 * hq) = make_float4(x[0] + d1.x, x[1] + d1.y, x[2] + d1.z, x[3] + d1.w);
+            }
+        }
+        // ================= C: dh1 = dq attn_h + hidden side -> gru_1 cell backward =================
+        float4 s1[4], hp1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (eok) {
+            const int64_t o = (int64_t)em * H + eu;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s1[q] = *reinterpret_cast<const float4*>(a.g1 + ((int64_t)t * 4 + q) * BH + o);
+            hp1 = *reinterpret_cast<const float4*>((t > 0 ? a.h2_all + (int64_t)(t - 1) * BH : a.h0) + o);
+        }
+        wait_count(cB + t * CNT_WORDS, PER_SHARD, a.err, dead);
+        {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            float4 ga[KB], gb[KB];
+            ld_rows_sc1<KB>(a.dqgh + ((int64_t)t * B + arow) * Q + wave * (C >> 3) + 8 * fg, ga, gb);
+#pragma unroll
+            for (int s = 0; s < KB; ++s) {
+                bf16x8 hf[3];
+                split8(ga[s], gb[s], hf);
+                acc = mma6(wb[s], hf, acc);
+            }
+            red[wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+        __syncthreads();
+        if (ep) {
+            float x[4];
+            red4(x);
+            if (eok) {
+                const float4 pbv = *reinterpret_cast<const float4*>(pb_s + fr * 8 + 4 * hq);
+                const float dh1[4] = {x[0] + pbv.x, x[1] + pbv.y, x[2] + pbv.z, x[3] + pbv.w};
+                float gi[3][4], gh[3][4], dr[4];
+                cell_bwd4(dh1, s1, hp1, gi, gh, dr);
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    st_sc1_f4(a.dgh1 + ((int64_t)t * B + em) * 3 * H + g * H + eu, make_float4(gh[g][0], gh[g][1], gh[g][2], gh[g][3]));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (threadIdx.x == 0) arrive(cC + t * CNT_WORDS, i);
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    *reinterpret_cast<float4*>(a.dgi1 + ((int64_t)t * B + em) * 3 * H + g * H + eu) = make_float4(gi[g][0], gi[g][1], gi[g][2], gi[g][3]);
+                *reinterpret_cast<float4*>(c1_s + fr * 8 + 4 * hq) = make_float4(dr[0], dr[1], dr[2], dr[3]);
+            } else if (threadIdx.x == 0) {
+                arrive(cC + t * CNT_WORDS, i);
+            }
+        }
+        // ================= D: dh2[t-1] = dgh1 W_hh1 + z1 * dh1 (+ the head's part) -> gru_2 cell backward of step t-1 =================
+        float4 dadd = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (eok && t > 0) dadd = *reinterpret_cast<const float4*>(a.d_h2_all + (int64_t)(t - 1) * BH + (int64_t)em * H + eu);
+        wait_count(cC + t * CNT_WORDS, PER_SHARD, a.err, dead);
+        {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            float4 ga[KC], gb[KC];
+            ld_rows_sc1<KC>(a.dgh1 + ((int64_t)t * B + arow) * 3 * H + wave * (3 * H >> 3) + 8 * fg, ga, gb);
+#pragma unroll
+            for (int s = 0; s < KC; ++s) {
+                bf16x8 hf[3];
+                split8(ga[s], gb[s], hf);
+                acc = mma6(wc[s], hf, acc);
+            }
+            red[wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+        __syncthreads();
+        if (ep) {
+            float x[4];
+            red4(x);
+            if (eok) {
+                const float4 c1 = *reinterpret_cast<const float4*>(c1_s + fr * 8 + 4 * hq);
+                const float dh2[4] = {x[0] + c1.x + dadd.x, x[1] + c1.y + dadd.y, x[2] + c1.z + dadd.z, x[3] + c1.w + dadd.w};
+                if (t > 0) cell2_bwd(t - 1, dh2);
+                else *reinterpret_cast<float4*>(a.d_h0 + (int64_t)em * H + eu) = make_float4(dh2[0], dh2[1], dh2[2], dh2[3]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void zero_u32_kernel(unsigned* p, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = 0u;
@@ -863,4 +1165,46 @@ int vag_persistent_timeouts_read(void) {
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_persist_timeouts), sizeof(v)) != hipSuccess) return -1;
     if (v != 0 && hipMemcpyToSymbol(HIP_SYMBOL(g_persist_timeouts), &z, sizeof(z)) != hipSuccess) return -1;
     return (int)v;
+}
+
+static int64_t dec_bwd_persistent_lds_bytes(int64_t Ts) {
+    const int64_t NP = 16 * Ts;
+    return 4 * (2048 + NP * 16 + 24 * NP + 2 * NP + 384 + 3 * 128 + 256 + 64);
+}
+bool vag_dec_bwd_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H) {
+    return vag_dec_persistent_ok(B, Ts, Tt, H) && dec_bwd_persistent_lds_bytes(Ts) <= 160 * 1024;
+}
+int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const float* v, const float* wcatT, const float* whh1T,
+                                  const float* h0, const float* h2_all, const float* h1, const float* g1, const float* g2,
+                                  const float* qhp, const float* alpha, const float* d_h2_all, const float* dah, float* dgi2,
+                                  float* dqgh, float* ds, float* dgi1, float* dgh1, float* d_h0, float* dal, unsigned* sync,
+                                  int64_t B, int64_t Ts, int64_t Tt, int64_t H, hipStream_t s) {
+    VAG_CHECK_ARG(pe && encwp && v && wcatT && whh1T && h0 && h2_all && h1 && g1 && g2 && qhp && alpha && d_h2_all && dah && dgi2 &&
+                  dqgh && ds && dgi1 && dgh1 && d_h0 && dal && sync && vag_dec_bwd_persistent_ok(B, Ts, Tt, H));
+    VAG_CHECK_ARG(aligned16(pe) && aligned16(encwp) && aligned16(wcatT) && aligned16(whh1T) && aligned16(h0) && aligned16(h2_all) &&
+                  aligned16(h1) && aligned16(g1) && aligned16(g2) && aligned16(qhp) && aligned16(d_h2_all) && aligned16(dgi2) &&
+                  aligned16(dqgh) && aligned16(dgi1) && aligned16(dgh1) && aligned16(d_h0));
+    DecBArgs a;
+    a.pe = pe; a.encwp = encwp; a.v = v; a.wcatT = wcatT; a.whh1T = whh1T; a.h0 = h0; a.h2_all = h2_all; a.h1 = h1; a.g1 = g1;
+    a.g2 = g2; a.qhp = qhp; a.alpha = alpha; a.d_h2_all = d_h2_all; a.dah = dah; a.dgi2 = dgi2; a.dqgh = dqgh; a.ds = ds;
+    a.dgi1 = dgi1; a.dgh1 = dgh1; a.d_h0 = d_h0; a.dal = dal;
+    a.B = (int)B; a.Ts = (int)Ts; a.Tt = (int)Tt; a.H = (int)H; a.RT = (int)cdiv64(B, 16);
+    const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
+    a.cnt = sync; a.err = sync + (nwords - 64);
+    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
+    VAG_LAUNCH_CHECK();
+    const int nsc = (int)(Tt * B * Ts);
+    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nsc, 256)), dim3(256), 0, s, reinterpret_cast<unsigned*>(dal), nsc);
+    VAG_LAUNCH_CHECK();
+    int64_t lds = dec_bwd_persistent_lds_bytes(Ts);
+    if (lds < 84 * 1024) lds = 84 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess) return VAG_EINVAL;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(dec_bwd_persistent_kernel, dim3((unsigned)(a.RT * DEC_WGS)), dim3(512), (size_t)lds, s, a);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
 }
