@@ -103,6 +103,7 @@ int vag_set_option(const char* name, int64_t value) {
         if (strcmp(name, e.n) == 0) { *e.p = (int)value; return VAG_OK; }
     if (strcmp(name, "head_chunk") == 0) { o.head_chunk = value; return VAG_OK; }
     if (strcmp(name, "dec_stamps") == 0) { o.dec_stamps = value; return VAG_OK; }
+    if (strcmp(name, "dec_bwd_stamps") == 0) { o.dec_bwd_stamps = value; return VAG_OK; }
     return VAG_EINVAL;
 }
 
