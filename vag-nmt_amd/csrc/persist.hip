@@ -944,12 +944,17 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
         const float* hrow = a.dqgh + ((int64_t)t * B + arow) * Q + C + wv4 * (3 * H >> 2) + 8 * fg;      // K share of waves 4-7: 3H / 4
         const float* wrow = a.wcatT + (int64_t)(u0 + (fr & 7)) * Q + C + wv4 * (3 * H >> 2) + 8 * fg;
         auto hidden_part = [&](int part) {                              // 4 of the wave's 12 k-steps
-            float4 ga[4], gb[4];
+            float4 ga[4], gb[4], w0[4], w1[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {                               // weight rows first (plain loads, L2): in flight with the rows below
+                w0[s] = *reinterpret_cast<const float4*>(wrow + part * 128 + 32 * s);
+                w1[s] = *reinterpret_cast<const float4*>(wrow + part * 128 + 32 * s + 4);
+            }
             ld_rows_sc1<4>(hrow + part * 128, ga, gb);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 bf16x8 wf[3], hf[3];
-                split8(*reinterpret_cast<const float4*>(wrow + part * 128 + 32 * s), *reinterpret_cast<const float4*>(wrow + part * 128 + 32 * s + 4), wf);
+                split8(w0[s], w1[s], wf);
                 split8(ga[s], gb[s], hf);
                 acc_h = mma6(wf, hf, acc_h);
             }
