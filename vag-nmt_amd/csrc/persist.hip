@@ -97,24 +97,6 @@ __device__ __forceinline__ void st_sc1_f4(float* p, float4 v) {
 __device__ __forceinline__ void st_sc1_f1(float* p, float v) {
     asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
 }
-// two row segments at once (4 k-steps at p, 6 at q): twenty 16-byte sc1 loads in flight, one wait
-__device__ __forceinline__ void ld_rows_sc1_4_6(const float* p, const float* q, float4 (&a)[4], float4 (&b)[4], float4 (&c)[6], float4 (&d)[6]) {
-    asm volatile("global_load_dwordx4 %0, %20, off sc1\n\tglobal_load_dwordx4 %1, %20, off offset:16 sc1\n\t"
-                 "global_load_dwordx4 %2, %20, off offset:128 sc1\n\tglobal_load_dwordx4 %3, %20, off offset:144 sc1\n\t"
-                 "global_load_dwordx4 %4, %20, off offset:256 sc1\n\tglobal_load_dwordx4 %5, %20, off offset:272 sc1\n\t"
-                 "global_load_dwordx4 %6, %20, off offset:384 sc1\n\tglobal_load_dwordx4 %7, %20, off offset:400 sc1\n\t"
-                 "global_load_dwordx4 %8, %21, off sc1\n\tglobal_load_dwordx4 %9, %21, off offset:16 sc1\n\t"
-                 "global_load_dwordx4 %10, %21, off offset:128 sc1\n\tglobal_load_dwordx4 %11, %21, off offset:144 sc1\n\t"
-                 "global_load_dwordx4 %12, %21, off offset:256 sc1\n\tglobal_load_dwordx4 %13, %21, off offset:272 sc1\n\t"
-                 "global_load_dwordx4 %14, %21, off offset:384 sc1\n\tglobal_load_dwordx4 %15, %21, off offset:400 sc1\n\t"
-                 "global_load_dwordx4 %16, %21, off offset:512 sc1\n\tglobal_load_dwordx4 %17, %21, off offset:528 sc1\n\t"
-                 "global_load_dwordx4 %18, %21, off offset:640 sc1\n\tglobal_load_dwordx4 %19, %21, off offset:656 sc1\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(a[0]), "=&v"(b[0]), "=&v"(a[1]), "=&v"(b[1]), "=&v"(a[2]), "=&v"(b[2]), "=&v"(a[3]), "=&v"(b[3]),
-                   "=&v"(c[0]), "=&v"(d[0]), "=&v"(c[1]), "=&v"(d[1]), "=&v"(c[2]), "=&v"(d[2]), "=&v"(c[3]), "=&v"(d[3]),
-                   "=&v"(c[4]), "=&v"(d[4]), "=&v"(c[5]), "=&v"(d[5])
-                 : "v"(p), "v"(q) : "memory");
-}
 // 8 consecutive floats -> three bf16x8 planes
 __device__ __forceinline__ void split8(const float4 a, const float4 b, bf16x8 (&p)[3]) {
     unsigned q[3][4];
@@ -781,7 +763,7 @@ struct DecBArgs {
     float* dal;                 // (Tt,B,Ts) accumulated with atomics: zero on entry
     unsigned* cnt;              // [3 phases][RT][Tt] x CNT_WORDS, zero on entry
     unsigned* err;
-    unsigned long long* dbg;    // NULL, or [Tt][8] timestamps of workgroup 0 (tools/exp_dec_phases.py bwd)
+    unsigned long long* dbg;    // NULL, or [Tt][8] timestamps of workgroup 0 (tools/exp_dec_bwd_phases.py)
     int B, Ts, Tt, H, RT;
 };
 
@@ -822,7 +804,7 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
     float* d1_s = gi_s + 384;                                        // [16][8] z2 * dh2: the direct path into dh1
     float* pb_s = d1_s + 128;                                        // [16][8] dgh2 W_hh2 + z2 * dh2
     float* c1_s = pb_s + 128;                                        // [16][8] z1 * dh1: the direct path into dh2[t-1]
-    float* dq_s = c1_s + 128;                                        // [2 halves][16][16] dq of the own columns (staging for 16-byte stores)
+    float* dq_s = c1_s + 128;                                        // [16][16] dq of the own columns (staging for 16-byte stores)
 
     // ---- register-resident weights (A operands, 16-row tile = the 8 own units twice): attn_h^T (K = C) and W_hh1^T (K = 3H)
     constexpr int KB = C / 8 / 32, KC = 3 * H / 8 / 32;             // k-steps per wave: 4 and 6
@@ -835,6 +817,7 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
 #pragma unroll
         for (int s = 0; s < KC; ++s) split8(*reinterpret_cast<const float4*>(pc + 32 * s), *reinterpret_cast<const float4*>(pc + 32 * s + 4), wc[s]);
     }
+    const float* wa_row = a.wcatT + (int64_t)(u0 + (fr & 7)) * Q + C + wave * (3 * H >> 3) + 8 * fg;      // W_hh2^T, streamed per step
     // ---- keys -> LDS
     for (int x = threadIdx.x; x < NP * 4; x += 512) {
         const int P = x >> 2, c4 = x & 3;
@@ -918,63 +901,28 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
         __syncthreads();
         if (threadIdx.x == 0) arrive(cA + t * CNT_WORDS, i);
         VAG_STAMP(1);
-        // ================= B: complete d alpha -> ds -> dq of the own query columns (waves 0-3), and BESIDE it, on waves 4-7,
-        // the hidden side of dh1: dgh2[t] W_hh2 + z2 * dh2 for the own units (dgh2 rows are complete since cA; W_hh2^T rows are
-        // streamed from L2 -- a third weight slice does not fit the registers).  Both halves pass the same three barriers.
-        const bool roleB = wave < 4;
-        constexpr int NI = 3;                                           // pairs per thread of waves 0-3 (NP <= 768)
-        float alv[NI], dhv[NI];
-        int64_t ofs[NI];
-        float qv = 0.f;
-        if (roleB) {
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int x = min((int)threadIdx.x + 256 * j, NP - 1);
-                const int r = x / Ts;
-                ofs[j] = ((int64_t)t * B + min(m0 + r, B - 1)) * Ts + (x - r * Ts);
-                alv[j] = a.alpha[ofs[j]];
-                dhv[j] = a.dah[ofs[j]];
-            }
-            qv = a.qhp[((int64_t)t * B + min(m0 + (int)(threadIdx.x >> 4), B - 1)) * Q + 16 * i + (threadIdx.x & 15)];
-        }
-        wait_count(cA + t * CNT_WORDS, PER_SHARD, a.err, dead);
-        VAG_STAMP(2);
-        f32x4 acc_h = {0.f, 0.f, 0.f, 0.f};
-        const int wv4 = wave & 3;
-        const float* hrow = a.dqgh + ((int64_t)t * B + arow) * Q + C + wv4 * (3 * H >> 2) + 8 * fg;      // K share of waves 4-7: 3H / 4
-        const float* wrow = a.wcatT + (int64_t)(u0 + (fr & 7)) * Q + C + wv4 * (3 * H >> 2) + 8 * fg;
-        auto hidden_part = [&](int part) {                              // 4 of the wave's 12 k-steps
-            float4 ga[4], gb[4], w0[4], w1[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {                               // weight rows first (plain loads, L2): in flight with the rows below
-                w0[s] = *reinterpret_cast<const float4*>(wrow + part * 128 + 32 * s);
-                w1[s] = *reinterpret_cast<const float4*>(wrow + part * 128 + 32 * s + 4);
-            }
-            ld_rows_sc1<4>(hrow + part * 128, ga, gb);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                bf16x8 wf[3], hf[3];
-                split8(w0[s], w1[s], wf);
-                split8(ga[s], gb[s], hf);
-                acc_h = mma6(wf, hf, acc_h);
-            }
-        };
-        if (roleB) {
-            float v[NI];
-            asm volatile("global_load_dword %0, %3, off sc1\n\tglobal_load_dword %1, %4, off sc1\n\tglobal_load_dword %2, %5, off sc1\n\t"
-                         "s_waitcnt vmcnt(0)"
-                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(a.dal + ofs[0]), "v"(a.dal + ofs[1]), "v"(a.dal + ofs[2]) : "memory");
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int x = threadIdx.x + 256 * j;
-                if (x < NP) { da_s[x] = v[j] + dhv[j]; al_s[x] = alv[j]; }
-            }
-        } else {
-            hidden_part(0);
-        }
-        __syncthreads();
-        if (roleB) {
-            for (int r = wave; r < 16; r += 4) {               // softmax backward, one wave per row
+        // operands of phase B that do not depend on the hand-off
+        float al0 = 0.f, al1 = 0.f, dh0 = 0.f, dh1_ = 0.f;
+        const int x0 = threadIdx.x, x1 = threadIdx.x + 512;
+        {
+            const int r0 = min(x0, NP - 1) / Ts, r1 = min(x1, NP - 1) / Ts;
+            const int64_t o0 = ((int64_t)t * B + min(m0 + r0, B - 1)) * Ts + (min(x0, NP - 1) - r0 * Ts);
+            const int64_t o1 = ((int64_t)t * B + min(m0 + r1, B - 1)) * Ts + (min(x1, NP - 1) - r1 * Ts);
+            al0 = a.alpha[o0]; dh0 = a.dah[o0];
+            if (x1 < NP) { al1 = a.alpha[o1]; dh1_ = a.dah[o1]; }
+            const float qv = threadIdx.x < 256 ? a.qhp[((int64_t)t * B + min(m0 + (int)(threadIdx.x >> 4), B - 1)) * Q + 16 * i + (threadIdx.x & 15)] : 0.f;
+            // ================= B: complete d alpha -> ds -> dq of the own query columns =================
+            wait_count(cA + t * CNT_WORDS, PER_SHARD, a.err, dead);
+            VAG_STAMP(2);
+            float v0, v1;
+            const float* p0 = a.dal + o0;
+            const float* p1 = a.dal + o1;
+            asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
+            if (x0 < NP) { da_s[x0] = v0 + dh0; al_s[x0] = al0; }
+            if (x1 < NP) { da_s[x1] = v1 + dh1_; al_s[x1] = al1; }
+            __syncthreads();
+            for (int r = wave; r < 16; r += 8) {               // softmax backward, one wave per row
                 float dot = 0.f;
                 for (int sp = lane; sp < Ts; sp += 64) dot += al_s[r * Ts + sp] * da_s[r * Ts + sp];
                 dot = wave_sum(dot);
@@ -984,45 +932,53 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
                     if (((r * Ts + sp) & (DEC_WGS - 1)) == i && m0 + r < B) a.ds[((int64_t)t * B + m0 + r) * Ts + sp] = d;
                 }
             }
-        } else {
-            hidden_part(1);
-            hidden_part(2);
-            red[wv4 * 64 + lane] = make_float4(acc_h[0], acc_h[1], acc_h[2], acc_h[3]);
-        }
-        __syncthreads();
-        if (roleB) {
-            const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
-            const float* pr = pe_s + (int64_t)r * Ts * 16 + c;
-            const float* dsr = da_s + r * Ts;
-            float acc0 = 0.f, acc1 = 0.f;
-            int sp = 0;
-            for (; sp + 1 < Ts; sp += 2) {
-                const float t0 = vag_tanh(pr[sp * 16] + qv), t1 = vag_tanh(pr[(sp + 1) * 16] + qv);
-                acc0 += dsr[sp] * (1.f - t0 * t0);
-                acc1 += dsr[sp + 1] * (1.f - t1 * t1);
+            __syncthreads();
+            if (threadIdx.x < 256) {
+                const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+                const float* pr = pe_s + (int64_t)r * Ts * 16 + c;
+                const float* dsr = da_s + r * Ts;
+                float acc0 = 0.f, acc1 = 0.f;
+                int sp = 0;
+                for (; sp + 1 < Ts; sp += 2) {
+                    const float t0 = vag_tanh(pr[sp * 16] + qv), t1 = vag_tanh(pr[(sp + 1) * 16] + qv);
+                    acc0 += dsr[sp] * (1.f - t0 * t0);
+                    acc1 += dsr[sp + 1] * (1.f - t1 * t1);
+                }
+                if (sp < Ts) { const float t0 = vag_tanh(pr[sp * 16] + qv); acc0 += dsr[sp] * (1.f - t0 * t0); }
+                dq_s[threadIdx.x] = (acc0 + acc1) * vq;
             }
-            if (sp < Ts) { const float t0 = vag_tanh(pr[sp * 16] + qv); acc0 += dsr[sp] * (1.f - t0 * t0); }
-            dq_s[threadIdx.x] = (acc0 + acc1) * vq;
-        } else if (wave == 4 && lane < 32) {
-            // the four partial tiles -> hidden side for (batch row lane & 15, units 4 (lane >> 4) .. + 3), plus z2 * dh2
-            const int r = lane & 15, q4 = lane >> 4;
-            float4 sum = red[q4 * 16 + r];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                const float4 o = red[w * 64 + q4 * 16 + r];
-                sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
+            __syncthreads();
+            if (threadIdx.x < 64) {                             // 16 rows x 4 column quads: one 16-byte sc1 store each
+                const int r = threadIdx.x >> 2, c4 = threadIdx.x & 3;
+                if (m0 + r < B) st_sc1_f4(a.dqgh + ((int64_t)t * B + m0 + r) * Q + 16 * i + 4 * c4, *reinterpret_cast<const float4*>(dq_s + r * 16 + 4 * c4));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (threadIdx.x == 0) arrive(cB + t * CNT_WORDS, i);
             }
-            const float4 d1 = *reinterpret_cast<const float4*>(d1_s + r * 8 + 4 * q4);
-            *reinterpret_cast<float4*>(pb_s + r * 8 + 4 * q4) = make_float4(sum.x + d1.x, sum.y + d1.y, sum.z + d1.z, sum.w + d1.w);
-        }
-        __syncthreads();
-        if (threadIdx.x < 64) {                                 // 16 rows x 4 column quads: one 16-byte sc1 store each
-            const int r = threadIdx.x >> 2, c4 = threadIdx.x & 3;
-            if (m0 + r < B) st_sc1_f4(a.dqgh + ((int64_t)t * B + m0 + r) * Q + 16 * i + 4 * c4, *reinterpret_cast<const float4*>(dq_s + r * 16 + 4 * c4));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (threadIdx.x == 0) arrive(cB + t * CNT_WORDS, i);
         }
         VAG_STAMP(3);
+        // ---- beside that hand-off: hidden side of dh1 for the own units, dgh2[t] W_hh2 + z2 * dh2 (dgh2 rows: complete since cA)
+        {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            float4 ga[KC], gb[KC], w0[KC], w1[KC];
+#pragma unroll
+            for (int s = 0; s < KC; ++s) { w0[s] = *reinterpret_cast<const float4*>(wa_row + 32 * s); w1[s] = *reinterpret_cast<const float4*>(wa_row + 32 * s + 4); }
+            ld_rows_sc1<KC>(a.dqgh + ((int64_t)t * B + arow) * Q + C + wave * (3 * H >> 3) + 8 * fg, ga, gb);
+#pragma unroll
+            for (int s = 0; s < KC; ++s) {
+                bf16x8 wf[3], hf[3];
+                split8(w0[s], w1[s], wf);
+                split8(ga[s], gb[s], hf);
+                acc = mma6(wf, hf, acc);
+            }
+            red[wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            __syncthreads();
+            if (ep) {
+                float x[4];
+                red4(x);
+                const float4 d1 = *reinterpret_cast<const float4*>(d1_s + fr * 8 + 4 * hq);
+                *reinterpret_cast<float4*>(pb_s + fr * 8 + 4 * hq) = make_float4(x[0] + d1.x, x[1] + d1.y, x[2] + d1.z, x[3] + d1.w);
+            }
+        }
         // ================= C: dh1 = dq attn_h + hidden side -> gru_1 cell backward =================
         float4 s1[4], hp1 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (eok) {
@@ -1232,10 +1188,10 @@ int vag_persistent_timeouts_read(void) {
 
 static int64_t dec_bwd_persistent_lds_bytes(int64_t Ts) {
     const int64_t NP = 16 * Ts;
-    return 4 * (2048 + NP * 16 + 24 * NP + 2 * NP + 384 + 3 * 128 + 512 + 64);
+    return 4 * (2048 + NP * 16 + 24 * NP + 2 * NP + 384 + 3 * 128 + 256 + 64);
 }
 bool vag_dec_bwd_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H) {
-    return vag_dec_persistent_ok(B, Ts, Tt, H) && Ts <= 48 && dec_bwd_persistent_lds_bytes(Ts) <= 160 * 1024;
+    return vag_dec_persistent_ok(B, Ts, Tt, H) && dec_bwd_persistent_lds_bytes(Ts) <= 160 * 1024;
 }
 int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const float* v, const float* wcatT, const float* whh1T,
                                   const float* h0, const float* h2_all, const float* h1, const float* g1, const float* g2,
