@@ -805,18 +805,23 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
     float* pb_s = d1_s + 128;                                        // [16][8] dgh2 W_hh2 + z2 * dh2
     float* c1_s = pb_s + 128;                                        // [16][8] z1 * dh1: the direct path into dh2[t-1]
     float* dq_s = c1_s + 128;                                        // [16][16] dq of the own columns (staging for 16-byte stores)
+    float* wb_s = dq_s + 256;                                        // [8 own units][C + 4] attn_h^T rows, fp32 (padded: the 8 rows of a
+                                                                     // fragment read fall on different banks); split on the fly
+    constexpr int WBLD = C + 4;
 
     // ---- register-resident weights (A operands, 16-row tile = the 8 own units twice): attn_h^T (K = C) and W_hh1^T (K = 3H)
     constexpr int KB = C / 8 / 32, KC = 3 * H / 8 / 32;             // k-steps per wave: 4 and 6
-    bf16x8 wb[KB][3], wc[KC][3];
+    bf16x8 wc[KC][3];
     {
-        const float* pb = a.wcatT + (int64_t)(u0 + (fr & 7)) * Q + wave * (C >> 3) + 8 * fg;
         const float* pc = a.whh1T + (int64_t)(u0 + (fr & 7)) * (3 * H) + wave * (3 * H >> 3) + 8 * fg;
-#pragma unroll
-        for (int s = 0; s < KB; ++s) split8(*reinterpret_cast<const float4*>(pb + 32 * s), *reinterpret_cast<const float4*>(pb + 32 * s + 4), wb[s]);
 #pragma unroll
         for (int s = 0; s < KC; ++s) split8(*reinterpret_cast<const float4*>(pc + 32 * s), *reinterpret_cast<const float4*>(pc + 32 * s + 4), wc[s]);
     }
+    for (int x = threadIdx.x; x < 8 * (C / 4); x += 512) {           // attn_h^T rows of the own units -> LDS
+        const int u = x / (C / 4), c4 = x - u * (C / 4);
+        *reinterpret_cast<float4*>(wb_s + u * WBLD + 4 * c4) = *reinterpret_cast<const float4*>(a.wcatT + (int64_t)(u0 + u) * Q + 4 * c4);
+    }
+    const float* wb_row = wb_s + (fr & 7) * WBLD + wave * (C >> 3) + 8 * fg;
     const float* wa_row = a.wcatT + (int64_t)(u0 + (fr & 7)) * Q + C + wave * (3 * H >> 3) + 8 * fg;      // W_hh2^T, streamed per step
     // ---- keys -> LDS
     for (int x = threadIdx.x; x < NP * 4; x += 512) {
@@ -959,14 +964,12 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
         // ---- beside that hand-off: hidden side of dh1 for the own units, dgh2[t] W_hh2 + z2 * dh2 (dgh2 rows: complete since cA)
         {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            float4 ga[KC], gb[KC], w0[KC], w1[KC];
-#pragma unroll
-            for (int s = 0; s < KC; ++s) { w0[s] = *reinterpret_cast<const float4*>(wa_row + 32 * s); w1[s] = *reinterpret_cast<const float4*>(wa_row + 32 * s + 4); }
+            float4 ga[KC], gb[KC];
             ld_rows_sc1<KC>(a.dqgh + ((int64_t)t * B + arow) * Q + C + wave * (3 * H >> 3) + 8 * fg, ga, gb);
 #pragma unroll
             for (int s = 0; s < KC; ++s) {
                 bf16x8 wf[3], hf[3];
-                split8(w0[s], w1[s], wf);
+                split8(*reinterpret_cast<const float4*>(wa_row + 32 * s), *reinterpret_cast<const float4*>(wa_row + 32 * s + 4), wf);
                 split8(ga[s], gb[s], hf);
                 acc = mma6(wf, hf, acc);
             }
@@ -996,9 +999,10 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
             ld_rows_sc1<KB>(a.dqgh + ((int64_t)t * B + arow) * Q + wave * (C >> 3) + 8 * fg, ga, gb);
 #pragma unroll
             for (int s = 0; s < KB; ++s) {
-                bf16x8 hf[3];
+                bf16x8 wf[3], hf[3];
+                split8(*reinterpret_cast<const float4*>(wb_row + 32 * s), *reinterpret_cast<const float4*>(wb_row + 32 * s + 4), wf);
                 split8(ga[s], gb[s], hf);
-                acc = mma6(wb[s], hf, acc);
+                acc = mma6(wf, hf, acc);
             }
             red[wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
@@ -1188,7 +1192,7 @@ int vag_persistent_timeouts_read(void) {
 
 static int64_t dec_bwd_persistent_lds_bytes(int64_t Ts) {
     const int64_t NP = 16 * Ts;
-    return 4 * (2048 + NP * 16 + 24 * NP + 2 * NP + 384 + 3 * 128 + 256 + 64);
+    return 4 * (2048 + NP * 16 + 24 * NP + 2 * NP + 384 + 3 * 128 + 256 + 8 * 1028 + 64);
 }
 bool vag_dec_bwd_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H) {
     return vag_dec_persistent_ok(B, Ts, Tt, H) && dec_bwd_persistent_lds_bytes(Ts) <= 160 * 1024;
