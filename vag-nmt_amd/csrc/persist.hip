@@ -964,17 +964,12 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
         // ---- beside that hand-off: hidden side of dh1 for the own units, dgh2[t] W_hh2 + z2 * dh2 (dgh2 rows: complete since cA)
         {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            float4 ga[KC], gb[KC], w0[KC], w1[KC];
-#pragma unroll
-            for (int s = 0; s < KC; ++s) {          // the streamed weight rows first: in flight together with the rows below
-                w0[s] = *reinterpret_cast<const float4*>(wa_row + 32 * s);
-                w1[s] = *reinterpret_cast<const float4*>(wa_row + 32 * s + 4);
-            }
+            float4 ga[KC], gb[KC];
             ld_rows_sc1<KC>(a.dqgh + ((int64_t)t * B + arow) * Q + C + wave * (3 * H >> 3) + 8 * fg, ga, gb);
 #pragma unroll
             for (int s = 0; s < KC; ++s) {
                 bf16x8 wf[3], hf[3];
-                split8(w0[s], w1[s], wf);
+                split8(*reinterpret_cast<const float4*>(wa_row + 32 * s), *reinterpret_cast<const float4*>(wa_row + 32 * s + 4), wf);
                 split8(ga[s], gb[s], hf);
                 acc = mma6(wf, hf, acc);
             }
