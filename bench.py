@@ -434,6 +434,8 @@ def main():
     ap.add_argument("--no-dropout", action="store_true", help="debug: disable the reference dropouts")
     ap.add_argument("--no-cfg5-row", action="store_true", help="skip the configs[4] row of the extras")
     ap.add_argument("--no-fused", action="store_true", help="debug: per-operator autograd path instead of vag_train_step")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="library option for A/B runs (vag_set_option), e.g. --opt persistent=0")
     ap.add_argument("--config", choices=["cfg2", "cfg5", "cfg5-f32"], default="cfg2",
                     help="cfg2 = BASELINE configs[1] (the metric's configuration); cfg5 = configs[4] (H=1024, T=80, B=256, "
                          "V=40k) with fp16 storage of the per-step streams; cfg5-f32 = the same sizes, fp32 storage")
@@ -466,7 +468,11 @@ def main():
 
     import random
     from vagnmt_hip.trainer import TrainStep
+    from vagnmt_hip import _lib as _L
     from machine_translation_vision.losses import PairwiseRankingLoss
+    for kv in args.opt:
+        name, val = kv.split("=", 1)
+        _L.set_option(name, int(val))
     c = CFG2 if args.config == "cfg2" else CFG5
     random.seed(1234)      # same teacher-forcing coin on every rank
     model = build_model(c, dev, dropout=not args.no_dropout)
