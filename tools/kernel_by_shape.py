@@ -3,7 +3,7 @@ import csv, glob, json, sys, collections
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    name = r['Kernel_Name'].split('(')[0].replace('void ', '')
+    name = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')
     if not any(k in name for k in ('gru_step', 'gru_bwd_step', 'skinny_plain', 'attn_')):
         continue
     grid = "%sx%sx%s" % (r.get('Grid_Size_X', r.get('Grid_Size', '?')), r.get('Grid_Size_Y', ''), r.get('Grid_Size_Z', ''))

@@ -11,7 +11,7 @@ t0 = int(step[0]['Start_Timestamp']); t1 = int(step[-1]['End_Timestamp'])
 print("kernels in step:", len(step), "span ms", (t1 - t0) / 1e6)
 agg = collections.OrderedDict(); busy = 0
 for r in step:
-    n = r['Kernel_Name'].split('(')[0][:64]
+    n = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0][:64]
     d = int(r['End_Timestamp']) - int(r['Start_Timestamp']); busy += d
     c = agg.setdefault(n, [0, 0]); c[0] += 1; c[1] += d
 print("busy ms", busy / 1e6)

@@ -11,7 +11,7 @@ t0 = int(step[0]['Start_Timestamp'])
 skip = ('gru_step', 'gru_bwd_step', 'skinny_plain', 'attn_scores', 'attn_ctx', 'attn_dq', 'gemm_')
 tot = 0
 for r in step:
-    n = r['Kernel_Name'].split('(')[0].replace('void ', '')
+    n = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')
     if any(k in n for k in skip):
         continue
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3

@@ -23,7 +23,7 @@ agg = collections.OrderedDict()
 busy = gaps = 0
 for r in step:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
-    n = r['Kernel_Name'].split('(')[0].replace('void ', '')[:56]
+    n = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')[:56]
     grid = "%sx%sx%s" % (r.get('Grid_Size_X', '?'), r.get('Grid_Size_Y', ''), r.get('Grid_Size_Z', ''))
     wg = r.get('Workgroup_Size_X', '?')
     gap = s - prev_end
