@@ -413,6 +413,39 @@ def measure_extras(c, dev, ts, args):
     return out
 
 
+def measure_recurrences(ts, batch, n=10):
+    """In-step durations of the four persistent recurrence kernels: HIP events recorded by the library around each launch
+    on the launching stream (vag_set_option("persist_timing"), include/vag_nmt.h: vag_recurrence_time) while the same
+    TrainStep runs `n` optimiser steps as eager launches (events cannot be read out of a graph replay; eager and replayed
+    steps take the same time on one stream).  Seconds per launch, or None where the kernel did not run."""
+    import ctypes as C
+    from vagnmt_hip import _lib as L
+    names = ("enc_fwd", "dec_fwd", "enc_bwd", "dec_bwd")
+
+    def read():
+        out = {}
+        for kind, name in enumerate(names):
+            ms, cnt = C.c_double(0.0), C.c_int(0)
+            L.call("vag_recurrence_time", kind, C.byref(ms), C.byref(cnt))
+            out[name] = ms.value * 1e-3 / cnt.value if cnt.value else None
+        return out
+    use_graph = ts.use_graph
+    ts.use_graph = False
+    L.set_option("persist_timing", 1)
+    try:
+        for _ in range(2):
+            ts.step(*batch)
+        torch.cuda.synchronize()
+        read()
+        for _ in range(n):
+            ts.step(*batch)
+        torch.cuda.synchronize()
+        return read()
+    finally:
+        L.set_option("persist_timing", 0)
+        ts.use_graph = use_graph
+
+
 def pmc_traffic():
     """HBM traffic per launch of the dominant kernel from rocprofv3 PMC passes (profiles/rNN_pmc.json, produced by
     tools/profile_round.sh -> tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs, FETCH doubled as
@@ -632,24 +665,47 @@ def main():
                                       "us_per_encoder_step": fam["encoder_fwd"] / c["Ts"] * 1e6},
         }
         # `roofline` = the dominant kernel of the step by total time (profiles/rNN_bench_cfg2_kernel_stats.csv).  Round 3: the
-        # persistent decoder forward recurrence (one launch = Tt steps; algorithmic bytes = Tt x F_dec of SURVEY 8(d): the
-        # streaming model prices every step's weights and keys again, the kernel keeps them on chip, so its measured HBM
-        # traffic is far BELOW the algorithmic bytes); where that kernel does not apply (configs[4]) the backward cell kernel.
-        if "decoder_recurrence" in fam:
-            rb = ab["F_dec"] * c["Tt"]
-            res["roofline"] = {"bound": "hbm",
-                               "kernel": "dec_fwd_persistent_kernel (Tt=%d decoder steps in one launch: gru_1, attention, gru_2; "
-                                         "B=%d, Ts=%d, H=%d)" % (c["Tt"], B, c["Ts"], H),
-                               "achieved": rb / fam["decoder_recurrence"] / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                               "frac": rb / fam["decoder_recurrence"] / HBM_PEAK,
-                               "traffic": pmc.get("dec_fwd_persistent_kernel_bytes_per_launch"),
-                               "algorithmic_bytes_per_launch": rb, "us_per_launch": fam["decoder_recurrence"] * 1e6,
-                               "us_per_decoder_step": fam["decoder_recurrence"] / c["Tt"] * 1e6}
+        # persistent decoder BACKWARD recurrence (one launch = Tt steps; algorithmic bytes = Tt x Bk_dec of SURVEY 8(d)).  The
+        # streaming model prices every step's weights and keys again, the kernels keep them on chip, so their measured HBM
+        # traffic is far BELOW the algorithmic bytes.  One row per recurrence family beside it ("reported per
+        # kernel family"), all from in-step HIP-event durations; where the kernels do not apply (configs[4]) the backward
+        # cell kernel of the launch chain.
+        rec = measure_recurrences(ts, (src, lens_t, tgt, im)) if (world == 1 and not args.no_fused) else {}
+        log("recurrence kernels in step: %s" % rec)
+
+        def rec_row(key, kernel, bytes_per_launch, steps, pmc_key):
+            t = rec.get(key)
+            if not t:
+                return None
+            return {"bound": "hbm", "kernel": kernel, "achieved": bytes_per_launch / t / 1e9, "peak": HBM_PEAK / 1e9,
+                    "unit": "GB/s", "frac": bytes_per_launch / t / HBM_PEAK, "traffic": pmc.get(pmc_key),
+                    "algorithmic_bytes_per_launch": bytes_per_launch, "us_per_launch": t * 1e6,
+                    "us_per_recurrent_step": t / steps * 1e6, "timing": "HIP events around the launch, inside the optimiser step"}
+        shape = "B=%d, Ts=%d, Tt=%d, H=%d" % (B, c["Ts"], c["Tt"], H)
+        rows = {
+            "roofline_dec_bwd": rec_row("dec_bwd", "dec_bwd_persistent_kernel (Tt decoder backward steps in one launch: gru_2, "
+                                        "attention, gru_1 backward; %s)" % shape, ab["Bk_dec"] * c["Tt"], c["Tt"],
+                                        "dec_bwd_persistent_kernel_bytes_per_launch"),
+            "roofline_dec_fwd": rec_row("dec_fwd", "dec_fwd_persistent_kernel (Tt decoder steps in one launch: gru_1, attention, "
+                                        "gru_2; %s)" % shape, ab["F_dec"] * c["Tt"], c["Tt"],
+                                        "dec_fwd_persistent_kernel_bytes_per_launch"),
+            "roofline_enc_bwd": rec_row("enc_bwd", "enc_bwd_persistent_kernel (both directions x Ts backward steps; %s)" % shape,
+                                        ab["Bk_enc"] * 2 * c["Ts"], c["Ts"], "enc_bwd_persistent_kernel_bytes_per_launch"),
+            "roofline_enc_fwd": rec_row("enc_fwd", "enc_fwd_persistent_kernel (both directions x Ts steps; %s)" % shape,
+                                        ab["F_enc"] * 2 * c["Ts"], c["Ts"], "enc_fwd_persistent_kernel_bytes_per_launch"),
+        }
+        for k_, v_ in rows.items():
+            if v_ is not None:
+                res[k_] = v_
+        if rows["roofline_dec_bwd"] is not None:
+            res["roofline"] = dict(rows["roofline_dec_bwd"])
+        elif rows["roofline_dec_fwd"] is not None:
+            res["roofline"] = dict(rows["roofline_dec_fwd"])
         else:
             res["roofline"] = dict(res["roofline_gru_cell_bwd"])
         if args.config != "cfg2":
-            res["roofline"]["traffic"] = res["roofline_decoder_step"]["traffic"] = None     # PMC passes were taken at cfg2
-            res["roofline_gru_cell_fwd"]["traffic"] = res["roofline_gru_cell_bwd"]["traffic"] = None
+            for k_ in [k_ for k_ in res if k_.startswith("roofline")]:                     # PMC passes were taken at cfg2
+                res[k_]["traffic"] = None
         whole = ab["F_enc"] * 2 * c["Ts"] + ab["F_dec"] * c["Tt"] + ab["Bk_enc"] * 2 * c["Ts"] + ab["Bk_dec"] * c["Tt"]
         if args.config == "cfg2":
             whole = 6.150e9            # chains + once-per-batch products (fwd, 2x bwd) + Adam, evaluated at cfg2

@@ -408,6 +408,11 @@ int vag_recurrence_supported(int kind, int64_t B, int64_t Ts, int64_t Tt, int64_
  * up after ~1 s instead of hanging, the launch's results are then void.  This returns how many waits gave up since the last
  * call (0 in a healthy run) and resets the count; it synchronises the device -- call it at checkpoints, not per step. */
 int vag_persistent_timeouts(void);
+/* Measurement: with vag_set_option("persist_timing", 1) every EAGER launch (not inside a stream capture) of a recurrence
+ * kernel is bracketed by HIP events on its stream.  This returns the accumulated kernel time and launch count of one kind
+ * (0 encoder forward, 1 decoder forward, 2 encoder backward, 3 decoder backward) since the last call and resets them; it
+ * waits for the last bracketed launch.  bench.py derives the per-family roofline rows from it. */
+int vag_recurrence_time(int kind, double* ms_total, int* launches);
 int64_t vag_recurrence_sync_words(int kind, int64_t B, int64_t T);
 int vag_cgru_recurrence_fwd(const float* pe, const float* mask, const float* h0, const float* xp1, vag_dec_w w, const float* wcat,
                             const float* bcat, const float* encwp, int64_t B, int64_t Ts, int64_t Tt, int64_t H, float* h1,

@@ -54,7 +54,9 @@ res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
        # round 3: the persistent recurrences (one launch = all steps); keys and weights stay on chip, so the measured traffic
        # is far below the streaming model's algorithmic bytes (Tt x 35.67 MB for the decoder)
        "dec_fwd_persistent_kernel_bytes_per_launch": per_launch("dec_fwd_persistent_kernel"),
-       "enc_fwd_persistent_kernel_bytes_per_launch": per_launch("enc_fwd_persistent_kernel")}
+       "enc_fwd_persistent_kernel_bytes_per_launch": per_launch("enc_fwd_persistent_kernel"),
+       "dec_bwd_persistent_kernel_bytes_per_launch": per_launch("dec_bwd_persistent_kernel"),
+       "enc_bwd_persistent_kernel_bytes_per_launch": per_launch("enc_bwd_persistent_kernel")}
 out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "pmc.json")
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -41,4 +41,15 @@ with torch.no_grad():
         call("vag_gru_cell_bwd", ptr(dgh_next), ptr(wt), ptr(carry), ptr(d_out), ptr(sv), ptr(hp), B, H, ptr(dgi), ptr(dgh),
              ptr(cout), stream())
 torch.cuda.synchronize()
+# three full optimiser steps (eager launches of vag_train_step): the backward persistent recurrences, for their traffic per launch
+from vagnmt_hip.trainer import TrainStep
+from machine_translation_vision.losses import PairwiseRankingLoss
+mt = bench.build_model(c, dev)
+vw = torch.ones(c["V"], device=dev); vw[0] = 0
+ts = TrainStep(mt, torch.nn.NLLLoss(weight=vw, reduction="none"), PairwiseRankingLoss(margin=0.1), lr=4e-4, weight_decay=1e-5,
+               clip=1.0, teacher_force_ratio=1.0, use_graph=False)
+for _ in range(3):
+    ts.step(src, lens_t, tgt, im)
+torch.cuda.synchronize()
+ts.check()
 print("done")

@@ -98,7 +98,8 @@ int vag_set_option(const char* name, int64_t value) {
     const struct { const char* n; int* p; } ints[] = {
         {"gemm_f32mfma", &o.gemm_f32mfma}, {"gemm_nogroup", &o.gemm_nogroup}, {"gemm_force_tile", &o.gemm_force_tile},
         {"gemm_force_splitk", &o.gemm_force_splitk}, {"gemm_debug", &o.gemm_debug}, {"head_fuse", &o.head_fuse},
-        {"head_bf16_grads", &o.head_bf16_grads}, {"persistent", &o.persistent}, {"persistent_dec_bwd", &o.persistent_dec_bwd}};
+        {"head_bf16_grads", &o.head_bf16_grads}, {"persistent", &o.persistent}, {"persistent_dec_bwd", &o.persistent_dec_bwd},
+        {"persist_timing", &o.persist_timing}};
     for (const auto& e : ints)
         if (strcmp(name, e.n) == 0) { *e.p = (int)value; return VAG_OK; }
     if (strcmp(name, "head_chunk") == 0) { o.head_chunk = value; return VAG_OK; }
@@ -1329,6 +1330,7 @@ int vag_recurrence_supported(int kind, int64_t B, int64_t Ts, int64_t Tt, int64_
     return 0;
 }
 int vag_persistent_timeouts(void) { return vag_persistent_timeouts_read(); }
+int vag_recurrence_time(int kind, double* ms_total, int* launches) { return vag_persistent_time_read(kind, ms_total, launches); }
 int64_t vag_recurrence_sync_words(int kind, int64_t B, int64_t T) {
     return kind == 0 ? vag_enc_persistent_sync_words(B, T) : vag_dec_persistent_sync_words(B, T);
 }

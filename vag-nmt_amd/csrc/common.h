@@ -98,6 +98,7 @@ struct VagOptions {
     int head_bf16_grads = 1;     // 2-byte storage mode: one bf16 plane in the head's two vocabulary-sized gradient products
     int persistent = 1;          // 0: the recurrences always run as chains of per-step launches (persist.hip off)
     int persistent_dec_bwd = 1;  // 0: only the decoder's backward recurrence stays a launch chain
+    int persist_timing = 0;      // 1: HIP events around the recurrence kernels of eager launches (vag_recurrence_time)
     int64_t dec_bwd_stamps = 0;  // the same for the persistent decoder backward
     int64_t dec_stamps = 0;      // device address of Tt x 8 uint64 for the persistent decoder's phase timestamps (0: none)
 };

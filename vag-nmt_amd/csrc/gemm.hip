@@ -10,10 +10,10 @@
 //                        v_mfma_f32_16x16x4_f32, LDS only for the cross-wave reduction.  Epilogues: plain
 //                        (bias/addend/tanh) and the fused GRU cell.
 #include "gemm_shared.h"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
-#include <cstdio>
-#include <cstdlib>
+#include <functional>
 int vag_copy2d_launch(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t rows, int64_t cols, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
@@ -451,6 +451,97 @@ void vag_gemm_group_abort() {        // error path: drop the queues
     for (int l = 0; l < 4; ++l) g_qn[l] = 0;
     vag_colsum_queue_abort();
 }
+// Split-K and block order of one grouped launch.  The chip runs 512 of these blocks at a time (two per CU) and hands out
+// blocks in index order to whichever slot frees first, i.e. list scheduling: with the longest blocks first the launch ends
+// on short ones.  A common target slice length L (k-steps of SP_BK) is tried over the slice lengths the products can have;
+// accumulating products are cut into round(K / L) slices (never shorter than 256), the others stay whole.  Each candidate is
+// priced by simulating that schedule (block cost = slice length + a fixed prologue / epilogue share) plus the extra atomic
+// traffic of the slices.  (The first version aimed at ~512 blocks with one common split: totals of 528 / 576 blocks -- the
+// decoder / encoder weight-gradient groups -- ran a full second round for 16 / 64 blocks: 204 and 108 us.)
+struct GroupPlanEntry { int n; int m[GROUP_MAX], nn[GROUP_MAX], k[GROUP_MAX]; bool acc[GROUP_MAX]; int split[GROUP_MAX], order[GROUP_MAX]; };
+static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order);
+// plans are remembered per list of shapes (a training run repeats a handful of them; the simulation costs ~1 ms of host time)
+static void group_plan(const GemmArgs* q, int n, int* split, int* order) {
+    constexpr int CACHE = 64;
+    static thread_local GroupPlanEntry cache[CACHE];
+    static thread_local int used = 0, next = 0;
+    for (int e = 0; e < used; ++e) {
+        const GroupPlanEntry& c = cache[e];
+        bool same = c.n == n;
+        for (int i = 0; same && i < n; ++i)
+            same = c.m[i] == q[i].M && c.nn[i] == q[i].N && c.k[i] == q[i].K && c.acc[i] == (q[i].beta != 0.f);
+        if (same) {
+            for (int i = 0; i < n; ++i) { split[i] = c.split[i]; order[i] = c.order[i]; }
+            return;
+        }
+    }
+    group_plan_compute(q, n, split, order);
+    GroupPlanEntry& c = cache[next];
+    next = (next + 1) % CACHE;
+    if (used < CACHE) ++used;
+    c.n = n;
+    for (int i = 0; i < n; ++i) {
+        c.m[i] = q[i].M; c.nn[i] = q[i].N; c.k[i] = q[i].K; c.acc[i] = q[i].beta != 0.f;
+        c.split[i] = split[i]; c.order[i] = order[i];
+    }
+}
+static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order) {
+    constexpr int SLOTS = 512;
+    constexpr double C0 = 4.0;                  // k-steps a block spends outside its main loop
+    constexpr double US_PER_KSTEP = 2.5;        // one 128x128x32 step of a block sharing its CU
+    int cand[GROUP_MAX * 10 + 1], nc = 0;
+    for (int i = 0; i < n; ++i) {
+        const int ks = (int)cdiv64(q[i].K, SP_BK);
+        const int smax = q[i].beta != 0.f ? std::max(1, std::min(10, q[i].K / 256)) : 1;
+        for (int j = 1; j <= smax; ++j) {
+            const int L = (ks + j - 1) / j;
+            bool seen = false;
+            for (int c = 0; c < nc; ++c) seen = seen || cand[c] == L;
+            if (!seen) cand[nc++] = L;
+        }
+    }
+    double best = 1e30;
+    double load[SLOTS];
+    for (int c = 0; c < nc; ++c) {
+        const int L = cand[c];
+        int sp[GROUP_MAX], len[GROUP_MAX], ord[GROUP_MAX];
+        double atomic_us = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const int ks = (int)cdiv64(q[i].K, SP_BK);
+            int s_i = 1;
+            if (q[i].beta != 0.f) {
+                s_i = (ks + L / 2) / L;
+                const int smax = std::max(1, q[i].K / 256);
+                s_i = std::max(1, std::min(s_i, smax));
+                atomic_us += (double)s_i * (double)q[i].M * (double)q[i].N * 4.0 / 3.0e6;
+            }
+            sp[i] = s_i;
+            len[i] = (ks + s_i - 1) / s_i;
+            ord[i] = i;
+        }
+        std::stable_sort(ord, ord + n, [&](int a, int b) { return len[a] > len[b]; });
+        // list scheduling of equal-cost batches onto the slots: a min-heap of slot loads
+        for (int k = 0; k < SLOTS; ++k) load[k] = 0.0;
+        std::make_heap(load, load + SLOTS, std::greater<double>());
+        double makespan = 0.0;
+        for (int j = 0; j < n; ++j) {
+            const int i = ord[j];
+            const int64_t blocks = cdiv64(q[i].M, 128) * cdiv64(q[i].N, 128) * sp[i];
+            const double cost = (double)len[i] + C0;
+            for (int64_t b = 0; b < blocks; ++b) {
+                std::pop_heap(load, load + SLOTS, std::greater<double>());
+                load[SLOTS - 1] += cost;
+                makespan = std::max(makespan, load[SLOTS - 1]);
+                std::push_heap(load, load + SLOTS, std::greater<double>());
+            }
+        }
+        const double us = makespan * US_PER_KSTEP + atomic_us;
+        if (us < best) {
+            best = us;
+            for (int i = 0; i < n; ++i) { split[i] = sp[i]; order[i] = ord[i]; }
+        }
+    }
+}
 static int gemm_group_flush_layout(int lay, hipStream_t stream) {
     const int n = g_qn[lay];
     g_qn[lay] = 0;
@@ -463,28 +554,22 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
         return rc;
     }
     const GemmArgs* q = g_q[lay];
-    int64_t tiles = 0;
-    for (int i = 0; i < n; ++i) tiles += cdiv64(q[i].M, 128) * cdiv64(q[i].N, 128);
-    // two co-resident blocks per CU: aim at ~512 blocks; only accumulating (beta = 1) products may be split, and no
-    // k-slice shorter than 256
-    int sp = (int)((512 + tiles / 2) / tiles);
-    if (sp < 1) sp = 1;
-    if (sp > 8) sp = 8;
     GemmGroupArgs G;
     G.n = n;
+    int split[GROUP_MAX], order[GROUP_MAX];
+    group_plan(q, n, split, order);
     int total = 0;
-    for (int i = 0; i < n; ++i) {
-        GemmArgs& a = G.p[i];
-        a = q[i];
-        int s_i = a.beta != 0.f ? sp : 1;
-        if (s_i > a.K / 256) s_i = a.K / 256 > 0 ? a.K / 256 : 1;
-        int kchunk = (int)(cdiv64(cdiv64(a.K, s_i), SP_BK) * SP_BK);
+    for (int j = 0; j < n; ++j) {
+        GemmArgs& a = G.p[j];
+        a = q[order[j]];
+        int s_i = split[order[j]];
+        const int kchunk = (int)(cdiv64(cdiv64(a.K, s_i), SP_BK) * SP_BK);
         s_i = (int)cdiv64(a.K, kchunk);
         a.kchunk = kchunk;
         // accumulating products always add atomically here (two of them may target the same gradient buffer);
         // splitk > 1 is what selects the atomic epilogue, the block count below uses the real number of k-slices
         a.splitk = a.beta != 0.f ? (s_i > 2 ? s_i : 2) : 1;
-        G.start[i] = total;
+        G.start[j] = total;
         total += (int)(cdiv64(a.M, 128) * cdiv64(a.N, 128)) * s_i;
     }
     G.start[n] = total;

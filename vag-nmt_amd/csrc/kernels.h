@@ -151,6 +151,7 @@ int vag_enc_bwd_persistent_launch(const float* whhT, const float* d_enc, const f
                                   const uint64_t* rng, float p_ctx, float* d_xp, float* dgh, unsigned* sync, int64_t B, int64_t Ts,
                                   int64_t H, hipStream_t s);
 int vag_persistent_timeouts_read(void);
+int vag_persistent_time_read(int kind, double* ms_total, int* launches);
 bool vag_dec_bwd_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H);
 int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const float* v, const float* wcatT, const float* whh1T,
                                   const float* h0, const float* h2_all, const float* h1, const float* g1, const float* g2,

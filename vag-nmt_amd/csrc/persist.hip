@@ -1077,6 +1077,38 @@ __global__ __launch_bounds__(256) void zero_u32_kernel(unsigned* p, int n) {
 
 // Eligibility: hidden size a multiple of 256 up to 1024 (register budget of the weight planes), all workgroups resident at
 // once (one per CU).
+// Optional HIP-event timing of the four recurrence kernels (option "persist_timing"; eager launches only -- events cannot be
+// read back from inside a stream capture).  kind: 0 encoder forward, 1 decoder forward, 2 encoder backward, 3 decoder backward.
+struct PersistTimer { hipEvent_t e0 = nullptr, e1 = nullptr; bool pending = false; double ms = 0.0; int n = 0; };
+static PersistTimer g_ptimer[4];
+static void ptimer_collect(PersistTimer& t) {
+    if (!t.pending) return;
+    float ms = 0.f;
+    if (hipEventSynchronize(t.e1) == hipSuccess && hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) { t.ms += ms; ++t.n; }
+    t.pending = false;
+}
+static bool ptimer_begin(int kind, hipStream_t s) {
+    if (!vag_opt().persist_timing) return false;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (st != hipStreamCaptureStatusNone) return false;
+    PersistTimer& t = g_ptimer[kind];
+    ptimer_collect(t);
+    if (!t.e0 && (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess)) return false;
+    return hipEventRecord(t.e0, s) == hipSuccess;
+}
+static void ptimer_end(int kind, hipStream_t s) {
+    if (hipEventRecord(g_ptimer[kind].e1, s) == hipSuccess) g_ptimer[kind].pending = true;
+}
+int vag_persistent_time_read(int kind, double* ms_total, int* launches) {
+    VAG_CHECK_ARG(kind >= 0 && kind < 4 && ms_total && launches);
+    PersistTimer& t = g_ptimer[kind];
+    ptimer_collect(t);
+    *ms_total = t.ms; *launches = t.n;
+    t.ms = 0.0; t.n = 0;
+    return VAG_OK;
+}
+
 bool vag_enc_persistent_ok(int64_t B, int64_t Ts, int64_t H) {
     static int cus = -1;
     if (cus < 0) {
@@ -1105,9 +1137,11 @@ int vag_enc_fwd_persistent_launch(const float* xp, const float* w_fw, const floa
     hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
     VAG_LAUNCH_CHECK();
     const dim3 grid((unsigned)(2 * a.RT * a.CS));
+    const bool timed = ptimer_begin(0, s);
     if (H == 256) hipLaunchKernelGGL(enc_fwd_persistent_kernel<1>, grid, dim3(512), 0, s, a);
     else if (H == 512) hipLaunchKernelGGL(enc_fwd_persistent_kernel<2>, grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL(enc_fwd_persistent_kernel<4>, grid, dim3(512), 0, s, a);
+    if (timed) ptimer_end(0, s);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
@@ -1159,7 +1193,9 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
                                 160 * 1024) != hipSuccess) return VAG_EINVAL;
         attr_set = true;
     }
+    const bool timed = ptimer_begin(1, s);
     hipLaunchKernelGGL(dec_fwd_persistent_kernel, dim3((unsigned)(a.RT * DEC_WGS)), dim3(512), (size_t)lds, s, a);
+    if (timed) ptimer_end(1, s);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
@@ -1177,7 +1213,9 @@ int vag_enc_bwd_persistent_launch(const float* whhT, const float* d_enc, const f
     a.cnt = sync; a.err = sync + (nwords - 64);
     hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
     VAG_LAUNCH_CHECK();
+    const bool timed = ptimer_begin(2, s);
     hipLaunchKernelGGL(enc_bwd_persistent_kernel<6>, dim3((unsigned)(2 * a.RT * a.CS)), dim3(512), 0, s, a);
+    if (timed) ptimer_end(2, s);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
@@ -1228,7 +1266,9 @@ int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const flo
                                 160 * 1024) != hipSuccess) return VAG_EINVAL;
         attr_set = true;
     }
+    const bool timed = ptimer_begin(3, s);
     hipLaunchKernelGGL(dec_bwd_persistent_kernel, dim3((unsigned)(a.RT * DEC_WGS)), dim3(512), (size_t)lds, s, a);
+    if (timed) ptimer_end(3, s);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

@@ -109,6 +109,7 @@ PROTOS = {
     "vag_set_option": (I32, [C.c_char_p, I64]),
     "vag_recurrence_supported": (I32, [I32, I64, I64, I64, I64]),
     "vag_persistent_timeouts": (I32, []),
+    "vag_recurrence_time": (I32, [I32, P, P]),
     "vag_recurrence_sync_words": (I64, [I32, I64, I64]),
     "vag_cgru_recurrence_fwd": (I32, [P, P, P, P, DecW, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P]),
     "vag_derived_floats": (I64, [I64]),
