@@ -26,8 +26,6 @@ static int linear_fwd(int64_t M, int64_t N, int64_t K, const float* x, int64_t l
 static int gemm_tn_acc(int64_t M, int64_t N, int64_t R, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
                        int64_t ldc, hipStream_t s) {
     if (R == 0) return VAG_OK;
-    // inside an operator's VagLeafHint region and the step driver's leaf bracket: held back for the step's one leaf launch
-    if (vag_gemm_leaf_active()) return vag_gemm_leaf_product(M, N, R, A, 1, lda, B, ldb, 1, C, ldc, s);
     return vag_gemm_launch(M, N, R, 1.f, A, 1, lda, B, ldb, 1, 1.f, C, ldc, nullptr, VAG_ACT_NONE, s);
 }
 // C = beta*C + A B with A (M,K) lda, B (K,N) ldb: data gradients  dX = dY W
@@ -57,7 +55,6 @@ static inline const float* as_f(const vag_half* p) { return reinterpret_cast<con
 // Infinity Cache) is the only logits storage that is touched.  Set by the step driver for large Tt*B*V (configs[4]).
 static thread_local int64_t g_head_chunk = 0;
 void vag_set_head_chunk(int64_t rows) { g_head_chunk = rows > 0 ? rows : 0; }
-int64_t vag_get_head_chunk() { return g_head_chunk; }
 // With a chunk set AND a backward that is known to follow in the same call (the step driver with phases 1|2), the forward
 // finishes each chunk completely: a row's log-sum-exp needs only that row, and d(loss)/d(loss_mt) = w_mt and 1/count are
 // known before the step starts, so d(logits) of the chunk, its share of d(tmid), of g(out.weight) and of g(out.bias) are
@@ -102,7 +99,7 @@ int vag_set_option(const char* name, int64_t value) {
         {"gemm_f32mfma", &o.gemm_f32mfma}, {"gemm_nogroup", &o.gemm_nogroup}, {"gemm_force_tile", &o.gemm_force_tile},
         {"gemm_force_splitk", &o.gemm_force_splitk}, {"gemm_debug", &o.gemm_debug}, {"head_fuse", &o.head_fuse},
         {"head_bf16_grads", &o.head_bf16_grads}, {"persistent", &o.persistent}, {"persistent_dec_bwd", &o.persistent_dec_bwd},
-        {"persist_timing", &o.persist_timing}, {"defer_leaves", &o.defer_leaves}};
+        {"persist_timing", &o.persist_timing}};
     for (const auto& e : ints)
         if (strcmp(name, e.n) == 0) { *e.p = (int)value; return VAG_OK; }
     if (strcmp(name, "head_chunk") == 0) { o.head_chunk = value; return VAG_OK; }
@@ -326,7 +323,6 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
         cur ^= 1;
     }
     VagGemmGroup grp1;      // the four weight gradients (both directions) go out as one grouped launch
-    VagLeafHint leaves;
     for (int d = 0; d < 2; ++d) {
         const vag_gru_g& gg = d == 0 ? g_fw : g_bw;
         const float* dgh = w.dgh + d * Ts * B * 3 * H;
@@ -401,7 +397,6 @@ int vag_attn_keys_proj_bwd(const float* enc, const float* attn_e, const float* d
     hipStream_t s = S_(stream);
     VAG_CHECK_ARG(enc && attn_e && d_pe && rows > 0 && C > 0);
     if (d_enc) VAG_TRY(gemm_nn(rows, C, C, d_pe, C, attn_e, C, accumulate_enc ? 1.f : 0.f, d_enc, C, s));
-    VagLeafHint leaves;
     if (g_attn_e) VAG_TRY(gemm_tn_acc(C, C, rows, d_pe, C, enc, C, g_attn_e, C, s));
     return VAG_OK;
 }
@@ -813,7 +808,6 @@ int vag_cgru_attn_decode_seq_bwd_weights(const float* h0, const int64_t* tok, va
                   g.gru2.w_ih && g.gru2.w_hh && g.gru2.b_ih && g.gru2.b_hh);
     const int64_t C = 2 * H;
     CgruBwdScratch z = cgru_bwd_scratch(scratch, B, Ts, Tt, E, H);
-    VagLeafHint leaves;             // (inside the step driver: with every other operator's, at the end of the step)
     VagGemmGroup grp3;              // the independent K = Tt*B weight gradients go out as one grouped launch,
     VAG_TRY(vag_colsum_launch(z.dvp, VAG_POST_CHUNKS(Ts) * B, C, C, g.attn_v, s));      // the bias sums as another
     VAG_TRY(vag_cgru_bwd_weights_chunk(h0, tok, w, B, Ts, Tt, E, H, h2_all, c_all, e_all, d_e_all, ws, g, scratch, 0, Tt, true,
@@ -1008,8 +1002,6 @@ static int head_bwd_weights(const float* h2_all, const float* c_all, const float
                             int64_t V, const float* tmid, const float* dlogits, int64_t ldl, const float* dt,
                             const vag_head_g& g, hipStream_t s, bool out_b_done = false, bool out_w_done = false) {
     const int64_t C = 2 * H;
-    // leaves only when the whole sequence is one chunk: a chunk's d(logits) is overwritten by the next chunk
-    VagLeafHint leaves(vag_get_head_chunk() == 0);
     VagGemmGroup grp6;
     if (!out_w_done) VAG_TRY(head_outw_gemm(V, E, R, dlogits, ldl, tmid, g.out_w, s));
     if (!out_b_done) VAG_TRY(vag_colsum_launch(dlogits, R, V, ldl, g.out_b, s));

@@ -98,7 +98,6 @@ struct VagOptions {
     int head_bf16_grads = 1;     // 2-byte storage mode: one bf16 plane in the head's two vocabulary-sized gradient products
     int persistent = 1;          // 0: the recurrences always run as chains of per-step launches (persist.hip off)
     int persistent_dec_bwd = 1;  // 0: only the decoder's backward recurrence stays a launch chain
-    int defer_leaves = 1;        // 0: weight-gradient products go out with their operator's group instead of one launch per step
     int persist_timing = 0;      // 1: HIP events around the recurrence kernels of eager launches (vag_recurrence_time)
     int64_t dec_bwd_stamps = 0;  // the same for the persistent decoder backward
     int64_t dec_stamps = 0;      // device address of Tt x 8 uint64 for the persistent decoder's phase timestamps (0: none)
@@ -150,30 +149,6 @@ struct VagGemmGroup {
     ~VagGemmGroup() { if (open) vag_gemm_group_abort(); }
     VagGemmGroup(const VagGemmGroup&) = delete;
     VagGemmGroup& operator=(const VagGemmGroup&) = delete;
-};
-// Leaf products (gemm.hip): held back until the step driver's vag_gemm_leaf_end.  VagLeafScope: the driver's bracket around one
-// call; VagLeafHint: an operator marks the gemm_tn_acc / column-sum calls inside it as parameter gradients nothing reads again.
-void vag_gemm_leaf_begin();
-int vag_gemm_leaf_end(hipStream_t stream);
-void vag_gemm_leaf_abort();
-void vag_gemm_leaf_hint(int delta);
-bool vag_gemm_leaf_active();
-int vag_gemm_leaf_product(int64_t M, int64_t N, int64_t K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
-                          int64_t sbn, float* C, int64_t ldc, hipStream_t stream);
-struct VagLeafScope {
-    bool open = true;
-    VagLeafScope() { vag_gemm_leaf_begin(); }
-    int end(hipStream_t s) { if (!open) return VAG_OK; open = false; return vag_gemm_leaf_end(s); }
-    ~VagLeafScope() { if (open) vag_gemm_leaf_abort(); }
-    VagLeafScope(const VagLeafScope&) = delete;
-    VagLeafScope& operator=(const VagLeafScope&) = delete;
-};
-struct VagLeafHint {
-    bool on;
-    explicit VagLeafHint(bool enable = true) : on(enable) { if (on) vag_gemm_leaf_hint(1); }
-    ~VagLeafHint() { if (on) vag_gemm_leaf_hint(-1); }
-    VagLeafHint(const VagLeafHint&) = delete;
-    VagLeafHint& operator=(const VagLeafHint&) = delete;
 };
 int vag_colsum_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* out, hipStream_t stream);
 int vag_colsum3_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* out, float* out2, float* out3,

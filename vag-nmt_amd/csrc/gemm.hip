@@ -440,8 +440,6 @@ static int vag_gemm_launch_now(const GemmArgs& q, hipStream_t stream);
 void vag_colsum_queue_begin();
 int vag_colsum_queue_flush(hipStream_t stream);
 void vag_colsum_queue_abort();
-int vag_colsum_leaf_flush(hipStream_t stream);
-void vag_colsum_leaf_abort();
 void vag_gemm_group_begin() {
     if (g_group_depth++ == 0) {
         for (int l = 0; l < 4; ++l) g_qn[l] = 0;
@@ -456,11 +454,11 @@ void vag_gemm_group_abort() {        // error path: drop the queues
 // Split-K and block order of one grouped launch.  The chip runs 512 of these blocks at a time (two per CU) and hands out
 // blocks in index order to whichever slot frees first, i.e. list scheduling: with the longest blocks first the launch ends
 // on short ones.  A common target slice length L (k-steps of SP_BK) is tried over the slice lengths the products can have;
-// products are cut into round(K / L) slices (never shorter than 256; a product that overwrites its output needs a fill launch first).  Each candidate is
+// accumulating products are cut into round(K / L) slices (never shorter than 256), the others stay whole.  Each candidate is
 // priced by simulating that schedule (block cost = slice length + a fixed prologue / epilogue share) plus the extra atomic
 // traffic of the slices.  (The first version aimed at ~512 blocks with one common split: totals of 528 / 576 blocks -- the
 // decoder / encoder weight-gradient groups -- ran a full second round for 16 / 64 blocks: 204 and 108 us.)
-struct GroupPlanEntry { int n; int m[GROUP_MAX], nn[GROUP_MAX], k[GROUP_MAX]; bool acc[GROUP_MAX], half[GROUP_MAX]; int split[GROUP_MAX], order[GROUP_MAX]; };
+struct GroupPlanEntry { int n; int m[GROUP_MAX], nn[GROUP_MAX], k[GROUP_MAX]; bool acc[GROUP_MAX]; int split[GROUP_MAX], order[GROUP_MAX]; };
 static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order);
 // plans are remembered per list of shapes (a training run repeats a handful of them; the simulation costs ~1 ms of host time)
 static void group_plan(const GemmArgs* q, int n, int* split, int* order) {
@@ -471,8 +469,7 @@ static void group_plan(const GemmArgs* q, int n, int* split, int* order) {
         const GroupPlanEntry& c = cache[e];
         bool same = c.n == n;
         for (int i = 0; same && i < n; ++i)
-            same = c.m[i] == q[i].M && c.nn[i] == q[i].N && c.k[i] == q[i].K && c.acc[i] == (q[i].beta != 0.f) &&
-                   c.half[i] == (q[i].c_half != 0);
+            same = c.m[i] == q[i].M && c.nn[i] == q[i].N && c.k[i] == q[i].K && c.acc[i] == (q[i].beta != 0.f);
         if (same) {
             for (int i = 0; i < n; ++i) { split[i] = c.split[i]; order[i] = c.order[i]; }
             return;
@@ -484,7 +481,7 @@ static void group_plan(const GemmArgs* q, int n, int* split, int* order) {
     if (used < CACHE) ++used;
     c.n = n;
     for (int i = 0; i < n; ++i) {
-        c.m[i] = q[i].M; c.nn[i] = q[i].N; c.k[i] = q[i].K; c.acc[i] = q[i].beta != 0.f; c.half[i] = q[i].c_half != 0;
+        c.m[i] = q[i].M; c.nn[i] = q[i].N; c.k[i] = q[i].K; c.acc[i] = q[i].beta != 0.f;
         c.split[i] = split[i]; c.order[i] = order[i];
     }
 }
@@ -495,7 +492,7 @@ static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order)
     int cand[GROUP_MAX * 10 + 1], nc = 0;
     for (int i = 0; i < n; ++i) {
         const int ks = (int)cdiv64(q[i].K, SP_BK);
-        const int smax = q[i].c_half ? 1 : std::max(1, std::min(10, q[i].K / 256));      // fp16 outputs are stored whole
+        const int smax = q[i].beta != 0.f ? std::max(1, std::min(10, q[i].K / 256)) : 1;
         for (int j = 1; j <= smax; ++j) {
             const int L = (ks + j - 1) / j;
             bool seen = false;
@@ -511,12 +508,13 @@ static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order)
         double atomic_us = 0.0;
         for (int i = 0; i < n; ++i) {
             const int ks = (int)cdiv64(q[i].K, SP_BK);
-            int s_i = (ks + L / 2) / L;
-            const int smax = q[i].c_half ? 1 : std::max(1, q[i].K / 256);
-            s_i = std::max(1, std::min(s_i, smax));
-            const double out_bytes = (double)q[i].M * (double)q[i].N * 4.0;
-            if (q[i].beta != 0.f) atomic_us += (double)s_i * out_bytes / 3.0e6;
-            else if (s_i > 1) atomic_us += (double)s_i * out_bytes / 3.0e6 + 4.0 + out_bytes / 4.0e6;   // + a fill launch first
+            int s_i = 1;
+            if (q[i].beta != 0.f) {
+                s_i = (ks + L / 2) / L;
+                const int smax = std::max(1, q[i].K / 256);
+                s_i = std::max(1, std::min(s_i, smax));
+                atomic_us += (double)s_i * (double)q[i].M * (double)q[i].N * 4.0 / 3.0e6;
+            }
             sp[i] = s_i;
             len[i] = (ks + s_i - 1) / s_i;
             ord[i] = i;
@@ -544,59 +542,18 @@ static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order)
         }
     }
 }
-// ---- leaf products: gradients of parameters, which nothing reads before the optimiser --------------------------------
-// Between vag_gemm_leaf_begin and vag_gemm_leaf_end (the step driver, one pair per call) the products an operator issues
-// under a VagLeafHint (its weight-gradient products g_W += dY^T X, and the bias column sums) are held back and go out as ONE
-// grouped launch at the end: the head's, the decoder's and the encoder's weight gradients each fill the chip to 70-85 %
-// on their own (352 / 936 / 432 blocks of equal length on 512 slots), together they pack.  Their operands (saved
-// activations and the d(pre-activation) buffers of the step workspace) are not rewritten before the step ends.
-static thread_local int g_leaf_depth = 0, g_leaf_region = 0, g_leaf_hint = 0;
-static thread_local int g_lqn[4] = {0, 0, 0, 0};
-static thread_local GemmArgs g_lq[4][GROUP_MAX];
-// region: the operator's VagLeafHint scope (every column sum inside it is a leaf); hint: set by vag_gemm_leaf_product around
-// the one vag_gemm_launch call that is a leaf (other products issued inside the region are not)
-bool vag_gemm_leaf_active() { return g_leaf_depth > 0 && g_leaf_region > 0 && vag_opt().defer_leaves != 0; }
-void vag_gemm_leaf_hint(int delta) { g_leaf_region += delta; }
-void vag_gemm_leaf_begin() {
-    if (g_leaf_depth++ == 0)
-        for (int l = 0; l < 4; ++l) g_lqn[l] = 0;
-}
-void vag_gemm_leaf_abort() {
-    g_leaf_depth = 0;
-    for (int l = 0; l < 4; ++l) g_lqn[l] = 0;
-    vag_colsum_leaf_abort();
-}
-static int gemm_group_flush(GemmArgs* queue, int n, int lay, hipStream_t stream);
-int vag_gemm_leaf_end(hipStream_t stream) {
-    if (g_leaf_depth <= 0) return VAG_OK;
-    if (--g_leaf_depth > 0) return VAG_OK;
-    int rc = vag_colsum_leaf_flush(stream);
-    for (int lay = 0; lay < 4 && rc == VAG_OK; ++lay) {
-        const int n = g_lqn[lay];
-        g_lqn[lay] = 0;
-        rc = gemm_group_flush(g_lq[lay], n, lay, stream);
-    }
-    if (rc != VAG_OK) vag_gemm_leaf_abort();
-    return rc;
-}
-
 static int gemm_group_flush_layout(int lay, hipStream_t stream) {
     const int n = g_qn[lay];
     g_qn[lay] = 0;
-    return gemm_group_flush(g_q[lay], n, lay, stream);
-}
-static int gemm_group_flush(GemmArgs* queue, int n, int lay, hipStream_t stream) {
     if (n == 0) return VAG_OK;
     if (n == 1) {
-        const int depth = g_group_depth, hint = g_leaf_hint;       // launch directly, not back into a queue
+        const int depth = g_group_depth;       // launch directly, not back into the queue
         g_group_depth = 0;
-        g_leaf_hint = 0;
-        const int rc = vag_gemm_launch_now(queue[0], stream);
+        const int rc = vag_gemm_launch_now(g_q[lay][0], stream);
         g_group_depth = depth;
-        g_leaf_hint = hint;
         return rc;
     }
-    const GemmArgs* q = queue;
+    const GemmArgs* q = g_q[lay];
     GemmGroupArgs G;
     G.n = n;
     int split[GROUP_MAX], order[GROUP_MAX];
@@ -611,13 +568,7 @@ static int gemm_group_flush(GemmArgs* queue, int n, int lay, hipStream_t stream)
         a.kchunk = kchunk;
         // accumulating products always add atomically here (two of them may target the same gradient buffer);
         // splitk > 1 is what selects the atomic epilogue, the block count below uses the real number of k-slices
-        a.splitk = a.beta != 0.f ? (s_i > 2 ? s_i : 2) : s_i;
-        if (a.beta == 0.f && s_i > 1) {          // sliced overwrite: the slices add into a zeroed output
-            int64_t nb = cdiv64((int64_t)a.M * a.N, 256 * 8);
-            if (nb > 2048) nb = 2048;
-            hipLaunchKernelGGL(fill2d_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a.C, a.ldc, (int64_t)a.M, (int64_t)a.N);
-            VAG_LAUNCH_CHECK();
-        }
+        a.splitk = a.beta != 0.f ? (s_i > 2 ? s_i : 2) : 1;
         G.start[j] = total;
         total += (int)(cdiv64(a.M, 128) * cdiv64(a.N, 128)) * s_i;
     }
@@ -669,16 +620,6 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     const int64_t lda = akc ? sam : sak, ldb = bkc ? sbn : sbk;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     const int lay = (akc ? 2 : 0) + (bkc ? 1 : 0);
-    if (g_leaf_hint > 0 && vag_gemm_leaf_active() && vec && alpha == 1.f && beta == 1.f && act == VAG_ACT_NONE && !bias && !c_half && M > 64 &&
-        N > 64 && K >= 256 && !opt_f32mfma && !opt_nogroup && g_gemm_planes == 3) {
-        if (g_lqn[lay] == GROUP_MAX) {          // full: what is queued goes out now
-            g_lqn[lay] = 0;
-            VAG_TRY(gemm_group_flush(g_lq[lay], GROUP_MAX, lay, stream));
-        }
-        g.kchunk = (int)K; g.splitk = 1;
-        g_lq[lay][g_lqn[lay]++] = g;
-        return VAG_OK;
-    }
     if (g_group_depth > 0 && g_qn[lay] < GROUP_MAX && vec && alpha == 1.f && (beta == 0.f || beta == 1.f) &&
         act == VAG_ACT_NONE && M > 64 && N > 64 && K >= 256 && !opt_f32mfma && !opt_nogroup) {
         g.kchunk = (int)K; g.splitk = 1;
@@ -752,14 +693,6 @@ int vag_gemm_launch_planes(int planes, int64_t M, int64_t N, int64_t K, float al
     const int rc = vag_gemm_launch(M, N, K, alpha, A, sam, sak, B, sbk, sbn, beta, C, ldc, nullptr, 0, stream, 0);
     g_group_depth = depth;
     g_gemm_planes = pl;
-    return rc;
-}
-// g_W += A^T-style accumulation that nothing reads before the optimiser (see the leaf queue above)
-int vag_gemm_leaf_product(int64_t M, int64_t N, int64_t K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
-                          int64_t sbn, float* C, int64_t ldc, hipStream_t stream) {
-    ++g_leaf_hint;
-    const int rc = vag_gemm_launch(M, N, K, 1.f, A, sam, sak, B, sbk, sbn, 1.f, C, ldc, nullptr, VAG_ACT_NONE, stream, 0);
-    --g_leaf_hint;
     return rc;
 }
 static int vag_gemm_launch_now(const GemmArgs& q, hipStream_t stream) {
@@ -1653,7 +1586,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 
 // Several column sums in one grid (blockIdx.z = task): inside a vag_gemm_group_begin/end bracket the bias-gradient sums
 // of an operator are queued like its weight-gradient products and go out together.
-constexpr int COLSUM_MAX = 16;
+constexpr int COLSUM_MAX = 8;
 struct ColsumTasks {
     const float* X[COLSUM_MAX]; float* out[COLSUM_MAX]; float* out2[COLSUM_MAX]; float* out3[COLSUM_MAX];
     int64_t ld[COLSUM_MAX];
@@ -1699,46 +1632,22 @@ int vag_colsum_queue_flush(hipStream_t stream) {       // launches what is queue
     return VAG_OK;
 }
 
-// the leaf queue (bias gradients under a VagLeafHint while the step driver holds vag_gemm_leaf_begin): flushed by vag_gemm_leaf_end
-static thread_local int g_colsum_leaf_n = 0;
-static thread_local ColsumTasks g_colsum_leaf;
-static thread_local unsigned g_colsum_leaf_gx = 0, g_colsum_leaf_gy = 0;
-void vag_colsum_leaf_abort() { g_colsum_leaf_n = 0; g_colsum_leaf_gx = g_colsum_leaf_gy = 0; }
-int vag_colsum_leaf_flush(hipStream_t stream) {
-    const int n = g_colsum_leaf_n;
-    const unsigned gx = g_colsum_leaf_gx, gy = g_colsum_leaf_gy;
-    vag_colsum_leaf_abort();
-    if (n == 0) return VAG_OK;
-    hipLaunchKernelGGL(colsum_multi_kernel, dim3(gx, gy, (unsigned)n), dim3(256), 0, stream, g_colsum_leaf);
-    VAG_LAUNCH_CHECK();
-    return VAG_OK;
-}
-static void colsum_enqueue(ColsumTasks& T, int& cnt, unsigned& qgx, unsigned& qgy, const float* X, int64_t M, int64_t N, int64_t ld,
-                           float* out, float* out2, float* out3) {
-    const int64_t nbx = cdiv64(N, 256);
-    int64_t splits = cdiv64(1024, nbx);
-    if (splits > cdiv64(M, 8)) splits = cdiv64(M, 8);
-    if (splits < 1) splits = 1;
-    const int rows_per = (int)cdiv64(M, splits);
-    const int k = cnt++;
-    T.X[k] = X; T.out[k] = out; T.out2[k] = out2; T.out3[k] = out3; T.ld[k] = ld;
-    T.M[k] = (int)M; T.N[k] = (int)N; T.rows_per[k] = rows_per;
-    if ((unsigned)nbx > qgx) qgx = (unsigned)nbx;
-    const unsigned gy = (unsigned)cdiv64(M, rows_per);
-    if (gy > qgy) qgy = gy;
-}
-
 int vag_colsum3_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* out, float* out2, float* out3,
                        hipStream_t stream) {
     VAG_CHECK_ARG(X && out && M >= 0 && N >= 0);
     if (M == 0 || N == 0) return VAG_OK;
-    if (vag_gemm_leaf_active() && M < (1ll << 30) && N < (1ll << 30)) {
-        if (g_colsum_leaf_n == COLSUM_MAX) VAG_TRY(vag_colsum_leaf_flush(stream));
-        colsum_enqueue(g_colsum_leaf, g_colsum_leaf_n, g_colsum_leaf_gx, g_colsum_leaf_gy, X, M, N, ld, out, out2, out3);
-        return VAG_OK;
-    }
     if (g_colsum_queue_on && g_colsum_n < COLSUM_MAX && M < (1ll << 30) && N < (1ll << 30)) {
-        colsum_enqueue(g_colsum, g_colsum_n, g_colsum_gx, g_colsum_gy, X, M, N, ld, out, out2, out3);
+        const int64_t nbx = cdiv64(N, 256);
+        int64_t splits = cdiv64(1024, nbx);
+        if (splits > cdiv64(M, 8)) splits = cdiv64(M, 8);
+        if (splits < 1) splits = 1;
+        const int rows_per = (int)cdiv64(M, splits);
+        const int k = g_colsum_n++;
+        g_colsum.X[k] = X; g_colsum.out[k] = out; g_colsum.out2[k] = out2; g_colsum.out3[k] = out3; g_colsum.ld[k] = ld;
+        g_colsum.M[k] = (int)M; g_colsum.N[k] = (int)N; g_colsum.rows_per[k] = rows_per;
+        if ((unsigned)nbx > g_colsum_gx) g_colsum_gx = (unsigned)nbx;
+        const unsigned gy = (unsigned)cdiv64(M, rows_per);
+        if (gy > g_colsum_gy) g_colsum_gy = gy;
         return VAG_OK;
     }
     const int64_t nbx = cdiv64(N, 256);

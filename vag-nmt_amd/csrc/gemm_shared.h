@@ -131,7 +131,7 @@ __device__ __forceinline__ bf16x8 sp_frag_tr(const __bf16* plane, int ob, int ks
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-constexpr int GROUP_MAX = 16;
+constexpr int GROUP_MAX = 12;
 struct GemmGroupArgs {
     GemmArgs p[GROUP_MAX];
     int start[GROUP_MAX + 1];      // first block of each product

@@ -179,7 +179,6 @@ void vag_set_store16(bool on);
 const float* vag_get_derived_override();
 bool vag_get_store16();
 void vag_set_head_chunk(int64_t rows);
-int64_t vag_get_head_chunk();
 void vag_set_head_fuse(const vag_head_g* g, const float* d_loss, float* dt);
 int vag_dec_init_bwd_impl(const float* mask, const float* xmix, const float* h0, float split, const float* W, float* d_h0,
                           int64_t B, int64_t Ts, int64_t C, int64_t H, float* d_enc, int accumulate_enc, float* d_ctx,

@@ -147,7 +147,6 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     if (vag_opt().head_chunk >= 0)      // vag_set_option("head_chunk", rows): rows per chunk (0 = never chunk); tests
         chunk = c.free_run ? 0 : vag_opt().head_chunk;
     DerivedScope scope(derived, c.storage == 1, chunk);
-    VagLeafScope leaf_scope;               // parameter-gradient products and bias sums of this call: one launch at its end
     // forward and backward in one call: the chunked head finishes each chunk (d(logits) and its products) in the forward;
     // a backward called on its own (phases = 2 after an earlier phases = 1) recomputes the chunks instead
     if (chunk > 0 && (phases & 3) == 3 && vag_opt().head_fuse != 0)
@@ -234,7 +233,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
         VAG_TRY(vag_bigru_seq_bwd(src, lengths, w.enc_fw, w.enc_bw, c.p_emb, c.p_ctx, crng, B, Ts, c.Es, H, k.d_enc, k.ws_enc,
                                   g.enc_emb, g.enc_fw, g.enc_bw, stream));
     }
-    return leaf_scope.end(s);
+    return VAG_OK;
 }
 
 }  // extern "C"
