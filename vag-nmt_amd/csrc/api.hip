@@ -99,7 +99,7 @@ int vag_set_option(const char* name, int64_t value) {
         {"gemm_f32mfma", &o.gemm_f32mfma}, {"gemm_nogroup", &o.gemm_nogroup}, {"gemm_force_tile", &o.gemm_force_tile},
         {"gemm_force_splitk", &o.gemm_force_splitk}, {"gemm_debug", &o.gemm_debug}, {"head_fuse", &o.head_fuse},
         {"head_bf16_grads", &o.head_bf16_grads}, {"persistent", &o.persistent}, {"persistent_dec_bwd", &o.persistent_dec_bwd},
-        {"persist_timing", &o.persist_timing}};
+        {"persist_timing", &o.persist_timing}, {"s16_one_plane", &o.s16_one_plane}};
     for (const auto& e : ints)
         if (strcmp(name, e.n) == 0) { *e.p = (int)value; return VAG_OK; }
     if (strcmp(name, "head_chunk") == 0) { o.head_chunk = value; return VAG_OK; }

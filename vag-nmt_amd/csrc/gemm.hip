@@ -227,9 +227,10 @@ __device__ __forceinline__ void sp_load(const float* __restrict__ P, int64_t so,
     }
 }
 
-// registers -> PL (3 or 2) bf16 planes in LDS, image [outer][k] per plane
-template <bool KC, int PL = 3>
+// registers -> PL (3, 2 or 1) bf16 planes in LDS, image [outer][k] per plane; F16 (PL = 1 only): one fp16 plane instead
+template <bool KC, int PL = 3, bool F16 = false>
 __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r) {
+    static_assert(!F16 || PL == 1, "the fp16 image is a single plane");
     const int tid = threadIdx.x;
     if (KC) {
 #pragma unroll
@@ -237,8 +238,16 @@ __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r
             const int idx = tid + i * 512;
             const int o = sp_row(idx >> 3), k = (idx & 7) << 2;
             unsigned a1, a2, a3, b1, b2, b3;
-            split3(r.v[4 * i + 0], r.v[4 * i + 1], a1, a2, a3);
-            split3(r.v[4 * i + 2], r.v[4 * i + 3], b1, b2, b3);
+            if (F16) {
+                a1 = pack_f16(r.v[4 * i + 0], r.v[4 * i + 1]); b1 = pack_f16(r.v[4 * i + 2], r.v[4 * i + 3]);
+                a2 = a3 = b2 = b3 = 0;
+            } else if (PL == 1) {
+                a1 = pack_bf16(r.v[4 * i + 0], r.v[4 * i + 1]); b1 = pack_bf16(r.v[4 * i + 2], r.v[4 * i + 3]);
+                a2 = a3 = b2 = b3 = 0;
+            } else {
+                split3(r.v[4 * i + 0], r.v[4 * i + 1], a1, a2, a3);
+                split3(r.v[4 * i + 2], r.v[4 * i + 3], b1, b2, b3);
+            }
             __bf16* d = S + o * SP_LD + k;
             *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
             if (PL >= 2) *reinterpret_cast<uint2*>(d + SP_PLANE) = make_uint2(a2, b2);
@@ -249,8 +258,16 @@ __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + i * 512;
             unsigned a1, a2, a3, b1, b2, b3;
-            split3(r.v[4 * i + 0], r.v[4 * i + 1], a1, a2, a3);
-            split3(r.v[4 * i + 2], r.v[4 * i + 3], b1, b2, b3);
+            if (F16) {
+                a1 = pack_f16(r.v[4 * i + 0], r.v[4 * i + 1]); b1 = pack_f16(r.v[4 * i + 2], r.v[4 * i + 3]);
+                a2 = a3 = b2 = b3 = 0;
+            } else if (PL == 1) {
+                a1 = pack_bf16(r.v[4 * i + 0], r.v[4 * i + 1]); b1 = pack_bf16(r.v[4 * i + 2], r.v[4 * i + 3]);
+                a2 = a3 = b2 = b3 = 0;
+            } else {
+                split3(r.v[4 * i + 0], r.v[4 * i + 1], a1, a2, a3);
+                split3(r.v[4 * i + 2], r.v[4 * i + 3], b1, b2, b3);
+            }
             __bf16* d = S + sp_oc_off(idx >> 5, (idx & 31) << 2);
             *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
             if (PL >= 2) *reinterpret_cast<uint2*>(d + SP_PLANE) = make_uint2(a2, b2);
@@ -261,7 +278,8 @@ __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r
 
 // Af / Bf: fragment base of a k-contiguous operand; As / Bs + (oa, obn): plane base and first outer index of this wave's
 // rows for an outer-contiguous one.
-template <int PL, bool AKC, bool BKC>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int PL, bool AKC, bool BKC, bool F16 = false>
 __device__ __forceinline__ void sp_compute(const __bf16* Af, const __bf16* Bf, const __bf16* As, const __bf16* Bs, int oa, int obn,
                                            f32x16 (&acc)[2]) {
 #pragma unroll
@@ -286,15 +304,19 @@ __device__ __forceinline__ void sp_compute(const __bf16* Af, const __bf16* Bf, c
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[PL >= 2 ? 1 : 0], acc[i], 0, 0, 0);
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PL >= 2 ? 1 : 0], bf[0], acc[i], 0, 0, 0);
             }
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i], 0, 0, 0);
+            if (F16)            // the plane holds fp16 bit patterns (sp_store<.., 1, true>): same fragments, the f16 instruction
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][0]), __builtin_bit_cast(f16x8, bf[0]),
+                                                                acc[i], 0, 0, 0);
+            else
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i], 0, 0, 0);
         }
     }
 }
 
-template <bool AKC, bool BKC, bool VEC, int PL = 3>
+template <bool AKC, bool BKC, bool VEC, int PL = 3, bool F16 = false>
 __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem, int bx, int by, int bz) {
     __bf16* As = smem;
-    __bf16* Bs = smem + 3 * SP_PLANE;
+    __bf16* Bs = smem + PL * SP_PLANE;
     const int m0 = by * 128, n0 = bx * 128;
     const int kbeg = bz * a.kchunk;
     const int kend = min(a.K, kbeg + a.kchunk);
@@ -315,14 +337,14 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
     sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, kbeg, a.M, kend, ra);
     sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, kbeg, a.N, kend, rb);
     for (int k0 = kbeg; k0 < kend; k0 += SP_BK) {
-        sp_store<AKC, PL>(As, ra);
-        sp_store<BKC, PL>(Bs, rb);
+        sp_store<AKC, PL, F16>(As, ra);
+        sp_store<BKC, PL, F16>(Bs, rb);
         __syncthreads();
         if (k0 + SP_BK < kend) {
             sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, k0 + SP_BK, a.M, kend, ra);
             sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, k0 + SP_BK, a.N, kend, rb);
         }
-        sp_compute<PL, AKC, BKC>(Af, Bf, As, Bs, wm * 64, wn * 32, acc);
+        sp_compute<PL, AKC, BKC, F16>(Af, Bf, As, Bs, wm * 64, wn * 32, acc);
         __syncthreads();
     }
 
@@ -344,26 +366,26 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
 // products: no change on hot operands (4096^3 NT 705 -> 710 us); grouped launches: SLOWER in the step (weight-gradient group
 // 150 -> 174 us, logits/keys group 67 -> 86 us) because an XCD then works through one product's blocks and the products'
 // K differ by 10x -- the round-robin dealing of blocks over the XCDs is what balances a group.)
-template <bool AKC, bool BKC, bool VEC, int PL = 3>
+template <bool AKC, bool BKC, bool VEC, int PL = 3, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_split_kernel(GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) __bf16 smem[6 * SP_PLANE];
-    gemm_split_body<AKC, BKC, VEC, PL>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * PL * SP_PLANE];      // 60 / 40 / 20 KB
+    gemm_split_body<AKC, BKC, VEC, PL, F16>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Grouped launch: the blocks of up to GROUP_MAX independent products of one operand layout (e.g. all "TN": both operands
 // outer-contiguous, the weight gradients g_W += dY^T X of one operator) in ONE grid.  Each of these products alone is a few dozen 128x128 tiles
 // with K = Tt*B: launched one by one they need split-K by 5-10 (atomics) to fill the chip and still pay a ramp and a
 // partial last wave each; together they fill it with split-K 1-2.
-template <bool AKC, bool BKC, int PL = 3>
+template <bool AKC, bool BKC, int PL = 3, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_split_group_kernel(GemmGroupArgs G) {
-    __shared__ __attribute__((aligned(16))) __bf16 smem[6 * SP_PLANE];
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * PL * SP_PLANE];
     int p = 0;
     while (p + 1 < G.n && (int)blockIdx.x >= G.start[p + 1]) ++p;
     const GemmArgs& a = G.p[p];
     const int id = blockIdx.x - G.start[p];
     const int tn = (a.N + 127) / 128, tm = (a.M + 127) / 128;
     const int bx = id % tn, by = (id / tn) % tm, bz = id / (tn * tm);
-    gemm_split_body<AKC, BKC, true, PL>(a, smem, bx, by, bz);
+    gemm_split_body<AKC, BKC, true, PL, F16>(a, smem, bx, by, bz);
 }
 
 // (A double-buffered variant -- 110 KB of LDS, one block per CU, split/store of tile t+1 issued between the k-halves of
@@ -374,14 +396,18 @@ __global__ __launch_bounds__(512) void gemm_split_group_kernel(GemmGroupArgs G) 
 // (tools/mfma_probe.hip) sustains 1.9-2.1 PFLOP/s bf16, i.e. 315-350 TFLOP/s fp32-equivalent at six products.)
 // Planes per operand of the bf16 split on the calling thread: 3 (default: six products, fp32-grade) or 2 (three products:
 // the 2-byte storage mode, set by the step driver for the duration of a call).
+// 11: ONE fp16 plane (v_mfma_f32_32x32x16_f16; operands rounded to fp16 on their way into LDS -- the 2-byte mode's forward
+// products in the step driver), 1: one bf16 plane (that mode's gradient products: fp16 would flush small gradients).
 static thread_local int g_gemm_planes = 3;
-void vag_gemm_set_planes(int planes) { g_gemm_planes = (planes == 2 || planes == 1) ? planes : 3; }
+void vag_gemm_set_planes(int planes) { g_gemm_planes = (planes == 2 || planes == 1 || planes == 11) ? planes : 3; }
+int vag_gemm_get_planes() { return g_gemm_planes; }
 
 static int gemm_split_dispatch(const GemmArgs& g, bool akc, bool bkc, bool vec, dim3 grid, hipStream_t s) {
 #define VAG_SPLIT_CASE(AK, BKc, V)                                                                    \
     if (akc == AK && bkc == BKc && vec == V) {                                                        \
         if (g_gemm_planes == 2) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 2>), grid, dim3(512), 0, s, g);   \
         else if (g_gemm_planes == 1) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 1>), grid, dim3(512), 0, s, g);   \
+        else if (g_gemm_planes == 11) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 1, true>), grid, dim3(512), 0, s, g);   \
         else hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 3>), grid, dim3(512), 0, s, g);        \
         VAG_LAUNCH_CHECK();                                                                           \
         return VAG_OK;                                                                                \
@@ -574,16 +600,19 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
     }
     G.start[n] = total;
     const bool akc = (lay & 2) != 0, bkc = (lay & 1) != 0;
-#define VAG_GROUP_GO(PLN)                                                                                                     \
+#define VAG_GROUP_GO(PLN, F)                                                                                                  \
     if (!akc && !bkc)                                                                                                         \
-        hipLaunchKernelGGL((gemm_split_group_kernel<false, false, PLN>), dim3((unsigned)total), dim3(512), 0, stream, G);     \
+        hipLaunchKernelGGL((gemm_split_group_kernel<false, false, PLN, F>), dim3((unsigned)total), dim3(512), 0, stream, G);  \
     else if (akc && !bkc)                                                                                                     \
-        hipLaunchKernelGGL((gemm_split_group_kernel<true, false, PLN>), dim3((unsigned)total), dim3(512), 0, stream, G);      \
+        hipLaunchKernelGGL((gemm_split_group_kernel<true, false, PLN, F>), dim3((unsigned)total), dim3(512), 0, stream, G);   \
     else if (akc && bkc)                                                                                                      \
-        hipLaunchKernelGGL((gemm_split_group_kernel<true, true, PLN>), dim3((unsigned)total), dim3(512), 0, stream, G);       \
+        hipLaunchKernelGGL((gemm_split_group_kernel<true, true, PLN, F>), dim3((unsigned)total), dim3(512), 0, stream, G);    \
     else                                                                                                                      \
-        hipLaunchKernelGGL((gemm_split_group_kernel<false, true, PLN>), dim3((unsigned)total), dim3(512), 0, stream, G);
-    if (g_gemm_planes <= 2) { VAG_GROUP_GO(2) } else { VAG_GROUP_GO(3) }      // one-plane products are never grouped
+        hipLaunchKernelGGL((gemm_split_group_kernel<false, true, PLN, F>), dim3((unsigned)total), dim3(512), 0, stream, G);
+    if (g_gemm_planes == 11) { VAG_GROUP_GO(1, true) }
+    else if (g_gemm_planes == 1) { VAG_GROUP_GO(1, false) }
+    else if (g_gemm_planes == 2) { VAG_GROUP_GO(2, false) }
+    else { VAG_GROUP_GO(3, false) }
 #undef VAG_GROUP_GO
     VAG_LAUNCH_CHECK();
     return VAG_OK;

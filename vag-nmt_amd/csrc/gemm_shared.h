@@ -78,6 +78,11 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     bf16x2 h = __builtin_convertvector(v, bf16x2);     // v_cvt_pk_bf16_f32 (round to nearest even)
     return __builtin_bit_cast(unsigned, h);
 }
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {     // two fp16 (round to nearest even), low half = a
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f16x2 h = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
 // a - b as ONE scalar v_sub_f32: under -O3 the SLP vectoriser pairs the two residuals of a split into v_pk_add_f32, and
 // packed f32 VALU beside MFMAs is an anti-lever on gfx950 (MI355X_MICROARCH.md price list: +13 cycles each): measured
 // +8-10 % on the k-contiguous products (4096^3 NT 147 -> 160 TF/s, d out.weight 96 -> 88 us).  Inline asm keeps it scalar

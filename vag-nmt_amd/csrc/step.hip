@@ -156,7 +156,12 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     float* h0 = k.hseq;                    // [h0, h2_0 .. h2_{Tt-1}] in one buffer: the W_hh1 gradient is one product
     float* h2_all = k.hseq + B * H;
     const uint64_t* crng = rng;
+    // 2-byte storage mode: what feeds the large products carries no more than fp16 there (fp16-stored keys and weights,
+    // activations the next fp16 product rounds anyway), so they run on one plane: fp16 operands forward (11 significand bits),
+    // bf16 operands for every gradient product (fp16 would flush small gradients; their rounding errors average over the long sums)
+    const bool one_plane = c.storage == 1 && !c.free_run && vag_opt().s16_one_plane != 0;
     if (phases & 1) {
+        if (one_plane) vag_gemm_set_planes(11);
         {
             int64_t nb = cdiv64((Tt + 1) * B, 256);
             if (nb > 1024) nb = 1024;
@@ -193,6 +198,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
                                          c.free_run ? 1 : 0, k.tmid, k.logits, c.ldl, k.lse, k.nll, k.inv_cnt, 1, nullptr,
                                          losses, w_mt, w_vse, has_vse ? 1 : 0, s));                     // V11.py:140,164-166
     }
+    if (one_plane && (phases & 6)) vag_gemm_set_planes(1);
     if (phases & 2) {
         VAG_TRY(vag_head_ce_seq_bwd(h2_all, k.c_all, k.e_all, w.head, tgt, vocab_weight, B, Tt, Et, H, V, c.p_out, crng, k.tmid,
                                     k.logits, c.ldl, k.lse, k.inv_cnt, k.consts + 0, k.d_h2, k.d_c, k.d_e, g.head, k.scr_head,
