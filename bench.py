@@ -476,6 +476,9 @@ def main():
     ap.add_argument("--no-dropout", action="store_true", help="debug: disable the reference dropouts")
     ap.add_argument("--no-cfg5-row", action="store_true", help="skip the configs[4] row of the extras")
     ap.add_argument("--no-fused", action="store_true", help="debug: per-operator autograd path instead of vag_train_step")
+    ap.add_argument("--comm", choices=["torch", "vag"], default="torch",
+                    help="multi-GPU exchange: torch.distributed's all_reduce (backend nccl = RCCL) or the C ABI's own RCCL "
+                         "communicator (vag_comm_*, include/vag_nmt.h)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="library option for A/B runs (vag_set_option), e.g. --opt persistent=0")
     ap.add_argument("--config", choices=["cfg2", "cfg5", "cfg5-f32"], default="cfg2",
@@ -522,9 +525,13 @@ def main():
     vw[0] = 0
     crit_mt = torch.nn.NLLLoss(weight=vw, reduction="none")
     crit_vse = PairwiseRankingLoss(margin=0.1)
+    comm = None
+    if world > 1 and args.comm == "vag" and not smoke_dp:
+        from vagnmt_hip.comm import Comm
+        comm = Comm(rank=rank, world_size=world)       # the id travels over the default process group
     ts = TrainStep(model, crit_mt, crit_vse, lr=4e-4, weight_decay=1e-5, clip=1.0, teacher_force_ratio=args.tfr,
                    use_graph=not args.no_graph, process_group=pg, world_size=world, fused=not args.no_fused,
-                   storage="f16" if args.config == "cfg5" else "f32")
+                   storage="f16" if args.config == "cfg5" else "f32", comm=comm)
     src, lens, tgt, im = make_batch(c, rank, dev, ragged=args.ragged)
     lens_t = torch.tensor(lens, dtype=torch.int32, device=dev)
 

@@ -419,6 +419,23 @@ int vag_cgru_recurrence_fwd(const float* pe, const float* mask, const float* h0,
                             float* g1, float* qhp, float* alpha, float* h2_all, float* g2, float* psc, void* sync,
                             vag_stream_t stream);
 
+/* ---- data-parallel gradient exchange over RCCL (SURVEY 8b "C1", 8e) -------------------------------------------------------
+ * One process per GPU, one communicator per process.  Rank 0 draws an id (128 opaque bytes) and ships it to the other
+ * ranks by any channel (the Python host uses the torch.distributed store); every rank then calls vag_comm_init with the
+ * same id -- a collective that binds the communicator to the CURRENT device.  vag_comm_allreduce sums `n` floats in place
+ * across the ranks (ncclAllReduce, ncclSum -- the caller scales by 1/N; vag_clip_adam_flat's grad_scale does) on `stream`;
+ * like every call here it only enqueues, so it can be captured with the step's kernels.  The reference has no
+ * distributed backend (nmt_multimodal_beam_DE.py:277-282 leaves nn.DataParallel commented out); this is the exchange
+ * SURVEY 8e adds.  librccl is loaded on the first vag_comm_* call (-38 = ENOSYS if it cannot be); RCCL's own errors come
+ * back as 10000 + ncclResult_t. */
+#define VAG_COMM_ID_BYTES 128
+typedef struct vag_comm_s* vag_comm_t;
+int vag_comm_unique_id(void* id);
+int vag_comm_init(vag_comm_t* comm, int nranks, int rank, const void* id);
+int vag_comm_allreduce(vag_comm_t comm, float* buf, int64_t n, vag_stream_t stream);
+int vag_comm_size(vag_comm_t comm);
+int vag_comm_destroy(vag_comm_t comm);
+
 /* ---- dropout helpers ---------------------------------------------------------------------------------- */
 /* which: 1 encoder-embedding (Ts,B,E), 2 encoder-context (B,Ts,2H), 3 decoder-output (Tt,B,E). */
 int vag_dropout_mask(const uint64_t* rng, int which, int64_t n, float p, float* out, vag_stream_t stream);

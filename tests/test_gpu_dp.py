@@ -139,3 +139,35 @@ def test_phased_sequence_with_rccl_collectives_world1():
     assert sa["captures"] >= 2 and sa["replays"] >= 4, sa
     assert np.allclose(la, lb, rtol=2e-4), (la, lb)
     assert np.allclose(fa, fb, rtol=2e-4, atol=2e-6), np.abs(fa - fb).max()
+
+
+def test_phased_sequence_with_vag_comm_world1():
+    """The same data-parallel sequence with the exchange going through the C ABI's own RCCL communicator (vag_comm_init /
+    vag_comm_allreduce on a side stream, include/vag_nmt.h) instead of torch.distributed: one rank, so the sum is the
+    identity and the result must equal the single-process step; covers id creation, communicator binding, the event
+    hand-offs between the step's stream and the exchange stream, and destruction."""
+    from vagnmt_hip.trainer import TrainStep
+    from vagnmt_hip.comm import Comm
+    from vagnmt_hip import _lib
+    res = {}
+    comm = Comm(rank=0, world_size=1)
+    assert _lib.lib().vag_comm_size(comm._h) == 1
+    for name, kw in (("phased", dict(comm=comm, force_phased=True)), ("single", {})):
+        m = _model(100)
+        cm, cv = _criteria()
+        ts = TrainStep(m, cm, cv, use_graph=True, **kw)
+        losses = [float(ts.step(*_batch(1000 + 10 * (s % 2)), teacher=True)[0]) for s in range(6)]
+        torch.cuda.synchronize()
+        res[name] = (ts.fp.flat.cpu().numpy().copy(), losses)
+    comm.close()
+    (fa, la), (fb, lb) = res["phased"], res["single"]
+    assert np.allclose(la, lb, rtol=2e-4), (la, lb)
+    assert np.allclose(fa, fb, rtol=2e-4, atol=2e-6), np.abs(fa - fb).max()
+    # a plain buffer: sum over one rank leaves it unchanged
+    comm = Comm(rank=0, world_size=1)
+    x = torch.randn(1 << 20, device="cuda")
+    y = x.clone()
+    comm.all_reduce(x).wait()
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+    comm.close()

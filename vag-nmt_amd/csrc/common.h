@@ -6,6 +6,7 @@
 
 #define VAG_OK 0
 #define VAG_EINVAL (-22)
+#define VAG_ENOSYS (-38)      // librccl could not be loaded (vag_comm_*)
 
 #define VAG_CHECK_ARG(cond)                     \
     do {                                        \

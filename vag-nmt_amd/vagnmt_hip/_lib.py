@@ -110,6 +110,11 @@ PROTOS = {
     "vag_recurrence_supported": (I32, [I32, I64, I64, I64, I64]),
     "vag_persistent_timeouts": (I32, []),
     "vag_recurrence_time": (I32, [I32, P, P]),
+    "vag_comm_unique_id": (I32, [P]),
+    "vag_comm_init": (I32, [P, I32, I32, P]),
+    "vag_comm_allreduce": (I32, [P, P, I64, P]),
+    "vag_comm_size": (I32, [P]),
+    "vag_comm_destroy": (I32, [P]),
     "vag_recurrence_sync_words": (I64, [I32, I64, I64]),
     "vag_cgru_recurrence_fwd": (I32, [P, P, P, P, DecW, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P]),
     "vag_derived_floats": (I64, [I64]),

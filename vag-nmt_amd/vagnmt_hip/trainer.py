@@ -104,7 +104,7 @@ class TrainStep:
     def __init__(self, model, criterion_mt, criterion_vse=None, lr=4e-4, weight_decay=1e-5, clip=1.0,
                  teacher_force_ratio=0.8, betas=(0.9, 0.999), eps=1e-8, vse_separate=False, use_graph=True,
                  process_group=None, world_size=1, max_graphs=48, pad_src=4, fused=None, backend=None,
-                 force_phased=False, storage="f32"):
+                 force_phased=False, storage="f32", comm=None):
         self.model = model
         self.criterion_mt = criterion_mt
         self.criterion_vse = criterion_vse
@@ -115,6 +115,9 @@ class TrainStep:
         self.use_graph = use_graph
         self.pg, self.world = process_group, world_size
         self.comm_enabled = True              # False: keep the phases but skip the all-reduces (measurement only)
+        # comm: a vagnmt_hip.comm.Comm (RCCL through the C ABI's vag_comm_*) instead of torch.distributed's all_reduce on
+        # process_group; the sequence of phases and buckets is the same
+        self.comm = comm
         self.force_phased = force_phased      # tests: the data-parallel sequence (two phases, two buckets) at world_size 1
         self.max_graphs = max_graphs
         self.pad_src = max(1, int(pad_src))
@@ -188,6 +191,8 @@ class TrainStep:
         import torch.distributed as dist
         if not self.comm_enabled:
             return _NoWork()
+        if self.comm is not None:
+            return self.comm.all_reduce(self.fp.grad[lo:hi])
         return dist.all_reduce(self.fp.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def resync(self):
@@ -220,7 +225,8 @@ class TrainStep:
         if be is None:
             raise RuntimeError("TrainStep needs HIP tensors and criteria (or an injected backend) to run a step")
         (bk0, bk1) = self.fp.buckets()
-        if (self.world > 1 or (self.force_phased and self.pg is not None)) and getattr(be, "phased", False):
+        if (self.world > 1 or (self.force_phased and (self.pg is not None or self.comm is not None))) and \
+                getattr(be, "phased", False):
             # backward in two phases; the first bucket's all-reduce runs beside the encoder's backward
             be.run(src, lengths, tgt, im, teacher, 3)
             w0 = self._allreduce_async(*bk0)
