@@ -94,3 +94,40 @@ def test_persistent_decoder_equals_launch_chain(B, Ts, Tt):
     for n in g0:
         scale = max(g0[n].abs().max().item(), 1e-3)
         assert (g0[n] - g1[n]).abs().max().item() <= 2e-5 * scale, n
+
+
+def test_wide_fp16_encoder_kernel_equals_the_launch_chain():
+    """2-byte storage mode at configs[4] widths (H = 1024, B = 256, ragged lengths): the one-launch encoder forward
+    (enc_fwd_wide16_kernel: fp16 weight slice in registers, states exchanged as fp16) against the chain of per-step launches
+    (fp32 states x fp16 weights).  The only difference is the fp16 rounding of the state that enters a step's product
+    (2^-12 relative): encoder states within 2e-3 absolute (|h| <= 1), losses within 1e-3."""
+    import ctypes as C
+    from test_gpu_round2 import _fp16_case
+    from vagnmt_hip import _lib as L
+    from vagnmt_hip.trainer import TrainStep
+    m_of, (src, lens, tgt, im), cm, cv = _fp16_case("wide")
+    lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    out = {}
+    try:
+        for persistent in (0, 1):
+            L.set_option("persistent", persistent)
+            m = m_of()
+            ts = TrainStep(m, cm, cv, use_graph=False, storage="f16", pad_src=1)
+            m.eval()
+            ts.backend.run(src, lt, tgt, im, True, 7)
+            torch.cuda.synchronize()
+            f = ts.backend.f
+            B, Ts = src.shape
+            c = f.cfg(B, Ts, tgt.shape[1], True, False)
+            off = L.lib().vag_step_ws_offset(C.byref(c), 0)
+            enc = f.ws[off:off + B * Ts * 2 * 1024].detach().clone()
+            out[persistent] = (enc, [float(x) for x in ts.backend.outputs()], ts.fp.grad.detach().clone())
+            assert L.lib().vag_persistent_timeouts() == 0
+    finally:
+        L.set_option("persistent", 1)
+    (e0, l0, g0), (e1, l1, g1) = out[0], out[1]
+    assert torch.isfinite(e1).all()
+    assert (e0 - e1).abs().max().item() <= 2e-3, (e0 - e1).abs().max().item()
+    assert (e0 - e1).abs().max().item() > 0.0           # the kernel really ran (fp16-rounded exchange differs in the last bits)
+    assert np.allclose(l0, l1, rtol=1e-3, atol=1e-4), (l0, l1)
+    assert (g0 - g1).abs().max().item() <= 1e-2 * g0.abs().max().item()

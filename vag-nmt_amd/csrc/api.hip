@@ -225,10 +225,17 @@ int vag_bigru_seq_fwd(const int64_t* src, const int32_t* lengths, const float* e
                                               Ts, H, s));
         return vag_dropout_apply_launch(enc, B * Ts * 2 * H, 0, rng, VAG_DROP_ENC_CTX, p_ctx, s);
     }
+    const vag_half* w16 = s16 ? derived_layout(const_cast<float*>(g_derived), H).enc16 : nullptr;
+    if (s16 && vag_opt().persistent && vag_enc_wide16_ok(B, Ts, H) && B >= 64) {
+        // 2-byte mode, wide batches: one launch, the fp16 weight slice of a workgroup in registers, four row tiles through
+        // it per step; the fp16 copy of the states that the workgroups exchange lives in the backward's (still unused) dgh
+        VAG_TRY(vag_enc_fwd_wide16_launch(w.xp, w16, w16 + 3 * H * H, fw.b_hh, bw.b_hh, lengths, w.hst, w.gates, enc,
+                                          reinterpret_cast<vag_half*>(w.dgh), w.sync, B, Ts, H, s));
+        return vag_dropout_apply_launch(enc, B * Ts * 2 * H, 0, rng, VAG_DROP_ENC_CTX, p_ctx, s);
+    }
     GruStepArgs a = {};
     a.lda = H; a.ldw = H; a.ldother = 6 * H; a.ldh = H; a.ld2 = Ts * 2 * H;
     a.M = (int)B; a.K = (int)H; a.H = (int)H; a.lengths = lengths; a.comp_hidden = 1;
-    const vag_half* w16 = s16 ? derived_layout(const_cast<float*>(g_derived), H).enc16 : nullptr;
     for (int64_t k = 0; k < Ts; ++k) {
         for (int d = 0; d < 2; ++d) {
             const int64_t t = d == 0 ? k : Ts - 1 - k;

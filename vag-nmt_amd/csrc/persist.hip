@@ -247,6 +247,189 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_persistent_kernel(EncPArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Encoder forward recurrence, 2-byte storage mode, WIDE batches (configs[4]: B = 256, H = 1024): both directions in ONE
+// launch.  The fp32 kernel above keeps a 48 x H slice of W_hh as three bf16 planes per workgroup and scales by adding row
+// tiles to the GRID (2 x B/16 x H/16 workgroups), which stops at B = 64 (H = 512) on 256 CUs.  Here the stored-fp16
+// recurrent weights (derived buffer, vag_derive_weights(with_fp16 = 1)) make a 96 x H slice fit the registers as ONE fp16
+// plane (96 VGPRs at H = 1024), and a workgroup takes FOUR row tiles (64 batch rows) through that slice per step:
+//   grid = 2 directions x ceil(B/64) row groups x H/32 unit slices (256 workgroups at B = 256, H = 1024);
+//   wave (kq, ch) of 8: K quarter kq (H/4 columns of h), unit half ch (16 units x 3 gates) -> per step and row tile
+//   3 x H/128 v_mfma_f32_16x16x32_f16; partial sums of the four K quarters meet in LDS (96 KB, which also keeps the CU to
+//   one workgroup), and wave (r, ch) runs the cell for row tile r: every wave has a product share AND an epilogue share.
+// The hidden state is published for the other workgroups' products as fp16 (8 bytes per lane, write-through), which is
+// what an fp16-operand product would round it to anyway; the carried state (registers), the saved states and gates and
+// the encoder output stay fp32.  Per step a workgroup ingests 64 x H fp16 = 128 KB instead of the launch chain's 48 x H
+// weights + rows per 16-row tile; hand-off as above (sc1 stores, drain, one counter add per wave, bounded poll, sc1 loads).
+struct EncWArgs {
+    const float* xp;            // (Ts, B, 6H): input projections [fwd r z n | rev r z n], biases included
+    const vag_half* W16[2];     // (3H, H) recurrent weights per direction, fp16
+    const float* bias[2];       // (3H) b_hh
+    const int* lengths;         // (B)
+    float* hst;                 // [2][Ts+1][B][H], step 0 zeros (caller)
+    float* gates;               // [2][Ts][4][B][H]
+    float* enc;                 // (B, Ts, 2H)
+    vag_half* hx;               // [2][Ts+1][B][H] fp16 copy of the states for the exchange; slot 0 is written here (zeros)
+    unsigned* cnt;              // [2][RG][Ts], zero on entry
+    unsigned* err;
+    int B, Ts, H, RG, CS;
+};
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+// N sc1 loads of 16 bytes at a 64-byte stride (k-steps of 32 halves) + their wait in one statement
+template <int N> __device__ __forceinline__ void ld16_sc1(const vag_half* p, u32x4 (&v)[N]);
+template <> __device__ __forceinline__ void ld16_sc1<4>(const vag_half* p, u32x4 (&v)[4]) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:64 sc1\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:128 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:192 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p) : "memory");
+}
+template <> __device__ __forceinline__ void ld16_sc1<8>(const vag_half* p, u32x4 (&v)[8]) {
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:64 sc1\n\t"
+                 "global_load_dwordx4 %2, %8, off offset:128 sc1\n\tglobal_load_dwordx4 %3, %8, off offset:192 sc1\n\t"
+                 "global_load_dwordx4 %4, %8, off offset:256 sc1\n\tglobal_load_dwordx4 %5, %8, off offset:320 sc1\n\t"
+                 "global_load_dwordx4 %6, %8, off offset:384 sc1\n\tglobal_load_dwordx4 %7, %8, off offset:448 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(p) : "memory");
+}
+__device__ __forceinline__ void st_sc1_h4(vag_half* p, float a, float b, float c, float d) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = {pack_f16(a, b), pack_f16(c, d)};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+
+// KST: k-steps of 32 per wave = H / 128
+template <int KST>
+__global__ __launch_bounds__(512, 1) void enc_fwd_wide16_kernel(EncWArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wide_lds[];      // [4 row tiles][4 K quarters][2 unit halves][3 gates][64] float4
+    const int wg = blockIdx.x;
+    const int cs = wg % a.CS, rg = (wg / a.CS) % a.RG, d = wg / (a.CS * a.RG);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kq = wave & 3, ch = wave >> 2;             // product role: K quarter, unit half
+    const int er = wave & 3, ech = wave >> 2;            // epilogue role: row tile, unit half
+    const int H = a.H, B = a.B, Ts = a.Ts;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int u0 = cs * 32, m0 = rg * 64;
+    const int kbase = kq * (H >> 2);
+    const int64_t BH = (int64_t)B * H;
+
+    // this wave's share of the weight slice: wf[s][gate] = W16[gate*H + u0 + 16 ch + fr][kbase + 32 s + 8 fg .. +7]
+    h16x8 wf[KST][3];
+    {
+        const vag_half* W = a.W16[d];
+#pragma unroll
+        for (int s = 0; s < KST; ++s)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const uint4 q = *reinterpret_cast<const uint4*>(W + (int64_t)(j * H + u0 + 16 * ch + fr) * H + kbase + 32 * s + 8 * fg);
+                const u32x4 t = {q.x, q.y, q.z, q.w};
+                wf[s][j] = __builtin_bit_cast(h16x8, t);
+            }
+    }
+    // epilogue identity: batch row em, units eu .. eu + 3
+    const int em = m0 + 16 * er + fr, eu = u0 + 16 * ech + 4 * fg;
+    const bool eok = em < B;
+    float4 bb[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    int len = 0;
+    if (eok) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) bb[j] = *reinterpret_cast<const float4*>(a.bias[d] + j * H + eu);
+        len = a.lengths[em];
+    }
+    float4 hp = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    float* hs = a.hst + (int64_t)d * (Ts + 1) * BH;
+    vag_half* hx = a.hx + (int64_t)d * (Ts + 1) * BH;
+    gu32* cnt = (gu32*)(a.cnt + ((int64_t)d * a.RG + rg) * Ts);
+    const unsigned target = (unsigned)a.CS * 8u;           // every wave of every workgroup of the row group signs a step
+    float4* red = reinterpret_cast<float4*>(wide_lds);
+    bool dead = false;
+
+    for (int k = 0; k < Ts; ++k) {
+        const int t = d == 0 ? k : Ts - 1 - k;
+        float4 xo[3];
+        if (eok) {
+            const float* xp = a.xp + ((int64_t)t * B + em) * 6 * H + d * 3 * H + eu;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) xo[j] = *reinterpret_cast<const float4*>(xp + j * H);
+        }
+        if (k > 0) {
+            if (threadIdx.x == 0 && !dead) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(cnt + (k - 1), RLX_AGENT) < target) {
+                    if (++spins > SPIN_LIMIT) { note_timeout(a.err); dead = true; break; }
+                }
+            }
+            __syncthreads();
+            // ---- products: the four row tiles of the group against this wave's weight share
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = min(m0 + 16 * r + fr, B - 1);
+                u32x4 hq[KST];
+                ld16_sc1<KST>(hx + ((int64_t)k * B + row) * H + kbase + 8 * fg, hq);
+                f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int s = 0; s < KST; ++s) {
+                    const h16x8 hf = __builtin_bit_cast(h16x8, hq[s]);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][j], hf, acc[j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    red[((((r * 4 + kq) * 2 + ch) * 3) + j) * 64 + lane] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+            }
+            __syncthreads();
+        }
+        // ---- cell of row tile er, unit half ech (step 0: h = 0, the product is zero)
+        float4 c[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k > 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 o = red[((((er * 4 + q) * 2 + ech) * 3) + j) * 64 + lane];
+                    sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
+                }
+            }
+            c[j] = make_float4(sum.x + bb[j].x, sum.y + bb[j].y, sum.z + bb[j].z, sum.w + bb[j].w);
+        }
+        if (eok) {
+            const bool active = t < len;
+            const float cr[4] = {c[0].x, c[0].y, c[0].z, c[0].w}, cz[4] = {c[1].x, c[1].y, c[1].z, c[1].w};
+            const float cn[4] = {c[2].x, c[2].y, c[2].z, c[2].w};
+            const float xr[4] = {xo[0].x, xo[0].y, xo[0].z, xo[0].w}, xz[4] = {xo[1].x, xo[1].y, xo[1].z, xo[1].w};
+            const float xn[4] = {xo[2].x, xo[2].y, xo[2].z, xo[2].w};
+            const float hpv[4] = {hp.x, hp.y, hp.z, hp.w};
+            float rr[4], zz[4], nn[4], ho[4], o2[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                rr[i] = vag_sigmoid(cr[i] + xr[i]);
+                zz[i] = vag_sigmoid(cz[i] + xz[i]);
+                nn[i] = vag_tanh(xn[i] + rr[i] * cn[i]);
+                const float hn = (1.f - zz[i]) * nn[i] + zz[i] * hpv[i];
+                ho[i] = active ? hn : hpv[i];
+                o2[i] = active ? hn : 0.f;
+            }
+            hp = make_float4(ho[0], ho[1], ho[2], ho[3]);
+            const int64_t o = (int64_t)em * H + eu;
+            st_sc1_h4(hx + (int64_t)(k + 1) * BH + o, ho[0], ho[1], ho[2], ho[3]);       // read by the other workgroups
+            // publish before the saves below (nobody in this launch reads those): drain, one lane signs for the wave
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(cnt + k, 1u, RLX_AGENT);      // (lane 0 = first row of the tile: valid whenever any is)
+            *reinterpret_cast<float4*>(hs + (int64_t)(k + 1) * BH + o) = hp;                 // fp32 state: backward's h_prev
+            float* sv = a.gates + ((int64_t)(d * Ts + k) * 4) * BH + o;
+            *reinterpret_cast<float4*>(sv) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+            *reinterpret_cast<float4*>(sv + BH) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+            *reinterpret_cast<float4*>(sv + 2 * BH) = make_float4(nn[0], nn[1], nn[2], nn[3]);
+            *reinterpret_cast<float4*>(sv + 3 * BH) = c[2];
+            *reinterpret_cast<float4*>(a.enc + ((int64_t)em * Ts + t) * 2 * H + d * H + eu) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+        } else if (lane == 0) {
+            __hip_atomic_fetch_add(cnt + k, 1u, RLX_AGENT);                     // a tile wholly past the batch edge still signs
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Encoder backward recurrence (what autograd replays for nn.GRU, layers/Encoder.py:58), both directions, in ONE launch.
 // Same decomposition and hand-off as the forward kernel: a workgroup owns 16 hidden units x 16 batch rows; its 16 rows of
 // W_hh^T (K = 3H) stay in registers as bf16x3 planes (72 VGPRs at H = 512); per step it reads the row tile's 16 x 3H gate
@@ -1109,13 +1292,17 @@ int vag_persistent_time_read(int kind, double* ms_total, int* launches) {
     return VAG_OK;
 }
 
-bool vag_enc_persistent_ok(int64_t B, int64_t Ts, int64_t H) {
+static int persist_cu_count() {
     static int cus = -1;
     if (cus < 0) {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
         cus = n;
     }
+    return cus;
+}
+bool vag_enc_persistent_ok(int64_t B, int64_t Ts, int64_t H) {
+    const int cus = persist_cu_count();
     if (!(H == 256 || H == 512 || H == 1024) || B <= 0 || Ts <= 0) return false;
     const int64_t wgs = 2 * cdiv64(B, 16) * (H / 16);
     return wgs <= cus && (int64_t)(Ts + 1) * B * H * 4 < (1ll << 31);
@@ -1153,13 +1340,7 @@ static int64_t dec_persistent_lds_bytes(int64_t Ts) {
 }
 bool vag_dec_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H) {
     if (H != 512 || B <= 0 || B > 64 || Ts <= 0 || Tt <= 0 || Ts > 512) return false;
-    if (!vag_enc_persistent_ok(16, 1, 512)) return false;            // a GPU with >= 64 CUs is present (CU count query)
-    static int cus = -1;
-    if (cus < 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-        cus = n;
-    }
+    const int cus = persist_cu_count();
     return cdiv64(B, 16) * DEC_WGS <= cus && dec_persistent_lds_bytes(Ts) <= 160 * 1024;
 }
 int64_t vag_dec_persistent_sync_words(int64_t B, int64_t Tt) { return 4 * cdiv64(B, 16) * Tt * CNT_WORDS + 64; }
@@ -1196,6 +1377,47 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
     const bool timed = ptimer_begin(1, s);
     hipLaunchKernelGGL(dec_fwd_persistent_kernel, dim3((unsigned)(a.RT * DEC_WGS)), dim3(512), (size_t)lds, s, a);
     if (timed) ptimer_end(1, s);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+// Eligibility of the wide fp16 forward kernel: H a multiple of 128 with 4 or 8 k-steps per wave, every workgroup resident.
+bool vag_enc_wide16_ok(int64_t B, int64_t Ts, int64_t H) {
+    if (!(H == 512 || H == 1024) || B < 1 || Ts < 1) return false;
+    const int64_t wgs = 2 * cdiv64(B, 64) * (H / 32);
+    if (wgs > persist_cu_count()) return false;
+    return 2 * cdiv64(B, 64) * Ts + 64 <= vag_enc_persistent_sync_words(B, Ts);
+}
+int vag_enc_fwd_wide16_launch(const float* xp, const vag_half* w16_fw, const vag_half* w16_bw, const float* b_fw, const float* b_bw,
+                              const int* lengths, float* hst, float* gates, float* enc, vag_half* hx, unsigned* sync, int64_t B,
+                              int64_t Ts, int64_t H, hipStream_t s) {
+    VAG_CHECK_ARG(xp && w16_fw && w16_bw && b_fw && b_bw && lengths && hst && gates && enc && hx && sync &&
+                  vag_enc_wide16_ok(B, Ts, H));
+    VAG_CHECK_ARG(aligned16(xp) && aligned16(w16_fw) && aligned16(w16_bw) && aligned16(b_fw) && aligned16(b_bw) && aligned16(hst) &&
+                  aligned16(gates) && aligned16(enc) && aligned16(hx));
+    EncWArgs a;
+    a.xp = xp; a.W16[0] = w16_fw; a.W16[1] = w16_bw; a.bias[0] = b_fw; a.bias[1] = b_bw; a.lengths = lengths;
+    a.hst = hst; a.gates = gates; a.enc = enc; a.hx = hx;
+    a.B = (int)B; a.Ts = (int)Ts; a.H = (int)H; a.RG = (int)cdiv64(B, 64); a.CS = (int)(H / 32);
+    const int nwords = (int)vag_enc_persistent_sync_words(B, Ts);
+    a.cnt = sync; a.err = sync + (nwords - 64);
+    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
+    VAG_LAUNCH_CHECK();
+    const size_t lds = 96 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fwd_wide16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fwd_wide16_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return VAG_EINVAL;
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)(2 * a.RG * a.CS));
+    const bool timed = ptimer_begin(0, s);
+    if (H == 512) hipLaunchKernelGGL(enc_fwd_wide16_kernel<4>, grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL(enc_fwd_wide16_kernel<8>, grid, dim3(512), lds, s, a);
+    if (timed) ptimer_end(0, s);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
