@@ -698,7 +698,8 @@ def main():
                                         "dec_fwd_persistent_kernel_bytes_per_launch"),
             "roofline_enc_bwd": rec_row("enc_bwd", "enc_bwd_persistent_kernel (both directions x Ts backward steps; %s)" % shape,
                                         ab["Bk_enc"] * 2 * c["Ts"], c["Ts"], "enc_bwd_persistent_kernel_bytes_per_launch"),
-            "roofline_enc_fwd": rec_row("enc_fwd", "enc_fwd_persistent_kernel (both directions x Ts steps; %s)" % shape,
+            "roofline_enc_fwd": rec_row("enc_fwd", "%s (both directions x Ts steps; %s)"
+                                        % ("enc_fwd_wide16_kernel" if args.config == "cfg5" else "enc_fwd_persistent_kernel", shape),
                                         ab["F_enc"] * 2 * c["Ts"], c["Ts"], "enc_fwd_persistent_kernel_bytes_per_launch"),
         }
         for k_, v_ in rows.items():
