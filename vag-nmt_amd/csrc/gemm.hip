@@ -480,11 +480,11 @@ void vag_gemm_group_abort() {        // error path: drop the queues
 // Split-K and block order of one grouped launch.  The chip runs 512 of these blocks at a time (two per CU) and hands out
 // blocks in index order to whichever slot frees first, i.e. list scheduling: with the longest blocks first the launch ends
 // on short ones.  A common target slice length L (k-steps of SP_BK) is tried over the slice lengths the products can have;
-// accumulating products are cut into round(K / L) slices (never shorter than 256), the others stay whole.  Each candidate is
+// products are cut into round(K / L) slices (never shorter than 256; one that overwrites its output needs a fill launch first).  Each candidate is
 // priced by simulating that schedule (block cost = slice length + a fixed prologue / epilogue share) plus the extra atomic
 // traffic of the slices.  (The first version aimed at ~512 blocks with one common split: totals of 528 / 576 blocks -- the
 // decoder / encoder weight-gradient groups -- ran a full second round for 16 / 64 blocks: 204 and 108 us.)
-struct GroupPlanEntry { int n; int m[GROUP_MAX], nn[GROUP_MAX], k[GROUP_MAX]; bool acc[GROUP_MAX]; int split[GROUP_MAX], order[GROUP_MAX]; };
+struct GroupPlanEntry { int n; int m[GROUP_MAX], nn[GROUP_MAX], k[GROUP_MAX]; bool acc[GROUP_MAX], half[GROUP_MAX]; int split[GROUP_MAX], order[GROUP_MAX]; };
 static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order);
 // plans are remembered per list of shapes (a training run repeats a handful of them; the simulation costs ~1 ms of host time)
 static void group_plan(const GemmArgs* q, int n, int* split, int* order) {
@@ -495,7 +495,8 @@ static void group_plan(const GemmArgs* q, int n, int* split, int* order) {
         const GroupPlanEntry& c = cache[e];
         bool same = c.n == n;
         for (int i = 0; same && i < n; ++i)
-            same = c.m[i] == q[i].M && c.nn[i] == q[i].N && c.k[i] == q[i].K && c.acc[i] == (q[i].beta != 0.f);
+            same = c.m[i] == q[i].M && c.nn[i] == q[i].N && c.k[i] == q[i].K && c.acc[i] == (q[i].beta != 0.f) &&
+                   c.half[i] == (q[i].c_half != 0);
         if (same) {
             for (int i = 0; i < n; ++i) { split[i] = c.split[i]; order[i] = c.order[i]; }
             return;
@@ -507,7 +508,7 @@ static void group_plan(const GemmArgs* q, int n, int* split, int* order) {
     if (used < CACHE) ++used;
     c.n = n;
     for (int i = 0; i < n; ++i) {
-        c.m[i] = q[i].M; c.nn[i] = q[i].N; c.k[i] = q[i].K; c.acc[i] = q[i].beta != 0.f;
+        c.m[i] = q[i].M; c.nn[i] = q[i].N; c.k[i] = q[i].K; c.acc[i] = q[i].beta != 0.f; c.half[i] = q[i].c_half != 0;
         c.split[i] = split[i]; c.order[i] = order[i];
     }
 }
@@ -518,7 +519,7 @@ static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order)
     int cand[GROUP_MAX * 10 + 1], nc = 0;
     for (int i = 0; i < n; ++i) {
         const int ks = (int)cdiv64(q[i].K, SP_BK);
-        const int smax = q[i].beta != 0.f ? std::max(1, std::min(10, q[i].K / 256)) : 1;
+        const int smax = q[i].c_half ? 1 : std::max(1, std::min(10, q[i].K / 256));      // fp16 outputs are stored whole
         for (int j = 1; j <= smax; ++j) {
             const int L = (ks + j - 1) / j;
             bool seen = false;
@@ -534,13 +535,12 @@ static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order)
         double atomic_us = 0.0;
         for (int i = 0; i < n; ++i) {
             const int ks = (int)cdiv64(q[i].K, SP_BK);
-            int s_i = 1;
-            if (q[i].beta != 0.f) {
-                s_i = (ks + L / 2) / L;
-                const int smax = std::max(1, q[i].K / 256);
-                s_i = std::max(1, std::min(s_i, smax));
-                atomic_us += (double)s_i * (double)q[i].M * (double)q[i].N * 4.0 / 3.0e6;
-            }
+            int s_i = (ks + L / 2) / L;
+            const int smax = q[i].c_half ? 1 : std::max(1, q[i].K / 256);
+            s_i = std::max(1, std::min(s_i, smax));
+            const double out_bytes = (double)q[i].M * (double)q[i].N * 4.0;
+            if (q[i].beta != 0.f) atomic_us += (double)s_i * out_bytes / 3.0e6;
+            else if (s_i > 1) atomic_us += (double)s_i * out_bytes / 3.0e6 + 4.0 + out_bytes / 4.0e6;   // + a fill launch first
             sp[i] = s_i;
             len[i] = (ks + s_i - 1) / s_i;
             ord[i] = i;
@@ -594,7 +594,13 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
         a.kchunk = kchunk;
         // accumulating products always add atomically here (two of them may target the same gradient buffer);
         // splitk > 1 is what selects the atomic epilogue, the block count below uses the real number of k-slices
-        a.splitk = a.beta != 0.f ? (s_i > 2 ? s_i : 2) : 1;
+        a.splitk = a.beta != 0.f ? (s_i > 2 ? s_i : 2) : s_i;
+        if (a.beta == 0.f && s_i > 1) {          // sliced overwrite: the slices add into a zeroed output
+            int64_t nb = cdiv64((int64_t)a.M * a.N, 256 * 8);
+            if (nb > 2048) nb = 2048;
+            hipLaunchKernelGGL(fill2d_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a.C, a.ldc, (int64_t)a.M, (int64_t)a.N);
+            VAG_LAUNCH_CHECK();
+        }
         G.start[j] = total;
         total += (int)(cdiv64(a.M, 128) * cdiv64(a.N, 128)) * s_i;
     }
