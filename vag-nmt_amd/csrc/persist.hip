@@ -97,6 +97,22 @@ __device__ __forceinline__ void st_sc1_f4(float* p, float4 v) {
 __device__ __forceinline__ void st_sc1_f1(float* p, float v) {
     asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
 }
+// Row loads in a quad-contiguous lane mapping.  The MFMA wants lane (row fr = lane & 15, k-group fg = lane >> 4), but a wave
+// request in which the four lanes of every quad touch four different rows costs the address unit one line request per lane
+// (64 per instruction).  So lane l LOADS row ld_row(l), k-group l & 3 -- the quad reads four 16-byte pieces of ONE 128-byte
+// line, 16 line requests per instruction -- and every loaded dword is then moved to the MFMA's lane through ds_bpermute (no
+// LDS storage): the MFMA lane (fr, fg) takes what lane 16 (fr & 3) + 4 (fr >> 2) + fg loaded.  Same trick as the launch-chain
+// kernels' skinny_xpose (gemm.hip).
+__device__ __forceinline__ int ld_row(int lane) { return 4 * ((lane >> 2) & 3) + (lane >> 4); }
+__device__ __forceinline__ int ld_src4(int lane) { return 4 * (16 * (lane & 3) + 4 * ((lane & 15) >> 2) + (lane >> 4)); }
+__device__ __forceinline__ float4 perm4(float4 v, int src4) {
+    float4 o;
+    o.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(v.x)));
+    o.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(v.y)));
+    o.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(v.z)));
+    o.w = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(v.w)));
+    return o;
+}
 // 8 consecutive floats -> three bf16x8 planes
 __device__ __forceinline__ void split8(const float4 a, const float4 b, bf16x8 (&p)[3]) {
     unsigned q[3][4];
@@ -161,7 +177,8 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_persistent_kernel(EncPArgs a) 
     float* hs = a.hst + (int64_t)d * (Ts + 1) * BH;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hs, 0, (unsigned)((int64_t)(Ts + 1) * BH * 4), 0x00020000);
     gu32* cnt = (gu32*)(a.cnt + ((int64_t)d * a.RT + rt) * Ts);
-    const int arow = min(m0 + fr, B - 1);                  // batch row of this lane's B-operand fragment (clamped past the edge)
+    const int lrow = min(m0 + ld_row(lane), B - 1);        // the batch row this lane LOADS (quad-contiguous mapping, see ld_row)
+    const int src4 = ld_src4(lane);
     float4* red = reinterpret_cast<float4*>(lds);          // [wave][gate][lane]
     bool dead = false;                                      // a wait gave up: stop waiting (results are void, the grid drains)
 
@@ -186,11 +203,11 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_persistent_kernel(EncPArgs a) 
         // ---- h_k rows of this row tile (all H columns; this wave: its K share), sc1 loads, split, six-product MFMAs
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         float4 h0[KS], h1[KS];
-        ld_rows_sc1<KS>(hs + ((int64_t)k * B + arow) * H + kbase + 8 * fg, h0, h1);
+        ld_rows_sc1<KS>(hs + ((int64_t)k * B + lrow) * H + kbase + 8 * (lane & 3), h0, h1);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             bf16x8 hf[3];
-            split8(h0[s], h1[s], hf);
+            split8(perm4(h0[s], src4), perm4(h1[s], src4), hf);
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc[j] = mma6(wf[s][j], hf, acc[j]);
         }
@@ -342,6 +359,7 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_wide16_kernel(EncWArgs a) {
     gu32* cnt = (gu32*)(a.cnt + ((int64_t)d * a.RG + rg) * Ts);
     const unsigned target = (unsigned)a.CS * 8u;           // every wave of every workgroup of the row group signs a step
     float4* red = reinterpret_cast<float4*>(wide_lds);
+    const int wsrc4 = ld_src4(lane);
     bool dead = false;
 
     for (int k = 0; k < Ts; ++k) {
@@ -363,9 +381,16 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_wide16_kernel(EncWArgs a) {
             // ---- products: the four row tiles of the group against this wave's weight share
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = min(m0 + 16 * r + fr, B - 1);
+                const int row = min(m0 + 16 * r + ld_row(lane), B - 1);          // quad-contiguous load mapping (see ld_row)
                 u32x4 hq[KST];
-                ld16_sc1<KST>(hx + ((int64_t)k * B + row) * H + kbase + 8 * fg, hq);
+                ld16_sc1<KST>(hx + ((int64_t)k * B + row) * H + kbase + 8 * (lane & 3), hq);
+#pragma unroll
+                for (int s = 0; s < KST; ++s) {
+                    hq[s][0] = (unsigned)__builtin_amdgcn_ds_bpermute(wsrc4, (int)hq[s][0]);
+                    hq[s][1] = (unsigned)__builtin_amdgcn_ds_bpermute(wsrc4, (int)hq[s][1]);
+                    hq[s][2] = (unsigned)__builtin_amdgcn_ds_bpermute(wsrc4, (int)hq[s][2]);
+                    hq[s][3] = (unsigned)__builtin_amdgcn_ds_bpermute(wsrc4, (int)hq[s][3]);
+                }
                 f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                 for (int s = 0; s < KST; ++s) {
@@ -472,7 +497,8 @@ __global__ __launch_bounds__(512, 1) void enc_bwd_persistent_kernel(EncBArgs a) 
     float4 carry = make_float4(0.f, 0.f, 0.f, 0.f);           // z * dh of the later step, own units
     float* dghd = a.dgh + (int64_t)d * Ts * B * K;
     gu32* cnt = (gu32*)(a.cnt + ((int64_t)d * a.RT + rt) * Ts);
-    const int arow = min(m0 + fr, B - 1);
+    const int lrow = min(m0 + ld_row(lane), B - 1);         // the row this lane LOADS (quad-contiguous mapping)
+    const int src4 = ld_src4(lane);
     float4* red = reinterpret_cast<float4*>(lds);
     bool dead = false;
     const int64_t ld_add = (int64_t)Ts * 2 * H;
@@ -500,11 +526,11 @@ __global__ __launch_bounds__(512, 1) void enc_bwd_persistent_kernel(EncBArgs a) 
             __syncthreads();
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             float4 ga[KS], gb[KS];
-            ld_rows_sc1<KS>(dghd + ((int64_t)(k + 1) * B + arow) * K + kbase + 8 * fg, ga, gb);
+            ld_rows_sc1<KS>(dghd + ((int64_t)(k + 1) * B + lrow) * K + kbase + 8 * (lane & 3), ga, gb);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 bf16x8 hf[3];
-                split8(ga[s], gb[s], hf);
+                split8(perm4(ga[s], src4), perm4(gb[s], src4), hf);
                 acc = mma6(wf[s], hf, acc);
             }
             red[wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -674,6 +700,8 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
     if (ep) *reinterpret_cast<float4*>(hs_s + 128 + fr * 8 + 4 * hq) = eok ? *reinterpret_cast<const float4*>(a.h0 + (int64_t)em * H + eu)
                                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
     const int arow = min(m0 + fr, B - 1);
+    const int lrow = min(m0 + ld_row(lane), B - 1);        // the batch row this lane LOADS (quad-contiguous mapping, see ld_row)
+    const int src4 = ld_src4(lane);
     gu32* c1 = (gu32*)(a.cnt + ((int64_t)0 * a.RT + rt) * Tt * CNT_WORDS);       // h2[t] published (waited on by step t + 1)
     gu32* c2 = (gu32*)(a.cnt + ((int64_t)1 * a.RT + rt) * Tt * CNT_WORDS);       // h1
     gu32* c4 = (gu32*)(a.cnt + ((int64_t)3 * a.RT + rt) * Tt * CNT_WORDS);       // scores
@@ -694,7 +722,9 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
         } else {
             wait_count(c1 + (t - 1) * CNT_WORDS, PER_SHARD, a.err, dead);
             VAG_STAMP(1);
-            ld_rows_sc1<KS>(a.h2_all + ((int64_t)(t - 1) * B + arow) * H + kbase + 8 * fg, ha, hb);
+            ld_rows_sc1<KS>(a.h2_all + ((int64_t)(t - 1) * B + lrow) * H + kbase + 8 * (lane & 3), ha, hb);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { ha[s] = perm4(ha[s], src4); hb[s] = perm4(hb[s], src4); }
         }
         {
             f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -762,7 +792,9 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
         VAG_STAMP(2);
         wait_count(c2 + t * CNT_WORDS, PER_SHARD, a.err, dead);
         VAG_STAMP(3);
-        ld_rows_sc1<KS>(a.h1 + ((int64_t)t * B + arow) * H + kbase + 8 * fg, ha, hb);
+        ld_rows_sc1<KS>(a.h1 + ((int64_t)t * B + lrow) * H + kbase + 8 * (lane & 3), ha, hb);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { ha[s] = perm4(ha[s], src4); hb[s] = perm4(hb[s], src4); }
         bf16x8 hf2[KS][3];
         {
             // the query first: its score shares (fp32 atomics) are in flight while the hidden-side products follow
@@ -1005,7 +1037,8 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
         *reinterpret_cast<float4*>(wb_s + u * WBLD + 4 * c4) = *reinterpret_cast<const float4*>(a.wcatT + (int64_t)(u0 + u) * Q + 4 * c4);
     }
     const float* wb_row = wb_s + (fr & 7) * WBLD + wave * (C >> 3) + 8 * fg;
-    const float* wa_row = a.wcatT + (int64_t)(u0 + (fr & 7)) * Q + C + wave * (3 * H >> 3) + 8 * fg;      // W_hh2^T, streamed per step
+    // W_hh2^T, streamed per step (L2 hits): loaded in the quad-contiguous lane mapping too and permuted into place
+    const float* wa_row = a.wcatT + (int64_t)(u0 + (ld_row(lane) & 7)) * Q + C + wave * (3 * H >> 3) + 8 * (lane & 3);
     // ---- keys -> LDS
     for (int x = threadIdx.x; x < NP * 4; x += 512) {
         const int P = x >> 2, c4 = x & 3;
@@ -1022,7 +1055,8 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
     const int hq = (threadIdx.x >> 4) & 1;
     const int em = m0 + fr, eu = u0 + 4 * hq;
     const bool ep = threadIdx.x < 32, eok = ep && em < B;
-    const int arow = min(m0 + fr, B - 1);
+    const int lrow = min(m0 + ld_row(lane), B - 1);        // the batch row this lane LOADS (quad-contiguous mapping, see ld_row)
+    const int src4 = ld_src4(lane);
     gu32* cA = (gu32*)(a.cnt + ((int64_t)0 * a.RT + rt) * Tt * CNT_WORDS);
     gu32* cB = (gu32*)(a.cnt + ((int64_t)1 * a.RT + rt) * Tt * CNT_WORDS);
     gu32* cC = (gu32*)(a.cnt + ((int64_t)2 * a.RT + rt) * Tt * CNT_WORDS);
@@ -1148,11 +1182,14 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
         {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             float4 ga[KC], gb[KC];
-            ld_rows_sc1<KC>(a.dqgh + ((int64_t)t * B + arow) * Q + C + wave * (3 * H >> 3) + 8 * fg, ga, gb);
+            ld_rows_sc1<KC>(a.dqgh + ((int64_t)t * B + lrow) * Q + C + wave * (3 * H >> 3) + 8 * (lane & 3), ga, gb);
+#pragma unroll
+            for (int s = 0; s < KC; ++s) { ga[s] = perm4(ga[s], src4); gb[s] = perm4(gb[s], src4); }
 #pragma unroll
             for (int s = 0; s < KC; ++s) {
                 bf16x8 wf[3], hf[3];
-                split8(*reinterpret_cast<const float4*>(wa_row + 32 * s), *reinterpret_cast<const float4*>(wa_row + 32 * s + 4), wf);
+                split8(perm4(*reinterpret_cast<const float4*>(wa_row + 32 * s), src4),
+                       perm4(*reinterpret_cast<const float4*>(wa_row + 32 * s + 4), src4), wf);
                 split8(ga[s], gb[s], hf);
                 acc = mma6(wf, hf, acc);
             }
@@ -1179,7 +1216,9 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
         {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             float4 ga[KB], gb[KB];
-            ld_rows_sc1<KB>(a.dqgh + ((int64_t)t * B + arow) * Q + wave * (C >> 3) + 8 * fg, ga, gb);
+            ld_rows_sc1<KB>(a.dqgh + ((int64_t)t * B + lrow) * Q + wave * (C >> 3) + 8 * (lane & 3), ga, gb);
+#pragma unroll
+            for (int s = 0; s < KB; ++s) { ga[s] = perm4(ga[s], src4); gb[s] = perm4(gb[s], src4); }
 #pragma unroll
             for (int s = 0; s < KB; ++s) {
                 bf16x8 wf[3], hf[3];
@@ -1226,7 +1265,9 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
         {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             float4 ga[KC], gb[KC];
-            ld_rows_sc1<KC>(a.dgh1 + ((int64_t)t * B + arow) * 3 * H + wave * (3 * H >> 3) + 8 * fg, ga, gb);
+            ld_rows_sc1<KC>(a.dgh1 + ((int64_t)t * B + lrow) * 3 * H + wave * (3 * H >> 3) + 8 * (lane & 3), ga, gb);
+#pragma unroll
+            for (int s = 0; s < KC; ++s) { ga[s] = perm4(ga[s], src4); gb[s] = perm4(gb[s], src4); }
 #pragma unroll
             for (int s = 0; s < KC; ++s) {
                 bf16x8 hf[3];
