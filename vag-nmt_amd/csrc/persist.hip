@@ -162,8 +162,12 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_persistent_kernel(EncPArgs a) 
                 split8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4), wf[s][j]);
             }
     }
-    // ---- epilogue threads (wave 0): lane = (batch row fr, unit quad fg): units u0 + 4 fg .. + 3 of row m0 + fr
-    const int em = m0 + fr, eu = u0 + 4 * fg;
+    // ---- epilogue threads (wave 0): lane = (batch row lane >> 2, unit quad lane & 3): units eu .. eu + 3 of row em.  A quad
+    // then loads / stores four consecutive 16-byte pieces of ONE row (the accumulator layout -- row lane & 15, quad lane >> 4 --
+    // would put four rows into every quad: four line requests per quad in each of the ~10 loads and stores of a step); the
+    // reduction reads the other lane's LDS slot instead
+    const int erow = lane >> 2, equad = lane & 3, eslot = erow + 16 * equad;
+    const int em = m0 + erow, eu = u0 + 4 * equad;
     const bool eok = wave == 0 && em < B;
     float4 bb[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
     int len = 0;
@@ -219,10 +223,10 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_persistent_kernel(EncPArgs a) 
             float4 c[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                float4 sum = red[j * 64 + lane];
+                float4 sum = red[j * 64 + eslot];
 #pragma unroll
                 for (int w = 1; w < 8; ++w) {
-                    const float4 o = red[(w * 3 + j) * 64 + lane];
+                    const float4 o = red[(w * 3 + j) * 64 + eslot];
                     sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
                 }
                 c[j] = make_float4(sum.x + bb[j].x, sum.y + bb[j].y, sum.z + bb[j].z, sum.w + bb[j].w);
@@ -491,7 +495,9 @@ __global__ __launch_bounds__(512, 1) void enc_bwd_persistent_kernel(EncBArgs a) 
 #pragma unroll
         for (int s = 0; s < KS; ++s) split8(*reinterpret_cast<const float4*>(WT + 32 * s), *reinterpret_cast<const float4*>(WT + 32 * s + 4), wf[s]);
     }
-    const int em = m0 + fr, eu = u0 + 4 * fg;
+    // epilogue lane = (batch row lane >> 2, unit quad lane & 3): a quad touches ONE row (see the forward kernel)
+    const int erow = lane >> 2, equad = lane & 3, eslot = erow + 16 * equad;
+    const int em = m0 + erow, eu = u0 + 4 * equad;
     const bool eok = wave == 0 && em < B;
     const int len = eok ? a.lengths[em] : 0;
     float4 carry = make_float4(0.f, 0.f, 0.f, 0.f);           // z * dh of the later step, own units
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(512, 1) void enc_bwd_persistent_kernel(EncBArgs a) 
             if (wave == 0) {
 #pragma unroll
                 for (int w = 0; w < 8; ++w) {
-                    const float4 o = red[w * 64 + lane];
+                    const float4 o = red[w * 64 + eslot];
                     dh.x += o.x; dh.y += o.y; dh.z += o.z; dh.w += o.w;
                 }
             }
