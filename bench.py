@@ -518,6 +518,10 @@ def main():
     for kv in args.opt:
         name, val = kv.split("=", 1)
         _L.set_option(name, int(val))
+    if smoke_dp:
+        # several ranks share ONE GPU here: the persistent recurrence kernels need every workgroup of their grid resident
+        # (one per CU), which two processes cannot both have -- their bounded waits would give up.  Launch chains instead.
+        _L.set_option("persistent", 0)
     c = CFG2 if args.config == "cfg2" else CFG5
     random.seed(1234)      # same teacher-forcing coin on every rank
     model = build_model(c, dev, dropout=not args.no_dropout)
