@@ -750,6 +750,7 @@ struct SkinnyArgs {
     // A rows taken through an index (A = embedding table, row m = A[row_idx[m]]); the column-tile-0 workgroups also write
     // the gathered rows out (the embedded inputs are needed again by the head and by the backward pass)
     const int64_t* row_idx = nullptr; float* gather_out = nullptr; int64_t ld_gather = 0;
+    float a_scale = 1.f;                   // fp16-weight products only: power of two applied to A before its fp16 rounding (gradients)
 };
 
 // Load pattern.  The MFMA wants lane l to hold row l&15, k-group l>>4, but a wave request whose lane QUADS each touch
@@ -836,24 +837,28 @@ __device__ __forceinline__ void skinny_mma(const float* const (&ap)[MT], const f
 // The same product with the W operand stored as fp16 (the 2-byte storage mode: weights the recurrences re-read at every
 // time step).  Chunks are 32 of K: lane (row r, segment g) loads 8 consecutive halves of W (one 16-byte request: quads
 // still read 64 contiguous bytes) and the matching 8 floats of A as two float4 (k = 8g..8g+3, 8g+4..8g+7); both go through
-// the same lane permutation and feed eight K=4 MFMAs in the same k order, so products are exact fp32 x fp16->fp32.
-// ap/wp are already offset by 8*skinny_ldseg(lane) elements.  K % 8 == 0.
+// the same lane permutation, which leaves MFMA lane (row, k-group G) with k = 8G..8G+7 of its row -- exactly the operand
+// layout of v_mfma_f32_16x16x32_f16.  Round 3: ONE fp16 MFMA per chunk (A rounded to fp16 in registers, fp32 accumulation)
+// instead of eight v_mfma_f32_16x16x4_f32 on fp32 A x converted W: at configs[4] (M = 256, K = 1024..3072) the per-step
+// kernels were bound by the f32 matrix pipe (1.6 GFLOP in 15-26 us = 60-110 TF/s of its 157), and the fp16 pipe runs the
+// same chunk in 1/16 of the cycles.  a_scale (a power of two): gradients are small -- backward kernels pass 2^12 so that
+// entries down to 1.5e-8 stay normal fp16 numbers and up to 16 stay finite; the sum is scaled back in fp32.  ap/wp are
+// already offset by 8*skinny_ldseg(lane) elements.  K % 8 == 0.
+typedef _Float16 sk_f16x8 __attribute__((ext_vector_type(8)));
 template <int WAVES, int MT, int NT, int U = 2>
-__device__ __forceinline__ void skinny_mma_h16(const float* const (&ap)[MT], const vag_half* const (&wp)[NT], int K, float* red) {
+__device__ __forceinline__ void skinny_mma_h16(const float* const (&ap)[MT], const vag_half* const (&wp)[NT], int K, float* red,
+                                               float a_scale) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = skinny_ldseg(lane);
     const int src4 = 4 * (16 * (lane & 3) + (lane & 12) + (lane >> 4));
     const int kper = ((K + WAVES - 1) / WAVES + 31) & ~31;
     const int kbeg = wave * kper;
     const int kend = min(K, kbeg + kper);
-    f32x4 acc[MT][NT][2];
+    f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            acc[i][j][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            acc[i][j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int c0 = kbeg; c0 < kend; c0 += 32 * U) {
         float4 a0[MT][U], a1[MT][U];
         uint4 wq[NT][U];
@@ -872,8 +877,14 @@ __device__ __forceinline__ void skinny_mma_h16(const float* const (&ap)[MT], con
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            sk_f16x8 af[MT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) { a0[i][u] = skinny_xpose(a0[i][u], src4); a1[i][u] = skinny_xpose(a1[i][u], src4); }
+            for (int i = 0; i < MT; ++i) {
+                const float4 x = skinny_xpose(a0[i][u], src4), y = skinny_xpose(a1[i][u], src4);
+                const u32x4 q = {pack_f16(x.x * a_scale, x.y * a_scale), pack_f16(x.z * a_scale, x.w * a_scale),
+                                 pack_f16(y.x * a_scale, y.y * a_scale), pack_f16(y.z * a_scale, y.w * a_scale)};
+                af[i] = __builtin_bit_cast(sk_f16x8, q);
+            }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 uint4 q = wq[j][u];
@@ -881,31 +892,19 @@ __device__ __forceinline__ void skinny_mma_h16(const float* const (&ap)[MT], con
                 q.y = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)q.y);
                 q.z = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)q.z);
                 q.w = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)q.w);
-                wq[j][u] = q;
+                const u32x4 t = {q.x, q.y, q.z, q.w};
+                const sk_f16x8 wf = __builtin_bit_cast(sk_f16x8, t);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], wf, acc[i][j], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const uint4 q = wq[j][u];
-                    acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][u].x, h16_lo(q.x), acc[i][j][0], 0, 0, 0);
-                    acc[i][j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][u].y, h16_hi(q.x), acc[i][j][1], 0, 0, 0);
-                    acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][u].z, h16_lo(q.y), acc[i][j][0], 0, 0, 0);
-                    acc[i][j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][u].w, h16_hi(q.y), acc[i][j][1], 0, 0, 0);
-                    acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][u].x, h16_lo(q.z), acc[i][j][0], 0, 0, 0);
-                    acc[i][j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][u].y, h16_hi(q.z), acc[i][j][1], 0, 0, 0);
-                    acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][u].z, h16_lo(q.w), acc[i][j][0], 0, 0, 0);
-                    acc[i][j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][u].w, h16_hi(q.w), acc[i][j][1], 0, 0, 0);
-                }
     }
+    const float inv = 1.f / a_scale;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            f32x4 s = acc[i][j][0] + acc[i][j][1];
+            const f32x4 s = acc[i][j] * inv;
             *reinterpret_cast<f32x4*>(&red[((wave * (MT * NT) + i * NT + j) * 64 + lane) * 4]) = s;
         }
     __syncthreads();
@@ -913,12 +912,13 @@ __device__ __forceinline__ void skinny_mma_h16(const float* const (&ap)[MT], con
 // Dispatch on the W storage type.  koff = this lane's element offset inside a chunk (4g for fp32 W, 8g for fp16 W).
 template <bool WH> __device__ __forceinline__ int skinny_koff(int g) { return WH ? 8 * g : 4 * g; }
 template <int WAVES, int MT, int NT, int U, bool WH>
-__device__ __forceinline__ void skinny_mma_any(const float* const (&ap)[MT], const float* const (&wp)[NT], int K, float* red) {
+__device__ __forceinline__ void skinny_mma_any(const float* const (&ap)[MT], const float* const (&wp)[NT], int K, float* red,
+                                               float a_scale = 1.f) {
     if constexpr (WH) {
         const vag_half* wh[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) wh[j] = reinterpret_cast<const vag_half*>(wp[j]);
-        skinny_mma_h16<WAVES, MT, NT, (U + 1) / 2>(ap, wh, K, red);
+        skinny_mma_h16<WAVES, MT, NT, (U + 1) / 2>(ap, wh, K, red, a_scale);
     } else {
         skinny_mma<WAVES, MT, NT, U>(ap, wp, K, red);
     }
@@ -977,7 +977,7 @@ __device__ __forceinline__ void skinny_plain_body(const SkinnyArgs& a, float* re
                     reinterpret_cast<const float4*>(a.A + a.row_idx[m0 + row] * a.lda)[c4];
         }
     }
-    skinny_mma_any<WAVES, 1, 1, U, WH>(ap, wp, a.K, red);
+    skinny_mma_any<WAVES, 1, 1, U, WH>(ap, wp, a.K, red, a.a_scale);
     if (!eok) return;
     float v = skinny_sum1<WAVES, 1>(red, 0, erow, ecol) + pre;
     if (a.act == VAG_ACT_TANH) v = vag_tanh(v);
@@ -1148,6 +1148,7 @@ int vag_attn_dot_side_launch(int mode, const float* x, const float* q, int64_t l
     SkinnyArgs a;
     a.A = A; a.W = Wt; a.lda = lda; a.ldw = ldw; a.M = (int)M; a.N = (int)Np; a.K = (int)K;
     a.bias = pbias; a.addend = padd; a.ldadd = Np; a.out = P; a.ldo = ldp; a.act = VAG_ACT_NONE;
+    a.a_scale = mode == 1 ? 4096.f : 1.f;           // backward: the riding product's A operand is a gate gradient
     const int tiles_x = (int)cdiv64(Np, 16), tiles_y = (int)cdiv64(M, 16);
     const dim3 grid((unsigned)(d.nscore + tiles_x * tiles_y));
     if (s16) {
@@ -1382,7 +1383,7 @@ __global__ __launch_bounds__(WAVES * 64) void gru_bwd_step_kernel(GruBwdStepArgs
     for (int i = 0; i < MT; ++i) ap[i] = sd.A + (int64_t)min(m0 + 16 * i + r, a.M - 1) * a.lda + skinny_koff<WH>(g);
 #pragma unroll
     for (int j = 0; j < NT; ++j) wp[j] = skinny_wptr<WH>(sd.WT, min(nb + 16 * j + r, H - 1), a.ldw, skinny_koff<WH>(g));
-    skinny_mma_any<WAVES, MT, NT, U, WH>(ap, wp, a.K, red);
+    skinny_mma_any<WAVES, MT, NT, U, WH>(ap, wp, a.K, red, 4096.f);       // A = gate gradients: scaled into fp16's range
 #pragma unroll
     for (int q = 0; q < OUTS; ++q) {
         if (!eok[q]) continue;
