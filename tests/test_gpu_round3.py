@@ -131,3 +131,27 @@ def test_wide_fp16_encoder_kernel_equals_the_launch_chain():
     assert (e0 - e1).abs().max().item() > 0.0           # the kernel really ran (fp16-rounded exchange differs in the last bits)
     assert np.allclose(l0, l1, rtol=1e-3, atol=1e-4), (l0, l1)
     assert (g0 - g1).abs().max().item() <= 1e-2 * g0.abs().max().item()
+
+
+@pytest.mark.parametrize("V", [10243, 40000])
+def test_one_pass_log_softmax_for_large_vocabularies(V):
+    """lse_nll_kernel<0> (vocabularies above 10240 words: one pass of 16-byte loads with a running (max, sum) pair per
+    thread) through the decode step's head (layers/NMT_Decoder.py:137-143): log-probabilities and arg-max against torch,
+    incl. a vocabulary that is not a multiple of 4 and a row whose maximum sits in the last, partial group."""
+    from vagnmt_hip import ops
+    torch.manual_seed(V)
+    N, E, H = 5, 64, 32
+    dev = "cuda"
+    h2, c, e = torch.randn(N, H, device=dev), torch.randn(N, 2 * H, device=dev), torch.randn(N, E, device=dev)
+    w1, w2, w3 = torch.randn(E, H, device=dev) * 0.2, torch.randn(E, 2 * H, device=dev) * 0.2, torch.randn(E, E, device=dev) * 0.2
+    b1, b2, b3 = torch.randn(E, device=dev) * 0.1, torch.randn(E, device=dev) * 0.1, torch.randn(E, device=dev) * 0.1
+    ow, ob = torch.randn(V, E, device=dev) * 0.3, torch.randn(V, device=dev) * 0.1
+    ob[V - 1] += 50.0 if V % 4 else 0.0            # a clear maximum in the partial last group of four
+    head = (w1, b1, w2, b2, w3, b3, ow, ob)
+    logp, am = ops.head_logp_step(h2, c, e, head, want_argmax=True)
+    t = torch.tanh(h2 @ w1.t() + b1 + c @ w2.t() + b2 + e @ w3.t() + b3)
+    ref = torch.log_softmax((t.double() @ ow.double().t() + ob.double()), dim=-1)
+    got = logp[:, :V].double()
+    assert (got - ref).abs().max().item() <= 2e-4, (got - ref).abs().max().item()
+    assert torch.equal(am.cpu(), ref.argmax(-1).cpu())
+    assert abs(float(torch.logsumexp(got, -1).abs().max())) <= 1e-4          # rows are normalised

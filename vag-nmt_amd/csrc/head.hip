@@ -46,23 +46,51 @@ __global__ __launch_bounds__(256) void lse_nll_kernel(const float* __restrict__ 
     }
     float mx = -INFINITY;
     int mi = 0x7fffffff;
+    float sum = 0.f;
+    float bm;
     if (NV > 0) {
 #pragma unroll
         for (int i = 0; i < NV; ++i)
             if (c[i] > mx) { mx = c[i]; mi = threadIdx.x + 256 * i; }      // strict >: first occurrence within a thread
-    } else {
-        for (int j = threadIdx.x; j < V; j += 256) {
-            const float v = x[j];
-            if (v > mx) { mx = v; mi = j; }
-        }
-    }
-    const float bm = block_reduce_max(mx, sh);
-    float sum = 0.f;
-    if (NV > 0) {
+        bm = block_reduce_max(mx, sh);
 #pragma unroll
         for (int i = 0; i < NV; ++i) sum += __expf(c[i] - bm);             // exp(-inf) = 0 past V
     } else {
-        for (int j = threadIdx.x; j < V; j += 256) sum += __expf(x[j] - bm);
+        // ONE pass over the row (round 3; before: a max pass and a sum pass of 4-byte loads, the second out of L2: 1.7 TB/s
+        // at V = 40000): 16-byte loads, four in flight per thread, a running (max, sum of exp) pair rescaled once per group
+        // of 16 values; the threads' pairs are merged after the block-wide max.  Row bases and ldl are 16-byte aligned.
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        const int n4 = (V + 3) >> 2;
+        for (int i0 = threadIdx.x; i0 < n4; i0 += 1024) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i4 = i0 + 256 * u;
+                v[u] = i4 < n4 ? x4[i4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            }
+            float e[16];
+            float gm = mx;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = 4 * (i0 + 256 * u);
+                e[4 * u + 0] = j + 0 < V ? v[u].x : -INFINITY;
+                e[4 * u + 1] = j + 1 < V ? v[u].y : -INFINITY;
+                e[4 * u + 2] = j + 2 < V ? v[u].z : -INFINITY;
+                e[4 * u + 3] = j + 3 < V ? v[u].w : -INFINITY;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (e[4 * u + q] > gm) { gm = e[4 * u + q]; mi = j + q; }          // ascending j within a thread: first occurrence
+            }
+            if (gm > -INFINITY) {
+                float part = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) part += __expf(e[q] - gm);                 // exp(-inf) = 0 past V
+                sum = (mx > -INFINITY ? sum * __expf(mx - gm) : 0.f) + part;
+                mx = gm;
+            }
+        }
+        bm = block_reduce_max(mx, sh);
+        sum = mx > -INFINITY ? sum * __expf(mx - bm) : 0.f;
     }
     sum = block_reduce_sum(sum, sh);
     const float l = bm + __logf(sum);
