@@ -235,6 +235,8 @@ int vag_meanpool_mix_launch(const float* enc, const float* mask, const float* ct
 __global__ __launch_bounds__(256) void meanpool_bwd_kernel(const float* __restrict__ mask, const float* __restrict__ dx,
                                                            float coef, int Ts, int C, float* __restrict__ d_enc,
                                                            int acc) {
+    // blockIdx.z = a chunk of 4 positions, all of a thread's read-modify-writes in flight together (round 3: one thread walked
+    // all Ts positions of its column one after the other: 15 us for 21 MB)
     const int b = blockIdx.y;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
@@ -242,12 +244,21 @@ __global__ __launch_bounds__(256) void meanpool_bwd_kernel(const float* __restri
     for (int t = 0; t < Ts; ++t) cnt += mask[(int64_t)b * Ts + t];
     const float v = coef * dx[(int64_t)b * C + c] / cnt;
     float* d = d_enc + (int64_t)b * Ts * C + c;
-    for (int t = 0; t < Ts; ++t) d[(int64_t)t * C] = acc ? d[(int64_t)t * C] + v : v;
+    const int t0 = blockIdx.z * 4;
+    float old[4] = {0.f, 0.f, 0.f, 0.f};
+    if (acc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (t0 + i < Ts) old[i] = d[(int64_t)(t0 + i) * C];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (t0 + i < Ts) d[(int64_t)(t0 + i) * C] = old[i] + v;
 }
 int vag_meanpool_bwd_launch(const float* mask, const float* dx, float coef, int64_t B, int64_t Ts, int64_t C,
                             float* d_enc, int accumulate, hipStream_t s) {
     VAG_CHECK_ARG(mask && dx && d_enc && B > 0 && Ts > 0 && C > 0);
-    dim3 grid((unsigned)cdiv64(C, 256), (unsigned)B);
+    dim3 grid((unsigned)cdiv64(C, 256), (unsigned)B, (unsigned)cdiv64(Ts, 4));
     hipLaunchKernelGGL(meanpool_bwd_kernel, grid, dim3(256), 0, s, mask, dx, coef, (int)Ts, (int)C, d_enc, accumulate);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
