@@ -610,6 +610,10 @@ def main():
                 except OSError:
                     pass
             dp_info["rccl_log_excerpt"] = lines[:16]
+    # in-step durations of the recurrence kernels (every rank runs the same extra steps: they contain the collectives)
+    rec_all = {}
+    if not args.no_fused and not args.no_operators and not smoke_dp:
+        rec_all = measure_recurrences(ts, (src, lens_t, tgt, im))
     if rank == 0:
         # configs[4] prices every streamed element at 2 bytes (F_dec = 199.3 MB)
         ab = algorithmic_bytes(c, w=2 if args.config == "cfg5" else 4)
@@ -681,7 +685,7 @@ def main():
         # traffic is far BELOW the algorithmic bytes.  One row per recurrence family beside it ("reported per
         # kernel family"), all from in-step HIP-event durations; where the kernels do not apply (configs[4]) the backward
         # cell kernel of the launch chain.
-        rec = measure_recurrences(ts, (src, lens_t, tgt, im)) if (world == 1 and not args.no_fused) else {}
+        rec = rec_all
         log("recurrence kernels in step: %s" % rec)
 
         def rec_row(key, kernel, bytes_per_launch, steps, pmc_key):
