@@ -117,7 +117,6 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
                     const float* bias, int act, hipStream_t stream, int c_half = 0);   // c_half: C stored as fp16 (beta = 0)
 // out[m,n] = act(sum_k A[m,k] W[n,k] + bias[n] + addend[m,n]);  M small (decode/recurrent steps).
 void vag_gemm_set_planes(int planes);
-int vag_gemm_get_planes();
 int vag_gemm_launch_planes(int planes, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
                            const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc, hipStream_t stream);      // 3: bf16x6 (default), 2: bf16x3 (2-byte storage mode), calling thread
 int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,

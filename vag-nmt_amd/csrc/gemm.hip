@@ -400,7 +400,6 @@ __global__ __launch_bounds__(512, 4) void gemm_split_group_kernel(GemmGroupArgs 
 // products in the step driver), 1: one bf16 plane (that mode's gradient products: fp16 would flush small gradients).
 static thread_local int g_gemm_planes = 3;
 void vag_gemm_set_planes(int planes) { g_gemm_planes = (planes == 2 || planes == 1 || planes == 11) ? planes : 3; }
-int vag_gemm_get_planes() { return g_gemm_planes; }
 
 static int gemm_split_dispatch(const GemmArgs& g, bool akc, bool bkc, bool vec, dim3 grid, hipStream_t s) {
 #define VAG_SPLIT_CASE(AK, BKc, V)                                                                    \
