@@ -155,3 +155,44 @@ def test_one_pass_log_softmax_for_large_vocabularies(V):
     assert (got - ref).abs().max().item() <= 2e-4, (got - ref).abs().max().item()
     assert torch.equal(am.cpu(), ref.argmax(-1).cpu())
     assert abs(float(torch.logsumexp(got, -1).abs().max())) <= 1e-4          # rows are normalised
+
+
+def test_recurrence_event_timing_reports_every_persistent_launch():
+    """vag_set_option("persist_timing") + vag_recurrence_time (include/vag_nmt.h): an eager optimiser step at the benched
+    shape records one launch of each of the four recurrence kernels with a plausible duration, a graph replay records
+    nothing (events cannot be read out of a replay), and reading resets the counters."""
+    import ctypes as C
+    import bench
+    from vagnmt_hip import _lib as L
+    from vagnmt_hip.trainer import TrainStep
+    from machine_translation_vision.losses import PairwiseRankingLoss
+    c = bench.CFG2
+    dev = torch.device("cuda:0")
+    m = bench.build_model(c, dev)
+    vw = torch.ones(c["V"], device=dev)
+    vw[0] = 0
+    ts = TrainStep(m, torch.nn.NLLLoss(weight=vw, reduction="none"), PairwiseRankingLoss(margin=0.1), use_graph=False)
+    src, lens, tgt, im = bench.make_batch(c, 0, dev)
+    lt = torch.tensor(lens, dtype=torch.int32, device=dev)
+
+    def read(kind):
+        ms, n = C.c_double(0.0), C.c_int(0)
+        L.call("vag_recurrence_time", kind, C.byref(ms), C.byref(n))
+        return ms.value, n.value
+    L.set_option("persist_timing", 1)
+    try:
+        for k in range(4):
+            read(k)
+        ts.step(src, lt, tgt, im, teacher=True)
+        torch.cuda.synchronize()
+        got = [read(k) for k in range(4)]
+        for ms, n in got:
+            assert n == 1 and 0.05 < ms < 5.0, got          # 0.13 .. 0.9 ms on an MI355X
+        assert got[3][0] > got[0][0]                           # the decoder backward is the longest, the encoder forward the shortest
+        assert all(read(k) == (0.0, 0) for k in range(4))      # reading resets
+    finally:
+        L.set_option("persist_timing", 0)
+    ts.step(src, lt, tgt, im, teacher=True)
+    torch.cuda.synchronize()
+    assert all(read(k)[1] == 0 for k in range(4))              # switched off: nothing is recorded
+    ts.check()
