@@ -366,8 +366,11 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
 // products: no change on hot operands (4096^3 NT 705 -> 710 us); grouped launches: SLOWER in the step (weight-gradient group
 // 150 -> 174 us, logits/keys group 67 -> 86 us) because an XCD then works through one product's blocks and the products'
 // K differ by 10x -- the round-robin dealing of blocks over the XCDs is what balances a group.)
+// Waves per SIMD asked of the compiler: 4 (two 8-wave blocks per CU: <= 128 VGPRs -- without the bound the forward group kernel
+// took 134 and two single-product layouts 130, i.e. ONE block per CU), 6 for the one-plane kernels of the 2-byte mode (20 KB of
+// LDS: three blocks per CU at <= 80 VGPRs, a few spills; configs[4] 33.3 -> 32.8 ms; 8 spills everything: 122 ms).
 template <bool AKC, bool BKC, bool VEC, int PL = 3, bool F16 = false>
-__global__ __launch_bounds__(512, 4) void gemm_split_kernel(GemmArgs a) {
+__global__ __launch_bounds__(512, PL == 1 ? 6 : 4) void gemm_split_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) __bf16 smem[2 * PL * SP_PLANE];      // 60 / 40 / 20 KB
     gemm_split_body<AKC, BKC, VEC, PL, F16>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(512, 4) void gemm_split_kernel(GemmArgs a) {
 // with K = Tt*B: launched one by one they need split-K by 5-10 (atomics) to fill the chip and still pay a ramp and a
 // partial last wave each; together they fill it with split-K 1-2.
 template <bool AKC, bool BKC, int PL = 3, bool F16 = false>
-__global__ __launch_bounds__(512, 4) void gemm_split_group_kernel(GemmGroupArgs G) {
+__global__ __launch_bounds__(512, PL == 1 ? 6 : 4) void gemm_split_group_kernel(GemmGroupArgs G) {
     __shared__ __attribute__((aligned(16))) __bf16 smem[2 * PL * SP_PLANE];
     int p = 0;
     while (p + 1 < G.n && (int)blockIdx.x >= G.start[p + 1]) ++p;
