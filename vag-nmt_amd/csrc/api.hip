@@ -221,9 +221,9 @@ int vag_bigru_seq_fwd(const int64_t* src, const int32_t* lengths, const float* e
     VAG_CHECK_ARG(!g_store16 || (g_derived && H % 8 == 0));
     if (!s16 && vag_opt().persistent && vag_enc_persistent_ok(B, Ts, H)) {
         // the whole recurrence, both directions, in ONE launch (persist.hip): W_hh stays in registers for all Ts steps
-        VAG_TRY(vag_enc_fwd_persistent_launch(w.xp, fw.w_hh, bw.w_hh, fw.b_hh, bw.b_hh, lengths, w.hst, w.gates, enc, w.sync, B,
-                                              Ts, H, s));
-        return vag_dropout_apply_launch(enc, B * Ts * 2 * H, 0, rng, VAG_DROP_ENC_CTX, p_ctx, s);
+        // (the context dropout is applied as the kernel writes enc: no separate pass)
+        return vag_enc_fwd_persistent_launch(w.xp, fw.w_hh, bw.w_hh, fw.b_hh, bw.b_hh, lengths, w.hst, w.gates, enc, w.sync, rng,
+                                             p_ctx, B, Ts, H, s);
     }
     const vag_half* w16 = s16 ? derived_layout(const_cast<float*>(g_derived), H).enc16 : nullptr;
     if (s16 && vag_opt().persistent && vag_enc_wide16_ok(B, Ts, H) && B >= 64) {

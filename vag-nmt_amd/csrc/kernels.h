@@ -145,8 +145,8 @@ int vag_clip_adam_launch(float* p, float* g, float* m, float* v, int64_t n, int 
 bool vag_enc_persistent_ok(int64_t B, int64_t Ts, int64_t H);
 int64_t vag_enc_persistent_sync_words(int64_t B, int64_t Ts);
 int vag_enc_fwd_persistent_launch(const float* xp, const float* w_fw, const float* w_bw, const float* b_fw, const float* b_bw,
-                                  const int* lengths, float* hst, float* gates, float* enc, unsigned* sync, int64_t B, int64_t Ts,
-                                  int64_t H, hipStream_t s);
+                                  const int* lengths, float* hst, float* gates, float* enc, unsigned* sync, const uint64_t* rng,
+                                  float p_ctx, int64_t B, int64_t Ts, int64_t H, hipStream_t s);
 int vag_enc_bwd_persistent_launch(const float* whhT, const float* d_enc, const float* gates, const float* hst, const int* lengths,
                                   const uint64_t* rng, float p_ctx, float* d_xp, float* dgh, unsigned* sync, int64_t B, int64_t Ts,
                                   int64_t H, hipStream_t s);

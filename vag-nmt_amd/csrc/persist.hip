@@ -46,6 +46,8 @@ struct EncPArgs {
     float* enc;                 // (B, Ts, 2H)
     unsigned* cnt;              // [2][RT][Ts], zero on entry
     unsigned* err;              // 1 word, set when a wait gave up
+    const uint64_t* rng;        // context dropout (Encoder.py:63-64) applied to enc as it is written (NULL / p_ctx = 0: none)
+    float p_ctx;
     int B, Ts, H, RT, CS;
 };
 
@@ -260,7 +262,12 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_persistent_kernel(EncPArgs a) 
                 *reinterpret_cast<float4*>(sv + BH) = make_float4(zz[0], zz[1], zz[2], zz[3]);
                 *reinterpret_cast<float4*>(sv + 2 * BH) = make_float4(nn[0], nn[1], nn[2], nn[3]);
                 *reinterpret_cast<float4*>(sv + 3 * BH) = c[2];
-                *reinterpret_cast<float4*>(a.enc + ((int64_t)em * Ts + t) * 2 * H + d * H + eu) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+                const int64_t eo = ((int64_t)em * Ts + t) * 2 * H + d * H + eu;
+                if (a.rng && a.p_ctx > 0.f) {               // the counter-based mask of this element (the backward kernel recomputes it)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o2[i] *= vag_drop_mul(a.rng, VAG_DROP_ENC_CTX, (uint64_t)eo + i, a.p_ctx);
+                }
+                *reinterpret_cast<float4*>(a.enc + eo) = make_float4(o2[0], o2[1], o2[2], o2[3]);
             }
         }
         // (the barrier behind the next step's wait separates wave 0's LDS reads of this step from the next step's writes)
@@ -1357,14 +1364,14 @@ bool vag_enc_persistent_ok(int64_t B, int64_t Ts, int64_t H) {
 int64_t vag_enc_persistent_sync_words(int64_t B, int64_t Ts) { return 2 * cdiv64(B, 16) * Ts + 64; }
 
 int vag_enc_fwd_persistent_launch(const float* xp, const float* w_fw, const float* w_bw, const float* b_fw, const float* b_bw,
-                                  const int* lengths, float* hst, float* gates, float* enc, unsigned* sync, int64_t B, int64_t Ts,
-                                  int64_t H, hipStream_t s) {
+                                  const int* lengths, float* hst, float* gates, float* enc, unsigned* sync, const uint64_t* rng,
+                                  float p_ctx, int64_t B, int64_t Ts, int64_t H, hipStream_t s) {
     VAG_CHECK_ARG(xp && w_fw && w_bw && b_fw && b_bw && lengths && hst && gates && enc && sync && vag_enc_persistent_ok(B, Ts, H));
     VAG_CHECK_ARG(aligned16(xp) && aligned16(w_fw) && aligned16(w_bw) && aligned16(b_fw) && aligned16(b_bw) && aligned16(hst) &&
                   aligned16(gates) && aligned16(enc));
     EncPArgs a;
     a.xp = xp; a.W[0] = w_fw; a.W[1] = w_bw; a.bias[0] = b_fw; a.bias[1] = b_bw; a.lengths = lengths;
-    a.hst = hst; a.gates = gates; a.enc = enc;
+    a.hst = hst; a.gates = gates; a.enc = enc; a.rng = rng; a.p_ctx = p_ctx;
     a.B = (int)B; a.Ts = (int)Ts; a.H = (int)H; a.RT = (int)cdiv64(B, 16); a.CS = (int)(H / 16);
     const int nwords = (int)vag_enc_persistent_sync_words(B, Ts);
     a.cnt = sync; a.err = sync + (nwords - 64);
