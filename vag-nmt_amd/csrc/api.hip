@@ -213,10 +213,6 @@ int vag_bigru_seq_fwd(const int64_t* src, const int32_t* lengths, const float* e
     VAG_TRY(vag_gemm_launch(R, 3 * H, E, 1.f, w.x, E, 1, bw.w_ih, 1, E, 0.f, w.xp + 3 * H, 6 * H, bw.b_ih, 0, s));
     VAG_TRY(grp0.end(s));
     const int64_t BH = B * H;
-    {
-        const VagJob zj[2] = {{nullptr, w.hst, B, H, H, H, 0}, {nullptr, w.hst + (Ts + 1) * BH, B, H, H, H, 0}};
-        VAG_TRY(vag_jobs_launch(zj, 2, s));          // initial states of both directions
-    }
     const bool s16 = g_store16 && g_derived;
     VAG_CHECK_ARG(!g_store16 || (g_derived && H % 8 == 0));
     if (!s16 && vag_opt().persistent && vag_enc_persistent_ok(B, Ts, H)) {
@@ -232,6 +228,10 @@ int vag_bigru_seq_fwd(const int64_t* src, const int32_t* lengths, const float* e
         VAG_TRY(vag_enc_fwd_wide16_launch(w.xp, w16, w16 + 3 * H * H, fw.b_hh, bw.b_hh, lengths, w.hst, w.gates, enc,
                                           reinterpret_cast<vag_half*>(w.dgh), w.sync, B, Ts, H, s));
         return vag_dropout_apply_launch(enc, B * Ts * 2 * H, 0, rng, VAG_DROP_ENC_CTX, p_ctx, s);
+    }
+    {
+        const VagJob zj[2] = {{nullptr, w.hst, B, H, H, H, 0}, {nullptr, w.hst + (Ts + 1) * BH, B, H, H, H, 0}};
+        VAG_TRY(vag_jobs_launch(zj, 2, s));          // initial states of both directions (the one-launch kernels write them themselves)
     }
     GruStepArgs a = {};
     a.lda = H; a.ldw = H; a.ldother = 6 * H; a.ldh = H; a.ld2 = Ts * 2 * H;

@@ -41,7 +41,7 @@ struct EncPArgs {
     const float* W[2];          // (3H, H) recurrent weights per direction
     const float* bias[2];       // (3H) b_hh
     const int* lengths;         // (B)
-    float* hst;                 // [2][Ts+1][B][H], step 0 zeros (caller)
+    float* hst;                 // [2][Ts+1][B][H]; slot 0 (zeros) is written here
     float* gates;               // [2][Ts][4][B][H]
     float* enc;                 // (B, Ts, 2H)
     unsigned* cnt;              // [2][RT][Ts], zero on entry
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_persistent_kernel(EncPArgs a) 
     float4 hp = make_float4(0.f, 0.f, 0.f, 0.f);           // this thread's previous state (step 0: zeros)
 
     float* hs = a.hst + (int64_t)d * (Ts + 1) * BH;
+    if (eok) *reinterpret_cast<float4*>(hs + (int64_t)em * H + eu) = hp;        // slot 0 (zeros): the backward pass reads it as h_prev
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hs, 0, (unsigned)((int64_t)(Ts + 1) * BH * 4), 0x00020000);
     gu32* cnt = (gu32*)(a.cnt + ((int64_t)d * a.RT + rt) * Ts);
     const int lrow = min(m0 + ld_row(lane), B - 1);        // the batch row this lane LOADS (quad-contiguous mapping, see ld_row)
@@ -209,7 +210,12 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_persistent_kernel(EncPArgs a) 
         // ---- h_k rows of this row tile (all H columns; this wave: its K share), sc1 loads, split, six-product MFMAs
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         float4 h0[KS], h1[KS];
-        ld_rows_sc1<KS>(hs + ((int64_t)k * B + lrow) * H + kbase + 8 * (lane & 3), h0, h1);
+        if (k > 0) {
+            ld_rows_sc1<KS>(hs + ((int64_t)k * B + lrow) * H + kbase + 8 * (lane & 3), h0, h1);
+        } else {                                            // the initial state is zero: nothing to read
+#pragma unroll
+            for (int s = 0; s < KS; ++s) h0[s] = h1[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             bf16x8 hf[3];
@@ -293,7 +299,7 @@ struct EncWArgs {
     const vag_half* W16[2];     // (3H, H) recurrent weights per direction, fp16
     const float* bias[2];       // (3H) b_hh
     const int* lengths;         // (B)
-    float* hst;                 // [2][Ts+1][B][H], step 0 zeros (caller)
+    float* hst;                 // [2][Ts+1][B][H]; slot 0 (zeros) is written here
     float* gates;               // [2][Ts][4][B][H]
     float* enc;                 // (B, Ts, 2H)
     vag_half* hx;               // [2][Ts+1][B][H] fp16 copy of the states for the exchange; slot 0 is written here (zeros)
@@ -366,6 +372,7 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_wide16_kernel(EncWArgs a) {
     float4 hp = make_float4(0.f, 0.f, 0.f, 0.f);
 
     float* hs = a.hst + (int64_t)d * (Ts + 1) * BH;
+    if (eok) *reinterpret_cast<float4*>(hs + (int64_t)em * H + eu) = hp;        // slot 0 (zeros): the backward pass reads it as h_prev
     vag_half* hx = a.hx + (int64_t)d * (Ts + 1) * BH;
     gu32* cnt = (gu32*)(a.cnt + ((int64_t)d * a.RG + rg) * Ts);
     const unsigned target = (unsigned)a.CS * 8u;           // every wave of every workgroup of the row group signs a step
