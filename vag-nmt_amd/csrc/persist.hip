@@ -1316,6 +1316,12 @@ __global__ __launch_bounds__(256) void zero_u32_kernel(unsigned* p, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = 0u;
 }
+// two regions in one launch (the decoder kernels' counters and their atomically accumulated scores)
+__global__ __launch_bounds__(256) void zero2_u32_kernel(unsigned* p, int n, unsigned* q, int m) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0u;
+    else if (i - n < m) q[i - n] = 0u;
+}
 
 }  // namespace
 
@@ -1422,10 +1428,9 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
     const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
     a.cnt = sync; a.err = sync + (nwords - 64);
     a.dbg = reinterpret_cast<unsigned long long*>(vag_opt().dec_stamps);
-    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
-    VAG_LAUNCH_CHECK();
     const int nsc = (int)(Tt * B * Ts);                              // the scores are accumulated with atomics: start from zero
-    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nsc, 256)), dim3(256), 0, s, reinterpret_cast<unsigned*>(psc), nsc);
+    hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64((int64_t)nwords + nsc, 256)), dim3(256), 0, s, sync, nwords,
+                       reinterpret_cast<unsigned*>(psc), nsc);
     VAG_LAUNCH_CHECK();
     int64_t lds = dec_persistent_lds_bytes(Ts);
     if (lds < 84 * 1024) lds = 84 * 1024;                            // never two workgroups on one CU
@@ -1536,10 +1541,9 @@ int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const flo
     a.B = (int)B; a.Ts = (int)Ts; a.Tt = (int)Tt; a.H = (int)H; a.RT = (int)cdiv64(B, 16);
     const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
     a.cnt = sync; a.err = sync + (nwords - 64);
-    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
-    VAG_LAUNCH_CHECK();
     const int nsc = (int)(Tt * B * Ts);
-    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nsc, 256)), dim3(256), 0, s, reinterpret_cast<unsigned*>(dal), nsc);
+    hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64((int64_t)nwords + nsc, 256)), dim3(256), 0, s, sync, nwords,
+                       reinterpret_cast<unsigned*>(dal), nsc);
     VAG_LAUNCH_CHECK();
     int64_t lds = dec_bwd_persistent_lds_bytes(Ts);
     if (lds < 84 * 1024) lds = 84 * 1024;
