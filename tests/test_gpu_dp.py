@@ -141,17 +141,17 @@ def test_phased_sequence_with_rccl_collectives_world1():
     assert np.allclose(fa, fb, rtol=2e-4, atol=2e-6), np.abs(fa - fb).max()
 
 
-def test_phased_sequence_with_vag_comm_world1():
-    """The same data-parallel sequence with the exchange going through the C ABI's own RCCL communicator (vag_comm_init /
-    vag_comm_allreduce on a side stream, include/vag_nmt.h) instead of torch.distributed: one rank, so the sum is the
-    identity and the result must equal the single-process step; covers id creation, communicator binding, the event
-    hand-offs between the step's stream and the exchange stream, and destruction."""
+def _vag_comm_worker(q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.cuda.set_device(0)
     from vagnmt_hip.trainer import TrainStep
     from vagnmt_hip.comm import Comm
     from vagnmt_hip import _lib
     res = {}
     comm = Comm(rank=0, world_size=1)
-    assert _lib.lib().vag_comm_size(comm._h) == 1
+    res["size"] = int(_lib.lib().vag_comm_size(comm._h))
     for name, kw in (("phased", dict(comm=comm, force_phased=True)), ("single", {})):
         m = _model(100)
         cm, cv = _criteria()
@@ -160,14 +160,32 @@ def test_phased_sequence_with_vag_comm_world1():
         torch.cuda.synchronize()
         res[name] = (ts.fp.flat.cpu().numpy().copy(), losses)
     comm.close()
-    (fa, la), (fb, lb) = res["phased"], res["single"]
-    assert np.allclose(la, lb, rtol=2e-4), (la, lb)
-    assert np.allclose(fa, fb, rtol=2e-4, atol=2e-6), np.abs(fa - fb).max()
-    # a plain buffer: sum over one rank leaves it unchanged
+    # a plain buffer: the sum over one rank leaves it unchanged
     comm = Comm(rank=0, world_size=1)
     x = torch.randn(1 << 20, device="cuda")
     y = x.clone()
     comm.all_reduce(x).wait()
     torch.cuda.synchronize()
-    assert torch.equal(x, y)
+    res["identity"] = bool(torch.equal(x, y))
     comm.close()
+    q.put(res)
+
+
+@pytest.mark.timeout(600)
+def test_phased_sequence_with_vag_comm_world1():
+    """The same data-parallel sequence with the exchange going through the C ABI's own RCCL communicator (vag_comm_init /
+    vag_comm_allreduce on a side stream, include/vag_nmt.h) instead of torch.distributed: one rank, so the sum is the
+    identity and the result must equal the single-process step; covers id creation, communicator binding, the event
+    hand-offs between the step's stream and the exchange stream, and destruction.  In a process of its own, like the
+    torch.distributed RCCL test above: RCCL and its helper threads stay out of the test runner."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_vag_comm_worker, args=(q,))
+    p.start()
+    res = q.get(timeout=500)
+    p.join(120)
+    assert p.exitcode == 0
+    assert res["size"] == 1 and res["identity"]
+    (fa, la), (fb, lb) = res["phased"], res["single"]
+    assert np.allclose(la, lb, rtol=2e-4), (la, lb)
+    assert np.allclose(fa, fb, rtol=2e-4, atol=2e-6), np.abs(fa - fb).max()
