@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <cstring>
+#include <new>
 
 namespace {
 
