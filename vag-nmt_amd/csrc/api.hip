@@ -23,10 +23,12 @@ static int linear_fwd(int64_t M, int64_t N, int64_t K, const float* x, int64_t l
     return vag_gemm_launch(M, N, K, 1.f, x, ldx, 1, W, 1, K, 0.f, y, ldy, bias, act, s);
 }
 // C (+)= A^T B with A (R,M) lda, B (R,N) ldb: weight gradients  g_W[m,n] += sum_r dY[r,m] X[r,n]
+// g_bias (optional): += sum_r A[r,:], the bias gradient that goes with this weight gradient -- taken from the A tiles inside the
+// product (GemmArgs::rowsum), no second pass over dY
 static int gemm_tn_acc(int64_t M, int64_t N, int64_t R, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
-                       int64_t ldc, hipStream_t s) {
+                       int64_t ldc, hipStream_t s, float* g_bias = nullptr) {
     if (R == 0) return VAG_OK;
-    return vag_gemm_launch(M, N, R, 1.f, A, 1, lda, B, ldb, 1, 1.f, C, ldc, nullptr, VAG_ACT_NONE, s);
+    return vag_gemm_launch(M, N, R, 1.f, A, 1, lda, B, ldb, 1, 1.f, C, ldc, nullptr, VAG_ACT_NONE, s, 0, g_bias);
 }
 // C = beta*C + A B with A (M,K) lda, B (K,N) ldb: data gradients  dX = dY W
 static int gemm_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
@@ -334,10 +336,8 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
         const vag_gru_g& gg = d == 0 ? g_fw : g_bw;
         const float* dgh = w.dgh + d * Ts * B * 3 * H;
         const float* hs = w.hst + d * (Ts + 1) * BH;
-        VAG_TRY(gemm_tn_acc(3 * H, H, R, dgh, 3 * H, hs, H, gg.w_hh, H, s));
-        VAG_TRY(vag_colsum_launch(dgh, R, 3 * H, 3 * H, gg.b_hh, s));
-        VAG_TRY(gemm_tn_acc(3 * H, E, R, d_xp + d * 3 * H, 6 * H, w.x, E, gg.w_ih, E, s));
-        VAG_TRY(vag_colsum_launch(d_xp + d * 3 * H, R, 3 * H, 6 * H, gg.b_ih, s));
+        VAG_TRY(gemm_tn_acc(3 * H, H, R, dgh, 3 * H, hs, H, gg.w_hh, H, s, gg.b_hh));                    // + bias gradient
+        VAG_TRY(gemm_tn_acc(3 * H, E, R, d_xp + d * 3 * H, 6 * H, w.x, E, gg.w_ih, E, s, gg.b_ih));
     }
     VAG_TRY(grp1.end(s));
     // d(embedded inputs) = sum over the directions of dgi W_ih: both products add into a zeroed buffer, one grouped launch
@@ -840,25 +840,22 @@ int vag_cgru_bwd_weights_chunk(const float* h0, const int64_t* tok, vag_dec_w w,
     const float* dgi1 = z.dgi1 + r0 * 3 * H;
     const float* dgh1 = z.dgh1 + r0 * 3 * H;
     const float* h1 = k.h1 + r0 * H;
-    VAG_TRY(gemm_tn_acc(3 * H, H, n, dgh2, Q, h1, H, g.gru2.w_hh, H, s));
-    VAG_TRY(vag_colsum_launch(dgh2, n, 3 * H, Q, g.gru2.b_hh, s));
+    VAG_TRY(gemm_tn_acc(3 * H, H, n, dgh2, Q, h1, H, g.gru2.w_hh, H, s, g.gru2.b_hh));       // (each with its bias gradient)
     VAG_TRY(gemm_tn_acc(C, H, n, dqgh, Q, h1, H, g.attn_h, H, s));
     // d(W_ih2 W_c2h) = dgi2^T c, then (vag_cgru_bwd_weights_finish) the chain rule through the folded product
-    VAG_TRY(vag_gemm_launch(3 * H, C, n, 1.f, dgi2, 1, 3 * H, c_all + r0 * C, C, 1, first ? 0.f : 1.f, z.dwp, C, nullptr, 0, s));
+    VAG_TRY(vag_gemm_launch(3 * H, C, n, 1.f, dgi2, 1, 3 * H, c_all + r0 * C, C, 1, first ? 0.f : 1.f, z.dwp, C, nullptr, 0, s, 0,
+                            g.gru2.b_ih));
     if (h0 + B * H == h2_all) {
         // caller keeps [h0, h2_all] in one buffer: the previous states of all steps are one (R,H) operand
-        VAG_TRY(gemm_tn_acc(3 * H, H, n, dgh1, 3 * H, h0 + r0 * H, H, g.gru1.w_hh, H, s));
+        VAG_TRY(gemm_tn_acc(3 * H, H, n, dgh1, 3 * H, h0 + r0 * H, H, g.gru1.w_hh, H, s, g.gru1.b_hh));
     } else {
-        if (t0 == 0) VAG_TRY(gemm_tn_acc(3 * H, H, B, dgh1, 3 * H, h0, H, g.gru1.w_hh, H, s));
+        if (t0 == 0) VAG_TRY(gemm_tn_acc(3 * H, H, B, dgh1, 3 * H, h0, H, g.gru1.w_hh, H, s, g.gru1.b_hh));
         const int64_t skip = t0 == 0 ? B : 0;
         if (n > skip)
             VAG_TRY(gemm_tn_acc(3 * H, H, n - skip, dgh1 + skip * 3 * H, 3 * H, h2_all + (r0 + skip - B) * H, H, g.gru1.w_hh, H,
-                                s));
+                                s, g.gru1.b_hh));      // (the two row ranges add their own shares of the bias gradient)
     }
-    VAG_TRY(gemm_tn_acc(3 * H, E, n, dgi1, 3 * H, e_all + r0 * E, E, g.gru1.w_ih, E, s));
-    VAG_TRY(vag_colsum_launch(dgi2, n, 3 * H, 3 * H, g.gru2.b_ih, s));
-    VAG_TRY(vag_colsum_launch(dgh1, n, 3 * H, 3 * H, g.gru1.b_hh, s));
-    VAG_TRY(vag_colsum_launch(dgi1, n, 3 * H, 3 * H, g.gru1.b_ih, s));
+    VAG_TRY(gemm_tn_acc(3 * H, E, n, dgi1, 3 * H, e_all + r0 * E, E, g.gru1.w_ih, E, s, g.gru1.b_ih));
     // d(embedded inputs) = dgi1 W_ih1 (+ the head's W3 path), scattered into the embedding gradient
     float* de = z.de + r0 * E;
     if (d_e_all) VAG_TRY(copy_async(de, d_e_all + r0 * E, n * E * sizeof(float), s));
@@ -1012,10 +1009,10 @@ static int head_bwd_weights(const float* h2_all, const float* c_all, const float
     VagGemmGroup grp6;
     if (!out_w_done) VAG_TRY(head_outw_gemm(V, E, R, dlogits, ldl, tmid, g.out_w, s));
     if (!out_b_done) VAG_TRY(vag_colsum_launch(dlogits, R, V, ldl, g.out_b, s));
-    VAG_TRY(gemm_tn_acc(E, H, R, dt, E, h2_all, H, g.w1, H, s));
-    VAG_TRY(gemm_tn_acc(E, C, R, dt, E, c_all, C, g.w2, C, s));
-    VAG_TRY(gemm_tn_acc(E, E, R, dt, E, e_all, E, g.w3, E, s));
-    VAG_TRY(vag_colsum3_launch(dt, R, E, E, g.b1, g.b2, g.b3, s));     // b1, b2, b3 enter the same sum (NMT_Decoder.py:137)
+    // b1, b2, b3 enter the same sum (NMT_Decoder.py:137): each of the three products leaves sum_r dt[r,:] in one of them
+    VAG_TRY(gemm_tn_acc(E, H, R, dt, E, h2_all, H, g.w1, H, s, g.b1));
+    VAG_TRY(gemm_tn_acc(E, C, R, dt, E, c_all, C, g.w2, C, s, g.b2));
+    VAG_TRY(gemm_tn_acc(E, E, R, dt, E, e_all, E, g.w3, E, s, g.b3));
     return grp6.end(s);
 }
 

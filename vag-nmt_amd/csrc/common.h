@@ -114,7 +114,8 @@ enum { VAG_DROP_ENC_EMB = 1, VAG_DROP_ENC_CTX = 2, VAG_DROP_DEC_OUT = 3 };
 // C[M,N] = act(alpha * op(A) op(B) + beta * C + bias[n]);  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn].
 int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
                     const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc,
-                    const float* bias, int act, hipStream_t stream, int c_half = 0);   // c_half: C stored as fp16 (beta = 0)
+                    const float* bias, int act, hipStream_t stream, int c_half = 0,    // c_half: C stored as fp16 (beta = 0)
+                    float* rowsum = nullptr);     // rowsum[m] += sum_k A(m,k) (A outer-contiguous): bias gradient of g_W += dY^T X
 // out[m,n] = act(sum_k A[m,k] W[n,k] + bias[n] + addend[m,n]);  M small (decode/recurrent steps).
 void vag_gemm_set_planes(int planes);
 int vag_gemm_launch_planes(int planes, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,

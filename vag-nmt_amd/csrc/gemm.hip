@@ -336,7 +336,16 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
     SpRegs ra, rb;
     sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, kbeg, a.M, kend, ra);
     sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, kbeg, a.N, kend, rb);
+    // row sums of A for the first column tile's blocks (outer-contiguous A: this thread's two items of a k-tile are the same
+    // four rows m at two k): the bias gradient of a weight-gradient product without a second pass over dY
+    // (three-plane kernels only: at the one-plane kernels' 80-VGPR cap the extra state spills; the launcher sends those
+    // products' row sums to a column-sum launch instead)
+    const bool do_rs = !AKC && PL == 3 && a.rowsum != nullptr && bx == 0;
+    float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k0 = kbeg; k0 < kend; k0 += SP_BK) {
+        if (!AKC && PL == 3 && do_rs) {
+            rs.x += ra.v[0] + ra.v[4]; rs.y += ra.v[1] + ra.v[5]; rs.z += ra.v[2] + ra.v[6]; rs.w += ra.v[3] + ra.v[7];
+        }
         sp_store<AKC, PL, F16>(As, ra);
         sp_store<BKC, PL, F16>(Bs, rb);
         __syncthreads();
@@ -346,6 +355,24 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
         }
         sp_compute<PL, AKC, BKC, F16>(Af, Bf, As, Bs, wm * 64, wn * 32, acc);
         __syncthreads();
+    }
+    if (!AKC && PL == 3 && do_rs) {           // (uniform over the block) 16 threads hold partial sums of the same four rows: meet in LDS
+        float4* rs_s = reinterpret_cast<float4*>(smem);
+        rs_s[threadIdx.x] = rs;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            float4 t = rs_s[threadIdx.x];
+#pragma unroll
+            for (int q = 1; q < 16; ++q) {
+                const float4 o = rs_s[threadIdx.x + 32 * q];
+                t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+            }
+            const int m = m0 + 4 * threadIdx.x;
+            if (m + 0 < a.M) atomicAdd(a.rowsum + m + 0, t.x);
+            if (m + 1 < a.M) atomicAdd(a.rowsum + m + 1, t.y);
+            if (m + 2 < a.M) atomicAdd(a.rowsum + m + 2, t.z);
+            if (m + 3 < a.M) atomicAdd(a.rowsum + m + 3, t.w);
+        }
     }
 
     // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -638,7 +665,7 @@ int vag_gemm_group_end(hipStream_t stream) {
 
 int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
                     const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc,
-                    const float* bias, int act, hipStream_t stream, int c_half) {
+                    const float* bias, int act, hipStream_t stream, int c_half, float* rowsum) {
     const bool opt_f32mfma = vag_opt().gemm_f32mfma != 0;      // vag_set_option("gemm_f32mfma"): the bf16x6 bound test flips it
     const bool opt_nogroup = vag_opt().gemm_nogroup != 0;
     VAG_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && A && B && C);
@@ -652,8 +679,13 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     const bool bkc = (sbk == 1);        // B: k contiguous
     g.sa_o = sam; g.sa_k = sak; g.sb_o = sbn; g.sb_k = sbk;
     g.ldc = ldc; g.M = (int)M; g.N = (int)N; g.K = (int)K;
-    g.alpha = alpha; g.beta = beta; g.act = act; g.c_half = c_half;
+    g.alpha = alpha; g.beta = beta; g.act = act; g.c_half = c_half; g.rowsum = rowsum;
     VAG_CHECK_ARG(!c_half || beta == 0.f);      // fp16 output: plain stores only (no split-K, no accumulation)
+    VAG_CHECK_ARG(!rowsum || sam == 1);         // row sums ride on outer-contiguous A tiles only
+    if (rowsum && g_gemm_planes != 3) {         // ... and on the three-plane kernels only: otherwise a column-sum pass over A
+        VAG_TRY(vag_colsum_launch(A, K, M, sak, rowsum, stream));
+        g.rowsum = rowsum = nullptr;
+    }
     const int64_t lda = akc ? sam : sak, ldb = bkc ? sbn : sbk;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     const int lay = (akc ? 2 : 0) + (bkc ? 1 : 0);
@@ -703,6 +735,10 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
         fprintf(stderr, "[vag_gemm] M=%lld N=%lld K=%lld akc=%d bkc=%d beta=%g -> T=%lld splitk=%lld model=%.1f us\n",
                 (long long)M, (long long)N, (long long)K, (int)akc, (int)bkc, (double)beta, (long long)T, (long long)splitk, best);
     const bool big = (T == 128);
+    if (rowsum && (!big || opt_f32mfma)) {          // the other kernels do not carry row sums: a column-sum pass over A instead
+        VAG_TRY(vag_colsum_launch(A, K, M, sak, rowsum, stream));
+        g.rowsum = nullptr;
+    }
     int kchunk = (int)(cdiv64(cdiv64(K, splitk), BK) * BK);
     splitk = cdiv64(K, kchunk);
     g.splitk = (int)splitk; g.kchunk = kchunk;
@@ -734,7 +770,7 @@ int vag_gemm_launch_planes(int planes, int64_t M, int64_t N, int64_t K, float al
 }
 static int vag_gemm_launch_now(const GemmArgs& q, hipStream_t stream) {
     return vag_gemm_launch(q.M, q.N, q.K, q.alpha, q.A, q.sa_o, q.sa_k, q.B, q.sb_k, q.sb_o, q.beta, q.C, q.ldc, q.bias, q.act,
-                           stream, q.c_half);
+                           stream, q.c_half, q.rowsum);
 }
 
 // ------------------------------------------------------------------------------------------------
