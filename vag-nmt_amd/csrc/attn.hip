@@ -285,57 +285,95 @@ int vag_attn_ctx_gru_launch(const float* scores, const float* encwp, int64_t N, 
 // ------------------------------------------------------------------ batched over time: out[t,b,:] = sum_s a[t,b,s] x[b,s,:]
 // (the contexts of all steps after the loop) and out[b,s,:] = sum_t a[t,b,s] y[t,b,:] (gradient of the projected keys).
 // grid (ceil(W/256), B, ceil(T/8)) / (ceil(W/256), B, ceil(Ts/8)); thread owns one float4 column, 8 outputs in registers.
-__global__ __launch_bounds__(64) void attn_wsum_time_kernel(const float* __restrict__ a, const float* __restrict__ x, int B,
-                                                            int Ts, int T, int W, float* __restrict__ out) {
+// Round 3: 256-thread blocks, wave w takes every 4th position of the summed dimension and the four partial sums meet in LDS (one
+// wave per block walked all Ts / T positions on its own: ~5 waves per CU, a serial chain of 40 loads: 17-20 us each).
+__global__ __launch_bounds__(256) void attn_wsum_time_kernel(const float* __restrict__ a, const float* __restrict__ x, int B,
+                                                             int Ts, int T, int W, float* __restrict__ out) {
+    __shared__ float4 part[3][8][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y, t0 = blockIdx.z * 8;
-    const int c = (blockIdx.x * 64 + threadIdx.x) * 4;
-    if (c >= W) return;
+    const int c = (blockIdx.x * 64 + lane) * 4;
+    const bool cok = c < W;
     float4 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* xr = x + (int64_t)b * Ts * W + c;
-    for (int s = 0; s < Ts; ++s) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + (int64_t)s * W);
+    if (cok) {
+        const float* xr = x + (int64_t)b * Ts * W + c;
+        for (int s = wave; s < Ts; s += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + (int64_t)s * W);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int t = min(t0 + i, T - 1);
-            const float al = a[((int64_t)t * B + b) * Ts + s];
-            acc[i].x += al * v.x; acc[i].y += al * v.y; acc[i].z += al * v.z; acc[i].w += al * v.w;
+            for (int i = 0; i < 8; ++i) {
+                const int t = min(t0 + i, T - 1);
+                const float al = a[((int64_t)t * B + b) * Ts + s];
+                acc[i].x += al * v.x; acc[i].y += al * v.y; acc[i].z += al * v.z; acc[i].w += al * v.w;
+            }
         }
     }
+    if (wave > 0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-        if (t0 + i < T) *reinterpret_cast<float4*>(out + ((int64_t)(t0 + i) * B + b) * W + c) = acc[i];
+        for (int i = 0; i < 8; ++i) part[wave - 1][i][lane] = acc[i];
+    }
+    __syncthreads();
+    if (wave == 0 && cok) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float4 r = acc[i];
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                const float4 o = part[w][i][lane];
+                r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+            }
+            if (t0 + i < T) *reinterpret_cast<float4*>(out + ((int64_t)(t0 + i) * B + b) * W + c) = r;
+        }
+    }
 }
-__global__ __launch_bounds__(64) void attn_wsum_src_kernel(const float* __restrict__ a, const float* __restrict__ y, int B,
-                                                           int Ts, int T, int W, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void attn_wsum_src_kernel(const float* __restrict__ a, const float* __restrict__ y, int B,
+                                                            int Ts, int T, int W, float* __restrict__ out) {
+    __shared__ float4 part[3][8][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y, s0 = blockIdx.z * 8;
-    const int c = (blockIdx.x * 64 + threadIdx.x) * 4;
-    if (c >= W) return;
+    const int c = (blockIdx.x * 64 + lane) * 4;
+    const bool cok = c < W;
     float4 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int t = 0; t < T; ++t) {
-        const float4 v = *reinterpret_cast<const float4*>(y + ((int64_t)t * B + b) * W + c);
-        const float* ar = a + ((int64_t)t * B + b) * Ts;
+    if (cok) {
+        for (int t = wave; t < T; t += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(y + ((int64_t)t * B + b) * W + c);
+            const float* ar = a + ((int64_t)t * B + b) * Ts;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float al = ar[min(s0 + i, Ts - 1)];
-            acc[i].x += al * v.x; acc[i].y += al * v.y; acc[i].z += al * v.z; acc[i].w += al * v.w;
+            for (int i = 0; i < 8; ++i) {
+                const float al = ar[min(s0 + i, Ts - 1)];
+                acc[i].x += al * v.x; acc[i].y += al * v.y; acc[i].z += al * v.z; acc[i].w += al * v.w;
+            }
         }
     }
+    if (wave > 0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-        if (s0 + i < Ts) *reinterpret_cast<float4*>(out + ((int64_t)b * Ts + s0 + i) * W + c) = acc[i];
+        for (int i = 0; i < 8; ++i) part[wave - 1][i][lane] = acc[i];
+    }
+    __syncthreads();
+    if (wave == 0 && cok) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float4 r = acc[i];
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                const float4 o = part[w][i][lane];
+                r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+            }
+            if (s0 + i < Ts) *reinterpret_cast<float4*>(out + ((int64_t)b * Ts + s0 + i) * W + c) = r;
+        }
+    }
 }
 int vag_attn_wsum_launch(int over_src, const float* a, const float* x, int64_t B, int64_t Ts, int64_t T, int64_t W, float* out,
                          hipStream_t s) {
     VAG_CHECK_ARG(a && x && out && B > 0 && Ts > 0 && T > 0 && W > 0 && W % 4 == 0 && aligned16(x) && aligned16(out));
     if (over_src) {     // out (T,B,W) = sum_s a x
-        hipLaunchKernelGGL(attn_wsum_time_kernel, dim3((unsigned)cdiv64(W, 256), (unsigned)B, (unsigned)cdiv64(T, 8)), dim3(64), 0,
+        hipLaunchKernelGGL(attn_wsum_time_kernel, dim3((unsigned)cdiv64(W, 256), (unsigned)B, (unsigned)cdiv64(T, 8)), dim3(256), 0,
                            s, a, x, (int)B, (int)Ts, (int)T, (int)W, out);
     } else {            // out (B,Ts,W) = sum_t a y
-        hipLaunchKernelGGL(attn_wsum_src_kernel, dim3((unsigned)cdiv64(W, 256), (unsigned)B, (unsigned)cdiv64(Ts, 8)), dim3(64), 0,
+        hipLaunchKernelGGL(attn_wsum_src_kernel, dim3((unsigned)cdiv64(W, 256), (unsigned)B, (unsigned)cdiv64(Ts, 8)), dim3(256), 0,
                            s, a, x, (int)B, (int)Ts, (int)T, (int)W, out);
     }
     VAG_LAUNCH_CHECK();
