@@ -148,7 +148,8 @@ def _time_graph(fn, reps=20):
     fn()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    from vagnmt_hip._lib import capture
+    with capture(g):
         fn()
     g.replay()
     torch.cuda.synchronize()

@@ -178,13 +178,19 @@ def test_phased_sequence_with_vag_comm_world1():
     identity and the result must equal the single-process step; covers id creation, communicator binding, the event
     hand-offs between the step's stream and the exchange stream, and destruction.  In a process of its own, like the
     torch.distributed RCCL test above: RCCL and its helper threads stay out of the test runner."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    p = ctx.Process(target=_vag_comm_worker, args=(q,))
-    p.start()
-    res = q.get(timeout=500)
-    p.join(120)
-    assert p.exitcode == 0
+    if os.environ.get("VAG_TEST_COMM_INPROC") == "1":          # rehearsal of the in-process use (a trainer's own process)
+        import queue
+        q = queue.Queue()
+        _vag_comm_worker(q)
+        res = q.get()
+    else:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        p = ctx.Process(target=_vag_comm_worker, args=(q,))
+        p.start()
+        res = q.get(timeout=500)
+        p.join(120)
+        assert p.exitcode == 0
     assert res["size"] == 1 and res["identity"]
     (fa, la), (fb, lb) = res["phased"], res["single"]
     assert np.allclose(la, lb, rtol=2e-4), (la, lb)

@@ -138,7 +138,7 @@ class Seq2SeqBase(nn.Module):
             st["chunk"] = torch.empty(CH, B, dtype=torch.int64, device=dev)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with _lib.capture(g):
                 hc, tc = st["h"], st["tok"]
                 for i in range(CH):
                     hc, c, e, _ = ops.decode_step(st["enc"], st["pe"], st["mask"], 1, tc, hc, emb, dp, st["prep"])
@@ -205,7 +205,7 @@ class Seq2SeqBase(nn.Module):
             if st["graph"] is None:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with _lib.capture(g):
                     for _ in range(CH):
                         h2, c, e, _ = ops.decode_step(enc_s, pe, mask_s, k, st["tok"], st["h"], emb, dp, prep)
                         logp, _ = ops.head_logp_step(h2, c, e, hp)

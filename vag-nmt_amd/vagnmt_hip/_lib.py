@@ -168,6 +168,34 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class capture:
+    """``with capture(graph):`` -- torch.cuda.graph(graph) with Python's garbage collector held off for the duration of the
+    capture and errors confined to the capturing thread.  A collection that runs INSIDE a capture can free tensors whose
+    storage the caching allocator must first fence on another stream (anything that went through ``record_stream``, e.g.
+    gradient buckets handed to an exchange stream): that event record on a non-capturing stream aborts the process (found as
+    a silent abort ~100 tests after a data-parallel test, always inside a decode-graph capture)."""
+
+    def __init__(self, graph):
+        self._cm = torch.cuda.graph(graph, capture_error_mode="thread_local")
+        self._gc = False
+
+    def __enter__(self):
+        import gc
+        self._gc = gc.isenabled()
+        if self._gc:
+            gc.collect()
+            gc.disable()
+        return self._cm.__enter__()
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self._cm.__exit__(*exc)
+        finally:
+            if self._gc:
+                gc.enable()
+
+
 def ptr(t, dtype=torch.float32):
     """Device pointer of a contiguous HIP tensor (None -> NULL)."""
     if t is None:

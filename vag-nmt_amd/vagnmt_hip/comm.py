@@ -4,7 +4,8 @@ One process per GPU.  Rank 0 draws the 128-byte id, the other ranks receive it o
 (here: torch.distributed's object broadcast on the default group, any backend -- gloo is enough; only the id travels that
 way), then every rank binds a communicator to its current device.  all_reduce() enqueues an in-place fp32 sum on a side
 stream that waits for the caller's stream, so the exchange of a finished gradient bucket runs beside the rest of backward;
-the returned handle's wait() makes the caller's stream wait for it (no host synchronisation anywhere)."""
+the returned handle's wait() makes the caller's stream wait for it (no host synchronisation anywhere).  The tensor handed to
+all_reduce() must stay alive until its handle has been waited on."""
 import ctypes as C
 
 import torch
@@ -54,7 +55,9 @@ class Comm:
                    C.c_void_p(self._side.cuda_stream))
             done = torch.cuda.Event()
             done.record()
-        t.record_stream(self._side)
+        # (no t.record_stream(side): the caller keeps `t` alive until wait() -- a gradient bucket lives as long as its driver --
+        # and a storage marked that way makes the allocator record an event on the side stream when it is freed, which
+        # aborts the process if that happens inside somebody's graph capture)
         return _Pending(done)
 
     def close(self):

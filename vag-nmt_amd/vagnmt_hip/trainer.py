@@ -24,7 +24,7 @@ import random
 
 import torch
 
-from ._lib import call, ptr, stream
+from ._lib import call, ptr, stream, capture as _capture
 
 
 def param_groups(named_params, vse_separate=False):
@@ -182,7 +182,7 @@ class TrainStep:
                 return self._optimizer()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with _capture(g):
                 self._optimizer()
             self._opt_graphs[key] = g
         g.replay()
@@ -318,7 +318,7 @@ class _FusedBackend:
                     ts.stats["evictions"] += 1
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with _capture(g):
                 launch()
             ent[phases] = g
             ts.stats["captures"] += 1
