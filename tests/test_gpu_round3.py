@@ -196,3 +196,41 @@ def test_recurrence_event_timing_reports_every_persistent_launch():
     torch.cuda.synchronize()
     assert all(read(k)[1] == 0 for k in range(4))              # switched off: nothing is recorded
     ts.check()
+
+
+def test_bf16_dlogits_chunks_match_fp32_dlogits_in_the_two_byte_mode():
+    """2-byte storage mode with the output head in row chunks (configs[4]'s regime) at H = 1024 / B = 256: d(logits) of a chunk
+    written and read as bf16 (head_bf16_dlogits = 1: ce_bwd_colsum's out16, the bf16-stored A operand of the one-plane
+    products) against the same step with fp32 d(logits) in place (whose products, at this reduced vocabulary, run on the exact
+    f32 kernel): gradients within the mode's 1e-2 of each tensor's largest entry (measured 2e-3: one bf16 rounding of
+    d(logits)); losses are untouched."""
+    from test_gpu_round2 import _fp16_case
+    from vagnmt_hip import _lib as L
+    from vagnmt_hip.trainer import TrainStep
+    m_of, (src, lens, tgt, im), cm, cv = _fp16_case("wide")
+    lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    B = src.shape[0]
+    out = {}
+    try:
+        L.set_option("head_chunk", B)                       # one time step (256 rows) per chunk, five chunks
+        for flag in (0, 1):
+            L.set_option("head_bf16_dlogits", flag)
+            m = m_of()
+            ts = TrainStep(m, cm, cv, use_graph=False, storage="f16", pad_src=1)
+            m.eval()
+            ts.backend.run(src, lt, tgt, im, True, 7)
+            torch.cuda.synchronize()
+            out[flag] = ([float(x) for x in ts.backend.outputs()],
+                         {n: p._vag_grad.detach().clone() for n, p in m.named_parameters()})
+    finally:
+        L.set_option("head_chunk", -1)
+        L.set_option("head_bf16_dlogits", 1)
+    (l0, g0), (l1, g1) = out[0], out[1]
+    assert np.allclose(l0, l1, rtol=1e-6, atol=1e-7), (l0, l1)
+    differs = False
+    for n in g0:
+        scale = max(g0[n].abs().max().item(), 1e-8)
+        err = (g0[n] - g1[n]).abs().max().item()
+        assert err <= 1e-2 * scale, (n, err, scale)
+        differs = differs or err > 0.0
+    assert differs                                           # the bf16 path really ran (sums in another order)

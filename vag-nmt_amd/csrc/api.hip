@@ -72,16 +72,27 @@ void vag_set_head_fuse(const vag_head_g* g, const float* d_loss, float* dt) { g_
 static bool head_grads_one_plane() {
     return vag_opt().head_bf16_grads != 0 && g_store16;
 }
+// dl16 (optional): the same d(logits) chunk as its producer stored it in bf16 (vag_ce_bwd_colsum_launch's out16), row stride ldl
 static int head_dt_gemm(int64_t R, int64_t E, int64_t V, const float* dlogits, int64_t ldl, const float* out_w, float* dt,
-                        hipStream_t s) {
+                        hipStream_t s, const void* dl16 = nullptr) {
+    if (dl16) return vag_gemm_launch_planes(1, R, E, V, 1.f, reinterpret_cast<const float*>(dl16), ldl, 1, out_w, E, 1, 0.f, dt, E, s, 1);
     if (head_grads_one_plane() && R > 128) return vag_gemm_launch_planes(1, R, E, V, 1.f, dlogits, ldl, 1, out_w, E, 1, 0.f, dt, E, s);
     return gemm_nn(R, E, V, dlogits, ldl, out_w, E, 0.f, dt, E, s);
 }
 static int head_outw_gemm(int64_t V, int64_t E, int64_t R, const float* dlogits, int64_t ldl, const float* tmid, float* g_out_w,
-                          hipStream_t s) {
+                          hipStream_t s, const void* dl16 = nullptr) {
     if (R == 0) return VAG_OK;
+    if (dl16) return vag_gemm_launch_planes(1, V, E, R, 1.f, reinterpret_cast<const float*>(dl16), 1, ldl, tmid, E, 1, 1.f, g_out_w, E, s, 1);
     if (head_grads_one_plane() && R > 128) return vag_gemm_launch_planes(1, V, E, R, 1.f, dlogits, 1, ldl, tmid, E, 1, 1.f, g_out_w, E, s);
     return gemm_tn_acc(V, E, R, dlogits, ldl, tmid, E, g_out_w, E, s);
+}
+
+// 2-byte storage mode, chunked head: the bf16 copy of a chunk's d(logits) lives behind the chunk inside the (whole-sequence
+// sized) logits buffer; NULL when the mode is off, the chunk is small, or there is no room behind it.
+static void* head_dl16_slot(float* logits, int64_t ldl, int64_t R, int64_t CH) {
+    if (!head_grads_one_plane() || CH <= 128 || vag_opt().head_bf16_dlogits == 0) return nullptr;
+    if (CH * 3 > R * 2) return nullptr;                      // CH * ldl floats of chunk + CH * ldl / 2 floats of bf16 must fit R * ldl
+    return logits + CH * ldl;
 }
 
 VagOptions& vag_opt() {
@@ -101,7 +112,8 @@ int vag_set_option(const char* name, int64_t value) {
         {"gemm_f32mfma", &o.gemm_f32mfma}, {"gemm_nogroup", &o.gemm_nogroup}, {"gemm_force_tile", &o.gemm_force_tile},
         {"gemm_force_splitk", &o.gemm_force_splitk}, {"gemm_debug", &o.gemm_debug}, {"head_fuse", &o.head_fuse},
         {"head_bf16_grads", &o.head_bf16_grads}, {"persistent", &o.persistent}, {"persistent_dec_bwd", &o.persistent_dec_bwd},
-        {"persist_timing", &o.persist_timing}, {"s16_one_plane", &o.s16_one_plane}};
+        {"persist_timing", &o.persist_timing}, {"s16_one_plane", &o.s16_one_plane},
+        {"head_bf16_dlogits", &o.head_bf16_dlogits}};
     for (const auto& e : ints)
         if (strcmp(name, e.n) == 0) { *e.p = (int)value; return VAG_OK; }
     if (strcmp(name, "head_chunk") == 0) { o.head_chunk = value; return VAG_OK; }
@@ -968,10 +980,11 @@ int vag_head_ce_seq_fwd_impl(const float* h2_all, const float* c_all, const floa
                                        nullptr, 0, s));
             if (g_head_fuse.g) {
                 const vag_head_g& g = *g_head_fuse.g;
+                void* dl16 = rows > 128 ? head_dl16_slot(logits, ldl, R, CH) : nullptr;
                 VAG_TRY(vag_ce_bwd_colsum_launch(logits, ldl, rows, V, tgt + r0 / B, B, Tt, vocab_weight, lse + r0, inv_cnt,
-                                                 g_head_fuse.d_loss, g.out_b, s));
-                VAG_TRY(head_dt_gemm(rows, E, V, logits, ldl, w.out_w, g_head_fuse.dt + r0 * E, s));
-                VAG_TRY(head_outw_gemm(V, E, rows, logits, ldl, tmid + r0 * E, g.out_w, s));
+                                                 g_head_fuse.d_loss, g.out_b, s, dl16));
+                VAG_TRY(head_dt_gemm(rows, E, V, logits, ldl, w.out_w, g_head_fuse.dt + r0 * E, s, dl16));
+                VAG_TRY(head_outw_gemm(V, E, rows, logits, ldl, tmid + r0 * E, g.out_w, s, dl16));
             }
         }
         if (g_head_fuse.g) g_head_fuse.done = true;
@@ -1058,10 +1071,11 @@ int vag_head_ce_seq_bwd(const float* h2_all, const float* c_all, const float* e_
         for (int64_t r0 = 0; r0 < R && !fused; r0 += CH) {
             const int64_t rows = R - r0 < CH ? R - r0 : CH;
             VAG_TRY(vag_gemm_launch(rows, V, E, 1.f, tmid + r0 * E, E, 1, w.out_w, 1, E, 0.f, logits, ldl, w.out_b, 0, s));
+            void* dl16 = rows > 128 ? head_dl16_slot(logits, ldl, R, CH) : nullptr;
             VAG_TRY(vag_ce_bwd_colsum_launch(logits, ldl, rows, V, tgt + r0 / B, B, Tt, vocab_weight, lse + r0, inv_cnt, d_loss,
-                                             g.out_b, s));
-            VAG_TRY(head_dt_gemm(rows, E, V, logits, ldl, w.out_w, scratch + r0 * E, s));
-            VAG_TRY(head_outw_gemm(V, E, rows, logits, ldl, tmid + r0 * E, g.out_w, s));
+                                             g.out_b, s, dl16));
+            VAG_TRY(head_dt_gemm(rows, E, V, logits, ldl, w.out_w, scratch + r0 * E, s, dl16));
+            VAG_TRY(head_outw_gemm(V, E, rows, logits, ldl, tmid + r0 * E, g.out_w, s, dl16));
         }
         VAG_TRY(head_bwd_data(w, R, E, H, V, p_out, rng, tmid, logits, ldl, d_h2_all, d_c_all, d_e_all, scratch, s, true));
         return head_bwd_weights(h2_all, c_all, e_all, R, E, H, V, tmid, logits, ldl, scratch, g, s, true, true);

@@ -101,6 +101,7 @@ struct VagOptions {
     int persistent_dec_bwd = 1;  // 0: only the decoder's backward recurrence stays a launch chain
     int s16_one_plane = 1;       // 2-byte storage mode of the step driver: forward products on ONE fp16 plane, gradient products on
                                  // ONE bf16 plane (0: two bf16 planes everywhere, as the operators on their own use)
+    int head_bf16_dlogits = 1;   // 2-byte storage mode, chunked head: d(logits) of a chunk is written and read as bf16 (0: fp32 in place)
     int persist_timing = 0;      // 1: HIP events around the recurrence kernels of eager launches (vag_recurrence_time)
     int64_t dec_bwd_stamps = 0;  // the same for the persistent decoder backward
     int64_t dec_stamps = 0;      // device address of Tt x 8 uint64 for the persistent decoder's phase timestamps (0: none)
@@ -115,11 +116,13 @@ enum { VAG_DROP_ENC_EMB = 1, VAG_DROP_ENC_CTX = 2, VAG_DROP_DEC_OUT = 3 };
 int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
                     const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc,
                     const float* bias, int act, hipStream_t stream, int c_half = 0,    // c_half: C stored as fp16 (beta = 0)
-                    float* rowsum = nullptr);     // rowsum[m] += sum_k A(m,k) (A outer-contiguous): bias gradient of g_W += dY^T X
+                    float* rowsum = nullptr,      // rowsum[m] += sum_k A(m,k) (A outer-contiguous): bias gradient of g_W += dY^T X
+                    int a_bf16 = 0);              // A stored as bf16 (one-plane bf16 kernel, ungrouped): the 2-byte mode's d(logits)
 // out[m,n] = act(sum_k A[m,k] W[n,k] + bias[n] + addend[m,n]);  M small (decode/recurrent steps).
 void vag_gemm_set_planes(int planes);
 int vag_gemm_launch_planes(int planes, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
-                           const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc, hipStream_t stream);      // 3: bf16x6 (default), 2: bf16x3 (2-byte storage mode), calling thread
+                           const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc, hipStream_t stream,
+                           int a_bf16 = 0);      // planes 3: bf16x6 (default), 2: bf16x3 (2-byte storage mode), calling thread
 int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
                       const float* bias, const float* addend, int64_t ldadd, float* out, int64_t ldo, int act,
                       hipStream_t stream, bool w16 = false);      // w16: W is stored as fp16 (2-byte storage mode)

@@ -227,10 +227,56 @@ __device__ __forceinline__ void sp_load(const float* __restrict__ P, int64_t so,
     }
 }
 
+// The same two items per thread of an operand STORED as bf16 (2-byte storage mode: d(logits) as its producer writes it): eight
+// bytes per item, kept as two packed pairs in r.v[4i], r.v[4i+1] -- they ARE the one bf16 plane, sp_store<.., PRE> passes them on.
+template <bool KC>
+__device__ __forceinline__ void sp_load_bf16(const unsigned short* __restrict__ P, int64_t so, int64_t sk, int o0, int k0, int OUT,
+                                             int KEND, SpRegs& r) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 512;
+        unsigned lo = 0u, hi = 0u;
+        if (KC) {
+            const int o = o0 + sp_row(idx >> 3), k = k0 + ((idx & 7) << 2);
+            if (o < OUT) {
+                const unsigned short* p = P + (int64_t)o * so + k;
+                if (k + 3 < KEND) {
+                    const uint2 v = *reinterpret_cast<const uint2*>(p);
+                    lo = v.x; hi = v.y;
+                } else {
+                    if (k + 0 < KEND) lo |= (unsigned)p[0];
+                    if (k + 1 < KEND) lo |= (unsigned)p[1] << 16;
+                    if (k + 2 < KEND) hi |= (unsigned)p[2];
+                    if (k + 3 < KEND) hi |= (unsigned)p[3] << 16;
+                }
+            }
+        } else {
+            const int k = k0 + (idx >> 5), o = o0 + ((idx & 31) << 2);
+            if (k < KEND) {
+                const unsigned short* p = P + (int64_t)k * sk + o;
+                if (o + 3 < OUT) {
+                    const uint2 v = *reinterpret_cast<const uint2*>(p);
+                    lo = v.x; hi = v.y;
+                } else {
+                    if (o + 0 < OUT) lo |= (unsigned)p[0];
+                    if (o + 1 < OUT) lo |= (unsigned)p[1] << 16;
+                    if (o + 2 < OUT) hi |= (unsigned)p[2];
+                    if (o + 3 < OUT) hi |= (unsigned)p[3] << 16;
+                }
+            }
+        }
+        r.v[4 * i + 0] = __builtin_bit_cast(float, lo);
+        r.v[4 * i + 1] = __builtin_bit_cast(float, hi);
+        r.v[4 * i + 2] = 0.f; r.v[4 * i + 3] = 0.f;
+    }
+}
+
 // registers -> PL (3, 2 or 1) bf16 planes in LDS, image [outer][k] per plane; F16 (PL = 1 only): one fp16 plane instead
-template <bool KC, int PL = 3, bool F16 = false>
+template <bool KC, int PL = 3, bool F16 = false, bool PRE = false>
 __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r) {
     static_assert(!F16 || PL == 1, "the fp16 image is a single plane");
+    static_assert(!PRE || (PL == 1 && !F16), "pre-packed bf16 pairs are the one bf16 plane");
     const int tid = threadIdx.x;
     if (KC) {
 #pragma unroll
@@ -238,7 +284,10 @@ __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r
             const int idx = tid + i * 512;
             const int o = sp_row(idx >> 3), k = (idx & 7) << 2;
             unsigned a1, a2, a3, b1, b2, b3;
-            if (F16) {
+            if (PRE) {
+                a1 = __builtin_bit_cast(unsigned, r.v[4 * i + 0]); b1 = __builtin_bit_cast(unsigned, r.v[4 * i + 1]);
+                a2 = a3 = b2 = b3 = 0;
+            } else if (F16) {
                 a1 = pack_f16(r.v[4 * i + 0], r.v[4 * i + 1]); b1 = pack_f16(r.v[4 * i + 2], r.v[4 * i + 3]);
                 a2 = a3 = b2 = b3 = 0;
             } else if (PL == 1) {
@@ -258,7 +307,10 @@ __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + i * 512;
             unsigned a1, a2, a3, b1, b2, b3;
-            if (F16) {
+            if (PRE) {
+                a1 = __builtin_bit_cast(unsigned, r.v[4 * i + 0]); b1 = __builtin_bit_cast(unsigned, r.v[4 * i + 1]);
+                a2 = a3 = b2 = b3 = 0;
+            } else if (F16) {
                 a1 = pack_f16(r.v[4 * i + 0], r.v[4 * i + 1]); b1 = pack_f16(r.v[4 * i + 2], r.v[4 * i + 3]);
                 a2 = a3 = b2 = b3 = 0;
             } else if (PL == 1) {
@@ -313,7 +365,7 @@ __device__ __forceinline__ void sp_compute(const __bf16* Af, const __bf16* Bf, c
     }
 }
 
-template <bool AKC, bool BKC, bool VEC, int PL = 3, bool F16 = false>
+template <bool AKC, bool BKC, bool VEC, int PL = 3, bool F16 = false, bool ABF = false>
 __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem, int bx, int by, int bz) {
     __bf16* As = smem;
     __bf16* Bs = smem + PL * SP_PLANE;
@@ -334,7 +386,8 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
     const __bf16* Bf = Bs + (wn * 32 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
 
     SpRegs ra, rb;
-    sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, kbeg, a.M, kend, ra);
+    if (ABF) sp_load_bf16<AKC>(reinterpret_cast<const unsigned short*>(a.A), a.sa_o, a.sa_k, m0, kbeg, a.M, kend, ra);
+    else sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, kbeg, a.M, kend, ra);
     sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, kbeg, a.N, kend, rb);
     // row sums of A for the first column tile's blocks (outer-contiguous A: this thread's two items of a k-tile are the same
     // four rows m at two k): the bias gradient of a weight-gradient product without a second pass over dY
@@ -346,11 +399,12 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
         if (!AKC && PL == 3 && do_rs) {
             rs.x += ra.v[0] + ra.v[4]; rs.y += ra.v[1] + ra.v[5]; rs.z += ra.v[2] + ra.v[6]; rs.w += ra.v[3] + ra.v[7];
         }
-        sp_store<AKC, PL, F16>(As, ra);
+        sp_store<AKC, PL, F16, ABF>(As, ra);
         sp_store<BKC, PL, F16>(Bs, rb);
         __syncthreads();
         if (k0 + SP_BK < kend) {
-            sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, k0 + SP_BK, a.M, kend, ra);
+            if (ABF) sp_load_bf16<AKC>(reinterpret_cast<const unsigned short*>(a.A), a.sa_o, a.sa_k, m0, k0 + SP_BK, a.M, kend, ra);
+            else sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, k0 + SP_BK, a.M, kend, ra);
             sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, k0 + SP_BK, a.N, kend, rb);
         }
         sp_compute<PL, AKC, BKC, F16>(Af, Bf, As, Bs, wm * 64, wn * 32, acc);
@@ -396,10 +450,10 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
 // Waves per SIMD asked of the compiler: 4 (two 8-wave blocks per CU: <= 128 VGPRs -- without the bound the forward group kernel
 // took 134 and two single-product layouts 130, i.e. ONE block per CU), 6 for the one-plane kernels of the 2-byte mode (20 KB of
 // LDS: three blocks per CU at <= 80 VGPRs, a few spills; configs[4] 33.3 -> 32.8 ms; 8 spills everything: 122 ms).
-template <bool AKC, bool BKC, bool VEC, int PL = 3, bool F16 = false>
+template <bool AKC, bool BKC, bool VEC, int PL = 3, bool F16 = false, bool ABF = false>
 __global__ __launch_bounds__(512, PL == 1 ? 6 : 4) void gemm_split_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) __bf16 smem[2 * PL * SP_PLANE];      // 60 / 40 / 20 KB
-    gemm_split_body<AKC, BKC, VEC, PL, F16>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    gemm_split_body<AKC, BKC, VEC, PL, F16, ABF>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Grouped launch: the blocks of up to GROUP_MAX independent products of one operand layout (e.g. all "TN": both operands
@@ -432,6 +486,13 @@ static thread_local int g_gemm_planes = 3;
 void vag_gemm_set_planes(int planes) { g_gemm_planes = (planes == 2 || planes == 1 || planes == 11) ? planes : 3; }
 
 static int gemm_split_dispatch(const GemmArgs& g, bool akc, bool bkc, bool vec, dim3 grid, hipStream_t s) {
+    if (g.a_bf16) {         // the head's two vocabulary-sized gradient products over a bf16 d(logits) chunk
+        if (g_gemm_planes != 1 || bkc || !vec) return VAG_EINVAL;
+        if (akc) hipLaunchKernelGGL((gemm_split_kernel<true, false, true, 1, false, true>), grid, dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((gemm_split_kernel<false, false, true, 1, false, true>), grid, dim3(512), 0, s, g);
+        VAG_LAUNCH_CHECK();
+        return VAG_OK;
+    }
 #define VAG_SPLIT_CASE(AK, BKc, V)                                                                    \
     if (akc == AK && bkc == BKc && vec == V) {                                                        \
         if (g_gemm_planes == 2) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 2>), grid, dim3(512), 0, s, g);   \
@@ -665,7 +726,7 @@ int vag_gemm_group_end(hipStream_t stream) {
 
 int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
                     const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc,
-                    const float* bias, int act, hipStream_t stream, int c_half, float* rowsum) {
+                    const float* bias, int act, hipStream_t stream, int c_half, float* rowsum, int a_bf16) {
     const bool opt_f32mfma = vag_opt().gemm_f32mfma != 0;      // vag_set_option("gemm_f32mfma"): the bf16x6 bound test flips it
     const bool opt_nogroup = vag_opt().gemm_nogroup != 0;
     VAG_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && A && B && C);
@@ -679,7 +740,8 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     const bool bkc = (sbk == 1);        // B: k contiguous
     g.sa_o = sam; g.sa_k = sak; g.sb_o = sbn; g.sb_k = sbk;
     g.ldc = ldc; g.M = (int)M; g.N = (int)N; g.K = (int)K;
-    g.alpha = alpha; g.beta = beta; g.act = act; g.c_half = c_half; g.rowsum = rowsum;
+    g.alpha = alpha; g.beta = beta; g.act = act; g.c_half = c_half; g.rowsum = rowsum; g.a_bf16 = a_bf16;
+    VAG_CHECK_ARG(!a_bf16 || (g_gemm_planes == 1 && g_group_depth == 0 && !rowsum));     // one-plane bf16 kernel, launched at once
     VAG_CHECK_ARG(!c_half || beta == 0.f);      // fp16 output: plain stores only (no split-K, no accumulation)
     VAG_CHECK_ARG(!rowsum || sam == 1);         // row sums ride on outer-contiguous A tiles only
     if (rowsum && g_gemm_planes != 3) {         // ... and on the three-plane kernels only: otherwise a column-sum pass over A
@@ -704,6 +766,7 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     const double atomic_rate = 3.0e6;
     for (int64_t t = 64; t <= 128; t *= 2) {
         if (t == 128 && (M <= 64 || N <= 64)) continue;
+        if (t == 64 && a_bf16 && M > 64 && N > 64) continue;       // a bf16-stored operand: the 128 x 128 one-plane kernel only
         const double eff = (t == 128) ? (opt_f32mfma ? 0.62 : 0.64) : 0.42;   // fraction of the f32-MFMA peak
         const int64_t base = cdiv64(M, t) * cdiv64(N, t);
         for (int64_t sp = 1; sp <= 64; sp += (sp < 16 ? 1 : sp < 32 ? 4 : 8)) {      // few tiles, long K (a row chunk of d(tmid)): up to 64
@@ -735,6 +798,7 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
         fprintf(stderr, "[vag_gemm] M=%lld N=%lld K=%lld akc=%d bkc=%d beta=%g -> T=%lld splitk=%lld model=%.1f us\n",
                 (long long)M, (long long)N, (long long)K, (int)akc, (int)bkc, (double)beta, (long long)T, (long long)splitk, best);
     const bool big = (T == 128);
+    VAG_CHECK_ARG(!a_bf16 || (big && !opt_f32mfma));       // a bf16-stored operand exists for the one-plane split kernel only
     if (rowsum && (!big || opt_f32mfma)) {          // the other kernels do not carry row sums: a column-sum pass over A instead
         VAG_TRY(vag_colsum_launch(A, K, M, sak, rowsum, stream));
         g.rowsum = nullptr;
@@ -759,11 +823,12 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
 
 // One product launched at once (not queued into an open group bracket) with `planes` bf16 planes per operand.
 int vag_gemm_launch_planes(int planes, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
-                           const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc, hipStream_t stream) {
+                           const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc, hipStream_t stream,
+                           int a_bf16) {
     const int depth = g_group_depth, pl = g_gemm_planes;
     g_group_depth = 0;
     g_gemm_planes = planes;
-    const int rc = vag_gemm_launch(M, N, K, alpha, A, sam, sak, B, sbk, sbn, beta, C, ldc, nullptr, 0, stream, 0);
+    const int rc = vag_gemm_launch(M, N, K, alpha, A, sam, sak, B, sbk, sbn, beta, C, ldc, nullptr, 0, stream, 0, nullptr, a_bf16);
     g_group_depth = depth;
     g_gemm_planes = pl;
     return rc;

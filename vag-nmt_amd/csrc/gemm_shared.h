@@ -12,6 +12,7 @@ struct GemmArgs {
     float alpha, beta;
     int act, splitk;
     int c_half;           // 1: C is stored as fp16 (outputs that the recurrences re-read every step); needs beta == 0, no split-K
+    int a_bf16;           // 1: A is stored as bf16 (2 bytes per element, same element strides): one-plane bf16 kernel only
     float* rowsum;        // optional (A outer-contiguous only): rowsum[m] += sum_k A(m,k), i.e. the bias gradient sum_r dY[r,m] of a
                           // weight-gradient product g_W += dY^T X, taken from the A tiles the product loads anyway
 };

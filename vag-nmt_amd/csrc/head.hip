@@ -240,7 +240,9 @@ __global__ __launch_bounds__(256) void ce_bwd_colsum_kernel(float* __restrict__ 
                                                             const float* __restrict__ vw, const float* __restrict__ lse,
                                                             const float* __restrict__ inv_cnt,
                                                             const float* __restrict__ d_loss, int rows, int rows_per,
-                                                            float* __restrict__ g_bias) {
+                                                            float* __restrict__ g_bias, unsigned short* __restrict__ out16) {
+    // out16 != NULL (2-byte storage mode, chunked head): d(logits) is written as bf16 into out16 (row stride ldl elements) and
+    // the fp32 logits are left alone -- its two consumers round it to one bf16 plane anyway, and read half the bytes this way
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= ldl) return;
     const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
@@ -264,7 +266,8 @@ __global__ __launch_bounds__(256) void ce_bwd_colsum_kernel(float* __restrict__ 
             if (r + u < r1) {
                 float g = 0.f;
                 if (j < V) g = coef[u] * (__expf(x[u] - l[u]) - (j == tg[u] ? 1.f : 0.f));
-                logits[(int64_t)(r + u) * ldl + j] = g;
+                if (out16) out16[(int64_t)(r + u) * ldl + j] = __builtin_bit_cast(unsigned short, (__bf16)g);
+                else logits[(int64_t)(r + u) * ldl + j] = g;
                 acc += g;
             }
         }
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256) void ce_bwd_colsum_kernel(float* __restrict__ 
 }
 int vag_ce_bwd_colsum_launch(float* logits, int64_t ldl, int64_t rows, int64_t V, const int64_t* tgt, int64_t B, int64_t Tt,
                              const float* vw, const float* lse, const float* inv_cnt, const float* d_loss, float* g_bias,
-                             hipStream_t s) {
+                             hipStream_t s, void* out16) {
     VAG_CHECK_ARG(logits && tgt && vw && lse && inv_cnt && d_loss && g_bias && rows % B == 0 && rows <= B * Tt && V > 0 &&
                   ldl >= V);      // rows < B*Tt: a chunk of whole time steps (tgt / lse already offset by the caller)
     if (rows == 0) return VAG_OK;
@@ -283,7 +286,7 @@ int vag_ce_bwd_colsum_launch(float* logits, int64_t ldl, int64_t rows, int64_t V
     const int rows_per = (int)cdiv64(rows, splits);
     dim3 grid((unsigned)nbx, (unsigned)cdiv64(rows, rows_per));
     hipLaunchKernelGGL(ce_bwd_colsum_kernel, grid, dim3(256), 0, s, logits, ldl, (int)V, tgt, (int)B, (int)Tt, vw, lse,
-                       inv_cnt, d_loss, (int)rows, rows_per, g_bias);
+                       inv_cnt, d_loss, (int)rows, rows_per, g_bias, reinterpret_cast<unsigned short*>(out16));
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

@@ -120,7 +120,7 @@ int vag_ce_bwd_launch(float* logits, int64_t ldl, int64_t rows, int64_t V, const
                       const float* vw, const float* lse, const float* inv_cnt, const float* d_loss, hipStream_t s);
 int vag_ce_bwd_colsum_launch(float* logits, int64_t ldl, int64_t rows, int64_t V, const int64_t* tgt, int64_t B, int64_t Tt,
                              const float* vw, const float* lse, const float* inv_cnt, const float* d_loss, float* g_bias,
-                             hipStream_t s);
+                             hipStream_t s, void* out16 = nullptr);
 
 int vag_logsoftmax_bwd_launch(const float* logp, int64_t ldlp, float* d, int64_t ldd, int64_t rows, int64_t V,
                               hipStream_t s);
