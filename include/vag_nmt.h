@@ -379,7 +379,10 @@ int vag_set_operator_context(const float* derived, int storage);
 /* Process-wide debug / tuning options by name, for the parity tests and tuning scripts (none is needed in normal use):
  * "gemm_f32mfma" (1: every product on the exact f32-input MFMA kernels), "gemm_nogroup", "gemm_force_tile" +
  * "gemm_force_splitk", "gemm_debug", "head_chunk" (rows per chunk of the output head; -1 automatic, 0 never),
- * "head_fuse", "head_bf16_grads".  Returns VAG_EINVAL for an unknown name. */
+ * "head_fuse", "head_bf16_grads", "head_bf16_dlogits" (2-byte mode, chunked head: d(logits) as bf16), "s16_one_plane"
+ * (2-byte mode of vag_train_step: one-plane products), "persistent" / "persistent_dec_bwd" (0: launch chains instead of the
+ * one-launch recurrence kernels), "persist_timing" (vag_recurrence_time), "dec_stamps" / "dec_bwd_stamps" (device address
+ * for phase timestamps of the decoder kernels).  Returns VAG_EINVAL for an unknown name. */
 int vag_set_option(const char* name, int64_t value);
 /* Up to four contiguous device byte ranges copied by one launch (src[i] -> dst[i], bytes[i]; host arrays): a batch's
  * src / lengths / tgt / image rows into the step driver's static input buffers. */
