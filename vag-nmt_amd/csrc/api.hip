@@ -189,7 +189,7 @@ static DerivedW derived_layout(float* p, int64_t H) {
 // bi-GRU encoder
 // =====================================================================================================
 struct BiGruWs {
-    float *x, *xp, *hst, *gates, *dgh, *carry, *dx, *whhT;
+    float *x, *xp, *hst, *gates, *dgh, *carry, *dx, *whhT, *gx;
     unsigned* sync;                      // counters of the persistent recurrence kernels (persist.hip)
     int64_t total;
 };
@@ -205,6 +205,7 @@ static BiGruWs bigru_ws(float* ws, int64_t B, int64_t Ts, int64_t E, int64_t H) 
     w.carry = take(4 * B * H);           // backward: [dir][2][B][H]
     w.dx = take(Ts * B * E);             // backward: d(embedded input)
     w.whhT = take(2 * 3 * H * H);        // backward: W_hh^T per direction (H,3H)
+    w.gx = take(3 * Ts * B * H);         // backward, 2-byte mode one-launch kernel: [dir][step][B][3H] fp16 copy of dgh for the exchange
     w.sync = reinterpret_cast<unsigned*>(take(vag_enc_persistent_sync_words(B, Ts)));
     w.total = o;
     return w;
@@ -290,8 +291,14 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
             VAG_TRY(vag_transpose_launch(g.w_hh, 3 * H, H, w.whhT + d * 3 * H * H, s));
         }
     }
-    const bool persist = !s16 && vag_opt().persistent && H == 512 && vag_enc_persistent_ok(B, Ts, H);
-    if (persist) {
+    const bool wide16 = s16 && vag_opt().persistent && vag_enc_wide16_ok(B, Ts, H) && B >= 64;
+    const bool persist = wide16 || (!s16 && vag_opt().persistent && H == 512 && vag_enc_persistent_ok(B, Ts, H));
+    if (wide16) {
+        // 2-byte mode, wide batches: the twin of the forward's one-launch kernel (fp16 W_hh^T slice in registers, gate gradients
+        // exchanged as fp16 x 2^12 -- what the chain's fp16-pipe product rounds them to)
+        VAG_TRY(vag_enc_bwd_wide16_launch(reinterpret_cast<const vag_half*>(whhT), d_enc, w.gates, w.hst, lengths, rng, p_ctx, d_xp,
+                                          w.dgh, reinterpret_cast<vag_half*>(w.gx), w.sync, B, Ts, H, s));
+    } else if (persist) {
         // the whole backward recurrence, both directions, in ONE launch (persist.hip)
         VAG_TRY(vag_enc_bwd_persistent_launch(whhT, d_enc, w.gates, w.hst, lengths, rng, p_ctx, d_xp, w.dgh, w.sync, B, Ts, H, s));
     }

@@ -603,6 +603,179 @@ __global__ __launch_bounds__(512, 1) void enc_bwd_persistent_kernel(EncBArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Encoder backward recurrence, 2-byte storage mode, wide batches (configs[4]): the twin of enc_fwd_wide16_kernel.  Same grid
+// (2 directions x ceil(B/64) row groups x H/32 unit slices), same wave roles: wave (kq, ch) holds rows [16 ch, 16 ch + 16) of
+// the workgroup's 32 rows of the stored-fp16 W_hh^T over K quarter kq of K = 3H (96 VGPRs at H = 1024) and takes the four
+// row tiles of the group through it; wave (r, ch) runs the cell backward of row tile r.  The gate gradients are published for
+// the other workgroups' products as fp16 scaled by 2^12 -- exactly what the launch chain's fp16-pipe product rounds them to
+// (skinny_mma_h16, a_scale) -- beside the fp32 copy the weight-gradient products read afterwards.
+struct EncWBArgs {
+    const vag_half* WT16[2];    // (H, 3H) W_hh^T per direction, fp16
+    const float* d_enc;         // (B, Ts, 2H) gradient of the encoder states (before the context dropout)
+    const float* gates;         // [2][Ts][4][B][H]
+    const float* hst;           // [2][Ts+1][B][H]
+    const int* lengths;
+    const uint64_t* rng; float p_ctx;
+    float* d_xp;                // (Ts, B, 6H)
+    float* dgh;                 // [2][Ts][B][3H] fp32
+    vag_half* gx;               // [2][Ts][B][3H] fp16 x 2^12: the exchanged copy
+    unsigned* cnt;              // [2][RG][Ts], zero on entry
+    unsigned* err;
+    int B, Ts, H, RG, CS;
+};
+template <> __device__ __forceinline__ void ld16_sc1<6>(const vag_half* p, u32x4 (&v)[6]) {
+    asm volatile("global_load_dwordx4 %0, %6, off sc1\n\tglobal_load_dwordx4 %1, %6, off offset:64 sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off offset:128 sc1\n\tglobal_load_dwordx4 %3, %6, off offset:192 sc1\n\t"
+                 "global_load_dwordx4 %4, %6, off offset:256 sc1\n\tglobal_load_dwordx4 %5, %6, off offset:320 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]) : "v"(p) : "memory");
+}
+template <> __device__ __forceinline__ void ld16_sc1<12>(const vag_half* p, u32x4 (&v)[12]) {
+    asm volatile("global_load_dwordx4 %0, %12, off sc1\n\tglobal_load_dwordx4 %1, %12, off offset:64 sc1\n\t"
+                 "global_load_dwordx4 %2, %12, off offset:128 sc1\n\tglobal_load_dwordx4 %3, %12, off offset:192 sc1\n\t"
+                 "global_load_dwordx4 %4, %12, off offset:256 sc1\n\tglobal_load_dwordx4 %5, %12, off offset:320 sc1\n\t"
+                 "global_load_dwordx4 %6, %12, off offset:384 sc1\n\tglobal_load_dwordx4 %7, %12, off offset:448 sc1\n\t"
+                 "global_load_dwordx4 %8, %12, off offset:512 sc1\n\tglobal_load_dwordx4 %9, %12, off offset:576 sc1\n\t"
+                 "global_load_dwordx4 %10, %12, off offset:640 sc1\n\tglobal_load_dwordx4 %11, %12, off offset:704 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+                   "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11])
+                 : "v"(p) : "memory");
+}
+
+// HK: half of a wave's k-steps of 32 (K quarter = 3H / 4 = 64 HK): 12 at H = 1024, 6 at H = 512
+template <int HK>
+__global__ __launch_bounds__(512, 1) void enc_bwd_wide16_kernel(EncWBArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wide_lds[];      // [4 row tiles][4 K quarters][2 unit halves][64] float4
+    constexpr float GSCALE = 4096.f;
+    const int wg = blockIdx.x;
+    const int cs = wg % a.CS, rg = (wg / a.CS) % a.RG, d = wg / (a.CS * a.RG);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kq = wave & 3, ch = wave >> 2;             // product role
+    const int er = wave & 3, ech = wave >> 2;            // epilogue role
+    const int H = a.H, B = a.B, Ts = a.Ts, K = 3 * H;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int u0 = cs * 32, m0 = rg * 64;
+    const int kbase = kq * (K >> 2);
+    const int64_t BH = (int64_t)B * H;
+    const int wsrc4 = ld_src4(lane);
+
+    h16x8 wf[2 * HK];
+    {
+        const vag_half* WT = a.WT16[d] + (int64_t)(u0 + 16 * ch + fr) * K + kbase + 8 * fg;
+#pragma unroll
+        for (int s = 0; s < 2 * HK; ++s) {
+            const uint4 q = *reinterpret_cast<const uint4*>(WT + 32 * s);
+            const u32x4 t = {q.x, q.y, q.z, q.w};
+            wf[s] = __builtin_bit_cast(h16x8, t);
+        }
+    }
+    const int em = m0 + 16 * er + fr, eu = u0 + 16 * ech + 4 * fg;
+    const bool eok = em < B;
+    const int len = eok ? a.lengths[em] : 0;
+    float4 carry = make_float4(0.f, 0.f, 0.f, 0.f);           // z * dh of the later step, own units
+    float* dghd = a.dgh + (int64_t)d * Ts * B * K;
+    vag_half* gxd = a.gx + (int64_t)d * Ts * B * K;
+    gu32* cnt = (gu32*)(a.cnt + ((int64_t)d * a.RG + rg) * Ts);
+    const unsigned target = (unsigned)a.CS * 8u;
+    float4* red = reinterpret_cast<float4*>(wide_lds);
+    bool dead = false;
+    const int64_t ld_add = (int64_t)Ts * 2 * H;
+
+    for (int k = Ts - 1; k >= 0; --k) {
+        const int t = d == 0 ? k : Ts - 1 - k;
+        float4 sv[4], hp, e4;
+        if (eok) {
+            const int64_t o = (int64_t)em * H + eu;
+            const float* g = a.gates + ((int64_t)(d * Ts + k) * 4) * BH + o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sv[q] = *reinterpret_cast<const float4*>(g + q * BH);
+            hp = *reinterpret_cast<const float4*>(a.hst + ((int64_t)d * (Ts + 1) + k) * BH + o);
+            e4 = *reinterpret_cast<const float4*>(a.d_enc + (int64_t)em * ld_add + (int64_t)t * 2 * H + d * H + eu);
+        }
+        float4 dh = carry;
+        if (k < Ts - 1) {
+            if (threadIdx.x == 0 && !dead) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(cnt + (k + 1), RLX_AGENT) < target) {
+                    if (++spins > SPIN_LIMIT) { note_timeout(a.err); dead = true; break; }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = min(m0 + 16 * r + ld_row(lane), B - 1);          // quad-contiguous load mapping (see ld_row)
+                const vag_half* gp = gxd + ((int64_t)(k + 1) * B + row) * K + kbase + 8 * (lane & 3);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int hf_ = 0; hf_ < 2; ++hf_) {
+                    u32x4 gq[HK];
+                    ld16_sc1<HK>(gp + hf_ * HK * 32, gq);
+#pragma unroll
+                    for (int s = 0; s < HK; ++s) {
+                        u32x4 q = gq[s];
+                        q[0] = (unsigned)__builtin_amdgcn_ds_bpermute(wsrc4, (int)q[0]);
+                        q[1] = (unsigned)__builtin_amdgcn_ds_bpermute(wsrc4, (int)q[1]);
+                        q[2] = (unsigned)__builtin_amdgcn_ds_bpermute(wsrc4, (int)q[2]);
+                        q[3] = (unsigned)__builtin_amdgcn_ds_bpermute(wsrc4, (int)q[3]);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[hf_ * HK + s], __builtin_bit_cast(h16x8, q), acc, 0, 0, 0);
+                    }
+                }
+                red[(((r * 4 + kq) * 2 + ch)) * 64 + lane] =
+                    make_float4(acc[0] * (1.f / GSCALE), acc[1] * (1.f / GSCALE), acc[2] * (1.f / GSCALE), acc[3] * (1.f / GSCALE));
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 o = red[(((er * 4 + q) * 2 + ech)) * 64 + lane];
+                dh.x += o.x; dh.y += o.y; dh.z += o.z; dh.w += o.w;
+            }
+        }
+        if (eok) {
+            const bool active = t < len;
+            float dhv[4] = {dh.x, dh.y, dh.z, dh.w};
+            float gi[3][4], gh[3][4], cy[4];
+            if (!active) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { gi[0][q] = gi[1][q] = gi[2][q] = gh[0][q] = gh[1][q] = gh[2][q] = 0.f; cy[q] = dhv[q]; }
+            } else {
+                const float ev[4] = {e4.x, e4.y, e4.z, e4.w};
+                const float r_[4] = {sv[0].x, sv[0].y, sv[0].z, sv[0].w}, z_[4] = {sv[1].x, sv[1].y, sv[1].z, sv[1].w};
+                const float n_[4] = {sv[2].x, sv[2].y, sv[2].z, sv[2].w}, hn[4] = {sv[3].x, sv[3].y, sv[3].z, sv[3].w};
+                const float hpv[4] = {hp.x, hp.y, hp.z, hp.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float e = ev[q];
+                    if (a.rng && a.p_ctx > 0.f)
+                        e *= vag_drop_mul(a.rng, VAG_DROP_ENC_CTX, (uint64_t)em * ld_add + (uint64_t)t * 2 * H + d * H + eu + q, a.p_ctx);
+                    const float x = dhv[q] + e;
+                    const float dn_pre = x * (1.f - z_[q]) * (1.f - n_[q] * n_[q]);
+                    const float dz_pre = x * (hpv[q] - n_[q]) * z_[q] * (1.f - z_[q]);
+                    const float dr_pre = dn_pre * hn[q] * r_[q] * (1.f - r_[q]);
+                    gi[0][q] = dr_pre; gi[1][q] = dz_pre; gi[2][q] = dn_pre;
+                    gh[0][q] = dr_pre; gh[1][q] = dz_pre; gh[2][q] = dn_pre * r_[q];
+                    cy[q] = x * z_[q];
+                }
+            }
+            carry = make_float4(cy[0], cy[1], cy[2], cy[3]);
+            const int64_t go = ((int64_t)k * B + em) * K + eu;
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                st_sc1_h4(gxd + go + g * H, gh[g][0] * GSCALE, gh[g][1] * GSCALE, gh[g][2] * GSCALE, gh[g][3] * GSCALE);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(cnt + k, 1u, RLX_AGENT);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) *reinterpret_cast<float4*>(dghd + go + g * H) = make_float4(gh[g][0], gh[g][1], gh[g][2], gh[g][3]);
+            float* gio = a.d_xp + ((int64_t)t * B + em) * 6 * H + d * 3 * H + eu;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) *reinterpret_cast<float4*>(gio + g * H) = make_float4(gi[g][0], gi[g][1], gi[g][2], gi[g][3]);
+        } else if (lane == 0) {
+            __hip_atomic_fetch_add(cnt + k, 1u, RLX_AGENT);                     // a tile wholly past the batch edge still signs
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Decoder forward recurrence, teacher forced (layers/NMT_Decoder.py:109-129 x the loop of models/...V11.py:138-146), in ONE
 // launch.  As a chain of launches a step is 4 kernels and ~24 us; every one of them re-reads, per workgroup, weights that
 // never change and keys that never change.  Here everything that is constant over the steps lives on chip:
@@ -1484,6 +1657,39 @@ int vag_enc_fwd_wide16_launch(const float* xp, const vag_half* w16_fw, const vag
     if (H == 512) hipLaunchKernelGGL(enc_fwd_wide16_kernel<4>, grid, dim3(512), lds, s, a);
     else hipLaunchKernelGGL(enc_fwd_wide16_kernel<8>, grid, dim3(512), lds, s, a);
     if (timed) ptimer_end(0, s);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+int vag_enc_bwd_wide16_launch(const vag_half* wt16, const float* d_enc, const float* gates, const float* hst, const int* lengths,
+                              const uint64_t* rng, float p_ctx, float* d_xp, float* dgh, vag_half* gx, unsigned* sync, int64_t B,
+                              int64_t Ts, int64_t H, hipStream_t s) {
+    VAG_CHECK_ARG(wt16 && d_enc && gates && hst && lengths && d_xp && dgh && gx && sync && vag_enc_wide16_ok(B, Ts, H));
+    VAG_CHECK_ARG(aligned16(wt16) && aligned16(d_enc) && aligned16(gates) && aligned16(hst) && aligned16(d_xp) && aligned16(dgh) &&
+                  aligned16(gx));
+    EncWBArgs a;
+    a.WT16[0] = wt16; a.WT16[1] = wt16 + 3 * H * H; a.d_enc = d_enc; a.gates = gates; a.hst = hst; a.lengths = lengths;
+    a.rng = rng; a.p_ctx = p_ctx; a.d_xp = d_xp; a.dgh = dgh; a.gx = gx;
+    a.B = (int)B; a.Ts = (int)Ts; a.H = (int)H; a.RG = (int)cdiv64(B, 64); a.CS = (int)(H / 32);
+    const int nwords = (int)vag_enc_persistent_sync_words(B, Ts);
+    a.cnt = sync; a.err = sync + (nwords - 64);
+    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
+    VAG_LAUNCH_CHECK();
+    const size_t lds = 84 * 1024;                      // 32 KB of reduction space; the rest keeps the CU to one workgroup
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bwd_wide16_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bwd_wide16_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return VAG_EINVAL;
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)(2 * a.RG * a.CS));
+    const bool timed = ptimer_begin(2, s);
+    if (H == 512) hipLaunchKernelGGL(enc_bwd_wide16_kernel<6>, grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL(enc_bwd_wide16_kernel<12>, grid, dim3(512), lds, s, a);
+    if (timed) ptimer_end(2, s);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
