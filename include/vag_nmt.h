@@ -416,6 +416,12 @@ int vag_persistent_timeouts(void);
  * (0 encoder forward, 1 decoder forward, 2 encoder backward, 3 decoder backward) since the last call and resets them; it
  * waits for the last bracketed launch.  bench.py derives the per-family roofline rows from it. */
 int vag_recurrence_time(int kind, double* ms_total, int* launches);
+/* Host-only (no device is touched): the plan the library makes for one grouped launch of n (<= 12) large products C_i (M_i x
+ * N_i) over K_i -- products an operator issues between its group brackets go out as ONE grid per operand layout.  The chip
+ * runs 512 blocks of 128 x 128 at a time and hands them out in index order; the plan is split[i] = number of K slices of
+ * product i (accumulate[i] != 0: the slices add into C; 0: C is overwritten, slicing costs a fill launch) and order[] = the
+ * products sorted by slice length, longest first, chosen by simulating that schedule.  Exposed for tests and tuning. */
+int vag_gemm_group_plan(int n, const int64_t* M, const int64_t* N, const int64_t* K, const int* accumulate, int* split, int* order);
 int64_t vag_recurrence_sync_words(int kind, int64_t B, int64_t T);
 int vag_cgru_recurrence_fwd(const float* pe, const float* mask, const float* h0, const float* xp1, vag_dec_w w, const float* wcat,
                             const float* bcat, const float* encwp, int64_t B, int64_t Ts, int64_t Tt, int64_t H, float* h1,

@@ -169,3 +169,50 @@ def test_checkpoint_roundtrip_with_optimizer_state(tmp_path):
     assert torch.equal(m3.decoder.attn.v, m.decoder.attn.v)
     # parameters are still views of the flat buffer after loading (the fused optimiser keeps working)
     assert m2.decoder.attn.v.data_ptr() == ts2.fp.flat[ts2.fp.offsets["decoder.attn.v"]:].data_ptr()
+
+
+def test_grouped_launch_plan_fills_the_block_slots_and_orders_longest_first():
+    """vag_gemm_group_plan (host only): the decoder's weight-gradient group of configs[1] -- five accumulating products over
+    K = Tt*B = 2560 and one that overwrites a scratch -- used to be cut into 528 equal blocks, a second round of the 512 block
+    slots for 16 of them.  The plan must (a) slice every product so that no slice is shorter than 256, (b) order products by
+    slice length, longest first, (c) beat the one-common-split plan in the list-scheduling model the planner itself uses."""
+    import ctypes as C
+    import heapq
+    from vagnmt_hip import _lib as L
+
+    def plan(shapes):
+        n = len(shapes)
+        M = (C.c_int64 * n)(*[s[0] for s in shapes]); N = (C.c_int64 * n)(*[s[1] for s in shapes])
+        K = (C.c_int64 * n)(*[s[2] for s in shapes]); acc = (C.c_int * n)(*[s[3] for s in shapes])
+        split, order = (C.c_int * n)(), (C.c_int * n)()
+        assert L.lib().vag_gemm_group_plan(n, M, N, K, acc, split, order) == 0
+        return list(split), list(order)
+
+    def makespan(shapes, split, order):
+        slots = [0.0] * 512
+        heapq.heapify(slots)
+        for i in order:
+            Mi, Ni, Ki, _ = shapes[i]
+            steps = -(-(-(-Ki // 32)) // split[i])
+            for _ in range(-(-Mi // 128) * -(-Ni // 128) * split[i]):
+                heapq.heappush(slots, heapq.heappop(slots) + steps + 4.0)
+        return max(slots)
+
+    H, C2, E, R = 512, 1024, 256, 2560
+    shapes = [(3 * H, H, R, 1), (C2, H, R, 1), (3 * H, C2, R, 0), (3 * H, H, R, 1), (3 * H, E, R, 1), (C2, C2, R, 1)]
+    split, order = plan(shapes)
+    assert sorted(order) == list(range(len(shapes)))
+    for (Mi, Ni, Ki, _), s in zip(shapes, split):
+        assert 1 <= s <= max(1, Ki // 256)
+    lens = [-(-(-(-shapes[i][2] // 32)) // split[i]) for i in order]
+    assert lens == sorted(lens, reverse=True)
+    tiles = sum(-(-m // 128) * -(-n // 128) for m, n, _, _ in shapes)
+    common = max(1, (512 + tiles // 2) // tiles)                       # the first version's rule: aim at ~512 blocks
+    old = [common if a else 1 for (_, _, _, a) in shapes]
+    assert makespan(shapes, split, order) <= makespan(shapes, old, list(range(len(shapes))))
+    # heterogeneous K, nothing may be sliced (all overwrite, K < 512): the plan is only an order
+    shapes2 = [(2560, 1024, 1024, 0), (2560, 1536, 256, 0), (2560, 1536, 1024, 0)]
+    split2, order2 = plan(shapes2)
+    assert split2[1] == 1 and shapes2[order2[-1]][2] == 256
+    # bad arguments come back as -EINVAL
+    assert L.lib().vag_gemm_group_plan(0, None, None, None, None, None, None) == -22

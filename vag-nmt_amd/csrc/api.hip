@@ -1355,6 +1355,10 @@ int vag_recurrence_supported(int kind, int64_t B, int64_t Ts, int64_t Tt, int64_
     return 0;
 }
 int vag_persistent_timeouts(void) { return vag_persistent_timeouts_read(); }
+int vag_gemm_group_plan(int n, const int64_t* M, const int64_t* N, const int64_t* K, const int* accumulate, int* split,
+                        int* order) {
+    return vag_gemm_group_plan_host(n, M, N, K, accumulate, split, order);
+}
 int vag_recurrence_time(int kind, double* ms_total, int* launches) { return vag_persistent_time_read(kind, ms_total, launches); }
 int64_t vag_recurrence_sync_words(int kind, int64_t B, int64_t T) {
     return kind == 0 ? vag_enc_persistent_sync_words(B, T) : vag_dec_persistent_sync_words(B, T);

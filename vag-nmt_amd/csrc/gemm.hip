@@ -658,6 +658,18 @@ static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order)
         }
     }
 }
+// Host-only view of the plan (include/vag_nmt.h: vag_gemm_group_plan): tests and tuning scripts
+int vag_gemm_group_plan_host(int n, const int64_t* M, const int64_t* N, const int64_t* K, const int* accumulate, int* split,
+                             int* order) {
+    VAG_CHECK_ARG(n >= 1 && n <= GROUP_MAX && M && N && K && accumulate && split && order);
+    GemmArgs q[GROUP_MAX] = {};
+    for (int i = 0; i < n; ++i) {
+        VAG_CHECK_ARG(M[i] > 0 && N[i] > 0 && K[i] > 0 && M[i] < (1ll << 30) && N[i] < (1ll << 30) && K[i] < (1ll << 30));
+        q[i].M = (int)M[i]; q[i].N = (int)N[i]; q[i].K = (int)K[i]; q[i].beta = accumulate[i] ? 1.f : 0.f; q[i].c_half = 0;
+    }
+    group_plan_compute(q, n, split, order);
+    return VAG_OK;
+}
 static int gemm_group_flush_layout(int lay, hipStream_t stream) {
     const int n = g_qn[lay];
     g_qn[lay] = 0;

@@ -157,6 +157,8 @@ int vag_enc_fwd_wide16_launch(const float* xp, const vag_half* w16_fw, const vag
 int vag_enc_bwd_wide16_launch(const vag_half* wt16, const float* d_enc, const float* gates, const float* hst, const int* lengths,
                               const uint64_t* rng, float p_ctx, float* d_xp, float* dgh, vag_half* gx, unsigned* sync, int64_t B,
                               int64_t Ts, int64_t H, hipStream_t s);
+int vag_gemm_group_plan_host(int n, const int64_t* M, const int64_t* N, const int64_t* K, const int* accumulate, int* split,
+                             int* order);
 int vag_persistent_timeouts_read(void);
 int vag_persistent_time_read(int kind, double* ms_total, int* launches);
 bool vag_dec_bwd_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H);

@@ -110,6 +110,7 @@ PROTOS = {
     "vag_recurrence_supported": (I32, [I32, I64, I64, I64, I64]),
     "vag_persistent_timeouts": (I32, []),
     "vag_recurrence_time": (I32, [I32, P, P]),
+    "vag_gemm_group_plan": (I32, [I32, P, P, P, P, P, P]),
     "vag_comm_unique_id": (I32, [P]),
     "vag_comm_init": (I32, [P, I32, I32, P]),
     "vag_comm_allreduce": (I32, [P, P, I64, P]),
