@@ -1,0 +1,110 @@
+"""the reference's own entry scripts must be able to import the shadow package.
+
+The import lines are read from the reference checkout at test time (nothing of it is stored here) and executed in a child
+interpreter started the way a user would start a script: through ``python -m vagnmt_hip.run`` with the checkout as working
+directory, i.e. with the checkout's own ``machine_translation_vision`` AHEAD on sys.path.  Skipped where /root/reference
+does not exist (the GPU box)."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "vag-nmt_amd")
+REF = "/root/reference"
+
+SCRIPTS = ["nmt_multimodal_beam_DE.py", "nmt_multimodal_beam_FR.py", "nmt_monomodal_beam_DE.py", "nmt_monomodal_beam_FR.py",
+           "test_multimodal.py", "test_monomodal.py", "preprocessing.py"]
+
+PROBE = r'''
+import inspect, json, sys
+%(imports)s
+out = {}
+for name, obj in list(globals().items()):
+    if name.startswith("_") or name in ("inspect", "json", "sys") or not (inspect.isclass(obj) or inspect.ismodule(obj)):
+        continue
+    out[name] = inspect.getsourcefile(obj)
+print("PROBE " + json.dumps(out))
+'''
+
+
+def _import_lines(script):
+    pat = re.compile(r"^(from machine_translation_vision[\w.]* import .+|import machine_translation_vision[\w.]*)\s*$")
+    with open(os.path.join(REF, script)) as f:
+        return [ln.strip() for ln in f if pat.match(ln.strip())]
+
+
+def _run(code, cwd, tmp_path, extra_path=()):
+    script = tmp_path / "probe_script.py"
+    script.write_text(code)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([PKG] + list(extra_path)), PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-W", "ignore", "-m", "vagnmt_hip.run", str(script)], cwd=cwd, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("PROBE ")][-1]
+    return json.loads(line[6:])
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference checkout")
+@pytest.mark.parametrize("script", SCRIPTS)
+def test_reference_script_import_block_runs_against_the_shadow_package(script, tmp_path):
+    lines = _import_lines(script)
+    assert lines, script
+    got = _run(PROBE % {"imports": "\n".join(lines)}, REF, tmp_path, extra_path=[REF])
+    hot = {"NMT_AttentionImagine_Seq2Seq_Beam_V11", "NMT_Seq2Seq_Beam_V2", "PairwiseRankingLoss", "ImageRetrievalRankingLoss",
+           "im_retrieval_eval", "BucketBatchSampler"}
+    for name, src in got.items():
+        if name in hot:
+            assert src.startswith(PKG), (name, src)             # the hot path stays on the HIP implementation
+        else:
+            assert src.startswith(REF), (name, src)             # Meteor, NMT_Seq2Seq_Beam, LIUMCVC_Seq2Seq_Beam: the checkout's
+    assert hot & set(got), got
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference checkout")
+def test_checkout_models_are_built_on_the_hip_layers(tmp_path):
+    """A variant off the hot path still gets the shadowed layers through its relative imports (models/NMT_Seq2Seq_Beam.py:10-11)
+    and the checkout's layers for what this package does not define (LIUMCVC_Decoder, FF)."""
+    code = PROBE % {"imports": "\n".join([
+        "from machine_translation_vision.models import NMT_Seq2Seq_Beam, LIUMCVC_Seq2Seq_Beam",
+        "a = NMT_Seq2Seq_Beam(50, 60, 16, 16, 24)",
+        "b = LIUMCVC_Seq2Seq_Beam(50, 60, 16, 16, 24)",
+        "enc_a, dec_a, enc_b, dec_b = type(a.encoder), type(a.decoder), type(b.encoder), type(b.decoder)",
+        "del a, b"])}
+    got = _run(code, REF, tmp_path, extra_path=[REF])
+    assert got["enc_a"].startswith(PKG) and got["dec_a"].startswith(PKG) and got["enc_b"].startswith(PKG)
+    assert got["dec_b"].startswith(REF)
+
+
+def test_without_a_checkout_the_names_import_and_raise_on_use(tmp_path):
+    code = "\n".join([
+        "from machine_translation_vision.models import NMT_Seq2Seq_Beam, LIUMCVC_Seq2Seq_Beam, NMT_Seq2Seq_Beam_V2",
+        "from machine_translation_vision.models import NMT_AttentionImagine_Seq2Seq_Beam_V11",
+        "from machine_translation_vision.layers import FF, LIUMCVC_Decoder, NMT_Decoder",
+        "import json",
+        "res = {}",
+        "for c in (NMT_Seq2Seq_Beam, LIUMCVC_Seq2Seq_Beam, FF, LIUMCVC_Decoder):",
+        "    try:",
+        "        c(1, 2, 3)",
+        "        res[c.__name__] = 'built'",
+        "    except NotImplementedError:",
+        "        res[c.__name__] = 'raises'",
+        "try:",
+        "    from machine_translation_vision.models import NoSuchModel",
+        "    res['NoSuchModel'] = 'imported'",
+        "except ImportError:",
+        "    res['NoSuchModel'] = 'ImportError'",
+        "try:",
+        "    import machine_translation_vision.meteor",
+        "    res['meteor'] = 'imported'",
+        "except ImportError:",
+        "    res['meteor'] = 'ImportError'",
+        "res['v2'] = NMT_Seq2Seq_Beam_V2.__module__",
+        "print('PROBE ' + json.dumps(res))"])
+    got = _run(code, str(tmp_path), tmp_path)
+    assert got == {"NMT_Seq2Seq_Beam": "raises", "LIUMCVC_Seq2Seq_Beam": "raises", "FF": "raises", "LIUMCVC_Decoder": "raises",
+                   "NoSuchModel": "ImportError", "meteor": "ImportError",
+                   "v2": "machine_translation_vision.models.NMT_Seq2Seq_Beam_V2"}
