@@ -314,6 +314,12 @@ int vag_beam_finish(const float* nll, const int64_t* beam, int64_t max_len, int6
  * seg_off (nseg+1), seg_lr, seg_wd are HOST arrays (read while enqueuing).  step: device int32 counter,
  * incremented here.  norm_out (1): total gradient norm before clipping.  scratch: VAG_ADAM_SCRATCH_BYTES, 8-byte aligned. */
 #define VAG_ADAM_SCRATCH_BYTES 2048
+/* A void gradient is never applied (train.py:44-49 holds for every step that IS applied): when the gradient norm is not
+ * finite, or a persistent recurrence kernel gave up a wait since the previous call (vag_persistent_timeouts; on a replica
+ * of a data-parallel run the give-up reaches every rank as a non-finite entry of the all-reduced gradient), this call leaves
+ * p, m, v and *step unchanged, still zeroes g (zero_grad), writes NaN to norm_out and adds one to the uint32 at byte
+ * VAG_ADAM_SCRATCH_SKIPPED_OFFSET of the scratch (a host reads it from there whenever it likes; TrainStep.skipped_steps). */
+#define VAG_ADAM_SCRATCH_SKIPPED_OFFSET 28
 /* zero_grad != 0: g is left zeroed (the next step's backward accumulates into it; no separate fill pass).
  * scratch must be zero before the FIRST call; every call leaves it ready for the next one.  Three launches.
  * lr_dev: NULL, or one DEVICE float that multiplies every seg_lr when the kernels run: with seg_lr = the groups' relative
@@ -408,8 +414,12 @@ int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_wh
 int vag_recurrence_supported(int kind, int64_t B, int64_t Ts, int64_t Tt, int64_t H);
 /* The persistent kernels wait on each other inside one launch, which needs every workgroup resident at once (one per CU;
  * vag_recurrence_supported checks the CU count).  Their waits are bounded: on a device where that does not hold they give
- * up after ~1 s instead of hanging, the launch's results are then void.  This returns how many waits gave up since the last
- * call (0 in a healthy run) and resets the count; it synchronises the device -- call it at checkpoints, not per step. */
+ * up after ~1 s instead of hanging, the launch's results are then void -- and never applied: the give-up sets a device word
+ * that vag_clip_adam_flat reads on the device (the optimiser step is skipped, see VAG_ADAM_SCRATCH_SKIPPED_OFFSET) and that
+ * the last launch of vag_train_step's backward turns into a non-finite gradient entry, so that every replica of a
+ * data-parallel run skips the same step after the all-reduce.  This returns how many waits gave up since the last
+ * call (0 in a healthy run) and resets the count; it synchronises the device -- call it at checkpoints, not per step.
+ * vag_set_option("persist_spin_limit", n): polls before a wait gives up (0 = default 2^19; tests force a give-up with 1). */
 int vag_persistent_timeouts(void);
 /* Measurement: with vag_set_option("persist_timing", 1) every EAGER launch (not inside a stream capture) of a recurrence
  * kernel is bracketed by HIP events on its stream.  This returns the accumulated kernel time and launch count of one kind

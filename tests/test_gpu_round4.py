@@ -1,0 +1,179 @@
+"""GPU, round 4: (1) a void gradient is never applied -- a persistent recurrence kernel that gives up a wait, or a non-finite
+gradient norm, makes the optimiser skip the step ON THE DEVICE and is reported (VERDICT r3 weak 2 / ADVICE r3 medium;
+semantics kept for every applied step: train.py:44-49); (2) the data-parallel phased sequence with the persistent kernels
+inside its phase graphs."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT, PKG
+
+pytestmark = pytest.mark.gpu
+
+DIMS = (300, 333, 64, 32, 512, 48)       # Vs, Vt, I, E, H, S: H = 512 / B = 64 is what the persistent kernels take
+
+
+def _model(seed=0):
+    from machine_translation_vision.models import NMT_AttentionImagine_Seq2Seq_Beam_V11
+    Vs, Vt, I, E, H, S = DIMS
+    torch.manual_seed(seed)
+    return NMT_AttentionImagine_Seq2Seq_Beam_V11(Vs, Vt, I, E, E, H, S, 0.99, tied_emb=True).cuda()
+
+
+def _batch(seed, B=64, Ts=12, Tt=5):
+    Vs, Vt, I = DIMS[:3]
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(4, Vs, (B, Ts), generator=g)
+    tgt = torch.randint(4, Vt, (B, Tt), generator=g)
+    tgt[:, -1] = 3
+    return src.cuda(), [Ts] * B, tgt.cuda(), torch.randn(B, I, generator=g).abs().cuda()
+
+
+def _driver(seed=0, **kw):
+    from machine_translation_vision.losses import PairwiseRankingLoss
+    from vagnmt_hip.trainer import TrainStep
+    m = _model(seed)
+    vw = torch.ones(DIMS[1], device="cuda")
+    vw[0] = 0
+    return m, TrainStep(m, torch.nn.NLLLoss(weight=vw, reduction="none"), PairwiseRankingLoss(0.1), teacher_force_ratio=1.0, **kw)
+
+
+def _state(ts):
+    torch.cuda.synchronize()
+    return (ts.fp.flat.clone(), ts.fp.m.clone(), ts.fp.v.clone(), int(ts.step_count.item()))
+
+
+def test_persistent_kernels_are_what_this_shape_runs():
+    from vagnmt_hip import _lib as L
+    for kind in (0, 1):
+        assert L.lib().vag_recurrence_supported(kind, 64, 12, 5, 512) == 1
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_forced_give_up_skips_the_step_on_the_device_and_is_reported(use_graph):
+    """Spin limit 1: every wait of the four persistent kernels gives up at once, their results are garbage.  The step must not
+    touch parameters, moments or the step counter; it must leave the gradient buffer zeroed, report NaN as the norm, count
+    one skipped step and make check() raise.  With the limit restored the next steps are healthy and change the weights."""
+    from vagnmt_hip import _lib as L
+    m, ts = _driver(use_graph=use_graph)
+    for s in range(3):                                  # healthy steps (the third one replays the captured graph)
+        ts.step(*_batch(10 + s), teacher=True)
+    assert L.lib().vag_persistent_timeouts() == 0 and ts.skipped_steps() == 0
+    before = _state(ts)
+    L.set_option("persist_spin_limit", 1)
+    try:
+        m2, ts_bad = None, ts
+        if use_graph:
+            ts_bad._graphs.clear()                      # the limit is a kernel argument: captured graphs hold the old one
+            ts_bad._seen.clear()
+            ts.step(*_batch(20), teacher=True)          # eager visit of the shape
+            n_eager = 1
+        else:
+            n_eager = 0
+        ts.step(*_batch(21), teacher=True)              # graph capture + replay (or eager)
+        torch.cuda.synchronize()
+    finally:
+        L.set_option("persist_spin_limit", 0)
+    after = _state(ts)
+    for a, b in zip(before[:3], after[:3]):
+        assert torch.equal(a, b)
+    assert before[3] == after[3]
+    assert float(ts.fp.grad.abs().max()) == 0.0
+    assert torch.isnan(ts.grad_norm).all()
+    assert ts.skipped_steps() == 1 + n_eager
+    with pytest.raises(L.VagError):
+        ts.check()
+    assert L.lib().vag_persistent_timeouts() == 0       # check() read and reset the count
+    ts._graphs.clear()
+    ts._seen.clear()
+    for s in range(3):
+        out = ts.step(*_batch(30 + s), teacher=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out[0]) and torch.isfinite(ts.grad_norm).all()
+    assert int(ts.step_count.item()) == before[3] + 3
+    assert not torch.equal(ts.fp.flat, before[0])
+    assert ts.skipped_steps() == 1 + n_eager
+    ts.check()
+
+
+def test_give_up_reaches_the_gradient_buffer_for_the_all_reduce():
+    """Data parallelism: a give-up on ONE replica must make EVERY replica skip.  The last launch of the backward pass turns
+    the give-up word into a non-finite entry of the flat gradient (the padding row of the encoder embedding, which no other
+    kernel writes); the sum all-reduce spreads it and each replica's norm pass sees it."""
+    from vagnmt_hip import _lib as L
+    m, ts = _driver(use_graph=False)
+    src, lens, tgt, im = _batch(40)
+    lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    m.train()
+    ts.backend.run(src, lt, tgt, im, True, 7)
+    torch.cuda.synchronize()
+    g00 = m.encoder.embedding.weight._vag_grad[0, 0]
+    assert float(g00) == 0.0                            # healthy: nobody writes the padding row's gradient
+    ts.fp.grad.zero_()
+    L.set_option("persist_spin_limit", 1)
+    try:
+        ts.backend.run(src, lt, tgt, im, True, 3)       # the phases of the data-parallel sequence
+        ts.backend.run(src, lt, tgt, im, True, 4, reuse=True)
+        torch.cuda.synchronize()
+    finally:
+        L.set_option("persist_spin_limit", 0)
+    assert torch.isinf(g00)
+    before = _state(ts)
+    # a replica that did NOT give up receives the entry through the all-reduce: emulate it by clearing the local word first
+    assert L.lib().vag_persistent_timeouts() > 0
+    ts._optimizer()                                     # (clears the word as well)
+    after = _state(ts)
+    assert torch.equal(before[0], after[0]) and before[3] == after[3] and ts.skipped_steps() == 1
+    ts.fp.grad[5] = float("inf")                        # no give-up word now: the non-finite norm alone must skip
+    ts._optimizer()
+    torch.cuda.synchronize()
+    assert torch.equal(before[0], ts.fp.flat) and ts.skipped_steps() == 2 and float(ts.fp.grad.abs().max()) == 0.0
+    ts.fp.grad[7] = float("nan")
+    ts._optimizer()
+    torch.cuda.synchronize()
+    assert torch.equal(before[0], ts.fp.flat) and ts.skipped_steps() == 3
+
+
+def _rccl_worker(port, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from vagnmt_hip import _lib as L
+    res = {"supported": [int(L.lib().vag_recurrence_supported(k, 64, 12, 5, 512)) for k in (0, 1)]}
+    for name, kw in (("phased", dict(process_group=dist.group.WORLD, force_phased=True)), ("single", {})):
+        m, ts = _driver(seed=7, use_graph=True, **kw)
+        losses = [float(ts.step(*_batch(1000 + 10 * (s % 2)), teacher=True)[0]) for s in range(6)]
+        torch.cuda.synchronize()
+        res[name] = (ts.fp.flat.cpu().numpy().copy(), losses, dict(ts.stats), ts.skipped_steps())
+    res["timeouts"] = int(L.lib().vag_persistent_timeouts())
+    q.put(res)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_phased_sequence_runs_the_persistent_kernels_inside_its_graphs():
+    """H = 512 / B = 64: graph A holds the persistent encoder forward, decoder forward and decoder backward, graph B the
+    persistent encoder backward, which runs while bucket 0's all-reduce is in flight on RCCL's stream (world 1: what one
+    GPU can rehearse).  No wait may give up, no step may be skipped, results equal the single-graph step."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(29800 + os.getpid() % 2000, q))
+    p.start()
+    res = q.get(timeout=500)
+    p.join(120)
+    assert p.exitcode == 0
+    assert res["supported"] == [1, 1] and res["timeouts"] == 0
+    (fa, la, sa, ka), (fb, lb, sb, kb) = res["phased"], res["single"]
+    assert ka == 0 and kb == 0
+    assert sa["captures"] >= 2 and sa["replays"] >= 4, sa
+    assert np.allclose(la, lb, rtol=2e-4), (la, lb)
+    assert np.allclose(fa, fb, rtol=2e-4, atol=2e-6), np.abs(fa - fb).max()

@@ -47,6 +47,7 @@ void vag_set_derived_override(const float* d) { g_derived = d; }
 // -- their weights (fp16 copies in the derived buffer) and the attention keys pe / projected keys encwp -- are fp16 in
 // memory; every product still accumulates in fp32, master weights, recurrent state, saved gates and all gradients stay fp32.
 static thread_local bool g_store16 = false;
+thread_local bool g_step_poison_inject = false;
 void vag_set_store16(bool on) { g_store16 = on; vag_gemm_set_planes(on ? 2 : 3); }
 const float* vag_get_derived_override() { return g_derived; }
 bool vag_get_store16() { return g_store16; }
@@ -89,8 +90,11 @@ static int head_outw_gemm(int64_t V, int64_t E, int64_t R, const float* dlogits,
 
 // 2-byte storage mode, chunked head: the bf16 copy of a chunk's d(logits) lives behind the chunk inside the (whole-sequence
 // sized) logits buffer; NULL when the mode is off, the chunk is small, or there is no room behind it.
-static void* head_dl16_slot(float* logits, int64_t ldl, int64_t R, int64_t CH) {
+static void* head_dl16_slot(float* logits, int64_t ldl, int64_t R, int64_t CH, int64_t E) {
     if (!head_grads_one_plane() || CH <= 128 || vag_opt().head_bf16_dlogits == 0) return nullptr;
+    // a bf16 A operand exists only for the 128 x 128 one-plane kernel (gemm.hip): narrow embeddings (the cost model then picks
+    // 64-wide tiles), the f32-MFMA switch and a forced tile keep the fp32 in-place d(logits)
+    if (E <= 64 || vag_opt().gemm_f32mfma != 0 || vag_opt().gemm_force_tile != 0) return nullptr;
     if (CH * 3 > R * 2) return nullptr;                      // CH * ldl floats of chunk + CH * ldl / 2 floats of bf16 must fit R * ldl
     return logits + CH * ldl;
 }
@@ -117,6 +121,7 @@ int vag_set_option(const char* name, int64_t value) {
     for (const auto& e : ints)
         if (strcmp(name, e.n) == 0) { *e.p = (int)value; return VAG_OK; }
     if (strcmp(name, "head_chunk") == 0) { o.head_chunk = value; return VAG_OK; }
+    if (strcmp(name, "persist_spin_limit") == 0) { o.persist_spin_limit = value; return VAG_OK; }
     if (strcmp(name, "dec_stamps") == 0) { o.dec_stamps = value; return VAG_OK; }
     if (strcmp(name, "dec_bwd_stamps") == 0) { o.dec_bwd_stamps = value; return VAG_OK; }
     return VAG_EINVAL;
@@ -365,7 +370,8 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
     for (int d = 0; d < 2; ++d)
         VAG_TRY(gemm_nn(R, E, 3 * H, d_xp + d * 3 * H, 6 * H, (d == 0 ? fw : bw).w_ih, E, 1.f, w.dx, E, s));
     VAG_TRY(grp2.end(s));
-    VAG_TRY(vag_embed_scatter_launch(src, 1, Ts, Ts, B, w.dx, E, g_emb, rng, VAG_DROP_ENC_EMB, p_emb, s));
+    VAG_TRY(vag_embed_scatter_launch(src, 1, Ts, Ts, B, w.dx, E, g_emb, rng, VAG_DROP_ENC_EMB, p_emb, s,
+                                     g_step_poison_inject ? vag_persist_poison_word() : nullptr));
     return VAG_OK;
 }
 
@@ -987,7 +993,7 @@ int vag_head_ce_seq_fwd_impl(const float* h2_all, const float* c_all, const floa
                                        nullptr, 0, s));
             if (g_head_fuse.g) {
                 const vag_head_g& g = *g_head_fuse.g;
-                void* dl16 = rows > 128 ? head_dl16_slot(logits, ldl, R, CH) : nullptr;
+                void* dl16 = rows > 128 ? head_dl16_slot(logits, ldl, R, CH, E) : nullptr;
                 VAG_TRY(vag_ce_bwd_colsum_launch(logits, ldl, rows, V, tgt + r0 / B, B, Tt, vocab_weight, lse + r0, inv_cnt,
                                                  g_head_fuse.d_loss, g.out_b, s, dl16));
                 VAG_TRY(head_dt_gemm(rows, E, V, logits, ldl, w.out_w, g_head_fuse.dt + r0 * E, s, dl16));
@@ -1078,7 +1084,7 @@ int vag_head_ce_seq_bwd(const float* h2_all, const float* c_all, const float* e_
         for (int64_t r0 = 0; r0 < R && !fused; r0 += CH) {
             const int64_t rows = R - r0 < CH ? R - r0 : CH;
             VAG_TRY(vag_gemm_launch(rows, V, E, 1.f, tmid + r0 * E, E, 1, w.out_w, 1, E, 0.f, logits, ldl, w.out_b, 0, s));
-            void* dl16 = rows > 128 ? head_dl16_slot(logits, ldl, R, CH) : nullptr;
+            void* dl16 = rows > 128 ? head_dl16_slot(logits, ldl, R, CH, E) : nullptr;
             VAG_TRY(vag_ce_bwd_colsum_launch(logits, ldl, rows, V, tgt + r0 / B, B, Tt, vocab_weight, lse + r0, inv_cnt, d_loss,
                                              g.out_b, s, dl16));
             VAG_TRY(head_dt_gemm(rows, E, V, logits, ldl, w.out_w, scratch + r0 * E, s, dl16));

@@ -102,6 +102,7 @@ struct VagOptions {
     int s16_one_plane = 1;       // 2-byte storage mode of the step driver: forward products on ONE fp16 plane, gradient products on
                                  // ONE bf16 plane (0: two bf16 planes everywhere, as the operators on their own use)
     int head_bf16_dlogits = 1;   // 2-byte storage mode, chunked head: d(logits) of a chunk is written and read as bf16 (0: fp32 in place)
+    int64_t persist_spin_limit = 0;   // > 0: polls before a persistent kernel's wait gives up (default 2^19); tests force a give-up with 1
     int persist_timing = 0;      // 1: HIP events around the recurrence kernels of eager launches (vag_recurrence_time)
     int64_t dec_bwd_stamps = 0;  // the same for the persistent decoder backward
     int64_t dec_stamps = 0;      // device address of Tt x 8 uint64 for the persistent decoder's phase timestamps (0: none)

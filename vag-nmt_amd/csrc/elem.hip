@@ -45,7 +45,12 @@ int vag_embed_gather_launch(const int64_t* idx, int64_t ist, int64_t isb, int64_
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ idx, int64_t ist, int64_t isb,
                                                             int T, int B, const float* __restrict__ g, int E,
                                                             float* __restrict__ gW, const uint64_t* rng, int sid,
-                                                            float p) {
+                                                            float p, const unsigned* poison) {
+    // a persistent recurrence of this step gave up a wait (persist.hip: g_persist_poison): its gradient is void.  The padding
+    // row's first entry (never touched otherwise) becomes non-finite, so that the norm pass -- after the all-reduce, on every
+    // replica -- sees it and the optimiser skips the step (optim.hip)
+    if (poison && blockIdx.x == 0 && threadIdx.x == 0 && __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+        gW[0] = __builtin_inff();
     const int E4 = E >> 2;
     const int64_t total = (int64_t)T * B * E4;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -71,11 +76,12 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __res
 }
 
 int vag_embed_scatter_launch(const int64_t* idx, int64_t ist, int64_t isb, int64_t T, int64_t B, const float* g,
-                             int64_t E, float* gW, const uint64_t* rng, int sid, float p, hipStream_t s) {
+                             int64_t E, float* gW, const uint64_t* rng, int sid, float p, hipStream_t s,
+                             const unsigned* poison) {
     VAG_CHECK_ARG(idx && g && gW && E > 0 && E % 4 == 0 && T >= 0 && B >= 0);
     if (T * B == 0) return VAG_OK;
     hipLaunchKernelGGL(embed_scatter_kernel, grid1d(T * B * E / 4), dim3(256), 0, s, idx, ist, isb, (int)T, (int)B, g,
-                       (int)E, gW, rng, sid, p);
+                       (int)E, gW, rng, sid, p, poison);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

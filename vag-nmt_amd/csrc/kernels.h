@@ -9,7 +9,11 @@ int vag_embed_gather_launch(const int64_t* idx, int64_t ist, int64_t isb, int64_
                             int64_t E, float* out, const uint64_t* rng, int sid, float p, hipStream_t s);
 // gW[idx, :] += g[(t*B+b), :] * dropout, skipping idx == 0 (padding_idx)
 int vag_embed_scatter_launch(const int64_t* idx, int64_t ist, int64_t isb, int64_t T, int64_t B, const float* g,
-                             int64_t E, float* gW, const uint64_t* rng, int sid, float p, hipStream_t s);
+                             int64_t E, float* gW, const uint64_t* rng, int sid, float p, hipStream_t s,
+                             const unsigned* poison = nullptr);   // poison: see embed_scatter_kernel
+// set by vag_train_step around its last phase: the encoder's embedding scatter then carries the persistent kernels' give-up word
+// into the gradient buffer (the per-operator entry points never do: their gradients go to the caller's own optimiser)
+extern thread_local bool g_step_poison_inject;
 
 struct GruBwdSide {
     const float* dh_carry;   // (M,H) gradient arriving from the later time step, or NULL
@@ -160,6 +164,7 @@ int vag_enc_bwd_wide16_launch(const vag_half* wt16, const float* d_enc, const fl
 int vag_gemm_group_plan_host(int n, const int64_t* M, const int64_t* N, const int64_t* K, const int* accumulate, int* split,
                              int* order);
 int vag_persistent_timeouts_read(void);
+unsigned* vag_persist_poison_word(void);     // device word set by a give-up; adam_prep_kernel reads and clears it
 int vag_persistent_time_read(int kind, double* ms_total, int* launches);
 bool vag_dec_bwd_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H);
 int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const float* v, const float* wcatT, const float* whh1T,

@@ -11,11 +11,15 @@ struct AdamScalars {          // lives in the caller's scratch (VAG_ADAM_SCRATCH
     float bc1;                // 1 - beta1^t
     float bc2_sqrt;           // sqrt(1 - beta2^t)
     float lr_base;            // multiplies every segment's learning rate: *lr_dev, or 1
+    unsigned skip;            // 1: this step's gradient is void (non-finite norm, or a persistent recurrence gave up a wait):
+                              // adam_kernel leaves parameters and moments alone and only zeroes the gradient
+    unsigned skipped;         // number of skipped steps so far (VAG_ADAM_SCRATCH_SKIPPED_OFFSET: hosts read it from the scratch)
     // the blocks' partial sums land in 128 slots (2048 double atomics on ONE address serialise in L2: ~25 of the
     // pass's 31 us); the last block to arrive adds the slots up in a fixed order
     double part[SUMSQ_SLOTS];
 };
 static_assert(sizeof(AdamScalars) <= 2048, "vag_clip_adam_flat scratch contract");
+static_assert(offsetof(AdamScalars, skipped) == VAG_ADAM_SCRATCH_SKIPPED_OFFSET, "vag_nmt.h: VAG_ADAM_SCRATCH_SKIPPED_OFFSET");
 
 // Pass 1: sum of squares of the gradient into 128 slots (plain relaxed atomics, no fences: an in-kernel "last block does the
 // scalar work" variant needs a device-scope fence per block, and 2048 of them cost 80 us -- measured -- against 2 us for
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 // Scalar work between the passes (norm, clip coefficient, bias corrections in double, step counter); leaves the slots zeroed
 // for the next call, so no separate zeroing launch is needed.
 __global__ void adam_prep_kernel(AdamScalars* sc, float clip, float grad_scale, float beta1, float beta2, int32_t* step,
-                                 float* norm_out, const float* lr_dev) {
+                                 float* norm_out, const float* lr_dev, unsigned* poison) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double ss = 0.0;
     for (int k = 0; k < SUMSQ_SLOTS; ++k) {                        // fixed order
@@ -62,6 +66,22 @@ __global__ void adam_prep_kernel(AdamScalars* sc, float clip, float grad_scale, 
         sc->part[k] = 0.0;
     }
     sc->sumsq = ss;
+    // A void gradient is never applied: the step is skipped when a persistent recurrence kernel gave up a wait since the last
+    // optimiser step (persist.hip: results of that launch are void) or when the gradient norm is not finite (which is also how a
+    // give-up on ANOTHER data-parallel replica arrives here: elem.hip, embed_scatter_kernel).  Skipped: no parameter, moment or
+    // step-counter change; the gradient buffer is still zeroed; the reported norm is NaN; `skipped` counts.
+    bool bad = !(ss == ss) || ss > 1.0e300 || ss * (double)grad_scale * (double)grad_scale > 3.0e38;
+    if (poison && __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        bad = true;
+        __hip_atomic_store(poison, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    sc->skip = bad ? 1u : 0u;
+    if (bad) {
+        sc->skipped += 1u;
+        sc->coef = 0.f; sc->bc1 = 1.f; sc->bc2_sqrt = 1.f; sc->lr_base = 0.f;
+        if (norm_out) norm_out[0] = __builtin_nanf("");
+        return;
+    }
     const double norm = sqrt(ss) * (double)grad_scale;             // norm of the scaled (averaged) gradient
     double c = (double)clip / (norm + 1e-6);                        // torch.nn.utils.clip_grad_norm_
     if (c > 1.0) c = 1.0;
@@ -91,6 +111,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     const float coef = sc->coef;
     const float step_size = lr * sc->lr_base / sc->bc1;
     const float inv_bc2s = 1.f / sc->bc2_sqrt;
+    if (sc->skip) {                                                 // void gradient (adam_prep_kernel): only throw it away
+        if (zero_grad)
+            for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) g[off + i] = 0.f;
+        return;
+    }
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) {
         const int64_t k = off + i;
         const float pk = p[k];
@@ -118,7 +143,8 @@ int vag_clip_adam_launch(float* p, float* g, float* m, float* v, int64_t n, int 
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, n, sc);
     VAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, sc, clip, grad_scale, beta1, beta2, step, norm_out, lr_dev);
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, sc, clip, grad_scale, beta1, beta2, step, norm_out, lr_dev,
+                       vag_persist_poison_word());
     VAG_LAUNCH_CHECK();
     AdamSegs sg;
     int64_t maxcnt = 0;

@@ -20,19 +20,28 @@
 //     fences.  A step waits only for the 32 workgroups of its own direction and row tile.
 #include "kernels.h"
 #include "gemm_shared.h"
+#include <atomic>
 
 namespace {
 
 typedef unsigned __attribute__((address_space(1))) gu32;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-constexpr unsigned SPIN_LIMIT = 1u << 19;       // polls before giving up (~a second; a healthy wait is a few hundred polls)
+constexpr unsigned SPIN_LIMIT = 1u << 19;       // polls before giving up (~a second; a healthy wait is a few hundred polls);
+                                                // vag_set_option("persist_spin_limit", n) overrides it (tests force a give-up)
 // Waits that gave up since the last vag_persistent_timeouts() (results of such a launch are void): the kernels assume that
 // every workgroup of the grid is resident at once -- one per CU, checked on the host against the CU count -- and a spin is
-// bounded so that a device on which that does not hold (CU masks, a partitioned GPU) drains instead of hanging.
+// bounded so that a device on which that does not hold (CU masks, a partitioned GPU, another process's or a collective's
+// kernels squatting on CUs) drains instead of hanging.  A give-up also sets g_persist_poison, the word the optimiser reads
+// on the device: adam_prep_kernel (optim.hip) skips the update of a step whose recurrences gave up a wait, and the encoder's
+// embedding scatter -- the last launch of a backward pass -- turns the word into a non-finite gradient entry so that under
+// data parallelism EVERY replica sees it after the all-reduce and skips the same step (train.py:44-49 semantics are kept
+// for every step that is applied; a void gradient is never applied).
 __device__ unsigned g_persist_timeouts;
+__device__ unsigned g_persist_poison;
 __device__ __forceinline__ void note_timeout(unsigned* err) {
     __hip_atomic_store((gu32*)err, 1u, RLX_AGENT);
+    __hip_atomic_store((gu32*)&g_persist_poison, 1u, RLX_AGENT);
     atomicAdd(&g_persist_timeouts, 1u);
 }
 
@@ -46,6 +55,7 @@ struct EncPArgs {
     float* enc;                 // (B, Ts, 2H)
     unsigned* cnt;              // [2][RT][Ts], zero on entry
     unsigned* err;              // 1 word, set when a wait gave up
+    unsigned spin;              // polls before a wait gives up
     const uint64_t* rng;        // context dropout (Encoder.py:63-64) applied to enc as it is written (NULL / p_ctx = 0: none)
     float p_ctx;
     int B, Ts, H, RT, CS;
@@ -202,7 +212,7 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_persistent_kernel(EncPArgs a) 
             if (threadIdx.x == 0 && !dead) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(cnt + (k - 1), RLX_AGENT) < (unsigned)a.CS) {
-                    if (++spins > SPIN_LIMIT) { note_timeout(a.err); dead = true; break; }
+                    if (++spins > a.spin) { note_timeout(a.err); dead = true; break; }
                 }
             }
             __syncthreads();
@@ -305,6 +315,7 @@ struct EncWArgs {
     vag_half* hx;               // [2][Ts+1][B][H] fp16 copy of the states for the exchange; slot 0 is written here (zeros)
     unsigned* cnt;              // [2][RG][Ts], zero on entry
     unsigned* err;
+    unsigned spin;
     int B, Ts, H, RG, CS;
 };
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -392,7 +403,7 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_wide16_kernel(EncWArgs a) {
             if (threadIdx.x == 0 && !dead) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(cnt + (k - 1), RLX_AGENT) < target) {
-                    if (++spins > SPIN_LIMIT) { note_timeout(a.err); dead = true; break; }
+                    if (++spins > a.spin) { note_timeout(a.err); dead = true; break; }
                 }
             }
             __syncthreads();
@@ -490,6 +501,7 @@ struct EncBArgs {
     float* dgh;                 // [2][Ts][B][3H]
     unsigned* cnt;              // [2][RT][Ts]
     unsigned* err;
+    unsigned spin;
     int B, Ts, H, RT, CS;
 };
 template <int KS>               // k-steps of 32 per wave: 3H / 8 / 32 (H = 512: 6)
@@ -540,7 +552,7 @@ __global__ __launch_bounds__(512, 1) void enc_bwd_persistent_kernel(EncBArgs a) 
             if (threadIdx.x == 0 && !dead) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(cnt + (k + 1), RLX_AGENT) < (unsigned)a.CS) {
-                    if (++spins > SPIN_LIMIT) { note_timeout(a.err); dead = true; break; }
+                    if (++spins > a.spin) { note_timeout(a.err); dead = true; break; }
                 }
             }
             __syncthreads();
@@ -621,6 +633,7 @@ struct EncWBArgs {
     vag_half* gx;               // [2][Ts][B][3H] fp16 x 2^12: the exchanged copy
     unsigned* cnt;              // [2][RG][Ts], zero on entry
     unsigned* err;
+    unsigned spin;
     int B, Ts, H, RG, CS;
 };
 template <> __device__ __forceinline__ void ld16_sc1<6>(const vag_half* p, u32x4 (&v)[6]) {
@@ -698,7 +711,7 @@ __global__ __launch_bounds__(512, 1) void enc_bwd_wide16_kernel(EncWBArgs a) {
             if (threadIdx.x == 0 && !dead) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(cnt + (k + 1), RLX_AGENT) < target) {
-                    if (++spins > SPIN_LIMIT) { note_timeout(a.err); dead = true; break; }
+                    if (++spins > a.spin) { note_timeout(a.err); dead = true; break; }
                 }
             }
             __syncthreads();
@@ -795,6 +808,7 @@ struct DecPArgs {
     float *h1, *g1, *qhp, *alpha, *h2_all, *g2, *psc;
     unsigned* cnt;              // [4 phases][RT][Tt], zero on entry
     unsigned* err;
+    unsigned spin;
     unsigned long long* dbg;    // NULL, or [Tt][8] 100 MHz timestamps of workgroup 0's phase boundaries (tools/exp_dec_phases.py)
     int B, Ts, Tt, H, RT;
 };
@@ -804,14 +818,14 @@ struct DecPArgs {
 // agent-scope loads until every shard holds its 16 arrivals, then the workgroup's barrier.
 constexpr int SHARDS = 4, SHARD_STRIDE = 16, CNT_WORDS = SHARDS * SHARD_STRIDE;
 __device__ __forceinline__ void arrive(gu32* c, int i) { __hip_atomic_fetch_add(c + (i & (SHARDS - 1)) * SHARD_STRIDE, 1u, RLX_AGENT); }
-__device__ __forceinline__ void wait_count(gu32* c, unsigned want_per_shard, unsigned* err, bool& dead) {
+__device__ __forceinline__ void wait_count(gu32* c, unsigned want_per_shard, unsigned* err, unsigned spin, bool& dead) {
     if (threadIdx.x < 64 && !dead) {
         const int lane = threadIdx.x;
         unsigned spins = 0;
         for (;;) {
             const bool ok = lane >= SHARDS || __hip_atomic_load(c + lane * SHARD_STRIDE, RLX_AGENT) >= want_per_shard;
             if (__all(ok)) break;
-            if (++spins > SPIN_LIMIT) { if (lane == 0) note_timeout(err); dead = true; break; }
+            if (++spins > spin) { if (lane == 0) note_timeout(err); dead = true; break; }
         }
     }
     __syncthreads();
@@ -913,7 +927,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
 #pragma unroll
             for (int s = 0; s < KS; ++s) { ha[s] = *reinterpret_cast<const float4*>(hp + 32 * s); hb[s] = *reinterpret_cast<const float4*>(hp + 32 * s + 4); }
         } else {
-            wait_count(c1 + (t - 1) * CNT_WORDS, PER_SHARD, a.err, dead);
+            wait_count(c1 + (t - 1) * CNT_WORDS, PER_SHARD, a.err, a.spin, dead);
             VAG_STAMP(1);
             ld_rows_sc1<KS>(a.h2_all + ((int64_t)(t - 1) * B + lrow) * H + kbase + 8 * (lane & 3), ha, hb);
 #pragma unroll
@@ -983,7 +997,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
         }
         // ================= phase 2: q = attn_h h1 (:47), hp2 = W_hh2 h1 + b_hh2 (hidden side of gru_2, :129) =================
         VAG_STAMP(2);
-        wait_count(c2 + t * CNT_WORDS, PER_SHARD, a.err, dead);
+        wait_count(c2 + t * CNT_WORDS, PER_SHARD, a.err, a.spin, dead);
         VAG_STAMP(3);
         ld_rows_sc1<KS>(a.h1 + ((int64_t)t * B + lrow) * H + kbase + 8 * (lane & 3), ha, hb);
 #pragma unroll
@@ -1066,7 +1080,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
         }
         // ================= phase 4: softmax (:44), projected context of own columns, gru_2 cell (:126-129) =================
         VAG_STAMP(6);
-        wait_count(c4 + t * CNT_WORDS, PER_SHARD, a.err, dead);
+        wait_count(c4 + t * CNT_WORDS, PER_SHARD, a.err, a.spin, dead);
         VAG_STAMP(7);
         for (int x0 = threadIdx.x; x0 < 16 * Ts; x0 += 1024) {                                // 4-byte sc1 loads, two in flight
             const int x1 = x0 + 512;
@@ -1171,6 +1185,7 @@ struct DecBArgs {
     float* dal;                 // (Tt,B,Ts) accumulated with atomics: zero on entry
     unsigned* cnt;              // [3 phases][RT][Tt] x CNT_WORDS, zero on entry
     unsigned* err;
+    unsigned spin;
     unsigned long long* dbg;    // NULL, or [Tt][8] timestamps of workgroup 0 (tools/exp_dec_bwd_phases.py)
     int B, Ts, Tt, H, RT;
 };
@@ -1327,7 +1342,7 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
             if (x1 < NP) { al1 = a.alpha[o1]; dh1_ = a.dah[o1]; }
             const float qv = threadIdx.x < 256 ? a.qhp[((int64_t)t * B + min(m0 + (int)(threadIdx.x >> 4), B - 1)) * Q + 16 * i + (threadIdx.x & 15)] : 0.f;
             // ================= B: complete d alpha -> ds -> dq of the own query columns =================
-            wait_count(cA + t * CNT_WORDS, PER_SHARD, a.err, dead);
+            wait_count(cA + t * CNT_WORDS, PER_SHARD, a.err, a.spin, dead);
             VAG_STAMP(2);
             float v0, v1;
             const float* p0 = a.dal + o0;
@@ -1404,7 +1419,7 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
             hp1 = *reinterpret_cast<const float4*>((t > 0 ? a.h2_all + (int64_t)(t - 1) * BH : a.h0) + o);
         }
         VAG_STAMP(4);
-        wait_count(cB + t * CNT_WORDS, PER_SHARD, a.err, dead);
+        wait_count(cB + t * CNT_WORDS, PER_SHARD, a.err, a.spin, dead);
         VAG_STAMP(5);
         {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1453,7 +1468,7 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
             hp2 = *reinterpret_cast<const float4*>(a.h1 + (int64_t)(t - 1) * BH + o);
         }
         VAG_STAMP(6);
-        wait_count(cC + t * CNT_WORDS, PER_SHARD, a.err, dead);
+        wait_count(cC + t * CNT_WORDS, PER_SHARD, a.err, a.spin, dead);
         VAG_STAMP(7);
         {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1532,20 +1547,53 @@ int vag_persistent_time_read(int kind, double* ms_total, int* launches) {
     return VAG_OK;
 }
 
-static int persist_cu_count() {
-    static int cus = -1;
-    if (cus < 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-        cus = n;
+// CU count and LDS capacity of the CURRENT device, cached per device id (a process may drive several devices from several
+// threads: atomics, no locks; a racing first query writes the same values twice).
+struct PersistDev { std::atomic<int> cus{-1}; std::atomic<int> lds{-1}; };
+static PersistDev g_pdev[64];
+static PersistDev* persist_dev() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    PersistDev& d = g_pdev[dev];
+    if (d.cus.load(std::memory_order_acquire) < 0) {
+        int n = 0, l = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        if (hipDeviceGetAttribute(&l, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) l = 0;
+        d.lds.store(l, std::memory_order_release);
+        d.cus.store(n, std::memory_order_release);
     }
-    return cus;
+    return &d;
+}
+static int persist_cu_count() {
+    PersistDev* d = persist_dev();
+    return d ? d->cus.load(std::memory_order_acquire) : 0;
+}
+// The kernels are written for gfx950's 160 KB of LDS per CU (84 KB static / up to 160 KB dynamic per workgroup): a device that
+// offers less takes the launch chains.
+static bool persist_lds_ok(int64_t bytes) {
+    PersistDev* d = persist_dev();
+    return d && (int64_t)d->lds.load(std::memory_order_acquire) >= bytes;
+}
+static unsigned spin_limit() {
+    const int64_t v = vag_opt().persist_spin_limit;
+    return v > 0 ? (unsigned)(v > 0x7fffffff ? 0x7fffffff : v) : SPIN_LIMIT;
+}
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and device, from whichever thread comes first
+struct AttrOnce { std::atomic<unsigned long long> done{0}; };
+static bool set_max_lds_once(AttrOnce& o, const void* fn) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    const unsigned long long bit = 1ull << dev;
+    if (o.done.load(std::memory_order_acquire) & bit) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    o.done.fetch_or(bit, std::memory_order_release);
+    return true;
 }
 bool vag_enc_persistent_ok(int64_t B, int64_t Ts, int64_t H) {
     const int cus = persist_cu_count();
     if (!(H == 256 || H == 512 || H == 1024) || B <= 0 || Ts <= 0) return false;
     const int64_t wgs = 2 * cdiv64(B, 16) * (H / 16);
-    return wgs <= cus && (int64_t)(Ts + 1) * B * H * 4 < (1ll << 31);
+    return wgs <= cus && persist_lds_ok(84 * 1024) && (int64_t)(Ts + 1) * B * H * 4 < (1ll << 31);
 }
 int64_t vag_enc_persistent_sync_words(int64_t B, int64_t Ts) { return 2 * cdiv64(B, 16) * Ts + 64; }
 
@@ -1560,7 +1608,7 @@ int vag_enc_fwd_persistent_launch(const float* xp, const float* w_fw, const floa
     a.hst = hst; a.gates = gates; a.enc = enc; a.rng = rng; a.p_ctx = p_ctx;
     a.B = (int)B; a.Ts = (int)Ts; a.H = (int)H; a.RT = (int)cdiv64(B, 16); a.CS = (int)(H / 16);
     const int nwords = (int)vag_enc_persistent_sync_words(B, Ts);
-    a.cnt = sync; a.err = sync + (nwords - 64);
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
     hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
     VAG_LAUNCH_CHECK();
     const dim3 grid((unsigned)(2 * a.RT * a.CS));
@@ -1581,7 +1629,7 @@ static int64_t dec_persistent_lds_bytes(int64_t Ts) {
 bool vag_dec_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H) {
     if (H != 512 || B <= 0 || B > 64 || Ts <= 0 || Tt <= 0 || Ts > 512) return false;
     const int cus = persist_cu_count();
-    return cdiv64(B, 16) * DEC_WGS <= cus && dec_persistent_lds_bytes(Ts) <= 160 * 1024;
+    return cdiv64(B, 16) * DEC_WGS <= cus && dec_persistent_lds_bytes(Ts) <= 160 * 1024 && persist_lds_ok(160 * 1024);
 }
 int64_t vag_dec_persistent_sync_words(int64_t B, int64_t Tt) { return 4 * cdiv64(B, 16) * Tt * CNT_WORDS + 64; }
 
@@ -1599,7 +1647,7 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
     a.b_ih2 = b_ih2; a.h1 = h1; a.g1 = g1; a.qhp = qhp; a.alpha = alpha; a.h2_all = h2_all; a.g2 = g2; a.psc = psc;
     a.B = (int)B; a.Ts = (int)Ts; a.Tt = (int)Tt; a.H = (int)H; a.RT = (int)cdiv64(B, 16);
     const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
-    a.cnt = sync; a.err = sync + (nwords - 64);
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
     a.dbg = reinterpret_cast<unsigned long long*>(vag_opt().dec_stamps);
     const int nsc = (int)(Tt * B * Ts);                              // the scores are accumulated with atomics: start from zero
     hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64((int64_t)nwords + nsc, 256)), dim3(256), 0, s, sync, nwords,
@@ -1607,12 +1655,8 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
     VAG_LAUNCH_CHECK();
     int64_t lds = dec_persistent_lds_bytes(Ts);
     if (lds < 84 * 1024) lds = 84 * 1024;                            // never two workgroups on one CU
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fwd_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess) return VAG_EINVAL;
-        attr_set = true;
-    }
+    static AttrOnce once;
+    if (!set_max_lds_once(once, reinterpret_cast<const void*>(dec_fwd_persistent_kernel))) return VAG_EINVAL;
     const bool timed = ptimer_begin(1, s);
     hipLaunchKernelGGL(dec_fwd_persistent_kernel, dim3((unsigned)(a.RT * DEC_WGS)), dim3(512), (size_t)lds, s, a);
     if (timed) ptimer_end(1, s);
@@ -1624,7 +1668,7 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
 bool vag_enc_wide16_ok(int64_t B, int64_t Ts, int64_t H) {
     if (!(H == 512 || H == 1024) || B < 1 || Ts < 1) return false;
     const int64_t wgs = 2 * cdiv64(B, 64) * (H / 32);
-    if (wgs > persist_cu_count()) return false;
+    if (wgs > persist_cu_count() || !persist_lds_ok(160 * 1024)) return false;
     return 2 * cdiv64(B, 64) * Ts + 64 <= vag_enc_persistent_sync_words(B, Ts);
 }
 int vag_enc_fwd_wide16_launch(const float* xp, const vag_half* w16_fw, const vag_half* w16_bw, const float* b_fw, const float* b_bw,
@@ -1639,19 +1683,14 @@ int vag_enc_fwd_wide16_launch(const float* xp, const vag_half* w16_fw, const vag
     a.hst = hst; a.gates = gates; a.enc = enc; a.hx = hx;
     a.B = (int)B; a.Ts = (int)Ts; a.H = (int)H; a.RG = (int)cdiv64(B, 64); a.CS = (int)(H / 32);
     const int nwords = (int)vag_enc_persistent_sync_words(B, Ts);
-    a.cnt = sync; a.err = sync + (nwords - 64);
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
     hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
     VAG_LAUNCH_CHECK();
     const size_t lds = 96 * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fwd_wide16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fwd_wide16_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return VAG_EINVAL;
-        attr_set = true;
-    }
+    static AttrOnce once4, once8;
+    if (!set_max_lds_once(once4, reinterpret_cast<const void*>(enc_fwd_wide16_kernel<4>)) ||
+        !set_max_lds_once(once8, reinterpret_cast<const void*>(enc_fwd_wide16_kernel<8>)))
+        return VAG_EINVAL;
     const dim3 grid((unsigned)(2 * a.RG * a.CS));
     const bool timed = ptimer_begin(0, s);
     if (H == 512) hipLaunchKernelGGL(enc_fwd_wide16_kernel<4>, grid, dim3(512), lds, s, a);
@@ -1672,19 +1711,14 @@ int vag_enc_bwd_wide16_launch(const vag_half* wt16, const float* d_enc, const fl
     a.rng = rng; a.p_ctx = p_ctx; a.d_xp = d_xp; a.dgh = dgh; a.gx = gx;
     a.B = (int)B; a.Ts = (int)Ts; a.H = (int)H; a.RG = (int)cdiv64(B, 64); a.CS = (int)(H / 32);
     const int nwords = (int)vag_enc_persistent_sync_words(B, Ts);
-    a.cnt = sync; a.err = sync + (nwords - 64);
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
     hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
     VAG_LAUNCH_CHECK();
     const size_t lds = 84 * 1024;                      // 32 KB of reduction space; the rest keeps the CU to one workgroup
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bwd_wide16_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bwd_wide16_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return VAG_EINVAL;
-        attr_set = true;
-    }
+    static AttrOnce once6, once12;
+    if (!set_max_lds_once(once6, reinterpret_cast<const void*>(enc_bwd_wide16_kernel<6>)) ||
+        !set_max_lds_once(once12, reinterpret_cast<const void*>(enc_bwd_wide16_kernel<12>)))
+        return VAG_EINVAL;
     const dim3 grid((unsigned)(2 * a.RG * a.CS));
     const bool timed = ptimer_begin(2, s);
     if (H == 512) hipLaunchKernelGGL(enc_bwd_wide16_kernel<6>, grid, dim3(512), lds, s, a);
@@ -1704,7 +1738,7 @@ int vag_enc_bwd_persistent_launch(const float* whhT, const float* d_enc, const f
     a.rng = rng; a.p_ctx = p_ctx; a.d_xp = d_xp; a.dgh = dgh;
     a.B = (int)B; a.Ts = (int)Ts; a.H = (int)H; a.RT = (int)cdiv64(B, 16); a.CS = (int)(H / 16);
     const int nwords = (int)vag_enc_persistent_sync_words(B, Ts);
-    a.cnt = sync; a.err = sync + (nwords - 64);
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
     hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
     VAG_LAUNCH_CHECK();
     const bool timed = ptimer_begin(2, s);
@@ -1714,6 +1748,12 @@ int vag_enc_bwd_persistent_launch(const float* whhT, const float* d_enc, const f
     return VAG_OK;
 }
 
+// Device address of the word a give-up sets (read and cleared by adam_prep_kernel; NULL if the symbol cannot be resolved).
+unsigned* vag_persist_poison_word(void) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_persist_poison)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return reinterpret_cast<unsigned*>(p);
+}
 // Number of waits that gave up since the last call (synchronises the device).  0 in a healthy run.
 int vag_persistent_timeouts_read(void) {
     unsigned v = 0, z = 0;
@@ -1746,19 +1786,15 @@ int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const flo
     a.dbg = reinterpret_cast<unsigned long long*>(vag_opt().dec_bwd_stamps);
     a.B = (int)B; a.Ts = (int)Ts; a.Tt = (int)Tt; a.H = (int)H; a.RT = (int)cdiv64(B, 16);
     const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
-    a.cnt = sync; a.err = sync + (nwords - 64);
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
     const int nsc = (int)(Tt * B * Ts);
     hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64((int64_t)nwords + nsc, 256)), dim3(256), 0, s, sync, nwords,
                        reinterpret_cast<unsigned*>(dal), nsc);
     VAG_LAUNCH_CHECK();
     int64_t lds = dec_bwd_persistent_lds_bytes(Ts);
     if (lds < 84 * 1024) lds = 84 * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess) return VAG_EINVAL;
-        attr_set = true;
-    }
+    static AttrOnce once;
+    if (!set_max_lds_once(once, reinterpret_cast<const void*>(dec_bwd_persistent_kernel))) return VAG_EINVAL;
     const bool timed = ptimer_begin(3, s);
     hipLaunchKernelGGL(dec_bwd_persistent_kernel, dim3((unsigned)(a.RT * DEC_WGS)), dim3(512), (size_t)lds, s, a);
     if (timed) ptimer_end(3, s);

@@ -236,6 +236,9 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
         }
     }
     if (phases & 4) {
+        // the last launch of the backward pass turns a give-up of any persistent recurrence of this step into a non-finite
+        // gradient entry (persist.hip, optim.hip: the optimiser then skips the step, on every replica)
+        struct Inject { Inject() { g_step_poison_inject = true; } ~Inject() { g_step_poison_inject = false; } } inject;
         VAG_TRY(vag_bigru_seq_bwd(src, lengths, w.enc_fw, w.enc_bw, c.p_emb, c.p_ctx, crng, B, Ts, c.Es, H, k.d_enc, k.ws_enc,
                                   g.enc_emb, g.enc_fw, g.enc_bw, stream));
     }

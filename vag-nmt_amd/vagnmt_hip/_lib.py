@@ -186,7 +186,12 @@ class capture:
         if self._gc:
             gc.collect()
             gc.disable()
-        return self._cm.__enter__()
+        try:
+            return self._cm.__enter__()
+        except BaseException:
+            if self._gc:          # the capture never began (already capturing, allocator error): __exit__ will not run
+                gc.enable()
+            raise
 
     def __exit__(self, *exc):
         import gc

@@ -18,6 +18,8 @@ def save_checkpoint(path, model, train_step=None, extra=None):
     if rng is not None:
         ckpt["dropout_rng"] = rng.detach().cpu().clone()
     if train_step is not None:
+        if hasattr(train_step, "check") and train_step.fp.flat.is_cuda:
+            train_step.check()            # never write a checkpoint over steps the device had to skip without saying so
         fp = train_step.fp
         m, v = {}, {}
         for name, p in fp.named:

@@ -157,6 +157,8 @@ class TrainStep:
         if float(lr) != self.lr:
             self.lr = float(lr)
             self._lr_dev.fill_(self.lr)
+        if self.fp.flat.is_cuda and self.backend is not None and getattr(self.backend, "with_optimizer", False):
+            self.check()                  # a validation point: the loop is synchronising anyway (it just read the dev loss)
 
     # ---- optimiser + collectives ----
     def _optimizer(self):
@@ -205,13 +207,29 @@ class TrainStep:
             if hasattr(self.backend, "after_optimizer"):
                 self.backend.after_optimizer()
 
-    def check(self):
-        """Synchronises and raises if a persistent recurrence kernel had to give up a wait since the last check (its
-        workgroups were not all resident: results of those steps are void).  For checkpoints / the end of an epoch."""
+    SKIPPED_OFFSET = 28          # VAG_ADAM_SCRATCH_SKIPPED_OFFSET (include/vag_nmt.h), bytes into the optimiser scratch
+
+    def skipped_steps(self):
+        """Optimiser steps the device refused to apply so far (non-finite gradient norm, or a persistent recurrence kernel
+        gave up a wait: the parameters, moments and step counter were left alone, ``grad_norm`` reads NaN for such a
+        step).  One 4-byte read = one device sync; 0 in a healthy run."""
+        if not self._scratch.is_cuda:
+            return 0
+        return int(self._scratch.view(torch.int32)[self.SKIPPED_OFFSET // 4].item())
+
+    def check(self, raise_on_skip=True):
+        """Synchronises and raises if steps were skipped or a persistent recurrence kernel had to give up a wait since the
+        last check (its workgroups were not all resident, e.g. another process or a collective's kernels on the same GPU:
+        the results of those launches are void; the optimiser skipped those steps on the device, so the weights are
+        intact).  Called by ``set_lr`` (the validation point of the reference's loop) and by ``save_checkpoint``."""
         from ._lib import lib, VagError
-        n = lib().vag_persistent_timeouts()
-        if n != 0:
-            raise VagError("persistent recurrence kernels: %d waits gave up; disable them with set_option('persistent', 0)" % n)
+        n = lib().vag_persistent_timeouts() if self.fp.flat.is_cuda else 0
+        sk = self.skipped_steps()
+        new_sk, self._skipped_seen = sk - getattr(self, "_skipped_seen", 0), sk
+        if n != 0 or (raise_on_skip and new_sk != 0):
+            raise VagError("%d optimiser step(s) skipped on the device (void gradient); persistent recurrence kernels: %d "
+                           "waits gave up%s" % (new_sk, n, "; a GPU that is not this process's alone needs "
+                                                "set_option('persistent', 0)" if n else ""))
 
     # ---- public ----
     def step(self, src, lengths, tgt, im=None, teacher=None):
