@@ -176,4 +176,8 @@ def test_phased_sequence_runs_the_persistent_kernels_inside_its_graphs():
     assert ka == 0 and kb == 0
     assert sa["captures"] >= 2 and sa["replays"] >= 4, sa
     assert np.allclose(la, lb, rtol=2e-4), (la, lb)
-    assert np.allclose(fa, fb, rtol=2e-4, atol=2e-6), np.abs(fa - fb).max()
+    # the persistent decoder adds score shares with fp32 atomics: two runs agree to rounding only, and six Adam steps turn a
+    # rounding-level difference of a near-zero gradient entry into a fraction of one update (lr = 4e-4): bound the worst entry
+    # by 5 % of one update and the mean by far less
+    assert np.allclose(fa, fb, rtol=2e-4, atol=2e-5), np.abs(fa - fb).max()
+    assert float(np.abs(fa - fb).mean()) <= 2e-7

@@ -52,7 +52,7 @@ def read_rec(kind):
 
 def run(label, squat=None, when="before", reps=5):
     """squat = (workgroups, threads, lds bytes, microseconds)"""
-    t4, k4 = [], []
+    t4, k4, tq = [], [], []
     for _ in range(reps):
         ts.fp.grad.zero_()
         ts.backend.run(src, lt, tgt, im, True, 3)
@@ -60,20 +60,27 @@ def run(label, squat=None, when="before", reps=5):
         read_rec(2)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         main = torch.cuda.current_stream()
+        q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if squat and when == "before":
+            q0.record(side)
             SQ.squat(side.cuda_stream, squat[0], squat[1], squat[2], float(squat[3]), sink.data_ptr())
+            q1.record(side)
         e0.record(main)
         ts.backend.run(src, lt, tgt, im, True, 4, reuse=True)
         e1.record(main)
         if squat and when == "after":
+            q0.record(side)
             SQ.squat(side.cuda_stream, squat[0], squat[1], squat[2], float(squat[3]), sink.data_ptr())
+            q1.record(side)
         torch.cuda.synchronize()
+        if squat:
+            tq.append(q0.elapsed_time(q1) * 1e3)
         t4.append(e0.elapsed_time(e1) * 1e3)
         k4.append(read_rec(2))
     to = L.lib().vag_persistent_timeouts()
-    t4.sort(), k4.sort()
-    print("%-64s phase 4 %7.1f us (min %7.1f)   enc_bwd kernel %7.1f us   give-ups %d" %
-          (label, t4[len(t4) // 2], t4[0], k4[len(k4) // 2], to), flush=True)
+    t4.sort(), k4.sort(), tq.sort()
+    print("%-64s phase 4 %7.1f us (min %7.1f)   enc_bwd kernel %7.1f us   squatter itself %7.1f us   give-ups %d" %
+          (label, t4[len(t4) // 2], t4[0], k4[len(k4) // 2], tq[len(tq) // 2] if tq else 0.0, to), flush=True)
 
 
 print("# persistent encoder backward beside a squatting kernel; configs[1] (B=64, Ts=40, H=512), eager launches, median of 5")

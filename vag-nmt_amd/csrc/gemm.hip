@@ -174,20 +174,22 @@ __global__ __launch_bounds__(NTH) void gemm_tiled_kernel(GemmArgs a) {
 // global -> registers (8 floats per thread per operand tile).
 // KC (k contiguous): two float4 = (row, 4 consecutive k) items.  OC (outer contiguous): two float4 = (k row, 4 consecutive
 // outer) items, stored as they come into the [k][outer] image (sp_oc_off) and transposed by the fragment reads.
-struct SpRegs { float v[8]; };
+template <int NW = 8> struct SpRegsT { float v[4 * (16 / NW)]; };      // 1024 float4 items per operand tile / threads
+typedef SpRegsT<8> SpRegs;
 // k-contiguous operands: the four rows a 32-lane group writes to LDS with one 8-byte store per lane are 4 apart, not
 // consecutive: with the 80-byte row stride rows r, r+4, r+8, r+12 start at banks 0, 16, 0, 16 (mod 32) and tile the 32 banks
 // exactly twice (consecutive rows: PMC had 20 % of the LDS-active cycles as bank conflicts).
 __device__ __forceinline__ int sp_row(int q) { return (q & ~15) | ((q & 3) << 2) | ((q >> 2) & 3); }
 
-template <bool KC, bool VEC>
+template <bool KC, bool VEC, int NW = 8>
 __device__ __forceinline__ void sp_load(const float* __restrict__ P, int64_t so, int64_t sk, int o0, int k0, int OUT,
-                                        int KEND, SpRegs& r) {
+                                        int KEND, SpRegsT<NW>& r) {
+    constexpr int NT = 64 * NW, NI = 1024 / NT;
     const int tid = threadIdx.x;
     if (KC) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + i * 512;
+        for (int i = 0; i < NI; ++i) {
+            const int idx = tid + i * NT;
             const int o = o0 + sp_row(idx >> 3), k = k0 + ((idx & 7) << 2);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (o < OUT) {
@@ -207,8 +209,8 @@ __device__ __forceinline__ void sp_load(const float* __restrict__ P, int64_t so,
         // two float4 along the outer dimension per thread: item idx -> k row idx>>5, outer group (idx&31)*4; a wave reads two
         // 512-byte row segments per instruction.  r.v[4i..4i+3] = the four outer elements of item i.
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + i * 512;
+        for (int i = 0; i < NI; ++i) {
+            const int idx = tid + i * NT;
             const int k = k0 + (idx >> 5), o = o0 + ((idx & 31) << 2);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k < KEND) {
@@ -273,15 +275,16 @@ __device__ __forceinline__ void sp_load_bf16(const unsigned short* __restrict__ 
 }
 
 // registers -> PL (3, 2 or 1) bf16 planes in LDS, image [outer][k] per plane; F16 (PL = 1 only): one fp16 plane instead
-template <bool KC, int PL = 3, bool F16 = false, bool PRE = false>
-__device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r) {
+template <bool KC, int PL = 3, bool F16 = false, bool PRE = false, int NW = 8>
+__device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegsT<NW>& r) {
+    constexpr int NT = 64 * NW, NI = 1024 / NT;
     static_assert(!F16 || PL == 1, "the fp16 image is a single plane");
     static_assert(!PRE || (PL == 1 && !F16), "pre-packed bf16 pairs are the one bf16 plane");
     const int tid = threadIdx.x;
     if (KC) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + i * 512;
+        for (int i = 0; i < NI; ++i) {
+            const int idx = tid + i * NT;
             const int o = sp_row(idx >> 3), k = (idx & 7) << 2;
             unsigned a1, a2, a3, b1, b2, b3;
             if (PRE) {
@@ -304,8 +307,8 @@ __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegs& r
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + i * 512;
+        for (int i = 0; i < NI; ++i) {
+            const int idx = tid + i * NT;
             unsigned a1, a2, a3, b1, b2, b3;
             if (PRE) {
                 a1 = __builtin_bit_cast(unsigned, r.v[4 * i + 0]); b1 = __builtin_bit_cast(unsigned, r.v[4 * i + 1]);
@@ -472,6 +475,125 @@ __global__ __launch_bounds__(512, PL == 1 ? 6 : 4) void gemm_split_group_kernel(
     gemm_split_body<AKC, BKC, true, PL, F16>(a, smem, bx, by, bz);
 }
 
+// ---- round 4: the same block tile on FOUR waves (2 x 2, 64 x 64 outputs each) ----------------------------------------
+// Why: the 8-wave kernel's counters read MFMA 31 % / LDS 39 % / VALU 26 % busy, i.e. its phases run one after the other, and the
+// LDS pipe is as loaded as the matrix pipe.  A 64 x 64 wave tile reads (2 + 2) x 3 fragments per k-step for 24 MFMAs (0.5 reads
+// per MFMA; 64 x 32: 9 for 12 = 0.75), and its four accumulators let consecutive MFMAs go to DIFFERENT accumulators (product-major
+// order), so one wave keeps the matrix pipe busy without a partner in the same phase; the two blocks of a CU (one wave per SIMD
+// each, 256 VGPRs available) are never at the same barrier, so one block's split / store phase runs beside the other's MFMAs.
+template <bool AKC, bool BKC>
+__device__ __forceinline__ void sp_compute4(const __bf16* Af, const __bf16* Bf, const __bf16* As, const __bf16* Bs, int oa, int obn,
+                                            f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i][p] = AKC ? sp_frag(Af + p * SP_PLANE + i * 32 * SP_LD + ks * 16) : sp_frag_tr(As + p * SP_PLANE, oa + 32 * i, ks);
+                bf[i][p] = BKC ? sp_frag(Bf + p * SP_PLANE + i * 32 * SP_LD + ks * 16) : sp_frag_tr(Bs + p * SP_PLANE, obn + 32 * i, ks);
+            }
+        // six products, smallest terms first; within a product the four accumulators take turns
+        constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[q]], bf[j][PB[q]], acc[i][j], 0, 0, 0);
+    }
+}
+
+template <bool AKC, bool BKC, bool VEC>
+__device__ __forceinline__ void gemm_split_body4(const GemmArgs& a, __bf16* smem, int bx, int by, int bz) {
+    __bf16* As = smem;
+    __bf16* Bs = smem + 3 * SP_PLANE;
+    const int m0 = by * 128, n0 = bx * 128;
+    const int kbeg = bz * a.kchunk;
+    const int kend = min(a.K, kbeg + a.kchunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const __bf16* Af = As + (wm * 64 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
+    const __bf16* Bf = Bs + (wn * 64 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
+    SpRegsT<4> ra, rb;
+    sp_load<AKC, VEC, 4>(a.A, a.sa_o, a.sa_k, m0, kbeg, a.M, kend, ra);
+    sp_load<BKC, VEC, 4>(a.B, a.sb_o, a.sb_k, n0, kbeg, a.N, kend, rb);
+    const bool do_rs = !AKC && a.rowsum != nullptr && bx == 0;        // bias gradient from the A tiles (see gemm_split_body)
+    float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k0 = kbeg; k0 < kend; k0 += SP_BK) {
+        if (!AKC && do_rs) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { rs.x += ra.v[4 * i]; rs.y += ra.v[4 * i + 1]; rs.z += ra.v[4 * i + 2]; rs.w += ra.v[4 * i + 3]; }
+        }
+        sp_store<AKC, 3, false, false, 4>(As, ra);
+        sp_store<BKC, 3, false, false, 4>(Bs, rb);
+        __syncthreads();
+        if (k0 + SP_BK < kend) {
+            sp_load<AKC, VEC, 4>(a.A, a.sa_o, a.sa_k, m0, k0 + SP_BK, a.M, kend, ra);
+            sp_load<BKC, VEC, 4>(a.B, a.sb_o, a.sb_k, n0, k0 + SP_BK, a.N, kend, rb);
+        }
+        sp_compute4<AKC, BKC>(Af, Bf, As, Bs, wm * 64, wn * 64, acc);
+        __syncthreads();
+    }
+    if (!AKC && do_rs) {       // 8 threads hold partial sums of the same four rows (item idx -> outer group idx & 31): meet in LDS
+        float4* rs_s = reinterpret_cast<float4*>(smem);
+        rs_s[threadIdx.x] = rs;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            float4 t = rs_s[threadIdx.x];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) {
+                const float4 o = rs_s[threadIdx.x + 32 * q];
+                t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+            }
+            const int m = m0 + 4 * threadIdx.x;
+            if (m + 0 < a.M) atomicAdd(a.rowsum + m + 0, t.x);
+            if (m + 1 < a.M) atomicAdd(a.rowsum + m + 1, t.y);
+            if (m + 2 < a.M) atomicAdd(a.rowsum + m + 2, t.z);
+            if (m + 3 < a.M) atomicAdd(a.rowsum + m + 3, t.w);
+        }
+    }
+    const bool atomic = a.splitk > 1;
+    const bool first = bz == 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (col >= a.N) continue;
+        const float bv = (a.bias && first) ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row0 = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+            if (a.c_half) gemm_epilogue16(acc[i][j], a.C, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, atomic, 1, (int64_t)row0 * a.ldc + col);
+            else gemm_epilogue16(acc[i][j], a.C + (int64_t)row0 * a.ldc + col, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, atomic);
+        }
+    }
+}
+template <bool AKC, bool BKC, bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_split4_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * 3 * SP_PLANE];       // 60 KB: two blocks per CU
+    gemm_split_body4<AKC, BKC, VEC>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 2) void gemm_split4_group_kernel(GemmGroupArgs G) {
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * 3 * SP_PLANE];
+    int p = 0;
+    while (p + 1 < G.n && (int)blockIdx.x >= G.start[p + 1]) ++p;
+    const GemmArgs& a = G.p[p];
+    const int id = blockIdx.x - G.start[p];
+    const int tn = (a.N + 127) / 128, tm = (a.M + 127) / 128;
+    const int bx = id % tn, by = (id / tn) % tm, bz = id / (tn * tm);
+    gemm_split_body4<AKC, BKC, true>(a, smem, bx, by, bz);
+}
+
 // (A double-buffered variant -- 110 KB of LDS, one block per CU, split/store of tile t+1 issued between the k-halves of
 // tile t -- measured 6-9 % slower than this single-stage kernel at two blocks per CU, and was dropped.  So was a
 // wave-specialised one -- 4 producer waves splitting into a second LDS stage while 4 consumer waves run 64x64 MFMA
@@ -495,7 +617,8 @@ static int gemm_split_dispatch(const GemmArgs& g, bool akc, bool bkc, bool vec, 
     }
 #define VAG_SPLIT_CASE(AK, BKc, V)                                                                    \
     if (akc == AK && bkc == BKc && vec == V) {                                                        \
-        if (g_gemm_planes == 2) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 2>), grid, dim3(512), 0, s, g);   \
+        if (g_gemm_planes == 3 && vag_opt().gemm_waves4 != 0) hipLaunchKernelGGL((gemm_split4_kernel<AK, BKc, V>), grid, dim3(256), 0, s, g);   \
+        else if (g_gemm_planes == 2) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 2>), grid, dim3(512), 0, s, g);   \
         else if (g_gemm_planes == 1) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 1>), grid, dim3(512), 0, s, g);   \
         else if (g_gemm_planes == 11) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 1, true>), grid, dim3(512), 0, s, g);   \
         else hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 3>), grid, dim3(512), 0, s, g);        \
@@ -720,6 +843,12 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
     if (g_gemm_planes == 11) { VAG_GROUP_GO(1, true) }
     else if (g_gemm_planes == 1) { VAG_GROUP_GO(1, false) }
     else if (g_gemm_planes == 2) { VAG_GROUP_GO(2, false) }
+    else if (vag_opt().gemm_waves4 != 0) {
+        if (!akc && !bkc) hipLaunchKernelGGL((gemm_split4_group_kernel<false, false>), dim3((unsigned)total), dim3(256), 0, stream, G);
+        else if (akc && !bkc) hipLaunchKernelGGL((gemm_split4_group_kernel<true, false>), dim3((unsigned)total), dim3(256), 0, stream, G);
+        else if (akc && bkc) hipLaunchKernelGGL((gemm_split4_group_kernel<true, true>), dim3((unsigned)total), dim3(256), 0, stream, G);
+        else hipLaunchKernelGGL((gemm_split4_group_kernel<false, true>), dim3((unsigned)total), dim3(256), 0, stream, G);
+    }
     else { VAG_GROUP_GO(3, false) }
 #undef VAG_GROUP_GO
     VAG_LAUNCH_CHECK();
