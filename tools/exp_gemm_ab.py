@@ -1,6 +1,7 @@
-"""A/B of the bf16x6 product kernels: 8 waves (64 x 32 wave tiles) against 4 waves (64 x 64 wave tiles, option gemm_waves4) on the
-step's product shapes (whole vag_gemm_f32 calls replayed from a graph, hot operands), with a bitwise comparison of the results
-(the six products enter every accumulator in the same order in both kernels)."""
+"""A/B of the bf16x6 product kernels: the single-stage kernel against the variant behind a library option (default gemm_pp: the
+ping-pong kernel) on the step's product shapes (whole vag_gemm_f32 calls replayed from a graph, hot operands), with a bitwise
+comparison of the results (the six products enter every accumulator in the same order in both kernels).
+Usage: python tools/exp_gemm_ab.py [option name]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "vag-nmt_amd"))
@@ -8,6 +9,7 @@ import torch
 import bench
 from vagnmt_hip import _lib as L
 
+OPT = sys.argv[1] if len(sys.argv) > 1 else "gemm_pp"
 dev = torch.device("cuda:0")
 SHAPES = [  # name, M, N, K, a_kc, b_kc, beta
     ("head logits", 2560, 9391, 256, True, True, 0),
@@ -24,7 +26,7 @@ SHAPES = [  # name, M, N, K, a_kc, b_kc, beta
     ("4096^3 NT", 4096, 4096, 4096, True, True, 0),
     ("4096^3 TN", 4096, 4096, 4096, False, False, 0),
 ]
-print("%-22s %28s %10s %10s %7s %s" % ("product", "shape", "8 waves", "4 waves", "ratio", "bitwise"))
+print("%-22s %28s %10s %10s %7s %s" % ("product", "shape", "baseline", OPT, "ratio", "bitwise"))
 for name, M, N, K, a_kc, b_kc, beta in SHAPES:
     lda, ldb = (M + 3) // 4 * 4, (N + 3) // 4 * 4
     A = torch.randn((M, K) if a_kc else (K, lda), device=dev)
@@ -34,7 +36,7 @@ for name, M, N, K, a_kc, b_kc, beta in SHAPES:
     sb = (1, K) if b_kc else (ldb, 1)
     res, ts = [], []
     for w4 in (0, 1):
-        L.set_option("gemm_waves4", w4)
+        L.set_option(OPT, w4)
         Cm = torch.zeros(M, ldc, device=dev)
         fn = lambda: L.call("vag_gemm_f32", M, N, K, 1.0, L.ptr(A), sa[0], sa[1], L.ptr(Bm), sb[0], sb[1], float(beta),
                             L.ptr(Cm), ldc, None, 0, L.stream())
@@ -42,7 +44,7 @@ for name, M, N, K, a_kc, b_kc, beta in SHAPES:
         torch.cuda.synchronize()
         res.append(Cm.clone())
         ts.append(bench._time_graph(fn, reps=10))
-    L.set_option("gemm_waves4", 0)
+    L.set_option(OPT, 0)
     fl = 2.0 * M * N * K
     same = torch.equal(res[0], res[1])
     err = (res[0] - res[1]).abs().max().item() / max(res[0].abs().max().item(), 1e-30)

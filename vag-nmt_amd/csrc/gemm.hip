@@ -11,6 +11,7 @@
 //                        (bias/addend/tanh) and the fused GRU cell.
 #include "gemm_shared.h"
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -229,6 +230,47 @@ __device__ __forceinline__ void sp_load(const float* __restrict__ P, int64_t so,
     }
 }
 
+// Round 4, the main loop's loads.  sp_load above spends ~45 instructions per 16-byte load on bounds checks and 64-bit address
+// arithmetic, every k-tile again -- and these kernels turned out to be bound by vector-instruction ISSUE, not by the matrix pipe,
+// the LDS or memory (a ping-pong variant that kept one wave per SIMD purely on MFMAs ran at the speed of its partner's ~330 VALU
+// instructions per k-tile; profiles/r04_exp_gemm_pp.txt).  Here everything that does not change from k-tile to k-tile is computed
+// once per block: a 32-bit element offset per item relative to a block-uniform base pointer that advances by a constant per
+// k-tile.  Rows (or 4-column groups) outside the operand are CLAMPED to a valid one instead of being zero-filled: what they
+// feed are accumulator rows / columns the epilogue never stores.  An outer-contiguous group that straddles the edge (o < OUT <=
+// o + 3) is loaded whole -- the vectorised kernels require the k-row stride to be a multiple of 4 floats, so the group lies
+// inside its row -- and its surplus lanes again only reach outputs that are not stored.  Only FULL k-tiles come this way; a
+// last partial tile (K % 32 != 0) takes sp_load, which zero-fills along k.
+template <bool KC, int NW = 8> struct SpFast { unsigned off[1024 / (64 * NW)]; const float* base; int64_t step; };
+template <bool KC, int NW = 8>
+__device__ __forceinline__ void sp_fast_init(SpFast<KC, NW>& f, const float* __restrict__ P, int64_t so, int64_t sk, int o0, int kbeg,
+                                             int OUT) {
+    constexpr int NT = 64 * NW, NI = 1024 / NT;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int idx = tid + i * NT;
+        if (KC) {
+            const int r = min(o0 + sp_row(idx >> 3), OUT - 1) - o0;
+            f.off[i] = (unsigned)(r * (int)so + ((idx & 7) << 2));
+        } else {
+            const int og = (idx & 31) << 2;
+            f.off[i] = (unsigned)((idx >> 5) * (int)sk + (o0 + og < OUT ? og : 0));
+        }
+    }
+    f.base = KC ? P + (int64_t)o0 * so + kbeg : P + o0 + (int64_t)kbeg * sk;
+    f.step = KC ? (int64_t)SP_BK : (int64_t)SP_BK * sk;
+}
+template <bool KC, int NW = 8>
+__device__ __forceinline__ void sp_fast_load(SpFast<KC, NW>& f, SpRegsT<NW>& r) {
+    constexpr int NI = 1024 / (64 * NW);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(f.base + f.off[i]);
+        r.v[4 * i + 0] = v.x; r.v[4 * i + 1] = v.y; r.v[4 * i + 2] = v.z; r.v[4 * i + 3] = v.w;
+    }
+    f.base += f.step;
+}
+
 // The same two items per thread of an operand STORED as bf16 (2-byte storage mode: d(logits) as its producer writes it): eight
 // bytes per item, kept as two packed pairs in r.v[4i], r.v[4i+1] -- they ARE the one bf16 plane, sp_store<.., PRE> passes them on.
 template <bool KC>
@@ -389,27 +431,42 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
     const __bf16* Bf = Bs + (wn * 32 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
 
     SpRegs ra, rb;
-    if (ABF) sp_load_bf16<AKC>(reinterpret_cast<const unsigned short*>(a.A), a.sa_o, a.sa_k, m0, kbeg, a.M, kend, ra);
-    else sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, kbeg, a.M, kend, ra);
-    sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, kbeg, a.N, kend, rb);
+    // full k-tiles through the precomputed-offset loads (sp_fast_*), a last partial one (and unaligned operands) through sp_load
+    constexpr bool FAST = VEC && !ABF;
+    const int nt = (kend - kbeg + SP_BK - 1) / SP_BK;
+    const int nfull = FAST ? (kend - kbeg) / SP_BK : 0;
+    SpFast<AKC> fa;
+    SpFast<BKC> fb;
+    if (FAST) {
+        sp_fast_init<AKC>(fa, a.A, a.sa_o, a.sa_k, m0, kbeg, a.M);
+        sp_fast_init<BKC>(fb, a.B, a.sb_o, a.sb_k, n0, kbeg, a.N);
+    }
+    auto load_tile = [&](int t) {
+        if (FAST && t < nfull) {
+            sp_fast_load<AKC>(fa, ra);
+            sp_fast_load<BKC>(fb, rb);
+        } else {
+            const int k0 = kbeg + t * SP_BK;
+            if (ABF) sp_load_bf16<AKC>(reinterpret_cast<const unsigned short*>(a.A), a.sa_o, a.sa_k, m0, k0, a.M, kend, ra);
+            else sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, k0, a.M, kend, ra);
+            sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, k0, a.N, kend, rb);
+        }
+    };
+    load_tile(0);
     // row sums of A for the first column tile's blocks (outer-contiguous A: this thread's two items of a k-tile are the same
     // four rows m at two k): the bias gradient of a weight-gradient product without a second pass over dY
     // (three-plane kernels only: at the one-plane kernels' 80-VGPR cap the extra state spills; the launcher sends those
     // products' row sums to a column-sum launch instead)
     const bool do_rs = !AKC && PL == 3 && a.rowsum != nullptr && bx == 0;
     float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k0 = kbeg; k0 < kend; k0 += SP_BK) {
+    for (int t = 0; t < nt; ++t) {
         if (!AKC && PL == 3 && do_rs) {
             rs.x += ra.v[0] + ra.v[4]; rs.y += ra.v[1] + ra.v[5]; rs.z += ra.v[2] + ra.v[6]; rs.w += ra.v[3] + ra.v[7];
         }
         sp_store<AKC, PL, F16, ABF>(As, ra);
         sp_store<BKC, PL, F16>(Bs, rb);
         __syncthreads();
-        if (k0 + SP_BK < kend) {
-            if (ABF) sp_load_bf16<AKC>(reinterpret_cast<const unsigned short*>(a.A), a.sa_o, a.sa_k, m0, k0 + SP_BK, a.M, kend, ra);
-            else sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, k0 + SP_BK, a.M, kend, ra);
-            sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, k0 + SP_BK, a.N, kend, rb);
-        }
+        if (t + 1 < nt) load_tile(t + 1);
         sp_compute<PL, AKC, BKC, F16>(Af, Bf, As, Bs, wm * 64, wn * 32, acc);
         __syncthreads();
     }
@@ -475,83 +532,121 @@ __global__ __launch_bounds__(512, PL == 1 ? 6 : 4) void gemm_split_group_kernel(
     gemm_split_body<AKC, BKC, true, PL, F16>(a, smem, bx, by, bz);
 }
 
-// ---- round 4: the same block tile on FOUR waves (2 x 2, 64 x 64 outputs each) ----------------------------------------
-// Why: the 8-wave kernel's counters read MFMA 31 % / LDS 39 % / VALU 26 % busy, i.e. its phases run one after the other, and the
-// LDS pipe is as loaded as the matrix pipe.  A 64 x 64 wave tile reads (2 + 2) x 3 fragments per k-step for 24 MFMAs (0.5 reads
-// per MFMA; 64 x 32: 9 for 12 = 0.75), and its four accumulators let consecutive MFMAs go to DIFFERENT accumulators (product-major
-// order), so one wave keeps the matrix pipe busy without a partner in the same phase; the two blocks of a CU (one wave per SIMD
-// each, 256 VGPRs available) are never at the same barrier, so one block's split / store phase runs beside the other's MFMAs.
+// ---- round 4: ping-pong kernel ------------------------------------------------------------------------------------------
+// The single-stage kernel above runs its phases one after the other (PMC: MFMA 31 %, LDS 39 %, VALU 26 % busy; 46-47 % MFMA at two
+// blocks per CU): all eight waves of a block split and store, barrier, all eight read fragments and issue MFMAs, barrier -- the
+// two waves that share a SIMD are always in the SAME phase, and nothing keeps the two blocks of a CU apart either.  Here the two
+// waves of every SIMD are kept in OPPOSITE phases by the barriers themselves (MI355X_MICROARCH.md, "Two waves per SIMD": one wave
+// in a matrix-heavy segment beside its partner in a load segment): waves 0-3 (one per SIMD) and waves 4-7 alternate, per barrier
+// interval, between [fragment reads + 24 MFMAs of k-tile t out of LDS stage t & 1] and [split + store of the own share of k-tile
+// t + 1 into the other stage, then the global loads of k-tile t + 2 into registers].  Two LDS stages of 60 KB (one block per CU,
+// 256 VGPRs per wave available), two barriers per k-tile as before, every wave still owns a 64 x 32 output tile.  (Tried before
+// this: a four-wave block with 64 x 64 wave tiles -- fewer LDS reads per MFMA -- was 1-18 % slower on every shape of the step,
+// profiles/r04_exp_gemm_waves4.txt.)
 template <bool AKC, bool BKC>
-__device__ __forceinline__ void sp_compute4(const __bf16* Af, const __bf16* Bf, const __bf16* As, const __bf16* Bs, int oa, int obn,
-                                            f32x16 (&acc)[2][2]) {
+__device__ __forceinline__ void sp_compute_pp(const __bf16* Af, const __bf16* Bf, const __bf16* As, const __bf16* Bs, int oa, int obn,
+                                              f32x16 (&acc)[2]) {
+    bf16x8 af[2][2][3], bf[2][3];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 af[2][3], bf[2][3];
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < 3; ++p) {
+            bf[ks][p] = BKC ? sp_frag(Bf + p * SP_PLANE + ks * 16) : sp_frag_tr(Bs + p * SP_PLANE, obn, ks);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i][p] = AKC ? sp_frag(Af + p * SP_PLANE + i * 32 * SP_LD + ks * 16) : sp_frag_tr(As + p * SP_PLANE, oa + 32 * i, ks);
-                bf[i][p] = BKC ? sp_frag(Bf + p * SP_PLANE + i * 32 * SP_LD + ks * 16) : sp_frag_tr(Bs + p * SP_PLANE, obn + 32 * i, ks);
-            }
-        // six products, smallest terms first; within a product the four accumulators take turns
-        constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+            for (int i = 0; i < 2; ++i)
+                af[ks][i][p] = AKC ? sp_frag(Af + p * SP_PLANE + i * 32 * SP_LD + ks * 16) : sp_frag_tr(As + p * SP_PLANE, oa + 32 * i, ks);
+        }
+    // smallest terms first; the two accumulators take turns so that no MFMA waits for the one before it
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int q = 0; q < 6; ++q)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[q]], bf[j][PB[q]], acc[i][j], 0, 0, 0);
-    }
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i][PA[q]], bf[ks][PB[q]], acc[i], 0, 0, 0);
 }
 
-template <bool AKC, bool BKC, bool VEC>
-__device__ __forceinline__ void gemm_split_body4(const GemmArgs& a, __bf16* smem, int bx, int by, int bz) {
-    __bf16* As = smem;
-    __bf16* Bs = smem + 3 * SP_PLANE;
+constexpr int PP_STAGE = 2 * 3 * SP_PLANE;            // bf16 elements per LDS stage (A planes + B planes): 60 KB
+constexpr int PP_LDS_BYTES = 2 * PP_STAGE * 2;        // 120 KB
+
+// Barrier between the ping-pong intervals: LDS traffic of this wave done, then s_barrier.  NOT __syncthreads(): that drains vmcnt too,
+// i.e. it would wait at every barrier for the global loads a wave has just issued for a k-tile it needs three tiles later.
+__device__ __forceinline__ void pp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <bool AKC, bool BKC, bool VEC, int D>
+__device__ __forceinline__ void gemm_pp_body(const GemmArgs& a, __bf16* smem, int bx, int by, int bz) {
     const int m0 = by * 128, n0 = bx * 128;
     const int kbeg = bz * a.kchunk;
     const int kend = min(a.K, kbeg + a.kchunk);
+    const int nt = (kend - kbeg + SP_BK - 1) / SP_BK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    f32x16 acc[2][2];
+    const int grp = wave >> 2;                           // 0: waves 0-3, 1: waves 4-7 (one wave of each group per SIMD)
+    const int wm = wave & 1, wn = ((wave >> 1) & 1) | ((wave >> 2) << 1);
+    f32x16 acc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const __bf16* Af = As + (wm * 64 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
-    const __bf16* Bf = Bs + (wn * 64 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
-    SpRegsT<4> ra, rb;
-    sp_load<AKC, VEC, 4>(a.A, a.sa_o, a.sa_k, m0, kbeg, a.M, kend, ra);
-    sp_load<BKC, VEC, 4>(a.B, a.sb_o, a.sb_k, n0, kbeg, a.N, kend, rb);
-    const bool do_rs = !AKC && a.rowsum != nullptr && bx == 0;        // bias gradient from the A tiles (see gemm_split_body)
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int foff_a = (wm * 64 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
+    const int foff_b = 3 * SP_PLANE + (wn * 32 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
+
+    // k-tile j >= 1 waits in register slot j % D from the moment slot's previous tenant (tile j - D) has gone to LDS: D tiles of
+    // global loads (D x 32 KB per CU) are in flight at any time
+    SpRegs ra[D], rb[D];
+    const bool do_rs = !AKC && a.rowsum != nullptr && bx == 0;
     float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k0 = kbeg; k0 < kend; k0 += SP_BK) {
-        if (!AKC && do_rs) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { rs.x += ra.v[4 * i]; rs.y += ra.v[4 * i + 1]; rs.z += ra.v[4 * i + 2]; rs.w += ra.v[4 * i + 3]; }
-        }
-        sp_store<AKC, 3, false, false, 4>(As, ra);
-        sp_store<BKC, 3, false, false, 4>(Bs, rb);
-        __syncthreads();
-        if (k0 + SP_BK < kend) {
-            sp_load<AKC, VEC, 4>(a.A, a.sa_o, a.sa_k, m0, k0 + SP_BK, a.M, kend, ra);
-            sp_load<BKC, VEC, 4>(a.B, a.sb_o, a.sb_k, n0, k0 + SP_BK, a.N, kend, rb);
-        }
-        sp_compute4<AKC, BKC>(Af, Bf, As, Bs, wm * 64, wn * 64, acc);
-        __syncthreads();
+    const int nfull = VEC ? (kend - kbeg) / SP_BK : 0;      // tiles are loaded in order 0, 1, 2, ...: the fast loaders' base pointers advance
+    SpFast<AKC> fa;
+    SpFast<BKC> fb;
+    if (VEC) {
+        sp_fast_init<AKC>(fa, a.A, a.sa_o, a.sa_k, m0, kbeg, a.M);
+        sp_fast_init<BKC>(fb, a.B, a.sb_o, a.sb_k, n0, kbeg, a.N);
     }
-    if (!AKC && do_rs) {       // 8 threads hold partial sums of the same four rows (item idx -> outer group idx & 31): meet in LDS
+#define PP_LOAD(T, SLOT)                                                                                  \
+    { if (VEC && (T) < nfull) { sp_fast_load<AKC>(fa, ra[SLOT]); sp_fast_load<BKC>(fb, rb[SLOT]); }       \
+      else { sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, kbeg + (T) * SP_BK, a.M, kend, ra[SLOT]);         \
+             sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, kbeg + (T) * SP_BK, a.N, kend, rb[SLOT]); } }
+#define PP_STORE(SLOT, STAGE)                                                                             \
+    { if (!AKC && do_rs) { rs.x += ra[SLOT].v[0] + ra[SLOT].v[4]; rs.y += ra[SLOT].v[1] + ra[SLOT].v[5];  \
+                           rs.z += ra[SLOT].v[2] + ra[SLOT].v[6]; rs.w += ra[SLOT].v[3] + ra[SLOT].v[7]; } \
+      __bf16* S_ = smem + (STAGE) * PP_STAGE;                                                             \
+      sp_store<AKC, 3>(S_, ra[SLOT]);                                                                     \
+      sp_store<BKC, 3>(S_ + 3 * SP_PLANE, rb[SLOT]); }
+#define PP_COMPUTE(STAGE)                                                                                 \
+    { const __bf16* S_ = smem + (STAGE) * PP_STAGE;                                                       \
+      sp_compute_pp<AKC, BKC>(S_ + foff_a, S_ + foff_b, S_, S_ + 3 * SP_PLANE, wm * 64, wn * 32, acc); }
+    PP_LOAD(0, 0)
+    PP_STORE(0, 0)
+#pragma unroll
+    for (int j = 1; j <= D; ++j)
+        if (j < nt) PP_LOAD(j, j % D)
+    pp_barrier();
+    for (int base = 0; base < nt; base += D) {
+#pragma unroll
+        for (int tt = 0; tt < D; ++tt) {
+            const int t = base + tt;
+            if (t >= nt) break;
+            const int st = t & 1;
+            constexpr int dummy = 0; (void)dummy;
+            if (grp == 0) PP_COMPUTE(st)
+            else if (t + 1 < nt) { PP_STORE((tt + 1) % D, st ^ 1) if (t + 1 + D < nt) PP_LOAD(t + 1 + D, (tt + 1) % D) }
+            pp_barrier();
+            if (grp == 1) PP_COMPUTE(st)
+            else if (t + 1 < nt) { PP_STORE((tt + 1) % D, st ^ 1) if (t + 1 + D < nt) PP_LOAD(t + 1 + D, (tt + 1) % D) }
+            pp_barrier();
+        }
+    }
+#undef PP_LOAD
+#undef PP_STORE
+#undef PP_COMPUTE
+    if (!AKC && do_rs) {           // see gemm_split_body
         float4* rs_s = reinterpret_cast<float4*>(smem);
         rs_s[threadIdx.x] = rs;
         __syncthreads();
         if (threadIdx.x < 32) {
             float4 t = rs_s[threadIdx.x];
 #pragma unroll
-            for (int q = 1; q < 8; ++q) {
+            for (int q = 1; q < 16; ++q) {
                 const float4 o = rs_s[threadIdx.x + 32 * q];
                 t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
             }
@@ -564,34 +659,43 @@ __device__ __forceinline__ void gemm_split_body4(const GemmArgs& a, __bf16* smem
     }
     const bool atomic = a.splitk > 1;
     const bool first = bz == 0;
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col >= a.N) return;
+    const float bv = (a.bias && first) ? a.bias[col] : 0.f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-        if (col >= a.N) continue;
-        const float bv = (a.bias && first) ? a.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row0 = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
-            if (a.c_half) gemm_epilogue16(acc[i][j], a.C, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, atomic, 1, (int64_t)row0 * a.ldc + col);
-            else gemm_epilogue16(acc[i][j], a.C + (int64_t)row0 * a.ldc + col, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, atomic);
-        }
+    for (int i = 0; i < 2; ++i) {
+        const int row0 = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+        if (a.c_half) gemm_epilogue16(acc[i], a.C, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, atomic, 1, (int64_t)row0 * a.ldc + col);
+        else gemm_epilogue16(acc[i], a.C + (int64_t)row0 * a.ldc + col, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, atomic);
     }
 }
+constexpr int PP_DEPTH = 3;
 template <bool AKC, bool BKC, bool VEC>
-__global__ __launch_bounds__(256, 2) void gemm_split4_kernel(GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * 3 * SP_PLANE];       // 60 KB: two blocks per CU
-    gemm_split_body4<AKC, BKC, VEC>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 pp_smem[];
+    gemm_pp_body<AKC, BKC, VEC, PP_DEPTH>(a, pp_smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 template <bool AKC, bool BKC>
-__global__ __launch_bounds__(256, 2) void gemm_split4_group_kernel(GemmGroupArgs G) {
-    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * 3 * SP_PLANE];
+__global__ __launch_bounds__(512, 2) void gemm_pp_group_kernel(GemmGroupArgs G) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 pp_smem[];
     int p = 0;
     while (p + 1 < G.n && (int)blockIdx.x >= G.start[p + 1]) ++p;
     const GemmArgs& a = G.p[p];
     const int id = blockIdx.x - G.start[p];
     const int tn = (a.N + 127) / 128, tm = (a.M + 127) / 128;
     const int bx = id % tn, by = (id / tn) % tm, bz = id / (tn * tm);
-    gemm_split_body4<AKC, BKC, true>(a, smem, bx, by, bz);
+    gemm_pp_body<AKC, BKC, true, PP_DEPTH>(a, pp_smem, bx, by, bz);
+}
+// dynamic LDS above 64 KB needs the attribute once per kernel (and device)
+template <typename K> static bool pp_attr(K kernel) {
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (done.load(std::memory_order_acquire) & (1ull << dev)) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) != hipSuccess)
+        return false;
+    done.fetch_or(1ull << dev, std::memory_order_release);
+    return true;
 }
 
 // (A double-buffered variant -- 110 KB of LDS, one block per CU, split/store of tile t+1 issued between the k-halves of
@@ -617,8 +721,10 @@ static int gemm_split_dispatch(const GemmArgs& g, bool akc, bool bkc, bool vec, 
     }
 #define VAG_SPLIT_CASE(AK, BKc, V)                                                                    \
     if (akc == AK && bkc == BKc && vec == V) {                                                        \
-        if (g_gemm_planes == 3 && vag_opt().gemm_waves4 != 0) hipLaunchKernelGGL((gemm_split4_kernel<AK, BKc, V>), grid, dim3(256), 0, s, g);   \
-        else if (g_gemm_planes == 2) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 2>), grid, dim3(512), 0, s, g);   \
+        if (g_gemm_planes == 3 && vag_opt().gemm_pp != 0) {                                           \
+            if (!pp_attr(gemm_pp_kernel<AK, BKc, V>)) return VAG_EINVAL;                              \
+            hipLaunchKernelGGL((gemm_pp_kernel<AK, BKc, V>), grid, dim3(512), PP_LDS_BYTES, s, g);    \
+        } else if (g_gemm_planes == 2) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 2>), grid, dim3(512), 0, s, g);   \
         else if (g_gemm_planes == 1) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 1>), grid, dim3(512), 0, s, g);   \
         else if (g_gemm_planes == 11) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 1, true>), grid, dim3(512), 0, s, g);   \
         else hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 3>), grid, dim3(512), 0, s, g);        \
@@ -843,11 +949,15 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
     if (g_gemm_planes == 11) { VAG_GROUP_GO(1, true) }
     else if (g_gemm_planes == 1) { VAG_GROUP_GO(1, false) }
     else if (g_gemm_planes == 2) { VAG_GROUP_GO(2, false) }
-    else if (vag_opt().gemm_waves4 != 0) {
-        if (!akc && !bkc) hipLaunchKernelGGL((gemm_split4_group_kernel<false, false>), dim3((unsigned)total), dim3(256), 0, stream, G);
-        else if (akc && !bkc) hipLaunchKernelGGL((gemm_split4_group_kernel<true, false>), dim3((unsigned)total), dim3(256), 0, stream, G);
-        else if (akc && bkc) hipLaunchKernelGGL((gemm_split4_group_kernel<true, true>), dim3((unsigned)total), dim3(256), 0, stream, G);
-        else hipLaunchKernelGGL((gemm_split4_group_kernel<false, true>), dim3((unsigned)total), dim3(256), 0, stream, G);
+    else if (vag_opt().gemm_pp != 0) {
+#define VAG_PP_GO(AK, BKc)                                                                                                    \
+        { if (!pp_attr(gemm_pp_group_kernel<AK, BKc>)) return VAG_EINVAL;                                                     \
+          hipLaunchKernelGGL((gemm_pp_group_kernel<AK, BKc>), dim3((unsigned)total), dim3(512), PP_LDS_BYTES, stream, G); }
+        if (!akc && !bkc) VAG_PP_GO(false, false)
+        else if (akc && !bkc) VAG_PP_GO(true, false)
+        else if (akc && bkc) VAG_PP_GO(true, true)
+        else VAG_PP_GO(false, true)
+#undef VAG_PP_GO
     }
     else { VAG_GROUP_GO(3, false) }
 #undef VAG_GROUP_GO
