@@ -172,244 +172,7 @@ __global__ __launch_bounds__(NTH) void gemm_tiled_kernel(GemmArgs a) {
 // global memory into LDS (three bf16 planes per operand), so global traffic is unchanged.
 // Block 128x128x32, 8 waves (2x4, 64x32 each), LDS single-staged (61 KB: two blocks per CU), register prefetch.
 // ------------------------------------------------------------------------------------------------
-// global -> registers (8 floats per thread per operand tile).
-// KC (k contiguous): two float4 = (row, 4 consecutive k) items.  OC (outer contiguous): two float4 = (k row, 4 consecutive
-// outer) items, stored as they come into the [k][outer] image (sp_oc_off) and transposed by the fragment reads.
-template <int NW = 8> struct SpRegsT { float v[4 * (16 / NW)]; };      // 1024 float4 items per operand tile / threads
-typedef SpRegsT<8> SpRegs;
-// k-contiguous operands: the four rows a 32-lane group writes to LDS with one 8-byte store per lane are 4 apart, not
-// consecutive: with the 80-byte row stride rows r, r+4, r+8, r+12 start at banks 0, 16, 0, 16 (mod 32) and tile the 32 banks
-// exactly twice (consecutive rows: PMC had 20 % of the LDS-active cycles as bank conflicts).
-__device__ __forceinline__ int sp_row(int q) { return (q & ~15) | ((q & 3) << 2) | ((q >> 2) & 3); }
-
-template <bool KC, bool VEC, int NW = 8>
-__device__ __forceinline__ void sp_load(const float* __restrict__ P, int64_t so, int64_t sk, int o0, int k0, int OUT,
-                                        int KEND, SpRegsT<NW>& r) {
-    constexpr int NT = 64 * NW, NI = 1024 / NT;
-    const int tid = threadIdx.x;
-    if (KC) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int idx = tid + i * NT;
-            const int o = o0 + sp_row(idx >> 3), k = k0 + ((idx & 7) << 2);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (o < OUT) {
-                const float* p = P + (int64_t)o * so + k;
-                if (VEC && k + 3 < KEND) {
-                    v = *reinterpret_cast<const float4*>(p);
-                } else {
-                    if (k + 0 < KEND) v.x = p[0];
-                    if (k + 1 < KEND) v.y = p[1];
-                    if (k + 2 < KEND) v.z = p[2];
-                    if (k + 3 < KEND) v.w = p[3];
-                }
-            }
-            r.v[4 * i + 0] = v.x; r.v[4 * i + 1] = v.y; r.v[4 * i + 2] = v.z; r.v[4 * i + 3] = v.w;
-        }
-    } else {
-        // two float4 along the outer dimension per thread: item idx -> k row idx>>5, outer group (idx&31)*4; a wave reads two
-        // 512-byte row segments per instruction.  r.v[4i..4i+3] = the four outer elements of item i.
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int idx = tid + i * NT;
-            const int k = k0 + (idx >> 5), o = o0 + ((idx & 31) << 2);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < KEND) {
-                const float* p = P + (int64_t)k * sk + o;
-                if (VEC && o + 3 < OUT) {
-                    v = *reinterpret_cast<const float4*>(p);
-                } else {
-                    if (o + 0 < OUT) v.x = p[0];
-                    if (o + 1 < OUT) v.y = p[1];
-                    if (o + 2 < OUT) v.z = p[2];
-                    if (o + 3 < OUT) v.w = p[3];
-                }
-            }
-            r.v[4 * i + 0] = v.x; r.v[4 * i + 1] = v.y; r.v[4 * i + 2] = v.z; r.v[4 * i + 3] = v.w;
-        }
-    }
-}
-
-// Round 4, the main loop's loads.  sp_load above spends ~45 instructions per 16-byte load on bounds checks and 64-bit address
-// arithmetic, every k-tile again -- and these kernels turned out to be bound by vector-instruction ISSUE, not by the matrix pipe,
-// the LDS or memory (a ping-pong variant that kept one wave per SIMD purely on MFMAs ran at the speed of its partner's ~330 VALU
-// instructions per k-tile; profiles/r04_exp_gemm_pp.txt).  Here everything that does not change from k-tile to k-tile is computed
-// once per block: a 32-bit element offset per item relative to a block-uniform base pointer that advances by a constant per
-// k-tile.  Rows (or 4-column groups) outside the operand are CLAMPED to a valid one instead of being zero-filled: what they
-// feed are accumulator rows / columns the epilogue never stores.  An outer-contiguous group that straddles the edge (o < OUT <=
-// o + 3) is loaded whole -- the vectorised kernels require the k-row stride to be a multiple of 4 floats, so the group lies
-// inside its row -- and its surplus lanes again only reach outputs that are not stored.  Only FULL k-tiles come this way; a
-// last partial tile (K % 32 != 0) takes sp_load, which zero-fills along k.
-template <bool KC, int NW = 8> struct SpFast { unsigned off[1024 / (64 * NW)]; const float* base; int64_t step; };
-template <bool KC, int NW = 8>
-__device__ __forceinline__ void sp_fast_init(SpFast<KC, NW>& f, const float* __restrict__ P, int64_t so, int64_t sk, int o0, int kbeg,
-                                             int OUT) {
-    constexpr int NT = 64 * NW, NI = 1024 / NT;
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int idx = tid + i * NT;
-        if (KC) {
-            const int r = min(o0 + sp_row(idx >> 3), OUT - 1) - o0;
-            f.off[i] = (unsigned)(r * (int)so + ((idx & 7) << 2));
-        } else {
-            const int og = (idx & 31) << 2;
-            f.off[i] = (unsigned)((idx >> 5) * (int)sk + (o0 + og < OUT ? og : 0));
-        }
-    }
-    f.base = KC ? P + (int64_t)o0 * so + kbeg : P + o0 + (int64_t)kbeg * sk;
-    f.step = KC ? (int64_t)SP_BK : (int64_t)SP_BK * sk;
-}
-template <bool KC, int NW = 8>
-__device__ __forceinline__ void sp_fast_load(SpFast<KC, NW>& f, SpRegsT<NW>& r) {
-    constexpr int NI = 1024 / (64 * NW);
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const float4 v = *reinterpret_cast<const float4*>(f.base + f.off[i]);
-        r.v[4 * i + 0] = v.x; r.v[4 * i + 1] = v.y; r.v[4 * i + 2] = v.z; r.v[4 * i + 3] = v.w;
-    }
-    f.base += f.step;
-}
-
-// The same two items per thread of an operand STORED as bf16 (2-byte storage mode: d(logits) as its producer writes it): eight
-// bytes per item, kept as two packed pairs in r.v[4i], r.v[4i+1] -- they ARE the one bf16 plane, sp_store<.., PRE> passes them on.
-template <bool KC>
-__device__ __forceinline__ void sp_load_bf16(const unsigned short* __restrict__ P, int64_t so, int64_t sk, int o0, int k0, int OUT,
-                                             int KEND, SpRegs& r) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = tid + i * 512;
-        unsigned lo = 0u, hi = 0u;
-        if (KC) {
-            const int o = o0 + sp_row(idx >> 3), k = k0 + ((idx & 7) << 2);
-            if (o < OUT) {
-                const unsigned short* p = P + (int64_t)o * so + k;
-                if (k + 3 < KEND) {
-                    const uint2 v = *reinterpret_cast<const uint2*>(p);
-                    lo = v.x; hi = v.y;
-                } else {
-                    if (k + 0 < KEND) lo |= (unsigned)p[0];
-                    if (k + 1 < KEND) lo |= (unsigned)p[1] << 16;
-                    if (k + 2 < KEND) hi |= (unsigned)p[2];
-                    if (k + 3 < KEND) hi |= (unsigned)p[3] << 16;
-                }
-            }
-        } else {
-            const int k = k0 + (idx >> 5), o = o0 + ((idx & 31) << 2);
-            if (k < KEND) {
-                const unsigned short* p = P + (int64_t)k * sk + o;
-                if (o + 3 < OUT) {
-                    const uint2 v = *reinterpret_cast<const uint2*>(p);
-                    lo = v.x; hi = v.y;
-                } else {
-                    if (o + 0 < OUT) lo |= (unsigned)p[0];
-                    if (o + 1 < OUT) lo |= (unsigned)p[1] << 16;
-                    if (o + 2 < OUT) hi |= (unsigned)p[2];
-                    if (o + 3 < OUT) hi |= (unsigned)p[3] << 16;
-                }
-            }
-        }
-        r.v[4 * i + 0] = __builtin_bit_cast(float, lo);
-        r.v[4 * i + 1] = __builtin_bit_cast(float, hi);
-        r.v[4 * i + 2] = 0.f; r.v[4 * i + 3] = 0.f;
-    }
-}
-
-// registers -> PL (3, 2 or 1) bf16 planes in LDS, image [outer][k] per plane; F16 (PL = 1 only): one fp16 plane instead
-template <bool KC, int PL = 3, bool F16 = false, bool PRE = false, int NW = 8>
-__device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegsT<NW>& r) {
-    constexpr int NT = 64 * NW, NI = 1024 / NT;
-    static_assert(!F16 || PL == 1, "the fp16 image is a single plane");
-    static_assert(!PRE || (PL == 1 && !F16), "pre-packed bf16 pairs are the one bf16 plane");
-    const int tid = threadIdx.x;
-    if (KC) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int idx = tid + i * NT;
-            const int o = sp_row(idx >> 3), k = (idx & 7) << 2;
-            unsigned a1, a2, a3, b1, b2, b3;
-            if (PRE) {
-                a1 = __builtin_bit_cast(unsigned, r.v[4 * i + 0]); b1 = __builtin_bit_cast(unsigned, r.v[4 * i + 1]);
-                a2 = a3 = b2 = b3 = 0;
-            } else if (F16) {
-                a1 = pack_f16(r.v[4 * i + 0], r.v[4 * i + 1]); b1 = pack_f16(r.v[4 * i + 2], r.v[4 * i + 3]);
-                a2 = a3 = b2 = b3 = 0;
-            } else if (PL == 1) {
-                a1 = pack_bf16(r.v[4 * i + 0], r.v[4 * i + 1]); b1 = pack_bf16(r.v[4 * i + 2], r.v[4 * i + 3]);
-                a2 = a3 = b2 = b3 = 0;
-            } else {
-                split3(r.v[4 * i + 0], r.v[4 * i + 1], a1, a2, a3);
-                split3(r.v[4 * i + 2], r.v[4 * i + 3], b1, b2, b3);
-            }
-            __bf16* d = S + o * SP_LD + k;
-            *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
-            if (PL >= 2) *reinterpret_cast<uint2*>(d + SP_PLANE) = make_uint2(a2, b2);
-            if (PL == 3) *reinterpret_cast<uint2*>(d + 2 * SP_PLANE) = make_uint2(a3, b3);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int idx = tid + i * NT;
-            unsigned a1, a2, a3, b1, b2, b3;
-            if (PRE) {
-                a1 = __builtin_bit_cast(unsigned, r.v[4 * i + 0]); b1 = __builtin_bit_cast(unsigned, r.v[4 * i + 1]);
-                a2 = a3 = b2 = b3 = 0;
-            } else if (F16) {
-                a1 = pack_f16(r.v[4 * i + 0], r.v[4 * i + 1]); b1 = pack_f16(r.v[4 * i + 2], r.v[4 * i + 3]);
-                a2 = a3 = b2 = b3 = 0;
-            } else if (PL == 1) {
-                a1 = pack_bf16(r.v[4 * i + 0], r.v[4 * i + 1]); b1 = pack_bf16(r.v[4 * i + 2], r.v[4 * i + 3]);
-                a2 = a3 = b2 = b3 = 0;
-            } else {
-                split3(r.v[4 * i + 0], r.v[4 * i + 1], a1, a2, a3);
-                split3(r.v[4 * i + 2], r.v[4 * i + 3], b1, b2, b3);
-            }
-            __bf16* d = S + sp_oc_off(idx >> 5, (idx & 31) << 2);
-            *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
-            if (PL >= 2) *reinterpret_cast<uint2*>(d + SP_PLANE) = make_uint2(a2, b2);
-            if (PL == 3) *reinterpret_cast<uint2*>(d + 2 * SP_PLANE) = make_uint2(a3, b3);
-        }
-    }
-}
-
-// Af / Bf: fragment base of a k-contiguous operand; As / Bs + (oa, obn): plane base and first outer index of this wave's
-// rows for an outer-contiguous one.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-template <int PL, bool AKC, bool BKC, bool F16 = false>
-__device__ __forceinline__ void sp_compute(const __bf16* Af, const __bf16* Bf, const __bf16* As, const __bf16* Bs, int oa, int obn,
-                                           f32x16 (&acc)[2]) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 af[2][PL], bf[PL];
-#pragma unroll
-        for (int p = 0; p < PL; ++p) {
-            bf[p] = BKC ? sp_frag(Bf + p * SP_PLANE + ks * 16) : sp_frag_tr(Bs + p * SP_PLANE, obn, ks);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                af[i][p] = AKC ? sp_frag(Af + p * SP_PLANE + i * 32 * SP_LD + ks * 16) : sp_frag_tr(As + p * SP_PLANE, oa + 32 * i, ks);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            // smallest terms first
-            if (PL == 3) {
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[PL - 1], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[1], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PL - 1], bf[0], acc[i], 0, 0, 0);
-            }
-            if (PL >= 2) {
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[PL >= 2 ? 1 : 0], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PL >= 2 ? 1 : 0], bf[0], acc[i], 0, 0, 0);
-            }
-            if (F16)            // the plane holds fp16 bit patterns (sp_store<.., 1, true>): same fragments, the f16 instruction
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][0]), __builtin_bit_cast(f16x8, bf[0]),
-                                                                acc[i], 0, 0, 0);
-            else
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i], 0, 0, 0);
-        }
-    }
-}
-
+// (operand loaders, the split + LDS store and the fragment reads / MFMA step live in gemm_shared.h: gemm_swp.hip uses them too)
 template <bool AKC, bool BKC, bool VEC, int PL = 3, bool F16 = false, bool ABF = false>
 __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem, int bx, int by, int bz) {
     __bf16* As = smem;
@@ -532,172 +295,6 @@ __global__ __launch_bounds__(512, PL == 1 ? 6 : 4) void gemm_split_group_kernel(
     gemm_split_body<AKC, BKC, true, PL, F16>(a, smem, bx, by, bz);
 }
 
-// ---- round 4: ping-pong kernel ------------------------------------------------------------------------------------------
-// The single-stage kernel above runs its phases one after the other (PMC: MFMA 31 %, LDS 39 %, VALU 26 % busy; 46-47 % MFMA at two
-// blocks per CU): all eight waves of a block split and store, barrier, all eight read fragments and issue MFMAs, barrier -- the
-// two waves that share a SIMD are always in the SAME phase, and nothing keeps the two blocks of a CU apart either.  Here the two
-// waves of every SIMD are kept in OPPOSITE phases by the barriers themselves (MI355X_MICROARCH.md, "Two waves per SIMD": one wave
-// in a matrix-heavy segment beside its partner in a load segment): waves 0-3 (one per SIMD) and waves 4-7 alternate, per barrier
-// interval, between [fragment reads + 24 MFMAs of k-tile t out of LDS stage t & 1] and [split + store of the own share of k-tile
-// t + 1 into the other stage, then the global loads of k-tile t + 2 into registers].  Two LDS stages of 60 KB (one block per CU,
-// 256 VGPRs per wave available), two barriers per k-tile as before, every wave still owns a 64 x 32 output tile.  (Tried before
-// this: a four-wave block with 64 x 64 wave tiles -- fewer LDS reads per MFMA -- was 1-18 % slower on every shape of the step,
-// profiles/r04_exp_gemm_waves4.txt.)
-template <bool AKC, bool BKC>
-__device__ __forceinline__ void sp_compute_pp(const __bf16* Af, const __bf16* Bf, const __bf16* As, const __bf16* Bs, int oa, int obn,
-                                              f32x16 (&acc)[2]) {
-    bf16x8 af[2][2][3], bf[2][3];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            bf[ks][p] = BKC ? sp_frag(Bf + p * SP_PLANE + ks * 16) : sp_frag_tr(Bs + p * SP_PLANE, obn, ks);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                af[ks][i][p] = AKC ? sp_frag(Af + p * SP_PLANE + i * 32 * SP_LD + ks * 16) : sp_frag_tr(As + p * SP_PLANE, oa + 32 * i, ks);
-        }
-    // smallest terms first; the two accumulators take turns so that no MFMA waits for the one before it
-    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i][PA[q]], bf[ks][PB[q]], acc[i], 0, 0, 0);
-}
-
-constexpr int PP_STAGE = 2 * 3 * SP_PLANE;            // bf16 elements per LDS stage (A planes + B planes): 60 KB
-constexpr int PP_LDS_BYTES = 2 * PP_STAGE * 2;        // 120 KB
-
-// Barrier between the ping-pong intervals: LDS traffic of this wave done, then s_barrier.  NOT __syncthreads(): that drains vmcnt too,
-// i.e. it would wait at every barrier for the global loads a wave has just issued for a k-tile it needs three tiles later.
-__device__ __forceinline__ void pp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-template <bool AKC, bool BKC, bool VEC, int D>
-__device__ __forceinline__ void gemm_pp_body(const GemmArgs& a, __bf16* smem, int bx, int by, int bz) {
-    const int m0 = by * 128, n0 = bx * 128;
-    const int kbeg = bz * a.kchunk;
-    const int kend = min(a.K, kbeg + a.kchunk);
-    const int nt = (kend - kbeg + SP_BK - 1) / SP_BK;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int grp = wave >> 2;                           // 0: waves 0-3, 1: waves 4-7 (one wave of each group per SIMD)
-    const int wm = wave & 1, wn = ((wave >> 1) & 1) | ((wave >> 2) << 1);
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    const int foff_a = (wm * 64 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
-    const int foff_b = 3 * SP_PLANE + (wn * 32 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
-
-    // k-tile j >= 1 waits in register slot j % D from the moment slot's previous tenant (tile j - D) has gone to LDS: D tiles of
-    // global loads (D x 32 KB per CU) are in flight at any time
-    SpRegs ra[D], rb[D];
-    const bool do_rs = !AKC && a.rowsum != nullptr && bx == 0;
-    float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int nfull = VEC ? (kend - kbeg) / SP_BK : 0;      // tiles are loaded in order 0, 1, 2, ...: the fast loaders' base pointers advance
-    SpFast<AKC> fa;
-    SpFast<BKC> fb;
-    if (VEC) {
-        sp_fast_init<AKC>(fa, a.A, a.sa_o, a.sa_k, m0, kbeg, a.M);
-        sp_fast_init<BKC>(fb, a.B, a.sb_o, a.sb_k, n0, kbeg, a.N);
-    }
-#define PP_LOAD(T, SLOT)                                                                                  \
-    { if (VEC && (T) < nfull) { sp_fast_load<AKC>(fa, ra[SLOT]); sp_fast_load<BKC>(fb, rb[SLOT]); }       \
-      else { sp_load<AKC, VEC>(a.A, a.sa_o, a.sa_k, m0, kbeg + (T) * SP_BK, a.M, kend, ra[SLOT]);         \
-             sp_load<BKC, VEC>(a.B, a.sb_o, a.sb_k, n0, kbeg + (T) * SP_BK, a.N, kend, rb[SLOT]); } }
-#define PP_STORE(SLOT, STAGE)                                                                             \
-    { if (!AKC && do_rs) { rs.x += ra[SLOT].v[0] + ra[SLOT].v[4]; rs.y += ra[SLOT].v[1] + ra[SLOT].v[5];  \
-                           rs.z += ra[SLOT].v[2] + ra[SLOT].v[6]; rs.w += ra[SLOT].v[3] + ra[SLOT].v[7]; } \
-      __bf16* S_ = smem + (STAGE) * PP_STAGE;                                                             \
-      sp_store<AKC, 3>(S_, ra[SLOT]);                                                                     \
-      sp_store<BKC, 3>(S_ + 3 * SP_PLANE, rb[SLOT]); }
-#define PP_COMPUTE(STAGE)                                                                                 \
-    { const __bf16* S_ = smem + (STAGE) * PP_STAGE;                                                       \
-      sp_compute_pp<AKC, BKC>(S_ + foff_a, S_ + foff_b, S_, S_ + 3 * SP_PLANE, wm * 64, wn * 32, acc); }
-    PP_LOAD(0, 0)
-    PP_STORE(0, 0)
-#pragma unroll
-    for (int j = 1; j <= D; ++j)
-        if (j < nt) PP_LOAD(j, j % D)
-    pp_barrier();
-    for (int base = 0; base < nt; base += D) {
-#pragma unroll
-        for (int tt = 0; tt < D; ++tt) {
-            const int t = base + tt;
-            if (t >= nt) break;
-            const int st = t & 1;
-            constexpr int dummy = 0; (void)dummy;
-            if (grp == 0) PP_COMPUTE(st)
-            else if (t + 1 < nt) { PP_STORE((tt + 1) % D, st ^ 1) if (t + 1 + D < nt) PP_LOAD(t + 1 + D, (tt + 1) % D) }
-            pp_barrier();
-            if (grp == 1) PP_COMPUTE(st)
-            else if (t + 1 < nt) { PP_STORE((tt + 1) % D, st ^ 1) if (t + 1 + D < nt) PP_LOAD(t + 1 + D, (tt + 1) % D) }
-            pp_barrier();
-        }
-    }
-#undef PP_LOAD
-#undef PP_STORE
-#undef PP_COMPUTE
-    if (!AKC && do_rs) {           // see gemm_split_body
-        float4* rs_s = reinterpret_cast<float4*>(smem);
-        rs_s[threadIdx.x] = rs;
-        __syncthreads();
-        if (threadIdx.x < 32) {
-            float4 t = rs_s[threadIdx.x];
-#pragma unroll
-            for (int q = 1; q < 16; ++q) {
-                const float4 o = rs_s[threadIdx.x + 32 * q];
-                t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
-            }
-            const int m = m0 + 4 * threadIdx.x;
-            if (m + 0 < a.M) atomicAdd(a.rowsum + m + 0, t.x);
-            if (m + 1 < a.M) atomicAdd(a.rowsum + m + 1, t.y);
-            if (m + 2 < a.M) atomicAdd(a.rowsum + m + 2, t.z);
-            if (m + 3 < a.M) atomicAdd(a.rowsum + m + 3, t.w);
-        }
-    }
-    const bool atomic = a.splitk > 1;
-    const bool first = bz == 0;
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col >= a.N) return;
-    const float bv = (a.bias && first) ? a.bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row0 = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
-        if (a.c_half) gemm_epilogue16(acc[i], a.C, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, atomic, 1, (int64_t)row0 * a.ldc + col);
-        else gemm_epilogue16(acc[i], a.C + (int64_t)row0 * a.ldc + col, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, atomic);
-    }
-}
-constexpr int PP_DEPTH = 3;
-template <bool AKC, bool BKC, bool VEC>
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) __bf16 pp_smem[];
-    gemm_pp_body<AKC, BKC, VEC, PP_DEPTH>(a, pp_smem, blockIdx.x, blockIdx.y, blockIdx.z);
-}
-template <bool AKC, bool BKC>
-__global__ __launch_bounds__(512, 2) void gemm_pp_group_kernel(GemmGroupArgs G) {
-    extern __shared__ __attribute__((aligned(16))) __bf16 pp_smem[];
-    int p = 0;
-    while (p + 1 < G.n && (int)blockIdx.x >= G.start[p + 1]) ++p;
-    const GemmArgs& a = G.p[p];
-    const int id = blockIdx.x - G.start[p];
-    const int tn = (a.N + 127) / 128, tm = (a.M + 127) / 128;
-    const int bx = id % tn, by = (id / tn) % tm, bz = id / (tn * tm);
-    gemm_pp_body<AKC, BKC, true, PP_DEPTH>(a, pp_smem, bx, by, bz);
-}
-// dynamic LDS above 64 KB needs the attribute once per kernel (and device)
-template <typename K> static bool pp_attr(K kernel) {
-    static std::atomic<unsigned long long> done{0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    if (done.load(std::memory_order_acquire) & (1ull << dev)) return true;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) != hipSuccess)
-        return false;
-    done.fetch_or(1ull << dev, std::memory_order_release);
-    return true;
-}
-
 // (A double-buffered variant -- 110 KB of LDS, one block per CU, split/store of tile t+1 issued between the k-halves of
 // tile t -- measured 6-9 % slower than this single-stage kernel at two blocks per CU, and was dropped.  So was a
 // wave-specialised one -- 4 producer waves splitting into a second LDS stage while 4 consumer waves run 64x64 MFMA
@@ -721,10 +318,8 @@ static int gemm_split_dispatch(const GemmArgs& g, bool akc, bool bkc, bool vec, 
     }
 #define VAG_SPLIT_CASE(AK, BKc, V)                                                                    \
     if (akc == AK && bkc == BKc && vec == V) {                                                        \
-        if (g_gemm_planes == 3 && vag_opt().gemm_pp != 0) {                                           \
-            if (!pp_attr(gemm_pp_kernel<AK, BKc, V>)) return VAG_EINVAL;                              \
-            hipLaunchKernelGGL((gemm_pp_kernel<AK, BKc, V>), grid, dim3(512), PP_LDS_BYTES, s, g);    \
-        } else if (g_gemm_planes == 2) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 2>), grid, dim3(512), 0, s, g);   \
+        if (g_gemm_planes == 3 && V && vag_opt().gemm_swp != 0) return vag_gemm_swp_launch(g, AK, BKc, grid, s);   \
+        if (g_gemm_planes == 2) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 2>), grid, dim3(512), 0, s, g);   \
         else if (g_gemm_planes == 1) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 1>), grid, dim3(512), 0, s, g);   \
         else if (g_gemm_planes == 11) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 1, true>), grid, dim3(512), 0, s, g);   \
         else hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 3>), grid, dim3(512), 0, s, g);        \
@@ -949,16 +544,7 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
     if (g_gemm_planes == 11) { VAG_GROUP_GO(1, true) }
     else if (g_gemm_planes == 1) { VAG_GROUP_GO(1, false) }
     else if (g_gemm_planes == 2) { VAG_GROUP_GO(2, false) }
-    else if (vag_opt().gemm_pp != 0) {
-#define VAG_PP_GO(AK, BKc)                                                                                                    \
-        { if (!pp_attr(gemm_pp_group_kernel<AK, BKc>)) return VAG_EINVAL;                                                     \
-          hipLaunchKernelGGL((gemm_pp_group_kernel<AK, BKc>), dim3((unsigned)total), dim3(512), PP_LDS_BYTES, stream, G); }
-        if (!akc && !bkc) VAG_PP_GO(false, false)
-        else if (akc && !bkc) VAG_PP_GO(true, false)
-        else if (akc && bkc) VAG_PP_GO(true, true)
-        else VAG_PP_GO(false, true)
-#undef VAG_PP_GO
-    }
+    else if (vag_opt().gemm_swp != 0) { return vag_gemm_swp_group_launch(G, akc, bkc, total, stream); }
     else { VAG_GROUP_GO(3, false) }
 #undef VAG_GROUP_GO
     VAG_LAUNCH_CHECK();

@@ -91,9 +91,13 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b) {     // two fp16
 // +8-10 % on the k-contiguous products (4096^3 NT 147 -> 160 TF/s, d out.weight 96 -> 88 us).  Inline asm keeps it scalar
 // here without switching SLP off for the rest of the file (that cost the recurrent-step kernels more than it gained).
 __device__ __forceinline__ float sub_f32(float a, float b) {
+#ifdef VAG_SPLIT_PLAIN_SUB      // gemm_swp.hip: built with the SLP vectoriser off, and its scheduling groups need to see a VALU instruction
+    return a - b;
+#else
     float r;
     asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
+#endif
 }
 // split two floats into three packed bf16 pairs (low half = first element)
 __device__ __forceinline__ void split3(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
@@ -139,9 +143,252 @@ __device__ __forceinline__ bf16x8 sp_frag_tr(const __bf16* plane, int ob, int ks
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// global -> registers (8 floats per thread per operand tile).
+// KC (k contiguous): two float4 = (row, 4 consecutive k) items.  OC (outer contiguous): two float4 = (k row, 4 consecutive
+// outer) items, stored as they come into the [k][outer] image (sp_oc_off) and transposed by the fragment reads.
+template <int NW = 8> struct SpRegsT { float v[4 * (16 / NW)]; };      // 1024 float4 items per operand tile / threads
+typedef SpRegsT<8> SpRegs;
+// k-contiguous operands: the four rows a 32-lane group writes to LDS with one 8-byte store per lane are 4 apart, not
+// consecutive: with the 80-byte row stride rows r, r+4, r+8, r+12 start at banks 0, 16, 0, 16 (mod 32) and tile the 32 banks
+// exactly twice (consecutive rows: PMC had 20 % of the LDS-active cycles as bank conflicts).
+__device__ __forceinline__ int sp_row(int q) { return (q & ~15) | ((q & 3) << 2) | ((q >> 2) & 3); }
+
+template <bool KC, bool VEC, int NW = 8>
+__device__ __forceinline__ void sp_load(const float* __restrict__ P, int64_t so, int64_t sk, int o0, int k0, int OUT,
+                                        int KEND, SpRegsT<NW>& r) {
+    constexpr int NT = 64 * NW, NI = 1024 / NT;
+    const int tid = threadIdx.x;
+    if (KC) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int idx = tid + i * NT;
+            const int o = o0 + sp_row(idx >> 3), k = k0 + ((idx & 7) << 2);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (o < OUT) {
+                const float* p = P + (int64_t)o * so + k;
+                if (VEC && k + 3 < KEND) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (k + 0 < KEND) v.x = p[0];
+                    if (k + 1 < KEND) v.y = p[1];
+                    if (k + 2 < KEND) v.z = p[2];
+                    if (k + 3 < KEND) v.w = p[3];
+                }
+            }
+            r.v[4 * i + 0] = v.x; r.v[4 * i + 1] = v.y; r.v[4 * i + 2] = v.z; r.v[4 * i + 3] = v.w;
+        }
+    } else {
+        // two float4 along the outer dimension per thread: item idx -> k row idx>>5, outer group (idx&31)*4; a wave reads two
+        // 512-byte row segments per instruction.  r.v[4i..4i+3] = the four outer elements of item i.
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int idx = tid + i * NT;
+            const int k = k0 + (idx >> 5), o = o0 + ((idx & 31) << 2);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < KEND) {
+                const float* p = P + (int64_t)k * sk + o;
+                if (VEC && o + 3 < OUT) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (o + 0 < OUT) v.x = p[0];
+                    if (o + 1 < OUT) v.y = p[1];
+                    if (o + 2 < OUT) v.z = p[2];
+                    if (o + 3 < OUT) v.w = p[3];
+                }
+            }
+            r.v[4 * i + 0] = v.x; r.v[4 * i + 1] = v.y; r.v[4 * i + 2] = v.z; r.v[4 * i + 3] = v.w;
+        }
+    }
+}
+
+// Round 4, the main loop's loads.  sp_load above spends ~45 instructions per 16-byte load on bounds checks and 64-bit address
+// arithmetic, every k-tile again -- and these kernels turned out to be bound by vector-instruction ISSUE, not by the matrix pipe,
+// the LDS or memory (a ping-pong variant that kept one wave per SIMD purely on MFMAs ran at the speed of its partner's ~330 VALU
+// instructions per k-tile; profiles/r04_exp_gemm_pp.txt).  Here everything that does not change from k-tile to k-tile is computed
+// once per block: a 32-bit element offset per item relative to a block-uniform base pointer that advances by a constant per
+// k-tile.  Rows (or 4-column groups) outside the operand are CLAMPED to a valid one instead of being zero-filled: what they
+// feed are accumulator rows / columns the epilogue never stores.  An outer-contiguous group that straddles the edge (o < OUT <=
+// o + 3) is loaded whole -- the vectorised kernels require the k-row stride to be a multiple of 4 floats, so the group lies
+// inside its row -- and its surplus lanes again only reach outputs that are not stored.  Only FULL k-tiles come this way; a
+// last partial tile (K % 32 != 0) takes sp_load, which zero-fills along k.
+template <bool KC, int NW = 8> struct SpFast { unsigned off[1024 / (64 * NW)]; const float* base; int64_t step; };
+template <bool KC, int NW = 8>
+__device__ __forceinline__ void sp_fast_init(SpFast<KC, NW>& f, const float* __restrict__ P, int64_t so, int64_t sk, int o0, int kbeg,
+                                             int OUT) {
+    constexpr int NT = 64 * NW, NI = 1024 / NT;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int idx = tid + i * NT;
+        if (KC) {
+            const int r = min(o0 + sp_row(idx >> 3), OUT - 1) - o0;
+            f.off[i] = (unsigned)(r * (int)so + ((idx & 7) << 2));
+        } else {
+            const int og = (idx & 31) << 2;
+            f.off[i] = (unsigned)((idx >> 5) * (int)sk + (o0 + og < OUT ? og : 0));
+        }
+    }
+    f.base = KC ? P + (int64_t)o0 * so + kbeg : P + o0 + (int64_t)kbeg * sk;
+    f.step = KC ? (int64_t)SP_BK : (int64_t)SP_BK * sk;
+}
+template <bool KC, int NW = 8>
+__device__ __forceinline__ void sp_fast_load(SpFast<KC, NW>& f, SpRegsT<NW>& r) {
+    constexpr int NI = 1024 / (64 * NW);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(f.base + f.off[i]);
+        r.v[4 * i + 0] = v.x; r.v[4 * i + 1] = v.y; r.v[4 * i + 2] = v.z; r.v[4 * i + 3] = v.w;
+    }
+    f.base += f.step;
+}
+
+// The same two items per thread of an operand STORED as bf16 (2-byte storage mode: d(logits) as its producer writes it): eight
+// bytes per item, kept as two packed pairs in r.v[4i], r.v[4i+1] -- they ARE the one bf16 plane, sp_store<.., PRE> passes them on.
+template <bool KC>
+__device__ __forceinline__ void sp_load_bf16(const unsigned short* __restrict__ P, int64_t so, int64_t sk, int o0, int k0, int OUT,
+                                             int KEND, SpRegs& r) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 512;
+        unsigned lo = 0u, hi = 0u;
+        if (KC) {
+            const int o = o0 + sp_row(idx >> 3), k = k0 + ((idx & 7) << 2);
+            if (o < OUT) {
+                const unsigned short* p = P + (int64_t)o * so + k;
+                if (k + 3 < KEND) {
+                    const uint2 v = *reinterpret_cast<const uint2*>(p);
+                    lo = v.x; hi = v.y;
+                } else {
+                    if (k + 0 < KEND) lo |= (unsigned)p[0];
+                    if (k + 1 < KEND) lo |= (unsigned)p[1] << 16;
+                    if (k + 2 < KEND) hi |= (unsigned)p[2];
+                    if (k + 3 < KEND) hi |= (unsigned)p[3] << 16;
+                }
+            }
+        } else {
+            const int k = k0 + (idx >> 5), o = o0 + ((idx & 31) << 2);
+            if (k < KEND) {
+                const unsigned short* p = P + (int64_t)k * sk + o;
+                if (o + 3 < OUT) {
+                    const uint2 v = *reinterpret_cast<const uint2*>(p);
+                    lo = v.x; hi = v.y;
+                } else {
+                    if (o + 0 < OUT) lo |= (unsigned)p[0];
+                    if (o + 1 < OUT) lo |= (unsigned)p[1] << 16;
+                    if (o + 2 < OUT) hi |= (unsigned)p[2];
+                    if (o + 3 < OUT) hi |= (unsigned)p[3] << 16;
+                }
+            }
+        }
+        r.v[4 * i + 0] = __builtin_bit_cast(float, lo);
+        r.v[4 * i + 1] = __builtin_bit_cast(float, hi);
+        r.v[4 * i + 2] = 0.f; r.v[4 * i + 3] = 0.f;
+    }
+}
+
+// registers -> PL (3, 2 or 1) bf16 planes in LDS, image [outer][k] per plane; F16 (PL = 1 only): one fp16 plane instead
+template <bool KC, int PL = 3, bool F16 = false, bool PRE = false, int NW = 8>
+__device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegsT<NW>& r) {
+    constexpr int NT = 64 * NW, NI = 1024 / NT;
+    static_assert(!F16 || PL == 1, "the fp16 image is a single plane");
+    static_assert(!PRE || (PL == 1 && !F16), "pre-packed bf16 pairs are the one bf16 plane");
+    const int tid = threadIdx.x;
+    if (KC) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int idx = tid + i * NT;
+            const int o = sp_row(idx >> 3), k = (idx & 7) << 2;
+            unsigned a1, a2, a3, b1, b2, b3;
+            if (PRE) {
+                a1 = __builtin_bit_cast(unsigned, r.v[4 * i + 0]); b1 = __builtin_bit_cast(unsigned, r.v[4 * i + 1]);
+                a2 = a3 = b2 = b3 = 0;
+            } else if (F16) {
+                a1 = pack_f16(r.v[4 * i + 0], r.v[4 * i + 1]); b1 = pack_f16(r.v[4 * i + 2], r.v[4 * i + 3]);
+                a2 = a3 = b2 = b3 = 0;
+            } else if (PL == 1) {
+                a1 = pack_bf16(r.v[4 * i + 0], r.v[4 * i + 1]); b1 = pack_bf16(r.v[4 * i + 2], r.v[4 * i + 3]);
+                a2 = a3 = b2 = b3 = 0;
+            } else {
+                split3(r.v[4 * i + 0], r.v[4 * i + 1], a1, a2, a3);
+                split3(r.v[4 * i + 2], r.v[4 * i + 3], b1, b2, b3);
+            }
+            __bf16* d = S + o * SP_LD + k;
+            *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
+            if (PL >= 2) *reinterpret_cast<uint2*>(d + SP_PLANE) = make_uint2(a2, b2);
+            if (PL == 3) *reinterpret_cast<uint2*>(d + 2 * SP_PLANE) = make_uint2(a3, b3);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int idx = tid + i * NT;
+            unsigned a1, a2, a3, b1, b2, b3;
+            if (PRE) {
+                a1 = __builtin_bit_cast(unsigned, r.v[4 * i + 0]); b1 = __builtin_bit_cast(unsigned, r.v[4 * i + 1]);
+                a2 = a3 = b2 = b3 = 0;
+            } else if (F16) {
+                a1 = pack_f16(r.v[4 * i + 0], r.v[4 * i + 1]); b1 = pack_f16(r.v[4 * i + 2], r.v[4 * i + 3]);
+                a2 = a3 = b2 = b3 = 0;
+            } else if (PL == 1) {
+                a1 = pack_bf16(r.v[4 * i + 0], r.v[4 * i + 1]); b1 = pack_bf16(r.v[4 * i + 2], r.v[4 * i + 3]);
+                a2 = a3 = b2 = b3 = 0;
+            } else {
+                split3(r.v[4 * i + 0], r.v[4 * i + 1], a1, a2, a3);
+                split3(r.v[4 * i + 2], r.v[4 * i + 3], b1, b2, b3);
+            }
+            __bf16* d = S + sp_oc_off(idx >> 5, (idx & 31) << 2);
+            *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
+            if (PL >= 2) *reinterpret_cast<uint2*>(d + SP_PLANE) = make_uint2(a2, b2);
+            if (PL == 3) *reinterpret_cast<uint2*>(d + 2 * SP_PLANE) = make_uint2(a3, b3);
+        }
+    }
+}
+
+// Af / Bf: fragment base of a k-contiguous operand; As / Bs + (oa, obn): plane base and first outer index of this wave's
+// rows for an outer-contiguous one.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int PL, bool AKC, bool BKC, bool F16 = false>
+__device__ __forceinline__ void sp_compute(const __bf16* Af, const __bf16* Bf, const __bf16* As, const __bf16* Bs, int oa, int obn,
+                                           f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[2][PL], bf[PL];
+#pragma unroll
+        for (int p = 0; p < PL; ++p) {
+            bf[p] = BKC ? sp_frag(Bf + p * SP_PLANE + ks * 16) : sp_frag_tr(Bs + p * SP_PLANE, obn, ks);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                af[i][p] = AKC ? sp_frag(Af + p * SP_PLANE + i * 32 * SP_LD + ks * 16) : sp_frag_tr(As + p * SP_PLANE, oa + 32 * i, ks);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            // smallest terms first
+            if (PL == 3) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[PL - 1], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[1], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PL - 1], bf[0], acc[i], 0, 0, 0);
+            }
+            if (PL >= 2) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[PL >= 2 ? 1 : 0], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PL >= 2 ? 1 : 0], bf[0], acc[i], 0, 0, 0);
+            }
+            if (F16)            // the plane holds fp16 bit patterns (sp_store<.., 1, true>): same fragments, the f16 instruction
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][0]), __builtin_bit_cast(f16x8, bf[0]),
+                                                                acc[i], 0, 0, 0);
+            else
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i], 0, 0, 0);
+        }
+    }
+}
+
+
 constexpr int GROUP_MAX = 12;
 struct GemmGroupArgs {
     GemmArgs p[GROUP_MAX];
     int start[GROUP_MAX + 1];      // first block of each product
     int n;
 };
+
+// gemm_swp.hip (round 4): the software-pipelined bf16x6 kernel
+int vag_gemm_swp_launch(const GemmArgs& g, bool akc, bool bkc, dim3 grid, hipStream_t s);
+int vag_gemm_swp_group_launch(const GemmGroupArgs& G, bool akc, bool bkc, int total_blocks, hipStream_t s);
