@@ -114,7 +114,7 @@ int vag_set_option(const char* name, int64_t value) {
     VagOptions& o = vag_opt();
     const struct { const char* n; int* p; } ints[] = {
         {"gemm_f32mfma", &o.gemm_f32mfma}, {"gemm_nogroup", &o.gemm_nogroup}, {"gemm_force_tile", &o.gemm_force_tile},
-        {"gemm_force_splitk", &o.gemm_force_splitk}, {"gemm_debug", &o.gemm_debug}, {"gemm_swp", &o.gemm_swp}, {"head_fuse", &o.head_fuse},
+        {"gemm_force_splitk", &o.gemm_force_splitk}, {"gemm_debug", &o.gemm_debug}, {"head_fuse", &o.head_fuse},
         {"head_bf16_grads", &o.head_bf16_grads}, {"persistent", &o.persistent}, {"persistent_dec_bwd", &o.persistent_dec_bwd},
         {"persist_timing", &o.persist_timing}, {"s16_one_plane", &o.s16_one_plane},
         {"head_bf16_dlogits", &o.head_bf16_dlogits}};

@@ -93,7 +93,6 @@ struct VagOptions {
     int gemm_nogroup = 0;        // 1: products inside a group bracket are launched one by one
     int gemm_force_tile = 0;     // 64 / 128 together with gemm_force_splitk >= 1: override the tile / split-K choice
     int gemm_force_splitk = 0;
-    int gemm_swp = 0;            // 1: the bf16x6 products on the software-pipelined kernel (gemm_swp.hip, round 4)
     int gemm_debug = 0;          // 1: print the choice per product
     int64_t head_chunk = -1;     // rows per chunk of the output head (-1: automatic, 0: never chunk)
     int head_fuse = 1;           // 0: the chunked head recomputes its chunks in backward instead of finishing them in forward

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(NTH) void gemm_tiled_kernel(GemmArgs a) {
 // global memory into LDS (three bf16 planes per operand), so global traffic is unchanged.
 // Block 128x128x32, 8 waves (2x4, 64x32 each), LDS single-staged (61 KB: two blocks per CU), register prefetch.
 // ------------------------------------------------------------------------------------------------
-// (operand loaders, the split + LDS store and the fragment reads / MFMA step live in gemm_shared.h: gemm_swp.hip uses them too)
+// (operand loaders, the split + LDS store and the fragment reads / MFMA step live in gemm_shared.h)
 template <bool AKC, bool BKC, bool VEC, int PL = 3, bool F16 = false, bool ABF = false>
 __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem, int bx, int by, int bz) {
     __bf16* As = smem;
@@ -295,6 +295,10 @@ __global__ __launch_bounds__(512, PL == 1 ? 6 : 4) void gemm_split_group_kernel(
     gemm_split_body<AKC, BKC, true, PL, F16>(a, smem, bx, by, bz);
 }
 
+// (Round 4, measured and dropped -- profiles/r04_exp_gemm_waves4.txt, _pp.txt, _swp.txt: a four-wave block with 64 x 64 wave tiles;
+// a ping-pong of the two wave halves between MFMA and split intervals; one software-pipelined MFMA + split stream per wave.  All within
+// +-10 % of this kernel: two waves per SIMD carrying 24 MFMAs + ~90 vector instructions + 30 LDS accesses per k-tile saturate the SIMD's
+// issue port at ~75 % matrix-pipe occupancy whatever the order.)
 // (A double-buffered variant -- 110 KB of LDS, one block per CU, split/store of tile t+1 issued between the k-halves of
 // tile t -- measured 6-9 % slower than this single-stage kernel at two blocks per CU, and was dropped.  So was a
 // wave-specialised one -- 4 producer waves splitting into a second LDS stage while 4 consumer waves run 64x64 MFMA
@@ -318,7 +322,6 @@ static int gemm_split_dispatch(const GemmArgs& g, bool akc, bool bkc, bool vec, 
     }
 #define VAG_SPLIT_CASE(AK, BKc, V)                                                                    \
     if (akc == AK && bkc == BKc && vec == V) {                                                        \
-        if (g_gemm_planes == 3 && V && vag_opt().gemm_swp != 0) return vag_gemm_swp_launch(g, AK, BKc, grid, s);   \
         if (g_gemm_planes == 2) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 2>), grid, dim3(512), 0, s, g);   \
         else if (g_gemm_planes == 1) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 1>), grid, dim3(512), 0, s, g);   \
         else if (g_gemm_planes == 11) hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, V, 1, true>), grid, dim3(512), 0, s, g);   \
@@ -544,7 +547,6 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
     if (g_gemm_planes == 11) { VAG_GROUP_GO(1, true) }
     else if (g_gemm_planes == 1) { VAG_GROUP_GO(1, false) }
     else if (g_gemm_planes == 2) { VAG_GROUP_GO(2, false) }
-    else if (vag_opt().gemm_swp != 0) { return vag_gemm_swp_group_launch(G, akc, bkc, total, stream); }
     else { VAG_GROUP_GO(3, false) }
 #undef VAG_GROUP_GO
     VAG_LAUNCH_CHECK();

@@ -91,13 +91,9 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b) {     // two fp16
 // +8-10 % on the k-contiguous products (4096^3 NT 147 -> 160 TF/s, d out.weight 96 -> 88 us).  Inline asm keeps it scalar
 // here without switching SLP off for the rest of the file (that cost the recurrent-step kernels more than it gained).
 __device__ __forceinline__ float sub_f32(float a, float b) {
-#ifdef VAG_SPLIT_PLAIN_SUB      // gemm_swp.hip: built with the SLP vectoriser off, and its scheduling groups need to see a VALU instruction
-    return a - b;
-#else
     float r;
     asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
-#endif
 }
 // split two floats into three packed bf16 pairs (low half = first element)
 __device__ __forceinline__ void split3(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
@@ -389,6 +385,3 @@ struct GemmGroupArgs {
     int n;
 };
 
-// gemm_swp.hip (round 4): the software-pipelined bf16x6 kernel
-int vag_gemm_swp_launch(const GemmArgs& g, bool akc, bool bkc, dim3 grid, hipStream_t s);
-int vag_gemm_swp_group_launch(const GemmGroupArgs& G, bool akc, bool bkc, int total_blocks, hipStream_t s);
