@@ -91,4 +91,13 @@ for wgs, thr, lds, us in ((64, 256, 16384, 400), (64, 512, 16384, 400), (256, 25
         run("squatter %3d wg x %4d thr, %3d KB LDS, %4d us, launched %-6s" % (wgs, thr, lds // 1024, us, when),
             (wgs, thr, lds, us), when)
 run("alone (again)")
+# the alternative under data parallelism: the encoder backward as a launch chain (80 launches of 128-256 workgroups)
+L.set_option("persistent", 0)
+print("# launch chain instead of the persistent kernel (set_option persistent 0); 'enc_bwd kernel' is not timed there")
+run("chain, alone")
+for wgs, thr, lds, us in ((64, 256, 16384, 400), (64, 512, 16384, 400), (64, 1024, 65536, 400)):
+    for when in ("before", "after"):
+        run("chain, squatter %3d wg x %4d thr, %3d KB LDS, %4d us, launched %-6s" % (wgs, thr, lds // 1024, us, when),
+            (wgs, thr, lds, us), when)
+L.set_option("persistent", 1)
 ts.fp.grad.zero_()

@@ -120,6 +120,7 @@ class Seq2SeqBase(nn.Module):
         B = enc.shape[0]
         dev = enc.device
         toks = torch.empty(tgt_l, B, dtype=torch.int64, device=dev)
+        self.last_decode_steps = tgt_l
         if not (self.decode_graph and enc.is_cuda):
             pe = ops.KeysProj.apply(enc, dec.attn.attn_e.weight)
             tok = torch.full((B,), SOS_token, dtype=torch.int64, device=dev)
@@ -223,6 +224,7 @@ class Seq2SeqBase(nn.Module):
         call("vag_beam_finish", ptr(nll), ptr(beam, torch.int64), max_length, steps, B, k, ptr(out, torch.int64), ptr(best),
              stream())
         self.last_beam_scores = best
+        self.last_decode_steps = steps            # decoder steps actually run (bench.py prices one step)
         return self._cut(out.cpu().numpy())
 
     @staticmethod
