@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "vag-nmt_amd"))
 import numpy as np
 import torch, bench
 from vagnmt_hip import _lib as L
+L.use_lab_build()          # the product library carries no stamp / debug hooks (csrc/Makefile: LAB=1)
 c = bench.CFG2
 dev = torch.device("cuda:0")
 Tt = c["Tt"]

@@ -20,6 +20,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "vag-nmt_amd"))
 import torch, bench
 from vagnmt_hip.trainer import TrainStep
 from vagnmt_hip import _lib
+_lib.use_lab_build()          # the product library carries no stamp / debug hooks (csrc/Makefile: LAB=1)
 _lib.set_option("gemm_debug", 1)
 from machine_translation_vision.losses import PairwiseRankingLoss
 c = bench.CFG2

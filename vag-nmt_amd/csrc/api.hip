@@ -114,7 +114,7 @@ int vag_set_option(const char* name, int64_t value) {
     VagOptions& o = vag_opt();
     const struct { const char* n; int* p; } ints[] = {
         {"gemm_f32mfma", &o.gemm_f32mfma}, {"gemm_nogroup", &o.gemm_nogroup}, {"gemm_force_tile", &o.gemm_force_tile},
-        {"gemm_force_splitk", &o.gemm_force_splitk}, {"gemm_debug", &o.gemm_debug}, {"head_fuse", &o.head_fuse},
+        {"gemm_force_splitk", &o.gemm_force_splitk}, {"head_fuse", &o.head_fuse},
         {"head_bf16_grads", &o.head_bf16_grads}, {"persistent", &o.persistent}, {"persistent_dec_bwd", &o.persistent_dec_bwd},
         {"persist_timing", &o.persist_timing}, {"s16_one_plane", &o.s16_one_plane},
         {"head_bf16_dlogits", &o.head_bf16_dlogits}};
@@ -122,8 +122,11 @@ int vag_set_option(const char* name, int64_t value) {
         if (strcmp(name, e.n) == 0) { *e.p = (int)value; return VAG_OK; }
     if (strcmp(name, "head_chunk") == 0) { o.head_chunk = value; return VAG_OK; }
     if (strcmp(name, "persist_spin_limit") == 0) { o.persist_spin_limit = value; return VAG_OK; }
+#ifdef VAG_LAB          // lab build only (make LAB=1): phase timestamps of the persistent decoder kernels, per-product choice printing
     if (strcmp(name, "dec_stamps") == 0) { o.dec_stamps = value; return VAG_OK; }
     if (strcmp(name, "dec_bwd_stamps") == 0) { o.dec_bwd_stamps = value; return VAG_OK; }
+    if (strcmp(name, "gemm_debug") == 0) { o.gemm_debug = (int)value; return VAG_OK; }
+#endif
     return VAG_EINVAL;
 }
 

@@ -633,9 +633,11 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
         const int ft = vag_opt().gemm_force_tile, fs = vag_opt().gemm_force_splitk;
         if ((ft == 64 || ft == 128) && fs >= 1 && (fs == 1 || can_split)) { T = ft; splitk = fs; }
     }
+#ifdef VAG_LAB
     if (vag_opt().gemm_debug)
         fprintf(stderr, "[vag_gemm] M=%lld N=%lld K=%lld akc=%d bkc=%d beta=%g -> T=%lld splitk=%lld model=%.1f us\n",
                 (long long)M, (long long)N, (long long)K, (int)akc, (int)bkc, (double)beta, (long long)T, (long long)splitk, best);
+#endif
     const bool big = (T == 128);
     VAG_CHECK_ARG(!a_bf16 || (big && !opt_f32mfma));       // a bf16-stored operand exists for the one-plane split kernel only
     if (rowsum && (!big || opt_f32mfma)) {          // the other kernels do not carry row sums: a column-sum pass over A instead

@@ -915,8 +915,12 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
     constexpr unsigned PER_SHARD = DEC_WGS / SHARDS;
     bool dead = false;
     __syncthreads();
+#ifdef VAG_LAB          // phase timestamps: lab builds only (make LAB=1 -> libvagnmt_lab.so); the product kernels carry no hook
     const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
 #define VAG_STAMP(k) do { if (stamp) a.dbg[t * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define VAG_STAMP(k) do { } while (0)
+#endif
 
     for (int t = 0; t < Tt; ++t) {
         VAG_STAMP(0);
@@ -1314,8 +1318,12 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
     }
     __syncthreads();
 
+#ifdef VAG_LAB          // phase timestamps: lab builds only (make LAB=1 -> libvagnmt_lab.so); the product kernels carry no hook
     const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
 #define VAG_STAMP(k) do { if (stamp) a.dbg[t * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define VAG_STAMP(k) do { } while (0)
+#endif
     for (int t = Tt - 1; t >= 0; --t) {
         VAG_STAMP(0);
         // ================= A: d alpha shares of the own gate columns (atomics); dgh2[t] was published by cell2_bwd =================
@@ -1648,7 +1656,11 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
     a.B = (int)B; a.Ts = (int)Ts; a.Tt = (int)Tt; a.H = (int)H; a.RT = (int)cdiv64(B, 16);
     const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
     a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
+#ifdef VAG_LAB
     a.dbg = reinterpret_cast<unsigned long long*>(vag_opt().dec_stamps);
+#else
+    a.dbg = nullptr;
+#endif
     const int nsc = (int)(Tt * B * Ts);                              // the scores are accumulated with atomics: start from zero
     hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64((int64_t)nwords + nsc, 256)), dim3(256), 0, s, sync, nwords,
                        reinterpret_cast<unsigned*>(psc), nsc);
@@ -1783,7 +1795,11 @@ int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const flo
     a.pe = pe; a.encwp = encwp; a.v = v; a.wcatT = wcatT; a.whh1T = whh1T; a.h0 = h0; a.h2_all = h2_all; a.h1 = h1; a.g1 = g1;
     a.g2 = g2; a.qhp = qhp; a.alpha = alpha; a.d_h2_all = d_h2_all; a.dah = dah; a.dgi2 = dgi2; a.dqgh = dqgh; a.ds = ds;
     a.dgi1 = dgi1; a.dgh1 = dgh1; a.d_h0 = d_h0; a.dal = dal;
+#ifdef VAG_LAB
     a.dbg = reinterpret_cast<unsigned long long*>(vag_opt().dec_bwd_stamps);
+#else
+    a.dbg = nullptr;
+#endif
     a.B = (int)B; a.Ts = (int)Ts; a.Tt = (int)Tt; a.H = (int)H; a.RT = (int)cdiv64(B, 16);
     const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
     a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();

@@ -128,6 +128,19 @@ PROTOS = {
 _lib = None
 
 
+def use_lab_build():
+    """Measurement tools only (tools/exp_dec_phases.py, list_gemms.py): build and load ../lib/libvagnmt_lab.so (`make LAB=1`:
+    phase timestamps inside the persistent decoder kernels, the "gemm_debug" / "dec_stamps" / "dec_bwd_stamps" options)
+    instead of the product library.  Call before the first lib()."""
+    global LIB_PATH
+    assert _lib is None, "use_lab_build() must come before the library is loaded"
+    r = subprocess.run(["make", "-C", CSRC, "-j8", "LAB=1"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libvagnmt_lab.so failed:\n" + r.stderr[-2000:])
+    LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libvagnmt_lab.so")
+    return LIB_PATH
+
+
 def build(verbose=False):
     """Compile libvagnmt.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
