@@ -181,3 +181,26 @@ def test_phased_sequence_runs_the_persistent_kernels_inside_its_graphs():
     # by 5 % of one update and the mean by far less
     assert np.allclose(fa, fb, rtol=2e-4, atol=2e-5), np.abs(fa - fb).max()
     assert float(np.abs(fa - fb).mean()) <= 2e-7
+
+
+@pytest.mark.parametrize("M,N,K", [(192, 9391, 256), (16, 9391, 256), (64, 9391, 256), (97, 4100, 256), (137, 5000, 512), (256, 4096, 768),
+                                   (100, 40000, 256), (133, 4097, 320)])
+def test_tall_skinny_vocabulary_product_is_fp32_grade(M, N, K):
+    """The per-step vocabulary head of decoding / free-running steps (NMT_Decoder.py:143 at one time step) on the tall-skinny
+    bf16x6 kernel: against a float64 product, with the error bound of an fp32 dot product of length K (a few ulp of
+    sum |a||w|); ragged M (not a multiple of 32), N (not a multiple of 64), K in two LDS chunks."""
+    from vagnmt_hip import _lib as L
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.3).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    ldy = (N + 3) // 4 * 4
+    y = torch.full((M, ldy), float("nan"), device="cuda")
+    L.call("vag_linear_fwd", M, N, K, L.ptr(x), L.ptr(W), L.ptr(b), 0, L.ptr(y), L.stream())
+    torch.cuda.synchronize()
+    # vag_linear_fwd writes a dense (M, N) result: read it back with that stride
+    got = y.view(-1)[: M * N].view(M, N).double().cpu()
+    want = x.double().cpu() @ W.double().cpu().t() + b.double().cpu()
+    bound = (x.abs().double().cpu() @ W.abs().double().cpu().t() + b.abs().double().cpu()) * 2.0 ** -21
+    assert torch.isfinite(got).all()
+    assert bool(((got - want).abs() <= bound).all()), float(((got - want).abs() / bound).max())

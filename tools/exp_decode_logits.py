@@ -19,4 +19,10 @@ for M in (192, 128, 96, 64, 16):
         except Exception as e:
             row.append("T=%d failed" % tile)
     L.set_option("gemm_force_tile", 0); L.set_option("gemm_force_splitk", 0)
+    yd = torch.empty(M, N, device=dev)
+    for f32, name in ((0, "linear_fwd (tall-skinny bf16x6)"), (1, "linear_fwd with gemm_f32mfma=1 (round-3 path)")):
+        L.set_option("gemm_f32mfma", f32)
+        t = bench._time_graph(lambda: L.call("vag_linear_fwd", M, N, K, L.ptr(x), L.ptr(W), L.ptr(b), 0, L.ptr(yd), L.stream()), reps=20)
+        row.append("%s %.1f us" % (name, t * 1e6))
+    L.set_option("gemm_f32mfma", 0)
     print("M=%3d: %s" % (M, " | ".join(row)), flush=True)

@@ -51,27 +51,22 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __res
     // replica -- sees it and the optimiser skips the step (optim.hip)
     if (poison && blockIdx.x == 0 && threadIdx.x == 0 && __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
         gW[0] = __builtin_inff();
-    const int E4 = E >> 2;
-    const int64_t total = (int64_t)T * B * E4;
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t row = i / E4;
-        const int e = (int)(i - row * E4) << 2;
+    // One WAVE per (row, 64-float column block): its lanes add 64 CONSECUTIVE floats, i.e. every atomic wave-instruction covers
+    // 256 contiguous bytes -- the shape float atomics run at full rate for (MI355X_MICROARCH.md, global float atomics).  Round 3
+    // gave every lane a float4 and issued four atomics of one dword every 16 bytes: a quarter of each 64-byte atomic request
+    // carried data (16 us for the decoder's 2560 x 256 rows; now ~5).
+    const int EB = (E + 63) >> 6;                                  // 64-float blocks per row
+    const int64_t total = (int64_t)T * B * EB;                     // wave tasks
+    const int lane = threadIdx.x & 63;
+    for (int64_t w = blockIdx.x * 4ll + (threadIdx.x >> 6); w < total; w += (int64_t)gridDim.x * 4) {
+        const int64_t row = w / EB;
+        const int e = (int)(w - row * EB) * 64 + lane;
         const int t = (int)(row / B), b = (int)(row - (int64_t)t * B);
         const int64_t tok = idx[b * isb + t * ist];
-        if (tok == 0) continue;   // padding_idx: no gradient
-        float4 v = *reinterpret_cast<const float4*>(g + row * E + e);
-        if (rng && p > 0.f) {
-            const uint64_t o = (uint64_t)row * E + e;
-            v.x *= vag_drop_mul(rng, sid, o + 0, p);
-            v.y *= vag_drop_mul(rng, sid, o + 1, p);
-            v.z *= vag_drop_mul(rng, sid, o + 2, p);
-            v.w *= vag_drop_mul(rng, sid, o + 3, p);
-        }
-        float* d = gW + tok * E + e;
-        atomicAdd(d + 0, v.x);
-        atomicAdd(d + 1, v.y);
-        atomicAdd(d + 2, v.z);
-        atomicAdd(d + 3, v.w);
+        if (tok == 0 || e >= E) continue;   // padding_idx: no gradient
+        float v = g[row * E + e];
+        if (rng && p > 0.f) v *= vag_drop_mul(rng, sid, (uint64_t)row * E + e, p);
+        atomicAdd(gW + tok * E + e, v);
     }
 }
 
@@ -80,7 +75,7 @@ int vag_embed_scatter_launch(const int64_t* idx, int64_t ist, int64_t isb, int64
                              const unsigned* poison) {
     VAG_CHECK_ARG(idx && g && gW && E > 0 && E % 4 == 0 && T >= 0 && B >= 0);
     if (T * B == 0) return VAG_OK;
-    hipLaunchKernelGGL(embed_scatter_kernel, grid1d(T * B * E / 4), dim3(256), 0, s, idx, ist, isb, (int)T, (int)B, g,
+    hipLaunchKernelGGL(embed_scatter_kernel, grid1d(T * B * ((E + 63) / 64) * 64), dim3(256), 0, s, idx, ist, isb, (int)T, (int)B, g,
                        (int)E, gW, rng, sid, p, poison);
     VAG_LAUNCH_CHECK();
     return VAG_OK;

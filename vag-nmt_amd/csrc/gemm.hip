@@ -1391,6 +1391,175 @@ int vag_skinny_gather_launch(int64_t M, int64_t N, int64_t K, const float* table
     return VAG_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tall-skinny product for the per-step vocabulary head of decoding and of free-running training steps (round 4):
+// out[M, N] = A[M, K] W[N, K]^T + bias, M <= 256 rows (B*k hypotheses, or the batch), N = V large, K = E small.
+// (NMT_Decoder.py:143 at one time step: models/...V11.py:148-160 free running, :259-313 beam search.)
+// The 16x16-tile skinny kernel requests M*N*K/2 bytes chip-wide (230 MB at 192 x 9391 x 256: 38 us) and the 64x64 LDS-tiled f32
+// kernel took 17.5 us in the beam step / 16 us in the greedy step (profiles/r04_decode_kernel_stats.csv): both pay for
+// re-reading operands, W above all.  Here a workgroup owns 64 columns for ALL rows: its W tile is read once, split exactly into
+// three bf16 planes and kept in LDS (K chunks of 256: 99 KB), wave (row tile, k split) streams its 32 rows of A straight from
+// memory in MFMA operand layout, splits them in registers and runs the six products (bf16x6, fp32-grade: the arithmetic of the
+// training step's logits product, gemm.hip above).  Requested bytes: N/64 x (M + 64) x K x 4 (38 MB instead of 230).
+struct TallArgs {
+    const float* A; const float* W; const float* bias; float* out;
+    int64_t lda, ldw, ldo;
+    int M, N, K, RT, KS;       // RT = ceil(M / 32) row tiles, KS = k splits: RT * KS <= 8 waves
+};
+constexpr int TALL_KC = 256;                       // K chunk staged in LDS
+constexpr int TALL_LD = TALL_KC + 8;               // bf16 elements per LDS row: 528 B = 132 dwords = 4 mod 64 banks: conflict-free b128 reads
+constexpr int TALL_PLANE = 64 * TALL_LD;
+constexpr int TALL_LDS_BYTES = 3 * TALL_PLANE * 2; // 101376
+__global__ __launch_bounds__(512, 2) void skinny_tall_kernel(TallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 tall_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 64;
+    const int rt = wave / a.KS, ks = wave % a.KS;
+    const bool active = rt < a.RT;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int arow = min(rt * 32 + (lane & 31), a.M - 1);
+    const float* Ap = a.A + (int64_t)arow * a.lda + 8 * (lane >> 5);
+    // staging map: thread -> (W row = tid >> 3, 32 consecutive k at (tid & 7) * 32)
+    const int srow = threadIdx.x >> 3, sk = (threadIdx.x & 7) * 32;
+    const float* Wp = a.W + (int64_t)min(n0 + srow, a.N - 1) * a.ldw + sk;
+    for (int kc = 0; kc < a.K; kc += TALL_KC) {
+        const int klen = min(TALL_KC, a.K - kc);              // multiple of 32 (launcher)
+        if (kc > 0) __syncthreads();
+        if (sk < klen) {
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(Wp + kc + 4 * i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                      // 8 consecutive k -> one 16-byte store per plane
+                unsigned p[3][4];
+                split3(v[2 * i].x, v[2 * i].y, p[0][0], p[1][0], p[2][0]);
+                split3(v[2 * i].z, v[2 * i].w, p[0][1], p[1][1], p[2][1]);
+                split3(v[2 * i + 1].x, v[2 * i + 1].y, p[0][2], p[1][2], p[2][2]);
+                split3(v[2 * i + 1].z, v[2 * i + 1].w, p[0][3], p[1][3], p[2][3]);
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    *reinterpret_cast<uint4*>(tall_smem + q * TALL_PLANE + srow * TALL_LD + sk + 8 * i) =
+                        make_uint4(p[q][0], p[q][1], p[q][2], p[q][3]);
+            }
+        }
+        __syncthreads();
+        if (active) {
+            const int per = klen / a.KS;                       // k range of this wave inside the chunk: 64, 128 or 256 (launcher)
+            const int kb = ks * per;
+            const __bf16* Bf = tall_smem + (lane & 31) * TALL_LD + 8 * (lane >> 5);
+            // the wave's rows of A in groups of 64 k (8 x 16-byte loads per lane), the next group in flight under the current
+            // one's MFMAs: a k-step that waited for its own two loads cost a memory round trip each (16 us at 16 k-steps)
+            const int ng = per >> 6;
+            float4 xa[2][8];
+            auto load_group = [&](int g, float4 (&x)[8]) {
+                const float* src = Ap + kc + kb + 64 * g;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    x[2 * i] = *reinterpret_cast<const float4*>(src + 16 * i);
+                    x[2 * i + 1] = *reinterpret_cast<const float4*>(src + 16 * i + 4);
+                }
+            };
+            auto compute_group = [&](int g, const float4 (&x)[8]) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k0 = kb + 64 * g + 16 * i;
+                    const float4 x0 = x[2 * i], x1 = x[2 * i + 1];
+                    unsigned q[3][4];
+                    split3(x0.x, x0.y, q[0][0], q[1][0], q[2][0]);
+                    split3(x0.z, x0.w, q[0][1], q[1][1], q[2][1]);
+                    split3(x1.x, x1.y, q[0][2], q[1][2], q[2][2]);
+                    split3(x1.z, x1.w, q[0][3], q[1][3], q[2][3]);
+                    bf16x8 af[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const u32x4 t = {q[p][0], q[p][1], q[p][2], q[p][3]};
+                        af[p] = __builtin_bit_cast(bf16x8, t);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        bf16x8 bf[3];
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) bf[p] = sp_frag(Bf + p * TALL_PLANE + j * 32 * TALL_LD + k0);
+                        // smallest terms first (the order of sp_compute)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[j], 0, 0, 0);
+                    }
+                }
+            };
+            load_group(0, xa[0]);
+            for (int g = 0; g < ng; g += 2) {
+                if (g + 1 < ng) load_group(g + 1, xa[1]);
+                compute_group(g, xa[0]);
+                if (g + 1 < ng) {
+                    if (g + 2 < ng) load_group(g + 2, xa[0]);
+                    compute_group(g + 1, xa[1]);
+                }
+            }
+        }
+    }
+    // the k splits of a row tile meet in LDS (the W planes are done with)
+    if (a.KS > 1) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(tall_smem);      // [wave][j][r][lane]
+        if (active && ks > 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((wave * 2 + j) * 16 + r) * 64 + lane] = acc[j][r];
+        }
+        __syncthreads();
+        if (active && ks == 0) {
+            for (int o = 1; o < a.KS; ++o)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][r] += red[(((wave + o) * 2 + j) * 16 + r) * 64 + lane];
+        }
+    }
+    if (!active || ks != 0) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + j * 32 + (lane & 31);
+        if (col >= a.N) continue;
+        const float bv = a.bias ? a.bias[col] : 0.f;
+        const int row0 = rt * 32 + 4 * (lane >> 5);
+        gemm_epilogue16(acc[j], a.out + (int64_t)row0 * a.ldo + col, a.ldo, a.M - row0, 1.f, 0.f, bv, 0, false);
+    }
+}
+static bool skinny_tall_ok(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw) {
+    // measured (tools/exp_tall.py, 20 launches per graph; us): M = 192: V = 9391 16.2 vs 18.3 on the LDS-tiled f32 kernel, V = 40000 45 vs 49;
+    // M = 16: 7.1 vs 4.1 on the 16x16 skinny kernel -- one workgroup per CU is a chain of memory round trips, so only the wide cases come here
+    return M > 96 && M <= 256 && N >= 4096 && K >= 256 && K % 256 == 0 && K <= 4096 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) &&
+           aligned16(W);
+}
+static int skinny_tall_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
+                              const float* bias, float* out, int64_t ldo, hipStream_t stream) {
+    TallArgs a;
+    a.A = A; a.W = W; a.bias = bias; a.out = out; a.lda = lda; a.ldw = ldw; a.ldo = ldo;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.RT = (int)cdiv64(M, 32);
+    a.KS = a.RT <= 2 ? 4 : (a.RT <= 4 ? 2 : 1);     // k range per wave and chunk: a multiple of 64 (K % 256 == 0, skinny_tall_ok)
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VAG_EINVAL;
+    if (!(done.load(std::memory_order_acquire) & (1ull << dev))) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_tall_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                TALL_LDS_BYTES) != hipSuccess) return VAG_EINVAL;
+        done.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(skinny_tall_kernel, dim3((unsigned)cdiv64(N, 64)), dim3(512), TALL_LDS_BYTES, stream, a);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
 int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
                       const float* bias, const float* addend, int64_t ldadd, float* out, int64_t ldo, int act,
                       hipStream_t stream, bool w16) {
@@ -1405,6 +1574,9 @@ int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
         VAG_LAUNCH_CHECK();
         return VAG_OK;
     }
+    // vocabulary-sized products of one decoding / free-running step: the tall-skinny bf16x6 kernel above
+    if (!addend && act == 0 && vag_opt().gemm_f32mfma == 0 && skinny_tall_ok(M, N, K, A, lda, W, ldw))
+        return skinny_tall_launch(M, N, K, A, lda, W, ldw, bias, out, ldo, stream);
     // every 16x16 output tile re-reads its operand rows: M*N*K/2 bytes requested in all.  Measured at the beam-decode
     // shape (B*k = 192 rows): the 192x2560x512 query/gate product (126 MB) is still faster here (5 vs 16 us), the
     // 192x9391x256 vocabulary product (230 MB) is faster on the LDS-tiled kernel (19 vs 38 us).
