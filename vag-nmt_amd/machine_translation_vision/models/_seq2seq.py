@@ -143,8 +143,7 @@ class Seq2SeqBase(nn.Module):
                 hc, tc = st["h"], st["tok"]
                 for i in range(CH):
                     hc, c, e, _ = ops.decode_step(st["enc"], st["pe"], st["mask"], 1, tc, hc, emb, dp, st["prep"])
-                    _, tc = ops.head_logp_step(hc, c, e, hp, want_argmax=True)
-                    st["chunk"][i].copy_(tc)
+                    _, tc = ops.head_logp_step(hc, c, e, hp, want_argmax=True, argmax_out=st["chunk"][i])
                 st["h"].copy_(hc)
                 st["tok"].copy_(tc)
             st["graph"] = g

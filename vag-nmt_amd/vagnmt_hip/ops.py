@@ -481,13 +481,18 @@ def decode_step(enc, pe, mask, rows_per_src, tok, h_in, emb, dec, prep):
     return h_out, c, e, alpha
 
 
-def head_logp_step(h2, c, e, head, want_argmax=False):
+def head_logp_step(h2, c, e, head, want_argmax=False, argmax_out=None):
+    """argmax_out: optional (N,) int64 HIP tensor the arg-max tokens are written into (greedy decode hands in a row of its token
+    chunk, which saves a copy launch per step)."""
     N, H = h2.shape
     E = e.shape[1]
     V = head[7].shape[0]
     ldl = (V + 3) // 4 * 4
     logp = _f32(N, ldl, like=h2)
-    am = torch.empty(N, dtype=I64, device=h2.device) if want_argmax else None
+    am = None
+    if want_argmax:
+        am = argmax_out if argmax_out is not None else torch.empty(N, dtype=I64, device=h2.device)
+        assert am.dtype == I64 and am.is_contiguous() and am.numel() == N
     scratch = _f32(2 * N * E, like=h2)
     call("vag_head_logp_step", ptr(h2), ptr(c), ptr(e), _head_w(head), N, E, H, V, ptr(logp), ldl,
          ptr(am, I64) if am is not None else None, ptr(scratch), stream())
