@@ -492,6 +492,20 @@ def pmc_traffic():
     return None
 
 
+def pmc_step(cfg):
+    """Whole-step HBM-side traffic (L2 misses: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes over three eager optimiser steps:
+    tools/prof_step.py -> tools/pmc_step_summary.py -> profiles/rNN_pmc_step_<cfg>.json): bytes per step and per kernel."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step_%s.json" % cfg)), reverse=True):
+        try:
+            d = json.load(open(path))
+            d["file"] = os.path.relpath(path, ROOT)
+            return d
+        except Exception:
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -756,8 +770,17 @@ def main():
             # the row is the decoder forward step as a whole against its streaming bytes (the BASELINE target quantity)
             res["roofline"] = dict(res["roofline_decoder_step"])
         if args.config != "cfg2":
-            for k_ in [k_ for k_ in res if k_.startswith("roofline")]:                     # PMC passes were taken at cfg2
+            for k_ in [k_ for k_ in res if k_.startswith("roofline")]:                     # the per-kernel PMC passes were taken at cfg2
                 res[k_]["traffic"] = None
+        ps = pmc_step("cfg2" if args.config == "cfg2" else "cfg5") if args.config != "cfg5-f32" else None
+        if ps and args.config == "cfg5":
+            # configs[4]: the decoder forward step = its four chain kernels per time step (profiles/rNN_pmc_step_cfg5.json)
+            names = ("gru_step_kernel<", "skinny_plain_kernel<8, true>", "attn_dot_side_kernel<0,", "attn_ctx_gru_kernel<true>")
+            by = sum(v["fetch_bytes_per_step"] + v["write_bytes_per_step"] for k_, v in ps["kernels"].items()
+                     if any(k_.startswith(n) for n in names))
+            for k_ in ("roofline", "roofline_decoder_step"):
+                res[k_]["traffic"] = by / c["Tt"]
+                res[k_]["traffic_source"] = ps["file"] + ": gru_step + skinny (query) + attn_dot_side<0> + attn_ctx_gru, per time step"
         whole = ab["F_enc"] * 2 * c["Ts"] + ab["F_dec"] * c["Tt"] + ab["Bk_enc"] * 2 * c["Ts"] + ab["Bk_dec"] * c["Tt"]
         if args.config == "cfg2":
             whole = 6.150e9            # chains + once-per-batch products (fwd, 2x bwd) + Adam, evaluated at cfg2
@@ -765,7 +788,10 @@ def main():
         res["roofline_whole_step"] = {"bound": "hbm", "kernel": "zero-grad + forward + backward + clip + Adam (SURVEY 8d streaming model)",
                                       "achieved": whole / step_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                       "frac": whole / step_s / HBM_PEAK, "algorithmic_bytes_per_step": whole,
-                                      "target_frac": 0.40}
+                                      "target_frac": 0.40,
+                                      "traffic": ps["step_bytes"] if ps else None,
+                                      "traffic_source": (ps["file"] + ": L2-miss bytes of one optimiser step (FETCH_SIZE x2 + WRITE_SIZE)")
+                                      if ps else None}
         if dp_info is not None:
             res["dp"] = dp_info
         if world == 1 and not args.no_extras:

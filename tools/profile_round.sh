@@ -27,6 +27,13 @@ rm -rf /tmp/pf /tmp/pw /tmp/pg
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf -o f --output-format csv -- python3 $ROOT/tools/prof_decoder_fwd.py > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pw -o w --output-format csv -- python3 $ROOT/tools/prof_decoder_fwd.py > $OUT/pmc_write.log 2>&1
 python3 $ROOT/tools/pmc_summary.py /tmp/pf /tmp/pw $OUT/pmc.json > $OUT/pmc_summary.log 2>&1 || tail -5 $OUT/pmc_summary.log
+# whole-step HBM traffic, configs[1] and configs[4]
+for CFG in cfg2 cfg5; do
+  rm -rf /tmp/sf /tmp/sw
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/sf -o f --output-format csv -- python3 $ROOT/tools/prof_step.py $CFG > $OUT/pmc_step_fetch_$CFG.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/sw -o w --output-format csv -- python3 $ROOT/tools/prof_step.py $CFG > $OUT/pmc_step_write_$CFG.log 2>&1
+  python3 $ROOT/tools/pmc_step_summary.py /tmp/sf /tmp/sw $OUT/pmc_step_$CFG.json > $OUT/pmc_step_$CFG.txt 2>&1 || tail -5 $OUT/pmc_step_$CFG.txt
+done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pg -o g --output-format csv -- python3 $ROOT/tools/pmc_gemm.py > $OUT/pmc_gemm.log 2>&1 || true
 python3 $ROOT/tools/pmc_agg.py /tmp/pg > $OUT/pmc_gemm.txt 2>&1 || true
 cat $OUT/pmc.json; cat $OUT/pmc_gemm.txt
