@@ -113,7 +113,7 @@ int vag_set_option(const char* name, int64_t value) {
     VAG_CHECK_ARG(name != nullptr);
     VagOptions& o = vag_opt();
     const struct { const char* n; int* p; } ints[] = {
-        {"gemm_f32mfma", &o.gemm_f32mfma}, {"gemm_nogroup", &o.gemm_nogroup}, {"gemm_force_tile", &o.gemm_force_tile},
+        {"gemm_f32mfma", &o.gemm_f32mfma}, {"gemm_nogroup", &o.gemm_nogroup}, {"gemm_big", &o.gemm_big}, {"gemm_force_tile", &o.gemm_force_tile},
         {"gemm_force_splitk", &o.gemm_force_splitk}, {"head_fuse", &o.head_fuse},
         {"head_bf16_grads", &o.head_bf16_grads}, {"persistent", &o.persistent}, {"persistent_dec_bwd", &o.persistent_dec_bwd},
         {"persist_timing", &o.persist_timing}, {"s16_one_plane", &o.s16_one_plane},
@@ -126,6 +126,7 @@ int vag_set_option(const char* name, int64_t value) {
     if (strcmp(name, "dec_stamps") == 0) { o.dec_stamps = value; return VAG_OK; }
     if (strcmp(name, "dec_bwd_stamps") == 0) { o.dec_bwd_stamps = value; return VAG_OK; }
     if (strcmp(name, "gemm_debug") == 0) { o.gemm_debug = (int)value; return VAG_OK; }
+    if (strcmp(name, "gemm_planes") == 0) { vag_gemm_set_planes((int)value); return VAG_OK; }      // calling thread: 3, 2, 1, 11
 #endif
     return VAG_EINVAL;
 }

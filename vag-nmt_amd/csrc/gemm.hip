@@ -295,6 +295,150 @@ __global__ __launch_bounds__(512, PL == 1 ? 6 : 4) void gemm_split_group_kernel(
     gemm_split_body<AKC, BKC, true, PL, F16>(a, smem, bx, by, bz);
 }
 
+// ---- round 4: 256 x 256 block tile for the ONE-plane products of the 2-byte storage mode (configs[4]) ----------------------
+// With one plane per operand a 128 x 128 x 32 k-tile is 8 MFMAs per wave (256 matrix-pipe cycles per SIMD and block) behind 32 KB of
+// fp32 operands: at the ~70 GB/s a CU draws from its L2 that is 0.46 us of ingest per 0.11 us of MFMA work -- the kernel above runs at
+// 280-560 TF/s on configs[4]'s shapes (11-22 % of the bf16 peak; tools/exp_gemm_oneplane.py), bound by operand BYTES, as DESIGN
+// section 9 already said of the large products in that mode.  A 256 x 256 tile does four times the MFMA work per k-tile on twice
+// the bytes.  Eight waves (2 x 4, 128 x 64 outputs each: 8 accumulators), operands still fp32 in memory and rounded on their way
+// into LDS (sp_load / sp_store, one plane; an operand's 256 rows are two of the 128-row images), two LDS stages of 40 KB, the loads of
+// k-tile t + 2 and the store of t + 1 issued around the MFMAs of t, ONE barrier per k-tile.
+constexpr int BIG_STAGE = 4 * SP_PLANE;                 // bf16 elements per stage: A halves 0,1 then B halves 0,1 (4 x 10 KB)
+constexpr int BIG_LDS_BYTES = 2 * BIG_STAGE * 2;        // 81920
+__device__ __forceinline__ void big_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool AKC, bool BKC, bool F16, bool ABF>
+__device__ __forceinline__ void gemm_big_body(const GemmArgs& a, __bf16* smem, int bx, int by, int bz) {
+    const int m0 = by * 256, n0 = bx * 256;
+    const int kbeg = bz * a.kchunk;
+    const int kend = min(a.K, kbeg + a.kchunk);
+    const int nt = (kend - kbeg + SP_BK - 1) / SP_BK;
+    const int nfull = (kend - kbeg) / SP_BK;               // full k-tiles: precomputed-offset loads (a bf16-stored A keeps its own loader)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 2, wn = wave & 3;               // rows wm * 128 .. +128 (= A half wm), columns wn * 64 .. +64 (B half wn >> 1)
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // fragment bases inside a stage (k-contiguous operands) / first outer index inside the half (outer-contiguous ones)
+    const int foff_a = wm * SP_PLANE + (lane & 31) * SP_LD + 8 * (lane >> 5);
+    const int foff_b = (2 + (wn >> 1)) * SP_PLANE + ((wn & 1) * 64 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
+    SpRegs ra[2], rb[2];                                   // halves of the k-tile in flight
+    SpFast<AKC> fa[2];
+    SpFast<BKC> fb[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        // a half that lies entirely outside the operand is clamped onto its last valid row / group like any other out-of-range row
+        if (!ABF) sp_fast_init<AKC>(fa[h], a.A, a.sa_o, a.sa_k, min(m0 + 128 * h, AKC ? a.M - 1 : ((a.M - 1) & ~3)), kbeg, a.M);
+        sp_fast_init<BKC>(fb[h], a.B, a.sb_o, a.sb_k, min(n0 + 128 * h, BKC ? a.N - 1 : ((a.N - 1) & ~3)), kbeg, a.N);
+    }
+    auto load_tile = [&](int t) {
+        const int k0 = kbeg + t * SP_BK;
+        if (t < nfull) {            // ONE branch around all of a k-tile's loads: a select per load makes hipcc wait for each load in turn
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (ABF) sp_load_bf16<AKC>(reinterpret_cast<const unsigned short*>(a.A), a.sa_o, a.sa_k, m0 + 128 * h, k0, a.M, kend, ra[h]);
+                else sp_fast_load<AKC>(fa[h], ra[h]);
+                sp_fast_load<BKC>(fb[h], rb[h]);
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (ABF) sp_load_bf16<AKC>(reinterpret_cast<const unsigned short*>(a.A), a.sa_o, a.sa_k, m0 + 128 * h, k0, a.M, kend, ra[h]);
+                else sp_load<AKC, true>(a.A, a.sa_o, a.sa_k, m0 + 128 * h, k0, a.M, kend, ra[h]);
+                sp_load<BKC, true>(a.B, a.sb_o, a.sb_k, n0 + 128 * h, k0, a.N, kend, rb[h]);
+            }
+        }
+    };
+    auto store_tile = [&](int stage) {
+        __bf16* S = smem + stage * BIG_STAGE;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            sp_store<AKC, 1, F16, ABF>(S + h * SP_PLANE, ra[h]);
+            sp_store<BKC, 1, F16>(S + (2 + h) * SP_PLANE, rb[h]);
+        }
+    };
+    auto compute = [&](int stage) {
+        const __bf16* S = smem + stage * BIG_STAGE;
+        const __bf16* Ah = S + wm * SP_PLANE;                       // this wave's A half (outer-contiguous image base)
+        const __bf16* Bh = S + (2 + (wn >> 1)) * SP_PLANE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bf[j] = BKC ? sp_frag(S + foff_b + j * 32 * SP_LD + ks * 16) : sp_frag_tr(Bh, (wn & 1) * 64 + 32 * j, ks);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                af[i] = AKC ? sp_frag(S + foff_a + i * 32 * SP_LD + ks * 16) : sp_frag_tr(Ah, 32 * i, ks);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (F16)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i]), __builtin_bit_cast(f16x8, bf[j]),
+                                                                           acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+    load_tile(0);
+    store_tile(0);
+    if (nt > 1) load_tile(1);
+    big_barrier();
+    for (int t = 0; t < nt; ++t) {
+        const int st = t & 1;
+        if (t + 1 < nt) store_tile(st ^ 1);           // k-tile t + 1 (in registers since the previous iteration)
+        if (t + 2 < nt) load_tile(t + 2);
+        compute(st);
+        big_barrier();
+    }
+    const bool atomic = a.splitk > 1;
+    const bool first = bz == 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (col >= a.N) continue;
+        const float bv = (a.bias && first) ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row0 = m0 + wm * 128 + i * 32 + 4 * (lane >> 5);
+            if (a.c_half) gemm_epilogue16(acc[i][j], a.C, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, atomic, 1, (int64_t)row0 * a.ldc + col);
+            else gemm_epilogue16(acc[i][j], a.C + (int64_t)row0 * a.ldc + col, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, atomic);
+        }
+    }
+}
+template <bool AKC, bool BKC, bool F16, bool ABF>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 big_smem[];
+    gemm_big_body<AKC, BKC, F16, ABF>(a, big_smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+template <bool AKC, bool BKC, bool F16>
+__global__ __launch_bounds__(512, 2) void gemm_big_group_kernel(GemmGroupArgs G) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 big_smem[];
+    int p = 0;
+    while (p + 1 < G.n && (int)blockIdx.x >= G.start[p + 1]) ++p;
+    const GemmArgs& a = G.p[p];
+    const int id = blockIdx.x - G.start[p];
+    const int tn = (a.N + 255) / 256, tm = (a.M + 255) / 256;
+    const int bx = id % tn, by = (id / tn) % tm, bz = id / (tn * tm);
+    gemm_big_body<AKC, BKC, F16, false>(a, big_smem, bx, by, bz);
+}
+template <typename K> static bool big_attr(K kernel) {          // dynamic LDS above 64 KB: the attribute once per kernel and device
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (done.load(std::memory_order_acquire) & (1ull << dev)) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_BYTES) != hipSuccess)
+        return false;
+    done.fetch_or(1ull << dev, std::memory_order_release);
+    return true;
+}
+
 // (Round 4, measured and dropped -- profiles/r04_exp_gemm_waves4.txt, _pp.txt, _swp.txt: a four-wave block with 64 x 64 wave tiles;
 // a ping-pong of the two wave halves between MFMA and split intervals; one software-pipelined MFMA + split stream per wave.  All within
 // +-10 % of this kernel: two waves per SIMD carrying 24 MFMAs + ~90 vector instructions + 30 LDS accesses per k-tile saturate the SIMD's
@@ -401,16 +545,16 @@ void vag_gemm_group_abort() {        // error path: drop the queues
 // priced by simulating that schedule (block cost = slice length + a fixed prologue / epilogue share) plus the extra atomic
 // traffic of the slices.  (The first version aimed at ~512 blocks with one common split: totals of 528 / 576 blocks -- the
 // decoder / encoder weight-gradient groups -- ran a full second round for 16 / 64 blocks: 204 and 108 us.)
-struct GroupPlanEntry { int n; int m[GROUP_MAX], nn[GROUP_MAX], k[GROUP_MAX]; bool acc[GROUP_MAX], half[GROUP_MAX]; int split[GROUP_MAX], order[GROUP_MAX]; };
-static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order);
+struct GroupPlanEntry { int n, tile; int m[GROUP_MAX], nn[GROUP_MAX], k[GROUP_MAX]; bool acc[GROUP_MAX], half[GROUP_MAX]; int split[GROUP_MAX], order[GROUP_MAX]; };
+static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order, int tile);
 // plans are remembered per list of shapes (a training run repeats a handful of them; the simulation costs ~1 ms of host time)
-static void group_plan(const GemmArgs* q, int n, int* split, int* order) {
+static void group_plan(const GemmArgs* q, int n, int* split, int* order, int tile = 128) {
     constexpr int CACHE = 64;
     static thread_local GroupPlanEntry cache[CACHE];
     static thread_local int used = 0, next = 0;
     for (int e = 0; e < used; ++e) {
         const GroupPlanEntry& c = cache[e];
-        bool same = c.n == n;
+        bool same = c.n == n && c.tile == tile;
         for (int i = 0; same && i < n; ++i)
             same = c.m[i] == q[i].M && c.nn[i] == q[i].N && c.k[i] == q[i].K && c.acc[i] == (q[i].beta != 0.f) &&
                    c.half[i] == (q[i].c_half != 0);
@@ -419,20 +563,21 @@ static void group_plan(const GemmArgs* q, int n, int* split, int* order) {
             return;
         }
     }
-    group_plan_compute(q, n, split, order);
+    group_plan_compute(q, n, split, order, tile);
     GroupPlanEntry& c = cache[next];
     next = (next + 1) % CACHE;
     if (used < CACHE) ++used;
-    c.n = n;
+    c.n = n; c.tile = tile;
     for (int i = 0; i < n; ++i) {
         c.m[i] = q[i].M; c.nn[i] = q[i].N; c.k[i] = q[i].K; c.acc[i] = q[i].beta != 0.f; c.half[i] = q[i].c_half != 0;
         c.split[i] = split[i]; c.order[i] = order[i];
     }
 }
-static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order) {
-    constexpr int SLOTS = 512;
-    constexpr double C0 = 4.0;                  // k-steps a block spends outside its main loop
-    constexpr double US_PER_KSTEP = 2.5;        // one 128x128x32 step of a block sharing its CU
+static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order, int tile) {
+    constexpr int MAXSLOTS = 512;
+    const int SLOTS = tile == 256 ? 256 : 512;  // 256 x 256 one-plane blocks (gemm_big_kernel): one per CU
+    const double C0 = tile == 256 ? 8.0 : 4.0;  // k-steps a block spends outside its main loop
+    const double US_PER_KSTEP = tile == 256 ? 1.0 : 2.5;        // one 128x128x32 step of a block sharing its CU / one 256x256x32 one-plane step
     int cand[GROUP_MAX * 10 + 1], nc = 0;
     for (int i = 0; i < n; ++i) {
         const int ks = (int)cdiv64(q[i].K, SP_BK);
@@ -445,7 +590,7 @@ static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order)
         }
     }
     double best = 1e30;
-    double load[SLOTS];
+    double load[MAXSLOTS];
     for (int c = 0; c < nc; ++c) {
         const int L = cand[c];
         int sp[GROUP_MAX], len[GROUP_MAX], ord[GROUP_MAX];
@@ -469,7 +614,7 @@ static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order)
         double makespan = 0.0;
         for (int j = 0; j < n; ++j) {
             const int i = ord[j];
-            const int64_t blocks = cdiv64(q[i].M, 128) * cdiv64(q[i].N, 128) * sp[i];
+            const int64_t blocks = cdiv64(q[i].M, tile) * cdiv64(q[i].N, tile) * sp[i];
             const double cost = (double)len[i] + C0;
             for (int64_t b = 0; b < blocks; ++b) {
                 std::pop_heap(load, load + SLOTS, std::greater<double>());
@@ -494,7 +639,7 @@ int vag_gemm_group_plan_host(int n, const int64_t* M, const int64_t* N, const in
         VAG_CHECK_ARG(M[i] > 0 && N[i] > 0 && K[i] > 0 && M[i] < (1ll << 30) && N[i] < (1ll << 30) && K[i] < (1ll << 30));
         q[i].M = (int)M[i]; q[i].N = (int)N[i]; q[i].K = (int)K[i]; q[i].beta = accumulate[i] ? 1.f : 0.f; q[i].c_half = 0;
     }
-    group_plan_compute(q, n, split, order);
+    group_plan_compute(q, n, split, order, 128);
     return VAG_OK;
 }
 static int gemm_group_flush_layout(int lay, hipStream_t stream) {
@@ -512,7 +657,11 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
     GemmGroupArgs G;
     G.n = n;
     int split[GROUP_MAX], order[GROUP_MAX];
-    group_plan(q, n, split, order);
+    // the 2-byte storage mode's one-plane products: 256 x 256 tiles when every product of the group is large enough for them
+    bool big = (g_gemm_planes == 1 || g_gemm_planes == 11) && vag_opt().gemm_big != 0;
+    for (int j = 0; j < n && big; ++j) big = q[j].M >= 192 && q[j].N >= 192 && q[j].rowsum == nullptr && !q[j].a_bf16;
+    const int T = big ? 256 : 128;
+    group_plan(q, n, split, order, T);
     int total = 0;
     for (int j = 0; j < n; ++j) {
         GemmArgs& a = G.p[j];
@@ -531,7 +680,7 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
             VAG_LAUNCH_CHECK();
         }
         G.start[j] = total;
-        total += (int)(cdiv64(a.M, 128) * cdiv64(a.N, 128)) * s_i;
+        total += (int)(cdiv64(a.M, T) * cdiv64(a.N, T)) * s_i;
     }
     G.start[n] = total;
     const bool akc = (lay & 2) != 0, bkc = (lay & 1) != 0;
@@ -544,7 +693,18 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
         hipLaunchKernelGGL((gemm_split_group_kernel<true, true, PLN, F>), dim3((unsigned)total), dim3(512), 0, stream, G);    \
     else                                                                                                                      \
         hipLaunchKernelGGL((gemm_split_group_kernel<false, true, PLN, F>), dim3((unsigned)total), dim3(512), 0, stream, G);
-    if (g_gemm_planes == 11) { VAG_GROUP_GO(1, true) }
+    if (big) {
+#define VAG_BIG_GO(AK, BKc, F)                                                                                                \
+        { if (!big_attr(gemm_big_group_kernel<AK, BKc, F>)) return VAG_EINVAL;                                                \
+          hipLaunchKernelGGL((gemm_big_group_kernel<AK, BKc, F>), dim3((unsigned)total), dim3(512), BIG_LDS_BYTES, stream, G); }
+        const bool f16 = g_gemm_planes == 11;
+        if (!akc && !bkc) { if (f16) VAG_BIG_GO(false, false, true) else VAG_BIG_GO(false, false, false) }
+        else if (akc && !bkc) { if (f16) VAG_BIG_GO(true, false, true) else VAG_BIG_GO(true, false, false) }
+        else if (akc && bkc) { if (f16) VAG_BIG_GO(true, true, true) else VAG_BIG_GO(true, true, false) }
+        else { if (f16) VAG_BIG_GO(false, true, true) else VAG_BIG_GO(false, true, false) }
+#undef VAG_BIG_GO
+    }
+    else if (g_gemm_planes == 11) { VAG_GROUP_GO(1, true) }
     else if (g_gemm_planes == 1) { VAG_GROUP_GO(1, false) }
     else if (g_gemm_planes == 2) { VAG_GROUP_GO(2, false) }
     else { VAG_GROUP_GO(3, false) }
@@ -638,6 +798,37 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
         fprintf(stderr, "[vag_gemm] M=%lld N=%lld K=%lld akc=%d bkc=%d beta=%g -> T=%lld splitk=%lld model=%.1f us\n",
                 (long long)M, (long long)N, (long long)K, (int)akc, (int)bkc, (double)beta, (long long)T, (long long)splitk, best);
 #endif
+    // the 2-byte storage mode's one-plane products on 256 x 256 tiles (gemm_big_kernel): split-K so that tiles x slices fill the
+    // 256 CUs about once; a bf16-stored A (d(logits) chunks) included
+    // (only where the cost model above chose the 128 x 128 one-plane kernel: products it sends to the exact f32 64 x 64 kernel stay there)
+    if (T == 128 && (g_gemm_planes == 1 || g_gemm_planes == 11) && vec && !opt_f32mfma && vag_opt().gemm_big != 0 && M >= 192 && N >= 192 &&
+        !g.rowsum && (!a_bf16 || !bkc) && vag_opt().gemm_force_tile == 0) {
+        const int64_t tiles = cdiv64(M, 256) * cdiv64(N, 256);
+        int64_t sp = 1;
+        if (can_split) while (tiles * sp < 208 && K / (sp + 1) >= 512 && sp < 32) ++sp;
+        int kc = (int)(cdiv64(cdiv64(K, sp), BK) * BK);
+        sp = cdiv64(K, kc);
+        g.splitk = (int)sp; g.kchunk = kc;
+        if (sp > 1 && beta == 0.f) {
+            int64_t nb = cdiv64(M * N, 256 * 8);
+            if (nb > 2048) nb = 2048;
+            hipLaunchKernelGGL(fill2d_kernel, dim3((unsigned)nb), dim3(256), 0, stream, C, ldc, M, N);
+            VAG_LAUNCH_CHECK();
+        }
+        const dim3 grid((unsigned)cdiv64(N, 256), (unsigned)cdiv64(M, 256), (unsigned)sp);
+        const bool f16 = g_gemm_planes == 11;
+#define VAG_BIG1(AK, BKc, F, AB)                                                                                              \
+        { if (!big_attr(gemm_big_kernel<AK, BKc, F, AB>)) return VAG_EINVAL;                                                  \
+          hipLaunchKernelGGL((gemm_big_kernel<AK, BKc, F, AB>), grid, dim3(512), BIG_LDS_BYTES, stream, g); }
+        if (a_bf16) { if (akc) VAG_BIG1(true, false, false, true) else VAG_BIG1(false, false, false, true) }
+        else if (!akc && !bkc) { if (f16) VAG_BIG1(false, false, true, false) else VAG_BIG1(false, false, false, false) }
+        else if (akc && !bkc) { if (f16) VAG_BIG1(true, false, true, false) else VAG_BIG1(true, false, false, false) }
+        else if (akc && bkc) { if (f16) VAG_BIG1(true, true, true, false) else VAG_BIG1(true, true, false, false) }
+        else { if (f16) VAG_BIG1(false, true, true, false) else VAG_BIG1(false, true, false, false) }
+#undef VAG_BIG1
+        VAG_LAUNCH_CHECK();
+        return VAG_OK;
+    }
     const bool big = (T == 128);
     VAG_CHECK_ARG(!a_bf16 || (big && !opt_f32mfma));       // a bf16-stored operand exists for the one-plane split kernel only
     if (rowsum && (!big || opt_f32mfma)) {          // the other kernels do not carry row sums: a column-sum pass over A instead
