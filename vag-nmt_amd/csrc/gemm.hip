@@ -328,11 +328,14 @@ __device__ __forceinline__ void gemm_big_body(const GemmArgs& a, __bf16* smem, i
     const int foff_b = (2 + (wn >> 1)) * SP_PLANE + ((wn & 1) * 64 + (lane & 31)) * SP_LD + 8 * (lane >> 5);
     SpRegs ra[2], rb[2];                                   // halves of the k-tile in flight
     SpFast<AKC> fa[2];
+    SpFastH<AKC> fah[2];
     SpFast<BKC> fb[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         // a half that lies entirely outside the operand is clamped onto its last valid row / group like any other out-of-range row
         if (!ABF) sp_fast_init<AKC>(fa[h], a.A, a.sa_o, a.sa_k, min(m0 + 128 * h, AKC ? a.M - 1 : ((a.M - 1) & ~3)), kbeg, a.M);
+        else sp_fast_init_bf16<AKC>(fah[h], reinterpret_cast<const unsigned short*>(a.A), a.sa_o, a.sa_k,
+                                    min(m0 + 128 * h, AKC ? a.M - 1 : ((a.M - 1) & ~3)), kbeg, a.M);
         sp_fast_init<BKC>(fb[h], a.B, a.sb_o, a.sb_k, min(n0 + 128 * h, BKC ? a.N - 1 : ((a.N - 1) & ~3)), kbeg, a.N);
     }
     auto load_tile = [&](int t) {
@@ -340,7 +343,7 @@ __device__ __forceinline__ void gemm_big_body(const GemmArgs& a, __bf16* smem, i
         if (t < nfull) {            // ONE branch around all of a k-tile's loads: a select per load makes hipcc wait for each load in turn
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                if (ABF) sp_load_bf16<AKC>(reinterpret_cast<const unsigned short*>(a.A), a.sa_o, a.sa_k, m0 + 128 * h, k0, a.M, kend, ra[h]);
+                if (ABF) sp_fast_load_bf16<AKC>(fah[h], ra[h]);
                 else sp_fast_load<AKC>(fa[h], ra[h]);
                 sp_fast_load<BKC>(fb[h], rb[h]);
             }

@@ -238,6 +238,39 @@ __device__ __forceinline__ void sp_fast_load(SpFast<KC, NW>& f, SpRegsT<NW>& r) 
     f.base += f.step;
 }
 
+// the same for an operand STORED as bf16 (d(logits) chunks of the 2-byte storage mode): 8-byte items, kept as two packed pairs in
+// r.v[4i], r.v[4i+1] exactly as sp_load_bf16 leaves them
+template <bool KC> struct SpFastH { unsigned off[2]; const unsigned short* base; int64_t step; };
+template <bool KC>
+__device__ __forceinline__ void sp_fast_init_bf16(SpFastH<KC>& f, const unsigned short* __restrict__ P, int64_t so, int64_t sk, int o0, int kbeg,
+                                                  int OUT) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 512;
+        if (KC) {
+            const int r = min(o0 + sp_row(idx >> 3), OUT - 1) - o0;
+            f.off[i] = (unsigned)(r * (int)so + ((idx & 7) << 2));
+        } else {
+            const int og = (idx & 31) << 2;
+            f.off[i] = (unsigned)((idx >> 5) * (int)sk + (o0 + og < OUT ? og : 0));
+        }
+    }
+    f.base = KC ? P + (int64_t)o0 * so + kbeg : P + o0 + (int64_t)kbeg * sk;
+    f.step = KC ? (int64_t)SP_BK : (int64_t)SP_BK * sk;
+}
+template <bool KC>
+__device__ __forceinline__ void sp_fast_load_bf16(SpFastH<KC>& f, SpRegs& r) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint2 v = *reinterpret_cast<const uint2*>(f.base + f.off[i]);
+        r.v[4 * i + 0] = __builtin_bit_cast(float, v.x);
+        r.v[4 * i + 1] = __builtin_bit_cast(float, v.y);
+        r.v[4 * i + 2] = 0.f; r.v[4 * i + 3] = 0.f;
+    }
+    f.base += f.step;
+}
+
 // The same two items per thread of an operand STORED as bf16 (2-byte storage mode: d(logits) as its producer writes it): eight
 // bytes per item, kept as two packed pairs in r.v[4i], r.v[4i+1] -- they ARE the one bf16 plane, sp_store<.., PRE> passes them on.
 template <bool KC>
