@@ -442,7 +442,8 @@ template <typename K> static bool big_attr(K kernel) {          // dynamic LDS a
     return true;
 }
 
-// (Round 4, measured and dropped -- profiles/r04_exp_gemm_waves4.txt, _pp.txt, _swp.txt: a four-wave block with 64 x 64 wave tiles;
+// (Round 4, measured and dropped -- profiles/r04_exp_gemm_waves4.txt, _pp.txt, _swp.txt, _big3.txt: a four-wave block with 64 x 64 wave tiles;
+// 256 x 256 tiles for the three-plane products (+8-10 % at 4096^3, 0.5-0.8x at configs[1]'s M = 2560 shapes);
 // a ping-pong of the two wave halves between MFMA and split intervals; one software-pipelined MFMA + split stream per wave.  All within
 // +-10 % of this kernel: two waves per SIMD carrying 24 MFMAs + ~90 vector instructions + 30 LDS accesses per k-tile saturate the SIMD's
 // issue port at ~75 % matrix-pipe occupancy whatever the order.)
