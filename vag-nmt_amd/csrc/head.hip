@@ -242,14 +242,16 @@ __global__ __launch_bounds__(256) void ce_bwd_colsum_kernel(float* __restrict__ 
                                                             const float* __restrict__ d_loss, int rows, int rows_per,
                                                             float* __restrict__ g_bias, unsigned short* __restrict__ out16) {
     // out16 != NULL (2-byte storage mode, chunked head): d(logits) is written as bf16 into out16 (row stride ldl elements) and
-    // the fp32 logits are left alone -- its two consumers round it to one bf16 plane anyway, and read half the bytes this way
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= ldl) return;
-    const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+    // the fp32 logits are left alone -- its two consumers round it to one bf16 plane anyway, and read half the bytes this way.
+    // Round 4: a thread owns FOUR consecutive columns (16-byte loads, 16-byte fp32 / 8-byte bf16 stores; ldl % 4 == 0): with one
+    // column per thread the bf16 rows went out as 2-byte stores (342 us per 655 MB chunk at configs[4] = 2.9 TB/s, 52 us at configs[1]).
+    const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int r0 = blockIdx.y * rows_per, r1 = j < ldl ? min(rows, r0 + rows_per) : r0;      // columns past ldl: no rows, zero sums
     const float dl = d_loss[0] / (float)B;
-    float acc = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int r = r0; r < r1; r += 4) {
-        float x[4], coef[4], l[4];
+        float4 x[4];
+        float coef[4], l[4];
         int tg[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -259,20 +261,43 @@ __global__ __launch_bounds__(256) void ce_bwd_colsum_kernel(float* __restrict__ 
             tg[u] = (int)g;
             coef[u] = dl * inv_cnt[b] * vw[g];
             l[u] = lse[row];
-            x[u] = logits[(int64_t)row * ldl + j];
+            x[u] = *reinterpret_cast<const float4*>(logits + (int64_t)row * ldl + j);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (r + u < r1) {
-                float g = 0.f;
-                if (j < V) g = coef[u] * (__expf(x[u] - l[u]) - (j == tg[u] ? 1.f : 0.f));
-                if (out16) out16[(int64_t)(r + u) * ldl + j] = __builtin_bit_cast(unsigned short, (__bf16)g);
-                else logits[(int64_t)(r + u) * ldl + j] = g;
-                acc += g;
+                const float xv[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+                float g[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    g[q] = (j + q < V) ? coef[u] * (__expf(xv[q] - l[u]) - (j + q == tg[u] ? 1.f : 0.f)) : 0.f;
+                    acc[q] += g[q];
+                }
+                if (out16) {
+                    typedef __bf16 hbf2 __attribute__((ext_vector_type(2)));
+                    typedef float hf2 __attribute__((ext_vector_type(2)));
+                    const hf2 lo = {g[0], g[1]}, hi = {g[2], g[3]};
+                    const hbf2 hl = __builtin_convertvector(lo, hbf2), hh = __builtin_convertvector(hi, hbf2);     // v_cvt_pk_bf16_f32
+                    *reinterpret_cast<uint2*>(out16 + (int64_t)(r + u) * ldl + j) =
+                        make_uint2(__builtin_bit_cast(unsigned, hl), __builtin_bit_cast(unsigned, hh));
+                } else {
+                    *reinterpret_cast<float4*>(logits + (int64_t)(r + u) * ldl + j) = make_float4(g[0], g[1], g[2], g[3]);
+                }
             }
         }
     }
-    if (j < V) atomicAdd(g_bias + j, acc);
+    // the strip's column sums: through LDS so that every atomic wave-instruction adds 64 CONSECUTIVE columns (256 contiguous bytes:
+    // the shape float atomics run at full rate for); straight from the registers a lane would own every fourth dword
+    __shared__ float cs[1024];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cs[4 * threadIdx.x + q] = acc[q];
+    __syncthreads();
+    const int jb = blockIdx.x * 1024;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = jb + q * 256 + threadIdx.x;
+        if (c < V) atomicAdd(g_bias + c, cs[q * 256 + threadIdx.x]);
+    }
 }
 int vag_ce_bwd_colsum_launch(float* logits, int64_t ldl, int64_t rows, int64_t V, const int64_t* tgt, int64_t B, int64_t Tt,
                              const float* vw, const float* lse, const float* inv_cnt, const float* d_loss, float* g_bias,
@@ -280,8 +305,9 @@ int vag_ce_bwd_colsum_launch(float* logits, int64_t ldl, int64_t rows, int64_t V
     VAG_CHECK_ARG(logits && tgt && vw && lse && inv_cnt && d_loss && g_bias && rows % B == 0 && rows <= B * Tt && V > 0 &&
                   ldl >= V);      // rows < B*Tt: a chunk of whole time steps (tgt / lse already offset by the caller)
     if (rows == 0) return VAG_OK;
-    const int64_t nbx = cdiv64(ldl, 256);
-    int64_t splits = cdiv64(2048, nbx);
+    VAG_CHECK_ARG(ldl % 4 == 0 && aligned16(logits) && (!out16 || (reinterpret_cast<uintptr_t>(out16) & 7) == 0));
+    const int64_t nbx = cdiv64(ldl, 1024);
+    int64_t splits = cdiv64(1024, nbx);                  // ~1024 blocks: every strip costs ldl atomics
     if (splits > cdiv64(rows, 8)) splits = cdiv64(rows, 8);
     const int rows_per = (int)cdiv64(rows, splits);
     dim3 grid((unsigned)nbx, (unsigned)cdiv64(rows, rows_per));
