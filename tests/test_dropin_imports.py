@@ -108,3 +108,34 @@ def test_without_a_checkout_the_names_import_and_raise_on_use(tmp_path):
     assert got == {"NMT_Seq2Seq_Beam": "raises", "LIUMCVC_Seq2Seq_Beam": "raises", "FF": "raises", "LIUMCVC_Decoder": "raises",
                    "NoSuchModel": "ImportError", "meteor": "ImportError",
                    "v2": "machine_translation_vision.models.NMT_Seq2Seq_Beam_V2"}
+
+
+def test_resolution_against_a_synthetic_checkout(tmp_path):
+    """The same machinery without /root/reference (the GPU box, CI): a stand-in checkout with a `meteor` sub-package, one model variant
+    that imports layers relatively (as models/NMT_Seq2Seq_Beam.py:10-11 does) and one layer this package does not define.  The shadowed
+    names must still come from this package, the rest from the stand-in."""
+    co = tmp_path / "checkout" / "machine_translation_vision"
+    for sub in ("", "meteor", "models", "layers", "losses", "utils", "samplers"):
+        (co / sub).mkdir(parents=True, exist_ok=True)
+        (co / sub / "__init__.py").write_text("")
+    (co / "meteor" / "meteor.py").write_text("class Meteor:\n    origin = 'checkout'\n")
+    (co / "layers" / "ff.py").write_text("class FF:\n    origin = 'checkout'\n")
+    (co / "layers" / "Encoder.py").write_text("class LIUMCVC_Encoder:\n    origin = 'checkout (must be shadowed)'\n")
+    (co / "models" / "NMT_Seq2Seq_Beam.py").write_text(
+        "from ..layers import LIUMCVC_Encoder\nfrom ..layers import NMT_Decoder\nfrom ..layers import FF\n"
+        "class NMT_Seq2Seq_Beam:\n    parts = (LIUMCVC_Encoder, NMT_Decoder, FF)\n")
+    code = "\n".join([
+        "import json, inspect",
+        "from machine_translation_vision.meteor.meteor import Meteor",
+        "from machine_translation_vision.models import NMT_Seq2Seq_Beam, NMT_Seq2Seq_Beam_V2, LIUMCVC_Seq2Seq_Beam",
+        "from machine_translation_vision.layers import FF, LIUMCVC_Encoder",
+        "res = {'meteor': Meteor.origin, 'ff': FF.origin,",
+        "       'parts': [inspect.getsourcefile(c) for c in NMT_Seq2Seq_Beam.parts],",
+        "       'encoder': inspect.getsourcefile(LIUMCVC_Encoder), 'v2': inspect.getsourcefile(NMT_Seq2Seq_Beam_V2),",
+        "       'liumcvc_is_placeholder': bool(getattr(LIUMCVC_Seq2Seq_Beam, '_vag_placeholder', False))}",
+        "print('PROBE ' + json.dumps(res))"])
+    got = _run(code, str(tmp_path), tmp_path, extra_path=[str(tmp_path / "checkout")])
+    assert got["meteor"] == "checkout" and got["ff"] == "checkout"
+    assert got["encoder"].startswith(PKG) and got["v2"].startswith(PKG)
+    assert got["parts"][0].startswith(PKG) and got["parts"][1].startswith(PKG) and got["parts"][2].startswith(str(tmp_path))
+    assert got["liumcvc_is_placeholder"] is True       # the stand-in lacks that file: a placeholder, as without a checkout

@@ -78,10 +78,15 @@ def resolve(sub, name):
     if name not in table:
         raise AttributeError("module %r has no attribute %r" % ("%s.%s" % (_PKG, sub), name))
     pkg = sys.modules["%s.%s" % (_PKG, sub)]
+    obj = None
     if find_checkout() is not None:
-        mod = importlib.import_module(".%s" % table[name], pkg.__name__)
-        obj = getattr(mod, name)
-    else:
+        full = "%s.%s" % (pkg.__name__, table[name])
+        try:
+            obj = getattr(importlib.import_module(full), name)
+        except ModuleNotFoundError as e:          # a checkout that lacks this file (a trimmed copy): placeholder, like no checkout
+            if e.name != full:
+                raise
+    if obj is None:
         obj = _placeholder(sub, name)
     setattr(pkg, name, obj)
     return obj
