@@ -32,16 +32,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Wave-wide all-reduce without the LDS pipe (round 4): four row_ror DPP steps inside the rows of 16 lanes, then gfx950's
+// v_permlane16_swap and v_permlane32_swap (odd rows / the upper half of one copy <-> even rows / the lower half of the other) with one
+// combine each: ~12 vector instructions.  Six __shfl_xor steps are six DEPENDENT ds_bpermute of ~64 cycles each (~400 cycles), which
+// the persistent decoder kernels pay twice per time step on their critical path (softmax: max, then sum).
+template <bool MAX>
+__device__ __forceinline__ float wave_allreduce(float v) {
+#define VAG_DPP_ROR(N) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (N), 0xf, 0xf, false))
+    { const float o = VAG_DPP_ROR(8); v = MAX ? fmaxf(v, o) : v + o; }
+    { const float o = VAG_DPP_ROR(4); v = MAX ? fmaxf(v, o) : v + o; }
+    { const float o = VAG_DPP_ROR(2); v = MAX ? fmaxf(v, o) : v + o; }
+    { const float o = VAG_DPP_ROR(1); v = MAX ? fmaxf(v, o) : v + o; }
+#undef VAG_DPP_ROR
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    v = MAX ? fmaxf(a, b) : a + b;
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return MAX ? fmaxf(a, b) : a + b;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave_allreduce<false>(v); }
+__device__ __forceinline__ float wave_max(float v) { return wave_allreduce<true>(v); }
 // tanh / sigmoid on the v_exp_f32 path; absolute error ~1e-7, saturates cleanly at +-1 / 0,1.
 // v_rcp_f32 is accurate to 1 ulp; one v_exp_f32 + one v_rcp_f32 per activation instead of an IEEE division.
 __device__ __forceinline__ float vag_tanh(float x) {
