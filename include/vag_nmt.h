@@ -140,6 +140,20 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
                                  int64_t H, int64_t V, float* h2_all, float* c_all, float* e_all, float* ws,
                                  int free_run, const vag_head_w* head, float p_out, const uint64_t* rng,
                                  float* tmid, float* logits, int64_t ldl, vag_stream_t stream);
+/* The free-running form as ONE launch (round 4; persist.hip: the recurrence kernel also forms the head's hidden layer, the
+ * logits of its vocabulary tiles and the arg-max, and feeds the token back: two more hand-offs per step instead of nine
+ * launches).  Same outputs and saved tensors as vag_cgru_attn_decode_seq_fwd(free_run = 1), so the backward entry points
+ * are unchanged.  vag_cgru_free_supported: H = 512, E = 256, B <= 64, keys fit the LDS, every workgroup resident.
+ * tables: vag_cgru_free_tables_floats floats of scratch (the input projection of every vocabulary entry, emb W3^T, enc W2^T,
+ * arg-max candidates), filled here.  logits may be NULL (greedy decoding, V11.py:207-226: only tok is read); c_all / e_all
+ * may be NULL then too. */
+int vag_cgru_free_supported(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, int64_t V);
+int64_t vag_cgru_free_tables_floats(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, int64_t V);
+int vag_cgru_attn_decode_free_fwd(const float* enc, const float* pe, const float* mask, const float* h0, int64_t* tok,
+                                  vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, int64_t V,
+                                  float* h2_all, float* c_all, float* e_all, float* ws, const vag_head_w* head,
+                                  float p_out, const uint64_t* rng, float* tmid, float* logits, int64_t ldl,
+                                  float* tables, vag_stream_t stream);
 /* Backward through time.  Inputs: gradients w.r.t. the three outputs (d_h2_all, d_c_all are consumed;
  * d_e_all may be NULL).  Writes d_enc_out (B,Ts,C) (accumulate_enc: adds), d_pe (B,Ts,C), d_h0 (B,H);
  * accumulates the parameter gradients in g (g.emb: pad row untouched). */

@@ -115,7 +115,7 @@ int vag_set_option(const char* name, int64_t value) {
     const struct { const char* n; int* p; } ints[] = {
         {"gemm_f32mfma", &o.gemm_f32mfma}, {"gemm_nogroup", &o.gemm_nogroup}, {"gemm_big", &o.gemm_big}, {"gemm_force_tile", &o.gemm_force_tile},
         {"gemm_force_splitk", &o.gemm_force_splitk}, {"head_fuse", &o.head_fuse},
-        {"head_bf16_grads", &o.head_bf16_grads}, {"persistent", &o.persistent}, {"persistent_dec_bwd", &o.persistent_dec_bwd},
+        {"head_bf16_grads", &o.head_bf16_grads}, {"persistent", &o.persistent}, {"persistent_dec_bwd", &o.persistent_dec_bwd}, {"free_persistent", &o.free_persistent},
         {"persist_timing", &o.persist_timing}, {"s16_one_plane", &o.s16_one_plane},
         {"head_bf16_dlogits", &o.head_bf16_dlogits}};
     for (const auto& e : ints)
@@ -708,6 +708,50 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
                                        tok + (t + 1) * B, 1, nullptr, 0, s));
         }
     }
+    return VAG_OK;
+}
+
+int vag_cgru_free_supported(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, int64_t V) {
+    return vag_opt().persistent && vag_opt().free_persistent && !g_store16 && vag_dec_free_persistent_ok(B, Ts, Tt, E, H, V) ? 1 : 0;
+}
+int64_t vag_cgru_free_tables_floats(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, int64_t V) {
+    return vag_dec_free_tables_floats(B, Ts, Tt, E, H, V);
+}
+int vag_cgru_attn_decode_free_fwd(const float* enc, const float* pe, const float* mask, const float* h0, int64_t* tok,
+                                  vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, int64_t V,
+                                  float* h2_all, float* c_all, float* e_all, float* ws, const vag_head_w* head, float p_out,
+                                  const uint64_t* rng, float* tmid, float* logits, int64_t ldl, float* tables,
+                                  vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(enc && pe && mask && h0 && tok && h2_all && ws && head && tmid && tables && dec_w_ok(w));
+    VAG_CHECK_ARG(head->w1 && head->b1 && head->w2 && head->b2 && head->w3 && head->b3 && head->out_w && head->out_b);
+    VAG_CHECK_ARG(vag_cgru_free_supported(B, Ts, Tt, E, H, V) && aligned16(ws) && aligned16(tables));
+    VAG_CHECK_ARG(!logits || (ldl >= V && ldl % 4 == 0));
+    const int64_t C = 2 * H;
+    CgruWs k = cgru_ws(ws, B, Ts, Tt, E, H);
+    CgruPrep p = cgru_prep(k.prep, H);
+    if (g_derived) p = cgru_prep(derived_layout(const_cast<float*>(g_derived), H).prep, H);
+    else VAG_TRY(vag_cgru_prepare(w, H, k.prep, stream));
+    auto r64 = [](int64_t n) { return (n + 63) & ~63ll; };
+    float* embp = tables;
+    float* embw3 = embp + r64(V * 3 * H);
+    float* encw2 = embw3 + r64(V * E);
+    {
+        // what a step needs of a token or of a key, for every token and every key, as four products in one grouped launch:
+        // the input projection of gru_1 (:118-121), W3 e (:137), the keys as gru_2 sees them (:127-129), W2 enc (:137)
+        VagGemmGroup grp;
+        VAG_TRY(vag_gemm_launch(V, 3 * H, E, 1.f, w.emb, E, 1, w.gru1.w_ih, 1, E, 0.f, embp, 3 * H, w.gru1.b_ih, 0, s));
+        VAG_TRY(vag_gemm_launch(V, E, E, 1.f, w.emb, E, 1, head->w3, 1, E, 0.f, embw3, E, nullptr, 0, s));
+        VAG_TRY(vag_gemm_launch(B * Ts, 3 * H, C, 1.f, enc, C, 1, p.wp, 1, C, 0.f, k.encwp, 3 * H, nullptr, 0, s));
+        VAG_TRY(vag_gemm_launch(B * Ts, E, C, 1.f, enc, C, 1, head->w2, 1, C, 0.f, encw2, E, nullptr, 0, s));
+        VAG_TRY(grp.end(s));
+    }
+    VAG_TRY(vag_dec_free_persistent_launch(pe, mask, h0, w.gru1.w_hh, w.gru1.b_hh, p.wcat, p.bcat, w.attn_v, k.encwp, w.gru2.b_ih,
+                                           k.h1, k.g1, k.qhp, k.alpha, h2_all, k.g2, k.psc, k.sync, tables, head->w1, head->b1,
+                                           head->b2, head->b3, head->out_w, head->out_b, tmid, logits, ldl, tok, rng, p_out, B, Ts,
+                                           Tt, E, H, V, s));
+    if (c_all) VAG_TRY(vag_attn_wsum_launch(1, k.alpha, enc, B, Ts, Tt, C, c_all, s));                       // all contexts :126
+    if (e_all) VAG_TRY(vag_embed_gather_launch(tok, B, 1, Tt, B, w.emb, E, e_all, nullptr, 0, 0.f, s));     // the inputs it chose
     return VAG_OK;
 }
 

@@ -178,6 +178,16 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
                                   const float* b1, const float* wcat, const float* bcat, const float* v, const float* encwp,
                                   const float* b_ih2, float* h1, float* g1, float* qhp, float* alpha, float* h2_all, float* g2,
                                   float* psc, unsigned* sync, int64_t B, int64_t Ts, int64_t Tt, int64_t H, hipStream_t s);
+// free-running form (the kernel feeds its own arg-max back): see persist.hip
+bool vag_dec_free_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, int64_t V);
+int64_t vag_dec_free_tables_floats(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, int64_t V);
+int vag_dec_free_persistent_launch(const float* pe, const float* mask, const float* h0, const float* W1, const float* b1,
+                                   const float* wcat, const float* bcat, const float* v, const float* encwp, const float* b_ih2,
+                                   float* h1, float* g1, float* qhp, float* alpha, float* h2_all, float* g2, float* psc,
+                                   unsigned* sync, const float* tables, const float* hw1, const float* hb1, const float* hb2,
+                                   const float* hb3, const float* out_w, const float* out_b, float* tmid, float* logits, int64_t ldl,
+                                   int64_t* tok, const uint64_t* rng, float p_out, int64_t B, int64_t Ts, int64_t Tt, int64_t E,
+                                   int64_t H, int64_t V, hipStream_t s);
 
 // ---------------- beam.hip ----------------
 int64_t vag_beam_scratch_bytes_impl(int64_t B, int64_t k, int64_t V);

@@ -806,11 +806,23 @@ __global__ __launch_bounds__(512, 1) void enc_bwd_wide16_kernel(EncWBArgs a) {
 struct DecPArgs {
     const float *pe, *mask, *h0, *xp1, *W1, *b1, *wcat, *bcat, *v, *encwp, *b_ih2;
     float *h1, *g1, *qhp, *alpha, *h2_all, *g2, *psc;
-    unsigned* cnt;              // [4 phases][RT][Tt], zero on entry
+    unsigned* cnt;              // [5 phases][RT][Tt], zero on entry (2 and 4: free-running form only)
     unsigned* err;
     unsigned spin;
     unsigned long long* dbg;    // NULL, or [Tt][8] 100 MHz timestamps of workgroup 0's phase boundaries (tools/exp_dec_phases.py)
     int B, Ts, Tt, H, RT;
+    // ---- free-running form (FREE = true): the kernel feeds its own arg-max back (V11.py:148-160 / :207-226), xp1 is not read
+    const float *embp;          // (V, 3H)  emb W_ih1^T + b_ih1: the input projection of gru_1 for every possible token
+    const float *embw3;         // (V, E)   emb W3^T: the head's share of the embedded input (NMT_Decoder.py:137)
+    const float *encw2;         // (B, Ts, E) enc W2^T: the head's share of a context is alpha . encw2
+    const float *hw1, *hb1, *hb2, *hb3, *out_w, *out_b;     // head: W1 (E, H), the three biases, out (V, E), (V)
+    float *tmid;                // (Tt, B, E) tanh(.) * dropout, exchanged between the workgroups and kept for the backward pass
+    float *logits;              // (Tt * B, ldl) or NULL (decoding: nobody reads them)
+    unsigned long long* cand;   // (Tt, B, 64) per-workgroup arg-max candidates
+    int64_t* tok;               // (Tt + 1, B): row 0 given; row t + 1 = arg-max of step t
+    const uint64_t* rng;        // output dropout (:140-141), NULL / p_out = 0: none
+    float p_out;
+    int V, ldl;
 };
 
 // A counter of the decoder kernel is 4 shards, 64 bytes apart (64 arrivals on ONE word serialise at the memory side, ~12 ns
@@ -834,9 +846,20 @@ __device__ __forceinline__ void wait_count(gu32* c, unsigned want_per_shard, uns
 constexpr int DEC_WGS = 64;          // workgroups per row tile
 constexpr int DEC_U = 8;             // hidden units per workgroup (H = 512)
 
+#ifndef VAG_FREE_RING
+#define VAG_FREE_RING 4
+#endif
+constexpr int DEC_E = 4 * DEC_WGS;   // free-running form: embedding width, 4 columns of the head's hidden layer per workgroup
+__device__ __forceinline__ unsigned long long cand_key(float v, int idx) {       // larger value first, then smaller index
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    return ((unsigned long long)(u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u)) << 32) | (unsigned long long)(0xffffffffu - (unsigned)idx);
+}
+
+template <bool FREE>
 __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) {
     extern __shared__ __attribute__((aligned(16))) float dlds[];
     constexpr int H = DEC_WGS * DEC_U, C = 2 * H, Q = C + 3 * H, KS = 2;       // K share of a wave: H / 8 = 64 = 2 k-steps
+    constexpr int E = DEC_E;
     const int i = blockIdx.x % DEC_WGS, rt = blockIdx.x / DEC_WGS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int B = a.B, Ts = a.Ts, Tt = a.Tt;
@@ -856,6 +879,12 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
     float* v_s = hs_s + 256;                                         // [C] attention vector
     float* mk_s = v_s + C;                                           // [16][Ts] source mask of the tile's pairs
     float* q_s = mk_s + 16 * Ts;                                     // [16][16] this step's query, own columns
+    float* cw_s = q_s + 256;                                         // FREE: [16][4] alpha . encw2 of the own head columns
+    float* hb_s = cw_s + 64;                                         // FREE: [4] b1 + b2 + b3 of the own head columns (+ 12 pad)
+    int* tok_s = reinterpret_cast<int*>(hb_s + 16);                  // FREE: [16] the tile's input tokens of the current step
+    float* ew2_s = reinterpret_cast<float*>(tok_s + 16);             // FREE: [16][Ts][4] own head columns of encw2
+    unsigned long long* cb_s = reinterpret_cast<unsigned long long*>(q_s);            // FREE: [128] arg-max partials (q_s is idle then)
+    bf16x8* tm_s = reinterpret_cast<bf16x8*>(red);                                   // FREE: [3 planes][8 k-steps][64 lanes] the head's hidden layer, while `red` is idle
 
     // ---- weights as bf16 planes in registers (A operands: rows = output columns).  Row of a tile held by lane fr:
     //   cell tiles: tile 0 = [r | z] of the 8 own units (fr < 8: gate r, unit fr; else gate z, unit fr - 8), tile 1 = [n | n again]
@@ -867,6 +896,9 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
             const int ko = kbase + 32 * s + 8 * fg;
             const float* p0 = a.W1 + (int64_t)(g01 * H + u0 + ur) * H + ko;
             const float* p1 = a.W1 + (int64_t)(2 * H + u0 + ur) * H + ko;
+            // FREE: rows 8..11 of tile 1 (a second copy of n otherwise) are the own four rows of the head's W1: W1 h2[t-1]
+            // comes out of the product that gru_1 of step t needs anyway
+            if (FREE && fr >= 8 && fr < 12) p1 = a.hw1 + (int64_t)(4 * i + fr - 8) * H + ko;
             split8(*reinterpret_cast<const float4*>(p0), *reinterpret_cast<const float4*>(p0 + 4), w1[s][0]);
             split8(*reinterpret_cast<const float4*>(p1), *reinterpret_cast<const float4*>(p1 + 4), w1[s][1]);
             const float* q0 = a.wcat + (int64_t)(16 * i + fr) * H + ko;                         // attn_h rows = query columns
@@ -906,23 +938,47 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
     }
     if (ep) *reinterpret_cast<float4*>(hs_s + 128 + fr * 8 + 4 * hq) = eok ? *reinterpret_cast<const float4*>(a.h0 + (int64_t)em * H + eu)
                                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 e3 = make_float4(0.f, 0.f, 0.f, 0.f);          // FREE, threads 0..15: embw3 row of the current input token, own columns
+    if (FREE) {
+        for (int x = threadIdx.x; x < 16 * Ts; x += 512) {           // (row, position) -> one float4
+            const int r = x / Ts, sp = x - r * Ts, b = min(m0 + r, B - 1);
+            reinterpret_cast<float4*>(ew2_s)[x] = *reinterpret_cast<const float4*>(a.encw2 + ((int64_t)b * Ts + sp) * E + 4 * i);
+        }
+        if (threadIdx.x < 4) hb_s[threadIdx.x] = a.hb1[4 * i + threadIdx.x] + a.hb2[4 * i + threadIdx.x] + a.hb3[4 * i + threadIdx.x];
+        if (threadIdx.x < 16) {
+            const int tk = (int)a.tok[min(m0 + (int)threadIdx.x, B - 1)];
+            tok_s[threadIdx.x] = tk;
+            e3 = *reinterpret_cast<const float4*>(a.embw3 + (int64_t)tk * E + 4 * i);
+        }
+    }
     const int arow = min(m0 + fr, B - 1);
     const int lrow = min(m0 + ld_row(lane), B - 1);        // the batch row this lane LOADS (quad-contiguous mapping, see ld_row)
     const int src4 = ld_src4(lane);
     gu32* c1 = (gu32*)(a.cnt + ((int64_t)0 * a.RT + rt) * Tt * CNT_WORDS);       // h2[t] published (waited on by step t + 1)
     gu32* c2 = (gu32*)(a.cnt + ((int64_t)1 * a.RT + rt) * Tt * CNT_WORDS);       // h1
     gu32* c4 = (gu32*)(a.cnt + ((int64_t)3 * a.RT + rt) * Tt * CNT_WORDS);       // scores
+    gu32* c5 = (gu32*)(a.cnt + ((int64_t)2 * a.RT + rt) * Tt * CNT_WORDS);       // FREE: the head's hidden layer of step t
+    gu32* c6 = (gu32*)(a.cnt + ((int64_t)4 * a.RT + rt) * Tt * CNT_WORDS);       // FREE: arg-max candidates of step t
     constexpr unsigned PER_SHARD = DEC_WGS / SHARDS;
     bool dead = false;
     __syncthreads();
 #ifdef VAG_LAB          // phase timestamps: lab builds only (make LAB=1 -> libvagnmt_lab.so); the product kernels carry no hook
     const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
-#define VAG_STAMP(k) do { if (stamp) a.dbg[t * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define VAG_STAMP(k) do { if (stamp) a.dbg[t * (FREE ? 16 : 8) + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define VAG_STAMP(k) do { } while (0)
 #endif
 
-    for (int t = 0; t < Tt; ++t) {
+    for (int t = 0; t < Tt + (FREE ? 1 : 0); ++t) {       // FREE: one more pass for the head and arg-max of the last step
+        // FREE: the thread's coordinates again, opaque to the compiler: every address of a pass is then recomputed (a few integer
+        // instructions) instead of being hoisted out of the time loop -- hoisted, they and the weight planes they displace end
+        // up in scratch memory (measured: 110 spilled registers, 3-5 us per step).  Teacher-forced form: the same values as outside.
+        int tx = threadIdx.x;
+        if (FREE) asm volatile("" : "+v"(tx));
+        const int lane = tx & 63, wave = FREE ? __builtin_amdgcn_readfirstlane(tx >> 6) : tx >> 6, fr = lane & 15, fg = lane >> 4;
+        const int kbase = wave * (H >> 3), hq = (tx >> 4) & 1, em = m0 + fr, eu = u0 + 4 * hq;
+        const bool ep = tx < 32, eok = ep && em < B;
+        const int arow = min(m0 + fr, B - 1), lrow = min(m0 + ld_row(lane), B - 1), src4 = ld_src4(lane);
         VAG_STAMP(0);
         // ================= phase 1: gru_1 cell (NMT_Decoder.py:121) =================
         float4 ha[KS], hb[KS];
@@ -950,16 +1006,16 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
             red[(wave * 3 + 1) * 64 + lane] = make_float4(acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
         }
         float4 xo[3];                                   // the input projection of this step: arrives under the barrier + reduction
-        if (eok) {
+        if (!FREE && eok) {
             const float* xp = a.xp1 + ((int64_t)t * B + em) * 3 * H + eu;
 #pragma unroll
             for (int g = 0; g < 3; ++g) xo[g] = *reinterpret_cast<const float4*>(xp + g * H);
         }
         __syncthreads();
+        // D[tile row][batch row]: lane (fr, fg) of a tile holds rows 4 fg + i.  r of units 4 hq + i: tile 0, fg = hq;
+        // z: tile 0, fg = 2 + hq; n: tile 1, fg = hq; FREE: the head's W1 h2[t-1], own four columns: tile 1, fg = 2
+        float4 cr = make_float4(0, 0, 0, 0), cz = cr, cn = cr, hw = cr;
         if (ep) {
-            // D[tile row][batch row]: lane (fr, fg) of a tile holds rows 4 fg + i.  r of units 4 hq + i: tile 0, fg = hq;
-            // z: tile 0, fg = 2 + hq; n: tile 1, fg = hq
-            float4 cr = make_float4(0, 0, 0, 0), cz = cr, cn = cr;
 #pragma unroll
             for (int w = 0; w < 8; ++w) {
                 const float4 x0 = red[(w * 3 + 0) * 64 + hq * 16 + fr], x1 = red[(w * 3 + 0) * 64 + (2 + hq) * 16 + fr];
@@ -967,7 +1023,149 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
                 cr.x += x0.x; cr.y += x0.y; cr.z += x0.z; cr.w += x0.w;
                 cz.x += x1.x; cz.y += x1.y; cz.z += x1.z; cz.w += x1.w;
                 cn.x += x2.x; cn.y += x2.y; cn.z += x2.z; cn.w += x2.w;
+                if (FREE) {
+                    const float4 x3 = red[(w * 3 + 1) * 64 + 2 * 16 + fr];
+                    hw.x += x3.x; hw.y += x3.y; hw.z += x3.z; hw.w += x3.w;
+                }
             }
+        }
+        if (FREE) {
+            VAG_STAMP(8);
+            if (t >= 1) {
+                // ---- head of step t - 1 (NMT_Decoder.py:137-141): own four columns of tanh(W1 h2 + W2 c + W3 e + b), dropout
+                const int ts = t - 1;
+                const int V = a.V, NVT = (V + 15) >> 4, NJ = i < NVT ? (NVT - i + 63) >> 6 : 0;      // own tiles: i, i + 64, ...
+                const int mytiles = NJ > wave ? (NJ - wave + 7) >> 3 : 0;          // this wave's tiles: i + 64 (wave + 8 n)
+                constexpr int RING = VAG_FREE_RING;
+                float4 wr[RING][2];                                                // out.weight rows, RING k-steps in flight
+                if (mytiles > 0) {
+                    const float* wp = a.out_w + (int64_t)min(16 * (i + 64 * wave) + fr, V - 1) * E + 8 * fg;
+#pragma unroll
+                    for (int u = 0; u < RING; ++u) { wr[u][0] = *reinterpret_cast<const float4*>(wp + 32 * u); wr[u][1] = *reinterpret_cast<const float4*>(wp + 32 * u + 4); }
+                }
+                if (tx < 16) {
+                    const float4 cw = *reinterpret_cast<const float4*>(cw_s + 4 * fr);
+                    const float4 bb = *reinterpret_cast<const float4*>(hb_s);
+                    const uint64_t di = ((uint64_t)ts * B + (uint64_t)min(m0 + fr, B - 1)) * E + 4 * i;
+                    float4 tv;
+                    tv.x = vag_tanh(hw.x + cw.x + e3.x + bb.x) * vag_drop_mul(a.rng, VAG_DROP_DEC_OUT, di + 0, a.p_out);
+                    tv.y = vag_tanh(hw.y + cw.y + e3.y + bb.y) * vag_drop_mul(a.rng, VAG_DROP_DEC_OUT, di + 1, a.p_out);
+                    tv.z = vag_tanh(hw.z + cw.z + e3.z + bb.z) * vag_drop_mul(a.rng, VAG_DROP_DEC_OUT, di + 2, a.p_out);
+                    tv.w = vag_tanh(hw.w + cw.w + e3.w + bb.w) * vag_drop_mul(a.rng, VAG_DROP_DEC_OUT, di + 3, a.p_out);
+                    if (m0 + fr < B) st_sc1_f4(a.tmid + ((int64_t)ts * B + m0 + fr) * E + 4 * i, tv);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (tx == 0) arrive(c5 + ts * CNT_WORDS, i);
+                wait_count(c5 + ts * CNT_WORDS, PER_SHARD, a.err, a.spin, dead);        // (its barrier also frees `red`)
+                VAG_STAMP(9);
+                // ---- logits of step t - 1 (:143) for the own vocabulary tiles (16 words each, tile i + 64 j) and their arg-max.
+                // The step's hidden layer (16 rows x E) is split once into bf16 planes and parked in `red` in MFMA operand
+                // layout (each wave contributes the k-step it loaded); a wave then owns whole tiles (j = wave, wave + 8, ...)
+                // over all of K = E: no reduction between waves.  The weight rows stream from L2 (the slices of the 8
+                // workgroups of an XCD stay there: 1.2 MB), four k-steps ahead.
+                {
+                    float4 ta[1], tb[1];
+                    bf16x8 tf[3];
+                    ld_rows_sc1<1>(a.tmid + ((int64_t)ts * B + lrow) * E + 32 * wave + 8 * (lane & 3), ta, tb);
+                    split8(perm4(ta[0], src4), perm4(tb[0], src4), tf);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) tm_s[(pl * 8 + wave) * 64 + lane] = tf[pl];
+                }
+                __syncthreads();
+                unsigned long long best = 0ull;                                   // batch row fr
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int g = 0; g < (8 / RING) * mytiles; ++g) {                  // RING k-steps per pass
+#pragma unroll
+                    for (int u = 0; u < RING; ++u) {
+                        const int pp = RING * g + u, ks = pp & 7;
+                        const float4 ca = wr[u][0], cb = wr[u][1];
+                        if (pp + RING < 8 * mytiles) {
+                            const int vt = i + 64 * (wave + 8 * ((pp + RING) >> 3));
+                            const float* wp = a.out_w + (int64_t)min(16 * vt + fr, V - 1) * E + 32 * ((pp + RING) & 7) + 8 * fg;
+                            wr[u][0] = *reinterpret_cast<const float4*>(wp); wr[u][1] = *reinterpret_cast<const float4*>(wp + 4);
+                        }
+                        bf16x8 aw[3], bw[3];
+                        split8(ca, cb, aw);
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) bw[pl] = tm_s[(pl * 8 + ks) * 64 + lane];
+                        acc = mma6(aw, bw, acc);
+                    }
+                    if ((g & (8 / RING - 1)) == 8 / RING - 1) {                    // a tile is complete: words v0 .. v0 + 3 of batch row fr
+                        const int v0 = 16 * (i + 64 * (wave + 8 * (g / (8 / RING)))) + 4 * fg;
+                        float lv[4] = {acc[0], acc[1], acc[2], acc[3]};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (v0 + q < V) {
+                                lv[q] += a.out_b[v0 + q];
+                                const unsigned long long key = cand_key(lv[q], v0 + q);
+                                best = key > best ? key : best;
+                            }
+                        if (a.logits && m0 + fr < B) {
+                            float* lp = a.logits + ((int64_t)ts * B + m0 + fr) * a.ldl + v0;
+                            if (v0 + 3 < V) *reinterpret_cast<float4*>(lp) = make_float4(lv[0], lv[1], lv[2], lv[3]);
+                            else
+                                for (int q = 0; q < 4; ++q) if (v0 + q < V) lp[q] = lv[q];
+                        }
+                        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                VAG_STAMP(10);
+                {   // the four row groups of the wave hold the same batch rows: combine them, lanes 0..15 publish the wave's best
+                    unsigned lo = (unsigned)best, hi = (unsigned)(best >> 32);
+#pragma unroll
+                    for (int o = 16; o <= 32; o <<= 1) {
+                        const unsigned olo = __shfl_xor(lo, o, 64), ohi = __shfl_xor(hi, o, 64);
+                        const unsigned long long ob = ((unsigned long long)ohi << 32) | olo;
+                        if (ob > best) { best = ob; lo = olo; hi = ohi; }
+                    }
+                    if (lane < 16) cb_s[wave * 16 + lane] = best;
+                }
+                __syncthreads();
+                if (tx < 16) {                                            // batch row fr: the 8 waves' bests
+                    unsigned long long b = 0ull;
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) { const unsigned long long c = cb_s[16 * x + fr]; b = c > b ? c : b; }
+                    if (m0 + fr < B)
+                        __hip_atomic_store(a.cand + ((int64_t)ts * B + m0 + fr) * DEC_WGS + i, b, RLX_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (tx == 0) arrive(c6 + ts * CNT_WORDS, i);
+                wait_count(c6 + ts * CNT_WORDS, PER_SHARD, a.err, a.spin, dead);
+                VAG_STAMP(11);
+                // every workgroup of the tile reduces the 64 candidates of its 16 rows itself: 32 lanes per row, two each
+                if (tx < 128) {
+                    const int r = tx >> 3, c0 = tx & 7;
+                    const unsigned long long* cp = a.cand + ((int64_t)ts * B + min(m0 + r, B - 1)) * DEC_WGS + c0;
+                    unsigned long long k[8];
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) k[x] = __hip_atomic_load(cp + 8 * x, RLX_AGENT);
+                    unsigned long long b = k[0];
+#pragma unroll
+                    for (int x = 1; x < 8; ++x) b = k[x] > b ? k[x] : b;
+                    cb_s[tx] = b;
+                }
+                __syncthreads();
+                if (tx < 16) {
+                    unsigned long long b = 0ull;
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) { const unsigned long long c = cb_s[fr * 8 + x]; b = c > b ? c : b; }
+                    const int tk = (int)(0xffffffffu - (unsigned)(b & 0xffffffffull));
+                    tok_s[fr] = tk;
+                    if (i == 0 && m0 + fr < B) a.tok[(int64_t)t * B + m0 + fr] = tk;             // V11.py:157
+                    e3 = *reinterpret_cast<const float4*>(a.embw3 + (int64_t)min(tk, V - 1) * E + 4 * i);
+                }
+                __syncthreads();
+            }
+            VAG_STAMP(12);
+            if (t == Tt) break;
+
+            if (eok) {
+                const float* xp = a.embp + (int64_t)tok_s[fr] * 3 * H + eu;      // (bias included)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) xo[g] = *reinterpret_cast<const float4*>(xp + g * H);
+            }
+        }
+        if (ep) {
             if (eok) {
                 const float4 b0 = *reinterpret_cast<const float4*>(bs_s + 0 * 8 + 4 * hq), b1_ = *reinterpret_cast<const float4*>(bs_s + 1 * 8 + 4 * hq);
                 const float4 b2_ = *reinterpret_cast<const float4*>(bs_s + 2 * 8 + 4 * hq);
@@ -997,7 +1195,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
                 *reinterpret_cast<float4*>(sv + 3 * BH) = make_float4(gh[0], gh[1], gh[2], gh[3]);
             }
             // (threads 0..31 are half of wave 0: the drain above covered every storing lane of the wave)
-            if (threadIdx.x == 0) arrive(c2 + t * CNT_WORDS, i);
+            if (tx == 0) arrive(c2 + t * CNT_WORDS, i);
         }
         // ================= phase 2: q = attn_h h1 (:47), hp2 = W_hh2 h1 + b_hh2 (hidden side of gru_2, :129) =================
         VAG_STAMP(2);
@@ -1035,9 +1233,9 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
         // array with fp32 atomics -- no exchange of q, one hop less per step.  (The order in which the 64 shares of a score
         // arrive is not fixed: scores are reproducible to fp32 rounding, like the split-K products of gemm.hip.)
         {
-            const int cq = threadIdx.x & 3;
+            const int cq = tx & 3;
             const float4 vq = *reinterpret_cast<const float4*>(v_s + 16 * i + 4 * cq);
-            for (int P = threadIdx.x >> 2; P < 16 * Ts; P += 128) {
+            for (int P = tx >> 2; P < 16 * Ts; P += 128) {
                 const int r = P / Ts;
                 const float4 pv = reinterpret_cast<const float4*>(pe_s)[P * 4 + cq];
                 const float4 qq = *reinterpret_cast<const float4*>(q_s + r * 16 + 4 * cq);
@@ -1062,7 +1260,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
         VAG_STAMP(4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave's atomics have been performed ...
         __syncthreads();                                       // ... before the one lane that signals for all of them
-        if (threadIdx.x == 0) arrive(c4 + t * CNT_WORDS, i);
+        if (tx == 0) arrive(c4 + t * CNT_WORDS, i);
         VAG_STAMP(5);
         if (ep) {
             float4 hp2[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
@@ -1086,7 +1284,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
         VAG_STAMP(6);
         wait_count(c4 + t * CNT_WORDS, PER_SHARD, a.err, a.spin, dead);
         VAG_STAMP(7);
-        for (int x0 = threadIdx.x; x0 < 16 * Ts; x0 += 1024) {                                // 4-byte sc1 loads, two in flight
+        for (int x0 = tx; x0 < 16 * Ts; x0 += 1024) {                                // 4-byte sc1 loads, two in flight
             const int x1 = x0 + 512;
             const int r0 = x0 / Ts, r1 = min(x1, 16 * Ts - 1) / Ts;
             const float* p0 = a.psc + ((int64_t)t * B + min(m0 + r0, B - 1)) * Ts + (x0 - r0 * Ts);
@@ -1114,15 +1312,24 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
             }
         }
         __syncthreads();
-        if (threadIdx.x < 16 * 24) {
-            const int r = threadIdx.x / 24, col = threadIdx.x - r * 24;
+        if (tx < 16 * 24) {
+            const int r = tx / 24, col = tx - r * 24;
             const float* al = sc_s + r * Ts;
             const float* ew = ew_s + (int64_t)r * Ts * 24 + col;
             float s0 = 0.f, s1 = 0.f;
             int sp = 0;
             for (; sp + 1 < Ts; sp += 2) { s0 += al[sp] * ew[sp * 24]; s1 += al[sp + 1] * ew[(sp + 1) * 24]; }
             if (sp < Ts) s0 += al[sp] * ew[sp * 24];
-            gi_s[threadIdx.x] = s0 + s1;
+            gi_s[tx] = s0 + s1;
+        } else if (FREE && tx < 16 * 24 + 64) {              // the head's share of the context (W2 c = alpha . encw2), own columns
+            const int x = tx - 16 * 24, r = x >> 2, col = x & 3;
+            const float* al = sc_s + r * Ts;
+            const float* ew = ew2_s + (int64_t)r * Ts * 4 + col;
+            float s0 = 0.f, s1 = 0.f;
+            int sp = 0;
+            for (; sp + 1 < Ts; sp += 2) { s0 += al[sp] * ew[sp * 4]; s1 += al[sp + 1] * ew[(sp + 1) * 4]; }
+            if (sp < Ts) s0 += al[sp] * ew[sp * 4];
+            cw_s[x] = s0 + s1;
         }
         __syncthreads();
         if (eok) {
@@ -1164,7 +1371,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
             *reinterpret_cast<float4*>(sv + 2 * BH) = make_float4(nn[0], nn[1], nn[2], nn[3]);
             *reinterpret_cast<float4*>(sv + 3 * BH) = make_float4(hn[0], hn[1], hn[2], hn[3]);
         }
-        if (threadIdx.x == 0) arrive(c1 + t * CNT_WORDS, i);
+        if (tx == 0) arrive(c1 + t * CNT_WORDS, i);
     }
 #undef VAG_STAMP
 }
@@ -1631,15 +1838,16 @@ int vag_enc_fwd_persistent_launch(const float* xp, const float* w_fw, const floa
 
 // Eligibility of the persistent decoder: H = 512 (8 units per workgroup x 64 workgroups per row tile), at most 4 row tiles
 // (B <= 64: 256 workgroups, one per CU), keys of a row tile fit the LDS, 4-float alignment of the row strides.
-static int64_t dec_persistent_lds_bytes(int64_t Ts) {
-    return 4 * (6144 + 16 * Ts * 16 + 16 * Ts * 24 + 16 * Ts + 16 * 24 + 16 * 24 + 80 + 256 + 1024 + 16 * Ts + 256);
+static int64_t dec_persistent_lds_bytes(int64_t Ts, bool free_run = false) {
+    return 4 * (6144 + 16 * Ts * 16 + 16 * Ts * 24 + 16 * Ts + 16 * 24 + 16 * 24 + 80 + 256 + 1024 + 16 * Ts + 256 +
+                (free_run ? 64 + 16 + 16 + 16 * Ts * 4 : 0));
 }
 bool vag_dec_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H) {
     if (H != 512 || B <= 0 || B > 64 || Ts <= 0 || Tt <= 0 || Ts > 512) return false;
     const int cus = persist_cu_count();
     return cdiv64(B, 16) * DEC_WGS <= cus && dec_persistent_lds_bytes(Ts) <= 160 * 1024 && persist_lds_ok(160 * 1024);
 }
-int64_t vag_dec_persistent_sync_words(int64_t B, int64_t Tt) { return 4 * cdiv64(B, 16) * Tt * CNT_WORDS + 64; }
+int64_t vag_dec_persistent_sync_words(int64_t B, int64_t Tt) { return 5 * cdiv64(B, 16) * Tt * CNT_WORDS + 64; }
 
 int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const float* h0, const float* xp1, const float* W1,
                                   const float* b1, const float* wcat, const float* bcat, const float* v, const float* encwp,
@@ -1650,7 +1858,7 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
     VAG_CHECK_ARG(aligned16(pe) && aligned16(h0) && aligned16(xp1) && aligned16(W1) && aligned16(b1) && aligned16(wcat) &&
                   aligned16(bcat) && aligned16(v) && aligned16(encwp) && aligned16(b_ih2) && aligned16(h1) && aligned16(g1) &&
                   aligned16(qhp) && aligned16(h2_all) && aligned16(g2));
-    DecPArgs a;
+    DecPArgs a = {};
     a.pe = pe; a.mask = mask; a.h0 = h0; a.xp1 = xp1; a.W1 = W1; a.b1 = b1; a.wcat = wcat; a.bcat = bcat; a.v = v; a.encwp = encwp;
     a.b_ih2 = b_ih2; a.h1 = h1; a.g1 = g1; a.qhp = qhp; a.alpha = alpha; a.h2_all = h2_all; a.g2 = g2; a.psc = psc;
     a.B = (int)B; a.Ts = (int)Ts; a.Tt = (int)Tt; a.H = (int)H; a.RT = (int)cdiv64(B, 16);
@@ -1668,9 +1876,67 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
     int64_t lds = dec_persistent_lds_bytes(Ts);
     if (lds < 84 * 1024) lds = 84 * 1024;                            // never two workgroups on one CU
     static AttrOnce once;
-    if (!set_max_lds_once(once, reinterpret_cast<const void*>(dec_fwd_persistent_kernel))) return VAG_EINVAL;
+    if (!set_max_lds_once(once, reinterpret_cast<const void*>(dec_fwd_persistent_kernel<false>))) return VAG_EINVAL;
     const bool timed = ptimer_begin(1, s);
-    hipLaunchKernelGGL(dec_fwd_persistent_kernel, dim3((unsigned)(a.RT * DEC_WGS)), dim3(512), (size_t)lds, s, a);
+    hipLaunchKernelGGL(dec_fwd_persistent_kernel<false>, dim3((unsigned)(a.RT * DEC_WGS)), dim3(512), (size_t)lds, s, a);
+    if (timed) ptimer_end(1, s);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+// Free-running form of the same kernel (V11.py:148-160 training without teacher forcing, :207-226 greedy decoding): the kernel
+// computes the head's hidden layer, the logits of its own vocabulary tiles and the arg-max itself and feeds the token back,
+// two more hand-offs per step.  E = 256 (four head columns per workgroup); the keys' share of the head is one more LDS slice.
+bool vag_dec_free_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, int64_t V) {
+    if (H != 512 || E != DEC_E || B <= 0 || B > 64 || Ts <= 0 || Tt <= 0 || V < 16 || V >= (1ll << 30)) return false;
+    const int cus = persist_cu_count();
+    return cdiv64(B, 16) * DEC_WGS <= cus && dec_persistent_lds_bytes(Ts, true) <= 160 * 1024 && persist_lds_ok(160 * 1024);
+}
+// tables: [embp (V,3H) | embw3 (V,E) | encw2 (B,Ts,E) | cand (Tt,B,64) 8-byte words]
+int64_t vag_dec_free_tables_floats(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, int64_t V) {
+    auto r = [](int64_t n) { return (n + 63) & ~63ll; };
+    return r(V * 3 * H) + r(V * E) + r(B * Ts * E) + r(2 * Tt * B * DEC_WGS);
+}
+int vag_dec_free_persistent_launch(const float* pe, const float* mask, const float* h0, const float* W1, const float* b1,
+                                   const float* wcat, const float* bcat, const float* v, const float* encwp, const float* b_ih2,
+                                   float* h1, float* g1, float* qhp, float* alpha, float* h2_all, float* g2, float* psc,
+                                   unsigned* sync, const float* tables, const float* hw1, const float* hb1, const float* hb2,
+                                   const float* hb3, const float* out_w, const float* out_b, float* tmid, float* logits, int64_t ldl,
+                                   int64_t* tok, const uint64_t* rng, float p_out, int64_t B, int64_t Ts, int64_t Tt, int64_t E,
+                                   int64_t H, int64_t V, hipStream_t s) {
+    VAG_CHECK_ARG(pe && mask && h0 && W1 && b1 && wcat && bcat && v && encwp && b_ih2 && h1 && g1 && qhp && alpha && h2_all && g2 &&
+                  psc && sync && tables && hw1 && hb1 && hb2 && hb3 && out_w && out_b && tmid && tok &&
+                  vag_dec_free_persistent_ok(B, Ts, Tt, E, H, V));
+    VAG_CHECK_ARG(aligned16(pe) && aligned16(h0) && aligned16(W1) && aligned16(b1) && aligned16(wcat) && aligned16(bcat) &&
+                  aligned16(v) && aligned16(encwp) && aligned16(b_ih2) && aligned16(h1) && aligned16(g1) && aligned16(qhp) &&
+                  aligned16(h2_all) && aligned16(g2) && aligned16(tables) && aligned16(hw1) && aligned16(out_w) && aligned16(tmid));
+    VAG_CHECK_ARG(!logits || (aligned16(logits) && ldl >= V && ldl % 4 == 0));
+    auto r = [](int64_t n) { return (n + 63) & ~63ll; };
+    DecPArgs a = {};
+    a.pe = pe; a.mask = mask; a.h0 = h0; a.xp1 = nullptr; a.W1 = W1; a.b1 = b1; a.wcat = wcat; a.bcat = bcat; a.v = v; a.encwp = encwp;
+    a.b_ih2 = b_ih2; a.h1 = h1; a.g1 = g1; a.qhp = qhp; a.alpha = alpha; a.h2_all = h2_all; a.g2 = g2; a.psc = psc;
+    a.B = (int)B; a.Ts = (int)Ts; a.Tt = (int)Tt; a.H = (int)H; a.RT = (int)cdiv64(B, 16);
+    a.embp = tables; a.embw3 = a.embp + r(V * 3 * H); a.encw2 = a.embw3 + r(V * E);
+    a.cand = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.encw2 + r(B * Ts * E)));
+    a.hw1 = hw1; a.hb1 = hb1; a.hb2 = hb2; a.hb3 = hb3; a.out_w = out_w; a.out_b = out_b; a.tmid = tmid; a.logits = logits;
+    a.tok = tok; a.rng = rng; a.p_out = p_out; a.V = (int)V; a.ldl = (int)ldl;
+    const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
+#ifdef VAG_LAB
+    a.dbg = reinterpret_cast<unsigned long long*>(vag_opt().dec_stamps);       // (Tt + 1) x 16 words in this form
+#else
+    a.dbg = nullptr;
+#endif
+    const int nsc = (int)(Tt * B * Ts);
+    hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64((int64_t)nwords + nsc, 256)), dim3(256), 0, s, sync, nwords,
+                       reinterpret_cast<unsigned*>(psc), nsc);
+    VAG_LAUNCH_CHECK();
+    int64_t lds = dec_persistent_lds_bytes(Ts, true);
+    if (lds < 84 * 1024) lds = 84 * 1024;
+    static AttrOnce once;
+    if (!set_max_lds_once(once, reinterpret_cast<const void*>(dec_fwd_persistent_kernel<true>))) return VAG_EINVAL;
+    const bool timed = ptimer_begin(1, s);
+    hipLaunchKernelGGL(dec_fwd_persistent_kernel<true>, dim3((unsigned)(a.RT * DEC_WGS)), dim3(512), (size_t)lds, s, a);
     if (timed) ptimer_end(1, s);
     VAG_LAUNCH_CHECK();
     return VAG_OK;

@@ -20,6 +20,7 @@ struct StepWs {
     float *xmix, *hseq, *c_all, *e_all, *ws_dec, *tmid, *logits, *lse, *nll, *inv_cnt, *consts;
     int64_t* tok;
     float *d_enc, *d_pe, *d_h2, *d_c, *d_e, *d_h0, *d_ctx, *d_im, *d_txt, *scr_dec, *scr_head, *scr_ini;
+    float* free_tab;            // tables of the one-launch free-running decoder (shapes it can take only)
     int64_t total;
 };
 
@@ -44,6 +45,8 @@ StepWs step_ws(float* p, const vag_step_cfg& c) {
     w.d_enc = take(B * Ts * C); w.d_pe = take(B * Ts * C); w.d_h2 = take(R * H); w.d_c = take(R * C); w.d_e = take(R * c.Et);
     w.d_h0 = take(B * H); w.d_ctx = take(mm ? B * C : 0); w.d_im = take(mm ? B * S : 0); w.d_txt = take(mm ? B * S : 0);
     w.scr_dec = take(vag_cgru_bwd_scratch_floats(B, Ts, Tt, c.Et, H)); w.scr_head = take(R * c.Et); w.scr_ini = take(B * C);
+    // (by shape, not by device: a workspace size must not depend on where it is asked for)
+    w.free_tab = take(H == 512 && c.Et == 256 && B <= 64 ? vag_dec_free_tables_floats(B, Ts, Tt, c.Et, H, c.V) : 0);
     w.total = o;
     return w;
 }
@@ -189,6 +192,11 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
             // would hold back.)
             VagGemmGroup outer(derived != nullptr);
             VAG_TRY(vag_attn_keys_proj(k.enc, w.attn_e, B * Ts, C, k.pe, stream));                      // NMT_Decoder.py:47
+            if (c.free_run && vag_cgru_free_supported(B, Ts, Tt, Et, H, V))
+                VAG_TRY(vag_cgru_attn_decode_free_fwd(k.enc, k.pe, k.mask, h0, k.tok, w.dec, B, Ts, Tt, Et, H, V, h2_all, k.c_all,
+                                                      k.e_all, k.ws_dec, &w.head, c.p_out, crng, k.tmid, k.logits, c.ldl,
+                                                      k.free_tab, stream));                             // V11.py:148-160, one launch
+            else
             VAG_TRY(vag_cgru_attn_decode_seq_fwd(k.enc, k.pe, k.mask, h0, k.tok, w.dec, B, Ts, Tt, Et, H, V, h2_all, k.c_all,
                                                  k.e_all, k.ws_dec, c.free_run, &w.head, c.p_out, crng, k.tmid, k.logits,
                                                  c.ldl, stream));                                       // V11.py:138-160

@@ -86,6 +86,7 @@ class Seq2SeqBase(nn.Module):
     # only looks at the device every chunk.  ``model.decode_graph = False`` runs the same kernels launch by launch.
     DECODE_CHUNK = 8
     decode_graph = True
+    decode_persistent = True      # greedy decoding in one launch where the shape allows it (ops.greedy_decode)
 
     def _decode_state(self, kind, enc, mask, k, max_length):
         """Static buffers (+ captured graph, filled in by the caller) for one decode shape; refreshed per call."""
@@ -121,6 +122,13 @@ class Seq2SeqBase(nn.Module):
         dev = enc.device
         toks = torch.empty(tgt_l, B, dtype=torch.int64, device=dev)
         self.last_decode_steps = tgt_l
+        if self.decode_persistent and enc.is_cuda:
+            dp, hp, emb = dec.dec_params(), dec.head_params(), dec.embedding.weight
+            if ops.greedy_decode_supported(B, enc.shape[1], tgt_l, emb.shape[1], h.shape[1], hp[7].shape[0]):
+                # every step in ONE launch: the recurrence kernel forms the logits and the arg-max itself (persist.hip)
+                pe = ops.KeysProj.apply(enc, dec.attn.attn_e.weight)
+                toks = ops.greedy_decode(enc, pe, mask, h, emb, dp, hp, tgt_l, SOS_token)
+                return self._cut(toks.t().cpu().numpy())
         if not (self.decode_graph and enc.is_cuda):
             pe = ops.KeysProj.apply(enc, dec.attn.attn_e.weight)
             tok = torch.full((B,), SOS_token, dtype=torch.int64, device=dev)

@@ -64,6 +64,10 @@ PROTOS = {
     "vag_cgru_ws_floats": (I64, [I64, I64, I64, I64, I64]),
     "vag_cgru_attn_decode_seq_fwd": (I32, [P, P, P, P, P, DecW, I64, I64, I64, I64, I64, I64, P, P, P, P, I32,
                                            C.POINTER(HeadW), F, P, P, P, I64, P]),
+    "vag_cgru_free_supported": (I32, [I64, I64, I64, I64, I64, I64]),
+    "vag_cgru_free_tables_floats": (I64, [I64, I64, I64, I64, I64, I64]),
+    "vag_cgru_attn_decode_free_fwd": (I32, [P, P, P, P, P, DecW, I64, I64, I64, I64, I64, I64, P, P, P, P,
+                                            C.POINTER(HeadW), F, P, P, P, I64, P, P]),
     "vag_cgru_bwd_scratch_floats": (I64, [I64, I64, I64, I64, I64]),
     "vag_cgru_attn_decode_seq_bwd": (I32, [P, P, P, P, P, DecW, I64, I64, I64, I64, I64, I64, P, P, P, P, P, P, P, P,
                                            I32, P, P, DecW, P, P]),

@@ -198,9 +198,16 @@ class _CGRUDecodeSeq(Function):
             tmid = _f32(Tt, B, E, like=enc)
             logits = _f32(Tt * B, ldl, like=enc)
             hw = C.byref(_head_w(head))
-        call("vag_cgru_attn_decode_seq_fwd", ptr(enc), ptr(pe), ptr(mask), ptr(h0), ptr(tok, I64), _dec_w(emb, dec),
-             B, Ts, Tt, E, H, V, ptr(h2), ptr(c), ptr(e), ptr(ws), int(bool(free_run)), hw, float(p_out),
-             ptr(rng, torch.int64) if rng is not None else None, ptr(tmid), ptr(logits), ldl, stream())
+        if free_run and L.lib().vag_cgru_free_supported(B, Ts, Tt, E, H, V):
+            # one launch for all steps (persist.hip, free-running form); same outputs and saved tensors
+            tables = _f32(L.lib().vag_cgru_free_tables_floats(B, Ts, Tt, E, H, V), like=enc)
+            call("vag_cgru_attn_decode_free_fwd", ptr(enc), ptr(pe), ptr(mask), ptr(h0), ptr(tok, I64), _dec_w(emb, dec),
+                 B, Ts, Tt, E, H, V, ptr(h2), ptr(c), ptr(e), ptr(ws), hw, float(p_out),
+                 ptr(rng, torch.int64) if rng is not None else None, ptr(tmid), ptr(logits), ldl, ptr(tables), stream())
+        else:
+            call("vag_cgru_attn_decode_seq_fwd", ptr(enc), ptr(pe), ptr(mask), ptr(h0), ptr(tok, I64), _dec_w(emb, dec),
+                 B, Ts, Tt, E, H, V, ptr(h2), ptr(c), ptr(e), ptr(ws), int(bool(free_run)), hw, float(p_out),
+                 ptr(rng, torch.int64) if rng is not None else None, ptr(tmid), ptr(logits), ldl, stream())
         ctx.save_for_backward(enc, pe, mask, h0, tok, ws, h2, c, e, emb, *dec)
         ctx.gviews = _grad_views((emb,) + tuple(dec))
         ctx.cfg = (B, Ts, Tt, E, H, V)
@@ -479,6 +486,29 @@ def decode_step(enc, pe, mask, rows_per_src, tok, h_in, emb, dec, prep):
     call("vag_cgru_attn_decode_step", ptr(enc), ptr(pe), ptr(mask), rows_per_src, ptr(_c(tok).view(-1), I64), ptr(_c(h_in)),
          _dec_w(emb, dec), ptr(prep), N, Ts, E, H, ptr(h_out), ptr(c), ptr(e), ptr(alpha), ptr(scratch), stream())
     return h_out, c, e, alpha
+
+
+def greedy_decode_supported(B, Ts, steps, E, H, V):
+    return bool(L.lib().vag_cgru_free_supported(B, Ts, steps, E, H, V))
+
+
+def greedy_decode(enc, pe, mask, h0, emb, dec, head, steps, sos):
+    """Arg-max decoding for exactly `steps` steps (V11.py:207-226) in ONE launch of the free-running recurrence kernel.
+    Returns the chosen tokens (steps, B) int64.  Only for shapes greedy_decode_supported accepts."""
+    B, Ts, Cc = enc.shape
+    H = Cc // 2
+    E = emb.shape[1]
+    V = head[7].shape[0]
+    tok = torch.empty(steps + 1, B, dtype=I64, device=enc.device)
+    tok[0].fill_(sos)
+    hseq = _f32(steps, B, H, like=enc)
+    tmid = _f32(steps, B, E, like=enc)
+    ws = _f32(L.lib().vag_cgru_ws_floats(B, Ts, steps, E, H), like=enc)
+    tables = _f32(L.lib().vag_cgru_free_tables_floats(B, Ts, steps, E, H, V), like=enc)
+    call("vag_cgru_attn_decode_free_fwd", ptr(_c(enc)), ptr(_c(pe)), ptr(_c(mask)), ptr(_c(h0)), ptr(tok, I64), _dec_w(emb, dec),
+         B, Ts, steps, E, H, V, ptr(hseq), None, None, ptr(ws), C.byref(_head_w(head)), 0.0, None, ptr(tmid), None, 0,
+         ptr(tables), stream())
+    return tok[1:]
 
 
 def head_logp_step(h2, c, e, head, want_argmax=False, argmax_out=None):
