@@ -199,7 +199,7 @@ static DerivedW derived_layout(float* p, int64_t H) {
 // =====================================================================================================
 struct BiGruWs {
     float *x, *xp, *hst, *gates, *dgh, *carry, *dx, *whhT, *gx;
-    unsigned* sync;                      // counters of the persistent recurrence kernels (persist.hip)
+    unsigned *sync, *sync_b;             // counters of the persistent recurrence kernels (persist.hip): forward, backward
     int64_t total;
 };
 static BiGruWs bigru_ws(float* ws, int64_t B, int64_t Ts, int64_t E, int64_t H) {
@@ -216,6 +216,7 @@ static BiGruWs bigru_ws(float* ws, int64_t B, int64_t Ts, int64_t E, int64_t H) 
     w.whhT = take(2 * 3 * H * H);        // backward: W_hh^T per direction (H,3H)
     w.gx = take(3 * Ts * B * H);         // backward, 2-byte mode one-launch kernel: [dir][step][B][3H] fp16 copy of dgh for the exchange
     w.sync = reinterpret_cast<unsigned*>(take(vag_enc_persistent_sync_words(B, Ts)));
+    w.sync_b = reinterpret_cast<unsigned*>(take(vag_enc_persistent_sync_words(B, Ts)));      // (adjacent: one range to zero)
     w.total = o;
     return w;
 }
@@ -230,8 +231,7 @@ int vag_bigru_seq_fwd(const int64_t* src, const int32_t* lengths, const float* e
     VAG_CHECK_ARG(fw.w_ih && fw.w_hh && fw.b_ih && fw.b_hh && bw.w_ih && bw.w_hh && bw.b_ih && bw.b_hh);
     BiGruWs w = bigru_ws(ws, B, Ts, E, H);
     const int64_t R = Ts * B;
-    VAG_TRY(vag_src_mask_launch(src, B * Ts, mask, s));
-    VAG_TRY(vag_embed_gather_launch(src, 1, Ts, Ts, B, emb, E, w.x, rng, VAG_DROP_ENC_EMB, p_emb, s));
+    VAG_TRY(vag_embed_gather_launch(src, 1, Ts, Ts, B, emb, E, w.x, rng, VAG_DROP_ENC_EMB, p_emb, s, mask));    // (+ the source mask)
     VagGemmGroup grp0;              // both directions' input projections: one grouped launch
     VAG_TRY(vag_gemm_launch(R, 3 * H, E, 1.f, w.x, E, 1, fw.w_ih, 1, E, 0.f, w.xp, 6 * H, fw.b_ih, 0, s));
     VAG_TRY(vag_gemm_launch(R, 3 * H, E, 1.f, w.x, E, 1, bw.w_ih, 1, E, 0.f, w.xp + 3 * H, 6 * H, bw.b_ih, 0, s));
@@ -306,10 +306,10 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
         // 2-byte mode, wide batches: the twin of the forward's one-launch kernel (fp16 W_hh^T slice in registers, gate gradients
         // exchanged as fp16 x 2^12 -- what the chain's fp16-pipe product rounds them to)
         VAG_TRY(vag_enc_bwd_wide16_launch(reinterpret_cast<const vag_half*>(whhT), d_enc, w.gates, w.hst, lengths, rng, p_ctx, d_xp,
-                                          w.dgh, reinterpret_cast<vag_half*>(w.gx), w.sync, B, Ts, H, s));
+                                          w.dgh, reinterpret_cast<vag_half*>(w.gx), w.sync_b, B, Ts, H, s));
     } else if (persist) {
         // the whole backward recurrence, both directions, in ONE launch (persist.hip)
-        VAG_TRY(vag_enc_bwd_persistent_launch(whhT, d_enc, w.gates, w.hst, lengths, rng, p_ctx, d_xp, w.dgh, w.sync, B, Ts, H, s));
+        VAG_TRY(vag_enc_bwd_persistent_launch(whhT, d_enc, w.gates, w.hst, lengths, rng, p_ctx, d_xp, w.dgh, w.sync_b, B, Ts, H, s));
     }
     // last processed step: plain elementwise cell backward (no gradient arrives from a later step)
     GruBwdArgs a = {};
@@ -524,6 +524,8 @@ struct CgruWs {
     float *xp1, *h1, *g1, *g2, *qhp, *scores, *alpha, *tmp, *prep, *encwp;
     float* psc;                 // persistent decoder (persist.hip): the steps' scores as exchanged between workgroups (Tt,B,Ts)
     unsigned* sync;             // ... and its counters
+    unsigned* sync_b;           // the backward kernel's counters ...
+    float* dal;                 // ... and its d alpha accumulator (Tt,B,Ts)   [psc .. dal: one range to zero]
     int64_t total;
 };
 static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
@@ -543,9 +545,24 @@ static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, i
     w.encwp = take(B * Ts * 3 * H);         // (W_ih2 W_c2h) enc[b,s,:]: the keys as gru_2 sees them, once per batch
     w.psc = take(Tt * B * Ts);
     w.sync = reinterpret_cast<unsigned*>(take(vag_dec_persistent_sync_words(B, Tt)));
+    w.sync_b = reinterpret_cast<unsigned*>(take(vag_dec_persistent_sync_words(B, Tt)));
+    w.dal = take(Tt * B * Ts);
     w.total = o;
     return w;
 }
+}  // extern "C"
+// What the recurrence kernels of one training step expect to find zeroed, as two word ranges (vag_train_step's prologue launch
+// zeroes them and tells the launch functions so: persist.hip, g_prezeroed)
+void vag_step_zero_ranges(float* ws_enc, float* ws_dec, int64_t B, int64_t Ts, int64_t Tt, int64_t Es, int64_t Et, int64_t H,
+                          unsigned** p, int64_t* n) {
+    BiGruWs e = bigru_ws(ws_enc, B, Ts, Es, H);
+    p[0] = e.sync;
+    n[0] = (reinterpret_cast<unsigned*>(ws_enc) + e.total) - e.sync;
+    CgruWs d = cgru_ws(ws_dec, B, Ts, Tt, Et, H);
+    p[1] = reinterpret_cast<unsigned*>(d.psc);
+    n[1] = (reinterpret_cast<unsigned*>(ws_dec) + d.total) - p[1];
+}
+extern "C" {
 int64_t vag_cgru_ws_floats(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
     return cgru_ws(nullptr, B, Ts, Tt, E, H).total;
 }
@@ -831,9 +848,9 @@ int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const f
     else
         VAG_TRY(vag_attn_scores_ex_launch(1, enc, d_c_all, C, nullptr, nullptr, Tt * B, 1, B, Ts, C, nullptr, z.dah, s));
     if (persist) {
-        // the whole backward recurrence in ONE launch (persist.hip); k.psc (the forward's score exchange) holds d alpha
+        // the whole backward recurrence in ONE launch (persist.hip); k.dal holds d alpha
         VAG_TRY(vag_dec_bwd_persistent_launch(pe, k.encwp, w.attn_v, z.wcatT, z.whh1T, h0, h2_all, k.h1, k.g1, k.g2, k.qhp, k.alpha,
-                                              d_h2_all, z.dah, z.dgi2, z.dqgh, z.ds, z.dgi1, z.dgh1, d_h0, k.psc, k.sync, B, Ts, Tt, H,
+                                              d_h2_all, z.dah, z.dgi2, z.dqgh, z.ds, z.dgi1, z.dgh1, d_h0, k.dal, k.sync_b, B, Ts, Tt, H,
                                               s));
     }
     for (int64_t t = Tt - 1; t >= 0 && !persist; --t) {

@@ -51,6 +51,12 @@ __device__ __forceinline__ float wave_allreduce(float v) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
     return MAX ? fmaxf(a, b) : a + b;
 }
+// sum over the four lanes of a quad (DPP quad_perm [1,0,3,2] then [2,3,0,1]: two VALU instructions, no LDS pipe)
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) { return wave_allreduce<false>(v); }
 __device__ __forceinline__ float wave_max(float v) { return wave_allreduce<true>(v); }
 // tanh / sigmoid on the v_exp_f32 path; absolute error ~1e-7, saturates cleanly at +-1 / 0,1.

@@ -12,7 +12,7 @@ static inline dim3 grid1d(int64_t n, int bs = 256) {
 __global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __restrict__ idx, int64_t ist, int64_t isb,
                                                            int T, int B, const float* __restrict__ W, int E,
                                                            float* __restrict__ out, const uint64_t* rng, int sid,
-                                                           float p) {
+                                                           float p, float* __restrict__ mask_out) {
     const int E4 = E >> 2;
     const int64_t total = (int64_t)T * B * E4;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __rest
         const int e = (int)(i - row * E4) << 2;
         const int t = (int)(row / B), b = (int)(row - (int64_t)t * B);
         const int64_t tok = idx[b * isb + t * ist];
+        if (mask_out && e == 0) mask_out[b * isb + t * ist] = tok != 0 ? 1.f : 0.f;     // the source mask (V11.py:100) on the way
         float4 v = *reinterpret_cast<const float4*>(W + tok * E + e);
         if (rng && p > 0.f) {
             const uint64_t o = (uint64_t)row * E + e;
@@ -33,11 +34,11 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __rest
 }
 
 int vag_embed_gather_launch(const int64_t* idx, int64_t ist, int64_t isb, int64_t T, int64_t B, const float* W,
-                            int64_t E, float* out, const uint64_t* rng, int sid, float p, hipStream_t s) {
+                            int64_t E, float* out, const uint64_t* rng, int sid, float p, hipStream_t s, float* mask_out) {
     VAG_CHECK_ARG(idx && W && out && E > 0 && E % 4 == 0 && T >= 0 && B >= 0);
     if (T * B == 0) return VAG_OK;
     hipLaunchKernelGGL(embed_gather_kernel, grid1d(T * B * E / 4), dim3(256), 0, s, idx, ist, isb, (int)T, (int)B, W,
-                       (int)E, out, rng, sid, p);
+                       (int)E, out, rng, sid, p, mask_out);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

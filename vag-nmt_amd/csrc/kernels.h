@@ -5,8 +5,10 @@
 
 // ---------------- elem.hip ----------------
 // out[(t*B+b), :] = W[idx[b*isb + t*ist], :] * dropout
+// mask_out (optional, indexed like idx): 1 where the index is not the padding index 0
 int vag_embed_gather_launch(const int64_t* idx, int64_t ist, int64_t isb, int64_t T, int64_t B, const float* W,
-                            int64_t E, float* out, const uint64_t* rng, int sid, float p, hipStream_t s);
+                            int64_t E, float* out, const uint64_t* rng, int sid, float p, hipStream_t s,
+                            float* mask_out = nullptr);
 // gW[idx, :] += g[(t*B+b), :] * dropout, skipping idx == 0 (padding_idx)
 int vag_embed_scatter_launch(const int64_t* idx, int64_t ist, int64_t isb, int64_t T, int64_t B, const float* g,
                              int64_t E, float* gW, const uint64_t* rng, int sid, float p, hipStream_t s,
@@ -172,6 +174,9 @@ int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const flo
                                   const float* qhp, const float* alpha, const float* d_h2_all, const float* dah, float* dgi2,
                                   float* dqgh, float* ds, float* dgi1, float* dgh1, float* d_h0, float* dal, unsigned* sync,
                                   int64_t B, int64_t Ts, int64_t Tt, int64_t H, hipStream_t s);
+void vag_step_zero_ranges(float* ws_enc, float* ws_dec, int64_t B, int64_t Ts, int64_t Tt, int64_t Es, int64_t Et, int64_t H,
+                          unsigned** p, int64_t* n);                 // api.hip
+void vag_persist_set_prezeroed(bool v);      // calling thread: the launches below skip zeroing their counters / exchange buffers
 bool vag_dec_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H);
 int64_t vag_dec_persistent_sync_words(int64_t B, int64_t Tt);
 int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const float* h0, const float* xp1, const float* W1,

@@ -951,9 +951,6 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
             e3 = *reinterpret_cast<const float4*>(a.embw3 + (int64_t)tk * E + 4 * i);
         }
     }
-    const int arow = min(m0 + fr, B - 1);
-    const int lrow = min(m0 + ld_row(lane), B - 1);        // the batch row this lane LOADS (quad-contiguous mapping, see ld_row)
-    const int src4 = ld_src4(lane);
     gu32* c1 = (gu32*)(a.cnt + ((int64_t)0 * a.RT + rt) * Tt * CNT_WORDS);       // h2[t] published (waited on by step t + 1)
     gu32* c2 = (gu32*)(a.cnt + ((int64_t)1 * a.RT + rt) * Tt * CNT_WORDS);       // h1
     gu32* c4 = (gu32*)(a.cnt + ((int64_t)3 * a.RT + rt) * Tt * CNT_WORDS);       // scores
@@ -978,7 +975,9 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
         const int lane = tx & 63, wave = FREE ? __builtin_amdgcn_readfirstlane(tx >> 6) : tx >> 6, fr = lane & 15, fg = lane >> 4;
         const int kbase = wave * (H >> 3), hq = (tx >> 4) & 1, em = m0 + fr, eu = u0 + 4 * hq;
         const bool ep = tx < 32, eok = ep && em < B;
-        const int arow = min(m0 + fr, B - 1), lrow = min(m0 + ld_row(lane), B - 1), src4 = ld_src4(lane);
+        const int arow = min(m0 + fr, B - 1);
+        const int lrow = min(m0 + ld_row(lane), B - 1);    // the batch row this lane LOADS (quad-contiguous mapping, see ld_row)
+        const int src4 = ld_src4(lane);
         VAG_STAMP(0);
         // ================= phase 1: gru_1 cell (NMT_Decoder.py:121) =================
         float4 ha[KS], hb[KS];
@@ -1241,8 +1240,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
                 const float4 qq = *reinterpret_cast<const float4*>(q_s + r * 16 + 4 * cq);
                 float acc = vq.x * vag_tanh(pv.x + qq.x) + vq.y * vag_tanh(pv.y + qq.y) + vq.z * vag_tanh(pv.z + qq.z) +
                             vq.w * vag_tanh(pv.w + qq.w);
-                acc += __shfl_xor(acc, 1, 64);
-                acc += __shfl_xor(acc, 2, 64);
+                acc = quad_sum(acc);
                 if (cq == 0 && m0 + r < B) atomicAdd(a.psc + ((int64_t)t * B + m0 + r) * Ts + (P - r * Ts), acc);
             }
         }
@@ -1732,6 +1730,11 @@ __global__ __launch_bounds__(256) void zero2_u32_kernel(unsigned* p, int n, unsi
 // once (one per CU).
 // Optional HIP-event timing of the four recurrence kernels (option "persist_timing"; eager launches only -- events cannot be
 // read back from inside a stream capture).  kind: 0 encoder forward, 1 decoder forward, 2 encoder backward, 3 decoder backward.
+// vag_train_step zeroes every counter / exchange buffer of a step's recurrence kernels in its prologue launch (one launch
+// instead of four) and says so for the duration of its call: the launch functions below then skip their own zeroing.
+static thread_local bool g_prezeroed = false;
+void vag_persist_set_prezeroed(bool v) { g_prezeroed = v; }
+
 struct PersistTimer { hipEvent_t e0 = nullptr, e1 = nullptr; bool pending = false; double ms = 0.0; int n = 0; };
 static PersistTimer g_ptimer[4];
 static void ptimer_collect(PersistTimer& t) {
@@ -1824,8 +1827,10 @@ int vag_enc_fwd_persistent_launch(const float* xp, const float* w_fw, const floa
     a.B = (int)B; a.Ts = (int)Ts; a.H = (int)H; a.RT = (int)cdiv64(B, 16); a.CS = (int)(H / 16);
     const int nwords = (int)vag_enc_persistent_sync_words(B, Ts);
     a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
-    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
-    VAG_LAUNCH_CHECK();
+    if (!g_prezeroed) {
+        hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
+        VAG_LAUNCH_CHECK();
+    }
     const dim3 grid((unsigned)(2 * a.RT * a.CS));
     const bool timed = ptimer_begin(0, s);
     if (H == 256) hipLaunchKernelGGL(enc_fwd_persistent_kernel<1>, grid, dim3(512), 0, s, a);
@@ -1870,9 +1875,11 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
     a.dbg = nullptr;
 #endif
     const int nsc = (int)(Tt * B * Ts);                              // the scores are accumulated with atomics: start from zero
-    hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64((int64_t)nwords + nsc, 256)), dim3(256), 0, s, sync, nwords,
-                       reinterpret_cast<unsigned*>(psc), nsc);
-    VAG_LAUNCH_CHECK();
+    if (!g_prezeroed) {
+        hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64((int64_t)nwords + nsc, 256)), dim3(256), 0, s, sync, nwords,
+                           reinterpret_cast<unsigned*>(psc), nsc);
+        VAG_LAUNCH_CHECK();
+    }
     int64_t lds = dec_persistent_lds_bytes(Ts);
     if (lds < 84 * 1024) lds = 84 * 1024;                            // never two workgroups on one CU
     static AttrOnce once;
@@ -1928,9 +1935,11 @@ int vag_dec_free_persistent_launch(const float* pe, const float* mask, const flo
     a.dbg = nullptr;
 #endif
     const int nsc = (int)(Tt * B * Ts);
-    hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64((int64_t)nwords + nsc, 256)), dim3(256), 0, s, sync, nwords,
-                       reinterpret_cast<unsigned*>(psc), nsc);
-    VAG_LAUNCH_CHECK();
+    if (!g_prezeroed) {
+        hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64((int64_t)nwords + nsc, 256)), dim3(256), 0, s, sync, nwords,
+                           reinterpret_cast<unsigned*>(psc), nsc);
+        VAG_LAUNCH_CHECK();
+    }
     int64_t lds = dec_persistent_lds_bytes(Ts, true);
     if (lds < 84 * 1024) lds = 84 * 1024;
     static AttrOnce once;
@@ -1962,8 +1971,10 @@ int vag_enc_fwd_wide16_launch(const float* xp, const vag_half* w16_fw, const vag
     a.B = (int)B; a.Ts = (int)Ts; a.H = (int)H; a.RG = (int)cdiv64(B, 64); a.CS = (int)(H / 32);
     const int nwords = (int)vag_enc_persistent_sync_words(B, Ts);
     a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
-    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
-    VAG_LAUNCH_CHECK();
+    if (!g_prezeroed) {
+        hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
+        VAG_LAUNCH_CHECK();
+    }
     const size_t lds = 96 * 1024;
     static AttrOnce once4, once8;
     if (!set_max_lds_once(once4, reinterpret_cast<const void*>(enc_fwd_wide16_kernel<4>)) ||
@@ -1990,8 +2001,10 @@ int vag_enc_bwd_wide16_launch(const vag_half* wt16, const float* d_enc, const fl
     a.B = (int)B; a.Ts = (int)Ts; a.H = (int)H; a.RG = (int)cdiv64(B, 64); a.CS = (int)(H / 32);
     const int nwords = (int)vag_enc_persistent_sync_words(B, Ts);
     a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
-    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
-    VAG_LAUNCH_CHECK();
+    if (!g_prezeroed) {
+        hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
+        VAG_LAUNCH_CHECK();
+    }
     const size_t lds = 84 * 1024;                      // 32 KB of reduction space; the rest keeps the CU to one workgroup
     static AttrOnce once6, once12;
     if (!set_max_lds_once(once6, reinterpret_cast<const void*>(enc_bwd_wide16_kernel<6>)) ||
@@ -2017,8 +2030,10 @@ int vag_enc_bwd_persistent_launch(const float* whhT, const float* d_enc, const f
     a.B = (int)B; a.Ts = (int)Ts; a.H = (int)H; a.RT = (int)cdiv64(B, 16); a.CS = (int)(H / 16);
     const int nwords = (int)vag_enc_persistent_sync_words(B, Ts);
     a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
-    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
-    VAG_LAUNCH_CHECK();
+    if (!g_prezeroed) {
+        hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
+        VAG_LAUNCH_CHECK();
+    }
     const bool timed = ptimer_begin(2, s);
     hipLaunchKernelGGL(enc_bwd_persistent_kernel<6>, dim3((unsigned)(2 * a.RT * a.CS)), dim3(512), 0, s, a);
     if (timed) ptimer_end(2, s);
@@ -2070,9 +2085,11 @@ int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const flo
     const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
     a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
     const int nsc = (int)(Tt * B * Ts);
-    hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64((int64_t)nwords + nsc, 256)), dim3(256), 0, s, sync, nwords,
-                       reinterpret_cast<unsigned*>(dal), nsc);
-    VAG_LAUNCH_CHECK();
+    if (!g_prezeroed) {
+        hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64((int64_t)nwords + nsc, 256)), dim3(256), 0, s, sync, nwords,
+                           reinterpret_cast<unsigned*>(dal), nsc);
+        VAG_LAUNCH_CHECK();
+    }
     int64_t lds = dec_bwd_persistent_lds_bytes(Ts);
     if (lds < 84 * 1024) lds = 84 * 1024;
     static AttrOnce once;

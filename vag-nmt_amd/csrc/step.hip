@@ -60,10 +60,21 @@ bool cfg_ok(const vag_step_cfg* c) {
 
 // rng step counter, the two loss-mix constants, the decoder's input token matrix (row 0 = SOS, row t+1 = target word t:
 // V11.py:117,146), the per-sentence token counts -- one launch for the step's scalar bookkeeping.
+// Also zeroes the counters and exchange buffers of the step's four recurrence kernels (two word ranges, api.hip:
+// vag_step_zero_ranges): one launch instead of four.
 __global__ __launch_bounds__(256) void step_prologue_kernel(uint64_t* rng, const int64_t* __restrict__ tgt, int B, int Tt,
                                                             int64_t* __restrict__ tok, float* __restrict__ consts,
-                                                            float* __restrict__ inv_cnt, float w_mt, float w_vse) {
+                                                            float* __restrict__ inv_cnt, float w_mt, float w_vse,
+                                                            unsigned* __restrict__ z0, int64_t n0, unsigned* __restrict__ z1,
+                                                            int64_t n1) {
     const int64_t gid = blockIdx.x * 256ll + threadIdx.x;
+    for (int64_t i = gid; i < n0; i += (int64_t)gridDim.x * 256) z0[i] = 0u;
+    {   // the large range: 16 bytes per thread (the range starts 256-byte aligned; its tail word by word)
+        const int64_t n4 = n1 >> 2;
+        uint4* z4 = reinterpret_cast<uint4*>(z1);
+        for (int64_t i = gid; i < n4; i += (int64_t)gridDim.x * 256) z4[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int64_t i = (n4 << 2) + gid; i < n1; i += (int64_t)gridDim.x * 256) z1[i] = 0u;
+    }
     if (gid < B) {                          // inv_cnt[b] = 1 / #(tgt[b,:] != 0)   (V11.py:164)
         int c = 0;
         for (int t = 0; t < Tt; ++t) c += tgt[gid * Tt + t] != 0;
@@ -80,6 +91,10 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(uint64_t* rng, const
     }
 }
 
+struct PrezeroScope {       // the recurrence kernels of this call find their counters zeroed by the step's prologue launch
+    PrezeroScope() { vag_persist_set_prezeroed(true); }
+    ~PrezeroScope() { vag_persist_set_prezeroed(false); }
+};
 struct DerivedScope {       // points the operators at the driver's derived weights, storage mode and head chunk for one call
     const float* prev_d;    // ... and puts back what the caller had set with vag_set_operator_context ("until changed")
     bool prev16;
@@ -150,6 +165,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     if (vag_opt().head_chunk >= 0)      // vag_set_option("head_chunk", rows): rows per chunk (0 = never chunk); tests
         chunk = c.free_run ? 0 : vag_opt().head_chunk;
     DerivedScope scope(derived, c.storage == 1, chunk);
+    PrezeroScope prezero;           // (a backward-only call relies on the forward call of the same step having run first)
     // forward and backward in one call: the chunked head finishes each chunk (d(logits) and its products) in the forward;
     // a backward called on its own (phases = 2 after an earlier phases = 1) recomputes the chunks instead
     if (chunk > 0 && (phases & 3) == 3 && vag_opt().head_fuse != 0)
@@ -166,10 +182,14 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     if (phases & 1) {
         if (one_plane) vag_gemm_set_planes(11);
         {
+            unsigned* zp[2];
+            int64_t zn[2];
+            vag_step_zero_ranges(k.ws_enc, k.ws_dec, B, Ts, Tt, c.Es, Et, H, zp, zn);
             int64_t nb = cdiv64((Tt + 1) * B, 256);
+            if (nb < cdiv64(zn[1], 1024)) nb = cdiv64(zn[1], 1024);
             if (nb > 1024) nb = 1024;
             hipLaunchKernelGGL(step_prologue_kernel, dim3((unsigned)nb), dim3(256), 0, s, rng, tgt, (int)B, (int)Tt, k.tok,
-                               k.consts, k.inv_cnt, w_mt, w_vse);
+                               k.consts, k.inv_cnt, w_mt, w_vse, zp[0], zn[0], zp[1], zn[1]);
             VAG_LAUNCH_CHECK();
         }
         VAG_TRY(vag_bigru_seq_fwd(src, lengths, w.enc_emb, w.enc_fw, w.enc_bw, c.p_emb, c.p_ctx, crng, B, Ts, c.Es, H, k.enc,
