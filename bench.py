@@ -361,7 +361,10 @@ def measure_extras(c, dev, ts, args):
     ms08 = run(60, fb, ltf, teacher=None)
     ts.tfr = old
     out["teacher_force_ratio_0.8"] = {"ms_per_step": ms08, "pairs_per_s": c["B"] / ms08 * 1e3}
-    out["free_running"] = {"ms_per_step": ms_free, "pairs_per_s": c["B"] / ms_free * 1e3}
+    from vagnmt_hip import _lib as L
+    out["free_running"] = {"ms_per_step": ms_free, "pairs_per_s": c["B"] / ms_free * 1e3,
+                           "decoder_forward": "one launch (free-running form of the persistent recurrence kernel)" if
+                           L.lib().vag_cgru_free_supported(c["B"], c["Ts"], c["Tt"], c["E"], c["H"], c["V"]) else "launch chain"}
     # configs[3]
     c4 = dict(c)
     c4["B"] = 16
@@ -380,8 +383,13 @@ def measure_extras(c, dev, ts, args):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         steps = int(getattr(m4, "last_decode_steps", 80))
+        one_launch = k == 1 and getattr(m4, "decode_persistent", False) and bool(
+            L.lib().vag_cgru_free_supported(16, src.shape[1], 80, c4["E"], c4["H"], c4["V"]))
         out[key] = {"sentences_per_s": 16 / dt, "ms_per_batch": dt * 1e3, "eval_batch": 16, "max_length": 80,
-                    "mean_hyp_len": sum(len(h) for h in hyp) / 16.0, "decoder_steps_run": steps,
+                    "mean_hyp_len": sum(len(h) for h in hyp) / 16.0, "decoder_steps_run": steps, "us_per_step": dt / steps * 1e6,
+                    "path": ("all steps in ONE launch: dec_fwd_persistent_kernel<true> forms the head, the logits of its vocabulary "
+                             "tiles and the arg-max itself (persist.hip)") if one_launch else
+                            "one captured graph of 8 decoder steps (11 launches per step), replayed",
                     "note": "beam search stops once every hypothesis has emitted EOS (V11.py:266-269)",
                     "roofline": decode_roofline(c4, lens, k, dt / steps)}
     m4.train(was)

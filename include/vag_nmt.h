@@ -380,6 +380,10 @@ typedef struct {
                                            * all gradients stay fp32.  Teacher-forced steps only; needs `derived` built with
                                            * with_fp16 and H % 8 == 0 */
     float margin, loss_w, init_split, p_emb, p_ctx, p_out;
+    int32_t loss_ring;                    /* R > 0: `losses` holds 4 + 4 R floats; the forward phase also stores {loss, loss_mt, loss_vse}
+                                           * of its n-th execution (n kept in the bit pattern of losses[3]) at losses[4 + 4 (n % R)]:
+                                           * a driver that replays captured graphs hands out results that stay valid for R steps
+                                           * without a copy launch per step.  0: losses is 4 floats */
 } vag_step_cfg;
 /* phases: bit 0 forward (losses[0..2] = loss, loss_mt, loss_vse), bit 1 backward down to the encoder states (final for
  * every gradient except the encoder's), bit 2 the encoder's backward.  A data-parallel driver all-reduces the first

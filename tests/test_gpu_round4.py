@@ -204,3 +204,23 @@ def test_tall_skinny_vocabulary_product_is_fp32_grade(M, N, K):
     bound = (x.abs().double().cpu() @ W.abs().double().cpu().t() + b.abs().double().cpu()) * 2.0 ** -21
     assert torch.isfinite(got).all()
     assert bool(((got - want).abs() <= bound).all()), float(((got - want).abs() / bound).max())
+
+
+def test_step_results_stay_valid_without_a_copy_launch():
+    """TrainStep.step hands out views of the step's slot in the device-side result ring (vag_step_cfg.loss_ring): they must
+    still hold that step's losses after later steps have run (eager first visits, a capture, replays, both shapes of a
+    mixed run), and the host's and the device's execution counts must agree (check())."""
+    m, ts = _driver(seed=5)
+    kept, seen = [], []
+    for i in range(9):
+        b = _batch(20 + i % 3, Ts=12 if i % 2 == 0 else 8)
+        out = ts.step(*b, teacher=(i % 4 != 3))
+        kept.append(out)
+        seen.append([float(x) for x in out])        # read at once: the reference's loop does loss.item() here (train.py)
+    torch.cuda.synchronize()
+    later = [[float(x) for x in out] for out in kept]
+    assert later == seen
+    assert len({tuple(s) for s in seen}) > 1          # (the steps did produce different losses)
+    assert kept[0][0].data_ptr() != kept[1][0].data_ptr()
+    ts.check()
+    assert ts.backend.f.executed == 9

@@ -163,7 +163,7 @@ int vag_inv_cnt_launch(const int64_t* tgt, int64_t B, int64_t Tt, float* inv_cnt
 // losses != NULL: also the weighted total of V11.py:166 (losses = {loss, loss_mt, loss_vse}).
 __global__ __launch_bounds__(256) void loss_mt_kernel(const float* __restrict__ nll, const float* __restrict__ inv_cnt,
                                                       int B, int Tt, float* __restrict__ loss, float* __restrict__ losses,
-                                                      float w_mt, float w_vse, int has_vse) {
+                                                      float w_mt, float w_vse, int has_vse, int ring) {
     __shared__ float sh[4];
     const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float acc = 0.f;
@@ -179,14 +179,23 @@ __global__ __launch_bounds__(256) void loss_mt_kernel(const float* __restrict__ 
         if (losses) {
             losses[1] = mt;
             if (!has_vse) losses[2] = 0.f;
-            losses[0] = w_mt * mt + (has_vse ? w_vse * losses[2] : 0.f);
+            const float tot = w_mt * mt + (has_vse ? w_vse * losses[2] : 0.f);
+            losses[0] = tot;
+            if (ring > 0) {                 // vag_step_cfg.loss_ring: the n-th execution's results stay readable for `ring` steps
+                const unsigned n = __float_as_uint(losses[3]);
+                float* r = losses + 4 + 4 * (n % (unsigned)ring);
+                r[0] = tot; r[1] = mt; r[2] = losses[2];
+                losses[3] = __uint_as_float(n + 1u);
+            }
         }
     }
 }
+static thread_local int g_loss_ring = 0;        // vag_train_step sets it for its call (vag_step_cfg.loss_ring)
+void vag_set_loss_ring(int r) { g_loss_ring = r; }
 int vag_loss_mt_launch(const float* nll, const float* inv_cnt, int64_t B, int64_t Tt, float* loss, hipStream_t s) {
     VAG_CHECK_ARG(nll && inv_cnt && loss && B > 0 && Tt > 0);
     hipLaunchKernelGGL(loss_mt_kernel, dim3(1), dim3(256), 0, s, nll, inv_cnt, (int)B, (int)Tt, loss, (float*)nullptr, 0.f,
-                       0.f, 0);
+                       0.f, 0, 0);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
@@ -194,7 +203,7 @@ int vag_loss_mt_mix_launch(const float* nll, const float* inv_cnt, int64_t B, in
                            float w_vse, int has_vse, hipStream_t s) {
     VAG_CHECK_ARG(nll && inv_cnt && losses && B > 0 && Tt > 0);
     hipLaunchKernelGGL(loss_mt_kernel, dim3(1), dim3(256), 0, s, nll, inv_cnt, (int)B, (int)Tt, (float*)nullptr, losses, w_mt,
-                       w_vse, has_vse);
+                       w_vse, has_vse, g_loss_ring);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

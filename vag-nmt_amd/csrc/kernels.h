@@ -119,6 +119,7 @@ int vag_lse_nll_launch(const float* logits, int64_t ldl, int64_t rows, int64_t V
 int vag_inv_cnt_launch(const int64_t* tgt, int64_t B, int64_t Tt, float* inv_cnt, hipStream_t s);
 int vag_loss_mt_launch(const float* nll, const float* inv_cnt, int64_t B, int64_t Tt, float* loss, hipStream_t s);
 // the same, writing losses[1] = loss_mt and the mixed total losses[0] = w_mt*loss_mt + w_vse*losses[2] (V11.py:166)
+void vag_set_loss_ring(int r);
 int vag_loss_mt_mix_launch(const float* nll, const float* inv_cnt, int64_t B, int64_t Tt, float* losses, float w_mt,
                            float w_vse, int has_vse, hipStream_t s);
 // in place: logits[r,j] = d_loss * inv_cnt[b]/B * w[tgt] * (softmax_j - [j==tgt]); pad columns [V,ldl) = 0

@@ -53,7 +53,7 @@ StepWs step_ws(float* p, const vag_step_cfg& c) {
 
 bool cfg_ok(const vag_step_cfg* c) {
     return c && c->B > 0 && c->Ts > 0 && c->Tt > 0 && c->Es > 0 && c->Et > 0 && c->H > 0 && c->V > 0 && c->Es % 4 == 0 &&
-           c->Et % 4 == 0 && c->H % 4 == 0 && c->ldl >= c->V && c->ldl % 4 == 0 &&
+           c->Et % 4 == 0 && c->H % 4 == 0 && c->ldl >= c->V && c->ldl % 4 == 0 && c->loss_ring >= 0 &&
            (!c->multimodal || (c->S > 0 && c->S % 4 == 0 && c->I > 0 && (c->attn_method == 0 || c->attn_method == 1) &&
                                c->rank_kind >= -1 && c->rank_kind <= 1));
 }
@@ -91,6 +91,10 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(uint64_t* rng, const
     }
 }
 
+struct LossRingScope {
+    explicit LossRingScope(int r) { vag_set_loss_ring(r); }
+    ~LossRingScope() { vag_set_loss_ring(0); }
+};
 struct PrezeroScope {       // the recurrence kernels of this call find their counters zeroed by the step's prologue launch
     PrezeroScope() { vag_persist_set_prezeroed(true); }
     ~PrezeroScope() { vag_persist_set_prezeroed(false); }
@@ -165,6 +169,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     if (vag_opt().head_chunk >= 0)      // vag_set_option("head_chunk", rows): rows per chunk (0 = never chunk); tests
         chunk = c.free_run ? 0 : vag_opt().head_chunk;
     DerivedScope scope(derived, c.storage == 1, chunk);
+    LossRingScope lring(c.loss_ring);
     PrezeroScope prezero;           // (a backward-only call relies on the forward call of the same step having run first)
     // forward and backward in one call: the chunked head finishes each chunk (d(logits) and its products) in the forward;
     // a backward called on its own (phases = 2 after an earlier phases = 1) recomputes the chunks instead

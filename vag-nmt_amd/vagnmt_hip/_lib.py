@@ -42,7 +42,7 @@ class StepCfg(C.Structure):
     """vag_step_cfg"""
     _fields_ = [(n, I64) for n in ("B", "Ts", "Tt", "Es", "Et", "H", "S", "I", "V", "ldl")] + \
                [(n, I32) for n in ("multimodal", "attn_method", "activation_vse", "rank_kind", "free_run", "storage")] + \
-               [(n, F) for n in ("margin", "loss_w", "init_split", "p_emb", "p_ctx", "p_out")]
+               [(n, F) for n in ("margin", "loss_w", "init_split", "p_emb", "p_ctx", "p_out")] + [("loss_ring", I32)]
 
 
 # name -> (restype, argtypes); mirrors include/vag_nmt.h declaration by declaration

@@ -55,6 +55,7 @@ def model_struct(model, grad=False):
 
 
 class FusedStep:
+    LOSS_RING = 256
     def __init__(self, model, criterion_mt, criterion_vse, storage="f32"):
         """storage: "f32", or "f16" = BASELINE configs[4]'s 2-byte storage: the recurrences' weights and the attention keys
         are kept as fp16 in HBM on teacher-forced steps (free-running steps of the same driver use fp32 storage)."""
@@ -83,7 +84,10 @@ class FusedStep:
         self.w = model_struct(model, grad=False)
         self.g = model_struct(model, grad=True)
         self.derived = torch.empty(L.lib().vag_derived_floats(self.H), dtype=torch.float32, device=self.dev)
-        self.losses = torch.zeros(4, dtype=torch.float32, device=self.dev)
+        # [loss, loss_mt, loss_vse, execution count] + a ring of the last LOSS_RING steps' results (vag_step_cfg.loss_ring): what a
+        # step hands out stays valid for that many further steps without a copy launch per step
+        self.losses = torch.zeros(4 + 4 * self.LOSS_RING, dtype=torch.float32, device=self.dev)
+        self.executed = 0             # forward phases executed so far (eager calls and graph replays; the device counts the same)
         self.ws = None
         self.cap = (0, 0, 0)          # (B*Ts, B*Tt, B) capacity of the static input buffers
         self.src = self.tgt = self.im = self.lens = None
@@ -107,6 +111,7 @@ class FusedStep:
         c.p_emb = float(m.encoder.dropout_emb) if train else 0.0
         c.p_ctx = float(m.encoder.dropout_ctx) if train else 0.0
         c.p_out = float(m.decoder.dropout_out) if train else 0.0
+        c.loss_ring = self.LOSS_RING
         return c
 
     def reserve(self, B, Ts, Tt):
@@ -164,6 +169,8 @@ class FusedStep:
         rng = None
         if train and max(c.p_emb, c.p_ctx, c.p_out) > 0:
             rng = dropout_rng(m, self.dev)
+        if (int(phases) & 1) and not (self.dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            self.executed += 1
         call("vag_train_step", C.byref(c), C.byref(self.w), C.byref(self.g), ptr(self.src, torch.int64),
              ptr(self.lens, torch.int32), ptr(self.tgt, torch.int64), ptr(self.im) if self.mm else None, ptr(self.vw),
              ptr(rng, torch.int64) if rng is not None else None, ptr(self.derived), ptr(self.ws), ptr(self.losses),

@@ -226,6 +226,12 @@ class TrainStep:
         n = lib().vag_persistent_timeouts() if self.fp.flat.is_cuda else 0
         sk = self.skipped_steps()
         new_sk, self._skipped_seen = sk - getattr(self, "_skipped_seen", 0), sk
+        f = getattr(self.backend, "f", None)
+        if f is not None and f.losses.is_cuda:
+            dev_n = int(f.losses[3:4].view(torch.int32).item())
+            if dev_n != (f.executed & 0x7fffffff):           # the result ring is addressed by this count on both sides
+                raise VagError("result ring out of step: the device executed %d forward phases, the host counted %d"
+                               % (dev_n, f.executed))
         if n != 0 or (raise_on_skip and new_sk != 0):
             raise VagError("%d optimiser step(s) skipped on the device (void gradient); persistent recurrence kernels: %d "
                            "waits gave up%s" % (new_sk, n, "; a GPU that is not this process's alone needs "
@@ -342,12 +348,15 @@ class _FusedBackend:
             ts.stats["captures"] += 1
         ts.stats["replays"] += 1
         ent[phases].replay()
+        if phases & 1:
+            f.executed += 1               # (a capture does not execute; FusedStep.run counts its eager executions itself)
 
     def outputs(self):
-        """(loss, loss_mt, loss_vse) of the step just enqueued, as a copy (the static result words are overwritten by the
-        next step; a caller may keep these tensors and read them later)."""
-        out = self.f.losses.clone()
-        return out[0], out[1], out[2]
+        """(loss, loss_mt, loss_vse) of the step just enqueued: views of that step's slot in the result ring the forward phase
+        writes (vag_step_cfg.loss_ring), valid for FusedStep.LOSS_RING further steps -- no copy launch per step."""
+        f = self.f
+        o = 4 + 4 * ((f.executed - 1) % f.LOSS_RING)
+        return f.losses[o], f.losses[o + 1], f.losses[o + 2]
 
     def after_optimizer(self):
         self.f.refresh_derived()
