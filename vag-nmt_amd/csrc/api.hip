@@ -1318,20 +1318,30 @@ extern "C" {
 // =====================================================================================================
 int vag_rank_loss_fwd(const float* im, const float* sv, int64_t B, int64_t S, float margin, int kind, float* scores,
                       float* G, float* loss, vag_stream_t stream) {
-    hipStream_t s = S_(stream);
-    VAG_CHECK_ARG(im && sv && scores && G && loss && B > 0 && S > 0);
-    VAG_TRY(linear_fwd(B, B, S, im, S, sv, nullptr, 0, scores, B, s));                             // im s^T  (:12)
-    return vag_rank_loss_launch(scores, B, margin, kind, G, loss, s);
+    return vag_rank_loss_fwd_impl(im, sv, B, S, margin, kind, scores, G, loss, nullptr, S_(stream));
 }
 int vag_rank_loss_bwd(const float* im, const float* sv, const float* G, const float* d_loss, int64_t B, int64_t S,
                       float* d_im, float* d_s, vag_stream_t stream) {
-    hipStream_t s = S_(stream);
-    VAG_CHECK_ARG(im && sv && G && d_loss && d_im && d_s && B > 0 && S > 0);
+    VAG_CHECK_ARG(d_loss != nullptr);
+    return vag_rank_loss_bwd_impl(im, sv, G, d_loss, B, S, d_im, d_s, S_(stream));
+}
+}  // extern "C"
+int vag_rank_loss_fwd_impl(const float* im, const float* sv, int64_t B, int64_t S, float margin, int kind, float* scores,
+                           float* G, float* loss, const float* g_scale, hipStream_t s) {
+    VAG_CHECK_ARG(im && sv && scores && G && loss && B > 0 && S > 0);
+    VAG_TRY(linear_fwd(B, B, S, im, S, sv, nullptr, 0, scores, B, s));                             // im s^T  (:12)
+    return vag_rank_loss_launch(scores, B, margin, kind, G, loss, s, g_scale);
+}
+int vag_rank_loss_bwd_impl(const float* im, const float* sv, const float* G, const float* d_loss, int64_t B, int64_t S,
+                           float* d_im, float* d_s, hipStream_t s) {
+    VAG_CHECK_ARG(im && sv && G && d_im && d_s && B > 0 && S > 0);
     VAG_TRY(gemm_nn(B, S, B, G, B, sv, S, 0.f, d_im, S, s));                                       // d_im = G s
     VAG_TRY(vag_gemm_launch(B, S, B, 1.f, G, 1, B, im, S, 1, 0.f, d_s, S, nullptr, 0, s));        // d_s  = G^T im
+    if (!d_loss) return VAG_OK;                                                                    // (G came pre-multiplied)
     VAG_TRY(vag_scale_by_dev_launch(d_im, B * S, d_loss, s));
     return vag_scale_by_dev_launch(d_s, B * S, d_loss, s);
 }
+extern "C" {
 
 // batch assembly from a device-resident corpus (preprocessing.py:308-384)
 int vag_gather_rows_i64(const int64_t* in, int64_t ld, const int64_t* idx, int64_t rows, int64_t w, int64_t* out,

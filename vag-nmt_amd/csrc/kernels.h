@@ -137,7 +137,8 @@ int vag_l2norm_fwd_launch(const float* y, int64_t B, int64_t S, float* nrm, floa
 // dy = l2norm backward of d_out, then (act) * (1 - y^2); written to dy (may alias d_out)
 int vag_l2norm_bwd_launch(const float* y, const float* nrm, const float* out, const float* d_out, int64_t B, int64_t S,
                           int act, float* dy, hipStream_t s);
-int vag_rank_loss_launch(const float* scores, int64_t B, float margin, int kind, float* G, float* loss, hipStream_t s);
+int vag_rank_loss_launch(const float* scores, int64_t B, float margin, int kind, float* G, float* loss, hipStream_t s,
+                         const float* g_scale = nullptr);
 int vag_retrieval_rank_launch(const float* scores, int64_t N, int* ranks, hipStream_t s);
 // x[i] *= *scalar
 int vag_scale_by_dev_launch(float* x, int64_t n, const float* scalar, hipStream_t s);
@@ -210,6 +211,11 @@ const float* vag_get_derived_override();
 bool vag_get_store16();
 void vag_set_head_chunk(int64_t rows);
 void vag_set_head_fuse(const vag_head_g* g, const float* d_loss, float* dt);
+// the fused step's ranking loss: G pre-multiplied by a device scalar in the forward (g_scale), no scaling pass in the backward (d_loss NULL)
+int vag_rank_loss_fwd_impl(const float* im, const float* sv, int64_t B, int64_t S, float margin, int kind, float* scores,
+                           float* G, float* loss, const float* g_scale, hipStream_t s);
+int vag_rank_loss_bwd_impl(const float* im, const float* sv, const float* G, const float* d_loss, int64_t B, int64_t S,
+                           float* d_im, float* d_s, hipStream_t s);
 int vag_dec_init_bwd_impl(const float* mask, const float* xmix, const float* h0, float split, const float* W, float* d_h0,
                           int64_t B, int64_t Ts, int64_t C, int64_t H, float* d_enc, int accumulate_enc, float* d_ctx,
                           int accumulate_ctx, float* g_W, float* g_b, float* scratch, hipStream_t s);

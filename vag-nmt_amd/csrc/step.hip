@@ -206,7 +206,8 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
             VAG_TRY(vag_img_proj_l2_fwd(k.ctx, w.txt_w, w.txt_b, B, C, S, c.activation_vse, k.y_txt, k.nrm_txt, k.txt_emb,
                                         stream));
             if (has_vse)
-                VAG_TRY(vag_rank_loss_fwd(k.im_emb, k.txt_emb, B, S, c.margin, c.rank_kind, k.rscores, k.G, losses + 2, stream));
+                VAG_TRY(vag_rank_loss_fwd_impl(k.im_emb, k.txt_emb, B, S, c.margin, c.rank_kind, k.rscores, k.G, losses + 2,
+                                               k.consts + 1, s));      // (G times the loss weight: no scaling pass in the backward)
         }
         VAG_TRY(vag_dec_init_fwd(k.enc, k.mask, mm ? k.ctx : nullptr, mm ? c.init_split : 0.f, w.ini_w, w.ini_b, B, Ts, C, H,
                                  k.xmix, h0, stream));                                                  // V11.py:118
@@ -250,7 +251,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
         }
         if (mm) {
             if (has_vse) {
-                VAG_TRY(vag_rank_loss_bwd(k.im_emb, k.txt_emb, k.G, k.consts + 1, B, S, k.d_im, k.d_txt, stream));
+                VAG_TRY(vag_rank_loss_bwd_impl(k.im_emb, k.txt_emb, k.G, nullptr, B, S, k.d_im, k.d_txt, s));
             } else {
                 VAG_TRY(vag_axpy_launch(0.f, k.d_im, k.d_im, B * S, 2, s));
                 VAG_TRY(vag_axpy_launch(0.f, k.d_txt, k.d_txt, B * S, 2, s));

@@ -63,8 +63,12 @@ int vag_l2norm_bwd_launch(const float* y, const float* nrm, const float* out, co
 
 // loss = sum_{i != j} max(0, m - d_j + S_ij)  [+ sum_{i != j} max(0, m - d_i + S_ij) when kind == 0]
 // G = d loss / d S.  Single 1024-thread block (B is a mini-batch size); column/row hinge counts go through LDS.
+// g_scale (optional, one device float): G is stored multiplied by it -- the fused step hands in the loss weight, its backward then
+// needs no scaling pass over d(im) / d(s).
 __global__ __launch_bounds__(1024) void rank_loss_kernel(const float* __restrict__ S, int B, float margin, int kind,
-                                                         float* __restrict__ G, float* __restrict__ loss) {
+                                                         float* __restrict__ G, float* __restrict__ loss,
+                                                         const float* __restrict__ g_scale) {
+    const float gs = g_scale ? g_scale[0] : 1.f;
     extern __shared__ float sh[];        // [B] diag-grad accumulators, then 16 floats of reduction space
     float* dacc = sh;
     float* red = sh + B;
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(1024) void rank_loss_kernel(const float* __restrict
             const float ci = margin - S[(int64_t)i * B + i] + sij;  // PairwiseRankingLoss.py:18
             if (ci > 0.f) { part += ci; g += 1.f; atomicAdd(&dacc[i], -1.f); }
         }
-        G[e] = g;
+        G[e] = g * gs;
     }
     part = wave_sum(part);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
@@ -93,12 +97,13 @@ __global__ __launch_bounds__(1024) void rank_loss_kernel(const float* __restrict
         for (int w = 0; w < 16; ++w) t += red[w];
         loss[0] = t;
     }
-    for (int i = threadIdx.x; i < B; i += 1024) G[(int64_t)i * B + i] = dacc[i];
+    for (int i = threadIdx.x; i < B; i += 1024) G[(int64_t)i * B + i] = dacc[i] * gs;
 }
-int vag_rank_loss_launch(const float* scores, int64_t B, float margin, int kind, float* G, float* loss, hipStream_t s) {
+int vag_rank_loss_launch(const float* scores, int64_t B, float margin, int kind, float* G, float* loss, hipStream_t s,
+                         const float* g_scale) {
     VAG_CHECK_ARG(scores && G && loss && B > 0 && B <= 8192 && (kind == 0 || kind == 1));
     hipLaunchKernelGGL(rank_loss_kernel, dim3(1), dim3(1024), (size_t)(B + 16) * sizeof(float), s, scores, (int)B, margin,
-                       kind, G, loss);
+                       kind, G, loss, g_scale);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
