@@ -1122,6 +1122,33 @@ __device__ __forceinline__ void skinny_plain_body(const SkinnyArgs& a, float* re
     if (a.act == VAG_ACT_TANH) v = vag_tanh(v);
     a.out[(int64_t)em * a.ldo + ej] = v;
 }
+// MT x NT 16 x 16 tiles per workgroup (round 4, for M >= 128 rows: configs[4]'s per-step products have 256).  A 16 x 16 tile
+// requests 16 rows of each operand; at M = 256, N = 3072, K = 1024 that is 295 MB per product, and the launch runs at the
+// chip's aggregate request rate (~6-8 TB/s), not at anything the product itself needs: 2 x 4 tiles request 98 MB.
+// red: WAVES x MT NT KB.  No row gather (the decoding-step forms keep the 16 x 16 body).
+template <int WAVES, int MT, int NT, int U, bool WH>
+__device__ __forceinline__ void skinny_plain_body_mn(const SkinnyArgs& a, float* red, int bx, int by) {
+    const int lane = threadIdx.x & 63;
+    const int r = skinny_ldrow(lane), g = skinny_ldseg(lane);
+    const int m0 = by * 16 * MT, nb = bx * 16 * NT;
+    const float* ap[MT];
+    const float* wp[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) ap[i] = a.A + (int64_t)min(m0 + 16 * i + r, a.M - 1) * a.lda + skinny_koff<WH>(g);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wp[j] = skinny_wptr<WH>(a.W, min(nb + 16 * j + r, a.N - 1), a.ldw, skinny_koff<WH>(g));
+    skinny_mma_any<WAVES, MT, NT, U, WH>(ap, wp, a.K, red, a.a_scale);
+    for (int o = threadIdx.x; o < 256 * MT * NT; o += WAVES * 64) {
+        const int tile = o >> 8, erow = (o >> 4) & 15, ecol = o & 15;
+        const int em = m0 + 16 * (tile / NT) + erow, ej = nb + 16 * (tile % NT) + ecol;
+        if (em >= a.M || ej >= a.N) continue;
+        float v = skinny_sum1<WAVES, MT * NT>(red, tile, erow, ecol);
+        if (a.bias) v += a.bias[ej];
+        if (a.addend) v += a.addend[(int64_t)em * a.ldadd + ej];
+        if (a.act == VAG_ACT_TANH) v = vag_tanh(v);
+        a.out[(int64_t)em * a.ldo + ej] = v;
+    }
+}
 // WH: the W operand is stored as fp16 (batched launches, blockIdx.z, are fp32-only)
 template <int WAVES, bool WH = false>
 __global__ __launch_bounds__(WAVES * 64) void skinny_plain_kernel(SkinnyArgs a) {
@@ -1235,12 +1262,15 @@ struct DotArgs {
 template <int MODE, int DS_WAVES, bool S16 = false>
 __global__ __launch_bounds__(64 * DS_WAVES) void attn_dot_side_kernel(DotArgs d, SkinnyArgs a, int tiles_x) {
     __shared__ __attribute__((aligned(16))) float red[DS_WAVES * 64 * 4];
-    const int id = blockIdx.x;
-    if (id >= d.nscore) {
-        const int t = id - d.nscore;
+    // the side product's blocks come FIRST in the grid: each is one long K loop, the reduction's blocks are many and short -- behind
+    // them (round 2-3 order) the side product was the kernel's tail: 35.5 / 42.6 us at configs[4] whatever the reduction cost
+    const int nside = gridDim.x - d.nscore;
+    if ((int)blockIdx.x < nside) {
+        const int t = blockIdx.x;
         skinny_plain_body<DS_WAVES, (MODE == 1 ? 6 : 4), S16>(a, red, t % tiles_x, t / tiles_x);
         return;
     }
+    const int id = blockIdx.x - nside;
     const int lane = threadIdx.x & 63;
     const int s = (id % d.gx) * DS_WAVES + (threadIdx.x >> 6);
     if (s >= d.Ts) return;
@@ -1268,6 +1298,82 @@ __global__ __launch_bounds__(64 * DS_WAVES) void attn_dot_side_kernel(DotArgs d,
         d.out[n * d.Ts + s] = acc;
     }
 }
+// Round 4: the same two reductions with the row-constant operands in REGISTERS.  The kernel above re-reads q (and v) for every
+// position -- 16 + 16 bytes out of L1 per 8 streamed bytes in the 2-byte mode: the L1, not HBM, set its pace (2.4 / 3.0 TB/s on
+// configs[4]'s 84 / 126 MB per step, against 4.1-5.6 TB/s of the neighbouring streaming kernels).  Here a wave owns positions
+// s0 + wave, + DS_WAVES, ... of ONE query row and keeps its 8 NJ-float share of q (and v) -- elements 512 j + 8 lane + e -- for all
+// of them; a position is NJ 16-byte (fp16 keys) or 2 NJ 16-byte (fp32) loads per lane and nothing else from memory, two positions
+// in flight.  W = 512 NJ, NJ in {2, 3, 4, 6} (C = 2H and 3H at H = 512 / 1024); other widths keep the kernel above.
+template <bool S16> __device__ __forceinline__ void ld8_any(const float* base, int64_t elem, float (&o)[8]) {
+    if (S16) {
+        const uint4 p = *reinterpret_cast<const uint4*>(reinterpret_cast<const vag_half*>(base) + elem);
+        o[0] = h16_lo(p.x); o[1] = h16_hi(p.x); o[2] = h16_lo(p.y); o[3] = h16_hi(p.y);
+        o[4] = h16_lo(p.z); o[5] = h16_hi(p.z); o[6] = h16_lo(p.w); o[7] = h16_hi(p.w);
+    } else {
+        const float4 a = *reinterpret_cast<const float4*>(base + elem), b = *reinterpret_cast<const float4*>(base + elem + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    }
+}
+// WIDE: the side product on 2 x 4 (forward, 8 waves) / 2 x 2 (backward, 16 waves) tiles per workgroup (M >= 128 rows)
+template <int MODE, int DS_WAVES, bool S16, int NJ, bool WIDE>
+__global__ __launch_bounds__(64 * DS_WAVES) void attn_dot_side_reg_kernel(DotArgs d, SkinnyArgs a, int tiles_x) {
+    constexpr int SMT = WIDE ? 2 : 1, SNT = WIDE ? (MODE == 0 ? 4 : 2) : 1;
+    __shared__ __attribute__((aligned(16))) float red[DS_WAVES * 64 * 4 * SMT * SNT];
+    // the side product's blocks come first in the grid (each is one long K loop, the reduction's blocks are many and short).
+    // At configs[4] the side product IS the kernel's duration: 35.5 / 42.6 us whatever the reduction costs, until its tiles grew
+    const int nside = gridDim.x - d.nscore;
+    if ((int)blockIdx.x < nside) {
+        const int t = blockIdx.x;
+        if (WIDE) skinny_plain_body_mn<DS_WAVES, SMT, SNT, (MODE == 1 ? 4 : 4), S16>(a, red, t % tiles_x, t / tiles_x);
+        else skinny_plain_body<DS_WAVES, (MODE == 1 ? 6 : 4), S16>(a, red, t % tiles_x, t / tiles_x);
+        return;
+    }
+    const int id = blockIdx.x - nside;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n = id / d.gx;
+    const int ppb = (d.Ts + d.gx - 1) / d.gx;                       // positions of this block: [s0, s1)
+    const int s0 = (id % d.gx) * ppb, s1 = min(d.Ts, s0 + ppb);
+    const float* qr = d.q + n * d.ldq + 8 * lane;
+    float q[NJ][8], v[MODE == 0 ? NJ : 1][8];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        ld8_any<false>(qr, 512 * j, q[j]);
+        if (MODE == 0) ld8_any<false>(d.v + 8 * lane, 512 * j, v[j]);
+    }
+    auto dot = [&](const float (&x)[NJ][8]) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += MODE == 0 ? v[j][e] * vag_tanh(x[j][e] + q[j][e]) : x[j][e] * q[j][e];
+        return wave_sum(acc);
+    };
+    auto put = [&](int s, float acc) {
+        if (lane == 0) {
+            if (d.addend) acc += d.addend[n * d.Ts + s];
+            if (MODE == 0 && d.mask && d.mask[n * d.Ts + s] == 0.f) acc = -INFINITY;
+            d.out[n * d.Ts + s] = acc;
+        }
+    };
+    const int64_t xbase = n * d.Ts * (int64_t)d.W + 8 * lane;
+    int s = s0 + wave;
+    for (; s + DS_WAVES < s1; s += 2 * DS_WAVES) {                   // two positions in flight
+        float x0[NJ][8], x1[NJ][8];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            ld8_any<S16>(d.x, xbase + (int64_t)s * d.W + 512 * j, x0[j]);
+            ld8_any<S16>(d.x, xbase + (int64_t)(s + DS_WAVES) * d.W + 512 * j, x1[j]);
+        }
+        put(s, dot(x0));
+        put(s + DS_WAVES, dot(x1));
+    }
+    if (s < s1) {
+        float x0[NJ][8];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) ld8_any<S16>(d.x, xbase + (int64_t)s * d.W + 512 * j, x0[j]);
+        put(s, dot(x0));
+    }
+}
 // mode 1: out (N,Ts) = x[n,s,:] . q[n,:] + addend;  mode 0: out = v . tanh(x[n,s,:] + q[n,:]), -inf where mask (N,Ts) == 0.
 // One source row per query row (training: N = B).  Side product in the same grid:
 // P (M,Np) = A (M,K) Wt^T + pbias + padd;  A row stride lda, Wt (Np,K) row stride ldw, padd (M,Np) contiguous, P row stride ldp.
@@ -1289,6 +1395,34 @@ int vag_attn_dot_side_launch(int mode, const float* x, const float* q, int64_t l
     a.bias = pbias; a.addend = padd; a.ldadd = Np; a.out = P; a.ldo = ldp; a.act = VAG_ACT_NONE;
     a.a_scale = mode == 1 ? 4096.f : 1.f;           // backward: the riding product's A operand is a gate gradient
     const int tiles_x = (int)cdiv64(Np, 16), tiles_y = (int)cdiv64(M, 16);
+    if (W % 512 == 0 && (W == 1024 || W == 1536 || W == 2048 || W == 3072) && aligned16(v ? v : q) && (!s16 || K % 8 == 0) &&
+        vag_opt().attn_dot_reg != 0) {
+        // row-constant operands in registers (attn_dot_side_reg_kernel): a block = positions [g ppb, (g + 1) ppb) of one row
+        int64_t gx = cdiv64(512, N);
+        const int64_t gmax = Ts / (2 * DS_WAVES) > 1 ? Ts / (2 * DS_WAVES) : 1;
+        if (gx > gmax) gx = gmax;
+        d.gx = (int)gx;
+        d.nscore = (int)(gx * N);
+        const bool wide = M >= 128;                 // the side product on 32 x 64 / 32 x 32 tiles (skinny_plain_body_mn)
+        const int stx = wide ? (int)cdiv64(Np, mode == 0 ? 64 : 32) : tiles_x, sty = wide ? (int)cdiv64(M, 32) : tiles_y;
+        const dim3 grid2((unsigned)(d.nscore + stx * sty));
+#define VAG_DOTREG(MODE_, WV, S16_, NJ_)                                                                                        \
+        { if (wide) hipLaunchKernelGGL((attn_dot_side_reg_kernel<MODE_, WV, S16_, NJ_, true>), grid2, dim3(64 * WV), 0, stream, d, a, stx); \
+          else hipLaunchKernelGGL((attn_dot_side_reg_kernel<MODE_, WV, S16_, NJ_, false>), grid2, dim3(64 * WV), 0, stream, d, a, stx); }
+#define VAG_DOTREG_NJ(MODE_, WV, S16_)                                                      \
+        switch (W / 512) {                                                                  \
+            case 2: VAG_DOTREG(MODE_, WV, S16_, 2); break;                                  \
+            case 3: VAG_DOTREG(MODE_, WV, S16_, 3); break;                                  \
+            case 4: VAG_DOTREG(MODE_, WV, S16_, 4); break;                                  \
+            default: VAG_DOTREG(MODE_, WV, S16_, 6); break;                                 \
+        }
+        if (s16) { if (mode == 0) { VAG_DOTREG_NJ(0, 8, true) } else { VAG_DOTREG_NJ(1, 16, true) } }
+        else { if (mode == 0) { VAG_DOTREG_NJ(0, 8, false) } else { VAG_DOTREG_NJ(1, 16, false) } }
+#undef VAG_DOTREG_NJ
+#undef VAG_DOTREG
+        VAG_LAUNCH_CHECK();
+        return VAG_OK;
+    }
     const dim3 grid((unsigned)(d.nscore + tiles_x * tiles_y));
     if (s16) {
         VAG_CHECK_ARG(K % 8 == 0 && W % 4 == 0);
@@ -1557,7 +1691,20 @@ static bool skinny_ok(const float* A, int64_t lda, const float* W, int64_t ldw, 
     return aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && K % 4 == 0 && K >= 4;
 }
 
+// 32 x 64 outputs per workgroup (skinny_plain_body_mn): wide batches
+template <int WAVES, bool WH>
+__global__ __launch_bounds__(WAVES * 64) void skinny_plain_mn_kernel(SkinnyArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[WAVES * 64 * 4 * 8];
+    skinny_plain_body_mn<WAVES, 2, 4, 4, WH>(a, red, blockIdx.x, blockIdx.y);
+}
 static void skinny_plain_go(const SkinnyArgs& a, hipStream_t stream, bool w16 = false) {
+    // wide batches (configs[4]: 256 rows): 32 x 64 tiles request a third of the operand bytes; as long as >= 256 workgroups remain
+    if (a.M >= 128 && a.K > 256 && a.K <= 1024 && !a.row_idx && !a.gather_out && cdiv64(a.N, 64) * cdiv64(a.M, 32) >= 256) {
+        dim3 gw((unsigned)cdiv64(a.N, 64), (unsigned)cdiv64(a.M, 32), 1);
+        if (w16) hipLaunchKernelGGL((skinny_plain_mn_kernel<8, true>), gw, dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((skinny_plain_mn_kernel<8, false>), gw, dim3(512), 0, stream, a);
+        return;
+    }
     dim3 grid((unsigned)cdiv64(a.N, 16), (unsigned)cdiv64(a.M, 16), 1);
     if (w16) {
         if (a.K <= 256) hipLaunchKernelGGL((skinny_plain_kernel<4, true>), grid, dim3(256), 0, stream, a);
