@@ -224,3 +224,45 @@ def test_step_results_stay_valid_without_a_copy_launch():
     assert kept[0][0].data_ptr() != kept[1][0].data_ptr()
     ts.check()
     assert ts.backend.f.executed == 9
+
+
+@pytest.mark.parametrize("B,H,storage", [(130, 512, "f32"), (256, 1024, "f16"), (136, 1024, "f32")])
+def test_wide_batch_launch_chain_kernels_match_the_round3_kernels(B, H, storage):
+    """Round 4 kernels of the per-step launch chains at wide batches (what configs[4] runs): the score / d-alpha reductions with
+    the row-constant operands in registers, their riding products and the query product on 32 x 64 / 32 x 32 tiles.  Against the
+    round-2/3 kernels (option attn_dot_reg = 0 keeps them for the reductions and their riding products) on the same step:
+    loss and every gradient; B not a multiple of 32, fp32 and 2-byte storage."""
+    from machine_translation_vision.losses import PairwiseRankingLoss
+    from machine_translation_vision.models import NMT_AttentionImagine_Seq2Seq_Beam_V11
+    from vagnmt_hip import _lib as L
+    from vagnmt_hip.trainer import TrainStep
+    Vs, Vt, I, E, S, Ts, Tt = 120, 150, 64, 64, 48, 16, 6
+    res = []
+    for reg in (1, 0):
+        assert L.lib().vag_set_option(b"attn_dot_reg", reg) == 0
+        try:
+            torch.manual_seed(3)
+            m = NMT_AttentionImagine_Seq2Seq_Beam_V11(Vs, Vt, I, E, E, H, S, 0.99, tied_emb=True).cuda()
+            vw = torch.ones(Vt, device="cuda")
+            vw[0] = 0
+            ts = TrainStep(m, torch.nn.NLLLoss(weight=vw, reduction="none"), PairwiseRankingLoss(0.1), use_graph=False, pad_src=1,
+                           storage=storage)
+            m.eval()
+            g = torch.Generator().manual_seed(9)
+            src = torch.randint(4, Vs, (B, Ts), generator=g).cuda()
+            tgt = torch.randint(4, Vt, (B, Tt), generator=g)
+            tgt[:, -1] = 3
+            im = torch.randn(B, I, generator=g).abs().cuda()
+            lt = torch.full((B,), Ts, dtype=torch.int32, device="cuda")
+            ts.backend.run(src, lt, tgt.cuda(), im, True, 7)
+            torch.cuda.synchronize()
+            res.append(([float(x) for x in ts.backend.outputs()],
+                        {n: p._vag_grad.detach().cpu().clone() for n, p in m.named_parameters()}))
+        finally:
+            L.lib().vag_set_option(b"attn_dot_reg", 1)
+    (la, ga), (lb, gb) = res
+    tol = 2e-5 if storage == "f32" else 2e-3
+    assert np.allclose(la, lb, rtol=tol, atol=tol), (la, lb)
+    for n in ga:
+        err = (ga[n] - gb[n]).abs().max().item()
+        assert err <= (3e-5 if storage == "f32" else 5e-3) * max(gb[n].abs().max().item(), 1e-3), (n, err)
