@@ -35,7 +35,8 @@ def test_shapes_the_one_launch_form_takes():
     assert ok(64, 40, 40, 256, 512, 9391) == 0
 
 
-@pytest.mark.parametrize("B,Ts,Tt,Vt,p_out", [(64, 40, 7, 9391, 0.0), (37, 23, 9, 1003, 0.3), (5, 3, 4, 50, 0.0), (16, 43, 3, 4096, 0.5)])
+@pytest.mark.parametrize("B,Ts,Tt,Vt,p_out", [(64, 40, 7, 9391, 0.0), (37, 23, 9, 1003, 0.3), (5, 3, 4, 50, 0.0), (16, 43, 3, 4096, 0.5),
+                                              (3, 2, 1, 40, 0.0), (33, 17, 2, 20011, 0.0)])
 def test_operator_equals_the_launch_chain(B, Ts, Tt, Vt, p_out):
     """vag_cgru_attn_decode_free_fwd against vag_cgru_attn_decode_seq_fwd(free_run = 1) on the same inputs: the chosen tokens
     are identical, every output and every tensor saved for the backward pass agrees to fp32 rounding."""

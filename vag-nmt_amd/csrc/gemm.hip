@@ -1698,8 +1698,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_plain_mn_kernel(SkinnyArgs 
     skinny_plain_body_mn<WAVES, 2, 4, 4, WH>(a, red, blockIdx.x, blockIdx.y);
 }
 static void skinny_plain_go(const SkinnyArgs& a, hipStream_t stream, bool w16 = false) {
-    // wide batches (configs[4]: 256 rows): 32 x 64 tiles request a third of the operand bytes; as long as >= 256 workgroups remain
-    if (a.M >= 128 && a.K > 256 && a.K <= 1024 && !a.row_idx && !a.gather_out && cdiv64(a.N, 64) * cdiv64(a.M, 32) >= 256) {
+    // wide batches (configs[4]: 256 rows): 32 x 64 tiles request a third of the operand bytes; as long as >= 192 workgroups remain (beam decoding has 192 rows)
+    if (a.M >= 128 && a.K > 256 && a.K <= 1024 && !a.row_idx && !a.gather_out && cdiv64(a.N, 64) * cdiv64(a.M, 32) >= 192) {
         dim3 gw((unsigned)cdiv64(a.N, 64), (unsigned)cdiv64(a.M, 32), 1);
         if (w16) hipLaunchKernelGGL((skinny_plain_mn_kernel<8, true>), gw, dim3(512), 0, stream, a);
         else hipLaunchKernelGGL((skinny_plain_mn_kernel<8, false>), gw, dim3(512), 0, stream, a);
@@ -2002,9 +2002,9 @@ int vag_gru_step_launch(const GruStepArgs& a, int nz, hipStream_t stream, bool w
         VAG_LAUNCH_CHECK();
         return VAG_OK;
     }
-    // wide batches: two row tiles per workgroup (half the W re-reads) as long as >= 256 workgroups remain
+    // wide batches: two row tiles per workgroup (half the W re-reads) as long as >= 192 workgroups remain (beam decoding has 192 rows)
     constexpr int opt_wide = 1;
-    if (opt_wide && a.M >= 128 && a.K > 256 && (int64_t)grid.x * cdiv64(a.M, 32) * nz >= 256) {
+    if (opt_wide && a.M >= 128 && a.K > 256 && (int64_t)grid.x * cdiv64(a.M, 32) * nz >= 192) {
         const dim3 gw(grid.x, (unsigned)cdiv64(a.M, 32), grid.z);
         if (w16) hipLaunchKernelGGL((gru_step_kernel<8, true, 2>), gw, dim3(512), 0, stream, a);
         else hipLaunchKernelGGL((gru_step_kernel<8, false, 2>), gw, dim3(512), 0, stream, a);

@@ -946,7 +946,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
         }
         if (threadIdx.x < 4) hb_s[threadIdx.x] = a.hb1[4 * i + threadIdx.x] + a.hb2[4 * i + threadIdx.x] + a.hb3[4 * i + threadIdx.x];
         if (threadIdx.x < 16) {
-            const int tk = (int)a.tok[min(m0 + (int)threadIdx.x, B - 1)];
+            const int tk = min(max((int)a.tok[min(m0 + (int)threadIdx.x, B - 1)], 0), a.V - 1);     // (a table row, whatever the caller wrote)
             tok_s[threadIdx.x] = tk;
             e3 = *reinterpret_cast<const float4*>(a.embw3 + (int64_t)tk * E + 4 * i);
         }
@@ -1148,10 +1148,10 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
                     unsigned long long b = 0ull;
 #pragma unroll
                     for (int x = 0; x < 8; ++x) { const unsigned long long c = cb_s[fr * 8 + x]; b = c > b ? c : b; }
-                    const int tk = (int)(0xffffffffu - (unsigned)(b & 0xffffffffull));
+                    const int tk = min(max((int)(0xffffffffu - (unsigned)(b & 0xffffffffull)), 0), V - 1);
                     tok_s[fr] = tk;
                     if (i == 0 && m0 + fr < B) a.tok[(int64_t)t * B + m0 + fr] = tk;             // V11.py:157
-                    e3 = *reinterpret_cast<const float4*>(a.embw3 + (int64_t)min(tk, V - 1) * E + 4 * i);
+                    e3 = *reinterpret_cast<const float4*>(a.embw3 + (int64_t)tk * E + 4 * i);
                 }
                 __syncthreads();
             }
