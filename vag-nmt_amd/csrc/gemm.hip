@@ -1314,10 +1314,10 @@ template <bool S16> __device__ __forceinline__ void ld8_any(const float* base, i
         o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
     }
 }
-// WIDE: the side product on 2 x 4 (forward, 8 waves) / 2 x 2 (backward, 16 waves) tiles per workgroup (M >= 128 rows)
+// WIDE: the side product on 2 x 4 tiles per workgroup (M >= 128 rows; 8 waves)
 template <int MODE, int DS_WAVES, bool S16, int NJ, bool WIDE>
 __global__ __launch_bounds__(64 * DS_WAVES) void attn_dot_side_reg_kernel(DotArgs d, SkinnyArgs a, int tiles_x) {
-    constexpr int SMT = WIDE ? 2 : 1, SNT = WIDE ? (MODE == 0 ? 4 : 2) : 1;
+    constexpr int SMT = WIDE ? 2 : 1, SNT = WIDE ? 4 : 1;
     __shared__ __attribute__((aligned(16))) float red[DS_WAVES * 64 * 4 * SMT * SNT];
     // the side product's blocks come first in the grid (each is one long K loop, the reduction's blocks are many and short).
     // At configs[4] the side product IS the kernel's duration: 35.5 / 42.6 us whatever the reduction costs, until its tiles grew
@@ -1398,13 +1398,14 @@ int vag_attn_dot_side_launch(int mode, const float* x, const float* q, int64_t l
     if (W % 512 == 0 && (W == 1024 || W == 1536 || W == 2048 || W == 3072) && aligned16(v ? v : q) && (!s16 || K % 8 == 0) &&
         vag_opt().attn_dot_reg != 0) {
         // row-constant operands in registers (attn_dot_side_reg_kernel): a block = positions [g ppb, (g + 1) ppb) of one row
+        const bool wide = M >= 128;                 // the side product on 32 x 64 tiles (skinny_plain_body_mn), 8 waves either way
+        const int WV = (mode == 0 || wide) ? 8 : 16;
         int64_t gx = cdiv64(512, N);
-        const int64_t gmax = Ts / (2 * DS_WAVES) > 1 ? Ts / (2 * DS_WAVES) : 1;
+        const int64_t gmax = Ts / (2 * WV) > 1 ? Ts / (2 * WV) : 1;
         if (gx > gmax) gx = gmax;
         d.gx = (int)gx;
         d.nscore = (int)(gx * N);
-        const bool wide = M >= 128;                 // the side product on 32 x 64 / 32 x 32 tiles (skinny_plain_body_mn)
-        const int stx = wide ? (int)cdiv64(Np, mode == 0 ? 64 : 32) : tiles_x, sty = wide ? (int)cdiv64(M, 32) : tiles_y;
+        const int stx = wide ? (int)cdiv64(Np, 64) : tiles_x, sty = wide ? (int)cdiv64(M, 32) : tiles_y;
         const dim3 grid2((unsigned)(d.nscore + stx * sty));
 #define VAG_DOTREG(MODE_, WV, S16_, NJ_)                                                                                        \
         { if (wide) hipLaunchKernelGGL((attn_dot_side_reg_kernel<MODE_, WV, S16_, NJ_, true>), grid2, dim3(64 * WV), 0, stream, d, a, stx); \
@@ -1416,8 +1417,8 @@ int vag_attn_dot_side_launch(int mode, const float* x, const float* q, int64_t l
             case 4: VAG_DOTREG(MODE_, WV, S16_, 4); break;                                  \
             default: VAG_DOTREG(MODE_, WV, S16_, 6); break;                                 \
         }
-        if (s16) { if (mode == 0) { VAG_DOTREG_NJ(0, 8, true) } else { VAG_DOTREG_NJ(1, 16, true) } }
-        else { if (mode == 0) { VAG_DOTREG_NJ(0, 8, false) } else { VAG_DOTREG_NJ(1, 16, false) } }
+        if (s16) { if (mode == 0) { VAG_DOTREG_NJ(0, 8, true) } else if (wide) { VAG_DOTREG_NJ(1, 8, true) } else { VAG_DOTREG_NJ(1, 16, true) } }
+        else { if (mode == 0) { VAG_DOTREG_NJ(0, 8, false) } else if (wide) { VAG_DOTREG_NJ(1, 8, false) } else { VAG_DOTREG_NJ(1, 16, false) } }
 #undef VAG_DOTREG_NJ
 #undef VAG_DOTREG
         VAG_LAUNCH_CHECK();
