@@ -846,9 +846,6 @@ __device__ __forceinline__ void wait_count(gu32* c, unsigned want_per_shard, uns
 constexpr int DEC_WGS = 64;          // workgroups per row tile
 constexpr int DEC_U = 8;             // hidden units per workgroup (H = 512)
 
-#ifndef VAG_FREE_RING
-#define VAG_FREE_RING 4
-#endif
 constexpr int DEC_E = 4 * DEC_WGS;   // free-running form: embedding width, 4 columns of the head's hidden layer per workgroup
 __device__ __forceinline__ unsigned long long cand_key(float v, int idx) {       // larger value first, then smaller index
     const unsigned u = __builtin_bit_cast(unsigned, v);
@@ -1034,13 +1031,23 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
                 // ---- head of step t - 1 (NMT_Decoder.py:137-141): own four columns of tanh(W1 h2 + W2 c + W3 e + b), dropout
                 const int ts = t - 1;
                 const int V = a.V, NVT = (V + 15) >> 4, NJ = i < NVT ? (NVT - i + 63) >> 6 : 0;      // own tiles: i, i + 64, ...
-                const int mytiles = NJ > wave ? (NJ - wave + 7) >> 3 : 0;          // this wave's tiles: i + 64 (wave + 8 n)
-                constexpr int RING = VAG_FREE_RING;
-                float4 wr[RING][2];                                                // out.weight rows, RING k-steps in flight
-                if (mytiles > 0) {
-                    const float* wp = a.out_w + (int64_t)min(16 * (i + 64 * wave) + fr, V - 1) * E + 8 * fg;
+                // Tiles to waves, in passes of four k-steps: tile i + 64 (wave + 8 n) whole for n < NJ / 8 (two passes each); of the
+                // NJ % 8 tiles left over, each goes to a PAIR of waves by halves of K when there are at most three (one pass each; the
+                // odd wave's partial tile crosses through LDS), else whole to one wave.  (At V = 9391: 9-10 tiles, 3 passes per wave
+                // at most instead of 4.)
+                const int nfull = NJ >> 3, rext = NJ & 7;
+                const bool splitx = rext >= 1 && rext <= 3;
+                const int xj = splitx ? (wave < 2 * rext ? 8 * nfull + (wave >> 1) : -1) : (wave < rext ? 8 * nfull + wave : -1);
+                const int npass = 2 * nfull + (xj < 0 ? 0 : (splitx ? 1 : 2));
+                auto pass_ptr = [&](int g, int u) -> const float* {               // weight rows of pass g, k-step u of it (this lane's 32 bytes)
+                    const int j = g < 2 * nfull ? wave + 8 * (g >> 1) : xj;
+                    const int k0 = g < 2 * nfull ? 4 * (g & 1) : (splitx ? 4 * (wave & 1) : 4 * (g - 2 * nfull));
+                    return a.out_w + (int64_t)min(16 * (i + 64 * j) + fr, V - 1) * E + 32 * (k0 + u) + 8 * fg;
+                };
+                float4 wr[4][2];                                                   // out.weight rows, four k-steps in flight
+                if (npass > 0) {
 #pragma unroll
-                    for (int u = 0; u < RING; ++u) { wr[u][0] = *reinterpret_cast<const float4*>(wp + 32 * u); wr[u][1] = *reinterpret_cast<const float4*>(wp + 32 * u + 4); }
+                    for (int u = 0; u < 4; ++u) { const float* wp = pass_ptr(0, u); wr[u][0] = *reinterpret_cast<const float4*>(wp); wr[u][1] = *reinterpret_cast<const float4*>(wp + 4); }
                 }
                 if (tx < 16) {
                     const float4 cw = *reinterpret_cast<const float4*>(cw_s + 4 * fr);
@@ -1073,40 +1080,48 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
                 __syncthreads();
                 unsigned long long best = 0ull;                                   // batch row fr
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                for (int g = 0; g < (8 / RING) * mytiles; ++g) {                  // RING k-steps per pass
+                float* part_s = gi_s;                                              // [3][64 lanes][4]: partial tiles of the odd waves (gi_s, hp_s are idle)
+                auto finish_tile = [&](int j, const f32x4& t4) {                  // words v0 .. v0 + 3 of batch row fr
+                    const int v0 = 16 * (i + 64 * j) + 4 * fg;
+                    float lv[4] = {t4[0], t4[1], t4[2], t4[3]};
 #pragma unroll
-                    for (int u = 0; u < RING; ++u) {
-                        const int pp = RING * g + u, ks = pp & 7;
+                    for (int q = 0; q < 4; ++q)
+                        if (v0 + q < V) {
+                            lv[q] += a.out_b[v0 + q];
+                            const unsigned long long key = cand_key(lv[q], v0 + q);
+                            best = key > best ? key : best;
+                        }
+                    if (a.logits && m0 + fr < B) {
+                        float* lp = a.logits + ((int64_t)ts * B + m0 + fr) * a.ldl + v0;
+                        if (v0 + 3 < V) *reinterpret_cast<float4*>(lp) = make_float4(lv[0], lv[1], lv[2], lv[3]);
+                        else
+                            for (int q = 0; q < 4; ++q) if (v0 + q < V) lp[q] = lv[q];
+                    }
+                };
+                for (int g = 0; g < npass; ++g) {                                 // four k-steps per pass
+                    const int k0 = g < 2 * nfull ? 4 * (g & 1) : (splitx ? 4 * (wave & 1) : 4 * (g - 2 * nfull));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
                         const float4 ca = wr[u][0], cb = wr[u][1];
-                        if (pp + RING < 8 * mytiles) {
-                            const int vt = i + 64 * (wave + 8 * ((pp + RING) >> 3));
-                            const float* wp = a.out_w + (int64_t)min(16 * vt + fr, V - 1) * E + 32 * ((pp + RING) & 7) + 8 * fg;
+                        if (g + 1 < npass) {
+                            const float* wp = pass_ptr(g + 1, u);
                             wr[u][0] = *reinterpret_cast<const float4*>(wp); wr[u][1] = *reinterpret_cast<const float4*>(wp + 4);
                         }
                         bf16x8 aw[3], bw[3];
                         split8(ca, cb, aw);
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) bw[pl] = tm_s[(pl * 8 + ks) * 64 + lane];
+                        for (int pl = 0; pl < 3; ++pl) bw[pl] = tm_s[(pl * 8 + k0 + u) * 64 + lane];
                         acc = mma6(aw, bw, acc);
                     }
-                    if ((g & (8 / RING - 1)) == 8 / RING - 1) {                    // a tile is complete: words v0 .. v0 + 3 of batch row fr
-                        const int v0 = 16 * (i + 64 * (wave + 8 * (g / (8 / RING)))) + 4 * fg;
-                        float lv[4] = {acc[0], acc[1], acc[2], acc[3]};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (v0 + q < V) {
-                                lv[q] += a.out_b[v0 + q];
-                                const unsigned long long key = cand_key(lv[q], v0 + q);
-                                best = key > best ? key : best;
-                            }
-                        if (a.logits && m0 + fr < B) {
-                            float* lp = a.logits + ((int64_t)ts * B + m0 + fr) * a.ldl + v0;
-                            if (v0 + 3 < V) *reinterpret_cast<float4*>(lp) = make_float4(lv[0], lv[1], lv[2], lv[3]);
-                            else
-                                for (int q = 0; q < 4; ++q) if (v0 + q < V) lp[q] = lv[q];
-                        }
+                    if (g < 2 * nfull ? (g & 1) : (!splitx && g == npass - 1)) {   // a whole tile is complete
+                        finish_tile(g < 2 * nfull ? wave + 8 * (g >> 1) : xj, acc);
                         acc = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
+                }
+                if (splitx) {                                                      // (uniform over the workgroup)
+                    if (xj >= 0 && (wave & 1)) *reinterpret_cast<f32x4*>(part_s + ((wave >> 1) * 64 + lane) * 4) = acc;
+                    __syncthreads();
+                    if (xj >= 0 && !(wave & 1)) finish_tile(xj, acc + *reinterpret_cast<const f32x4*>(part_s + ((wave >> 1) * 64 + lane) * 4));
                 }
                 VAG_STAMP(10);
                 {   // the four row groups of the wave hold the same batch rows: combine them, lanes 0..15 publish the wave's best
