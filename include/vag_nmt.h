@@ -318,6 +318,16 @@ int vag_beam_step_dev(float* logp, int64_t ldl, float* nll, int64_t* beam, int32
 /* Final selection (:315-324) after `steps` calls of vag_beam_step (steps < max_len after an early stop): follow the
  * back-pointers, force EOS in the last row, length-normalise, pick the best hypothesis.
  * out (B,max_len) int64 (0 past the written rows), best_score (B). */
+/* Beam step on RAW logits (round 4): the vocabulary product of vag_head_logits_step leaves, per row, vag_head_logits_parts_count
+ * (max, sum exp) pairs -- the pieces of the row's log-sum-exp -- in `parts` (count, N, 2); the expansion kernel normalises the
+ * candidates it reads with them, so no pass over the (B k, V) logits is needed between product and selection (V11.py:276,297).
+ * count = 0: the shape is not taken (use vag_head_logp_step + vag_beam_step_dev).  scratch of vag_head_logits_step: 2 N E floats. */
+int64_t vag_head_logits_parts_count(vag_head_w w, int64_t N, int64_t E, int64_t V);
+int vag_head_logits_step(const float* h2, const float* c, const float* e, vag_head_w w, int64_t N, int64_t E, int64_t H,
+                         int64_t V, float* logits, int64_t ldl, float* parts, float* scratch, vag_stream_t stream);
+int vag_beam_step_logits_dev(float* logits, int64_t ldl, const float* parts, int64_t nparts, float* nll, int64_t* beam,
+                             int32_t* di_state, int64_t max_len, const float* h_in, float* h_out, int64_t* tok_out, int64_t B,
+                             int64_t k, int64_t V, int64_t H, int32_t* n_alive, void* scratch, vag_stream_t stream);
 int vag_beam_finish(const float* nll, const int64_t* beam, int64_t max_len, int64_t steps, int64_t B, int64_t k,
                     int64_t* out, float* best_score, vag_stream_t stream);
 

@@ -266,3 +266,27 @@ def test_wide_batch_launch_chain_kernels_match_the_round3_kernels(B, H, storage)
     for n in ga:
         err = (ga[n] - gb[n]).abs().max().item()
         assert err <= (3e-5 if storage == "f32" else 5e-3) * max(gb[n].abs().max().item(), 1e-3), (n, err)
+
+
+def test_beam_search_on_raw_logits_equals_the_log_softmax_path():
+    """Beam search whose expansion kernel normalises RAW logits with the log-sum-exp pieces the vocabulary product's epilogue
+    leaves (vag_head_logits_step / vag_beam_step_logits_dev; B k = 192 rows, V = 4100: the shape class of configs[3]) against
+    the path that materialises log-probabilities first: same hypotheses, same scores; finished hypotheses included."""
+    from test_gpu_edge_and_full import make
+    from vagnmt_hip import ops
+    B, k, Ts, V, L = 16, 12, 9, 4100, 14
+    lens = sorted([int(x) for x in torch.randint(1, Ts + 1, (B,), generator=torch.Generator().manual_seed(2))], reverse=True)
+    lens[0] = Ts
+    m, src, _, im = make(80, V, 64, 256, 64, 48, B, Ts, 3, lens, seed=4)
+    with torch.no_grad():
+        m.decoder.out.bias[3] += 6.0                  # some hypotheses finish early
+    mg = m.cuda().eval()
+    assert ops.head_logits_parts_count(mg.decoder.head_params(), B * k, 256, V) == (V + 63) // 64
+    res = {}
+    for raw in (True, False):
+        mg.decode_raw_logits = raw
+        hyp = [[int(t) for t in h] for h in mg.beamsearch_decode(src.cuda(), lens, im.cuda(), k, L)]
+        res[raw] = (hyp, mg.last_beam_scores.cpu().numpy().copy())
+    assert res[True][0] == res[False][0]
+    assert np.allclose(res[True][1], res[False][1], rtol=1e-5, atol=1e-5)
+    assert any(len(h) < L - 1 for h in res[True][0])

@@ -1203,6 +1203,29 @@ int vag_head_logp_step(const float* h2, const float* c, const float* e, vag_head
     return VAG_OK;
 }
 
+// The same step for beam search without the normalising pass: raw logits plus, per row, the pieces of its log-sum-exp written by
+// the vocabulary product's epilogue (gemm.hip, TallArgs::parts); vag_beam_step_logits_dev normalises on the fly.  The count is 0
+// for shapes the tall-skinny kernel does not take (N = B k <= 96 rows, V < 4096, E % 256 != 0): use vag_head_logp_step there.
+int64_t vag_head_logits_parts_count(vag_head_w w, int64_t N, int64_t E, int64_t V) {
+    if (!w.out_w || N <= 0 || E <= 0 || V <= 0) return 0;
+    alignas(16) static const float dummy[4] = {0.f, 0.f, 0.f, 0.f};
+    return vag_logits_parts_count(N, V, E, dummy, E, w.out_w, E);
+}
+int vag_head_logits_step(const float* h2, const float* c, const float* e, vag_head_w w, int64_t N, int64_t E, int64_t H,
+                         int64_t V, float* logits, int64_t ldl, float* parts, float* scratch, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(h2 && c && e && logits && parts && scratch && N > 0 && E % 4 == 0 && H % 4 == 0 && V > 0 && ldl >= V);
+    VAG_CHECK_ARG(w.w1 && w.b1 && w.w2 && w.b2 && w.w3 && w.b3 && w.out_w && w.out_b && aligned16(scratch));
+    VAG_CHECK_ARG(N <= 256 && aligned16(h2) && aligned16(c) && aligned16(e) && aligned16(w.w1) && aligned16(w.w2) && aligned16(w.w3));
+    float* tmid = scratch + N * E;   // (N,E)
+    const float* A3[3] = {h2, c, e};
+    const float* W3[3] = {w.w1, w.w2, w.w3};
+    const float* B3[3] = {w.b1, w.b2, w.b3};
+    const int64_t C = 2 * H, ld3[3] = {H, C, E}, K3[3] = {H, C, E};
+    VAG_TRY(vag_skinny3_launch(N, E, A3, ld3, W3, ld3, K3, B3, tmid, E, VAG_ACT_TANH, nullptr, VAG_DROP_DEC_OUT, 0.f, 0, s));
+    return vag_logits_parts_launch(N, V, E, tmid, E, w.out_w, E, w.out_b, logits, ldl, parts, s);
+}
+
 // =====================================================================================================
 // shared-space projections
 // =====================================================================================================
@@ -1412,6 +1435,13 @@ int vag_beam_step_dev(float* logp, int64_t ldl, float* nll, int64_t* beam, int32
     VAG_CHECK_ARG(di_state != nullptr);
     return vag_beam_step_launch(logp, ldl, nll, beam, 0, di_state, max_len, h_in, h_out, tok_out, B, k, V, H, n_alive, scratch,
                                 S_(stream));
+}
+int vag_beam_step_logits_dev(float* logits, int64_t ldl, const float* parts, int64_t nparts, float* nll, int64_t* beam,
+                             int32_t* di_state, int64_t max_len, const float* h_in, float* h_out, int64_t* tok_out, int64_t B,
+                             int64_t k, int64_t V, int64_t H, int32_t* n_alive, void* scratch, vag_stream_t stream) {
+    VAG_CHECK_ARG(di_state != nullptr && parts != nullptr && nparts > 0);
+    return vag_beam_step_launch(logits, ldl, nll, beam, 0, di_state, max_len, h_in, h_out, tok_out, B, k, V, H, n_alive, scratch,
+                                S_(stream), parts, nparts);
 }
 int vag_beam_finish(const float* nll, const int64_t* beam, int64_t max_len, int64_t steps, int64_t B, int64_t k, int64_t* out,
                     float* best_score, vag_stream_t stream) {

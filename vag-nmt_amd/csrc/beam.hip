@@ -169,9 +169,29 @@ __global__ __launch_bounds__(256) void beam_stage1_kernel(const float* __restric
                                                           const float* __restrict__ nll_in, const int64_t* __restrict__ beam,
                                                           const int32_t* di_state, int di_host, int max_len, int B,
                                                           int k_in, int k, int V, float* __restrict__ cval,
-                                                          int* __restrict__ cidx, int32_t* __restrict__ n_alive) {
+                                                          int* __restrict__ cidx, int32_t* __restrict__ n_alive,
+                                                          const float* __restrict__ parts, int nparts) {
     const int di = di_state ? __atomic_load_n(di_state, __ATOMIC_RELAXED) : di_host;
     if (di >= max_len || (di_state && di < 1)) return;                          // replayed past the end: nothing to do
+    // parts != NULL: `logp` holds raw logits and parts (nparts, rows, 2) the (max, sum exp) pieces of every row's log-sum-exp
+    // (the vocabulary product's epilogue wrote them: gemm.hip, TallArgs::parts).  A chunk of 2048 candidates touches at most
+    // ceil(2048 / V) + 1 rows; waves 0..3 combine the pieces of the first four of them (V >= 683 whenever pieces exist).
+    __shared__ float lse_s[4];
+    const int jfirst = (int)(((int64_t)blockIdx.x * CHUNK) / V);
+    if (parts) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int j = min(jfirst + wave, k_in - 1);
+        const int64_t rows = (int64_t)B * k_in;                    // pieces are laid out [piece][row]
+        const float* pr = parts + ((int64_t)blockIdx.y * k_in + j) * 2;
+        float m = -INFINITY;
+        for (int x = lane; x < nparts; x += 64) m = fmaxf(m, pr[2 * x * rows]);
+        m = wave_max(m);
+        float sm = 0.f;
+        for (int x = lane; x < nparts; x += 64) sm += pr[2 * x * rows + 1] * __expf(pr[2 * x * rows] - m);
+        sm = wave_sum(sm);
+        if (lane == 0) lse_s[wave] = m + __logf(sm);
+        __syncthreads();
+    }
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *n_alive = 0;   // stage 2 (next launch) counts into it
     const int penal = di > 0;
     const float* nll = di > 0 ? nll_in : nullptr;
@@ -192,6 +212,7 @@ __global__ __launch_bounds__(256) void beam_stage1_kernel(const float* __restric
         const int w = fc - j * V;
         const int64_t n = (int64_t)b * k_in + j;
         float lp = logp[n * ldl + w];
+        if (parts) lp -= lse_s[min(j - jfirst, 3)];
         const int64_t pt = penal ? prev_tok[n] : (int64_t)-1;
         const float base = nll ? nll[n] : 0.f;
         if (pt == EOS) lp = (w == EOS) ? 0.f : NEG_PEN;           // V11.py:291-294
@@ -325,8 +346,9 @@ int64_t vag_beam_scratch_bytes_impl(int64_t B, int64_t k, int64_t V) {
 
 int vag_beam_step_launch(float* logp, int64_t ldl, float* nll, int64_t* beam, int64_t di, int32_t* di_state,
                          int64_t max_len, const float* h_in, float* h_out, int64_t* tok_out, int64_t B, int64_t k,
-                         int64_t V, int64_t H, int32_t* n_alive, void* scratch, hipStream_t s) {
+                         int64_t V, int64_t H, int32_t* n_alive, void* scratch, hipStream_t s, const float* parts, int64_t nparts) {
     VAG_CHECK_ARG(logp && nll && beam && h_in && h_out && n_alive && scratch);
+    VAG_CHECK_ARG(!parts || (nparts > 0 && V >= CHUNK));         // (a chunk then spans at most two rows)
     VAG_CHECK_ARG(B > 0 && k > 0 && k <= 64 && V > 0 && H > 0 && ldl >= V && max_len > 0);
     VAG_CHECK_ARG(di_state || (di >= 0 && di < max_len));
     const int k_in = (!di_state && di == 0) ? 1 : (int)k;
@@ -336,7 +358,7 @@ int vag_beam_step_launch(float* logp, int64_t ldl, float* nll, int64_t* beam, in
     float* cval = reinterpret_cast<float*>(scratch);
     int* cidx = reinterpret_cast<int*>(cval + B * cdiv64(k * V, CHUNK) * k);
     hipLaunchKernelGGL(beam_stage1_kernel, dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, s, logp, ldl, nll, beam,
-                       di_state, (int)di, (int)max_len, (int)B, k_in, (int)k, (int)V, cval, cidx, n_alive);
+                       di_state, (int)di, (int)max_len, (int)B, k_in, (int)k, (int)V, cval, cidx, n_alive, parts, (int)nparts);
     VAG_LAUNCH_CHECK();
     hipLaunchKernelGGL(beam_stage2_kernel, dim3((unsigned)B), dim3(256), 0, s, cval, cidx, chunks, k_in, (int)k, (int)V,
                        (int)H, nll, beam, di_state, (int)di, (int)max_len, (int)B, h_in, h_out, tok_out, n_alive);

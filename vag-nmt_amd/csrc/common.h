@@ -57,6 +57,19 @@ __device__ __forceinline__ float quad_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
     return v;
 }
+// the same over each 32-lane half of the wave (lanes 0-31 / 32-63): without the last exchange
+template <bool MAX>
+__device__ __forceinline__ float half_allreduce(float v) {
+#define VAG_DPP_ROR(N) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (N), 0xf, 0xf, false))
+    { const float o = VAG_DPP_ROR(8); v = MAX ? fmaxf(v, o) : v + o; }
+    { const float o = VAG_DPP_ROR(4); v = MAX ? fmaxf(v, o) : v + o; }
+    { const float o = VAG_DPP_ROR(2); v = MAX ? fmaxf(v, o) : v + o; }
+    { const float o = VAG_DPP_ROR(1); v = MAX ? fmaxf(v, o) : v + o; }
+#undef VAG_DPP_ROR
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return MAX ? fmaxf(a, b) : a + b;
+}
 __device__ __forceinline__ float wave_sum(float v) { return wave_allreduce<false>(v); }
 __device__ __forceinline__ float wave_max(float v) { return wave_allreduce<true>(v); }
 // tanh / sigmoid on the v_exp_f32 path; absolute error ~1e-7, saturates cleanly at +-1 / 0,1.
@@ -144,6 +157,9 @@ void vag_gemm_set_planes(int planes);
 int vag_gemm_launch_planes(int planes, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
                            const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc, hipStream_t stream,
                            int a_bf16 = 0);      // planes 3: bf16x6 (default), 2: bf16x3 (2-byte storage mode), calling thread
+int64_t vag_logits_parts_count(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw);
+int vag_logits_parts_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
+                            const float* bias, float* out, int64_t ldo, float* parts, hipStream_t stream);
 int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
                       const float* bias, const float* addend, int64_t ldadd, float* out, int64_t ldo, int act,
                       hipStream_t stream, bool w16 = false);      // w16: W is stored as fp16 (2-byte storage mode)

@@ -1746,6 +1746,8 @@ int vag_skinny_gather_launch(int64_t M, int64_t N, int64_t K, const float* table
 // training step's logits product, gemm.hip above).  Requested bytes: N/64 x (M + 64) x K x 4 (38 MB instead of 230).
 struct TallArgs {
     const float* A; const float* W; const float* bias; float* out;
+    float* parts;              // NULL, or (gridDim.x, M, 2): per row the (max, sum of exp(. - max)) of this workgroup's 64 columns -- the
+                               // pieces of the row's log-sum-exp, so that decoding needs no pass over the logits to normalise them
     int64_t lda, ldw, ldo;
     int M, N, K, RT, KS;       // RT = ceil(M / 32) row tiles, KS = k splits: RT * KS <= 8 waves
 };
@@ -1867,14 +1869,50 @@ __global__ __launch_bounds__(512, 2) void skinny_tall_kernel(TallArgs a) {
                     for (int r = 0; r < 16; ++r) acc[j][r] += red[(((wave + o) * 2 + j) * 16 + r) * 64 + lane];
         }
     }
+    if (a.parts) __syncthreads();      // the epilogue below transposes through the LDS the other waves' MFMAs may still be reading
     if (!active || ks != 0) return;
+    const int row0 = rt * 32 + 4 * (lane >> 5);
+    float bvj[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + j * 32 + (lane & 31);
+        bvj[j] = (a.bias && col < a.N) ? a.bias[col] : 0.f;
         if (col >= a.N) continue;
-        const float bv = a.bias ? a.bias[col] : 0.f;
-        const int row0 = rt * 32 + 4 * (lane >> 5);
-        gemm_epilogue16(acc[j], a.out + (int64_t)row0 * a.ldo + col, a.ldo, a.M - row0, 1.f, 0.f, bv, 0, false);
+        gemm_epilogue16(acc[j], a.out + (int64_t)row0 * a.ldo + col, a.ldo, a.M - row0, 1.f, 0.f, bvj[j], 0, false);
+    }
+    if (a.parts) {
+        // A row's 64 values sit in the 32 lanes of one half of the wave.  Through LDS (the W planes are done with; 4.2 KB per wave
+        // beyond the k-split reduction area, row stride 33) so that lane l owns row l & 31, columns 16 (l >> 5) .. + 15 of a 32-column
+        // half, serially; the two column halves and the two lane halves are merged as (max, sum) pairs.  Layout [workgroup][row]:
+        // a wave's 32 results are 256 contiguous bytes.
+        float* T = reinterpret_cast<float*>(tall_smem) + 16384 + wave * (32 * 33);
+        const int rl = lane & 31, ch = lane >> 5;
+        float m = -INFINITY, sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool cok = n0 + j * 32 + rl < a.N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * ch) * 33 + rl] = cok ? acc[j][r] + bvj[j] : -INFINITY;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            float v[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = T[rl * 33 + 16 * ch + e];
+            float mj = v[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mj = fmaxf(mj, v[e]);
+            float sj = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sj += v[e] == -INFINITY ? 0.f : __expf(v[e] - mj);
+            const float mn = fmaxf(m, mj);
+            sm = (m == -INFINITY ? 0.f : sm * __expf(m - mn)) + (mj == -INFINITY ? 0.f : sj * __expf(mj - mn));
+            m = mn;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        const float mo = __shfl_xor(m, 32, 64), so = __shfl_xor(sm, 32, 64);
+        const float mn = fmaxf(m, mo);
+        sm = (m == -INFINITY ? 0.f : sm * __expf(m - mn)) + (mo == -INFINITY ? 0.f : so * __expf(mo - mn));
+        const int row = rt * 32 + rl;
+        if (ch == 0 && row < a.M) *reinterpret_cast<float2*>(a.parts + ((int64_t)blockIdx.x * a.M + row) * 2) = make_float2(mn, sm);
     }
 }
 static bool skinny_tall_ok(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw) {
@@ -1884,9 +1922,9 @@ static bool skinny_tall_ok(int64_t M, int64_t N, int64_t K, const float* A, int6
            aligned16(W);
 }
 static int skinny_tall_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
-                              const float* bias, float* out, int64_t ldo, hipStream_t stream) {
+                              const float* bias, float* out, int64_t ldo, hipStream_t stream, float* parts = nullptr) {
     TallArgs a;
-    a.A = A; a.W = W; a.bias = bias; a.out = out; a.lda = lda; a.ldw = ldw; a.ldo = ldo;
+    a.A = A; a.W = W; a.bias = bias; a.out = out; a.parts = parts; a.lda = lda; a.ldw = ldw; a.ldo = ldo;
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.RT = (int)cdiv64(M, 32);
     a.KS = a.RT <= 2 ? 4 : (a.RT <= 4 ? 2 : 1);     // k range per wave and chunk: a multiple of 64 (K % 256 == 0, skinny_tall_ok)
@@ -1901,6 +1939,17 @@ static int skinny_tall_launch(int64_t M, int64_t N, int64_t K, const float* A, i
     hipLaunchKernelGGL(skinny_tall_kernel, dim3((unsigned)cdiv64(N, 64)), dim3(512), TALL_LDS_BYTES, stream, a);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
+}
+
+// The vocabulary product of a decoding step with the pieces of every row's log-sum-exp (TallArgs::parts): number of pieces per
+// row (= workgroups), or 0 when the tall-skinny kernel does not take the shape (the caller then normalises with lse_nll_kernel).
+int64_t vag_logits_parts_count(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw) {
+    return vag_opt().gemm_f32mfma == 0 && skinny_tall_ok(M, N, K, A, lda, W, ldw) ? cdiv64(N, 64) : 0;
+}
+int vag_logits_parts_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
+                            const float* bias, float* out, int64_t ldo, float* parts, hipStream_t stream) {
+    VAG_CHECK_ARG(A && W && out && parts && vag_logits_parts_count(M, N, K, A, lda, W, ldw) > 0);
+    return skinny_tall_launch(M, N, K, A, lda, W, ldw, bias, out, ldo, stream, parts);
 }
 
 int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,

@@ -200,7 +200,8 @@ int vag_dec_free_persistent_launch(const float* pe, const float* mask, const flo
 int64_t vag_beam_scratch_bytes_impl(int64_t B, int64_t k, int64_t V);
 int vag_beam_step_launch(float* logp, int64_t ldl, float* nll, int64_t* beam, int64_t di, int32_t* di_state,
                          int64_t max_len, const float* h_in, float* h_out, int64_t* tok_out, int64_t B, int64_t k,
-                         int64_t V, int64_t H, int32_t* n_alive, void* scratch, hipStream_t s);
+                         int64_t V, int64_t H, int32_t* n_alive, void* scratch, hipStream_t s, const float* parts = nullptr,
+                         int64_t nparts = 0);
 int vag_beam_finish_launch(const float* nll, const int64_t* beam, int64_t max_len, int64_t steps, int64_t B, int64_t k,
                            int64_t* out, float* best, hipStream_t s);
 

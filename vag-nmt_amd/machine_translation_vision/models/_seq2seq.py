@@ -87,6 +87,7 @@ class Seq2SeqBase(nn.Module):
     DECODE_CHUNK = 8
     decode_graph = True
     decode_persistent = True      # greedy decoding in one launch where the shape allows it (ops.greedy_decode)
+    decode_raw_logits = True      # beam search: expansion on raw logits + log-sum-exp pieces (no normalising pass) where available
 
     def _decode_state(self, kind, enc, mask, k, max_length):
         """Static buffers (+ captured graph, filled in by the caller) for one decode shape; refreshed per call."""
@@ -96,7 +97,8 @@ class Seq2SeqBase(nn.Module):
         dev = enc.device
         dp, hp, emb = dec.dec_params(), dec.head_params(), dec.embedding.weight
         Tp = (Ts + 7) // 8 * 8
-        key = (kind, B, k, Tp, max_length) + tuple(t.data_ptr() for t in list(dp) + list(hp) + [emb, dec.attn.attn_e.weight])
+        key = (kind, B, k, Tp, max_length, self.decode_raw_logits) + \
+            tuple(t.data_ptr() for t in list(dp) + list(hp) + [emb, dec.attn.attn_e.weight])
         cache = self.__dict__.setdefault("_decode_cache", {})
         st = cache.get(key)
         if st is None:
@@ -213,9 +215,18 @@ class Seq2SeqBase(nn.Module):
             if st["graph"] is None:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
+                # raw logits + the pieces of their rows' log-sum-exp where the vocabulary product provides them: the beam
+                # expansion normalises on the fly, no pass over the (B k, V) logits in between
+                nparts = ops.head_logits_parts_count(hp, B * k, emb.shape[1], V) if self.decode_raw_logits else 0
                 with _lib.capture(g):
                     for _ in range(CH):
                         h2, c, e, _ = ops.decode_step(enc_s, pe, mask_s, k, st["tok"], st["h"], emb, dp, prep)
+                        if nparts > 0:
+                            logits, parts = ops.head_logits_step(h2, c, e, hp, nparts)
+                            call("vag_beam_step_logits_dev", ptr(logits), logits.shape[1], ptr(parts), nparts, ptr(nll),
+                                 ptr(beam, torch.int64), ptr(st["di"], torch.int32), max_length, ptr(h2), ptr(st["h"]),
+                                 ptr(st["tok"], torch.int64), B, k, V, H, ptr(n_alive, torch.int32), scratch.data_ptr(), stream())
+                            continue
                         logp, _ = ops.head_logp_step(h2, c, e, hp)
                         call("vag_beam_step_dev", ptr(logp), logp.shape[1], ptr(nll), ptr(beam, torch.int64),
                              ptr(st["di"], torch.int32), max_length, ptr(h2), ptr(st["h"]), ptr(st["tok"], torch.int64),

@@ -102,6 +102,9 @@ PROTOS = {
     "vag_beam_scratch_bytes": (I64, [I64, I64, I64, I64]),
     "vag_beam_step": (I32, [P, I64, P, P, I64, I64, P, P, I64, I64, I64, I64, P, P, P]),
     "vag_beam_step_dev": (I32, [P, I64, P, P, P, I64, P, P, P, I64, I64, I64, I64, P, P, P]),
+    "vag_head_logits_parts_count": (I64, [HeadW, I64, I64, I64]),
+    "vag_head_logits_step": (I32, [P, P, P, HeadW, I64, I64, I64, I64, P, I64, P, P, P]),
+    "vag_beam_step_logits_dev": (I32, [P, I64, P, I64, P, P, P, I64, P, P, P, I64, I64, I64, I64, P, P, P]),
     "vag_beam_finish": (I32, [P, P, I64, I64, I64, I64, P, P, P]),
     "vag_clip_adam_flat": (I32, [P, P, P, P, I64, I32, C.POINTER(I64), C.POINTER(F), C.POINTER(F), F, F, F, F, F, I32, P,
                                  P, P, P, P]),

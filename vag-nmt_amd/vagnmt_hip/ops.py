@@ -511,6 +511,26 @@ def greedy_decode(enc, pe, mask, h0, emb, dec, head, steps, sos):
     return tok[1:]
 
 
+def head_logits_parts_count(head, N, E, V):
+    """Pieces per row that head_logits_step leaves of every row's log-sum-exp (0: shape not taken, use head_logp_step)."""
+    return int(L.lib().vag_head_logits_parts_count(_head_w(head), N, E, V))
+
+
+def head_logits_step(h2, c, e, head, nparts):
+    """Raw logits (N, ldl) of one decoding step and the (N, nparts, 2) pieces of their rows' log-sum-exp (beam search on raw
+    logits: vag_beam_step_logits_dev)."""
+    N, H = h2.shape
+    E = e.shape[1]
+    V = head[7].shape[0]
+    ldl = (V + 3) // 4 * 4
+    logits = _f32(N, ldl, like=h2)
+    parts = _f32(nparts, N, 2, like=h2)
+    scratch = _f32(2 * N * E, like=h2)
+    call("vag_head_logits_step", ptr(h2), ptr(c), ptr(e), _head_w(head), N, E, H, V, ptr(logits), ldl, ptr(parts), ptr(scratch),
+         stream())
+    return logits, parts
+
+
 def head_logp_step(h2, c, e, head, want_argmax=False, argmax_out=None):
     """argmax_out: optional (N,) int64 HIP tensor the arg-max tokens are written into (greedy decode hands in a row of its token
     chunk, which saves a copy launch per step)."""
