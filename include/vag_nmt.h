@@ -318,6 +318,21 @@ int vag_beam_step_dev(float* logp, int64_t ldl, float* nll, int64_t* beam, int32
 /* Final selection (:315-324) after `steps` calls of vag_beam_step (steps < max_len after an early stop): follow the
  * back-pointers, force EOS in the last row, length-normalise, pick the best hypothesis.
  * out (B,max_len) int64 (0 past the written rows), best_score (B). */
+/* The decoding step in its hoisted form (round 4): the keys as gru_2 sees them and the head's share of them are projected once per
+ * decode call (vag_cgru_decode_keys: keys = [(W_ih2 W_c2h) enc (B,Ts,3H) | enc W2^T (B,Ts,E)], vag_cgru_decode_keys_floats floats;
+ * prep from vag_cgru_prepare, w2 = head W2 (E,C)); a step is then four launches and returns cw (N,E) = W2 c instead of the
+ * context c, which vag_head_logp_step_h / vag_head_logits_step_h take in its place.  N <= 256 hypotheses, rows_per_src divides N.
+ * scratch: vag_cgru_step_scratch_floats. */
+int64_t vag_cgru_decode_keys_floats(int64_t B, int64_t Ts, int64_t E, int64_t H);
+int vag_cgru_decode_keys(const float* enc, const float* prep, const float* w2, int64_t B, int64_t Ts, int64_t E, int64_t H,
+                         float* keys, vag_stream_t stream);
+int vag_cgru_attn_decode_step_h(const float* pe, const float* mask, const float* keys, int64_t rows_per_src, const int64_t* tok,
+                                const float* h_in, vag_dec_w w, const float* prep, int64_t N, int64_t Ts, int64_t E, int64_t H,
+                                float* h_out, float* cw, float* e, float* alpha, float* scratch, vag_stream_t stream);
+int vag_head_logp_step_h(const float* h2, const float* cw, const float* e, vag_head_w w, int64_t N, int64_t E, int64_t H,
+                         int64_t V, float* logp, int64_t ldl, int64_t* argmax, float* scratch, vag_stream_t stream);
+int vag_head_logits_step_h(const float* h2, const float* cw, const float* e, vag_head_w w, int64_t N, int64_t E, int64_t H,
+                           int64_t V, float* logits, int64_t ldl, float* parts, float* scratch, vag_stream_t stream);
 /* Beam step on RAW logits (round 4): the vocabulary product of vag_head_logits_step leaves, per row, vag_head_logits_parts_count
  * (max, sum exp) pairs -- the pieces of the row's log-sum-exp -- in `parts` (count, N, 2); the expansion kernel normalises the
  * candidates it reads with them, so no pass over the (B k, V) logits is needed between product and selection (V11.py:276,297).

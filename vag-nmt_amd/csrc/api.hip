@@ -602,6 +602,15 @@ static int cgru_step(const float* enc, const float* pe, const float* mask, int64
 }
 
 // tanh(W1 h2 + W2 c + W3 e + biases) -> dropout -> logits   for N rows of one step (NMT_Decoder.py:137-143)
+// tmid for a step whose context share cw (N,E) = alpha . (enc W2^T) is at hand instead of the context (hoisted decoding step)
+static int head_pre_step_h(const float* h2, const float* cw, const float* e, const vag_head_w& w, int64_t N, int64_t E, int64_t H,
+                           float* tmid, hipStream_t s) {
+    const float* A3[3] = {h2, nullptr, e};
+    const float* W3[3] = {w.w1, nullptr, w.w3};
+    const float* B3[3] = {w.b1, w.b2, w.b3};
+    const int64_t ld3[3] = {H, 0, E}, K3[3] = {H, 0, E};
+    return vag_skinny3_launch(N, E, A3, ld3, W3, ld3, K3, B3, tmid, E, VAG_ACT_TANH, nullptr, VAG_DROP_DEC_OUT, 0.f, 0, s, cw, E);
+}
 static int head_step(const float* h2, const float* c, const float* e, const vag_head_w& w, int64_t N, int64_t E, int64_t H,
                      int64_t V, float p_out, const uint64_t* rng, int64_t drop_idx0, float* tmp, float* tmid,
                      float* logits, int64_t ldl, hipStream_t s) {
@@ -1009,6 +1018,56 @@ int vag_cgru_attn_decode_step(const float* enc, const float* pe, const float* ma
     return cgru_step(enc, pe, mask, rows_per_src, w, p, N, Ts, H, b, s);
 }
 
+// The decoding step in its HOISTED form (round 4): what the training chain does since round 2 -- the keys as gru_2 sees them are
+// projected once per call (encwp = (W_ih2 W_c2h) enc), so the second cell has no product left and rides as the epilogue of the
+// softmax + weighted-sum kernel -- plus the head's share of the context as a second weighted sum in the same launch
+// (cw = alpha . (enc W2^T)): the context itself is never formed.  Four launches instead of five, and the head's product over
+// C = 2H columns is gone.  vag_cgru_decode_keys: once per decode call; `keys` = [encwp (B,Ts,3H) | encw2 (B,Ts,E)].
+int64_t vag_cgru_decode_keys_floats(int64_t B, int64_t Ts, int64_t E, int64_t H) {
+    return ((B * Ts * 3 * H + 63) & ~63ll) + ((B * Ts * E + 63) & ~63ll);
+}
+int vag_cgru_decode_keys(const float* enc, const float* prep, const float* w2, int64_t B, int64_t Ts, int64_t E, int64_t H,
+                         float* keys, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(enc && prep && w2 && keys && B > 0 && Ts > 0 && E % 4 == 0 && H % 4 == 0 && aligned16(keys) && aligned16(prep));
+    const int64_t C = 2 * H;
+    CgruPrep p = cgru_prep(const_cast<float*>(prep), H);
+    float* encw2 = keys + ((B * Ts * 3 * H + 63) & ~63ll);
+    VagGemmGroup grp;
+    VAG_TRY(vag_gemm_launch(B * Ts, 3 * H, C, 1.f, enc, C, 1, p.wp, 1, C, 0.f, keys, 3 * H, nullptr, 0, s));
+    VAG_TRY(vag_gemm_launch(B * Ts, E, C, 1.f, enc, C, 1, w2, 1, C, 0.f, encw2, E, nullptr, 0, s));
+    return grp.end(s);
+}
+int vag_cgru_attn_decode_step_h(const float* pe, const float* mask, const float* keys, int64_t rows_per_src, const int64_t* tok,
+                                const float* h_in, vag_dec_w w, const float* prep, int64_t N, int64_t Ts, int64_t E, int64_t H,
+                                float* h_out, float* cw, float* e, float* alpha, float* scratch, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(pe && mask && keys && tok && h_in && h_out && cw && e && alpha && scratch && prep && dec_w_ok(w));
+    VAG_CHECK_ARG(N > 0 && N <= 256 && Ts > 0 && E % 4 == 0 && H % 4 == 0 && rows_per_src >= 1 && N % rows_per_src == 0 &&
+                  aligned16(scratch) && aligned16(prep) && aligned16(keys) && aligned16(w.emb) && aligned16(w.gru1.w_ih) && aligned16(e));
+    const int64_t C = 2 * H, Q = C + 3 * H, Bs = N / rows_per_src;
+    CgruPrep p = cgru_prep(const_cast<float*>(prep), H);
+    const float* encw2 = keys + ((Bs * Ts * 3 * H + 63) & ~63ll);
+    float* q = scratch;
+    float* xp1 = q; q += N * 3 * H;
+    float* h1 = q; q += N * H;
+    float* qhp = q; q += N * Q;
+    float* scores = q;
+    VAG_TRY(vag_skinny_gather_launch(N, 3 * H, E, w.emb, E, tok, w.gru1.w_ih, E, w.gru1.b_ih, xp1, 3 * H, e, E, s));          // :118
+    GruStepArgs a = {};
+    a.lda = H; a.ldw = H; a.ldother = 3 * H; a.ldh = H; a.ld2 = 0;
+    a.M = (int)N; a.K = (int)H; a.H = (int)H; a.lengths = nullptr; a.comp_hidden = 1;
+    a.s[0].A = h_in; a.s[0].W = w.gru1.w_hh; a.s[0].bias = w.gru1.b_hh; a.s[0].other = xp1;
+    a.s[0].hprev = h_in; a.s[0].hout = h1; a.s[0].out2 = nullptr; a.s[0].save = nullptr; a.s[0].t = 0;
+    VAG_TRY(vag_gru_step_launch(a, 1, s));                                                                               // gru_1 :121
+    // (the training chain lets W_hh2 h1 ride in the score kernel's grid; at 192 rows the one (q | hp2) product + the plain score
+    // kernel measured 3.5 us less than q + scores-with-rider: the rider is a long K loop of few workgroups)
+    VAG_TRY(vag_skinny_launch(N, Q, H, h1, H, p.wcat, H, p.bcat, nullptr, 0, qhp, Q, 0, s));                  // attn_h(h1) :47 | W_hh2 h1 + b
+    VAG_TRY(vag_attn_scores_launch(0, pe, qhp, Q, w.attn_v, mask, N, rows_per_src, Ts, C, scores, s));        // :47-51, :41-43
+    return vag_attn_ctx_gru_launch(scores, keys, N, rows_per_src, Ts, H, w.gru2.b_ih, qhp + C, Q, h1, alpha, h_out, nullptr, s,
+                                   false, encw2, E, cw);                                                                 // :44, :126-129
+}
+
 // =====================================================================================================
 // output head + cross entropy
 // =====================================================================================================
@@ -1203,6 +1262,28 @@ int vag_head_logp_step(const float* h2, const float* c, const float* e, vag_head
     return VAG_OK;
 }
 
+// ... with the context share of a hoisted decoding step (vag_cgru_attn_decode_step_h) in place of the context
+int vag_head_logp_step_h(const float* h2, const float* cw, const float* e, vag_head_w w, int64_t N, int64_t E, int64_t H,
+                         int64_t V, float* logp, int64_t ldl, int64_t* argmax, float* scratch, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(h2 && cw && e && logp && scratch && N > 0 && N <= 256 && E % 4 == 0 && H % 4 == 0 && V > 0 && ldl >= V);
+    VAG_CHECK_ARG(w.w1 && w.b1 && w.b2 && w.w3 && w.b3 && w.out_w && w.out_b && aligned16(h2) && aligned16(e) && aligned16(w.w1) &&
+                  aligned16(w.w3));
+    float* tmid = scratch + N * E;   // (N,E)
+    VAG_TRY(head_pre_step_h(h2, cw, e, w, N, E, H, tmid, s));
+    VAG_TRY(linear_fwd(N, V, E, tmid, E, w.out_w, w.out_b, 0, logp, ldl, s));
+    return vag_lse_nll_launch(logp, ldl, N, V, nullptr, 0, 0, nullptr, nullptr, nullptr, argmax, 1, logp, ldl, s);
+}
+int vag_head_logits_step_h(const float* h2, const float* cw, const float* e, vag_head_w w, int64_t N, int64_t E, int64_t H,
+                           int64_t V, float* logits, int64_t ldl, float* parts, float* scratch, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(h2 && cw && e && logits && parts && scratch && N > 0 && N <= 256 && E % 4 == 0 && H % 4 == 0 && V > 0 && ldl >= V);
+    VAG_CHECK_ARG(w.w1 && w.b1 && w.b2 && w.w3 && w.b3 && w.out_w && w.out_b && aligned16(scratch) && aligned16(h2) && aligned16(e) &&
+                  aligned16(w.w1) && aligned16(w.w3));
+    float* tmid = scratch + N * E;   // (N,E)
+    VAG_TRY(head_pre_step_h(h2, cw, e, w, N, E, H, tmid, s));
+    return vag_logits_parts_launch(N, V, E, tmid, E, w.out_w, E, w.out_b, logits, ldl, parts, s);
+}
 // The same step for beam search without the normalising pass: raw logits plus, per row, the pieces of its log-sum-exp written by
 // the vocabulary product's epilogue (gemm.hip, TallArgs::parts); vag_beam_step_logits_dev normalises on the fly.  The count is 0
 // for shapes the tall-skinny kernel does not take (N = B k <= 96 rows, V < 4096, E % 256 != 0): use vag_head_logp_step there.

@@ -160,13 +160,44 @@ __global__ __launch_bounds__(64 * CG_WAVES) void attn_ctx_gru_kernel(const float
                                                                      const float* __restrict__ hp, int64_t ldhp,
                                                                      const float* __restrict__ hprev, int64_t N,
                                                                      float* __restrict__ alpha, float* __restrict__ hout,
-                                                                     float* __restrict__ save) {
+                                                                     float* __restrict__ save, const float* __restrict__ x2,
+                                                                     int W2, float* __restrict__ out2) {
+    // x2 (B, Ts, W2) / out2 (N, W2), optional: a second weighted sum with the same attention weights, out2[n] = sum_s alpha_s x2[b,s,:]
+    // (decoding: x2 = enc W2^T, the head's share of the context -- the context itself is then never formed), done by the blocks
+    // blockIdx.x >= ceil(H / 256).
     extern __shared__ __attribute__((aligned(16))) float w[];   // Ts weights, CG_WAVES x 3 x 64 float4 partials
     float4* part = reinterpret_cast<float4*>(w + ((Ts + 3) & ~3));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t n = blockIdx.y;
     const int64_t b = rps == 1 ? n : (int64_t)((int)blockIdx.y / rps);
     const float* sc = scores + n * Ts;
+    const int hblocks = (H + 255) >> 8;
+    if ((int)blockIdx.x >= hblocks) {
+        const int c = (((int)blockIdx.x - hblocks) * 64 + lane) * 4;
+        float mx = -INFINITY;
+        for (int s = lane; s < Ts; s += 64) mx = fmaxf(mx, sc[s]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int s = lane; s < Ts; s += 64) sum += __expf(sc[s] - mx);
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        float4 a2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < W2)
+            for (int s = wave; s < Ts; s += CG_WAVES) {
+                const float al = __expf(sc[s] - mx) * inv;
+                const float4 v = *reinterpret_cast<const float4*>(x2 + (b * Ts + s) * (int64_t)W2 + c);
+                a2.x += al * v.x; a2.y += al * v.y; a2.z += al * v.z; a2.w += al * v.w;
+            }
+        part[wave * 64 + lane] = a2;
+        __syncthreads();
+        if (wave != 0 || c >= W2) return;
+        for (int q = 1; q < CG_WAVES; ++q) {
+            const float4 o = part[q * 64 + lane];
+            a2.x += o.x; a2.y += o.y; a2.z += o.z; a2.w += o.w;
+        }
+        *reinterpret_cast<float4*>(out2 + n * W2 + c) = a2;
+        return;
+    }
     const int u = (blockIdx.x * 64 + lane) * 4;
     const bool uok = u < H;
     // Everything that does not depend on the softmax is requested first -- the first U value rows of this wave and, for
@@ -266,18 +297,19 @@ __global__ __launch_bounds__(64 * CG_WAVES) void attn_ctx_gru_kernel(const float
 }
 int vag_attn_ctx_gru_launch(const float* scores, const float* encwp, int64_t N, int64_t rps, int64_t Ts, int64_t H,
                             const float* b_ih, const float* hp, int64_t ldhp, const float* hprev, float* alpha, float* hout,
-                            float* save, hipStream_t s, bool x16) {
+                            float* save, hipStream_t s, bool x16, const float* x2, int64_t W2, float* out2) {
+    VAG_CHECK_ARG(!x2 || (out2 && W2 > 0 && W2 % 4 == 0 && aligned16(x2) && aligned16(out2)));
     VAG_CHECK_ARG(scores && encwp && b_ih && hp && hprev && hout && N > 0 && N < 65536 && Ts > 0 && H > 0 && H % 4 == 0);
     VAG_CHECK_ARG(ldhp % 4 == 0 && rps >= 1 && aligned16(encwp) && aligned16(hp) && aligned16(hprev) && aligned16(hout) &&
                   aligned16(b_ih) && (!save || aligned16(save)));
-    dim3 grid((unsigned)cdiv64(H, 256), (unsigned)N);
+    dim3 grid((unsigned)(cdiv64(H, 256) + (x2 ? cdiv64(W2, 256) : 0)), (unsigned)N);
     const size_t lds = (size_t)((Ts + 3) & ~3) * sizeof(float) + (size_t)CG_WAVES * 3 * 64 * 16;
     if (x16)
         hipLaunchKernelGGL(attn_ctx_gru_kernel<true>, grid, dim3(64 * CG_WAVES), lds, s, scores, encwp, (int)rps, (int)Ts,
-                           (int)H, b_ih, hp, ldhp, hprev, N, alpha, hout, save);
+                           (int)H, b_ih, hp, ldhp, hprev, N, alpha, hout, save, x2, (int)W2, out2);
     else
         hipLaunchKernelGGL(attn_ctx_gru_kernel<false>, grid, dim3(64 * CG_WAVES), lds, s, scores, encwp, (int)rps, (int)Ts,
-                           (int)H, b_ih, hp, ldhp, hprev, N, alpha, hout, save);
+                           (int)H, b_ih, hp, ldhp, hprev, N, alpha, hout, save, x2, (int)W2, out2);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

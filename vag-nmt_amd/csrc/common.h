@@ -167,13 +167,14 @@ int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
 int vag_attn_dot_side_launch(int mode, const float* x, const float* q, int64_t ldq, const float* v, const float* mask,
                              const float* addend, int64_t N, int64_t Ts, int64_t W, float* out, int64_t M, int64_t Np,
                              int64_t K, const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* pbias,
-                             const float* padd, float* P, int64_t ldp, hipStream_t stream, bool s16 = false);   // s16: x and Wt fp16
+                             const float* padd, float* P, int64_t ldp, hipStream_t stream, bool s16 = false,   // s16: x and Wt fp16
+                             int64_t rps = 1);                                                                  // query rows per source row
 int vag_skinny_gather_launch(int64_t M, int64_t N, int64_t K, const float* table, int64_t ldt, const int64_t* idx, const float* W,
                              int64_t ldw, const float* bias, float* out, int64_t ldo, float* gathered, int64_t ldg,
                              hipStream_t stream);
 int vag_skinny3_launch(int64_t M, int64_t N, const float* const* A, const int64_t* lda, const float* const* W, const int64_t* ldw,
                        const int64_t* K, const float* const* bias, float* out, int64_t ldo, int act, const uint64_t* rng, int sid,
-                       float p, int64_t drop_idx0, hipStream_t stream);
+                       float p, int64_t drop_idx0, hipStream_t stream, const float* addend = nullptr, int64_t ldadd = 0);
 int vag_skinny_batched_launch(int64_t nb, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t bsA,
                               const float* W, int64_t ldw, int64_t bsW, float* out, int64_t ldo, int64_t bsO,
                               hipStream_t stream);

@@ -1170,6 +1170,7 @@ struct Skinny3Args {
     int M, N;
     float* out; int64_t ldo; int act;
     const uint64_t* rng; int sid; float p; int64_t drop_idx0;      // dropout multiplier of element (m,n): index drop_idx0 + m*N + n
+    const float* addend = nullptr; int64_t ldadd = 0;              // optional (M,N) term added before the activation
 };
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void skinny3_kernel(Skinny3Args a) {
@@ -1185,6 +1186,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny3_kernel(Skinny3Args a) {
 #pragma unroll
         for (int q = 0; q < 3; ++q)
             if (a.bias[q]) pre += a.bias[q][ej];
+        if (a.addend) pre += a.addend[(int64_t)em * a.ldadd + ej];
     }
     const int src4 = 4 * (16 * (lane & 3) + (lane & 12) + (lane >> 4));
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
@@ -1228,15 +1230,15 @@ static bool skinny_ok(const float* A, int64_t lda, const float* W, int64_t ldw, 
 // Three-segment product; every (A_q, W_q, K_q) must satisfy the skinny alignment rules, M <= 256.
 int vag_skinny3_launch(int64_t M, int64_t N, const float* const* A, const int64_t* lda, const float* const* W, const int64_t* ldw,
                        const int64_t* K, const float* const* bias, float* out, int64_t ldo, int act, const uint64_t* rng, int sid,
-                       float p, int64_t drop_idx0, hipStream_t stream) {
+                       float p, int64_t drop_idx0, hipStream_t stream, const float* addend, int64_t ldadd) {
     VAG_CHECK_ARG(M > 0 && M <= 256 && N > 0 && out);
     Skinny3Args a;
     for (int q = 0; q < 3; ++q) {
-        VAG_CHECK_ARG(A[q] && W[q] && skinny_ok(A[q], lda[q], W[q], ldw[q], K[q]));
+        VAG_CHECK_ARG(K[q] == 0 || (A[q] && W[q] && skinny_ok(A[q], lda[q], W[q], ldw[q], K[q])));      // K = 0: the segment is skipped (its bias still counts)
         a.A[q] = A[q]; a.W[q] = W[q]; a.bias[q] = bias[q]; a.lda[q] = lda[q]; a.ldw[q] = ldw[q]; a.K[q] = (int)K[q];
     }
     a.M = (int)M; a.N = (int)N; a.out = out; a.ldo = ldo; a.act = act;
-    a.rng = rng; a.sid = sid; a.p = p; a.drop_idx0 = drop_idx0;
+    a.rng = rng; a.sid = sid; a.p = p; a.drop_idx0 = drop_idx0; a.addend = addend; a.ldadd = ldadd;
     const dim3 grid((unsigned)cdiv64(N, 16), (unsigned)cdiv64(M, 16));
     hipLaunchKernelGGL(skinny3_kernel<8>, grid, dim3(512), 0, stream, a);
     VAG_LAUNCH_CHECK();
@@ -1255,6 +1257,7 @@ struct DotArgs {
     const float* v; const float* mask;                                     // MODE 0: out = v . tanh(x + q), masked to -inf
     int64_t ldq;
     int Ts, W, gx, nscore;
+    int rps = 1;               // query rows per source row (beam search: the k hypotheses of a sentence share its keys and mask)
 };
 // DS_WAVES waves per block: that many (row, position) pairs, or the K split of one product tile
 // S16: 2-byte storage mode -- the streamed operand x (attention keys / projected keys) and the side product's weights
@@ -1275,7 +1278,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void attn_dot_side_kernel(DotArgs d,
     const int s = (id % d.gx) * DS_WAVES + (threadIdx.x >> 6);
     if (s >= d.Ts) return;
     const int64_t n = id / d.gx;
-    const int64_t xrow = (n * d.Ts + s) * d.W;
+    const int64_t xrow = ((n / d.rps) * d.Ts + s) * d.W;
     const float* qr = d.q + n * d.ldq;
     float acc = 0.f;
     for (int c = lane * 4; c < d.W; c += 256) {
@@ -1294,7 +1297,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void attn_dot_side_kernel(DotArgs d,
     acc = wave_sum(acc);
     if (lane == 0) {
         if (d.addend) acc += d.addend[n * d.Ts + s];
-        if (MODE == 0 && d.mask && d.mask[n * d.Ts + s] == 0.f) acc = -INFINITY;
+        if (MODE == 0 && d.mask && d.mask[(n / d.rps) * d.Ts + s] == 0.f) acc = -INFINITY;
         d.out[n * d.Ts + s] = acc;
     }
 }
@@ -1351,11 +1354,11 @@ __global__ __launch_bounds__(64 * DS_WAVES) void attn_dot_side_reg_kernel(DotArg
     auto put = [&](int s, float acc) {
         if (lane == 0) {
             if (d.addend) acc += d.addend[n * d.Ts + s];
-            if (MODE == 0 && d.mask && d.mask[n * d.Ts + s] == 0.f) acc = -INFINITY;
+            if (MODE == 0 && d.mask && d.mask[(n / d.rps) * d.Ts + s] == 0.f) acc = -INFINITY;
             d.out[n * d.Ts + s] = acc;
         }
     };
-    const int64_t xbase = n * d.Ts * (int64_t)d.W + 8 * lane;
+    const int64_t xbase = (n / d.rps) * d.Ts * (int64_t)d.W + 8 * lane;
     int s = s0 + wave;
     for (; s + DS_WAVES < s1; s += 2 * DS_WAVES) {                   // two positions in flight
         float x0[NJ][8], x1[NJ][8];
@@ -1380,12 +1383,13 @@ __global__ __launch_bounds__(64 * DS_WAVES) void attn_dot_side_reg_kernel(DotArg
 int vag_attn_dot_side_launch(int mode, const float* x, const float* q, int64_t ldq, const float* v, const float* mask,
                              const float* addend, int64_t N, int64_t Ts, int64_t W, float* out, int64_t M, int64_t Np,
                              int64_t K, const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* pbias,
-                             const float* padd, float* P, int64_t ldp, hipStream_t stream, bool s16) {
+                             const float* padd, float* P, int64_t ldp, hipStream_t stream, bool s16, int64_t rps) {
     VAG_CHECK_ARG(x && q && out && N > 0 && Ts > 0 && W > 0 && W % 4 == 0 && ldq % 4 == 0 && aligned16(x) && aligned16(q));
     VAG_CHECK_ARG((mode == 1 || (mode == 0 && v && aligned16(v))) && A && Wt && P && M > 0 && Np > 0 &&
                   skinny_ok(A, lda, Wt, ldw, K));
     DotArgs d;
-    d.x = x; d.q = q; d.addend = addend; d.out = out; d.v = v; d.mask = mask; d.ldq = ldq; d.Ts = (int)Ts; d.W = (int)W;
+    VAG_CHECK_ARG(rps >= 1 && N % rps == 0);
+    d.x = x; d.q = q; d.addend = addend; d.out = out; d.v = v; d.mask = mask; d.ldq = ldq; d.Ts = (int)Ts; d.W = (int)W; d.rps = (int)rps;
     const int DS_WAVES = mode == 0 ? 8 : 16;        // measured: forward side product K = H, backward K = 3H
     d.gx = (int)cdiv64(Ts, DS_WAVES);
     VAG_CHECK_ARG((int64_t)d.gx * N < (1ll << 30));

@@ -85,7 +85,8 @@ int vag_attn_scores_ex_launch(int mode, const float* pe, const float* q, int64_t
                               float* scores, hipStream_t s);
 int vag_attn_ctx_gru_launch(const float* scores, const float* encwp, int64_t N, int64_t rps, int64_t Ts, int64_t H,
                             const float* b_ih, const float* hp, int64_t ldhp, const float* hprev, float* alpha, float* hout,
-                            float* save, hipStream_t s, bool x16 = false);      // x16: encwp is fp16
+                            float* save, hipStream_t s, bool x16 = false,       // x16: encwp is fp16
+                            const float* x2 = nullptr, int64_t W2 = 0, float* out2 = nullptr);     // out2 (N,W2) = alpha . x2 (B,Ts,W2)
 int vag_attn_wsum_launch(int over_src, const float* a, const float* x, int64_t B, int64_t Ts, int64_t T, int64_t W, float* out,
                          hipStream_t s);
 // softmax=1: alpha[n,:] = softmax(scores[n,:]) (written to alpha), ctx[n,c] = sum_s alpha[n,s] enc[b,s,c]

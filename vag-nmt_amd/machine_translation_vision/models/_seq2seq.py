@@ -88,6 +88,7 @@ class Seq2SeqBase(nn.Module):
     decode_graph = True
     decode_persistent = True      # greedy decoding in one launch where the shape allows it (ops.greedy_decode)
     decode_raw_logits = True      # beam search: expansion on raw logits + log-sum-exp pieces (no normalising pass) where available
+    decode_hoisted = True         # decoding steps on keys projected once per call (4 launches, no context): ops.decode_step_h
 
     def _decode_state(self, kind, enc, mask, k, max_length):
         """Static buffers (+ captured graph, filled in by the caller) for one decode shape; refreshed per call."""
@@ -97,7 +98,8 @@ class Seq2SeqBase(nn.Module):
         dev = enc.device
         dp, hp, emb = dec.dec_params(), dec.head_params(), dec.embedding.weight
         Tp = (Ts + 7) // 8 * 8
-        key = (kind, B, k, Tp, max_length, self.decode_raw_logits) + \
+        hoisted = self.decode_hoisted and ops.decode_hoisted_ok(B * k, emb, dp, hp)
+        key = (kind, B, k, Tp, max_length, self.decode_raw_logits, hoisted) + \
             tuple(t.data_ptr() for t in list(dp) + list(hp) + [emb, dec.attn.attn_e.weight])
         cache = self.__dict__.setdefault("_decode_cache", {})
         st = cache.get(key)
@@ -107,7 +109,9 @@ class Seq2SeqBase(nn.Module):
             st = {"enc": torch.zeros(B, Tp, C, device=dev), "pe": torch.zeros(B, Tp, C, device=dev),
                   "mask": torch.zeros(B, Tp, device=dev), "h": torch.empty(B * k, H, device=dev),
                   "tok": torch.empty(B * k, dtype=torch.int64, device=dev),
-                  "prep": torch.empty(_lib.lib().vag_cgru_prep_floats(H), device=dev), "graph": None}
+                  "prep": torch.empty(_lib.lib().vag_cgru_prep_floats(H), device=dev), "graph": None, "hoisted": hoisted}
+            if hoisted:
+                st["keys"] = torch.empty(_lib.lib().vag_cgru_decode_keys_floats(B, Tp, emb.shape[1], H), device=dev)
             cache[key] = st
         if Ts < Tp:
             st["enc"][:, Ts:].zero_(); st["pe"][:, Ts:].zero_(); st["mask"][:, Ts:].zero_()
@@ -115,6 +119,8 @@ class Seq2SeqBase(nn.Module):
         st["pe"][:, :Ts].copy_(ops.KeysProj.apply(enc, dec.attn.attn_e.weight))
         st["mask"][:, :Ts].copy_(mask)
         st["prep"].copy_(ops.decode_prepare(emb, dp))
+        if hoisted:
+            st["keys"].copy_(ops.decode_keys(st["enc"], st["prep"], hp))
         return st, dp, hp, emb
 
     def _greedy(self, enc, mask, h, tgt_l):
@@ -152,8 +158,11 @@ class Seq2SeqBase(nn.Module):
             with _lib.capture(g):
                 hc, tc = st["h"], st["tok"]
                 for i in range(CH):
-                    hc, c, e, _ = ops.decode_step(st["enc"], st["pe"], st["mask"], 1, tc, hc, emb, dp, st["prep"])
-                    _, tc = ops.head_logp_step(hc, c, e, hp, want_argmax=True, argmax_out=st["chunk"][i])
+                    if st["hoisted"]:
+                        hc, c, e, _ = ops.decode_step_h(st["pe"], st["mask"], st["keys"], 1, tc, hc, emb, dp, st["prep"])
+                    else:
+                        hc, c, e, _ = ops.decode_step(st["enc"], st["pe"], st["mask"], 1, tc, hc, emb, dp, st["prep"])
+                    _, tc = ops.head_logp_step(hc, c, e, hp, want_argmax=True, argmax_out=st["chunk"][i], hoisted=st["hoisted"])
                 st["h"].copy_(hc)
                 st["tok"].copy_(tc)
             st["graph"] = g
@@ -179,17 +188,23 @@ class Seq2SeqBase(nn.Module):
         if graphed:
             st, dp, hp, emb = self._decode_state("beam", enc, mask, k, max_length)
             enc_s, pe, mask_s, prep = st["enc"], st["pe"], st["mask"], st["prep"]
+            hoisted, keys = st["hoisted"], st.get("keys")
         else:
             pe = ops.KeysProj.apply(enc, dec.attn.attn_e.weight)
             dp, hp, emb = dec.dec_params(), dec.head_params(), dec.embedding.weight
             prep = ops.decode_prepare(emb, dp)
             enc_s, mask_s = enc, mask
+            hoisted = self.decode_hoisted and ops.decode_hoisted_ok(B * k, emb, dp, hp)
+            keys = ops.decode_keys(enc, prep, hp) if hoisted else None
         h_next = st["h"] if graphed else torch.empty(B * k, H, dtype=torch.float32, device=dev)
         steps = 0
         for di in range(max_length):
             rps = 1 if di == 0 else k
-            h, c, e, _ = ops.decode_step(enc_s, pe, mask_s, rps, tok, h, emb, dp, prep)
-            logp, _ = ops.head_logp_step(h, c, e, hp)
+            if hoisted:
+                h, c, e, _ = ops.decode_step_h(pe, mask_s, keys, rps, tok, h, emb, dp, prep)
+            else:
+                h, c, e, _ = ops.decode_step(enc_s, pe, mask_s, rps, tok, h, emb, dp, prep)
+            logp, _ = ops.head_logp_step(h, c, e, hp, hoisted=hoisted)
             call("vag_beam_step", ptr(logp), logp.shape[1], ptr(nll), ptr(beam, torch.int64), di, max_length, ptr(h),
                  ptr(h_next), B, k, V, H, ptr(n_alive, torch.int32), scratch.data_ptr(), stream())
             steps = di + 1
@@ -220,14 +235,17 @@ class Seq2SeqBase(nn.Module):
                 nparts = ops.head_logits_parts_count(hp, B * k, emb.shape[1], V) if self.decode_raw_logits else 0
                 with _lib.capture(g):
                     for _ in range(CH):
-                        h2, c, e, _ = ops.decode_step(enc_s, pe, mask_s, k, st["tok"], st["h"], emb, dp, prep)
+                        if hoisted:
+                            h2, c, e, _ = ops.decode_step_h(pe, mask_s, keys, k, st["tok"], st["h"], emb, dp, prep)
+                        else:
+                            h2, c, e, _ = ops.decode_step(enc_s, pe, mask_s, k, st["tok"], st["h"], emb, dp, prep)
                         if nparts > 0:
-                            logits, parts = ops.head_logits_step(h2, c, e, hp, nparts)
+                            logits, parts = ops.head_logits_step(h2, c, e, hp, nparts, hoisted=hoisted)
                             call("vag_beam_step_logits_dev", ptr(logits), logits.shape[1], ptr(parts), nparts, ptr(nll),
                                  ptr(beam, torch.int64), ptr(st["di"], torch.int32), max_length, ptr(h2), ptr(st["h"]),
                                  ptr(st["tok"], torch.int64), B, k, V, H, ptr(n_alive, torch.int32), scratch.data_ptr(), stream())
                             continue
-                        logp, _ = ops.head_logp_step(h2, c, e, hp)
+                        logp, _ = ops.head_logp_step(h2, c, e, hp, hoisted=hoisted)
                         call("vag_beam_step_dev", ptr(logp), logp.shape[1], ptr(nll), ptr(beam, torch.int64),
                              ptr(st["di"], torch.int32), max_length, ptr(h2), ptr(st["h"]), ptr(st["tok"], torch.int64),
                              B, k, V, H, ptr(n_alive, torch.int32), scratch.data_ptr(), stream())

@@ -472,6 +472,39 @@ def decode_prepare(emb, dec):
     return prep
 
 
+def decode_hoisted_ok(N, emb, dec, head):
+    """The hoisted decoding step (decode_keys / decode_step_h) takes up to 256 hypotheses and 16-byte aligned parameters."""
+    E, H = emb.shape[1], dec[1].shape[1]
+    ts = [emb, dec[0], head[0], head[4]]
+    return N <= 256 and E % 4 == 0 and H % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in ts)
+
+
+def decode_keys(enc, prep, head):
+    """Once per decode call: [(W_ih2 W_c2h) enc | enc W2^T], what a hoisted decoding step needs of the source side."""
+    B, Ts, Cc = enc.shape
+    H = Cc // 2
+    E = head[2].shape[0]
+    keys = _f32(L.lib().vag_cgru_decode_keys_floats(B, Ts, E, H), like=enc)
+    call("vag_cgru_decode_keys", ptr(_c(enc)), ptr(prep), ptr(head[2]), B, Ts, E, H, ptr(keys), stream())
+    return keys
+
+
+def decode_step_h(pe, mask, keys, rows_per_src, tok, h_in, emb, dec, prep):
+    """One cGRU step for N hypotheses in the hoisted form -> (h_out (N,H), cw (N,E) = W2 c, e (N,E), alpha (N,Ts))."""
+    B, Ts, Cc = pe.shape
+    H = Cc // 2
+    E = emb.shape[1]
+    N = tok.numel()
+    h_out = _f32(N, H, like=pe)
+    cw = _f32(N, E, like=pe)
+    e = _f32(N, E, like=pe)
+    alpha = _f32(N, Ts, like=pe)
+    scratch = _f32(L.lib().vag_cgru_step_scratch_floats(N, Ts, E, H), like=pe)
+    call("vag_cgru_attn_decode_step_h", ptr(pe), ptr(mask), ptr(keys), rows_per_src, ptr(_c(tok).view(-1), I64), ptr(_c(h_in)),
+         _dec_w(emb, dec), ptr(prep), N, Ts, E, H, ptr(h_out), ptr(cw), ptr(e), ptr(alpha), ptr(scratch), stream())
+    return h_out, cw, e, alpha
+
+
 def decode_step(enc, pe, mask, rows_per_src, tok, h_in, emb, dec, prep):
     """One cGRU step for N hypotheses -> (h_out (N,H), c (N,C), e (N,E), alpha (N,Ts))."""
     B, Ts, Cc = enc.shape
@@ -516,7 +549,7 @@ def head_logits_parts_count(head, N, E, V):
     return int(L.lib().vag_head_logits_parts_count(_head_w(head), N, E, V))
 
 
-def head_logits_step(h2, c, e, head, nparts):
+def head_logits_step(h2, c, e, head, nparts, hoisted=False):
     """Raw logits (N, ldl) of one decoding step and the (N, nparts, 2) pieces of their rows' log-sum-exp (beam search on raw
     logits: vag_beam_step_logits_dev)."""
     N, H = h2.shape
@@ -526,12 +559,12 @@ def head_logits_step(h2, c, e, head, nparts):
     logits = _f32(N, ldl, like=h2)
     parts = _f32(nparts, N, 2, like=h2)
     scratch = _f32(2 * N * E, like=h2)
-    call("vag_head_logits_step", ptr(h2), ptr(c), ptr(e), _head_w(head), N, E, H, V, ptr(logits), ldl, ptr(parts), ptr(scratch),
-         stream())
+    call("vag_head_logits_step_h" if hoisted else "vag_head_logits_step", ptr(h2), ptr(c), ptr(e), _head_w(head), N, E, H, V,
+         ptr(logits), ldl, ptr(parts), ptr(scratch), stream())
     return logits, parts
 
 
-def head_logp_step(h2, c, e, head, want_argmax=False, argmax_out=None):
+def head_logp_step(h2, c, e, head, want_argmax=False, argmax_out=None, hoisted=False):
     """argmax_out: optional (N,) int64 HIP tensor the arg-max tokens are written into (greedy decode hands in a row of its token
     chunk, which saves a copy launch per step)."""
     N, H = h2.shape
@@ -544,8 +577,8 @@ def head_logp_step(h2, c, e, head, want_argmax=False, argmax_out=None):
         am = argmax_out if argmax_out is not None else torch.empty(N, dtype=I64, device=h2.device)
         assert am.dtype == I64 and am.is_contiguous() and am.numel() == N
     scratch = _f32(2 * N * E, like=h2)
-    call("vag_head_logp_step", ptr(h2), ptr(c), ptr(e), _head_w(head), N, E, H, V, ptr(logp), ldl,
-         ptr(am, I64) if am is not None else None, ptr(scratch), stream())
+    call("vag_head_logp_step_h" if hoisted else "vag_head_logp_step", ptr(h2), ptr(c), ptr(e), _head_w(head), N, E, H, V,
+         ptr(logp), ldl, ptr(am, I64) if am is not None else None, ptr(scratch), stream())
     return logp, am
 
 
