@@ -389,7 +389,7 @@ def measure_extras(c, dev, ts, args):
                     "mean_hyp_len": sum(len(h) for h in hyp) / 16.0, "decoder_steps_run": steps, "us_per_step": dt / steps * 1e6,
                     "path": ("all steps in ONE launch: dec_fwd_persistent_kernel<true> forms the head, the logits of its vocabulary "
                              "tiles and the arg-max itself (persist.hip)") if one_launch else
-                            "one captured graph of 8 decoder steps (9 launches per step: hoisted step, raw-logit expansion), replayed",
+                            "one captured graph of 8 decoder steps (8 launches per step: hoisted step on per-call key and token tables, raw-logit expansion), replayed",
                     "note": "beam search stops once every hypothesis has emitted EOS (V11.py:266-269)",
                     "roofline": decode_roofline(c4, lens, k, dt / steps)}
     m4.train(was)

@@ -326,13 +326,21 @@ int vag_beam_step_dev(float* logp, int64_t ldl, float* nll, int64_t* beam, int32
 int64_t vag_cgru_decode_keys_floats(int64_t B, int64_t Ts, int64_t E, int64_t H);
 int vag_cgru_decode_keys(const float* enc, const float* prep, const float* w2, int64_t B, int64_t Ts, int64_t E, int64_t H,
                          float* keys, vag_stream_t stream);
-int vag_cgru_attn_decode_step_h(const float* pe, const float* mask, const float* keys, int64_t rows_per_src, const int64_t* tok,
-                                const float* h_in, vag_dec_w w, const float* prep, int64_t N, int64_t Ts, int64_t E, int64_t H,
-                                float* h_out, float* cw, float* e, float* alpha, float* scratch, vag_stream_t stream);
-int vag_head_logp_step_h(const float* h2, const float* cw, const float* e, vag_head_w w, int64_t N, int64_t E, int64_t H,
-                         int64_t V, float* logp, int64_t ldl, int64_t* argmax, float* scratch, vag_stream_t stream);
-int vag_head_logits_step_h(const float* h2, const float* cw, const float* e, vag_head_w w, int64_t N, int64_t E, int64_t H,
-                           int64_t V, float* logits, int64_t ldl, float* parts, float* scratch, vag_stream_t stream);
+/* tables (optional, NULL: none): [emb W_ih1^T + b_ih1 (V,3H) | emb W3^T (V,E)] from vag_cgru_decode_tables, once per call
+ * (w3 = head W3): a step then has no embedding / input-projection launch, `e` is not produced (may be NULL) and the head reads
+ * its share of the embedded token from the table line `tok` picks. */
+int64_t vag_cgru_decode_tables_floats(int64_t V, int64_t E, int64_t H);
+int vag_cgru_decode_tables(vag_dec_w w, const float* w3, int64_t V, int64_t E, int64_t H, float* tables, vag_stream_t stream);
+int vag_cgru_attn_decode_step_h(const float* pe, const float* mask, const float* keys, const float* tables, int64_t V,
+                                int64_t rows_per_src, const int64_t* tok, const float* h_in, vag_dec_w w, const float* prep,
+                                int64_t N, int64_t Ts, int64_t E, int64_t H, float* h_out, float* cw, float* e, float* alpha,
+                                float* scratch, vag_stream_t stream);
+int vag_head_logp_step_h(const float* h2, const float* cw, const float* e, const float* tables, const int64_t* tok, vag_head_w w,
+                         int64_t N, int64_t E, int64_t H, int64_t V, float* logp, int64_t ldl, int64_t* argmax, float* scratch,
+                         vag_stream_t stream);
+int vag_head_logits_step_h(const float* h2, const float* cw, const float* e, const float* tables, const int64_t* tok, vag_head_w w,
+                           int64_t N, int64_t E, int64_t H, int64_t V, float* logits, int64_t ldl, float* parts, float* scratch,
+                           vag_stream_t stream);
 /* Beam step on RAW logits (round 4): the vocabulary product of vag_head_logits_step leaves, per row, vag_head_logits_parts_count
  * (max, sum exp) pairs -- the pieces of the row's log-sum-exp -- in `parts` (count, N, 2); the expansion kernel normalises the
  * candidates it reads with them, so no pass over the (B k, V) logits is needed between product and selection (V11.py:276,297).

@@ -603,13 +603,15 @@ static int cgru_step(const float* enc, const float* pe, const float* mask, int64
 
 // tanh(W1 h2 + W2 c + W3 e + biases) -> dropout -> logits   for N rows of one step (NMT_Decoder.py:137-143)
 // tmid for a step whose context share cw (N,E) = alpha . (enc W2^T) is at hand instead of the context (hoisted decoding step)
-static int head_pre_step_h(const float* h2, const float* cw, const float* e, const vag_head_w& w, int64_t N, int64_t E, int64_t H,
-                           float* tmid, hipStream_t s) {
-    const float* A3[3] = {h2, nullptr, e};
-    const float* W3[3] = {w.w1, nullptr, w.w3};
+// embw3 / tok: W3 e as a table line (vag_cgru_decode_tables) instead of a product over the embedded token e
+static int head_pre_step_h(const float* h2, const float* cw, const float* e, const float* embw3, const int64_t* tok,
+                           const vag_head_w& w, int64_t N, int64_t E, int64_t H, float* tmid, hipStream_t s) {
+    const float* A3[3] = {h2, nullptr, embw3 ? nullptr : e};
+    const float* W3[3] = {w.w1, nullptr, embw3 ? nullptr : w.w3};
     const float* B3[3] = {w.b1, w.b2, w.b3};
-    const int64_t ld3[3] = {H, 0, E}, K3[3] = {H, 0, E};
-    return vag_skinny3_launch(N, E, A3, ld3, W3, ld3, K3, B3, tmid, E, VAG_ACT_TANH, nullptr, VAG_DROP_DEC_OUT, 0.f, 0, s, cw, E);
+    const int64_t ld3[3] = {H, 0, E}, K3[3] = {H, 0, embw3 ? 0 : E};
+    return vag_skinny3_launch(N, E, A3, ld3, W3, ld3, K3, B3, tmid, E, VAG_ACT_TANH, nullptr, VAG_DROP_DEC_OUT, 0.f, 0, s, cw, E,
+                              embw3, tok, E);
 }
 static int head_step(const float* h2, const float* c, const float* e, const vag_head_w& w, int64_t N, int64_t E, int64_t H,
                      int64_t V, float p_out, const uint64_t* rng, int64_t drop_idx0, float* tmp, float* tmid,
@@ -1038,11 +1040,25 @@ int vag_cgru_decode_keys(const float* enc, const float* prep, const float* w2, i
     VAG_TRY(vag_gemm_launch(B * Ts, E, C, 1.f, enc, C, 1, w2, 1, C, 0.f, encw2, E, nullptr, 0, s));
     return grp.end(s);
 }
-int vag_cgru_attn_decode_step_h(const float* pe, const float* mask, const float* keys, int64_t rows_per_src, const int64_t* tok,
-                                const float* h_in, vag_dec_w w, const float* prep, int64_t N, int64_t Ts, int64_t E, int64_t H,
-                                float* h_out, float* cw, float* e, float* alpha, float* scratch, vag_stream_t stream) {
+// ... and what a step needs of a TOKEN, for every vocabulary entry, once per call: tables = [emb W_ih1^T + b_ih1 (V,3H) | emb W3^T (V,E)]
+// (the free-running recurrence kernel's tables, persist.hip).  With them a step has no embedding / input-projection launch: gru_1 reads
+// its input projection from the line its row's token picks, the head its share of the embedded token likewise.
+int64_t vag_cgru_decode_tables_floats(int64_t V, int64_t E, int64_t H) { return ((V * 3 * H + 63) & ~63ll) + ((V * E + 63) & ~63ll); }
+int vag_cgru_decode_tables(vag_dec_w w, const float* w3, int64_t V, int64_t E, int64_t H, float* tables, vag_stream_t stream) {
     hipStream_t s = S_(stream);
-    VAG_CHECK_ARG(pe && mask && keys && tok && h_in && h_out && cw && e && alpha && scratch && prep && dec_w_ok(w));
+    VAG_CHECK_ARG(dec_w_ok(w) && w3 && tables && V > 0 && E % 4 == 0 && H % 4 == 0 && aligned16(tables));
+    VagGemmGroup grp;
+    VAG_TRY(vag_gemm_launch(V, 3 * H, E, 1.f, w.emb, E, 1, w.gru1.w_ih, 1, E, 0.f, tables, 3 * H, w.gru1.b_ih, 0, s));
+    VAG_TRY(vag_gemm_launch(V, E, E, 1.f, w.emb, E, 1, w3, 1, E, 0.f, tables + ((V * 3 * H + 63) & ~63ll), E, nullptr, 0, s));
+    return grp.end(s);
+}
+int vag_cgru_attn_decode_step_h(const float* pe, const float* mask, const float* keys, const float* tables, int64_t V,
+                                int64_t rows_per_src, const int64_t* tok, const float* h_in, vag_dec_w w, const float* prep,
+                                int64_t N, int64_t Ts, int64_t E, int64_t H, float* h_out, float* cw, float* e, float* alpha,
+                                float* scratch, vag_stream_t stream) {
+    hipStream_t s = S_(stream);
+    VAG_CHECK_ARG(pe && mask && keys && tok && h_in && h_out && cw && (e || tables) && alpha && scratch && prep && dec_w_ok(w));
+    VAG_CHECK_ARG(!tables || (V > 0 && aligned16(tables)));
     VAG_CHECK_ARG(N > 0 && N <= 256 && Ts > 0 && E % 4 == 0 && H % 4 == 0 && rows_per_src >= 1 && N % rows_per_src == 0 &&
                   aligned16(scratch) && aligned16(prep) && aligned16(keys) && aligned16(w.emb) && aligned16(w.gru1.w_ih) && aligned16(e));
     const int64_t C = 2 * H, Q = C + 3 * H, Bs = N / rows_per_src;
@@ -1053,11 +1069,12 @@ int vag_cgru_attn_decode_step_h(const float* pe, const float* mask, const float*
     float* h1 = q; q += N * H;
     float* qhp = q; q += N * Q;
     float* scores = q;
-    VAG_TRY(vag_skinny_gather_launch(N, 3 * H, E, w.emb, E, tok, w.gru1.w_ih, E, w.gru1.b_ih, xp1, 3 * H, e, E, s));          // :118
+    if (!tables) VAG_TRY(vag_skinny_gather_launch(N, 3 * H, E, w.emb, E, tok, w.gru1.w_ih, E, w.gru1.b_ih, xp1, 3 * H, e, E, s));      // :118
     GruStepArgs a = {};
     a.lda = H; a.ldw = H; a.ldother = 3 * H; a.ldh = H; a.ld2 = 0;
     a.M = (int)N; a.K = (int)H; a.H = (int)H; a.lengths = nullptr; a.comp_hidden = 1;
-    a.s[0].A = h_in; a.s[0].W = w.gru1.w_hh; a.s[0].bias = w.gru1.b_hh; a.s[0].other = xp1;
+    a.s[0].A = h_in; a.s[0].W = w.gru1.w_hh; a.s[0].bias = w.gru1.b_hh; a.s[0].other = tables ? tables : xp1;
+    a.s[0].other_idx = tables ? tok : nullptr;
     a.s[0].hprev = h_in; a.s[0].hout = h1; a.s[0].out2 = nullptr; a.s[0].save = nullptr; a.s[0].t = 0;
     VAG_TRY(vag_gru_step_launch(a, 1, s));                                                                               // gru_1 :121
     // (the training chain lets W_hh2 h1 ride in the score kernel's grid; at 192 rows the one (q | hp2) product + the plain score
@@ -1263,25 +1280,29 @@ int vag_head_logp_step(const float* h2, const float* c, const float* e, vag_head
 }
 
 // ... with the context share of a hoisted decoding step (vag_cgru_attn_decode_step_h) in place of the context
-int vag_head_logp_step_h(const float* h2, const float* cw, const float* e, vag_head_w w, int64_t N, int64_t E, int64_t H,
-                         int64_t V, float* logp, int64_t ldl, int64_t* argmax, float* scratch, vag_stream_t stream) {
+int vag_head_logp_step_h(const float* h2, const float* cw, const float* e, const float* tables, const int64_t* tok, vag_head_w w,
+                         int64_t N, int64_t E, int64_t H, int64_t V, float* logp, int64_t ldl, int64_t* argmax, float* scratch,
+                         vag_stream_t stream) {
     hipStream_t s = S_(stream);
-    VAG_CHECK_ARG(h2 && cw && e && logp && scratch && N > 0 && N <= 256 && E % 4 == 0 && H % 4 == 0 && V > 0 && ldl >= V);
-    VAG_CHECK_ARG(w.w1 && w.b1 && w.b2 && w.w3 && w.b3 && w.out_w && w.out_b && aligned16(h2) && aligned16(e) && aligned16(w.w1) &&
-                  aligned16(w.w3));
+    VAG_CHECK_ARG(h2 && cw && (tables ? tok != nullptr : e != nullptr) && logp && scratch && N > 0 && N <= 256 && E % 4 == 0 &&
+                  H % 4 == 0 && V > 0 && ldl >= V);
+    VAG_CHECK_ARG(w.w1 && w.b1 && w.b2 && w.w3 && w.b3 && w.out_w && w.out_b && aligned16(h2) && (tables || aligned16(e)) &&
+                  aligned16(w.w1) && aligned16(w.w3));
     float* tmid = scratch + N * E;   // (N,E)
-    VAG_TRY(head_pre_step_h(h2, cw, e, w, N, E, H, tmid, s));
+    VAG_TRY(head_pre_step_h(h2, cw, e, tables ? tables + ((V * 3 * H + 63) & ~63ll) : nullptr, tok, w, N, E, H, tmid, s));
     VAG_TRY(linear_fwd(N, V, E, tmid, E, w.out_w, w.out_b, 0, logp, ldl, s));
     return vag_lse_nll_launch(logp, ldl, N, V, nullptr, 0, 0, nullptr, nullptr, nullptr, argmax, 1, logp, ldl, s);
 }
-int vag_head_logits_step_h(const float* h2, const float* cw, const float* e, vag_head_w w, int64_t N, int64_t E, int64_t H,
-                           int64_t V, float* logits, int64_t ldl, float* parts, float* scratch, vag_stream_t stream) {
+int vag_head_logits_step_h(const float* h2, const float* cw, const float* e, const float* tables, const int64_t* tok, vag_head_w w,
+                           int64_t N, int64_t E, int64_t H, int64_t V, float* logits, int64_t ldl, float* parts, float* scratch,
+                           vag_stream_t stream) {
     hipStream_t s = S_(stream);
-    VAG_CHECK_ARG(h2 && cw && e && logits && parts && scratch && N > 0 && N <= 256 && E % 4 == 0 && H % 4 == 0 && V > 0 && ldl >= V);
-    VAG_CHECK_ARG(w.w1 && w.b1 && w.b2 && w.w3 && w.b3 && w.out_w && w.out_b && aligned16(scratch) && aligned16(h2) && aligned16(e) &&
-                  aligned16(w.w1) && aligned16(w.w3));
+    VAG_CHECK_ARG(h2 && cw && (tables ? tok != nullptr : e != nullptr) && logits && parts && scratch && N > 0 && N <= 256 &&
+                  E % 4 == 0 && H % 4 == 0 && V > 0 && ldl >= V);
+    VAG_CHECK_ARG(w.w1 && w.b1 && w.b2 && w.w3 && w.b3 && w.out_w && w.out_b && aligned16(scratch) && aligned16(h2) &&
+                  (tables || aligned16(e)) && aligned16(w.w1) && aligned16(w.w3));
     float* tmid = scratch + N * E;   // (N,E)
-    VAG_TRY(head_pre_step_h(h2, cw, e, w, N, E, H, tmid, s));
+    VAG_TRY(head_pre_step_h(h2, cw, e, tables ? tables + ((V * 3 * H + 63) & ~63ll) : nullptr, tok, w, N, E, H, tmid, s));
     return vag_logits_parts_launch(N, V, E, tmid, E, w.out_w, E, w.out_b, logits, ldl, parts, s);
 }
 // The same step for beam search without the normalising pass: raw logits plus, per row, the pieces of its log-sum-exp written by

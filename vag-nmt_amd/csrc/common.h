@@ -174,7 +174,8 @@ int vag_skinny_gather_launch(int64_t M, int64_t N, int64_t K, const float* table
                              hipStream_t stream);
 int vag_skinny3_launch(int64_t M, int64_t N, const float* const* A, const int64_t* lda, const float* const* W, const int64_t* ldw,
                        const int64_t* K, const float* const* bias, float* out, int64_t ldo, int act, const uint64_t* rng, int sid,
-                       float p, int64_t drop_idx0, hipStream_t stream, const float* addend = nullptr, int64_t ldadd = 0);
+                       float p, int64_t drop_idx0, hipStream_t stream, const float* addend = nullptr, int64_t ldadd = 0,
+                       const float* addend2 = nullptr, const int64_t* idx2 = nullptr, int64_t ldadd2 = 0);
 int vag_skinny_batched_launch(int64_t nb, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t bsA,
                               const float* W, int64_t ldw, int64_t bsW, float* out, int64_t ldo, int64_t bsO,
                               hipStream_t stream);
@@ -207,6 +208,8 @@ struct GruSide {
     const float* W;      // (3H,K) weight of that projection, gate order r,z,n
     const float* bias;   // (3H) bias of that projection (may be NULL)
     const float* other;  // (M,3H) the other projection, bias already added
+    const int64_t* other_idx;   // NULL, or (M) row indices into `other` (decoding: the input projection of every vocabulary entry
+                                // is a table, a row's token picks its line)
     const float* hprev;  // (M,H) previous hidden state
     float* hout;         // (M,H) new hidden state (rows past their length keep hprev)
     float* out2;         // optional second copy with row stride ld2; zero for rows past their length

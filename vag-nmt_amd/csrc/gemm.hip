@@ -1171,6 +1171,7 @@ struct Skinny3Args {
     float* out; int64_t ldo; int act;
     const uint64_t* rng; int sid; float p; int64_t drop_idx0;      // dropout multiplier of element (m,n): index drop_idx0 + m*N + n
     const float* addend = nullptr; int64_t ldadd = 0;              // optional (M,N) term added before the activation
+    const float* addend2 = nullptr; const int64_t* idx2 = nullptr; int64_t ldadd2 = 0;     // ... and a second one, row m from line idx2[m]
 };
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void skinny3_kernel(Skinny3Args a) {
@@ -1187,6 +1188,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny3_kernel(Skinny3Args a) {
         for (int q = 0; q < 3; ++q)
             if (a.bias[q]) pre += a.bias[q][ej];
         if (a.addend) pre += a.addend[(int64_t)em * a.ldadd + ej];
+        if (a.addend2) pre += a.addend2[a.idx2[em] * a.ldadd2 + ej];
     }
     const int src4 = 4 * (16 * (lane & 3) + (lane & 12) + (lane >> 4));
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
@@ -1230,7 +1232,8 @@ static bool skinny_ok(const float* A, int64_t lda, const float* W, int64_t ldw, 
 // Three-segment product; every (A_q, W_q, K_q) must satisfy the skinny alignment rules, M <= 256.
 int vag_skinny3_launch(int64_t M, int64_t N, const float* const* A, const int64_t* lda, const float* const* W, const int64_t* ldw,
                        const int64_t* K, const float* const* bias, float* out, int64_t ldo, int act, const uint64_t* rng, int sid,
-                       float p, int64_t drop_idx0, hipStream_t stream, const float* addend, int64_t ldadd) {
+                       float p, int64_t drop_idx0, hipStream_t stream, const float* addend, int64_t ldadd, const float* addend2,
+                       const int64_t* idx2, int64_t ldadd2) {
     VAG_CHECK_ARG(M > 0 && M <= 256 && N > 0 && out);
     Skinny3Args a;
     for (int q = 0; q < 3; ++q) {
@@ -1239,6 +1242,8 @@ int vag_skinny3_launch(int64_t M, int64_t N, const float* const* A, const int64_
     }
     a.M = (int)M; a.N = (int)N; a.out = out; a.ldo = ldo; a.act = act;
     a.rng = rng; a.sid = sid; a.p = p; a.drop_idx0 = drop_idx0; a.addend = addend; a.ldadd = ldadd;
+    VAG_CHECK_ARG(!addend2 || idx2);
+    a.addend2 = addend2; a.idx2 = idx2; a.ldadd2 = ldadd2;
     const dim3 grid((unsigned)cdiv64(N, 16), (unsigned)cdiv64(M, 16));
     hipLaunchKernelGGL(skinny3_kernel<8>, grid, dim3(512), 0, stream, a);
     VAG_LAUNCH_CHECK();
@@ -1515,7 +1520,7 @@ __global__ __launch_bounds__(WAVES * 64) void gru_step_kernel(GruStepArgs a) {
         o_r[q] = o_z[q] = o_n[q] = hp[q] = b_r[q] = b_z[q] = b_n[q] = 0.f;
         active[q] = true;
         if (eok[q]) {
-            const float* op = sd.other + (int64_t)em * a.ldother + ej;
+            const float* op = sd.other + (sd.other_idx ? sd.other_idx[em] : (int64_t)em) * a.ldother + ej;
             o_r[q] = op[0]; o_z[q] = op[H]; o_n[q] = op[2 * H];
             hp[q] = sd.hprev[(int64_t)em * a.ldh + ej];
             if (sd.bias) { b_r[q] = sd.bias[ej]; b_z[q] = sd.bias[H + ej]; b_n[q] = sd.bias[2 * H + ej]; }
@@ -1574,7 +1579,7 @@ __global__ __launch_bounds__(WAVES * 64) void gru_step_small_kernel(GruStepArgs 
     float o_r = 0.f, o_z = 0.f, o_n = 0.f, hp = 0.f, b_r = 0.f, b_z = 0.f, b_n = 0.f;
     bool active = true;
     if (eok) {
-        const float* op = sd.other + (int64_t)em * a.ldother + ej;
+        const float* op = sd.other + (sd.other_idx ? sd.other_idx[em] : (int64_t)em) * a.ldother + ej;
         o_r = op[0]; o_z = op[H]; o_n = op[2 * H];
         hp = sd.hprev[(int64_t)em * a.ldh + ej];
         if (sd.bias) { b_r = sd.bias[ej]; b_z = sd.bias[H + ej]; b_n = sd.bias[2 * H + ej]; }

@@ -121,6 +121,11 @@ class Seq2SeqBase(nn.Module):
         st["prep"].copy_(ops.decode_prepare(emb, dp))
         if hoisted:
             st["keys"].copy_(ops.decode_keys(st["enc"], st["prep"], hp))
+            tb = ops.decode_tables(emb, dp, hp)             # per call: the weights may have changed since the last one
+            if tb is not None and st.get("tables") is not None:
+                st["tables"].copy_(tb)
+            elif st["graph"] is None:
+                st["tables"] = tb                           # (a captured graph keeps the choice it was captured with)
         return st, dp, hp, emb
 
     def _greedy(self, enc, mask, h, tgt_l):
@@ -158,11 +163,14 @@ class Seq2SeqBase(nn.Module):
             with _lib.capture(g):
                 hc, tc = st["h"], st["tok"]
                 for i in range(CH):
+                    tin = tc
                     if st["hoisted"]:
-                        hc, c, e, _ = ops.decode_step_h(st["pe"], st["mask"], st["keys"], 1, tc, hc, emb, dp, st["prep"])
+                        hc, c, e, _ = ops.decode_step_h(st["pe"], st["mask"], st["keys"], 1, tc, hc, emb, dp, st["prep"],
+                                                        tables=st.get("tables"))
                     else:
                         hc, c, e, _ = ops.decode_step(st["enc"], st["pe"], st["mask"], 1, tc, hc, emb, dp, st["prep"])
-                    _, tc = ops.head_logp_step(hc, c, e, hp, want_argmax=True, argmax_out=st["chunk"][i], hoisted=st["hoisted"])
+                    _, tc = ops.head_logp_step(hc, c, e, hp, want_argmax=True, argmax_out=st["chunk"][i], hoisted=st["hoisted"],
+                                               tables=st.get("tables") if st["hoisted"] else None, tok=tin)
                 st["h"].copy_(hc)
                 st["tok"].copy_(tc)
             st["graph"] = g
@@ -188,7 +196,7 @@ class Seq2SeqBase(nn.Module):
         if graphed:
             st, dp, hp, emb = self._decode_state("beam", enc, mask, k, max_length)
             enc_s, pe, mask_s, prep = st["enc"], st["pe"], st["mask"], st["prep"]
-            hoisted, keys = st["hoisted"], st.get("keys")
+            hoisted, keys, tables = st["hoisted"], st.get("keys"), st.get("tables")
         else:
             pe = ops.KeysProj.apply(enc, dec.attn.attn_e.weight)
             dp, hp, emb = dec.dec_params(), dec.head_params(), dec.embedding.weight
@@ -196,15 +204,16 @@ class Seq2SeqBase(nn.Module):
             enc_s, mask_s = enc, mask
             hoisted = self.decode_hoisted and ops.decode_hoisted_ok(B * k, emb, dp, hp)
             keys = ops.decode_keys(enc, prep, hp) if hoisted else None
+            tables = ops.decode_tables(emb, dp, hp) if hoisted else None
         h_next = st["h"] if graphed else torch.empty(B * k, H, dtype=torch.float32, device=dev)
         steps = 0
         for di in range(max_length):
             rps = 1 if di == 0 else k
             if hoisted:
-                h, c, e, _ = ops.decode_step_h(pe, mask_s, keys, rps, tok, h, emb, dp, prep)
+                h, c, e, _ = ops.decode_step_h(pe, mask_s, keys, rps, tok, h, emb, dp, prep, tables=tables)
             else:
                 h, c, e, _ = ops.decode_step(enc_s, pe, mask_s, rps, tok, h, emb, dp, prep)
-            logp, _ = ops.head_logp_step(h, c, e, hp, hoisted=hoisted)
+            logp, _ = ops.head_logp_step(h, c, e, hp, hoisted=hoisted, tables=tables if hoisted else None, tok=tok)
             call("vag_beam_step", ptr(logp), logp.shape[1], ptr(nll), ptr(beam, torch.int64), di, max_length, ptr(h),
                  ptr(h_next), B, k, V, H, ptr(n_alive, torch.int32), scratch.data_ptr(), stream())
             steps = di + 1
@@ -236,16 +245,17 @@ class Seq2SeqBase(nn.Module):
                 with _lib.capture(g):
                     for _ in range(CH):
                         if hoisted:
-                            h2, c, e, _ = ops.decode_step_h(pe, mask_s, keys, k, st["tok"], st["h"], emb, dp, prep)
+                            h2, c, e, _ = ops.decode_step_h(pe, mask_s, keys, k, st["tok"], st["h"], emb, dp, prep, tables=tables)
                         else:
                             h2, c, e, _ = ops.decode_step(enc_s, pe, mask_s, k, st["tok"], st["h"], emb, dp, prep)
                         if nparts > 0:
-                            logits, parts = ops.head_logits_step(h2, c, e, hp, nparts, hoisted=hoisted)
+                            logits, parts = ops.head_logits_step(h2, c, e, hp, nparts, hoisted=hoisted,
+                                                                 tables=tables if hoisted else None, tok=st["tok"])
                             call("vag_beam_step_logits_dev", ptr(logits), logits.shape[1], ptr(parts), nparts, ptr(nll),
                                  ptr(beam, torch.int64), ptr(st["di"], torch.int32), max_length, ptr(h2), ptr(st["h"]),
                                  ptr(st["tok"], torch.int64), B, k, V, H, ptr(n_alive, torch.int32), scratch.data_ptr(), stream())
                             continue
-                        logp, _ = ops.head_logp_step(h2, c, e, hp, hoisted=hoisted)
+                        logp, _ = ops.head_logp_step(h2, c, e, hp, hoisted=hoisted, tables=tables if hoisted else None, tok=st["tok"])
                         call("vag_beam_step_dev", ptr(logp), logp.shape[1], ptr(nll), ptr(beam, torch.int64),
                              ptr(st["di"], torch.int32), max_length, ptr(h2), ptr(st["h"]), ptr(st["tok"], torch.int64),
                              B, k, V, H, ptr(n_alive, torch.int32), scratch.data_ptr(), stream())

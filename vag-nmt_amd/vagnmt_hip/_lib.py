@@ -80,9 +80,11 @@ PROTOS = {
     "vag_cgru_attn_decode_step": (I32, [P, P, P, I64, P, P, DecW, P, I64, I64, I64, I64, P, P, P, P, P, P]),
     "vag_cgru_decode_keys_floats": (I64, [I64, I64, I64, I64]),
     "vag_cgru_decode_keys": (I32, [P, P, P, I64, I64, I64, I64, P, P]),
-    "vag_cgru_attn_decode_step_h": (I32, [P, P, P, I64, P, P, DecW, P, I64, I64, I64, I64, P, P, P, P, P, P]),
-    "vag_head_logp_step_h": (I32, [P, P, P, HeadW, I64, I64, I64, I64, P, I64, P, P, P]),
-    "vag_head_logits_step_h": (I32, [P, P, P, HeadW, I64, I64, I64, I64, P, I64, P, P, P]),
+    "vag_cgru_decode_tables_floats": (I64, [I64, I64, I64]),
+    "vag_cgru_decode_tables": (I32, [DecW, P, I64, I64, I64, P, P]),
+    "vag_cgru_attn_decode_step_h": (I32, [P, P, P, P, I64, I64, P, P, DecW, P, I64, I64, I64, I64, P, P, P, P, P, P]),
+    "vag_head_logp_step_h": (I32, [P, P, P, P, P, HeadW, I64, I64, I64, I64, P, I64, P, P, P]),
+    "vag_head_logits_step_h": (I32, [P, P, P, P, P, HeadW, I64, I64, I64, I64, P, I64, P, P, P]),
     "vag_head_ce_seq_fwd": (I32, [P, P, P, HeadW, P, P, I64, I64, I64, I64, I64, F, P, I32, P, P, I64, P, P, P, P, P]),
     "vag_head_ce_seq_bwd": (I32, [P, P, P, HeadW, P, P, I64, I64, I64, I64, I64, F, P, P, P, I64, P, P, P, P, P, P,
                                   HeadW, P, P]),

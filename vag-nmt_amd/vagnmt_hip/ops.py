@@ -489,19 +489,37 @@ def decode_keys(enc, prep, head):
     return keys
 
 
-def decode_step_h(pe, mask, keys, rows_per_src, tok, h_in, emb, dec, prep):
-    """One cGRU step for N hypotheses in the hoisted form -> (h_out (N,H), cw (N,E) = W2 c, e (N,E), alpha (N,Ts))."""
+DECODE_TABLES_MAX_BYTES = 256 << 20
+
+
+def decode_tables(emb, dec, head):
+    """Once per decode call: [emb W_ih1^T + b_ih1 (V,3H) | emb W3^T (V,E)] -- what a step needs of a token, for every vocabulary
+    entry (the free-running recurrence kernel's tables).  None when they would exceed DECODE_TABLES_MAX_BYTES."""
+    V, E = emb.shape
+    H = dec[1].shape[1]
+    n = L.lib().vag_cgru_decode_tables_floats(V, E, H)
+    if 4 * n > DECODE_TABLES_MAX_BYTES:
+        return None
+    tables = _f32(n, like=emb)
+    call("vag_cgru_decode_tables", _dec_w(emb, dec), ptr(head[4]), V, E, H, ptr(tables), stream())
+    return tables
+
+
+def decode_step_h(pe, mask, keys, rows_per_src, tok, h_in, emb, dec, prep, tables=None):
+    """One cGRU step for N hypotheses in the hoisted form -> (h_out (N,H), cw (N,E) = W2 c, e (N,E) or None with tables,
+    alpha (N,Ts))."""
     B, Ts, Cc = pe.shape
     H = Cc // 2
     E = emb.shape[1]
     N = tok.numel()
     h_out = _f32(N, H, like=pe)
     cw = _f32(N, E, like=pe)
-    e = _f32(N, E, like=pe)
+    e = _f32(N, E, like=pe) if tables is None else None
     alpha = _f32(N, Ts, like=pe)
     scratch = _f32(L.lib().vag_cgru_step_scratch_floats(N, Ts, E, H), like=pe)
-    call("vag_cgru_attn_decode_step_h", ptr(pe), ptr(mask), ptr(keys), rows_per_src, ptr(_c(tok).view(-1), I64), ptr(_c(h_in)),
-         _dec_w(emb, dec), ptr(prep), N, Ts, E, H, ptr(h_out), ptr(cw), ptr(e), ptr(alpha), ptr(scratch), stream())
+    call("vag_cgru_attn_decode_step_h", ptr(pe), ptr(mask), ptr(keys), ptr(tables) if tables is not None else None, emb.shape[0],
+         rows_per_src, ptr(_c(tok).view(-1), I64), ptr(_c(h_in)), _dec_w(emb, dec), ptr(prep), N, Ts, E, H, ptr(h_out), ptr(cw),
+         ptr(e) if e is not None else None, ptr(alpha), ptr(scratch), stream())
     return h_out, cw, e, alpha
 
 
@@ -549,26 +567,31 @@ def head_logits_parts_count(head, N, E, V):
     return int(L.lib().vag_head_logits_parts_count(_head_w(head), N, E, V))
 
 
-def head_logits_step(h2, c, e, head, nparts, hoisted=False):
+def head_logits_step(h2, c, e, head, nparts, hoisted=False, tables=None, tok=None):
     """Raw logits (N, ldl) of one decoding step and the (N, nparts, 2) pieces of their rows' log-sum-exp (beam search on raw
     logits: vag_beam_step_logits_dev)."""
     N, H = h2.shape
-    E = e.shape[1]
+    E = head[4].shape[0]
     V = head[7].shape[0]
     ldl = (V + 3) // 4 * 4
     logits = _f32(N, ldl, like=h2)
     parts = _f32(nparts, N, 2, like=h2)
     scratch = _f32(2 * N * E, like=h2)
-    call("vag_head_logits_step_h" if hoisted else "vag_head_logits_step", ptr(h2), ptr(c), ptr(e), _head_w(head), N, E, H, V,
-         ptr(logits), ldl, ptr(parts), ptr(scratch), stream())
+    if hoisted:
+        call("vag_head_logits_step_h", ptr(h2), ptr(c), ptr(e) if e is not None else None,
+             ptr(tables) if tables is not None else None, ptr(_c(tok).view(-1), I64) if tables is not None else None,
+             _head_w(head), N, E, H, V, ptr(logits), ldl, ptr(parts), ptr(scratch), stream())
+    else:
+        call("vag_head_logits_step", ptr(h2), ptr(c), ptr(e), _head_w(head), N, E, H, V, ptr(logits), ldl, ptr(parts),
+             ptr(scratch), stream())
     return logits, parts
 
 
-def head_logp_step(h2, c, e, head, want_argmax=False, argmax_out=None, hoisted=False):
+def head_logp_step(h2, c, e, head, want_argmax=False, argmax_out=None, hoisted=False, tables=None, tok=None):
     """argmax_out: optional (N,) int64 HIP tensor the arg-max tokens are written into (greedy decode hands in a row of its token
     chunk, which saves a copy launch per step)."""
     N, H = h2.shape
-    E = e.shape[1]
+    E = head[4].shape[0]
     V = head[7].shape[0]
     ldl = (V + 3) // 4 * 4
     logp = _f32(N, ldl, like=h2)
@@ -577,8 +600,13 @@ def head_logp_step(h2, c, e, head, want_argmax=False, argmax_out=None, hoisted=F
         am = argmax_out if argmax_out is not None else torch.empty(N, dtype=I64, device=h2.device)
         assert am.dtype == I64 and am.is_contiguous() and am.numel() == N
     scratch = _f32(2 * N * E, like=h2)
-    call("vag_head_logp_step_h" if hoisted else "vag_head_logp_step", ptr(h2), ptr(c), ptr(e), _head_w(head), N, E, H, V,
-         ptr(logp), ldl, ptr(am, I64) if am is not None else None, ptr(scratch), stream())
+    if hoisted:
+        call("vag_head_logp_step_h", ptr(h2), ptr(c), ptr(e) if e is not None else None,
+             ptr(tables) if tables is not None else None, ptr(_c(tok).view(-1), I64) if tables is not None else None,
+             _head_w(head), N, E, H, V, ptr(logp), ldl, ptr(am, I64) if am is not None else None, ptr(scratch), stream())
+    else:
+        call("vag_head_logp_step", ptr(h2), ptr(c), ptr(e), _head_w(head), N, E, H, V, ptr(logp), ldl,
+             ptr(am, I64) if am is not None else None, ptr(scratch), stream())
     return logp, am
 
 
