@@ -57,19 +57,6 @@ __device__ __forceinline__ float quad_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
     return v;
 }
-// the same over each 32-lane half of the wave (lanes 0-31 / 32-63): without the last exchange
-template <bool MAX>
-__device__ __forceinline__ float half_allreduce(float v) {
-#define VAG_DPP_ROR(N) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (N), 0xf, 0xf, false))
-    { const float o = VAG_DPP_ROR(8); v = MAX ? fmaxf(v, o) : v + o; }
-    { const float o = VAG_DPP_ROR(4); v = MAX ? fmaxf(v, o) : v + o; }
-    { const float o = VAG_DPP_ROR(2); v = MAX ? fmaxf(v, o) : v + o; }
-    { const float o = VAG_DPP_ROR(1); v = MAX ? fmaxf(v, o) : v + o; }
-#undef VAG_DPP_ROR
-    float a = v, b = v;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    return MAX ? fmaxf(a, b) : a + b;
-}
 __device__ __forceinline__ float wave_sum(float v) { return wave_allreduce<false>(v); }
 __device__ __forceinline__ float wave_max(float v) { return wave_allreduce<true>(v); }
 // tanh / sigmoid on the v_exp_f32 path; absolute error ~1e-7, saturates cleanly at +-1 / 0,1.
@@ -167,8 +154,7 @@ int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
 int vag_attn_dot_side_launch(int mode, const float* x, const float* q, int64_t ldq, const float* v, const float* mask,
                              const float* addend, int64_t N, int64_t Ts, int64_t W, float* out, int64_t M, int64_t Np,
                              int64_t K, const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* pbias,
-                             const float* padd, float* P, int64_t ldp, hipStream_t stream, bool s16 = false,   // s16: x and Wt fp16
-                             int64_t rps = 1);                                                                  // query rows per source row
+                             const float* padd, float* P, int64_t ldp, hipStream_t stream, bool s16 = false);   // s16: x and Wt fp16
 int vag_skinny_gather_launch(int64_t M, int64_t N, int64_t K, const float* table, int64_t ldt, const int64_t* idx, const float* W,
                              int64_t ldw, const float* bias, float* out, int64_t ldo, float* gathered, int64_t ldg,
                              hipStream_t stream);

@@ -1262,7 +1262,6 @@ struct DotArgs {
     const float* v; const float* mask;                                     // MODE 0: out = v . tanh(x + q), masked to -inf
     int64_t ldq;
     int Ts, W, gx, nscore;
-    int rps = 1;               // query rows per source row (beam search: the k hypotheses of a sentence share its keys and mask)
 };
 // DS_WAVES waves per block: that many (row, position) pairs, or the K split of one product tile
 // S16: 2-byte storage mode -- the streamed operand x (attention keys / projected keys) and the side product's weights
@@ -1283,7 +1282,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void attn_dot_side_kernel(DotArgs d,
     const int s = (id % d.gx) * DS_WAVES + (threadIdx.x >> 6);
     if (s >= d.Ts) return;
     const int64_t n = id / d.gx;
-    const int64_t xrow = ((n / d.rps) * d.Ts + s) * d.W;
+    const int64_t xrow = (n * d.Ts + s) * d.W;
     const float* qr = d.q + n * d.ldq;
     float acc = 0.f;
     for (int c = lane * 4; c < d.W; c += 256) {
@@ -1302,7 +1301,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void attn_dot_side_kernel(DotArgs d,
     acc = wave_sum(acc);
     if (lane == 0) {
         if (d.addend) acc += d.addend[n * d.Ts + s];
-        if (MODE == 0 && d.mask && d.mask[(n / d.rps) * d.Ts + s] == 0.f) acc = -INFINITY;
+        if (MODE == 0 && d.mask && d.mask[n * d.Ts + s] == 0.f) acc = -INFINITY;
         d.out[n * d.Ts + s] = acc;
     }
 }
@@ -1359,11 +1358,11 @@ __global__ __launch_bounds__(64 * DS_WAVES) void attn_dot_side_reg_kernel(DotArg
     auto put = [&](int s, float acc) {
         if (lane == 0) {
             if (d.addend) acc += d.addend[n * d.Ts + s];
-            if (MODE == 0 && d.mask && d.mask[(n / d.rps) * d.Ts + s] == 0.f) acc = -INFINITY;
+            if (MODE == 0 && d.mask && d.mask[n * d.Ts + s] == 0.f) acc = -INFINITY;
             d.out[n * d.Ts + s] = acc;
         }
     };
-    const int64_t xbase = (n / d.rps) * d.Ts * (int64_t)d.W + 8 * lane;
+    const int64_t xbase = n * d.Ts * (int64_t)d.W + 8 * lane;
     int s = s0 + wave;
     for (; s + DS_WAVES < s1; s += 2 * DS_WAVES) {                   // two positions in flight
         float x0[NJ][8], x1[NJ][8];
@@ -1388,13 +1387,12 @@ __global__ __launch_bounds__(64 * DS_WAVES) void attn_dot_side_reg_kernel(DotArg
 int vag_attn_dot_side_launch(int mode, const float* x, const float* q, int64_t ldq, const float* v, const float* mask,
                              const float* addend, int64_t N, int64_t Ts, int64_t W, float* out, int64_t M, int64_t Np,
                              int64_t K, const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* pbias,
-                             const float* padd, float* P, int64_t ldp, hipStream_t stream, bool s16, int64_t rps) {
+                             const float* padd, float* P, int64_t ldp, hipStream_t stream, bool s16) {
     VAG_CHECK_ARG(x && q && out && N > 0 && Ts > 0 && W > 0 && W % 4 == 0 && ldq % 4 == 0 && aligned16(x) && aligned16(q));
     VAG_CHECK_ARG((mode == 1 || (mode == 0 && v && aligned16(v))) && A && Wt && P && M > 0 && Np > 0 &&
                   skinny_ok(A, lda, Wt, ldw, K));
     DotArgs d;
-    VAG_CHECK_ARG(rps >= 1 && N % rps == 0);
-    d.x = x; d.q = q; d.addend = addend; d.out = out; d.v = v; d.mask = mask; d.ldq = ldq; d.Ts = (int)Ts; d.W = (int)W; d.rps = (int)rps;
+    d.x = x; d.q = q; d.addend = addend; d.out = out; d.v = v; d.mask = mask; d.ldq = ldq; d.Ts = (int)Ts; d.W = (int)W;
     const int DS_WAVES = mode == 0 ? 8 : 16;        // measured: forward side product K = H, backward K = 3H
     d.gx = (int)cdiv64(Ts, DS_WAVES);
     VAG_CHECK_ARG((int64_t)d.gx * N < (1ll << 30));
