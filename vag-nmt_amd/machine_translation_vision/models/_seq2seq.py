@@ -120,12 +120,12 @@ class Seq2SeqBase(nn.Module):
         st["mask"][:, :Ts].copy_(mask)
         st["prep"].copy_(ops.decode_prepare(emb, dp))
         if hoisted:
-            st["keys"].copy_(ops.decode_keys(st["enc"], st["prep"], hp))
-            tb = ops.decode_tables(emb, dp, hp)             # per call: the weights may have changed since the last one
-            if tb is not None and st.get("tables") is not None:
-                st["tables"].copy_(tb)
-            elif st["graph"] is None:
-                st["tables"] = tb                           # (a captured graph keeps the choice it was captured with)
+            ops.decode_keys(st["enc"], st["prep"], hp, out=st["keys"])
+            # per call: the weights may have changed since the last one (same storage: captured graphs keep their pointers)
+            if "tables" not in st:
+                st["tables"] = ops.decode_tables(emb, dp, hp)
+            elif st["tables"] is not None:
+                ops.decode_tables(emb, dp, hp, out=st["tables"])
         return st, dp, hp, emb
 
     def _greedy(self, enc, mask, h, tgt_l):

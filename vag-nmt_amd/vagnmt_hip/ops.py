@@ -479,12 +479,12 @@ def decode_hoisted_ok(N, emb, dec, head):
     return N <= 256 and E % 4 == 0 and H % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in ts)
 
 
-def decode_keys(enc, prep, head):
+def decode_keys(enc, prep, head, out=None):
     """Once per decode call: [(W_ih2 W_c2h) enc | enc W2^T], what a hoisted decoding step needs of the source side."""
     B, Ts, Cc = enc.shape
     H = Cc // 2
     E = head[2].shape[0]
-    keys = _f32(L.lib().vag_cgru_decode_keys_floats(B, Ts, E, H), like=enc)
+    keys = out if out is not None else _f32(L.lib().vag_cgru_decode_keys_floats(B, Ts, E, H), like=enc)
     call("vag_cgru_decode_keys", ptr(_c(enc)), ptr(prep), ptr(head[2]), B, Ts, E, H, ptr(keys), stream())
     return keys
 
@@ -492,15 +492,16 @@ def decode_keys(enc, prep, head):
 DECODE_TABLES_MAX_BYTES = 256 << 20
 
 
-def decode_tables(emb, dec, head):
+def decode_tables(emb, dec, head, out=None):
     """Once per decode call: [emb W_ih1^T + b_ih1 (V,3H) | emb W3^T (V,E)] -- what a step needs of a token, for every vocabulary
-    entry (the free-running recurrence kernel's tables).  None when they would exceed DECODE_TABLES_MAX_BYTES."""
+    entry (the free-running recurrence kernel's tables).  None when they would exceed DECODE_TABLES_MAX_BYTES.  out: a buffer of
+    an earlier call to fill instead of a new one."""
     V, E = emb.shape
     H = dec[1].shape[1]
     n = L.lib().vag_cgru_decode_tables_floats(V, E, H)
     if 4 * n > DECODE_TABLES_MAX_BYTES:
         return None
-    tables = _f32(n, like=emb)
+    tables = out if out is not None else _f32(n, like=emb)
     call("vag_cgru_decode_tables", _dec_w(emb, dec), ptr(head[4]), V, E, H, ptr(tables), stream())
     return tables
 
