@@ -373,25 +373,28 @@ def measure_extras(c, dev, ts, args):
     m4.eval()
     src, lens, _, im = make_batch(c4, 0, dev, ragged=True)
     for k, key in ((12, "beam12_decode"), (1, "greedy_decode")):
-        for _ in range(2):
-            m4.beamsearch_decode(src, lens, im, k, 80)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = 3
-        for _ in range(n):
-            hyp = m4.beamsearch_decode(src, lens, im, k, 80)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n
-        steps = int(getattr(m4, "last_decode_steps", 80))
-        one_launch = k == 1 and getattr(m4, "decode_persistent", False) and bool(
-            L.lib().vag_cgru_free_supported(16, src.shape[1], 80, c4["E"], c4["H"], c4["V"]))
-        out[key] = {"sentences_per_s": 16 / dt, "ms_per_batch": dt * 1e3, "eval_batch": 16, "max_length": 80,
-                    "mean_hyp_len": sum(len(h) for h in hyp) / 16.0, "decoder_steps_run": steps, "us_per_step": dt / steps * 1e6,
-                    "path": ("all steps in ONE launch: dec_fwd_persistent_kernel<true> forms the head, the logits of its vocabulary "
-                             "tiles and the arg-max itself (persist.hip)") if one_launch else
-                            "one captured graph of 8 decoder steps (8 launches per step: hoisted step on per-call key and token tables, raw-logit expansion), replayed",
-                    "note": "beam search stops once every hypothesis has emitted EOS (V11.py:266-269)",
-                    "roofline": decode_roofline(c4, lens, k, dt / steps)}
+        try:                                    # (a row that fails becomes an "error" entry; the other rows stand)
+            for _ in range(2):
+                m4.beamsearch_decode(src, lens, im, k, 80)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 3
+            for _ in range(n):
+                hyp = m4.beamsearch_decode(src, lens, im, k, 80)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            steps = int(getattr(m4, "last_decode_steps", 80))
+            one_launch = k == 1 and getattr(m4, "decode_persistent", False) and bool(
+                L.lib().vag_cgru_free_supported(16, src.shape[1], 80, c4["E"], c4["H"], c4["V"]))
+            out[key] = {"sentences_per_s": 16 / dt, "ms_per_batch": dt * 1e3, "eval_batch": 16, "max_length": 80,
+                        "mean_hyp_len": sum(len(h) for h in hyp) / 16.0, "decoder_steps_run": steps, "us_per_step": dt / steps * 1e6,
+                        "path": ("all steps in ONE launch: dec_fwd_persistent_kernel<true> forms the head, the logits of its vocabulary "
+                                 "tiles and the arg-max itself (persist.hip)") if one_launch else
+                                "one captured graph of 8 decoder steps (8 launches per step: hoisted step on per-call key and token tables, raw-logit expansion), replayed",
+                        "note": "beam search stops once every hypothesis has emitted EOS (V11.py:266-269)",
+                        "roofline": decode_roofline(c4, lens, k, dt / steps)}
+        except Exception as e:   # noqa: BLE001
+            out[key] = {"error": repr(e)[:300]}
     m4.train(was)
     # configs[4] in its 2-byte storage mode on a driver of its own; a failure here must not take the headline line down
     from vagnmt_hip.trainer import TrainStep
@@ -803,13 +806,23 @@ def main():
         if dp_info is not None:
             res["dp"] = dp_info
         if world == 1 and not args.no_extras:
-            res["copy_bandwidth"] = measure_copy_bandwidth(dev)
-            res["mfma"] = measure_dense(c, dev)
+            # the rows beside the headline must never take the headline line down: a failure becomes an "error" entry
+            def guarded(key, fn):
+                try:
+                    res[key] = fn()
+                except Exception as e:   # noqa: BLE001
+                    res[key] = {"error": repr(e)[:300]}
+                    log("%s failed: %r" % (key, e))
+            guarded("copy_bandwidth", lambda: measure_copy_bandwidth(dev))
+            guarded("mfma", lambda: measure_dense(c, dev))
             if args.config == "cfg2" and not args.no_graph and not args.no_fused:
-                res["extra"] = measure_extras(c, dev, ts, args)
+                guarded("extra", lambda: measure_extras(c, dev, ts, args))
             log("extras done")
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
-            res["cpu_baseline"] = cpu_baseline(c)
+            try:
+                res["cpu_baseline"] = cpu_baseline(c)
+            except Exception as e:   # noqa: BLE001
+                res["cpu_baseline"] = {"error": repr(e)[:300]}
         print(json.dumps(res))
     if world > 1:
         import torch.distributed as dist
