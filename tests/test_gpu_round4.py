@@ -290,3 +290,39 @@ def test_beam_search_on_raw_logits_equals_the_log_softmax_path():
     assert res[True][0] == res[False][0]
     assert np.allclose(res[True][1], res[False][1], rtol=1e-5, atol=1e-5)
     assert any(len(h) < L - 1 for h in res[True][0])
+
+
+def test_cached_decoding_tables_follow_the_weights():
+    """What decoding derives from the weights alone (stacked decoder matrices, per-token tables) is kept between decode calls.
+    It must be rebuilt after an optimiser step of the step driver (which writes the parameters through the flat buffer, unseen by
+    torch's version counters) and after an in-place write from outside: decoding with the kept buffers == decoding with the
+    caches dropped."""
+    m, ts = _driver(seed=8, lr=0.05)
+    src, lens, tgt, im = _batch(31, B=16, Ts=9, Tt=5)
+
+    def decode(k):
+        m.eval()
+        hyp = [[int(t) for t in h] for h in m.beamsearch_decode(src, lens, im, k, 12)]
+        sc = m.last_beam_scores.cpu().numpy().copy() if k > 1 else None
+        return hyp, sc
+
+    def fresh(k):
+        m.__dict__.pop("_decode_wcache", None)
+        m.__dict__.pop("_decode_cache", None)
+        return decode(k)
+
+    first = decode(3)
+    for _ in range(3):
+        ts.step(src, lens, tgt, im, teacher=True)            # large learning rate: the weights really move
+    got, want = decode(3), fresh(3)
+    # (not bitwise: the tables come out of split-K products whose atomics land in a run-dependent order)
+    assert got[0] == want[0] and np.allclose(got[1], want[1], rtol=0, atol=1e-5)
+    assert not np.allclose(first[1], got[1], rtol=0, atol=1e-2)       # (the steps did change what decoding sees, grossly)
+    with torch.no_grad():
+        m.decoder.embedding.weight.mul_(1.5)                  # tied output / input embedding: tables and head both depend on it
+    stale = got[1]
+    got, want = decode(3), fresh(3)
+    assert got[0] == want[0] and np.allclose(got[1], want[1], rtol=0, atol=1e-5)
+    assert not np.allclose(stale, got[1], rtol=0, atol=1e-2)
+    gg, gw = decode(1), fresh(1)                              # the graphed greedy path (E = 32: not the one-launch form)
+    assert gg[0] == gw[0]

@@ -90,6 +90,34 @@ class Seq2SeqBase(nn.Module):
     decode_raw_logits = True      # beam search: expansion on raw logits + log-sum-exp pieces (no normalising pass) where available
     decode_hoisted = True         # decoding steps on keys projected once per call (4 launches, no context): ops.decode_step_h
 
+    def _decode_weights(self, dp, hp, emb, hoisted):
+        """What decoding derives from the WEIGHTS alone -- the stacked / folded decoder matrices (ops.decode_prepare) and, for
+        the hoisted step, the per-token tables (ops.decode_tables) -- shared by every decode shape and kept until the weights
+        change: an optimiser step of the step driver bumps ``_vag_weights_version``, anything else that writes a parameter in
+        place bumps the tensor's own version counter, a re-assigned parameter has another address.  Refreshed in place, so the
+        captured graphs that read these buffers stay valid."""
+        ts = list(dp) + list(hp) + [emb]
+        ptrs = tuple(t.data_ptr() for t in ts) + (hoisted,)
+        ver = (getattr(self, "_vag_weights_version", 0),) + tuple(int(t._version) for t in ts)
+        wc = self.__dict__.setdefault("_decode_wcache", {})
+        e = wc.get(ptrs)
+        if e is None:
+            if len(wc) >= 4:
+                wc.clear()
+                self.__dict__.pop("_decode_cache", None)          # (their graphs point at the buffers just dropped)
+            H = dp[1].shape[1]
+            e = {"prep": torch.empty(_lib.lib().vag_cgru_prep_floats(H), device=emb.device), "tables": None, "ver": None}
+            wc[ptrs] = e
+        if e["ver"] != ver:
+            e["prep"].copy_(ops.decode_prepare(emb, dp))
+            if hoisted:
+                if e["ver"] is None:
+                    e["tables"] = ops.decode_tables(emb, dp, hp)
+                elif e["tables"] is not None:
+                    ops.decode_tables(emb, dp, hp, out=e["tables"])
+            e["ver"] = ver
+        return e
+
     def _decode_state(self, kind, enc, mask, k, max_length):
         """Static buffers (+ captured graph, filled in by the caller) for one decode shape; refreshed per call."""
         dec = self.decoder
@@ -99,6 +127,7 @@ class Seq2SeqBase(nn.Module):
         dp, hp, emb = dec.dec_params(), dec.head_params(), dec.embedding.weight
         Tp = (Ts + 7) // 8 * 8
         hoisted = self.decode_hoisted and ops.decode_hoisted_ok(B * k, emb, dp, hp)
+        wd = self._decode_weights(dp, hp, emb, hoisted)
         key = (kind, B, k, Tp, max_length, self.decode_raw_logits, hoisted) + \
             tuple(t.data_ptr() for t in list(dp) + list(hp) + [emb, dec.attn.attn_e.weight])
         cache = self.__dict__.setdefault("_decode_cache", {})
@@ -109,7 +138,7 @@ class Seq2SeqBase(nn.Module):
             st = {"enc": torch.zeros(B, Tp, C, device=dev), "pe": torch.zeros(B, Tp, C, device=dev),
                   "mask": torch.zeros(B, Tp, device=dev), "h": torch.empty(B * k, H, device=dev),
                   "tok": torch.empty(B * k, dtype=torch.int64, device=dev),
-                  "prep": torch.empty(_lib.lib().vag_cgru_prep_floats(H), device=dev), "graph": None, "hoisted": hoisted}
+                  "prep": wd["prep"], "tables": wd["tables"], "graph": None, "hoisted": hoisted}
             if hoisted:
                 st["keys"] = torch.empty(_lib.lib().vag_cgru_decode_keys_floats(B, Tp, emb.shape[1], H), device=dev)
             cache[key] = st
@@ -118,14 +147,8 @@ class Seq2SeqBase(nn.Module):
         st["enc"][:, :Ts].copy_(enc)
         st["pe"][:, :Ts].copy_(ops.KeysProj.apply(enc, dec.attn.attn_e.weight))
         st["mask"][:, :Ts].copy_(mask)
-        st["prep"].copy_(ops.decode_prepare(emb, dp))
         if hoisted:
             ops.decode_keys(st["enc"], st["prep"], hp, out=st["keys"])
-            # per call: the weights may have changed since the last one (same storage: captured graphs keep their pointers)
-            if "tables" not in st:
-                st["tables"] = ops.decode_tables(emb, dp, hp)
-            elif st["tables"] is not None:
-                ops.decode_tables(emb, dp, hp, out=st["tables"])
         return st, dp, hp, emb
 
     def _greedy(self, enc, mask, h, tgt_l):

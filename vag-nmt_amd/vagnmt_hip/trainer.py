@@ -240,6 +240,9 @@ class TrainStep:
     # ---- public ----
     def step(self, src, lengths, tgt, im=None, teacher=None):
         self.model.train()
+        # the optimiser kernels write the parameters through the flat buffer: torch's version counters do not see that.  What is
+        # cached per set of weights (the decoding tables of models._seq2seq) looks at this counter as well.
+        self.model._vag_weights_version = getattr(self.model, "_vag_weights_version", 0) + 1
         if teacher is None:
             teacher = random.random() < self.tfr                     # models/...V11.py:136
         if not torch.is_tensor(lengths):
