@@ -174,6 +174,7 @@ class TrainStep:
 
     def _run_optimizer(self):
         """Clip + Adam (+ derived-weight refresh) replayed from a small graph of its own (one graph: the rate is a device word)."""
+        self.model._vag_weights_version = getattr(self.model, "_vag_weights_version", 0) + 1      # (see step())
         if not (self.use_graph and self.fp.flat.is_cuda) or hasattr(self.backend, "optimizer"):
             return self._optimizer()
         key = ("opt",)
