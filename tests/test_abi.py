@@ -35,6 +35,23 @@ def test_workspace_size_queries_are_pure_host_calls():
     assert L.vag_cgru_bwd_scratch_floats(64, 40, 40, 256, 512) > 0
     assert L.vag_beam_scratch_bytes(16, 12, 9391, 80) > 0
     assert L.vag_imagine_ws_floats(64, 40, 1024, 512, 1) > L.vag_imagine_ws_floats(64, 40, 1024, 512, 0)
+    # round 4: scratch of the one-launch free-running decoder and of the hoisted decoding step
+    r = lambda n: (n + 63) // 64 * 64      # noqa: E731
+    assert L.vag_cgru_free_tables_floats(64, 40, 40, 256, 512, 9391) == \
+        r(9391 * 1536) + r(9391 * 256) + r(64 * 40 * 256) + r(2 * 40 * 64 * 64)
+    assert L.vag_cgru_decode_keys_floats(16, 40, 256, 512) == r(16 * 40 * 1536) + r(16 * 40 * 256)
+    assert L.vag_cgru_decode_tables_floats(9391, 256, 512) == r(9391 * 1536) + r(9391 * 256)
+    # the step workspace holds the free-running tables for shapes the one-launch form can take, and only for those
+    c = _lib.StepCfg()
+    c.B, c.Ts, c.Tt, c.Es, c.Et, c.H, c.S, c.I, c.V, c.ldl = 64, 40, 40, 256, 256, 512, 512, 2048, 9391, 9392
+    c.multimodal, c.rank_kind = 1, 0
+    import ctypes as C
+    a = L.vag_step_ws_floats(C.byref(c))
+    c.B = 65
+    b = L.vag_step_ws_floats(C.byref(c))
+    c.B, c.loss_ring = 64, 256
+    assert L.vag_step_ws_floats(C.byref(c)) == a          # (the result ring lives in the caller's `losses`, not in the workspace)
+    assert a > 0 and b > 0 and a - b * 64 // 65 > 9391 * 1536
 
 
 def test_argument_errors_are_negative_codes_not_crashes():
@@ -45,3 +62,15 @@ def test_argument_errors_are_negative_codes_not_crashes():
     assert L.vag_bigru_seq_fwd(None, None, None, _lib.GruW(), _lib.GruW(), 0.0, 0.0, None, 1, 1, 4, 4, None, None, None,
                                None) == -22
     assert L.vag_rank_loss_fwd(None, None, 4, 4, 0.1, 0, None, None, None, None) == -22
+    # round 4 entry points
+    assert L.vag_cgru_attn_decode_free_fwd(None, None, None, None, None, _lib.DecW(), 64, 40, 40, 256, 512, 9391, None, None, None,
+                                           None, None, 0.0, None, None, None, 0, None, None) == -22
+    assert L.vag_cgru_decode_keys(None, None, None, 16, 40, 256, 512, None, None) == -22
+    assert L.vag_cgru_decode_tables(_lib.DecW(), None, 9391, 256, 512, None, None) == -22
+    assert L.vag_cgru_attn_decode_step_h(None, None, None, None, 0, 1, None, None, _lib.DecW(), None, 16, 40, 256, 512, None, None,
+                                         None, None, None, None) == -22
+    assert L.vag_head_logits_step(None, None, None, _lib.HeadW(), 192, 256, 512, 9391, None, 9392, None, None, None) == -22
+    assert L.vag_beam_step_logits_dev(None, 9392, None, 147, None, None, None, 80, None, None, None, 16, 12, 9391, 512, None, None,
+                                      None) == -22
+    assert L.vag_head_logits_parts_count(_lib.HeadW(), 192, 256, 9391) == 0        # no weights: nothing to take
+    assert L.vag_cgru_free_supported(64, 40, 40, 256, 512, 9391) in (0, 1)          # (0 without a device: the CU count decides)
