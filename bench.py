@@ -396,6 +396,11 @@ def measure_extras(c, dev, ts, args):
         except Exception as e:   # noqa: BLE001
             out[key] = {"error": repr(e)[:300]}
     m4.train(was)
+    # the boundary as the reference's trainer reaches it
+    try:
+        out.update(measure_reference_trainer(c, dev))
+    except Exception as e:   # noqa: BLE001
+        out["reference_trainer_step"] = {"error": repr(e)[:300]}
     # configs[4] in its 2-byte storage mode on a driver of its own; a failure here must not take the headline line down
     from vagnmt_hip.trainer import TrainStep
     from machine_translation_vision.losses import PairwiseRankingLoss
@@ -430,6 +435,70 @@ def measure_extras(c, dev, ts, args):
             torch.cuda.empty_cache()
         except Exception as e:   # noqa: BLE001
             out["configs4_fp16_storage"] = {"error": repr(e)[:200]}
+    return out
+
+
+def measure_reference_trainer(c, dev, n=40, warm=6):
+    """The step as the reference's own trainer runs it (nmt_multimodal_beam_DE.py:394 -> train.py:36-51), timed wall-clock around
+    n calls that each return three Python floats (the reference synchronises every step, train.py:51), teacher forcing ratio 1.0
+    like the headline, the lengths as the Python list the batch generator hands over (preprocessing.py:384):
+      module_api_step         the literal train.py:38-51 sequence on the shadow model: model(...) through the per-operator
+                              autograd path, loss.backward(), clip_grad_norm_, torch.optim.Adam with the :303-313 groups, three .item()
+      reference_trainer_step  the same call through vag-nmt_amd/train.py's train_imagine_beam (what `python -m vagnmt_hip.run
+                              nmt_multimodal_beam_DE.py` reaches through `from train import *`): the fused step behind the reference's
+                              signature, the caller's optimiser object read every call"""
+    import random
+    import train as shim
+    from machine_translation_vision.losses import PairwiseRankingLoss
+    out = {}
+    src, lens, tgt, im = make_batch(c, 0, dev)
+
+    def setup():
+        m = build_model(c, dev)
+        vw = torch.ones(c["V"], device=dev)
+        vw[0] = 0
+        named = [(n_, p) for n_, p in m.named_parameters() if p.requires_grad]
+        opt = torch.optim.Adam([{"params": [p for n_, p in named if "bias" not in n_], "weight_decay": 1e-5},
+                                {"params": [p for n_, p in named if "bias" in n_]}], lr=4e-4)
+        return m, opt, torch.nn.NLLLoss(weight=vw, reduction="none"), PairwiseRankingLoss(margin=0.1)
+
+    def literal(m, opt, cm, cv):
+        m.train()
+        opt.zero_grad()
+        loss, loss_mt, loss_vse = m(src, lens, tgt, im, 1.0, criterion_mt=cm, criterion_vse=cv)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        return loss.data.item(), loss_mt.data.item(), loss_vse.data.item()
+
+    def timed(fn, n_):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n_ * 1e3, r
+    random.seed(4321)
+    m, opt, cm, cv = setup()
+    ms, r = timed(lambda: literal(m, opt, cm, cv), max(5, n // 4))
+    out["module_api_step"] = {"ms_per_step": ms, "pairs_per_s": c["B"] / ms * 1e3, "last_losses": list(r),
+                              "path": "train.py:38-51 literally: per-operator autograd path + clip_grad_norm_ + torch.optim.Adam "
+                                      "(two groups, nmt_multimodal_beam_DE.py:303-313) + three .item()"}
+    del m, opt
+    torch.cuda.empty_cache()
+    m, opt, cm, cv = setup()
+    ms, r = timed(lambda: shim.train_imagine_beam(src, tgt, im, lens, m, opt, cm, cv, 0.99, 1.0, clip=1.0), n)
+    d = getattr(opt, "_vag_driver", None)
+    out["reference_trainer_step"] = {"ms_per_step": ms, "pairs_per_s": c["B"] / ms * 1e3, "last_losses": list(r),
+                                     "fused": d is not None, "graph_stats": dict(d.ts.stats) if d is not None else None,
+                                     "path": "train.train_imagine_beam of vag-nmt_amd/train.py (reference signature, train.py:36; "
+                                             "three Python floats per call = one device sync per step) -> TrainStep -> vag_train_step"}
+    if d is not None:
+        d.ts.check()
+    del m, opt
+    torch.cuda.empty_cache()
     return out
 
 
@@ -817,6 +886,10 @@ def main():
             guarded("mfma", lambda: measure_dense(c, dev))
             if args.config == "cfg2" and not args.no_graph and not args.no_fused:
                 guarded("extra", lambda: measure_extras(c, dev, ts, args))
+            for k_ in ("module_api_step", "reference_trainer_step"):
+                row = res.get("extra", {}).get(k_) if isinstance(res.get("extra"), dict) else None
+                if row and "ms_per_step" in row:
+                    row["ms_over_headline"] = row["ms_per_step"] / res["ms_per_step"]
             log("extras done")
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
             try:

@@ -139,3 +139,50 @@ def test_resolution_against_a_synthetic_checkout(tmp_path):
     assert got["encoder"].startswith(PKG) and got["v2"].startswith(PKG)
     assert got["parts"][0].startswith(PKG) and got["parts"][1].startswith(PKG) and got["parts"][2].startswith(str(tmp_path))
     assert got["liumcvc_is_placeholder"] is True       # the stand-in lacks that file: a placeholder, as without a checkout
+
+
+TRAIN_PROBE = r'''
+import inspect, json
+from train import *
+import train as _t
+out = {k: inspect.getsourcefile(v) for k, v in list(globals().items())
+       if inspect.isfunction(v) and not k.startswith("_")}
+out["MAX_LENGTH"] = globals().get("MAX_LENGTH")
+out["sig_imagine"] = str(inspect.signature(train_imagine_beam))
+out["sig_nmt"] = str(inspect.signature(train_nmt))
+out["module"] = _t.__file__
+print("PROBE " + json.dumps(out))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference checkout")
+def test_from_train_import_star_resolves_the_two_step_functions_to_the_shim_and_the_rest_to_the_checkout(tmp_path):
+    """nmt_multimodal_beam_DE.py:16 / nmt_monomodal_beam_DE.py:20 do ``from train import *`` and call train_imagine_beam (:394) /
+    train_nmt (:320): under the launcher those two are this package's (the fused step), every other public name of the module
+    is the checkout's own object, and the two signatures are the checkout's."""
+    import ast
+    got = _run(TRAIN_PROBE, REF, tmp_path, extra_path=[REF])
+    assert got["module"] == os.path.join(PKG, "train.py")
+    assert got["train_imagine_beam"] == os.path.join(PKG, "train.py") and got["train_nmt"] == os.path.join(PKG, "train.py")
+    tree = ast.parse(open(os.path.join(REF, "train.py")).read())
+    ref_funcs = {n.name: n for n in tree.body if isinstance(n, ast.FunctionDef)}
+    for name in ref_funcs:
+        if name not in ("train_imagine_beam", "train_nmt"):
+            assert got[name] == os.path.join(REF, "train.py"), (name, got.get(name))
+    assert got["MAX_LENGTH"] == 40
+    for key, name in (("sig_imagine", "train_imagine_beam"), ("sig_nmt", "train_nmt")):
+        ours = [a.split("=")[0].strip() for a in got[key].strip("()").split(",")]
+        assert ours == [a.arg for a in ref_funcs[name].args.args], (ours, name)
+
+
+def test_train_shim_against_a_synthetic_checkout_and_without_one(tmp_path):
+    co = tmp_path / "checkout"
+    co.mkdir()
+    (co / "train.py").write_text("MAX_LENGTH = 40\nCLIP = 2.5\ndef random_sample_display(a, b):\n    return 'checkout'\n"
+                                 "def train_imagine_beam(*a, **k):\n    return 'checkout (must be shadowed)'\n")
+    got = _run(TRAIN_PROBE, str(tmp_path), tmp_path, extra_path=[str(co)])
+    assert got["train_imagine_beam"] == os.path.join(PKG, "train.py") and got["train_nmt"] == os.path.join(PKG, "train.py")
+    assert got["random_sample_display"] == str(co / "train.py") and got["MAX_LENGTH"] == 40
+    bare = _run(TRAIN_PROBE, str(tmp_path), tmp_path)            # no checkout at all: the two step functions only
+    assert bare["train_imagine_beam"] == os.path.join(PKG, "train.py") and "random_sample_display" not in bare
+    assert bare["MAX_LENGTH"] is None

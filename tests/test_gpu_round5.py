@@ -1,0 +1,187 @@
+"""GPU, round 5.
+
+(1) The reference's trainer, unchanged, on the fused step: ``train_imagine_beam`` / ``train_nmt`` of the shadow module
+    ``train`` (vag-nmt_amd/train.py; reference train.py:36-51, :19-32, called from nmt_multimodal_beam_DE.py:394) with the
+    reference's own optimiser objects (``optim.Adam`` over the :303-332 groups, ``ReduceLROnPlateau`` :335):
+    three steps at configs[1] size against the oracle, and at fixture size against the literal sequence on torch.optim.Adam.
+"""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from test_gpu_golden import build, criteria, close
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+LOSS_TOL, GRAD_TOL = 1e-4, 3e-4
+
+
+def _shim():
+    import train                      # vag-nmt_amd/train.py (conftest puts vag-nmt_amd on sys.path)
+    assert os.path.dirname(os.path.abspath(train.__file__)).endswith("vag-nmt_amd"), train.__file__
+    return train
+
+
+def _reference_optimizer(model, lr=4e-4, wd=1e-5, vse_separate=False):
+    """nmt_multimodal_beam_DE.py:303-332, as the script builds it."""
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    if not vse_separate:
+        groups = [{"params": [p for n, p in named if "bias" not in n], "weight_decay": wd},
+                  {"params": [p for n, p in named if "bias" in n]}]
+    else:
+        groups = [{"params": [p for n, p in named if "bias" not in n and "vse_imagine" not in n], "weight_decay": wd},
+                  {"params": [p for n, p in named if "bias" in n and "vse_imagine" not in n]},
+                  {"params": [p for n, p in named if "bias" not in n and "vse_imagine" in n], "weight_decay": wd, "lr": lr / 2},
+                  {"params": [p for n, p in named if "bias" in n and "vse_imagine" in n], "lr": lr / 2}]
+    return torch.optim.Adam(groups, lr=lr)
+
+
+def test_reference_trainer_three_steps_at_cfg2_match_oracle():
+    """train_imagine_beam through the shim = the benched fused step: losses 1e-4, clip norm 3e-4, parameters after each of
+    three Adam steps within the element-wise bound of test_gpu_benched_path (iii); dropout on, the kernels' masks handed to
+    the oracle."""
+    import bench
+    from machine_translation_vision.losses import PairwiseRankingLoss
+    from oracle import vag_oracle as O
+    from test_gpu_benched_path import _masks
+    T = _shim()
+    c = bench.CFG2
+    dev = torch.device("cuda", 0)
+    m = bench.build_model(c, dev, dropout=True)
+    vw = torch.ones(c["V"], device=dev)
+    vw[0] = 0
+    cm, cv = torch.nn.NLLLoss(weight=vw, reduction="none"), PairwiseRankingLoss(margin=0.1)
+    opt = _reference_optimizer(m)
+    src, lens, tgt, im = bench.make_batch(c, 0, dev)
+    P = {n: p.detach().cpu().clone() for n, p in m.named_parameters()}
+    state, acc = {}, {}
+    for i in range(3):
+        got = T.train_imagine_beam(src, tgt, im, lens, m, opt, cm, cv, 0.99, 1.0, clip=1.0)
+        assert len(got) == 3 and all(type(x) is float for x in got), got
+        ts = opt._vag_driver.ts
+        masks = _masks(m, c)
+        o, grads, total, P, state = O.train_step(P, src.cpu(), lens, tgt.cpu(), im.cpu(), teacher=True, state=state,
+                                                 masks=masks, hoist=True)
+        for k, g in zip(("loss", "loss_mt", "loss_vse"), got):
+            assert abs(g - float(o[k])) <= LOSS_TOL * max(1.0, abs(float(o[k]))), (i, k, g, float(o[k]))
+        assert abs(float(ts.grad_norm[0]) - float(total)) <= 3e-4 * float(total), (i, float(ts.grad_norm[0]), float(total))
+        bc2 = 1.0 - 0.999 ** (i + 1)
+        for n, p in m.named_parameters():
+            gmax = float(grads[n].abs().max()) * min(1.0, 1.0 / (float(total) + 1e-6))
+            vhat = (state[n][1] / bc2).sqrt()
+            acc[n] = acc.get(n, 0.0) + 4e-4 * torch.clamp(2 * GRAD_TOL * gmax / (vhat + 1e-8), max=1.0)
+            err = (p.detach().cpu() - P[n]).abs()
+            assert not bool((err > 2e-5 + acc[n]).any()), (i, n, float(err.max()))
+            assert float(err.mean()) <= 2e-5, (i, n, float(err.mean()))
+    ts = opt._vag_driver.ts
+    assert ts.stats["captures"] == 1 and ts.stats["replays"] >= 2 and int(ts.step_count.item()) == 3, ts.stats
+    assert type(ts.backend).__name__ == "_FusedBackend"
+    sd = opt.state_dict()                                    # Adam's state under torch's names: step count and moments
+    assert all(float(st["step"]) == 3.0 for st in sd["state"].values())
+    p0 = opt.param_groups[0]["params"][0]
+    assert opt.state[p0]["exp_avg"].data_ptr() >= ts.fp.m.data_ptr()
+    ts.check()
+
+
+def _literal(m, opt, cm, cv, batch, clip, mm):
+    """train.py:38-51 / :21-32 on the per-operator path with the caller's torch.optim.Adam."""
+    src, lens, tgt, im = batch
+    m.train()
+    opt.zero_grad()
+    if mm:
+        loss, loss_mt, loss_vse = m(src, lens, tgt, im, 1.0, criterion_mt=cm, criterion_vse=cv)
+    else:
+        loss = m(src, lens, tgt, 1.0, criterion=cm)
+        loss_mt = loss_vse = loss
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(m.parameters(), clip)
+    opt.step()
+    return loss.item(), loss_mt.item(), loss_vse.item()
+
+
+@pytest.mark.parametrize("name,vse_separate", [("mm_dot_tied_mid_f32", False), ("mm_dot_tied_mid_f32", True),
+                                               ("mm_mlp_untied_s1_f32", True), ("text_tied_s0_f32", False)])
+def test_shim_equals_the_literal_sequence_with_torch_adam(name, vse_separate):
+    """Six steps, a ReduceLROnPlateau-style cut of every group's rate after step 3 (nmt_multimodal_beam_DE.py:335,469 multiplies
+    each group's lr by 0.2), the lr/2 groups of :316-329, a change of ``clip`` on the way: the shim (fused step, graphs) against the same
+    calls on the per-operator path + torch.optim.Adam."""
+    T = _shim()
+    meta, P, z = load_golden(name)
+    mm = meta["kind"] == "mm"
+    cm, cv = criteria(meta)
+    src, tgt = torch.from_numpy(z["src"]).cuda(), torch.from_numpy(z["tgt"]).cuda()
+    im = torch.from_numpy(z["im"]).cuda() if mm else None
+    batch = (src, meta["lengths"], tgt, im)
+    ma, mb = build(meta, P), build(meta, P)
+    oa, ob = _reference_optimizer(ma, vse_separate=vse_separate), _reference_optimizer(mb, vse_separate=vse_separate)
+    sched_a = torch.optim.lr_scheduler.ReduceLROnPlateau(oa, factor=0.2, patience=0)
+    sched_b = torch.optim.lr_scheduler.ReduceLROnPlateau(ob, factor=0.2, patience=0)
+    if not mm:
+        T.CLIP = 1.0
+    for i in range(6):
+        clip = 1.0 if i < 5 else 0.5
+        if mm:
+            got = T.train_imagine_beam(src, tgt, im, meta["lengths"], ma, oa, cm, cv, meta["loss_w"], 1.0, clip=clip)
+        else:
+            got = (T.train_nmt(src, tgt, meta["lengths"], ma, cm, oa, 1.0),) * 3
+            clip = 1.0
+        want = _literal(mb, ob, cm, cv if mm else None, batch, clip, mm)
+        assert np.allclose(got, want, rtol=2e-4, atol=2e-5), (i, got, want)
+        if i == 2:                      # two "bad" epochs in a row: the scheduler cuts every group's rate
+            for s in (sched_a, sched_b):
+                s.step(1.0)
+                s.step(2.0)
+            assert abs(oa.param_groups[0]["lr"] - 8e-5) < 1e-12
+    d = oa._vag_driver
+    assert type(d.ts.backend).__name__ == "_FusedBackend" and int(d.ts.step_count.item()) == 6
+    assert abs(d.ts.lr - 8e-5) < 1e-12
+    for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        close(pa, pb.detach().cpu().numpy(), 3e-5, "parameters after six steps: " + n)
+    # torch's view of the optimiser state is the driver's
+    sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
+    assert len(sa) == len(sb)
+    for k in sb:
+        assert float(sa[k]["step"]) == float(sb[k]["step"]) == 6.0
+        close(sa[k]["exp_avg"], sb[k]["exp_avg"].cpu().numpy(), 2e-4, "exp_avg %s" % k)
+
+
+def test_shim_serves_other_criteria_on_the_per_operator_path_and_keeps_one_state():
+    """A criterion the fused step does not implement (label smoothing by hand) goes through the literal sequence; on an optimiser
+    that already has a fused driver torch.optim.Adam then steps on the driver's own moment buffers and step count."""
+    T = _shim()
+    meta, P, z = load_golden("mm_dot_tied_mid_f32")
+    cm, cv = criteria(meta)
+    src, tgt, im = torch.from_numpy(z["src"]).cuda(), torch.from_numpy(z["tgt"]).cuda(), torch.from_numpy(z["im"]).cuda()
+    lens = meta["lengths"]
+
+    class Other(torch.nn.Module):
+        def forward(self, logp, target):
+            return torch.nn.functional.nll_loss(logp, target, reduction="none") * 0.9 - 0.1 * logp.mean(dim=1)
+
+    ma, mb = build(meta, P), build(meta, P)
+    oa, ob = _reference_optimizer(ma), _reference_optimizer(mb)
+    for i in range(4):
+        crit = cm if i != 2 else Other()
+        got = T.train_imagine_beam(src, tgt, im, lens, ma, oa, crit, cv, meta["loss_w"], 1.0, clip=1.0)
+        mb.train()
+        ob.zero_grad()
+        loss, loss_mt, loss_vse = mb(src, lens, tgt, im, 1.0, criterion_mt=crit, criterion_vse=cv)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(mb.parameters(), 1.0)
+        ob.step()
+        assert np.allclose(got, (loss.item(), loss_mt.item(), loss_vse.item()), rtol=2e-4, atol=2e-5), (i, got)
+    assert int(oa._vag_driver.ts.step_count.item()) == 4
+    for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        close(pa, pb.detach().cpu().numpy(), 3e-5, "parameters: " + n)
+    # decoding after shim steps sees the stepped weights (tables keyed on the weights version)
+    ma.eval()
+    mb.eval()
+    ta = ma.beamsearch_decode(src, lens, im, 3, 10)
+    tb = mb.beamsearch_decode(src, lens, im, 3, 10)
+    assert [list(map(int, x)) for x in ta] == [list(map(int, x)) for x in tb]

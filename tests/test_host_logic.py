@@ -216,3 +216,35 @@ def test_grouped_launch_plan_fills_the_block_slots_and_orders_longest_first():
     assert split2[1] == 1 and shapes2[order2[-1]][2] == 256
     # bad arguments come back as -EINVAL
     assert L.lib().vag_gemm_group_plan(0, None, None, None, None, None, None) == -22
+
+
+def test_flat_layout_with_explicit_groups_and_the_shims_optimizer_checks():
+    """The ``train`` shim hands TrainStep the caller's torch.optim.Adam groups (nmt_multimodal_beam_DE.py:303-332): every group is
+    split into its non-encoder / encoder part, its own weight decay travels as a number; the optimiser checks are host logic."""
+    import importlib
+    from machine_translation_vision.models import NMT_AttentionImagine_Seq2Seq_Beam_V11
+    from vagnmt_hip.trainer import flat_layout
+    m = NMT_AttentionImagine_Seq2Seq_Beam_V11(50, 60, 96, 16, 16, 24, 20, 0.99, tied_emb=True)
+    named = [(n, p) for n, p in m.named_parameters()]
+    w = [n for n, _ in named if "bias" not in n]
+    b = [n for n, _ in named if "bias" in n]
+    segs, offs, seg_off, total = flat_layout(named, groups=[("g0", w, 1e-5, 1.0), ("g1", b, 0.0, 1.0)])
+    assert [s[0] for s in segs] == ["g0", "g1", "g0/encoder", "g1/encoder"]
+    assert [s[2] for s in segs] == [1e-5, 0.0, 1e-5, 0.0]
+    assert sorted(offs) == sorted(n for n, _ in named) and seg_off[-1] == total
+    ref = flat_layout(named)                       # the by-name grouping gives the same offsets
+    assert ref[1] == offs and ref[2] == seg_off
+    T = importlib.import_module("train")
+    def groups():                                  # fresh dicts: an optimiser writes its defaults into them
+        return [{"params": [p for n, p in named if "bias" not in n], "weight_decay": 1e-5},
+                {"params": [p for n, p in named if "bias" in n]}]
+    opt = torch.optim.Adam(groups(), lr=4e-4)
+    assert T._plain_adam(opt) and T._covers(m, opt)
+    assert not T._plain_adam(torch.optim.Adam(groups(), lr=4e-4, amsgrad=True))
+    assert not T._plain_adam(torch.optim.SGD(groups(), lr=0.1))
+    assert not T._covers(m, torch.optim.Adam(groups()[:1], lr=4e-4))
+    vw = torch.ones(60)
+    vw[0] = 0
+    # CPU tensors never reach the fused driver; the literal sequence then fails loudly in the HIP operators (no CPU fallback)
+    d, existing = T._driver(m, opt, torch.nn.NLLLoss(weight=vw, reduction="none"), None, 1.0, 1.0)
+    assert d is None and existing is None

@@ -44,14 +44,16 @@ def is_late(name):
     return name.startswith("encoder.")
 
 
-def flat_layout(named_params, vse_separate=False):
+def flat_layout(named_params, vse_separate=False, groups=None):
     """Offsets of every parameter in the flat buffer.  Each optimiser group is split into an early and a late part
     (see is_late); all early segments come first.  Segments are contiguous, slots 256-byte aligned.
     Returns (segments [(name, [param names], wd?, lr_mult)], offsets dict, segment boundaries, total floats);
-    the early bucket is [0, boundary of the first late segment).  Pure host logic (no GPU needed)."""
+    the early bucket is [0, boundary of the first late segment).  Pure host logic (no GPU needed).
+    ``groups``: an explicit grouping [(name, [param names], wd, lr_mult)] instead of the reference's two / four groups by
+    name (the ``train`` shim passes what the caller's torch.optim.Adam holds; ``wd`` is then the group's own decay)."""
     byname = dict(named_params)
     early, late = [], []
-    for gname, names, wd, mult in param_groups(named_params, vse_separate):
+    for gname, names, wd, mult in (groups if groups is not None else param_groups(named_params, vse_separate)):
         e = [n for n in names if not is_late(n)]
         la = [n for n in names if is_late(n)]
         if e:
@@ -71,10 +73,10 @@ def flat_layout(named_params, vse_separate=False):
 class FlatParams:
     """Re-homes a module's parameters into one flat buffer (+ gradient, Adam m/v buffers)."""
 
-    def __init__(self, model, vse_separate=False):
+    def __init__(self, model, vse_separate=False, groups=None):
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]      # tied weights appear once
         dev = named[0][1].device
-        self.groups, self.offsets, self.seg_off, self.n = flat_layout(named, vse_separate)
+        self.groups, self.offsets, self.seg_off, self.n = flat_layout(named, vse_separate, groups)
         n_early = sum(1 for g in self.groups if not g[0].endswith("/encoder"))
         self.early_end = self.seg_off[n_early]              # [0, early_end): final before the encoder's backward
         self.flat = torch.zeros(self.n, dtype=torch.float32, device=dev)
@@ -104,7 +106,7 @@ class TrainStep:
     def __init__(self, model, criterion_mt, criterion_vse=None, lr=4e-4, weight_decay=1e-5, clip=1.0,
                  teacher_force_ratio=0.8, betas=(0.9, 0.999), eps=1e-8, vse_separate=False, use_graph=True,
                  process_group=None, world_size=1, max_graphs=48, pad_src=4, fused=None, backend=None,
-                 force_phased=False, storage="f32", comm=None):
+                 force_phased=False, storage="f32", comm=None, groups=None):
         self.model = model
         self.criterion_mt = criterion_mt
         self.criterion_vse = criterion_vse
@@ -121,14 +123,16 @@ class TrainStep:
         self.force_phased = force_phased      # tests: the data-parallel sequence (two phases, two buckets) at world_size 1
         self.max_graphs = max_graphs
         self.pad_src = max(1, int(pad_src))
-        self.fp = FlatParams(model, vse_separate)
+        self.fp = FlatParams(model, vse_separate, groups)
         dev = self.fp.flat.device
         if world_size > 1:
             import torch.distributed as dist
             dist.broadcast(self.fp.flat, src=0, group=process_group)       # identical replicas
         ns = len(self.fp.groups)
         self._seg_off = (C.c_int64 * (ns + 1))(*self.fp.seg_off)
-        self._seg_wd = (C.c_float * ns)(*[weight_decay if g[2] else 0.0 for g in self.fp.groups])
+        # g[2]: True / False = the driver's weight_decay or none (the reference's grouping by name), a number = that group's own
+        self._seg_wd = (C.c_float * ns)(*[(weight_decay if g[2] else 0.0) if isinstance(g[2], bool) else float(g[2])
+                                          for g in self.fp.groups])
         self._seg_lr = (C.c_float * ns)(*[g[3] for g in self.fp.groups])       # relative rates; the rate itself is on the device
         self._lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
         self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -159,6 +163,33 @@ class TrainStep:
             self._lr_dev.fill_(self.lr)
         if self.fp.flat.is_cuda and self.backend is not None and getattr(self.backend, "with_optimizer", False):
             self.check()                  # a validation point: the loop is synchronising anyway (it just read the dev loss)
+
+    def retune(self, seg_lr=None, seg_wd=None, clip=None, betas=None, eps=None):
+        """Change what the captured graphs hold BY VALUE: the segments' relative learning rates and weight decays (one entry per
+        segment of ``self.fp.groups``), the clip norm, Adam's betas / eps.  Returns True when something changed; the captured
+        graphs are dropped then (a shape is captured again on its next visit).  The learning rate itself is a device word:
+        ``set_lr``."""
+        ns = len(self.fp.groups)
+        changed = False
+        for arr, new in ((self._seg_lr, seg_lr), (self._seg_wd, seg_wd)):
+            if new is None:
+                continue
+            if len(new) != ns:
+                raise ValueError("one value per segment (%d), got %d" % (ns, len(new)))
+            for i, x in enumerate(new):
+                if C.c_float(float(x)).value != arr[i]:
+                    arr[i] = float(x)
+                    changed = True
+        if clip is not None and float(clip) != float(self.clip):
+            self.clip, changed = float(clip), True
+        if betas is not None and tuple(betas) != tuple(self.betas):
+            self.betas, changed = (float(betas[0]), float(betas[1])), True
+        if eps is not None and float(eps) != float(self.eps):
+            self.eps, changed = float(eps), True
+        if changed:
+            self._graphs.clear()
+            self._opt_graphs.clear()
+        return changed
 
     # ---- optimiser + collectives ----
     def _optimizer(self):
@@ -361,6 +392,12 @@ class _FusedBackend:
         f = self.f
         o = 4 + 4 * ((f.executed - 1) % f.LOSS_RING)
         return f.losses[o], f.losses[o + 1], f.losses[o + 2]
+
+    def outputs_row(self):
+        """The same three numbers as one contiguous 3-element view (one device-to-host copy reads them all)."""
+        f = self.f
+        o = 4 + 4 * ((f.executed - 1) % f.LOSS_RING)
+        return f.losses[o:o + 3]
 
     def after_optimizer(self):
         self.f.refresh_derived()
