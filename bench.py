@@ -396,6 +396,10 @@ def measure_extras(c, dev, ts, args):
         except Exception as e:   # noqa: BLE001
             out[key] = {"error": repr(e)[:300]}
     m4.train(was)
+    try:
+        out["configs0_text_only"] = measure_cfg1(dev, steps=60)
+    except Exception as e:   # noqa: BLE001
+        out["configs0_text_only"] = {"error": repr(e)[:300]}
     # the boundary as the reference's trainer reaches it
     try:
         out.update(measure_reference_trainer(c, dev))
@@ -436,6 +440,91 @@ def measure_extras(c, dev, ts, args):
         except Exception as e:   # noqa: BLE001
             out["configs4_fp16_storage"] = {"error": repr(e)[:200]}
     return out
+
+
+# BASELINE.json configs[0]: the text-only model of nmt_monomodal_beam_DE.py (NMT_Seq2Seq_Beam_V2), H=256, E=256, B=16, T=40
+CFG1 = dict(Vs=8507, V=9391, E=256, H=256, B=16, Ts=40, Tt=40)
+
+
+def build_text_model(c, dev, seed=1234, dropout=True):
+    from machine_translation_vision.models import NMT_Seq2Seq_Beam_V2
+    torch.manual_seed(seed)
+    d = 1.0 if dropout else 0.0
+    # nmt_monomodal_beam_DE.py:196-224: dropout_out is set from ARGS.dropout_rnn there, i.e. 0.0
+    m = NMT_Seq2Seq_Beam_V2(c["Vs"], c["V"], c["E"], c["E"], c["H"], dropout_ctx=0.5 * d, dropout_emb=0.3 * d, dropout_out=0.0,
+                            tied_emb=True)
+    return m.to(dev)
+
+
+def make_text_batch(c, rank, dev):
+    g = torch.Generator().manual_seed(1234 + rank)
+    src = torch.randint(4, c["Vs"], (c["B"], c["Ts"]), generator=g)
+    tgt = torch.randint(4, c["V"], (c["B"], c["Tt"]), generator=g)
+    tgt[:, -1] = 3
+    return src.to(dev), [c["Ts"]] * c["B"], tgt.to(dev)
+
+
+def measure_cfg1(dev, steps=100, warmup=10, cpu=True):
+    """BASELINE.json configs[0] ("CPU-only plumbing"): the text-only training step (train.py:19-32 on
+    NMT_Seq2Seq_Beam_V2.forward, models/NMT_Seq2Seq_Beam_V2.py:58-113) through the same step driver, and the oracle's time for it
+    on this host's cores in the reference's operation order."""
+    from vagnmt_hip.trainer import TrainStep
+    c = CFG1
+    m = build_text_model(c, dev)
+    vw = torch.ones(c["V"], device=dev)
+    vw[0] = 0
+    ts = TrainStep(m, torch.nn.NLLLoss(weight=vw, reduction="none"), None, lr=4e-4, weight_decay=1e-5, clip=1.0,
+                   teacher_force_ratio=1.0)
+    src, lens, tgt = make_text_batch(c, 0, dev)
+    lt = torch.tensor(lens, dtype=torch.int32, device=dev)
+    for _ in range(max(3, warmup)):
+        out = ts.step(src, lt, tgt, None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = ts.step(src, lt, tgt, None)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    ts.check()
+    ab = algorithmic_bytes(dict(c, S=0, I=0))
+    # the four recurrences of SURVEY 8(d) at these sizes (the once-per-batch products and Adam are not in this figure)
+    rec_bytes = 2 * c["Ts"] * (ab["F_enc"] + ab["Bk_enc"]) + c["Tt"] * (ab["F_dec"] + ab["Bk_dec"])
+    row = {"workload": "configs[0]: text-only en->de train step (NMT_Seq2Seq_Beam_V2), B=%d, Ts=Tt=%d, E=%d, H=%d, Vs=%d, V=%d, "
+                       "dropout 0.3/0.5/0.0 (nmt_monomodal_beam_DE.py:204), tied emb, teacher forcing" %
+                       (c["B"], c["Ts"], c["E"], c["H"], c["Vs"], c["V"]),
+           "ms_per_step": ms, "pairs_per_s": c["B"] / ms * 1e3, "final_loss": float(out[0].item()), "steps": steps,
+           "recurrence_bytes_per_step": rec_bytes, "recurrence_streaming_frac_of_step": rec_bytes / (ms * 1e-3) / HBM_PEAK}
+    if cpu:
+        from oracle import vag_oracle as O
+        mc = build_text_model(c, torch.device("cpu"))
+        s_, l_, t_ = make_text_batch(c, 0, torch.device("cpu"))
+        g = torch.Generator().manual_seed(7)
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+
+        def masks():
+            def mk(shape, p):
+                return (torch.rand(shape, generator=g) >= p).float() / (1.0 - p)
+            return {"emb": mk((c["Ts"], c["B"], c["E"]), 0.3), "ctx": mk((c["Ts"], c["B"], 2 * c["H"]), 0.5)}
+        best = None
+        for th in sorted({min(cores, x) for x in (4, 8, 16)}):
+            torch.set_num_threads(th)
+            P = {n: p.detach().clone() for n, p in mc.named_parameters()}
+            state, times = {}, []
+            for i in range(6):
+                t0 = time.time()
+                _, _, _, P, state = O.train_step(P, s_, l_, t_, None, teacher=True, state=state, masks=masks(), hoist=False)
+                times.append(time.time() - t0)
+            med = sorted(times[2:])[len(times[2:]) // 2]
+            if best is None or med < best[1]:
+                best = (th, med)
+        row["cpu_baseline"] = {"value": c["B"] / best[1], "unit": "sentence-pairs/s", "cores": best[0], "kind": "port",
+                               "s_per_step": best[1], "cpu_model": _cpu_model(), "host_cores": cores,
+                               "sample": "4 full optimiser steps (median, after 2 warm-up) per thread count in (4, 8, 16), the "
+                                         "fastest count reported; oracle in the reference's op order, train mode"}
+    return row
 
 
 def measure_reference_trainer(c, dev, n=40, warm=6):
@@ -606,7 +695,7 @@ def main():
                          "communicator (vag_comm_*, include/vag_nmt.h)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="library option for A/B runs (vag_set_option), e.g. --opt persistent=0")
-    ap.add_argument("--config", choices=["cfg2", "cfg5", "cfg5-f32"], default="cfg2",
+    ap.add_argument("--config", choices=["cfg2", "cfg5", "cfg5-f32", "cfg1"], default="cfg2",
                     help="cfg2 = BASELINE configs[1] (the metric's configuration); cfg5 = configs[4] (H=1024, T=80, B=256, "
                          "V=40k) with fp16 storage of the per-step streams; cfg5-f32 = the same sizes, fp32 storage")
     args = ap.parse_args()
@@ -647,6 +736,15 @@ def main():
         # several ranks share ONE GPU here: the persistent recurrence kernels need every workgroup of their grid resident
         # (one per CU), which two processes cannot both have -- their bounded waits would give up.  Launch chains instead.
         _L.set_option("persistent", 0)
+    if args.config == "cfg1":
+        # BASELINE.json configs[0] as a line of its own (single GPU; the default line carries it as extra.configs0_text_only)
+        row = measure_cfg1(dev, steps=args.steps, warmup=args.warmup, cpu=not args.no_cpu_baseline)
+        print(json.dumps({"metric": "training sentence-pairs/sec (Multi30K en->de, text-only, B=%d)" % CFG1["B"],
+                          "value": row["pairs_per_s"], "unit": "sentence-pairs/s", "n_gpus": 1, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": row["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": row["workload"]},
+                          "cpu_baseline": row.get("cpu_baseline"), "detail": row}))
+        return
     c = CFG2 if args.config == "cfg2" else CFG5
     random.seed(1234)      # same teacher-forcing coin on every rank
     model = build_model(c, dev, dropout=not args.no_dropout)

@@ -185,3 +185,110 @@ def test_shim_serves_other_criteria_on_the_per_operator_path_and_keeps_one_state
     ta = ma.beamsearch_decode(src, lens, im, 3, 10)
     tb = mb.beamsearch_decode(src, lens, im, 3, 10)
     assert [list(map(int, x)) for x in ta] == [list(map(int, x)) for x in tb]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (2) BASELINE.json configs[0] at its own size: the text-only model (models/NMT_Seq2Seq_Beam_V2.py:58-113), H = 256, E = 256,
+#     B = 16, T = 40.  At H = 256 the encoder takes the persistent kernels and the decoder the launch chain: a kernel selection
+#     no fixture-size test runs.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _text_oracle(m, batch, teacher):
+    from oracle import vag_oracle as O
+    src, lens, tgt = batch
+    leaves = {n: p.detach().cpu().clone().requires_grad_(True) for n, p in m.named_parameters()}
+    out = O.model_forward(leaves, src.cpu(), lens, tgt.cpu(), None, teacher=teacher, hoist=True)
+    out["loss"].backward()
+    return float(out["loss"]), {n: (v.grad if v.grad is not None else torch.zeros_like(v)) for n, v in leaves.items()}
+
+
+@pytest.mark.parametrize("teacher", [True, False])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_cfg1_text_only_at_config_size_matches_oracle(teacher, ragged):
+    """Loss 1e-4, every gradient 3e-4 of its tensor's largest entry, through BOTH host paths: the module API
+    (model(...), loss.backward(): what train.py:25-28 runs) and the fused step driver (eager and graph replay)."""
+    import bench
+    from vagnmt_hip.trainer import TrainStep
+    c = bench.CFG1
+    dev = torch.device("cuda", 0)
+    m = bench.build_text_model(c, dev, dropout=False)
+    src, lens, tgt = bench.make_text_batch(c, 0, dev)
+    if ragged:
+        g = torch.Generator().manual_seed(5)
+        lens = sorted(torch.clamp((torch.randn(c["B"], generator=g) * 5 + 15).round().long(), 4, c["Ts"]).tolist(), reverse=True)
+        lens[0] = c["Ts"]
+        for b, L in enumerate(lens):
+            src[b, L:] = 0
+        tgt[3, 20:] = 0
+        tgt[3, 19] = 3
+    vw = torch.ones(c["V"], device=dev)
+    vw[0] = 0
+    crit = torch.nn.NLLLoss(weight=vw, reduction="none")
+    want_l, want_g = _text_oracle(m, (src, lens, tgt), teacher)
+    # module API
+    m.train()
+    m.zero_grad(set_to_none=True)
+    loss = m(src, lens, tgt, 1.0 if teacher else 0.0, criterion=crit)
+    loss.backward()
+    assert abs(loss.item() - want_l) <= LOSS_TOL * max(1.0, abs(want_l)), ("module api", loss.item(), want_l)
+    for n, p in m.named_parameters():
+        g_ = p.grad if p.grad is not None else torch.zeros_like(p)
+        err = (g_.cpu() - want_g[n]).abs().max().item()
+        assert err <= GRAD_TOL * max(want_g[n].abs().max().item(), 1e-3), ("module api", n, err)
+    # fused step driver: eager, capture + replay, replay
+    ts = TrainStep(m, crit, None, teacher_force_ratio=1.0)
+    lt = torch.tensor(lens, dtype=torch.int32, device=dev)
+    for visit in range(3):
+        ts.fp.grad.zero_()
+        ts.backend.run(src, lt, tgt, None, teacher, 7)
+        got = float(ts.backend.outputs()[0])
+        assert abs(got - want_l) <= LOSS_TOL * max(1.0, abs(want_l)), ("fused", visit, got, want_l)
+        for n, p in m.named_parameters():
+            err = (p._vag_grad.cpu() - want_g[n]).abs().max().item()
+            assert err <= GRAD_TOL * max(want_g[n].abs().max().item(), 1e-3), ("fused", visit, n, err)
+    assert ts.stats["captures"] == 1
+    ts.check()
+
+
+def test_cfg1_greedy_and_beam_decode_at_config_size_match_oracle():
+    import bench
+    from oracle import vag_oracle as O
+    c = bench.CFG1
+    dev = torch.device("cuda", 0)
+    m = bench.build_text_model(c, dev, dropout=False).eval()
+    src, lens, _ = bench.make_text_batch(c, 0, dev)
+    P = {n: p.detach().cpu() for n, p in m.named_parameters()}
+    got = m.beamsearch_decode(src, lens, 1, 30)
+    want = O.greedy_decode(P, src.cpu(), lens, None, max_length=30)
+    assert [list(map(int, x)) for x in got] == [list(map(int, x)) for x in want]
+    got = m.beamsearch_decode(src, lens, 4, 20)
+    want = O.beam_search(P, src.cpu(), lens, None, beam_size=4, max_length=20)
+    assert [list(map(int, x)) for x in got] == [list(map(int, x)) for x in want]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (3) Run-to-run spread of the paths that use fp32 atomics (the persistent decoder's score / d-alpha shares, split-K products,
+#     embedding scatters): reproducible to rounding, and bounded here (VERDICT r4 weak 1).
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_run_to_run_spread_of_one_cfg2_step_is_bounded():
+    """Five replays of ONE configs[1] forward + backward (dropout off, same weights, same batch): loss spread <= 1e-6
+    relative, every gradient tensor's spread <= 1e-5 of its largest entry."""
+    import bench
+    from test_gpu_benched_path import _driver, _run_phases
+    c = bench.CFG2
+    m, ts = _driver(c, dropout=False)
+    batch = bench.make_batch(c, 0, torch.device("cuda", 0))
+    m.train()
+    runs = _run_phases(ts, batch, 6)[1:]                     # replays (and the capturing visit)
+    losses = np.array([r[0] for r in runs])
+    assert (losses.max(0) - losses.min(0) <= 1e-6 * np.maximum(1.0, np.abs(losses).max(0))).all(), losses
+    worst = (0.0, None)
+    for n in runs[0][1]:
+        st = torch.stack([r[1][n] for r in runs])
+        spread = float((st.max(0).values - st.min(0).values).max())
+        rel = spread / max(float(st.abs().max()), 1e-12)
+        if rel > worst[0]:
+            worst = (rel, n)
+        assert rel <= 1e-5, (n, spread, float(st.abs().max()))
+    print("run-to-run spread: worst gradient tensor %s at %.2e of its largest entry; losses %s"
+          % (worst[1], worst[0], (losses.max(0) - losses.min(0)).tolist()))
+    ts.check()
