@@ -362,11 +362,16 @@ int vag_beam_finish(const float* nll, const int64_t* beam, int64_t max_len, int6
  * incremented here.  norm_out (1): total gradient norm before clipping.  scratch: VAG_ADAM_SCRATCH_BYTES, 8-byte aligned. */
 #define VAG_ADAM_SCRATCH_BYTES 2048
 /* A void gradient is never applied (train.py:44-49 holds for every step that IS applied): when the gradient norm is not
- * finite, or a persistent recurrence kernel gave up a wait since the previous call (vag_persistent_timeouts; on a replica
+ * finite, or a persistent recurrence kernel launched under THIS scratch's guard pair (VAG_ADAM_SCRATCH_GUARD_OFFSET) gave up a wait
+ * since the previous call (on a replica
  * of a data-parallel run the give-up reaches every rank as a non-finite entry of the all-reduced gradient), this call leaves
  * p, m, v and *step unchanged, still zeroes g (zero_grad), writes NaN to norm_out and adds one to the uint32 at byte
  * VAG_ADAM_SCRATCH_SKIPPED_OFFSET of the scratch (a host reads it from there whenever it likes; TrainStep.skipped_steps). */
 #define VAG_ADAM_SCRATCH_SKIPPED_OFFSET 28
+/* The driver's guard pair {void flag, give-up count} (two uint32) lives at this byte offset of the scratch: pass its address as
+ * vag_step_cfg.guard (or vag_set_operator_guard) and this call skips exactly the steps whose OWN recurrence launches gave up a
+ * wait; the count is the driver's to read and reset (TrainStep.check). */
+#define VAG_ADAM_SCRATCH_GUARD_OFFSET 32
 /* zero_grad != 0: g is left zeroed (the next step's backward accumulates into it; no separate fill pass).
  * scratch must be zero before the FIRST call; every call leaves it ready for the next one.  Three launches.
  * lr_dev: NULL, or one DEVICE float that multiplies every seg_lr when the kernels run: with seg_lr = the groups' relative
@@ -417,6 +422,12 @@ typedef struct {
                                            * of its n-th execution (n kept in the bit pattern of losses[3]) at losses[4 + 4 (n % R)]:
                                            * a driver that replays captured graphs hands out results that stay valid for R steps
                                            * without a copy launch per step.  0: losses is 4 floats */
+    void* guard;                          /* NULL, or two caller-owned DEVICE uint32 {void flag, give-up count} (zero before the first
+                                           * call): the persistent recurrence kernels of THIS call report a give-up there and nowhere
+                                           * else, so several drivers on one device cannot void each other's steps.  The step driver
+                                           * passes (char*)adam_scratch + VAG_ADAM_SCRATCH_GUARD_OFFSET, the words vag_clip_adam_flat
+                                           * reads.  NULL: the calling thread's operator guard (vag_set_operator_guard), else the
+                                           * process-wide pair no optimiser reads */
 } vag_step_cfg;
 /* phases: bit 0 forward (losses[0..2] = loss, loss_mt, loss_vse), bit 1 backward down to the encoder states (final for
  * every gradient except the encoder's), bit 2 the encoder's backward.  A data-parallel driver all-reduces the first
@@ -465,13 +476,18 @@ int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_wh
 int vag_recurrence_supported(int kind, int64_t B, int64_t Ts, int64_t Tt, int64_t H);
 /* The persistent kernels wait on each other inside one launch, which needs every workgroup resident at once (one per CU;
  * vag_recurrence_supported checks the CU count).  Their waits are bounded: on a device where that does not hold they give
- * up after ~1 s instead of hanging, the launch's results are then void -- and never applied: the give-up sets a device word
- * that vag_clip_adam_flat reads on the device (the optimiser step is skipped, see VAG_ADAM_SCRATCH_SKIPPED_OFFSET) and that
+ * up after ~1 s instead of hanging, the launch's results are then void -- and never applied: the give-up sets the launch's guard
+ * flag (vag_step_cfg.guard, VAG_ADAM_SCRATCH_GUARD_OFFSET), which vag_clip_adam_flat reads on the device (the optimiser step is
+ * skipped, see VAG_ADAM_SCRATCH_SKIPPED_OFFSET) and which
  * the last launch of vag_train_step's backward turns into a non-finite gradient entry, so that every replica of a
- * data-parallel run skips the same step after the all-reduce.  This returns how many waits gave up since the last
- * call (0 in a healthy run) and resets the count; it synchronises the device -- call it at checkpoints, not per step.
+ * data-parallel run skips the same step after the all-reduce.  This returns how many waits gave up PROCESS-WIDE since the last
+ * call (0 in a healthy run; every driver's and every unguarded launch's) and resets the count; it synchronises the device --
+ * call it at checkpoints, not per step.
  * vag_set_option("persist_spin_limit", n): polls before a wait gives up (0 = default 2^19; tests force a give-up with 1). */
 int vag_persistent_timeouts(void);
+/* Operators called one by one (the module API under torch.autograd, decoding) have no vag_step_cfg: this sets the guard pair
+ * (see vag_step_cfg.guard) of every persistent launch the CALLING THREAD enqueues until changed; NULL = the process-wide pair. */
+int vag_set_operator_guard(void* guard);
 /* Measurement: with vag_set_option("persist_timing", 1) every EAGER launch (not inside a stream capture) of a recurrence
  * kernel is bracketed by HIP events on its stream.  This returns the accumulated kernel time and launch count of one kind
  * (0 encoder forward, 1 decoder forward, 2 encoder backward, 3 decoder backward) since the last call and resets them; it

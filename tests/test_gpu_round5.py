@@ -292,3 +292,45 @@ def test_run_to_run_spread_of_one_cfg2_step_is_bounded():
     print("run-to-run spread: worst gradient tensor %s at %.2e of its largest entry; losses %s"
           % (worst[1], worst[0], (losses.max(0) - losses.min(0)).tolist()))
     ts.check()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (4) Persistent-kernel give-up state per driver (vag_step_cfg.guard, VAG_ADAM_SCRATCH_GUARD_OFFSET): two drivers on one device.
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_two_drivers_on_one_device_do_not_void_each_others_steps():
+    """Driver A's recurrences are forced to give up (spin limit 1) between two of driver B's steps, and a greedy decode of a third
+    model gives up as well: A skips its step (weights untouched, check() raises), B's steps are all applied and B's check() is
+    clean -- before round 5 the give-up word was process-wide and B's next step would have been skipped too."""
+    from test_gpu_round4 import _driver, _batch, _state
+    from vagnmt_hip import _lib as L
+    ma, a = _driver(seed=3, use_graph=False)
+    mb, b = _driver(seed=4, use_graph=False)
+    for s in range(2):
+        a.step(*_batch(50 + s), teacher=True)
+        b.step(*_batch(60 + s), teacher=True)
+    a.check()
+    b.check()
+    a0, b0 = _state(a), _state(b)
+    L.set_option("persist_spin_limit", 1)
+    try:
+        a.step(*_batch(52), teacher=True)                   # void: every wait gives up
+        src, lens, _, im = _batch(70)
+        mb.eval()
+        mb.beamsearch_decode(src, lens, im, 1, 6)           # an unguarded launch gives up too (its tokens are garbage)
+        torch.cuda.synchronize()
+    finally:
+        L.set_option("persist_spin_limit", 0)
+    out = b.step(*_batch(62), teacher=True)                 # B's next step: healthy, must be APPLIED
+    torch.cuda.synchronize()
+    a1, b1 = _state(a), _state(b)
+    assert torch.equal(a0[0], a1[0]) and a0[3] == a1[3] and a.skipped_steps() == 1
+    assert b1[3] == b0[3] + 1 and not torch.equal(b0[0], b1[0]) and b.skipped_steps() == 0
+    assert torch.isfinite(out[0]) and torch.isfinite(b.grad_norm).all()
+    b.check()                                               # nothing of B gave up
+    assert b.process_timeouts > 0                           # ... although the process-wide diagnostic count saw A's and the decoder's
+    with pytest.raises(L.VagError):
+        a.check()
+    a.step(*_batch(53), teacher=True)                       # A recovers
+    torch.cuda.synchronize()
+    assert int(a.step_count.item()) == a0[3] + 1
+    a.check()

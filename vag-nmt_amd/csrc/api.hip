@@ -375,7 +375,7 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
         VAG_TRY(gemm_nn(R, E, 3 * H, d_xp + d * 3 * H, 6 * H, (d == 0 ? fw : bw).w_ih, E, 1.f, w.dx, E, s));
     VAG_TRY(grp2.end(s));
     VAG_TRY(vag_embed_scatter_launch(src, 1, Ts, Ts, B, w.dx, E, g_emb, rng, VAG_DROP_ENC_EMB, p_emb, s,
-                                     g_step_poison_inject ? vag_persist_poison_word() : nullptr));
+                                     g_step_poison_inject ? vag_persist_guard() : nullptr));
     return VAG_OK;
 }
 
@@ -1568,6 +1568,11 @@ int vag_recurrence_supported(int kind, int64_t B, int64_t Ts, int64_t Tt, int64_
     return 0;
 }
 int vag_persistent_timeouts(void) { return vag_persistent_timeouts_read(); }
+int vag_set_operator_guard(void* guard) {
+    VAG_CHECK_ARG((reinterpret_cast<uintptr_t>(guard) & 3) == 0);
+    vag_persist_guard_set(reinterpret_cast<unsigned*>(guard));
+    return VAG_OK;
+}
 int vag_gemm_group_plan(int n, const int64_t* M, const int64_t* N, const int64_t* K, const int* accumulate, int* split,
                         int* order) {
     return vag_gemm_group_plan_host(n, M, N, K, accumulate, split, order);

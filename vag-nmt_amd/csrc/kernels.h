@@ -169,7 +169,9 @@ int vag_enc_bwd_wide16_launch(const vag_half* wt16, const float* d_enc, const fl
 int vag_gemm_group_plan_host(int n, const int64_t* M, const int64_t* N, const int64_t* K, const int* accumulate, int* split,
                              int* order);
 int vag_persistent_timeouts_read(void);
-unsigned* vag_persist_poison_word(void);     // device word set by a give-up; adam_prep_kernel reads and clears it
+unsigned* vag_persist_guard(void);           // {void flag, give-up count} pair of the launches the calling thread enqueues (persist.hip)
+void vag_persist_guard_set(unsigned* g);     // the caller's own pair (NULL: the process-wide pair)
+unsigned* vag_persist_guard_peek(void);      // what vag_persist_guard_set last set on this thread (NULL: none)
 int vag_persistent_time_read(int kind, double* ms_total, int* launches);
 bool vag_dec_bwd_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H);
 int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const float* v, const float* wcatT, const float* whh1T,

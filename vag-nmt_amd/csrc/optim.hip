@@ -14,12 +14,15 @@ struct AdamScalars {          // lives in the caller's scratch (VAG_ADAM_SCRATCH
     unsigned skip;            // 1: this step's gradient is void (non-finite norm, or a persistent recurrence gave up a wait):
                               // adam_kernel leaves parameters and moments alone and only zeroes the gradient
     unsigned skipped;         // number of skipped steps so far (VAG_ADAM_SCRATCH_SKIPPED_OFFSET: hosts read it from the scratch)
+    unsigned guard[2];        // VAG_ADAM_SCRATCH_GUARD_OFFSET: {void flag, give-up count} of THIS driver's persistent recurrence launches
+                              // (persist.hip: note_timeout; the driver passes the address as vag_step_cfg.guard)
     // the blocks' partial sums land in 128 slots (2048 double atomics on ONE address serialise in L2: ~25 of the
     // pass's 31 us); the last block to arrive adds the slots up in a fixed order
     double part[SUMSQ_SLOTS];
 };
 static_assert(sizeof(AdamScalars) <= 2048, "vag_clip_adam_flat scratch contract");
 static_assert(offsetof(AdamScalars, skipped) == VAG_ADAM_SCRATCH_SKIPPED_OFFSET, "vag_nmt.h: VAG_ADAM_SCRATCH_SKIPPED_OFFSET");
+static_assert(offsetof(AdamScalars, guard) == VAG_ADAM_SCRATCH_GUARD_OFFSET, "vag_nmt.h: VAG_ADAM_SCRATCH_GUARD_OFFSET");
 
 // Pass 1: sum of squares of the gradient into 128 slots (plain relaxed atomics, no fences: an in-kernel "last block does the
 // scalar work" variant needs a device-scope fence per block, and 2048 of them cost 80 us -- measured -- against 2 us for
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 // Scalar work between the passes (norm, clip coefficient, bias corrections in double, step counter); leaves the slots zeroed
 // for the next call, so no separate zeroing launch is needed.
 __global__ void adam_prep_kernel(AdamScalars* sc, float clip, float grad_scale, float beta1, float beta2, int32_t* step,
-                                 float* norm_out, const float* lr_dev, unsigned* poison) {
+                                 float* norm_out, const float* lr_dev) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double ss = 0.0;
     for (int k = 0; k < SUMSQ_SLOTS; ++k) {                        // fixed order
@@ -66,14 +69,15 @@ __global__ void adam_prep_kernel(AdamScalars* sc, float clip, float grad_scale, 
         sc->part[k] = 0.0;
     }
     sc->sumsq = ss;
-    // A void gradient is never applied: the step is skipped when a persistent recurrence kernel gave up a wait since the last
-    // optimiser step (persist.hip: results of that launch are void) or when the gradient norm is not finite (which is also how a
+    // A void gradient is never applied: the step is skipped when a persistent recurrence kernel OF THIS DRIVER gave up a wait since
+    // its last optimiser step (persist.hip: results of that launch are void; the flag lives in this scratch, so another model's
+    // or a decoder's give-up on the same device does not reach here) or when the gradient norm is not finite (which is also how a
     // give-up on ANOTHER data-parallel replica arrives here: elem.hip, embed_scatter_kernel).  Skipped: no parameter, moment or
     // step-counter change; the gradient buffer is still zeroed; the reported norm is NaN; `skipped` counts.
     bool bad = !(ss == ss) || ss > 1.0e300 || ss * (double)grad_scale * (double)grad_scale > 3.0e38;
-    if (poison && __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+    if (__hip_atomic_load(&sc->guard[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
         bad = true;
-        __hip_atomic_store(poison, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sc->guard[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     sc->skip = bad ? 1u : 0u;
     if (bad) {
@@ -143,8 +147,7 @@ int vag_clip_adam_launch(float* p, float* g, float* m, float* v, int64_t n, int 
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, n, sc);
     VAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, sc, clip, grad_scale, beta1, beta2, step, norm_out, lr_dev,
-                       vag_persist_poison_word());
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, sc, clip, grad_scale, beta1, beta2, step, norm_out, lr_dev);
     VAG_LAUNCH_CHECK();
     AdamSegs sg;
     int64_t maxcnt = 0;

@@ -21,6 +21,7 @@
 #include "kernels.h"
 #include "gemm_shared.h"
 #include <atomic>
+#include <mutex>
 
 namespace {
 
@@ -32,16 +33,21 @@ constexpr unsigned SPIN_LIMIT = 1u << 19;       // polls before giving up (~a se
 // Waits that gave up since the last vag_persistent_timeouts() (results of such a launch are void): the kernels assume that
 // every workgroup of the grid is resident at once -- one per CU, checked on the host against the CU count -- and a spin is
 // bounded so that a device on which that does not hold (CU masks, a partitioned GPU, another process's or a collective's
-// kernels squatting on CUs) drains instead of hanging.  A give-up also sets g_persist_poison, the word the optimiser reads
-// on the device: adam_prep_kernel (optim.hip) skips the update of a step whose recurrences gave up a wait, and the encoder's
-// embedding scatter -- the last launch of a backward pass -- turns the word into a non-finite gradient entry so that under
-// data parallelism EVERY replica sees it after the all-reduce and skips the same step (train.py:44-49 semantics are kept
-// for every step that is applied; a void gradient is never applied).
+// kernels squatting on CUs) drains instead of hanging.  A give-up also sets the launch's GUARD: two caller-owned words
+// {void flag, give-up count} (vag_step_cfg.guard / vag_set_operator_guard; the step driver keeps them in its optimiser scratch,
+// VAG_ADAM_SCRATCH_GUARD_OFFSET).  adam_prep_kernel (optim.hip) reads the flag of ITS driver and skips the update of a step whose
+// recurrences gave up a wait, and the encoder's embedding scatter -- the last launch of a backward pass -- turns it into a
+// non-finite gradient entry so that under data parallelism EVERY replica sees it after the all-reduce and skips the same step
+// (train.py:44-49 semantics are kept for every step that is applied; a void gradient is never applied).  Two drivers on one
+// device (two models, a trainer and a decoder) therefore cannot void each other's steps.  Launches without a guard of their own
+// (operators called one by one, decoding) share the process-wide pair below; g_persist_timeouts counts every give-up of the
+// process for vag_persistent_timeouts().
 __device__ unsigned g_persist_timeouts;
-__device__ unsigned g_persist_poison;
-__device__ __forceinline__ void note_timeout(unsigned* err) {
+__device__ unsigned g_persist_guard[2];
+__device__ __forceinline__ void note_timeout(unsigned* err, unsigned* guard) {
     __hip_atomic_store((gu32*)err, 1u, RLX_AGENT);
-    __hip_atomic_store((gu32*)&g_persist_poison, 1u, RLX_AGENT);
+    __hip_atomic_store((gu32*)guard, 1u, RLX_AGENT);
+    atomicAdd(guard + 1, 1u);
     atomicAdd(&g_persist_timeouts, 1u);
 }
 
@@ -55,6 +61,7 @@ struct EncPArgs {
     float* enc;                 // (B, Ts, 2H)
     unsigned* cnt;              // [2][RT][Ts], zero on entry
     unsigned* err;              // 1 word, set when a wait gave up
+    unsigned* guard;            // {void flag, give-up count} of the driver this launch belongs to
     unsigned spin;              // polls before a wait gives up
     const uint64_t* rng;        // context dropout (Encoder.py:63-64) applied to enc as it is written (NULL / p_ctx = 0: none)
     float p_ctx;
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_persistent_kernel(EncPArgs a) 
             if (threadIdx.x == 0 && !dead) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(cnt + (k - 1), RLX_AGENT) < (unsigned)a.CS) {
-                    if (++spins > a.spin) { note_timeout(a.err); dead = true; break; }
+                    if (++spins > a.spin) { note_timeout(a.err, a.guard); dead = true; break; }
                 }
             }
             __syncthreads();
@@ -315,6 +322,7 @@ struct EncWArgs {
     vag_half* hx;               // [2][Ts+1][B][H] fp16 copy of the states for the exchange; slot 0 is written here (zeros)
     unsigned* cnt;              // [2][RG][Ts], zero on entry
     unsigned* err;
+    unsigned* guard;            // {void flag, give-up count} of the driver this launch belongs to
     unsigned spin;
     int B, Ts, H, RG, CS;
 };
@@ -403,7 +411,7 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_wide16_kernel(EncWArgs a) {
             if (threadIdx.x == 0 && !dead) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(cnt + (k - 1), RLX_AGENT) < target) {
-                    if (++spins > a.spin) { note_timeout(a.err); dead = true; break; }
+                    if (++spins > a.spin) { note_timeout(a.err, a.guard); dead = true; break; }
                 }
             }
             __syncthreads();
@@ -501,6 +509,7 @@ struct EncBArgs {
     float* dgh;                 // [2][Ts][B][3H]
     unsigned* cnt;              // [2][RT][Ts]
     unsigned* err;
+    unsigned* guard;            // {void flag, give-up count} of the driver this launch belongs to
     unsigned spin;
     int B, Ts, H, RT, CS;
 };
@@ -552,7 +561,7 @@ __global__ __launch_bounds__(512, 1) void enc_bwd_persistent_kernel(EncBArgs a) 
             if (threadIdx.x == 0 && !dead) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(cnt + (k + 1), RLX_AGENT) < (unsigned)a.CS) {
-                    if (++spins > a.spin) { note_timeout(a.err); dead = true; break; }
+                    if (++spins > a.spin) { note_timeout(a.err, a.guard); dead = true; break; }
                 }
             }
             __syncthreads();
@@ -633,6 +642,7 @@ struct EncWBArgs {
     vag_half* gx;               // [2][Ts][B][3H] fp16 x 2^12: the exchanged copy
     unsigned* cnt;              // [2][RG][Ts], zero on entry
     unsigned* err;
+    unsigned* guard;            // {void flag, give-up count} of the driver this launch belongs to
     unsigned spin;
     int B, Ts, H, RG, CS;
 };
@@ -711,7 +721,7 @@ __global__ __launch_bounds__(512, 1) void enc_bwd_wide16_kernel(EncWBArgs a) {
             if (threadIdx.x == 0 && !dead) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(cnt + (k + 1), RLX_AGENT) < target) {
-                    if (++spins > a.spin) { note_timeout(a.err); dead = true; break; }
+                    if (++spins > a.spin) { note_timeout(a.err, a.guard); dead = true; break; }
                 }
             }
             __syncthreads();
@@ -808,6 +818,7 @@ struct DecPArgs {
     float *h1, *g1, *qhp, *alpha, *h2_all, *g2, *psc;
     unsigned* cnt;              // [5 phases][RT][Tt], zero on entry (2 and 4: free-running form only)
     unsigned* err;
+    unsigned* guard;            // {void flag, give-up count} of the driver this launch belongs to
     unsigned spin;
     unsigned long long* dbg;    // NULL, or [Tt][8] 100 MHz timestamps of workgroup 0's phase boundaries (tools/exp_dec_phases.py)
     int B, Ts, Tt, H, RT;
@@ -830,14 +841,14 @@ struct DecPArgs {
 // agent-scope loads until every shard holds its 16 arrivals, then the workgroup's barrier.
 constexpr int SHARDS = 4, SHARD_STRIDE = 16, CNT_WORDS = SHARDS * SHARD_STRIDE;
 __device__ __forceinline__ void arrive(gu32* c, int i) { __hip_atomic_fetch_add(c + (i & (SHARDS - 1)) * SHARD_STRIDE, 1u, RLX_AGENT); }
-__device__ __forceinline__ void wait_count(gu32* c, unsigned want_per_shard, unsigned* err, unsigned spin, bool& dead) {
+__device__ __forceinline__ void wait_count(gu32* c, unsigned want_per_shard, unsigned* err, unsigned* guard, unsigned spin, bool& dead) {
     if (threadIdx.x < 64 && !dead) {
         const int lane = threadIdx.x;
         unsigned spins = 0;
         for (;;) {
             const bool ok = lane >= SHARDS || __hip_atomic_load(c + lane * SHARD_STRIDE, RLX_AGENT) >= want_per_shard;
             if (__all(ok)) break;
-            if (++spins > spin) { if (lane == 0) note_timeout(err); dead = true; break; }
+            if (++spins > spin) { if (lane == 0) note_timeout(err, guard); dead = true; break; }
         }
     }
     __syncthreads();
@@ -983,7 +994,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
 #pragma unroll
             for (int s = 0; s < KS; ++s) { ha[s] = *reinterpret_cast<const float4*>(hp + 32 * s); hb[s] = *reinterpret_cast<const float4*>(hp + 32 * s + 4); }
         } else {
-            wait_count(c1 + (t - 1) * CNT_WORDS, PER_SHARD, a.err, a.spin, dead);
+            wait_count(c1 + (t - 1) * CNT_WORDS, PER_SHARD, a.err, a.guard, a.spin, dead);
             VAG_STAMP(1);
             ld_rows_sc1<KS>(a.h2_all + ((int64_t)(t - 1) * B + lrow) * H + kbase + 8 * (lane & 3), ha, hb);
 #pragma unroll
@@ -1062,7 +1073,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 if (tx == 0) arrive(c5 + ts * CNT_WORDS, i);
-                wait_count(c5 + ts * CNT_WORDS, PER_SHARD, a.err, a.spin, dead);        // (its barrier also frees `red`)
+                wait_count(c5 + ts * CNT_WORDS, PER_SHARD, a.err, a.guard, a.spin, dead);        // (its barrier also frees `red`)
                 VAG_STAMP(9);
                 // ---- logits of step t - 1 (:143) for the own vocabulary tiles (16 words each, tile i + 64 j) and their arg-max.
                 // The step's hidden layer (16 rows x E) is split once into bf16 planes and parked in `red` in MFMA operand
@@ -1144,7 +1155,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 if (tx == 0) arrive(c6 + ts * CNT_WORDS, i);
-                wait_count(c6 + ts * CNT_WORDS, PER_SHARD, a.err, a.spin, dead);
+                wait_count(c6 + ts * CNT_WORDS, PER_SHARD, a.err, a.guard, a.spin, dead);
                 VAG_STAMP(11);
                 // every workgroup of the tile reduces the 64 candidates of its 16 rows itself: 32 lanes per row, two each
                 if (tx < 128) {
@@ -1213,7 +1224,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
         }
         // ================= phase 2: q = attn_h h1 (:47), hp2 = W_hh2 h1 + b_hh2 (hidden side of gru_2, :129) =================
         VAG_STAMP(2);
-        wait_count(c2 + t * CNT_WORDS, PER_SHARD, a.err, a.spin, dead);
+        wait_count(c2 + t * CNT_WORDS, PER_SHARD, a.err, a.guard, a.spin, dead);
         VAG_STAMP(3);
         ld_rows_sc1<KS>(a.h1 + ((int64_t)t * B + lrow) * H + kbase + 8 * (lane & 3), ha, hb);
 #pragma unroll
@@ -1295,7 +1306,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
         }
         // ================= phase 4: softmax (:44), projected context of own columns, gru_2 cell (:126-129) =================
         VAG_STAMP(6);
-        wait_count(c4 + t * CNT_WORDS, PER_SHARD, a.err, a.spin, dead);
+        wait_count(c4 + t * CNT_WORDS, PER_SHARD, a.err, a.guard, a.spin, dead);
         VAG_STAMP(7);
         for (int x0 = tx; x0 < 16 * Ts; x0 += 1024) {                                // 4-byte sc1 loads, two in flight
             const int x1 = x0 + 512;
@@ -1409,6 +1420,7 @@ struct DecBArgs {
     float* dal;                 // (Tt,B,Ts) accumulated with atomics: zero on entry
     unsigned* cnt;              // [3 phases][RT][Tt] x CNT_WORDS, zero on entry
     unsigned* err;
+    unsigned* guard;            // {void flag, give-up count} of the driver this launch belongs to
     unsigned spin;
     unsigned long long* dbg;    // NULL, or [Tt][8] timestamps of workgroup 0 (tools/exp_dec_bwd_phases.py)
     int B, Ts, Tt, H, RT;
@@ -1570,7 +1582,7 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
             if (x1 < NP) { al1 = a.alpha[o1]; dh1_ = a.dah[o1]; }
             const float qv = threadIdx.x < 256 ? a.qhp[((int64_t)t * B + min(m0 + (int)(threadIdx.x >> 4), B - 1)) * Q + 16 * i + (threadIdx.x & 15)] : 0.f;
             // ================= B: complete d alpha -> ds -> dq of the own query columns =================
-            wait_count(cA + t * CNT_WORDS, PER_SHARD, a.err, a.spin, dead);
+            wait_count(cA + t * CNT_WORDS, PER_SHARD, a.err, a.guard, a.spin, dead);
             VAG_STAMP(2);
             float v0, v1;
             const float* p0 = a.dal + o0;
@@ -1647,7 +1659,7 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
             hp1 = *reinterpret_cast<const float4*>((t > 0 ? a.h2_all + (int64_t)(t - 1) * BH : a.h0) + o);
         }
         VAG_STAMP(4);
-        wait_count(cB + t * CNT_WORDS, PER_SHARD, a.err, a.spin, dead);
+        wait_count(cB + t * CNT_WORDS, PER_SHARD, a.err, a.guard, a.spin, dead);
         VAG_STAMP(5);
         {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1696,7 +1708,7 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
             hp2 = *reinterpret_cast<const float4*>(a.h1 + (int64_t)(t - 1) * BH + o);
         }
         VAG_STAMP(6);
-        wait_count(cC + t * CNT_WORDS, PER_SHARD, a.err, a.spin, dead);
+        wait_count(cC + t * CNT_WORDS, PER_SHARD, a.err, a.guard, a.spin, dead);
         VAG_STAMP(7);
         {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1752,6 +1764,7 @@ void vag_persist_set_prezeroed(bool v) { g_prezeroed = v; }
 
 struct PersistTimer { hipEvent_t e0 = nullptr, e1 = nullptr; bool pending = false; double ms = 0.0; int n = 0; };
 static PersistTimer g_ptimer[4];
+static std::mutex g_ptimer_mu;          // measurement state, touched only with "persist_timing" on: one lock for the four timers
 static void ptimer_collect(PersistTimer& t) {
     if (!t.pending) return;
     float ms = 0.f;
@@ -1763,16 +1776,19 @@ static bool ptimer_begin(int kind, hipStream_t s) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
     if (st != hipStreamCaptureStatusNone) return false;
+    std::lock_guard<std::mutex> lk(g_ptimer_mu);
     PersistTimer& t = g_ptimer[kind];
     ptimer_collect(t);
     if (!t.e0 && (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess)) return false;
     return hipEventRecord(t.e0, s) == hipSuccess;
 }
 static void ptimer_end(int kind, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_ptimer_mu);
     if (hipEventRecord(g_ptimer[kind].e1, s) == hipSuccess) g_ptimer[kind].pending = true;
 }
 int vag_persistent_time_read(int kind, double* ms_total, int* launches) {
     VAG_CHECK_ARG(kind >= 0 && kind < 4 && ms_total && launches);
+    std::lock_guard<std::mutex> lk(g_ptimer_mu);
     PersistTimer& t = g_ptimer[kind];
     ptimer_collect(t);
     *ms_total = t.ms; *launches = t.n;
@@ -1841,7 +1857,7 @@ int vag_enc_fwd_persistent_launch(const float* xp, const float* w_fw, const floa
     a.hst = hst; a.gates = gates; a.enc = enc; a.rng = rng; a.p_ctx = p_ctx;
     a.B = (int)B; a.Ts = (int)Ts; a.H = (int)H; a.RT = (int)cdiv64(B, 16); a.CS = (int)(H / 16);
     const int nwords = (int)vag_enc_persistent_sync_words(B, Ts);
-    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard();
     if (!g_prezeroed) {
         hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
         VAG_LAUNCH_CHECK();
@@ -1883,7 +1899,7 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
     a.b_ih2 = b_ih2; a.h1 = h1; a.g1 = g1; a.qhp = qhp; a.alpha = alpha; a.h2_all = h2_all; a.g2 = g2; a.psc = psc;
     a.B = (int)B; a.Ts = (int)Ts; a.Tt = (int)Tt; a.H = (int)H; a.RT = (int)cdiv64(B, 16);
     const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
-    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard();
 #ifdef VAG_LAB
     a.dbg = reinterpret_cast<unsigned long long*>(vag_opt().dec_stamps);
 #else
@@ -1943,7 +1959,7 @@ int vag_dec_free_persistent_launch(const float* pe, const float* mask, const flo
     a.hw1 = hw1; a.hb1 = hb1; a.hb2 = hb2; a.hb3 = hb3; a.out_w = out_w; a.out_b = out_b; a.tmid = tmid; a.logits = logits;
     a.tok = tok; a.rng = rng; a.p_out = p_out; a.V = (int)V; a.ldl = (int)ldl;
     const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
-    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard();
 #ifdef VAG_LAB
     a.dbg = reinterpret_cast<unsigned long long*>(vag_opt().dec_stamps);       // (Tt + 1) x 16 words in this form
 #else
@@ -1985,7 +2001,7 @@ int vag_enc_fwd_wide16_launch(const float* xp, const vag_half* w16_fw, const vag
     a.hst = hst; a.gates = gates; a.enc = enc; a.hx = hx;
     a.B = (int)B; a.Ts = (int)Ts; a.H = (int)H; a.RG = (int)cdiv64(B, 64); a.CS = (int)(H / 32);
     const int nwords = (int)vag_enc_persistent_sync_words(B, Ts);
-    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard();
     if (!g_prezeroed) {
         hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
         VAG_LAUNCH_CHECK();
@@ -2015,7 +2031,7 @@ int vag_enc_bwd_wide16_launch(const vag_half* wt16, const float* d_enc, const fl
     a.rng = rng; a.p_ctx = p_ctx; a.d_xp = d_xp; a.dgh = dgh; a.gx = gx;
     a.B = (int)B; a.Ts = (int)Ts; a.H = (int)H; a.RG = (int)cdiv64(B, 64); a.CS = (int)(H / 32);
     const int nwords = (int)vag_enc_persistent_sync_words(B, Ts);
-    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard();
     if (!g_prezeroed) {
         hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
         VAG_LAUNCH_CHECK();
@@ -2044,7 +2060,7 @@ int vag_enc_bwd_persistent_launch(const float* whhT, const float* d_enc, const f
     a.rng = rng; a.p_ctx = p_ctx; a.d_xp = d_xp; a.dgh = dgh;
     a.B = (int)B; a.Ts = (int)Ts; a.H = (int)H; a.RT = (int)cdiv64(B, 16); a.CS = (int)(H / 16);
     const int nwords = (int)vag_enc_persistent_sync_words(B, Ts);
-    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard();
     if (!g_prezeroed) {
         hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
         VAG_LAUNCH_CHECK();
@@ -2056,10 +2072,15 @@ int vag_enc_bwd_persistent_launch(const float* whhT, const float* d_enc, const f
     return VAG_OK;
 }
 
-// Device address of the word a give-up sets (read and cleared by adam_prep_kernel; NULL if the symbol cannot be resolved).
-unsigned* vag_persist_poison_word(void) {
+// The guard pair of launches enqueued by the calling thread: the caller's own (vag_train_step: vag_step_cfg.guard; operators:
+// vag_set_operator_guard) or the process-wide pair.
+static thread_local unsigned* g_thread_guard = nullptr;
+void vag_persist_guard_set(unsigned* g) { g_thread_guard = g; }
+unsigned* vag_persist_guard_peek(void) { return g_thread_guard; }
+unsigned* vag_persist_guard(void) {
+    if (g_thread_guard) return g_thread_guard;
     void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_persist_poison)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_persist_guard)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return reinterpret_cast<unsigned*>(p);
 }
 // Number of waits that gave up since the last call (synchronises the device).  0 in a healthy run.
@@ -2098,7 +2119,7 @@ int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const flo
 #endif
     a.B = (int)B; a.Ts = (int)Ts; a.Tt = (int)Tt; a.H = (int)H; a.RT = (int)cdiv64(B, 16);
     const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
-    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit();
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard();
     const int nsc = (int)(Tt * B * Ts);
     if (!g_prezeroed) {
         hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64((int64_t)nwords + nsc, 256)), dim3(256), 0, s, sync, nwords,

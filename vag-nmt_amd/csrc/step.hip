@@ -53,7 +53,7 @@ StepWs step_ws(float* p, const vag_step_cfg& c) {
 
 bool cfg_ok(const vag_step_cfg* c) {
     return c && c->B > 0 && c->Ts > 0 && c->Tt > 0 && c->Es > 0 && c->Et > 0 && c->H > 0 && c->V > 0 && c->Es % 4 == 0 &&
-           c->Et % 4 == 0 && c->H % 4 == 0 && c->ldl >= c->V && c->ldl % 4 == 0 && c->loss_ring >= 0 &&
+           c->Et % 4 == 0 && c->H % 4 == 0 && c->ldl >= c->V && c->ldl % 4 == 0 && c->loss_ring >= 0 && (reinterpret_cast<uintptr_t>(c->guard) & 3) == 0 &&
            (!c->multimodal || (c->S > 0 && c->S % 4 == 0 && c->I > 0 && (c->attn_method == 0 || c->attn_method == 1) &&
                                c->rank_kind >= -1 && c->rank_kind <= 1));
 }
@@ -171,6 +171,14 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     DerivedScope scope(derived, c.storage == 1, chunk);
     LossRingScope lring(c.loss_ring);
     PrezeroScope prezero;           // (a backward-only call relies on the forward call of the same step having run first)
+    // this call's persistent recurrence launches report a give-up to the caller's guard pair (vag_step_cfg.guard), not process-wide
+    struct GuardScope {
+        unsigned* prev; bool on;
+        explicit GuardScope(void* g) : prev(nullptr), on(g != nullptr) {
+            if (on) { prev = vag_persist_guard_peek(); vag_persist_guard_set(reinterpret_cast<unsigned*>(g)); }
+        }
+        ~GuardScope() { if (on) vag_persist_guard_set(prev); }
+    } guard_scope(c.guard);
     // forward and backward in one call: the chunked head finishes each chunk (d(logits) and its products) in the forward;
     // a backward called on its own (phases = 2 after an earlier phases = 1) recomputes the chunks instead
     if (chunk > 0 && (phases & 3) == 3 && vag_opt().head_fuse != 0)

@@ -162,12 +162,21 @@ def _driver(model, optimizer, criterion_mt, criterion_vse, clip, tfr):
 
 def _unfused(existing, fn):
     """A step the fused driver does not serve, on an optimiser that may have one: torch.optim.Adam then steps on the driver's own
-    moment buffers (optimizer.state holds views of them), so only the step counter and what derives from the weights cross."""
-    if existing is not None:
-        existing.export_steps()
-    out = fn()
-    if existing is not None:
-        existing.import_steps()
+    moment buffers (optimizer.state holds views of them), so only the step counter and what derives from the weights cross.
+    The parameters' ``_vag_grad`` routing (vagnmt_hip.ops: backward accumulates straight into the flat gradient buffer and hands
+    autograd nothing) is lifted for the call, so that ``clip_grad_norm_`` and ``optimizer.step()`` see ordinary ``.grad``s."""
+    if existing is None:
+        return fn()
+    existing.export_steps()
+    routed = [(p, p._vag_grad) for _, p in existing.ts.fp.named if hasattr(p, "_vag_grad")]
+    for p, _ in routed:
+        del p._vag_grad
+    try:
+        out = fn()
+    finally:
+        for p, v in routed:
+            p._vag_grad = v
+    existing.import_steps()
     return out
 
 

@@ -42,7 +42,7 @@ class StepCfg(C.Structure):
     """vag_step_cfg"""
     _fields_ = [(n, I64) for n in ("B", "Ts", "Tt", "Es", "Et", "H", "S", "I", "V", "ldl")] + \
                [(n, I32) for n in ("multimodal", "attn_method", "activation_vse", "rank_kind", "free_run", "storage")] + \
-               [(n, F) for n in ("margin", "loss_w", "init_split", "p_emb", "p_ctx", "p_out")] + [("loss_ring", I32)]
+               [(n, F) for n in ("margin", "loss_w", "init_split", "p_emb", "p_ctx", "p_out")] + [("loss_ring", I32), ("guard", P)]
 
 
 # name -> (restype, argtypes); mirrors include/vag_nmt.h declaration by declaration
@@ -123,6 +123,7 @@ PROTOS = {
     "vag_set_option": (I32, [C.c_char_p, I64]),
     "vag_recurrence_supported": (I32, [I32, I64, I64, I64, I64]),
     "vag_persistent_timeouts": (I32, []),
+    "vag_set_operator_guard": (I32, [P]),
     "vag_recurrence_time": (I32, [I32, P, P]),
     "vag_gemm_group_plan": (I32, [I32, P, P, P, P, P, P]),
     "vag_comm_unique_id": (I32, [P]),

@@ -92,6 +92,9 @@ class FusedStep:
         self.cap = (0, 0, 0)          # (B*Ts, B*Tt, B) capacity of the static input buffers
         self.src = self.tgt = self.im = self.lens = None
         self.generation = 0           # bumped whenever a static buffer is re-allocated (captured graphs are then stale)
+        # device address of the owning driver's guard pair {void flag, give-up count} (vag_step_cfg.guard; TrainStep keeps it in its
+        # optimiser scratch) or None: the process-wide pair, which no optimiser reads
+        self.guard = None
         self.refresh_derived()
 
     # ---- configuration ----
@@ -112,6 +115,7 @@ class FusedStep:
         c.p_ctx = float(m.encoder.dropout_ctx) if train else 0.0
         c.p_out = float(m.decoder.dropout_out) if train else 0.0
         c.loss_ring = self.LOSS_RING
+        c.guard = self.guard
         return c
 
     def reserve(self, B, Ts, Tt):

@@ -240,6 +240,12 @@ class TrainStep:
                 self.backend.after_optimizer()
 
     SKIPPED_OFFSET = 28          # VAG_ADAM_SCRATCH_SKIPPED_OFFSET (include/vag_nmt.h), bytes into the optimiser scratch
+    GUARD_OFFSET = 32            # VAG_ADAM_SCRATCH_GUARD_OFFSET: this driver's {void flag, give-up count} (vag_step_cfg.guard)
+
+    def guard_ptr(self):
+        """Device address of this driver's guard pair: its persistent recurrence launches report a give-up there, its
+        optimiser kernels read it there -- another driver's (or a decoder's) give-up on the same device never voids a step here."""
+        return self._scratch.data_ptr() + self.GUARD_OFFSET if self._scratch.is_cuda else None
 
     def skipped_steps(self):
         """Optimiser steps the device refused to apply so far (non-finite gradient norm, or a persistent recurrence kernel
@@ -255,8 +261,13 @@ class TrainStep:
         the results of those launches are void; the optimiser skipped those steps on the device, so the weights are
         intact).  Called by ``set_lr`` (the validation point of the reference's loop) and by ``save_checkpoint``."""
         from ._lib import lib, VagError
-        n = lib().vag_persistent_timeouts() if self.fp.flat.is_cuda else 0
-        sk = self.skipped_steps()
+        n = sk = 0
+        if self.fp.flat.is_cuda:
+            w = self._scratch.view(torch.int32)
+            sk, _, n = w[self.SKIPPED_OFFSET // 4:self.GUARD_OFFSET // 4 + 2].tolist()      # one read: skipped, flag, give-ups
+            if n:
+                w[self.GUARD_OFFSET // 4 + 1:self.GUARD_OFFSET // 4 + 2].zero_()
+            self.process_timeouts = lib().vag_persistent_timeouts()      # every driver's and every unguarded launch's; read + reset
         new_sk, self._skipped_seen = sk - getattr(self, "_skipped_seen", 0), sk
         f = getattr(self.backend, "f", None)
         if f is not None and f.losses.is_cuda:
@@ -265,9 +276,9 @@ class TrainStep:
                 raise VagError("result ring out of step: the device executed %d forward phases, the host counted %d"
                                % (dev_n, f.executed))
         if n != 0 or (raise_on_skip and new_sk != 0):
-            raise VagError("%d optimiser step(s) skipped on the device (void gradient); persistent recurrence kernels: %d "
-                           "waits gave up%s" % (new_sk, n, "; a GPU that is not this process's alone needs "
-                                                "set_option('persistent', 0)" if n else ""))
+            raise VagError("%d optimiser step(s) skipped on the device (void gradient); persistent recurrence kernels of this "
+                           "driver: %d waits gave up%s" % (new_sk, n, "; a GPU that is not this process's alone needs "
+                                                           "set_option('persistent', 0)" if n else ""))
 
     # ---- public ----
     def step(self, src, lengths, tgt, im=None, teacher=None):
@@ -320,6 +331,7 @@ class _FusedBackend:
 
     def __init__(self, ts, fused):
         self.ts, self.f = ts, fused
+        fused.guard = ts.guard_ptr()
 
     @property
     def generation(self):
@@ -414,6 +426,17 @@ class _AutogradBackend:
     def run(self, src, lengths, tgt, im, teacher, phases, reuse=False):
         ts = self.ts
         tfr = 1.0 if teacher else 0.0       # the coin is drawn by the caller
+        g = ts.guard_ptr()
+        if g is not None:                   # the operators' persistent launches report to this driver's guard pair
+            call("vag_set_operator_guard", g)
+        try:
+            self._run(src, lengths, tgt, im, tfr)
+        finally:
+            if g is not None:
+                call("vag_set_operator_guard", None)
+
+    def _run(self, src, lengths, tgt, im, tfr):
+        ts = self.ts
         if ts.multimodal:
             loss, loss_mt, loss_vse = ts.model(src, lengths, tgt, im, tfr, criterion_mt=ts.criterion_mt,
                                                criterion_vse=ts.criterion_vse)
