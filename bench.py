@@ -397,6 +397,10 @@ def measure_extras(c, dev, ts, args):
             out[key] = {"error": repr(e)[:300]}
     m4.train(was)
     try:
+        out["stream"] = measure_stream(c, dev)
+    except Exception as e:   # noqa: BLE001
+        out["stream"] = {"error": repr(e)[:300]}
+    try:
         out["configs0_text_only"] = measure_cfg1(dev, steps=60)
     except Exception as e:   # noqa: BLE001
         out["configs0_text_only"] = {"error": repr(e)[:300]}
@@ -525,6 +529,91 @@ def measure_cfg1(dev, steps=100, warmup=10, cpu=True):
                                "sample": "4 full optimiser steps (median, after 2 warm-up) per thread count in (4, 8, 16), the "
                                          "fastest count reported; oracle in the reference's op order, train mode"}
     return row
+
+
+def measure_stream(c, dev, n_pairs=30000, eval_batches=64, seed=4242):
+    """An epoch-shaped run (preprocessing.py:308-384, samplers/bucket.py:37-99, nmt_multimodal_beam_DE.py:391-443):
+    a synthetic Multi30K-shaped corpus -- source and target lengths ~ clip(round(N(15, 5)), 4, 40), independent -- resident on the
+    device (DeviceCorpus), walked once in the reference's batch order (BucketBatchSampler over TARGET lengths, B = 64 with bucket
+    remainders, rows sorted by source length), every batch one optimiser step at the reference's teacher forcing ratio 0.8, then
+    one beam-12 and one greedy decode of `eval_batches` eval batches of 16.  Wall clock around the whole loop: batch assembly, the
+    lengths' upload, graph captures, LRU evictions and eager first visits are all inside.  A second epoch over the same corpus
+    (another shuffle, warm graph cache) is timed beside it."""
+    import random
+    import numpy as np
+    from vagnmt_hip.data import DeviceCorpus, data_generator_tl_mtv
+    from vagnmt_hip.trainer import TrainStep
+    from machine_translation_vision.losses import PairwiseRankingLoss
+    rs = np.random.RandomState(seed)
+    lx = np.clip(np.rint(rs.normal(15, 5, n_pairs)), 4, c["Ts"]).astype(np.int64)
+    ly = np.clip(np.rint(rs.normal(15, 5, n_pairs)), 4, c["Tt"]).astype(np.int64)
+    pairs = []
+    for i in range(n_pairs):
+        y = rs.randint(4, c["V"], ly[i])
+        y[-1] = 3
+        pairs.append((rs.randint(4, c["Vs"], lx[i]), y))
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(n_pairs, c["I"], generator=g).abs_()
+    corpus = DeviceCorpus(pairs, feats.numpy(), dev)
+    del feats
+    m = build_model(c, dev)
+    vw = torch.ones(c["V"], device=dev)
+    vw[0] = 0
+    ts = TrainStep(m, torch.nn.NLLLoss(weight=vw, reduction="none"), PairwiseRankingLoss(margin=0.1), lr=4e-4, weight_decay=1e-5,
+                   clip=1.0, teacher_force_ratio=0.8)
+    random.seed(seed)
+    out = {"corpus_pairs": n_pairs, "batch_size": c["B"], "teacher_force_ratio": 0.8, "max_graphs": ts.max_graphs,
+           "pad_src": ts.pad_src}
+    for epoch in range(2):
+        before = dict(ts.stats)
+        shapes = set()
+        n_steps = n_seen = 0
+        tok = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        t_host = 0.0
+        for bx, by, bim, xl, yl in data_generator_tl_mtv(corpus, c["B"], seed=seed + epoch):
+            th = time.perf_counter()
+            res = ts.step(bx, xl, by, bim)
+            t_host += time.perf_counter() - th
+            shapes.add((bx.shape[0], (bx.shape[1] + ts.pad_src - 1) // ts.pad_src * ts.pad_src, by.shape[1]))
+            n_steps += 1
+            n_seen += bx.shape[0]
+            tok += sum(yl)
+            if n_steps % 100 == 0:
+                float(res[0])                       # the reference prints a running loss every print_every steps (:406-416)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = {k: ts.stats[k] - before[k] for k in ts.stats}
+        out["epoch%d" % (epoch + 1)] = {"steps": n_steps, "pairs": n_seen, "seconds": dt, "pairs_per_s": n_seen / dt,
+                                        "ms_per_step": dt / n_steps * 1e3, "target_tokens_per_s": tok / dt,
+                                        "distinct_shapes": len(shapes), "host_seconds_inside_step_calls": t_host, **st}
+    ts.check()
+    out["skipped_steps"] = ts.skipped_steps()
+    # the evaluation cycle's decodes (nmt_multimodal_beam_DE.py:438-443: eval batch 16, beam 12, max length 80)
+    c4 = dict(c)
+    c4["B"] = 16
+    m.eval()
+    evs = [make_batch(c4, 100 + i, dev, ragged=True) for i in range(min(eval_batches, 8))]
+    dec = {}
+    for k, key in ((12, "beam12"), (1, "greedy")):
+        for b in evs[:2]:
+            m.beamsearch_decode(b[0], b[1], b[3], k, 80)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(eval_batches):
+            b = evs[i % len(evs)]
+            m.beamsearch_decode(b[0], b[1], b[3], k, 80)
+        torch.cuda.synchronize()
+        dec[key + "_seconds"] = time.perf_counter() - t0
+    out["decode"] = dict(dec, eval_batches=eval_batches, sentences=16 * eval_batches)
+    e2 = out["epoch2"]
+    # the reference evaluates every eval_every = 1000 steps (:65): the decodes' share of 1000 training steps + one cycle
+    per1000 = 1000 * e2["seconds"] / e2["steps"]
+    out["decode_share_of_wall_at_eval_every_1000"] = (dec["beam12_seconds"]) / (per1000 + dec["beam12_seconds"])
+    del corpus, ts, m
+    torch.cuda.empty_cache()
+    return out
 
 
 def measure_reference_trainer(c, dev, n=40, warm=6):

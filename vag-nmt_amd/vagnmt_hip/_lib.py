@@ -198,36 +198,61 @@ def stream():
 
 
 class capture:
-    """``with capture(graph):`` -- torch.cuda.graph(graph) with Python's garbage collector held off for the duration of the
-    capture and errors confined to the capturing thread.  A collection that runs INSIDE a capture can free tensors whose
-    storage the caching allocator must first fence on another stream (anything that went through ``record_stream``, e.g.
-    gradient buckets handed to an exchange stream): that event record on a non-capturing stream aborts the process (found as
-    a silent abort ~100 tests after a data-parallel test, always inside a decode-graph capture)."""
+    """``with capture(graph):`` -- stream capture into a torch.cuda.CUDAGraph on a side stream, errors confined to the capturing
+    thread, Python's garbage collector held off for the duration.
+
+    Not ``torch.cuda.graph(graph)``: that context manager runs ``torch.cuda.synchronize(); gc.collect(); torch.cuda.empty_cache()``
+    on entry -- ~25 ms per capture here, and every cached block of the allocator handed back to the driver, so the steps after a
+    capture pay ``hipMalloc`` again.  A bucketed batch stream meets a new (B, Ts, Tt) shape every few steps: with those captures an
+    epoch-shaped run was 4-5x SLOWER than eager launches (profiles/r05_exp_stream.txt).  The captured regions of this package
+    allocate nothing (static workspaces), so none of the three is needed.
+    The collector stays off because a collection that runs INSIDE a capture can free tensors whose storage the caching allocator
+    must first fence on another stream (anything that went through ``record_stream``, e.g. gradient buckets handed to an exchange
+    stream): that event record on a non-capturing stream aborts the process (found as a silent abort ~100 tests after a
+    data-parallel test, always inside a decode-graph capture)."""
+    _streams = {}
 
     def __init__(self, graph):
-        self._cm = torch.cuda.graph(graph, capture_error_mode="thread_local")
+        self._graph = graph
         self._gc = False
+        self._ctx = None
 
     def __enter__(self):
         import gc
+        dev = torch.cuda.current_device()
+        side = capture._streams.get(dev)
+        if side is None:
+            side = capture._streams[dev] = torch.cuda.Stream(device=dev)
         self._gc = gc.isenabled()
         if self._gc:
-            gc.collect()
             gc.disable()
         try:
-            return self._cm.__enter__()
+            side.wait_stream(torch.cuda.current_stream())
+            self._ctx = torch.cuda.stream(side)
+            self._ctx.__enter__()
+            try:
+                self._graph.capture_begin(capture_error_mode="thread_local")
+            except BaseException:
+                self._ctx.__exit__(None, None, None)
+                raise
         except BaseException:
             if self._gc:          # the capture never began (already capturing, allocator error): __exit__ will not run
                 gc.enable()
             raise
+        return self
 
     def __exit__(self, *exc):
         import gc
         try:
-            return self._cm.__exit__(*exc)
+            self._graph.capture_end()
         finally:
-            if self._gc:
-                gc.enable()
+            try:
+                self._ctx.__exit__(*exc)
+                torch.cuda.current_stream().wait_stream(capture._streams[torch.cuda.current_device()])
+            finally:
+                if self._gc:
+                    gc.enable()
+        return False
 
 
 def ptr(t, dtype=torch.float32):

@@ -16,7 +16,16 @@ from machine_translation_vision.samplers import BucketBatchSampler
 from ._lib import call, ptr, stream
 
 
+class LengthList(list):
+    """The reference's ``x_lengths_sorted`` (a Python list, preprocessing.py:384) that also carries the same numbers as an int32
+    device tensor (``.device_tensor``, uploaded together with the batch's row indices): TrainStep.step takes that instead of
+    uploading the list again from pageable memory -- a copy the host would wait on behind all queued GPU work."""
+    device_tensor = None
+
+
 class DeviceCorpus:
+    RING = 16                 # pinned upload slots: a slot is rewritten only after RING further batches (its copy has long run)
+
     def __init__(self, data_pairs, data_im, device):
         n = len(data_pairs)
         self.x_len = np.array([len(p[0]) for p in data_pairs], dtype=np.int64)
@@ -31,6 +40,34 @@ class DeviceCorpus:
         self.x = torch.from_numpy(x).to(device)
         self.y = torch.from_numpy(y).to(device)
         self.im = torch.as_tensor(np.asarray(data_im), dtype=torch.float32).contiguous().to(device) if data_im is not None else None
+        self._ring, self._slot, self._events = None, 0, None
+
+    def _upload(self, idx, x_len_sorted):
+        """Row indices (int64) and source lengths (int32) of a batch to the device in ONE asynchronous copy from a pinned slot:
+        the host does not wait for the GPU (a pageable copy is stream-ordered behind every queued kernel and blocks the host until
+        the device gets there: one drained pipeline per batch)."""
+        b = len(idx)
+        is_cuda = torch.device(self.device).type == "cuda"
+        if not is_cuda:
+            dev_idx = torch.from_numpy(np.ascontiguousarray(idx)).to(self.device)
+            return dev_idx, torch.tensor(x_len_sorted, dtype=torch.int32, device=self.device)
+        cap = 4 * max(b, 64)                   # (rows of the ring start 8-byte aligned: the int64 view below)
+        if self._ring is None or self._ring.shape[1] < 3 * b:
+            self._ring = torch.empty(self.RING, cap, dtype=torch.int32).pin_memory()
+            self._events = [None] * self.RING
+            self._slot = 0
+        k = self._slot
+        self._slot = (k + 1) % self.RING
+        if self._events[k] is not None:
+            self._events[k].synchronize()          # (RING batches ago: long done)
+        host = self._ring[k]
+        host[:2 * b].view(torch.int64).copy_(torch.from_numpy(np.ascontiguousarray(idx)))
+        host[2 * b:3 * b].copy_(torch.from_numpy(np.asarray(x_len_sorted, dtype=np.int32)))
+        dev = host[:3 * b].to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._events[k] = ev
+        return dev[:2 * b].view(torch.int64), dev[2 * b:3 * b]
 
     def batch(self, bidx):
         """Assemble one batch from sample indices (any order); returns the reference's tuple."""
@@ -38,11 +75,11 @@ class DeviceCorpus:
         xl = self.x_len[bidx]
         order = np.argsort(xl)[::-1]                       # preprocessing.py:354-356: argsort ascending, then reversed
         idx = bidx[order]
-        x_len_sorted = [int(v) for v in self.x_len[idx]]
+        x_len_sorted = LengthList(int(v) for v in self.x_len[idx])
         y_len_sorted = [int(v) for v in self.y_len[idx]]
         wx, wy = max(x_len_sorted), max(y_len_sorted)
         b = len(idx)
-        dev_idx = torch.from_numpy(np.ascontiguousarray(idx)).to(self.device)
+        dev_idx, x_len_sorted.device_tensor = self._upload(idx, x_len_sorted)
         bx = torch.empty(b, wx, dtype=torch.int64, device=self.device)
         by = torch.empty(b, wy, dtype=torch.int64, device=self.device)
         s = stream()

@@ -105,8 +105,8 @@ class TrainStep:
 
     def __init__(self, model, criterion_mt, criterion_vse=None, lr=4e-4, weight_decay=1e-5, clip=1.0,
                  teacher_force_ratio=0.8, betas=(0.9, 0.999), eps=1e-8, vse_separate=False, use_graph=True,
-                 process_group=None, world_size=1, max_graphs=48, pad_src=4, fused=None, backend=None,
-                 force_phased=False, storage="f32", comm=None, groups=None):
+                 process_group=None, world_size=1, max_graphs=256, pad_src=4, fused=None, backend=None,
+                 force_phased=False, storage="f32", comm=None, groups=None, capture_after=1):
         self.model = model
         self.criterion_mt = criterion_mt
         self.criterion_vse = criterion_vse
@@ -122,6 +122,10 @@ class TrainStep:
         self.comm = comm
         self.force_phased = force_phased      # tests: the data-parallel sequence (two phases, two buckets) at world_size 1
         self.max_graphs = max_graphs
+        # eager visits of a (shape, phases) key before it is captured: replay and eager launches take the same time while the GPU
+        # is the bottleneck (measured: 3.284 vs 3.292 ms at configs[1], 1.91 vs 2.02 ms per step on a bucketed stream), a capture
+        # costs ~1 ms, and a bucketed epoch holds ~200 keys of which many are met once or twice: shapes met once never pay for one (capture_after = 1: the second visit captures)
+        self.capture_after = max(1, int(capture_after))
         self.pad_src = max(1, int(pad_src))
         self.fp = FlatParams(model, vse_separate, groups)
         dev = self.fp.flat.device
@@ -214,7 +218,6 @@ class TrainStep:
             if key not in self._seen:
                 self._seen[key] = True
                 return self._optimizer()
-            torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with _capture(g):
                 self._optimizer()
@@ -289,7 +292,8 @@ class TrainStep:
         if teacher is None:
             teacher = random.random() < self.tfr                     # models/...V11.py:136
         if not torch.is_tensor(lengths):
-            lengths = torch.tensor(list(lengths), dtype=torch.int32, device=src.device)
+            dt = getattr(lengths, "device_tensor", None)      # vagnmt_hip.data.LengthList: already on the device
+            lengths = dt if dt is not None else torch.tensor(list(lengths), dtype=torch.int32, device=src.device)
         lengths = lengths.to(torch.int32)
         be = self.backend
         if be is None:
@@ -374,9 +378,10 @@ class _FusedBackend:
         if ent is not None:
             ts._graphs.move_to_end(key)
         if ent is None or phases not in ent:
-            if (key, phases) not in ts._seen:
-                # first visit of a shape: run eagerly (rare shapes never pay for a capture), capture on the next visit
-                ts._seen[(key, phases)] = True
+            seen = ts._seen.get((key, phases), 0)
+            if seen < ts.capture_after:
+                # the first visits of a shape run eagerly (rare shapes never pay for a capture), a later visit captures
+                ts._seen[(key, phases)] = seen + 1
                 while len(ts._seen) > 8192:
                     ts._seen.popitem(last=False)
                 ts.stats["eager_steps"] += 1
@@ -387,7 +392,6 @@ class _FusedBackend:
                 while len(ts._graphs) > ts.max_graphs:
                     ts._graphs.popitem(last=False)
                     ts.stats["evictions"] += 1
-            torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with _capture(g):
                 launch()
