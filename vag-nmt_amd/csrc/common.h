@@ -122,6 +122,9 @@ struct VagOptions {
     int s16_one_plane = 1;       // 2-byte storage mode of the step driver: forward products on ONE fp16 plane, gradient products on
                                  // ONE bf16 plane (0: two bf16 planes everywhere, as the operators on their own use)
     int head_bf16_dlogits = 1;   // 2-byte storage mode, chunked head: d(logits) of a chunk is written and read as bf16 (0: fp32 in place)
+    int leaf_queue = 1;          // 0: the small weight-gradient products of the VSE / initial-state backward go out one by one (round 4)
+    int step_fork = 0;           // side-stream branches inside vag_train_step, bit 0: the image projection beside the encoder, bit 1: the
+                                 // held-back weight-gradient leaves beside the encoder's backward.  Off: measured SLOWER
     int64_t persist_spin_limit = 0;   // > 0: polls before a persistent kernel's wait gives up (default 2^19); tests force a give-up with 1
     int persist_timing = 0;      // 1: HIP events around the recurrence kernels of eager launches (vag_recurrence_time)
     int64_t dec_bwd_stamps = 0;  // the same for the persistent decoder backward
@@ -182,6 +185,9 @@ struct VagGemmGroup {
     VagGemmGroup(const VagGemmGroup&) = delete;
     VagGemmGroup& operator=(const VagGemmGroup&) = delete;
 };
+void vag_leaf_begin();                 // hold back small rank-B weight-gradient products (+ their column sums): gemm.hip
+int vag_leaf_flush(hipStream_t stream);  // ... and launch them as one grid
+void vag_leaf_abort();
 int vag_colsum_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* out, hipStream_t stream);
 int vag_colsum3_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* out, float* out2, float* out3,
                        hipStream_t stream);

@@ -84,16 +84,15 @@ __device__ __forceinline__ void tile_store(float* __restrict__ S, const float4 (
 // NTH = 256: 4 waves as 2x2, each (BM/2)x(BN/2).  NTH = 512: 8 waves as 2x4, each (BM/2)x(BN/4): two waves per SIMD,
 // so one workgroup alone on a CU (the usual case for this model's mid-size products) still overlaps LDS reads with MFMAs.
 template <int BM, int BN, bool AKC, bool BKC, bool VEC, int NTH>
-__global__ __launch_bounds__(NTH) void gemm_tiled_kernel(GemmArgs a) {
+__device__ __forceinline__ void gemm_tiled_body(const GemmArgs& a, float* smem, int bx, int by, int bz) {
     constexpr int WN = NTH / 128;                 // waves along N
     constexpr int TM = BM / 64, TN = BN / (32 * WN);
     constexpr int LDA = BM + 4, LDB = BN + 4;
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDA + 2 * BK * LDB];
     float* As = smem;
     float* Bs = smem + 2 * BK * LDA;
 
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * a.kchunk;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int kbeg = bz * a.kchunk;
     const int kend = min(a.K, kbeg + a.kchunk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -146,7 +145,7 @@ __global__ __launch_bounds__(NTH) void gemm_tiled_kernel(GemmArgs a) {
 
     // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     const bool atomic = a.splitk > 1;
-    const bool first = blockIdx.z == 0;
+    const bool first = bz == 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -159,6 +158,41 @@ __global__ __launch_bounds__(NTH) void gemm_tiled_kernel(GemmArgs a) {
             if (a.c_half) gemm_epilogue16(acc[i][j], a.C, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, false, 1, (int64_t)row0 * a.ldc + col);
             else gemm_epilogue16(acc[i][j], cbase, a.ldc, a.M - row0, a.alpha, a.beta, bv, a.act, atomic);
         }
+}
+template <int BM, int BN, bool AKC, bool BKC, bool VEC, int NTH>
+__global__ __launch_bounds__(NTH) void gemm_tiled_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + 4) + 2 * BK * (BN + 4)];
+    gemm_tiled_body<BM, BN, AKC, BKC, VEC, NTH>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several small weight-gradient products g_W += dY^T X of ONE launch (the leaf queue below): 64 x 64 tiles of the exact f32 kernel,
+// both operands outer-contiguous, tiles of all tasks numbered through (tile0[k] = first tile of task k).  A task's optional
+// rowsum (the bias gradient sum_r dY[r,:] that goes with it) is taken by the task's first column of tiles straight from memory.
+constexpr int LEAF_MAX = 8;
+struct LeafTasks {
+    GemmArgs g[LEAF_MAX];
+    int tile0[LEAF_MAX + 1];
+    int tiles_x[LEAF_MAX];
+    int n;
+};
+__global__ __launch_bounds__(256) void gemm_tiled_multi_kernel(LeafTasks T) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * 68 + 2 * BK * 68];
+    int k = 0;
+    while (k + 1 < T.n && (int)blockIdx.x >= T.tile0[k + 1]) ++k;
+    const int t = blockIdx.x - T.tile0[k];
+    const GemmArgs& a = T.g[k];
+    const int bx = t % T.tiles_x[k], by = t / T.tiles_x[k];
+    if (a.rowsum && bx == 0 && threadIdx.x < 64) {
+        const int m = by * 64 + threadIdx.x;
+        if (m < a.M) {
+            float s0 = 0.f, s1 = 0.f;
+            int r = 0;
+            for (; r + 1 < a.K; r += 2) { s0 += a.A[(int64_t)r * a.sa_k + m]; s1 += a.A[(int64_t)(r + 1) * a.sa_k + m]; }
+            if (r < a.K) s0 += a.A[(int64_t)r * a.sa_k + m];
+            a.rowsum[m] += s0 + s1;
+        }
+    }
+    gemm_tiled_body<64, 64, false, false, true, 256>(a, smem, bx, by, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -727,11 +761,52 @@ int vag_gemm_group_end(hipStream_t stream) {
     return rc;
 }
 
+// Leaf queue (step driver, backward of the VSE branch and of the initial state: VSE_Imagine_Enc.py:110-152, V11.py:118): the
+// weight-gradient products of those operators are rank-B updates (K = B <= 128 rows) that nothing later in the step reads -- five
+// launches of the 64 x 64 kernel and three column-sum launches, ~5 us each, strung between the kernels of a 28-launch chain.  Between
+// vag_leaf_begin and vag_leaf_flush such products (and the column sums that go with them) are held back and go out as ONE launch
+// at the flush; their operands must stay untouched until then (the step driver's do: api.hip).
+static thread_local bool g_leaf_on = false;
+static thread_local LeafTasks g_leaf;
+void vag_leaf_begin() { g_leaf_on = vag_opt().leaf_queue != 0; g_leaf.n = 0; g_leaf.tile0[0] = 0; }
+void vag_leaf_abort() { g_leaf_on = false; g_leaf.n = 0; }
+bool vag_leaf_attach_rowsum(const float* X, int64_t rows, int64_t N, int64_t ld, float* out) {
+    if (!g_leaf_on) return false;
+    for (int k = 0; k < g_leaf.n; ++k) {
+        GemmArgs& q = g_leaf.g[k];
+        if (q.A == X && q.K == (int)rows && q.M == (int)N && q.sa_k == ld && !q.rowsum) { q.rowsum = out; return true; }
+    }
+    return false;
+}
+int vag_leaf_flush(hipStream_t stream) {
+    const bool was = g_leaf_on;
+    g_leaf_on = false;
+    const int n = g_leaf.n;
+    if (!was || n == 0) { g_leaf.n = 0; return VAG_OK; }
+    hipLaunchKernelGGL(gemm_tiled_multi_kernel, dim3((unsigned)g_leaf.tile0[n]), dim3(256), 0, stream, g_leaf);   // (n travels in the struct)
+    g_leaf.n = 0;
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
 int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
                     const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc,
                     const float* bias, int act, hipStream_t stream, int c_half, float* rowsum, int a_bf16) {
     const bool opt_f32mfma = vag_opt().gemm_f32mfma != 0;      // vag_set_option("gemm_f32mfma"): the bf16x6 bound test flips it
     const bool opt_nogroup = vag_opt().gemm_nogroup != 0;
+    if (g_leaf_on && g_leaf.n < LEAF_MAX && M > 0 && N > 0 && K > 0 && K <= 128 && sam == 1 && sbn == 1 && alpha == 1.f && beta == 1.f &&
+        !bias && act == VAG_ACT_NONE && !c_half && !a_bf16 && A && B && C && aligned16(A) && aligned16(B) && sak % 4 == 0 && sbk % 4 == 0 &&
+        M < (1 << 20) && N < (1 << 20)) {
+        const int k = g_leaf.n++;
+        GemmArgs& g = g_leaf.g[k];
+        g.A = A; g.B = B; g.C = C; g.bias = nullptr;
+        g.sa_o = 1; g.sa_k = sak; g.sb_o = 1; g.sb_k = sbk; g.ldc = ldc;
+        g.M = (int)M; g.N = (int)N; g.K = (int)K; g.kchunk = (int)(cdiv64(K, BK) * BK);
+        g.alpha = 1.f; g.beta = 1.f; g.act = VAG_ACT_NONE; g.splitk = 1; g.c_half = 0; g.a_bf16 = 0; g.rowsum = rowsum;
+        g_leaf.tiles_x[k] = (int)cdiv64(N, 64);
+        g_leaf.tile0[k + 1] = g_leaf.tile0[k] + (int)(cdiv64(N, 64) * cdiv64(M, 64));
+        return VAG_OK;
+    }
     VAG_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && A && B && C);
     if (M == 0 || N == 0) return VAG_OK;
     VAG_CHECK_ARG(M < (1ll << 30) && N < (1ll << 30) && K < (1ll << 30));
@@ -2187,6 +2262,7 @@ int vag_colsum3_launch(const float* X, int64_t M, int64_t N, int64_t ld, float* 
                        hipStream_t stream) {
     VAG_CHECK_ARG(X && out && M >= 0 && N >= 0);
     if (M == 0 || N == 0) return VAG_OK;
+    if (!out2 && !out3 && vag_leaf_attach_rowsum(X, M, N, ld, out)) return VAG_OK;     // rides in the held-back product that reads X
     if (g_colsum_queue_on && g_colsum_n < COLSUM_MAX && M < (1ll << 30) && N < (1ll << 30)) {
         const int64_t nbx = cdiv64(N, 256);
         int64_t splits = cdiv64(1024, nbx);

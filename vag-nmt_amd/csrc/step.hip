@@ -141,6 +141,61 @@ int64_t vag_step_ws_offset(const vag_step_cfg* cfg, int which) {
     return (int64_t)(p - base);
 }
 
+}  // extern "C"
+
+// Side branches of a step (round 5).  What a step launches is one chain on the caller's stream, except for work that nothing on
+// the chain waits for soon: the image projection of the forward pass (needs only the batch: it runs while the encoder does) and
+// the held-back weight-gradient leaves of the backward pass (needed by the optimiser only: they run beside the encoder's backward
+// recurrence).  Such work goes to a library-owned side stream between fork() and join(): an event recorded on the caller's
+// stream, waited for by the side stream, and back.  Under stream capture both become graph edges (the side stream joins the
+// capture through the event), eagerly they are two cheap runtime calls each.  One side stream and four events per host thread
+// and device, created on first use, never destroyed (a handful per process).
+namespace {
+struct ForkState { hipStream_t side = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; int dev = -1; };
+thread_local ForkState g_fork[8];
+ForkState* fork_state() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    ForkState* f = nullptr;
+    for (auto& x : g_fork) if (x.dev == dev) { f = &x; break; }
+    if (!f) for (auto& x : g_fork) if (x.dev < 0) { f = &x; break; }
+    if (!f) return nullptr;
+    if (!f->side) {
+        if (hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); f->side = nullptr; return nullptr; }
+        for (auto& e : f->ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        f->dev = dev;
+    }
+    return f;
+}
+// a branch: fork(main, slot) returns the side stream (or `main` itself when forks are off / unavailable: the work then simply
+// stays on the chain); join(main, slot) makes `main` wait for everything the side stream was given since
+struct StepBranch {
+    ForkState* f = nullptr;
+    bool open = false;
+    hipStream_t fork(hipStream_t main, int slot, int bit) {
+        if ((vag_opt().step_fork & bit) == 0) return main;
+        f = fork_state();
+        if (!f) return main;
+        if (hipEventRecord(f->ev[slot], main) != hipSuccess || hipStreamWaitEvent(f->side, f->ev[slot], 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return main;
+        }
+        open = true;
+        return f->side;
+    }
+    int join(hipStream_t main, int slot) {
+        if (!open) return VAG_OK;
+        open = false;
+        if (hipEventRecord(f->ev[slot], f->side) != hipSuccess || hipStreamWaitEvent(main, f->ev[slot], 0) != hipSuccess)
+            return (int)hipGetLastError();
+        return VAG_OK;
+    }
+};
+}  // namespace
+
+extern "C" {
+
 int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_model_g* gp, const int64_t* src,
                    const int32_t* lengths, const int64_t* tgt, const float* im, const float* vocab_weight, uint64_t* rng,
                    const float* derived, float* ws, float* losses, int phases, vag_stream_t stream) {
@@ -192,8 +247,14 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     // activations the next fp16 product rounds anyway), so they run on one plane: fp16 operands forward (11 significand bits),
     // bf16 operands for every gradient product (fp16 would flush small gradients; their rounding errors average over the long sums)
     const bool one_plane = c.storage == 1 && !c.free_run && vag_opt().s16_one_plane != 0;
+    StepBranch br_im, br_leaf;
     if (phases & 1) {
         if (one_plane) vag_gemm_set_planes(11);
+        if (mm) {
+            // V11.py:114, VSE_Imagine_Enc.py:123-132: the image projection needs the batch only -- beside the encoder
+            hipStream_t si = br_im.fork(s, 0, 1);
+            VAG_TRY(vag_img_proj_l2_fwd(im, w.im_w, w.im_b, B, c.I, S, c.activation_vse, k.y_im, k.nrm_im, k.im_emb, si));
+        }
         {
             unsigned* zp[2];
             int64_t zn[2];
@@ -208,7 +269,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
         VAG_TRY(vag_bigru_seq_fwd(src, lengths, w.enc_emb, w.enc_fw, w.enc_bw, c.p_emb, c.p_ctx, crng, B, Ts, c.Es, H, k.enc,
                                   k.mask, k.ws_enc, stream));                                           // V11.py:111
         if (mm) {                                                                                       // V11.py:114
-            VAG_TRY(vag_img_proj_l2_fwd(im, w.im_w, w.im_b, B, c.I, S, c.activation_vse, k.y_im, k.nrm_im, k.im_emb, stream));
+            VAG_TRY(br_im.join(s, 1));
             VAG_TRY(vag_imagine_attn_ctx_fwd(k.im_emb, k.enc, k.mask, w.ctx2ctx, w.emb2ctx, w.mlp_w, c.attn_method, B, Ts, C, S,
                                              k.alpha_v, k.ctx, k.ws_img, stream));
             VAG_TRY(vag_img_proj_l2_fwd(k.ctx, w.txt_w, w.txt_b, B, C, S, c.activation_vse, k.y_txt, k.nrm_txt, k.txt_emb,
@@ -257,6 +318,9 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
                                                          k.ws_dec, g.dec, k.scr_dec, stream));
             VAG_TRY(outer.end(s));
         }
+        // the weight-gradient products of the VSE branch and of the initial state (rank-B updates nothing later in the step reads)
+        // and their bias sums are held back and leave as ONE launch, on a side branch that joins before the optimiser
+        struct LeafScope { bool on = true; LeafScope() { vag_leaf_begin(); } ~LeafScope() { if (on) vag_leaf_abort(); } } leaf;
         if (mm) {
             if (has_vse) {
                 VAG_TRY(vag_rank_loss_bwd_impl(k.im_emb, k.txt_emb, k.G, nullptr, B, S, k.d_im, k.d_txt, s));
@@ -276,6 +340,13 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
             VAG_TRY(vag_img_proj_l2_bwd(im, w.im_w, k.y_im, k.nrm_im, k.im_emb, k.d_im, B, c.I, S, c.activation_vse, nullptr,
                                         g.im_w, g.im_b, stream));
         }
+        leaf.on = false;
+        {
+            // with the encoder's backward in the same call the leaves run beside its recurrence; a data-parallel driver's phase
+            // call ends here (these gradients belong to the bucket it all-reduces next): joined at once
+            hipStream_t sl = (phases & 4) ? br_leaf.fork(s, 2, 2) : s;
+            VAG_TRY(vag_leaf_flush(sl));
+        }
     }
     if (phases & 4) {
         // the last launch of the backward pass turns a give-up of any persistent recurrence of this step into a non-finite
@@ -284,6 +355,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
         VAG_TRY(vag_bigru_seq_bwd(src, lengths, w.enc_fw, w.enc_bw, c.p_emb, c.p_ctx, crng, B, Ts, c.Es, H, k.d_enc, k.ws_enc,
                                   g.enc_emb, g.enc_fw, g.enc_bw, stream));
     }
+    VAG_TRY(br_leaf.join(s, 3));
     return VAG_OK;
 }
 
