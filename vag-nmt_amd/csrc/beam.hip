@@ -37,64 +37,82 @@ __device__ __forceinline__ Cand block_best(Cand c, Cand* sh) {
     return r;
 }
 
-// ---- selection by radix search (round 2) ----
-// The k best of the candidates one WAVE holds in registers (E per lane), under the same total order (value desc, flat index
-// asc), without any cross-lane data movement: the k-th largest key is found bit by bit from ballots and population counts
-// (32 x E ballots, no LDS round trips; the former k rounds of a shuffle-tree argmax cost ~12 dependent ds_bpermute each).
-// Ties on the k-th value are broken by index in a (rare) slow loop.  The winners come out as an unordered set; the one place
-// that needs them ordered (stage 2's output) ranks its k entries afterwards.
+// ---- selection by radix search (round 2; 56-bit unique keys: round 5) ----
+// The k best of the candidates one WAVE holds in registers (E per lane), under the total order (value desc, flat index asc),
+// without any cross-lane data movement.  A candidate's KEY is its order-preserving value bits followed by its inverted flat
+// index (indices are below 2^24: vag_beam_step_launch checks k V < 2^24): keys are unique, a larger key is a better candidate,
+// and ties on the value need no handling of their own.  That matters: every continuation of a FINISHED hypothesis except EOS
+// carries the same value (its score - 1e5, V11.py:291-294), so once hypotheses have ended whole 2048-candidate slices tie.  With
+// 32-bit value keys such slices fell through to an exact search plus a tie loop in every wave: the expansion took 25-32 us
+// instead of 12, a beam step of a trained model 120 us instead of 94 (profiles/r05_exp_beam.txt).
 __device__ __forceinline__ unsigned fkey(float v) {       // order-preserving float -> uint (larger float, larger key)
     const unsigned b = __float_as_uint(v);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
+// A key in two words: hi = value bits (0 = hole; fkey(-inf) = 0x007fffff > 0, so a real candidate beats a hole), lo = inverted flat
+// index.  The searches below run over the 32 value bits and go on into the 24 index bits only when the k-th value is tied.
+struct Key2 { unsigned hi, lo; };
+__device__ __forceinline__ Key2 ckey(float v, int idx) {
+    Key2 q;
+    q.hi = idx == 0x7fffffff ? 0u : fkey(v);
+    q.lo = 0xffffffu - ((unsigned)idx & 0xffffffu);
+    return q;
+}
+__device__ __forceinline__ bool key_ge(Key2 a, Key2 t) { return a.hi > t.hi || (a.hi == t.hi && a.lo >= t.lo); }
+// the k-th largest of one key per lane (at least k lanes hold a valid key), found bit by bit from ballots
+__device__ __forceinline__ Key2 wave_kth_largest(Key2 x, int k) {
+    unsigned prefix = 0;
+    int need = k;
+    for (int b = 31; b >= 0; --b) {
+        const unsigned test = prefix | (1u << b);
+        const int c = __popcll(__ballot((x.hi >> b) == (test >> b)));
+        if (c >= need) prefix = test;
+        else need -= c;
+    }
+    Key2 t = {prefix, 0u};
+    if (__popcll(__ballot(x.hi == prefix)) == need) return t;          // no tie on the k-th value: every key of that value counts
+    for (int b = 23; b >= 0; --b) {                                     // tie: the `need` smallest indices among the tied lanes
+        const unsigned test = t.lo | (1u << b);
+        const int c = __popcll(__ballot(x.hi == prefix && (x.lo >> b) == (test >> b)));
+        if (c >= need) t.lo = test;
+        else need -= c;
+    }
+    return t;
+}
+// exact search over all E keys per lane (rare: the bound of wave_topk let more than 64 candidates through)
 template <int E>
-__device__ __forceinline__ void wave_select(const float (&val)[E], const int (&idx)[E], int k, bool (&sel)[E]) {
-    unsigned key[E];
+__device__ __forceinline__ void wave_select(const Key2 (&key)[E], int k, bool (&sel)[E]) {
     int nvalid = 0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const bool ok = idx[e] != 0x7fffffff;
-        key[e] = ok ? fkey(val[e]) : 0u;          // fkey(-inf) = 0x007fffff > 0: a real candidate always beats a hole
-        nvalid += __popcll(__ballot(ok));
-        sel[e] = false;
-    }
+    for (int e = 0; e < E; ++e) { nvalid += __popcll(__ballot(key[e].hi != 0u)); sel[e] = false; }
     const int kk = min(k, nvalid);
     if (kk == 0) return;
     unsigned prefix = 0;
     int need = kk;
     for (int b = 31; b >= 0; --b) {
         const unsigned test = prefix | (1u << b);
-        const unsigned himask = ~((1u << b) - 1u);
         int c = 0;
 #pragma unroll
-        for (int e = 0; e < E; ++e) c += __popcll(__ballot((key[e] & himask) == test && idx[e] != 0x7fffffff));
+        for (int e = 0; e < E; ++e) c += __popcll(__ballot((key[e].hi >> b) == (test >> b)));
         if (c >= need) prefix = test;
         else need -= c;
     }
-    // prefix = key of the kk-th best; `need` of the candidates equal to it are taken, smallest index first
+    Key2 t = {prefix, 0u};
     int neq = 0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const bool ok = idx[e] != 0x7fffffff;
-        sel[e] = ok && key[e] > prefix;
-        neq += __popcll(__ballot(ok && key[e] == prefix));
+    for (int e = 0; e < E; ++e) neq += __popcll(__ballot(key[e].hi == prefix));
+    if (neq != need) {
+        for (int b = 23; b >= 0; --b) {
+            const unsigned test = t.lo | (1u << b);
+            int c = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) c += __popcll(__ballot(key[e].hi == prefix && (key[e].lo >> b) == (test >> b)));
+            if (c >= need) t.lo = test;
+            else need -= c;
+        }
     }
-    if (neq == need) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) sel[e] = sel[e] || (idx[e] != 0x7fffffff && key[e] == prefix);
-        return;
-    }
-    for (int r = 0; r < need; ++r) {              // exact ties across candidates: rare
-        int best = 0x7fffffff;
-#pragma unroll
-        for (int e = 0; e < E; ++e)
-            if (idx[e] != 0x7fffffff && key[e] == prefix && !sel[e]) best = min(best, idx[e]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
-#pragma unroll
-        for (int e = 0; e < E; ++e)
-            if (idx[e] == best && key[e] == prefix) sel[e] = true;
-    }
+    for (int e = 0; e < E; ++e) sel[e] = key[e].hi != 0u && key_ge(key[e], t);      // (keys are unique: exactly kk)
 }
 // Writes the selected candidates of a wave densely to (ov, oi)[0 .. count): returns count (uniform over the wave).
 template <int E>
@@ -123,31 +141,23 @@ __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOM
 template <int E>
 __device__ __forceinline__ int wave_topk(const float (&val)[E], const int (&idx)[E], int k, float* sv, int* si, float* ov, int* oi) {
     const int lane = threadIdx.x & 63;
-    unsigned kb = 0;
+    Key2 key[E], kb = {0u, 0u};
 #pragma unroll
-    for (int e = 0; e < E; ++e)
-        if (idx[e] != 0x7fffffff) kb = max(kb, fkey(val[e]));
-    unsigned t0 = 1u;                                   // every valid key is >= fkey(-inf) > 1
-    if (__popcll(__ballot(kb != 0u)) >= k) {            // k-th largest of the lane maxima
-        unsigned prefix = 0;
-        int need = k;
-        for (int b = 31; b >= 0; --b) {
-            const unsigned test = prefix | (1u << b);
-            const int c = __popcll(__ballot((kb & ~((1u << b) - 1u)) == test));
-            if (c >= need) prefix = test;
-            else need -= c;
-        }
-        t0 = prefix;
+    for (int e = 0; e < E; ++e) {
+        key[e] = ckey(val[e], idx[e]);
+        if (key[e].hi != 0u && (kb.hi == 0u || !key_ge(kb, key[e]))) kb = key[e];
     }
+    Key2 t0 = {1u, 0u};                                 // every valid key has hi > 1
+    if (__popcll(__ballot(kb.hi != 0u)) >= k) t0 = wave_kth_largest(kb, k);     // k-th largest of the lane maxima
     bool sel[E];
     int n = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        sel[e] = idx[e] != 0x7fffffff && fkey(val[e]) >= t0;
+        sel[e] = key[e].hi != 0u && key_ge(key[e], t0);
         n += __popcll(__ballot(sel[e]));
     }
-    if (n > 64) {                                       // heavy ties: exact search over everything
-        wave_select<E>(val, idx, k, sel);
+    if (n > 64) {                                       // more than one per lane got through: exact search over everything
+        wave_select<E>(key, k, sel);
     }
     n = wave_compact<E>(val, idx, sel, sv, si);
     wave_lds_fence();
@@ -369,18 +379,33 @@ int vag_beam_step_launch(float* logp, int64_t ldl, float* nll, int64_t* beam, in
 // V11.py:315-324: force EOS in the last row, normalise by the number of tokens > 3, pick the best hypothesis.
 // `steps` rows of history were written (fewer than max_len after an early stop; the rest reads as padding 0).
 // Thread j walks the back-pointers of final hypothesis j (steps dependent 8-byte loads, once per decode).
+constexpr int FIN_LDS = 4096;            // (word, parent) pairs of one sentence's history kept in LDS: steps * k <= 4096
 __global__ __launch_bounds__(64) void beam_finish_kernel(const float* __restrict__ nll, const int64_t* __restrict__ beam,
                                                          int max_len, int steps, int B, int k, int64_t* __restrict__ out,
                                                          float* __restrict__ best) {
     const int b = blockIdx.x, j = threadIdx.x;
     const int64_t* par = beam + (int64_t)max_len * B * k;
+    // the sentence's history into LDS first (coalesced rows of k words / k parents per step): the walks below are chains of
+    // `steps` dependent reads -- from global memory 80 steps took ~52 us per call (a memory round trip each), from LDS ~5
+    __shared__ int hw[FIN_LDS], hp[FIN_LDS];
+    const bool lds = steps * k <= FIN_LDS;
+    if (lds) {
+        for (int e = j; e < steps * k; e += 64) {
+            const int t = e / k, p = e - t * k;
+            const int64_t o = ((int64_t)t * B + b) * k + p;
+            hw[e] = (int)beam[o];
+            hp[e] = (int)par[o];
+        }
+        __syncthreads();
+    }
     float sc = -INFINITY;
     if (j < k) {
         int len = 0, p = j;
         for (int t = steps - 1; t >= 0; --t) {
             const int64_t o = ((int64_t)t * B + b) * k + p;
-            if (t < max_len - 1) len += beam[o] > 3;       // row max_len-1 is forced to EOS (= 3), which never counts
-            p = (int)par[o];
+            const int w = lds ? hw[t * k + p] : (int)beam[o];
+            if (t < max_len - 1) len += w > 3;             // row max_len-1 is forced to EOS (= 3), which never counts
+            p = lds ? hp[t * k + p] : (int)par[o];
         }
         if (len < 1) len = 1;
         sc = nll[(int64_t)b * k + j] / (float)len;
@@ -399,8 +424,8 @@ __global__ __launch_bounds__(64) void beam_finish_kernel(const float* __restrict
         int p = bi;
         for (int t = steps - 1; t >= 0; --t) {
             const int64_t o = ((int64_t)t * B + b) * k + p;
-            row[t] = beam[o];
-            p = (int)par[o];
+            row[t] = lds ? (int64_t)hw[t * k + p] : beam[o];
+            p = lds ? hp[t * k + p] : (int)par[o];
         }
         row[max_len - 1] = EOS;
         if (best) best[b] = bv;

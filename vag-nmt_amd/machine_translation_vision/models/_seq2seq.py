@@ -210,17 +210,32 @@ class Seq2SeqBase(nn.Module):
         H = h.shape[1]
         V = dec.out.bias.shape[0]
         dev = enc.device
-        beam = torch.zeros(2 * max_length, B, k, dtype=torch.int64, device=dev)     # words | back-pointers
-        nll = torch.zeros(B, k, dtype=torch.float32, device=dev)
-        n_alive = torch.zeros(1, dtype=torch.int32, device=dev)
-        scratch = torch.empty(_lib.lib().vag_beam_scratch_bytes(B, k, V, max_length), dtype=torch.uint8, device=dev)
-        tok = torch.full((B,), SOS_token, dtype=torch.int64, device=dev)
         graphed = self.decode_graph and enc.is_cuda
+        st = None
         if graphed:
             st, dp, hp, emb = self._decode_state("beam", enc, mask, k, max_length)
             enc_s, pe, mask_s, prep = st["enc"], st["pe"], st["mask"], st["prep"]
             hoisted, keys, tables = st["hoisted"], st.get("keys"), st.get("tables")
+        if st is not None and "beam" in st:
+            # the search state of this decode shape lives in ONE buffer the captured graph points into: history (words |
+            # back-pointers), running scores, the alive counter and the device-side step index -- one fill per call instead of a
+            # fresh tensor and a copy each (22 small copy / fill launches per call before)
+            st["flat"].zero_()
+            beam, nll, n_alive, scratch = st["beam"], st["nll"], st["n_alive"], st["scratch"]
         else:
+            nb = 2 * max_length * B * k
+            flat = torch.zeros(nb + (B * k + 8 + 1) // 2, dtype=torch.int64, device=dev)
+            beam = flat[:nb].view(2 * max_length, B, k)                                  # words | back-pointers
+            tail = flat[nb:].view(torch.int32)
+            nll = tail[:B * k].view(torch.float32).view(B, k)
+            n_alive = tail[B * k:B * k + 1]
+            di_state = tail[B * k + 2:B * k + 4]
+            scratch = torch.empty(_lib.lib().vag_beam_scratch_bytes(B, k, V, max_length), dtype=torch.uint8, device=dev)
+            if st is not None:
+                st["flat"], st["beam"], st["nll"], st["n_alive"], st["scratch"], st["di"] = flat, beam, nll, n_alive, scratch, di_state
+                st["one"] = torch.ones(1, dtype=torch.int32, device=dev)
+        tok = torch.full((B,), SOS_token, dtype=torch.int64, device=dev)
+        if not graphed:
             pe = ops.KeysProj.apply(enc, dec.attn.attn_e.weight)
             dp, hp, emb = dec.dec_params(), dec.head_params(), dec.embedding.weight
             prep = ops.decode_prepare(emb, dp)
@@ -251,14 +266,7 @@ class Seq2SeqBase(nn.Module):
         if graphed and max_length > 1:
             CH = self.DECODE_CHUNK
             st["tok"].copy_(beam[0].view(-1))
-            # per-call state the graph works on: same storage every call, so the captured pointers stay valid
-            if st["graph"] is None:
-                st["beam"], st["nll"], st["n_alive"], st["scratch"] = beam, nll, n_alive, scratch
-                st["di"] = torch.zeros(2, dtype=torch.int32, device=dev)
-            else:
-                st["beam"].copy_(beam); st["nll"].copy_(nll); st["n_alive"].copy_(n_alive)
-                beam, nll, n_alive, scratch = st["beam"], st["nll"], st["n_alive"], st["scratch"]
-            st["di"].copy_(torch.tensor([1, 0], dtype=torch.int32), non_blocking=False)
+            st["di"][0:1].copy_(st["one"])              # the replayed steps start at step 1 (device to device: no host wait)
             if st["graph"] is None:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
