@@ -261,7 +261,7 @@ def _measure_operators(c, dev, m, src, lens_t, tgt, im, out):
             o_q = torch.empty(Tt, B, Q, device=dev)
             o_al = torch.empty(Tt, B, Ts, device=dev)
             o_h2 = torch.empty(Tt, B, H, device=dev)
-            psc = torch.empty(Tt, B, Ts, device=dev)
+            psc = torch.empty(Tt, 4, B, Ts, device=dev)
             sync = torch.zeros(L.lib().vag_recurrence_sync_words(1, B, Tt), dtype=torch.int32, device=dev)
             maskf = mask.contiguous()
             pe_c = pe.contiguous()

@@ -471,7 +471,7 @@ int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_wh
  * kind: 0 = the bi-GRU encoder kernels (H in {256, 512, 1024}, 2 * ceil(B/16) * H/16 workgroups <= CUs), 1 = the decoder.
  * xp1 (Tt,B,3H) = W_ih1 e_t + b_ih1; wcat (C+3H,H) = [attn_h; gru_2.w_hh], bcat (C+3H) = [0; gru_2.b_hh]; encwp (B,Ts,3H) =
  * (gru_2.w_ih context2hid) enc; outputs as vag_cgru_attn_decode_seq_fwd saves them: h1 (Tt,B,H), g1 / g2 (Tt,4,B,H),
- * qhp (Tt,B,C+3H), alpha (Tt,B,Ts), h2_all (Tt,B,H); psc (Tt,B,Ts) floats and sync (vag_recurrence_sync_words 32-bit
+ * qhp (Tt,B,C+3H), alpha (Tt,B,Ts), h2_all (Tt,B,H); psc (Tt,4,B,Ts) floats (the score accumulators, four copies) and sync (vag_recurrence_sync_words 32-bit
  * words) are scratch. */
 int vag_recurrence_supported(int kind, int64_t B, int64_t Ts, int64_t Tt, int64_t H);
 /* The persistent kernels wait on each other inside one launch, which needs every workgroup resident at once (one per CU;

@@ -522,10 +522,10 @@ int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_wh
 
 struct CgruWs {
     float *xp1, *h1, *g1, *g2, *qhp, *scores, *alpha, *tmp, *prep, *encwp;
-    float* psc;                 // persistent decoder (persist.hip): the steps' scores as exchanged between workgroups (Tt,B,Ts)
+    float* psc;                 // persistent decoder (persist.hip): the steps' scores as exchanged between workgroups (Tt,4,B,Ts)
     unsigned* sync;             // ... and its counters
     unsigned* sync_b;           // the backward kernel's counters ...
-    float* dal;                 // ... and its d alpha accumulator (Tt,B,Ts)   [psc .. dal: one range to zero]
+    float* dal;                 // ... and its d alpha accumulator (Tt,4,B,Ts)   [psc .. dal: one range to zero]
     int64_t total;
 };
 static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
@@ -543,10 +543,10 @@ static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, i
     w.tmp = take(B * E);
     w.prep = take(cgru_prep(nullptr, H).total);
     w.encwp = take(B * Ts * 3 * H);         // (W_ih2 W_c2h) enc[b,s,:]: the keys as gru_2 sees them, once per batch
-    w.psc = take(Tt * B * Ts);
+    w.psc = take(Tt * B * Ts * 4);          // four copies (persist.hip: ACC_SHARDS)
     w.sync = reinterpret_cast<unsigned*>(take(vag_dec_persistent_sync_words(B, Tt)));
     w.sync_b = reinterpret_cast<unsigned*>(take(vag_dec_persistent_sync_words(B, Tt)));
-    w.dal = take(Tt * B * Ts);
+    w.dal = take(Tt * B * Ts * 4);
     w.total = o;
     return w;
 }

@@ -854,7 +854,27 @@ __device__ __forceinline__ void wait_count(gu32* c, unsigned want_per_shard, uns
     __syncthreads();
 }
 
+// two accumulator words (see ACC_SHARDS) as the sums of their four copies, `stride` floats apart: eight 4-byte sc1 loads in flight
+__device__ __forceinline__ void ld_acc_shards(const float* p0, const float* p1, int64_t stride, float& v0, float& v1) {
+    float a0, a1, a2, a3, b0, b1, b2, b3;
+    const float *p02 = p0 + 2 * stride, *p12 = p1 + 2 * stride;
+    const float *p01 = p0 + stride, *p03 = p02 + stride, *p11 = p1 + stride, *p13 = p12 + stride;
+    asm volatile("global_load_dword %0, %8, off sc1\n\tglobal_load_dword %1, %9, off sc1\n\t"
+                 "global_load_dword %2, %10, off sc1\n\tglobal_load_dword %3, %11, off sc1\n\t"
+                 "global_load_dword %4, %12, off sc1\n\tglobal_load_dword %5, %13, off sc1\n\t"
+                 "global_load_dword %6, %14, off sc1\n\tglobal_load_dword %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+                 : "v"(p0), "v"(p01), "v"(p02), "v"(p03), "v"(p1), "v"(p11), "v"(p12), "v"(p13) : "memory");
+    v0 = (a0 + a1) + (a2 + a3);
+    v1 = (b0 + b1) + (b2 + b3);
+}
+
 constexpr int DEC_WGS = 64;          // workgroups per row tile
+// The 64 workgroups of a row tile add their shares of a step's scores (forward) / d alpha (backward) with fp32 atomics.  Atomics
+// execute at the memory side and adds to ONE address serialise there (~12 ns each: MI355X_MICROARCH.md, global float atomics /
+// fanin): 64 adders per word kept every wave's atomics outstanding for ~1.1 us.  So the accumulators exist in ACC_SHARDS copies,
+// workgroup i adds into copy i % ACC_SHARDS (16 adders per word) and the readers sum the copies (four loads in flight instead of one).
+constexpr int ACC_SHARDS = 4;
 constexpr int DEC_U = 8;             // hidden units per workgroup (H = 512)
 
 constexpr int DEC_E = 4 * DEC_WGS;   // free-running form: embedding width, 4 columns of the head's hidden layer per workgroup
@@ -1267,7 +1287,8 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
                 float acc = vq.x * vag_tanh(pv.x + qq.x) + vq.y * vag_tanh(pv.y + qq.y) + vq.z * vag_tanh(pv.z + qq.z) +
                             vq.w * vag_tanh(pv.w + qq.w);
                 acc = quad_sum(acc);
-                if (cq == 0 && m0 + r < B) atomicAdd(a.psc + ((int64_t)t * B + m0 + r) * Ts + (P - r * Ts), acc);
+                if (cq == 0 && m0 + r < B)
+                    atomicAdd(a.psc + (((int64_t)t * ACC_SHARDS + (i & (ACC_SHARDS - 1))) * B + m0 + r) * Ts + (P - r * Ts), acc);
             }
         }
         {
@@ -1311,11 +1332,10 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
         for (int x0 = tx; x0 < 16 * Ts; x0 += 1024) {                                // 4-byte sc1 loads, two in flight
             const int x1 = x0 + 512;
             const int r0 = x0 / Ts, r1 = min(x1, 16 * Ts - 1) / Ts;
-            const float* p0 = a.psc + ((int64_t)t * B + min(m0 + r0, B - 1)) * Ts + (x0 - r0 * Ts);
-            const float* p1 = a.psc + ((int64_t)t * B + min(m0 + r1, B - 1)) * Ts + (min(x1, 16 * Ts - 1) - r1 * Ts);
+            const float* p0 = a.psc + ((int64_t)t * ACC_SHARDS * B + min(m0 + r0, B - 1)) * Ts + (x0 - r0 * Ts);
+            const float* p1 = a.psc + ((int64_t)t * ACC_SHARDS * B + min(m0 + r1, B - 1)) * Ts + (min(x1, 16 * Ts - 1) - r1 * Ts);
             float v0, v1;
-            asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
-                         : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
+            ld_acc_shards(p0, p1, (int64_t)B * Ts, v0, v1);
             sc_s[x0] = mk_s[x0] == 0.f ? -INFINITY : v0;                                      // mask :41-43
             if (x1 < 16 * Ts) sc_s[x1] = mk_s[x1] == 0.f ? -INFINITY : v1;
         }
@@ -1565,7 +1585,8 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
             float acc = 0.f;
 #pragma unroll
             for (int k = 0; k < 24; ++k) acc += ew_t[k * NP + P] * g[k];
-            if (m0 + r < B) atomicAdd(a.dal + ((int64_t)t * B + m0 + r) * Ts + (P - r * Ts), acc);
+            if (m0 + r < B)
+                atomicAdd(a.dal + (((int64_t)t * ACC_SHARDS + (i & (ACC_SHARDS - 1))) * B + m0 + r) * Ts + (P - r * Ts), acc);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave's atomics and the epilogue's sc1 stores are done ...
         __syncthreads();
@@ -1585,10 +1606,9 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
             wait_count(cA + t * CNT_WORDS, PER_SHARD, a.err, a.guard, a.spin, dead);
             VAG_STAMP(2);
             float v0, v1;
-            const float* p0 = a.dal + o0;
-            const float* p1 = a.dal + o1;
-            asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
-                         : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
+            const float* p0 = a.dal + o0 + (int64_t)t * (ACC_SHARDS - 1) * B * Ts;      // (o0 = (t B + row) Ts + s: shard 0 of step t)
+            const float* p1 = a.dal + o1 + (int64_t)t * (ACC_SHARDS - 1) * B * Ts;
+            ld_acc_shards(p0, p1, (int64_t)B * Ts, v0, v1);
             if (x0 < NP) { da_s[x0] = v0 + dh0; al_s[x0] = al0; }
             if (x1 < NP) { da_s[x1] = v1 + dh1_; al_s[x1] = al1; }
             __syncthreads();
@@ -1905,7 +1925,7 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
 #else
     a.dbg = nullptr;
 #endif
-    const int nsc = (int)(Tt * B * Ts);                              // the scores are accumulated with atomics: start from zero
+    const int nsc = (int)(Tt * B * Ts) * ACC_SHARDS;                 // the scores are accumulated with atomics: start from zero
     if (!g_prezeroed) {
         hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64((int64_t)nwords + nsc, 256)), dim3(256), 0, s, sync, nwords,
                            reinterpret_cast<unsigned*>(psc), nsc);
@@ -1965,7 +1985,7 @@ int vag_dec_free_persistent_launch(const float* pe, const float* mask, const flo
 #else
     a.dbg = nullptr;
 #endif
-    const int nsc = (int)(Tt * B * Ts);
+    const int nsc = (int)(Tt * B * Ts) * ACC_SHARDS;
     if (!g_prezeroed) {
         hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64((int64_t)nwords + nsc, 256)), dim3(256), 0, s, sync, nwords,
                            reinterpret_cast<unsigned*>(psc), nsc);
@@ -2120,7 +2140,7 @@ int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const flo
     a.B = (int)B; a.Ts = (int)Ts; a.Tt = (int)Tt; a.H = (int)H; a.RT = (int)cdiv64(B, 16);
     const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
     a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard();
-    const int nsc = (int)(Tt * B * Ts);
+    const int nsc = (int)(Tt * B * Ts) * ACC_SHARDS;
     if (!g_prezeroed) {
         hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64((int64_t)nwords + nsc, 256)), dim3(256), 0, s, sync, nwords,
                            reinterpret_cast<unsigned*>(dal), nsc);
