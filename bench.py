@@ -782,6 +782,8 @@ def main():
     ap.add_argument("--comm", choices=["torch", "vag"], default="torch",
                     help="multi-GPU exchange: torch.distributed's all_reduce (backend nccl = RCCL) or the C ABI's own RCCL "
                          "communicator (vag_comm_*, include/vag_nmt.h)")
+    ap.add_argument("--buckets", type=int, choices=[2, 3], default=2,
+                    help="multi-GPU: gradient buckets (3 = a third cut after the decoder's backward, TrainStep(three_buckets=True))")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="library option for A/B runs (vag_set_option), e.g. --opt persistent=0")
     ap.add_argument("--config", choices=["cfg2", "cfg5", "cfg5-f32", "cfg1"], default="cfg2",
@@ -847,7 +849,7 @@ def main():
         comm = Comm(rank=rank, world_size=world)       # the id travels over the default process group
     ts = TrainStep(model, crit_mt, crit_vse, lr=4e-4, weight_decay=1e-5, clip=1.0, teacher_force_ratio=args.tfr,
                    use_graph=not args.no_graph, process_group=pg, world_size=world, fused=not args.no_fused,
-                   storage="f16" if args.config == "cfg5" else "f32", comm=comm)
+                   storage="f16" if args.config == "cfg5" else "f32", comm=comm, three_buckets=args.buckets == 3)
     src, lens, tgt, im = make_batch(c, rank, dev, ragged=args.ragged)
     lens_t = torch.tensor(lens, dtype=torch.int32, device=dev)
 

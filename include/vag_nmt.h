@@ -431,7 +431,9 @@ typedef struct {
 } vag_step_cfg;
 /* phases: bit 0 forward (losses[0..2] = loss, loss_mt, loss_vse), bit 1 backward down to the encoder states (final for
  * every gradient except the encoder's), bit 2 the encoder's backward.  A data-parallel driver all-reduces the first
- * gradient bucket while phase 4 runs.  rng: {seed, step} (step is advanced by the forward phase) or NULL (no dropout).
+ * gradient bucket while phase 4 runs.  Phase 2 may also be called as its two halves: 16 = output head + decoder (final for
+ * the head's, the decoder's and attn_e's gradients), 32 = visual grounding + initial state (final for vse_imagine.* and
+ * decoderini.*), for a driver that cuts the gradient into three buckets (phases 1|16, then 32, then 4).  rng: {seed, step} (step is advanced by the forward phase) or NULL (no dropout).
  * derived: vag_derived_floats(H) floats kept current with vag_derive_weights() after every optimiser step, or NULL
  * (derived weights are then rebuilt inside the call).  ws: vag_step_ws_floats(cfg) floats, kept between phases. */
 int64_t vag_step_ws_floats(const vag_step_cfg* cfg);

@@ -100,7 +100,10 @@ def test_intermediates(name):
         tok = torch.full((B,), 2, dtype=torch.long, device="cuda")
         for di in range(tgt.shape[1]):
             logp, h = m.decoder(tok, h, enc, ctx_mask=mask)
-            close(logp, z["logp_steps"][di], 2e-4, "logp step %d" % di)
+            # north_star: logits within 1e-4 of the reference.  Observed on MI355X (round 5, all five fixtures, every step):
+            # max |logp - reference| 9.5e-7 .. 1.4e-6 at max |logp| ~7; the bound is 2e-5 ABSOLUTE (was 2e-4 x max|logp| ~ 1.4e-3)
+            err = float((logp.detach().cpu().double() - torch.from_numpy(z["logp_steps"][di]).double()).abs().max())
+            assert err <= 2e-5, "logp step %d: max abs err %.3e" % (di, err)
             close(h[0], z["h2_steps"][di], what="h2 step %d" % di)
             tok = tgt[:, di]
 

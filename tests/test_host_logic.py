@@ -248,3 +248,22 @@ def test_flat_layout_with_explicit_groups_and_the_shims_optimizer_checks():
     # CPU tensors never reach the fused driver; the literal sequence then fails loudly in the HIP operators (no CPU fallback)
     d, existing = T._driver(m, opt, torch.nn.NLLLoss(weight=vw, reduction="none"), None, 1.0, 1.0)
     assert d is None and existing is None
+
+
+def test_three_bucket_layout_cuts_after_the_decoder_and_after_the_visual_grounding():
+    """TrainStep(three_buckets=True): [head + decoder + attn_e | vse_imagine.* + decoderini.* | encoder.*], each a contiguous range of the
+    flat buffer in the order the backward pass finishes them (vag_train_step phases 1|16, 32, 4); the default layout is unchanged."""
+    from machine_translation_vision.models import NMT_AttentionImagine_Seq2Seq_Beam_V11
+    from vagnmt_hip.trainer import flat_layout, is_late, is_mid
+    m = NMT_AttentionImagine_Seq2Seq_Beam_V11(50, 60, 96, 16, 16, 24, 20, 0.99, tied_emb=True)
+    named = [(n, p) for n, p in m.named_parameters()]
+    for vs in (False, True):
+        segs, offs, seg_off, total = flat_layout(named, vse_separate=vs, three_buckets=True)
+        kinds = [2 if s[0].endswith("/encoder") else 1 if s[0].endswith("/vse+init") else 0 for s in segs]
+        assert kinds == sorted(kinds) and set(kinds) == {0, 1, 2}
+        for (name, names, _, _), kind in zip(segs, kinds):
+            for n in names:
+                assert (2 if is_late(n) else 1 if is_mid(n) else 0) == kind, (name, n)
+        assert sorted(offs) == sorted(n for n, _ in named) and seg_off[-1] == total
+        two = flat_layout(named, vse_separate=vs)
+        assert two[3] == total and all(not s[0].endswith("/vse+init") for s in two[0])

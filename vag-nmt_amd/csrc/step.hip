@@ -207,7 +207,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     const bool mm = c.multimodal != 0;
     VAG_CHECK_ARG(!mm || (im && w.im_w && w.im_b && w.txt_w && w.txt_b && w.ctx2ctx && w.emb2ctx &&
                           (c.attn_method == 0 || w.mlp_w)));
-    VAG_CHECK_ARG(w.enc_emb && w.ini_w && w.ini_b && w.attn_e && (phases & 7) != 0);
+    VAG_CHECK_ARG(w.enc_emb && w.ini_w && w.ini_b && w.attn_e && (phases & 55) != 0 && (phases & ~55) == 0);
     const int64_t B = c.B, Ts = c.Ts, Tt = c.Tt, H = c.H, C = 2 * H, S = c.S, V = c.V, Et = c.Et;
     StepWs k = step_ws(ws, c);
     VAG_CHECK_ARG(c.storage == 0 || (c.storage == 1 && derived && !c.free_run && H % 8 == 0));
@@ -236,7 +236,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     } guard_scope(c.guard);
     // forward and backward in one call: the chunked head finishes each chunk (d(logits) and its products) in the forward;
     // a backward called on its own (phases = 2 after an earlier phases = 1) recomputes the chunks instead
-    if (chunk > 0 && (phases & 3) == 3 && vag_opt().head_fuse != 0)
+    if (chunk > 0 && (phases & 1) && (phases & (2 | 16)) && vag_opt().head_fuse != 0)
         vag_set_head_fuse(&g.head, k.consts + 0, k.scr_head);
     const bool has_vse = mm && c.rank_kind >= 0;
     const float w_mt = mm ? c.loss_w : 1.f, w_vse = mm ? 1.f - c.loss_w : 0.f;
@@ -301,8 +301,10 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
                                          c.free_run ? 1 : 0, k.tmid, k.logits, c.ldl, k.lse, k.nll, k.inv_cnt, 1, nullptr,
                                          losses, w_mt, w_vse, has_vse ? 1 : 0, s));                     // V11.py:140,164-166
     }
-    if (one_plane && (phases & 6)) vag_gemm_set_planes(1);
-    if (phases & 2) {
+    if (one_plane && (phases & 54)) vag_gemm_set_planes(1);
+    // phase 2 = its two halves 16 (head + decoder: final for the head's, the decoder's and attn_e's gradients) and 32 (visual grounding
+    // + initial state: final for vse_imagine.* and decoderini.*): a data-parallel driver with three buckets calls them one by one
+    if (phases & (2 | 16)) {
         VAG_TRY(vag_head_ce_seq_bwd(h2_all, k.c_all, k.e_all, w.head, tgt, vocab_weight, B, Tt, Et, H, V, c.p_out, crng, k.tmid,
                                     k.logits, c.ldl, k.lse, k.inv_cnt, k.consts + 0, k.d_h2, k.d_c, k.d_e, g.head, k.scr_head,
                                     stream));
@@ -318,6 +320,8 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
                                                          k.ws_dec, g.dec, k.scr_dec, stream));
             VAG_TRY(outer.end(s));
         }
+    }
+    if (phases & (2 | 32)) {
         // the weight-gradient products of the VSE branch and of the initial state (rank-B updates nothing later in the step reads)
         // and their bias sums are held back and leave as ONE launch, on a side branch that joins before the optimiser
         struct LeafScope { bool on = true; LeafScope() { vag_leaf_begin(); } ~LeafScope() { if (on) vag_leaf_abort(); } } leaf;

@@ -44,7 +44,14 @@ def is_late(name):
     return name.startswith("encoder.")
 
 
-def flat_layout(named_params, vse_separate=False, groups=None):
+def is_mid(name):
+    """With three buckets (TrainStep(three_buckets=True)): gradients that become final in the SECOND half of the backward pass down
+    to the encoder states -- the visual-grounding branch and the decoder's initial state (VSE_Imagine_Enc.py:110-152, V11.py:118) --
+    while the head's, the decoder's and attn_e's are final after its first half."""
+    return name.startswith("vse_imagine.") or name.startswith("decoderini.")
+
+
+def flat_layout(named_params, vse_separate=False, groups=None, three_buckets=False):
     """Offsets of every parameter in the flat buffer.  Each optimiser group is split into an early and a late part
     (see is_late); all early segments come first.  Segments are contiguous, slots 256-byte aligned.
     Returns (segments [(name, [param names], wd?, lr_mult)], offsets dict, segment boundaries, total floats);
@@ -52,15 +59,18 @@ def flat_layout(named_params, vse_separate=False, groups=None):
     ``groups``: an explicit grouping [(name, [param names], wd, lr_mult)] instead of the reference's two / four groups by
     name (the ``train`` shim passes what the caller's torch.optim.Adam holds; ``wd`` is then the group's own decay)."""
     byname = dict(named_params)
-    early, late = [], []
+    early, mid, late = [], [], []
     for gname, names, wd, mult in (groups if groups is not None else param_groups(named_params, vse_separate)):
-        e = [n for n in names if not is_late(n)]
+        e = [n for n in names if not is_late(n) and not (three_buckets and is_mid(n))]
+        mi = [n for n in names if three_buckets and is_mid(n)]
         la = [n for n in names if is_late(n)]
         if e:
             early.append((gname, e, wd, mult))
+        if mi:
+            mid.append((gname + "/vse+init", mi, wd, mult))
         if la:
             late.append((gname + "/encoder", la, wd, mult))
-    segs = early + late
+    segs = early + mid + late
     offs, seg_off, o = {}, [0], 0
     for _, names, _, _ in segs:
         for n in names:
@@ -73,12 +83,14 @@ def flat_layout(named_params, vse_separate=False, groups=None):
 class FlatParams:
     """Re-homes a module's parameters into one flat buffer (+ gradient, Adam m/v buffers)."""
 
-    def __init__(self, model, vse_separate=False, groups=None):
+    def __init__(self, model, vse_separate=False, groups=None, three_buckets=False):
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]      # tied weights appear once
         dev = named[0][1].device
-        self.groups, self.offsets, self.seg_off, self.n = flat_layout(named, vse_separate, groups)
+        self.groups, self.offsets, self.seg_off, self.n = flat_layout(named, vse_separate, groups, three_buckets)
         n_early = sum(1 for g in self.groups if not g[0].endswith("/encoder"))
         self.early_end = self.seg_off[n_early]              # [0, early_end): final before the encoder's backward
+        n_first = sum(1 for g in self.groups if not g[0].endswith("/encoder") and not g[0].endswith("/vse+init"))
+        self.first_end = self.seg_off[n_first]              # three buckets: [0, first_end) is final after the decoder's backward
         self.flat = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.m = torch.zeros(self.n, dtype=torch.float32, device=dev)
@@ -95,6 +107,8 @@ class FlatParams:
 
     def buckets(self):
         """Gradient buckets in the order backward finishes them."""
+        if self.first_end != self.early_end:
+            return [(0, self.first_end), (self.first_end, self.early_end), (self.early_end, self.n)]
         return [(0, self.early_end), (self.early_end, self.n)]
 
 
@@ -106,7 +120,7 @@ class TrainStep:
     def __init__(self, model, criterion_mt, criterion_vse=None, lr=4e-4, weight_decay=1e-5, clip=1.0,
                  teacher_force_ratio=0.8, betas=(0.9, 0.999), eps=1e-8, vse_separate=False, use_graph=True,
                  process_group=None, world_size=1, max_graphs=256, pad_src=4, fused=None, backend=None,
-                 force_phased=False, storage="f32", comm=None, groups=None, capture_after=1):
+                 force_phased=False, storage="f32", comm=None, groups=None, capture_after=1, three_buckets=False):
         self.model = model
         self.criterion_mt = criterion_mt
         self.criterion_vse = criterion_vse
@@ -127,7 +141,10 @@ class TrainStep:
         # costs ~1 ms, and a bucketed epoch holds ~200 keys of which many are met once or twice: shapes met once never pay for one (capture_after = 1: the second visit captures)
         self.capture_after = max(1, int(capture_after))
         self.pad_src = max(1, int(pad_src))
-        self.fp = FlatParams(model, vse_separate, groups)
+        # three_buckets: a third cut of the flat gradient after the decoder's backward (31.6 of bucket 0's 45.6 MB at configs[1] start
+        # their all-reduce ~0.15 ms earlier, behind the VSE / initial-state backward and the encoder's); a switch for the first
+        # multi-GPU session to A/B (what it buys depends on link bandwidth): the default stays two buckets
+        self.fp = FlatParams(model, vse_separate, groups, three_buckets)
         dev = self.fp.flat.device
         if world_size > 1:
             import torch.distributed as dist
@@ -298,16 +315,28 @@ class TrainStep:
         be = self.backend
         if be is None:
             raise RuntimeError("TrainStep needs HIP tensors and criteria (or an injected backend) to run a step")
-        (bk0, bk1) = self.fp.buckets()
+        bks = self.fp.buckets()
         if (self.world > 1 or (self.force_phased and (self.pg is not None or self.comm is not None))) and \
                 getattr(be, "phased", False):
-            # backward in two phases; the first bucket's all-reduce runs beside the encoder's backward
-            be.run(src, lengths, tgt, im, teacher, 3)
-            w0 = self._allreduce_async(*bk0)
-            be.run(src, lengths, tgt, im, teacher, 4, reuse=True)
-            w1 = self._allreduce_async(*bk1)
-            w0.wait()
-            w1.wait()
+            if len(bks) == 3:
+                # three cuts (vag_train_step phases 16 / 32: the two halves of phase 2)
+                be.run(src, lengths, tgt, im, teacher, 1 | 16)
+                w0 = self._allreduce_async(*bks[0])
+                be.run(src, lengths, tgt, im, teacher, 32, reuse=True)
+                wm = self._allreduce_async(*bks[1])
+                be.run(src, lengths, tgt, im, teacher, 4, reuse=True)
+                w1 = self._allreduce_async(*bks[2])
+                w0.wait()
+                wm.wait()
+                w1.wait()
+            else:
+                # backward in two phases; the first bucket's all-reduce runs beside the encoder's backward
+                be.run(src, lengths, tgt, im, teacher, 3)
+                w0 = self._allreduce_async(*bks[0])
+                be.run(src, lengths, tgt, im, teacher, 4, reuse=True)
+                w1 = self._allreduce_async(*bks[1])
+                w0.wait()
+                w1.wait()
         elif self.world == 1 and getattr(be, "with_optimizer", False) and self.use_graph:
             # single GPU: forward, backward and the optimiser in ONE captured graph per shape
             be.run(src, lengths, tgt, im, teacher, 7, optimizer=True)
