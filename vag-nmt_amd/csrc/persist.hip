@@ -104,6 +104,10 @@ template <> __device__ __forceinline__ void ld_rows_sc1<6>(const float* p, float
                    "=&v"(a[4]), "=&v"(b[4]), "=&v"(a[5]), "=&v"(b[5])
                  : "v"(p) : "memory");
 }
+// rows handed off with marks (see tag1): loaded until every word of this wave's share carries its mark
+template <int N>
+__device__ __forceinline__ void ld_rows_tagged(const float* p, float4 (&a)[N], float4 (&b)[N], unsigned spin, bool& dead,
+                                               unsigned* err, unsigned* guard);
 __device__ __forceinline__ void st_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
     const u32x4 u = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z),
                      __builtin_bit_cast(unsigned, v.w)};
@@ -112,6 +116,34 @@ __device__ __forceinline__ void st_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_o
 __device__ __forceinline__ void st_sc1_f4(float* p, float4 v) {
     const f32x4 x = {v.x, v.y, v.z, v.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(x) : "memory");
+}
+// Tagged hand-off (round 5).  A handed-off fp32 word carries its own "written" mark: its lowest significand bit is forced to 1
+// by the producer (at most one ulp: 6e-8 relative, below what the bf16x3 split keeps of it), and the buffer is all zeros when
+// the launch starts (the step's prologue launch / the launch function zero it).  The consumer still learns from the counter
+// WHEN to look, but the producer no longer drains its stores before it signals (s_waitcnt vmcnt(0) behind a write-through
+// store is a round trip to the memory side, ~0.8 us on the critical path of every hand-off): a word whose mark is not there
+// yet is simply loaded again.  The only assumptions are R2's (cdna_hip_programming.md, Guideline 16): an aligned 4-byte word
+// is never torn, and an sc1 load eventually observes an sc1 store.
+#ifndef VAG_TAGGED
+#define VAG_TAGGED 1
+#endif
+__device__ __forceinline__ float tag1(float x) { return VAG_TAGGED ? __uint_as_float(__float_as_uint(x) | 1u) : x; }
+__device__ __forceinline__ float4 tag4(float4 v) { return make_float4(tag1(v.x), tag1(v.y), tag1(v.z), tag1(v.w)); }
+__device__ __forceinline__ unsigned tagbits(float4 v) {
+    return __float_as_uint(v.x) & __float_as_uint(v.y) & __float_as_uint(v.z) & __float_as_uint(v.w);
+}
+template <int N>
+__device__ __forceinline__ void ld_rows_tagged(const float* p, float4 (&a)[N], float4 (&b)[N], unsigned spin, bool& dead,
+                                               unsigned* err, unsigned* guard) {
+    for (unsigned tries = 0;; ++tries) {
+        ld_rows_sc1<N>(p, a, b);
+        if (!VAG_TAGGED) return;
+        unsigned m = 1u;
+#pragma unroll
+        for (int s = 0; s < N; ++s) m &= tagbits(a[s]) & tagbits(b[s]);
+        if (__all((m & 1u) != 0u) || dead) return;
+        if (tries > spin) { if ((threadIdx.x & 63) == 0) note_timeout(err, guard); dead = true; return; }
+    }
 }
 __device__ __forceinline__ void st_sc1_f1(float* p, float v) {
     asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
@@ -1016,7 +1048,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
         } else {
             wait_count(c1 + (t - 1) * CNT_WORDS, PER_SHARD, a.err, a.guard, a.spin, dead);
             VAG_STAMP(1);
-            ld_rows_sc1<KS>(a.h2_all + ((int64_t)(t - 1) * B + lrow) * H + kbase + 8 * (lane & 3), ha, hb);
+            ld_rows_tagged<KS>(a.h2_all + ((int64_t)(t - 1) * B + lrow) * H + kbase + 8 * (lane & 3), ha, hb, a.spin, dead, a.err, a.guard);
 #pragma unroll
             for (int s = 0; s < KS; ++s) { ha[s] = perm4(ha[s], src4); hb[s] = perm4(hb[s], src4); }
         }
@@ -1228,11 +1260,12 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
                     nn[q] = vag_tanh(xn[q] + rr[q] * gh[q]);
                     ho[q] = (1.f - zz[q]) * nn[q] + zz[q] * hpv[q];
                 }
-                const float4 h1v = make_float4(ho[0], ho[1], ho[2], ho[3]);
+                const float4 h1v = tag4(make_float4(ho[0], ho[1], ho[2], ho[3]));
                 *reinterpret_cast<float4*>(hs_s + fr * 8 + 4 * hq) = h1v;
                 const int64_t o = (int64_t)em * H + eu;
                 st_sc1_f4(a.h1 + (int64_t)t * BH + o, h1v);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!VAG_TAGGED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (VAG_TAGGED && tx == 0) arrive(c2 + t * CNT_WORDS, i);            // marked words: no drain before the signal
                 float* sv = a.g1 + (int64_t)t * 4 * BH + o;
                 *reinterpret_cast<float4*>(sv) = make_float4(rr[0], rr[1], rr[2], rr[3]);
                 *reinterpret_cast<float4*>(sv + BH) = make_float4(zz[0], zz[1], zz[2], zz[3]);
@@ -1240,13 +1273,13 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
                 *reinterpret_cast<float4*>(sv + 3 * BH) = make_float4(gh[0], gh[1], gh[2], gh[3]);
             }
             // (threads 0..31 are half of wave 0: the drain above covered every storing lane of the wave)
-            if (tx == 0) arrive(c2 + t * CNT_WORDS, i);
+            if (tx == 0 && (!VAG_TAGGED || !eok)) arrive(c2 + t * CNT_WORDS, i);
         }
         // ================= phase 2: q = attn_h h1 (:47), hp2 = W_hh2 h1 + b_hh2 (hidden side of gru_2, :129) =================
         VAG_STAMP(2);
         wait_count(c2 + t * CNT_WORDS, PER_SHARD, a.err, a.guard, a.spin, dead);
         VAG_STAMP(3);
-        ld_rows_sc1<KS>(a.h1 + ((int64_t)t * B + lrow) * H + kbase + 8 * (lane & 3), ha, hb);
+        ld_rows_tagged<KS>(a.h1 + ((int64_t)t * B + lrow) * H + kbase + 8 * (lane & 3), ha, hb, a.spin, dead, a.err, a.guard);
 #pragma unroll
         for (int s = 0; s < KS; ++s) { ha[s] = perm4(ha[s], src4); hb[s] = perm4(hb[s], src4); }
         bf16x8 hf2[KS][3];
@@ -1404,18 +1437,19 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
                 nn[q] = vag_tanh(gi[2][q] + bi[2][q] + rr[q] * hn[q]);
                 ho[q] = (1.f - zz[q]) * nn[q] + zz[q] * h1a[q];
             }
-            const float4 h2v = make_float4(ho[0], ho[1], ho[2], ho[3]);
+            const float4 h2v = tag4(make_float4(ho[0], ho[1], ho[2], ho[3]));
             *reinterpret_cast<float4*>(hs_s + 128 + fr * 8 + 4 * hq) = h2v;
             const int64_t o = (int64_t)em * H + eu;
             st_sc1_f4(a.h2_all + (int64_t)t * BH + o, h2v);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!VAG_TAGGED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (VAG_TAGGED && tx == 0) arrive(c1 + t * CNT_WORDS, i);
             float* sv = a.g2 + (int64_t)t * 4 * BH + o;
             *reinterpret_cast<float4*>(sv) = make_float4(rr[0], rr[1], rr[2], rr[3]);
             *reinterpret_cast<float4*>(sv + BH) = make_float4(zz[0], zz[1], zz[2], zz[3]);
             *reinterpret_cast<float4*>(sv + 2 * BH) = make_float4(nn[0], nn[1], nn[2], nn[3]);
             *reinterpret_cast<float4*>(sv + 3 * BH) = make_float4(hn[0], hn[1], hn[2], hn[3]);
         }
-        if (tx == 0) arrive(c1 + t * CNT_WORDS, i);
+        if (tx == 0 && (!VAG_TAGGED || !eok)) arrive(c1 + t * CNT_WORDS, i);
     }
 #undef VAG_STAMP
 }
@@ -1931,6 +1965,12 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
                            reinterpret_cast<unsigned*>(psc), nsc);
         VAG_LAUNCH_CHECK();
     }
+    if (VAG_TAGGED) {        // the marked hand-off buffers start from zero (tag1)
+        const int nh = (int)(Tt * B * H);
+        hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64(2 * (int64_t)nh, 256)), dim3(256), 0, s,
+                           reinterpret_cast<unsigned*>(h1), nh, reinterpret_cast<unsigned*>(h2_all), nh);
+        VAG_LAUNCH_CHECK();
+    }
     int64_t lds = dec_persistent_lds_bytes(Ts);
     if (lds < 84 * 1024) lds = 84 * 1024;                            // never two workgroups on one CU
     static AttrOnce once;
@@ -1989,6 +2029,12 @@ int vag_dec_free_persistent_launch(const float* pe, const float* mask, const flo
     if (!g_prezeroed) {
         hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64((int64_t)nwords + nsc, 256)), dim3(256), 0, s, sync, nwords,
                            reinterpret_cast<unsigned*>(psc), nsc);
+        VAG_LAUNCH_CHECK();
+    }
+    if (VAG_TAGGED) {
+        const int nh = (int)(Tt * B * H);
+        hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64(2 * (int64_t)nh, 256)), dim3(256), 0, s,
+                           reinterpret_cast<unsigned*>(h1), nh, reinterpret_cast<unsigned*>(h2_all), nh);
         VAG_LAUNCH_CHECK();
     }
     int64_t lds = dec_persistent_lds_bytes(Ts, true);
