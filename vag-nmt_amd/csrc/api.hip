@@ -525,7 +525,7 @@ struct CgruWs {
     float* psc;                 // persistent decoder (persist.hip): the steps' scores as exchanged between workgroups (Tt,4,B,Ts)
     unsigned* sync;             // ... and its counters
     unsigned* sync_b;           // the backward kernel's counters ...
-    float* dal;                 // ... and its d alpha accumulator (Tt,4,B,Ts)   [psc .. dal: one range to zero]
+    float* dal;                 // ... and its d alpha accumulator (Tt,4,B,Ts)   [h1 .. dal: one range to zero]
     int64_t total;
 };
 static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
@@ -534,7 +534,6 @@ static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, i
     int64_t o = 0;
     auto take = [&](int64_t n) { float* p = ws ? ws + o : nullptr; o += (n + 63) & ~63ll; return p; };
     w.xp1 = take(Tt * B * 3 * H);
-    w.h1 = take(Tt * B * H);
     w.g1 = take(Tt * 4 * B * H);
     w.g2 = take(Tt * 4 * B * H);
     w.qhp = take(Tt * B * (C + 3 * H));     // [q | W_hh2 h1 + b_hh2] per step
@@ -543,6 +542,7 @@ static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, i
     w.tmp = take(B * E);
     w.prep = take(cgru_prep(nullptr, H).total);
     w.encwp = take(B * Ts * 3 * H);         // (W_ih2 W_c2h) enc[b,s,:]: the keys as gru_2 sees them, once per batch
+    w.h1 = take(Tt * B * H);                // (exchanged between workgroups with marked words: starts from zero, see vag_step_zero_ranges)
     w.psc = take(Tt * B * Ts * 4);          // four copies (persist.hip: ACC_SHARDS)
     w.sync = reinterpret_cast<unsigned*>(take(vag_dec_persistent_sync_words(B, Tt)));
     w.sync_b = reinterpret_cast<unsigned*>(take(vag_dec_persistent_sync_words(B, Tt)));
@@ -559,7 +559,7 @@ void vag_step_zero_ranges(float* ws_enc, float* ws_dec, int64_t B, int64_t Ts, i
     p[0] = e.sync;
     n[0] = (reinterpret_cast<unsigned*>(ws_enc) + e.total) - e.sync;
     CgruWs d = cgru_ws(ws_dec, B, Ts, Tt, Et, H);
-    p[1] = reinterpret_cast<unsigned*>(d.psc);
+    p[1] = reinterpret_cast<unsigned*>(d.h1);          // h1 | psc | sync | sync_b | dal: one range
     n[1] = (reinterpret_cast<unsigned*>(ws_dec) + d.total) - p[1];
 }
 extern "C" {

@@ -1965,7 +1965,7 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
                            reinterpret_cast<unsigned*>(psc), nsc);
         VAG_LAUNCH_CHECK();
     }
-    if (VAG_TAGGED) {        // the marked hand-off buffers start from zero (tag1)
+    if (VAG_TAGGED && !g_prezeroed) {        // the marked hand-off buffers start from zero (tag1; the step driver's prologue did it)
         const int nh = (int)(Tt * B * H);
         hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64(2 * (int64_t)nh, 256)), dim3(256), 0, s,
                            reinterpret_cast<unsigned*>(h1), nh, reinterpret_cast<unsigned*>(h2_all), nh);
@@ -2031,7 +2031,7 @@ int vag_dec_free_persistent_launch(const float* pe, const float* mask, const flo
                            reinterpret_cast<unsigned*>(psc), nsc);
         VAG_LAUNCH_CHECK();
     }
-    if (VAG_TAGGED) {
+    if (VAG_TAGGED && !g_prezeroed) {
         const int nh = (int)(Tt * B * H);
         hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64(2 * (int64_t)nh, 256)), dim3(256), 0, s,
                            reinterpret_cast<unsigned*>(h1), nh, reinterpret_cast<unsigned*>(h2_all), nh);

@@ -66,9 +66,10 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(uint64_t* rng, const
                                                             int64_t* __restrict__ tok, float* __restrict__ consts,
                                                             float* __restrict__ inv_cnt, float w_mt, float w_vse,
                                                             unsigned* __restrict__ z0, int64_t n0, unsigned* __restrict__ z1,
-                                                            int64_t n1) {
+                                                            int64_t n1, uint4* __restrict__ z2, int64_t n2) {
     const int64_t gid = blockIdx.x * 256ll + threadIdx.x;
     for (int64_t i = gid; i < n0; i += (int64_t)gridDim.x * 256) z0[i] = 0u;
+    for (int64_t i = gid; i < n2; i += (int64_t)gridDim.x * 256) z2[i] = make_uint4(0u, 0u, 0u, 0u);     // (16-byte units)
     {   // the large range: 16 bytes per thread (the range starts 256-byte aligned; its tail word by word)
         const int64_t n4 = n1 >> 2;
         uint4* z4 = reinterpret_cast<uint4*>(z1);
@@ -262,8 +263,10 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
             int64_t nb = cdiv64((Tt + 1) * B, 256);
             if (nb < cdiv64(zn[1], 1024)) nb = cdiv64(zn[1], 1024);
             if (nb > 1024) nb = 1024;
+            // the decoder's hidden states h2 are exchanged between workgroups with marked words (persist.hip: tag1): from zero
             hipLaunchKernelGGL(step_prologue_kernel, dim3((unsigned)nb), dim3(256), 0, s, rng, tgt, (int)B, (int)Tt, k.tok,
-                               k.consts, k.inv_cnt, w_mt, w_vse, zp[0], zn[0], zp[1], zn[1]);
+                               k.consts, k.inv_cnt, w_mt, w_vse, zp[0], zn[0], zp[1], zn[1], reinterpret_cast<uint4*>(h2_all),
+                               Tt * B * H / 4);
             VAG_LAUNCH_CHECK();
         }
         VAG_TRY(vag_bigru_seq_fwd(src, lengths, w.enc_emb, w.enc_fw, w.enc_bw, c.p_emb, c.p_ctx, crng, B, Ts, c.Es, H, k.enc,
