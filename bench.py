@@ -1051,12 +1051,20 @@ def main():
                 res[k_]["traffic"] = by / c["Tt"]
                 res[k_]["traffic_source"] = ps["file"] + ": gru_step + skinny (query) + attn_dot_side<0> + attn_ctx_gru, per time step"
         whole = ab["F_enc"] * 2 * c["Ts"] + ab["F_dec"] * c["Tt"] + ab["Bk_enc"] * 2 * c["Ts"] + ab["Bk_dec"] * c["Tt"]
+        whole_note = "recurrence chains only (2Ts F_enc + Tt F_dec + 2Ts Bk_enc + Tt Bk_dec); SURVEY 8(d) evaluates the full model at cfg2 and cfg5 only"
         if args.config == "cfg2":
             whole = 6.150e9            # chains + once-per-batch products (fwd, 2x bwd) + Adam, evaluated at cfg2
+            whole_note = "SURVEY 8(d), evaluated: chains 5.70 GB + once-per-batch products (fwd, 2x bwd) + Adam = 6.150 GB"
+        elif args.config == "cfg5":
+            # ONE figure for configs[4]: SURVEY 8(d)'s evaluated 66.9 GB per step (2 bytes per streamed element:
+            # chains 62.5 GB + once-per-batch products + Adam 7 x 4 B x P); rounds 3-4 printed the chains' 62.5 GB here
+            whole = 66.9e9
+            whole_note = "SURVEY 8(d), evaluated at configs[4] (fp16 streams): chains 62.5 GB + once-per-batch products + Adam = 66.9 GB"
         step_s = dt / args.steps
         res["roofline_whole_step"] = {"bound": "hbm", "kernel": "zero-grad + forward + backward + clip + Adam (SURVEY 8d streaming model)",
                                       "achieved": whole / step_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                       "frac": whole / step_s / HBM_PEAK, "algorithmic_bytes_per_step": whole,
+                                      "algorithmic_bytes_model": whole_note,
                                       "target_frac": 0.40,
                                       "traffic": ps["step_bytes"] if ps else None,
                                       "traffic_source": (ps["file"] + ": L2-miss bytes of one optimiser step (FETCH_SIZE x2 + WRITE_SIZE)")
