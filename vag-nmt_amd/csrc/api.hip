@@ -517,11 +517,17 @@ int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_wh
         };
         VAG_TRY(vag_jobs_launch(j16, 10, s));
     }
-    return gemm_nn(3 * H, C, H, w.gru2.w_ih, H, w.c2h, C, 0.f, p.wp, C, s);      // Wp = W_ih2 W_c2h
+    // (rounds 2-4 also formed the folded product Wp = W_ih2 W_c2h here, 29 us per optimiser step: the training step takes
+    // context2hid and W_ih2 one after the other now (cgru: uk), and the one path that still wants Wp -- the free-running launch
+    // chain -- forms it for itself)
+    (void)p;
+    return VAG_OK;
 }
 
 struct CgruWs {
     float *xp1, *h1, *g1, *g2, *qhp, *scores, *alpha, *tmp, *prep, *encwp;
+    float* uk;                  // (B,Ts,H) enc W_c2h^T: context2hid applied to the keys once per batch (round 5: the projected keys are
+                                // encwp = uk W_ih2^T -- two products through the H-wide intermediate instead of one through W_ih2 W_c2h)
     float* psc;                 // persistent decoder (persist.hip): the steps' scores as exchanged between workgroups (Tt,4,B,Ts)
     unsigned* sync;             // ... and its counters
     unsigned* sync_b;           // the backward kernel's counters ...
@@ -542,6 +548,7 @@ static CgruWs cgru_ws(float* ws, int64_t B, int64_t Ts, int64_t Tt, int64_t E, i
     w.tmp = take(B * E);
     w.prep = take(cgru_prep(nullptr, H).total);
     w.encwp = take(B * Ts * 3 * H);         // (W_ih2 W_c2h) enc[b,s,:]: the keys as gru_2 sees them, once per batch
+    w.uk = take(B * Ts * H);
     w.h1 = take(Tt * B * H);                // (exchanged between workgroups with marked words: starts from zero, see vag_step_zero_ranges)
     w.psc = take(Tt * B * Ts * 4);          // four copies (persist.hip: ACC_SHARDS)
     w.sync = reinterpret_cast<unsigned*>(take(vag_dec_persistent_sync_words(B, Tt)));
@@ -665,8 +672,16 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
             VAG_TRY(vag_embed_gather_launch(tok, B, 1, Tt, B, w.emb, E, e_all, nullptr, 0, 0.f, s));
             VAG_TRY(vag_gemm_launch(Tt * B, 3 * H, E, 1.f, e_all, E, 1, w.gru1.w_ih, 1, E, 0.f, k.xp1, 3 * H, w.gru1.b_ih, 0, s));
         }
-        VAG_TRY(vag_gemm_launch(B * Ts, 3 * H, C, 1.f, enc, C, 1, p.wp, 1, C, 0.f, k.encwp, 3 * H, nullptr, 0, s, s16 ? 1 : 0));
+        // the keys as gru_2 sees them (NMT_Decoder.py:127-129 hoisted): context2hid on the keys (joins the group), then W_ih2 on
+        // the H-wide result -- 6.7 instead of 9.6 GFLOP at configs[1] against the one product through W_ih2 W_c2h, and the
+        // per-optimiser-step product that forms W_ih2 W_c2h is gone (exact in real arithmetic; the reference's own order)
+        VAG_TRY(vag_gemm_launch(B * Ts, H, C, 1.f, enc, C, 1, w.c2h, 1, C, 0.f, k.uk, H, nullptr, 0, s));
         VAG_TRY(grp.end(s));
+    }
+    {
+        VagGemmGroup grp2;      // (launched at once: the recurrence below reads it)
+        VAG_TRY(vag_gemm_launch(B * Ts, 3 * H, H, 1.f, k.uk, H, 1, w.gru2.w_ih, 1, H, 0.f, k.encwp, 3 * H, nullptr, 0, s, s16 ? 1 : 0));
+        VAG_TRY(grp2.end(s));
     }
     auto hoisted_step = [&](int64_t t) -> int {
         const float* hprev = t == 0 ? h0 : h2_all + (t - 1) * BH;
@@ -709,6 +724,15 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
     }
     for (int64_t t = 0; hoist && t < Tt; ++t) VAG_TRY(hoisted_step(t));
     if (hoist) return vag_attn_wsum_launch(1, k.alpha, enc, B, Ts, Tt, C, c_all, s);                       // all contexts :126
+    if (g_derived) {
+        // the free-running launch chain takes gru_2's input projection from the context through the folded product
+        // Wp = W_ih2 W_c2h (cgru_step); a driver's derived buffer does not carry it any more: formed here, in this call's workspace
+        CgruPrep pk = cgru_prep(k.prep, H);
+        VagGemmGroup now;
+        VAG_TRY(gemm_nn(3 * H, C, H, w.gru2.w_ih, H, w.c2h, C, 0.f, pk.wp, C, s));
+        VAG_TRY(now.end(s));
+        p.wp = pk.wp;
+    }
     for (int64_t t = 0; t < Tt; ++t) {
         if (free_run) {
             if (B <= 256 && aligned16(w.emb) && aligned16(w.gru1.w_ih) && aligned16(e_all)) {
@@ -770,9 +794,14 @@ int vag_cgru_attn_decode_free_fwd(const float* enc, const float* pe, const float
         VagGemmGroup grp;
         VAG_TRY(vag_gemm_launch(V, 3 * H, E, 1.f, w.emb, E, 1, w.gru1.w_ih, 1, E, 0.f, embp, 3 * H, w.gru1.b_ih, 0, s));
         VAG_TRY(vag_gemm_launch(V, E, E, 1.f, w.emb, E, 1, head->w3, 1, E, 0.f, embw3, E, nullptr, 0, s));
-        VAG_TRY(vag_gemm_launch(B * Ts, 3 * H, C, 1.f, enc, C, 1, p.wp, 1, C, 0.f, k.encwp, 3 * H, nullptr, 0, s));
+        VAG_TRY(vag_gemm_launch(B * Ts, H, C, 1.f, enc, C, 1, w.c2h, 1, C, 0.f, k.uk, H, nullptr, 0, s));     // (see vag_cgru_attn_decode_seq_fwd)
         VAG_TRY(vag_gemm_launch(B * Ts, E, C, 1.f, enc, C, 1, head->w2, 1, C, 0.f, encw2, E, nullptr, 0, s));
         VAG_TRY(grp.end(s));
+    }
+    {
+        VagGemmGroup grp2;
+        VAG_TRY(vag_gemm_launch(B * Ts, 3 * H, H, 1.f, k.uk, H, 1, w.gru2.w_ih, 1, H, 0.f, k.encwp, 3 * H, nullptr, 0, s));
+        VAG_TRY(grp2.end(s));
     }
     VAG_TRY(vag_dec_free_persistent_launch(pe, mask, h0, w.gru1.w_hh, w.gru1.b_hh, p.wcat, p.bcat, w.attn_v, k.encwp, w.gru2.b_ih,
                                            k.h1, k.g1, k.qhp, k.alpha, h2_all, k.g2, k.psc, k.sync, tables, head->w1, head->b1,
@@ -785,6 +814,7 @@ int vag_cgru_attn_decode_free_fwd(const float* enc, const float* pe, const float
 
 struct CgruBwdScratch {
     float *wcatT, *wpT, *whh1T, *dgi2, *dqgh, *dalpha, *ds, *dgi1, *dgh1, *dh1d, *carry, *de, *dvp, *dwp, *dah, *dencwp, *pbuf;
+    float *u_all, *du_all, *duk;          // (R,H) context2hid(c_t); (R,H) its gradient dgi2 W_ih2; (B,Ts,H) gradient of uk
     int64_t total;
 };
 static CgruBwdScratch cgru_bwd_scratch(float* p, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
@@ -801,6 +831,7 @@ static CgruBwdScratch cgru_bwd_scratch(float* p, int64_t B, int64_t Ts, int64_t 
     w.dah = take(R * Ts);                   // d alpha through the head's use of the context, all steps
     w.dencwp = take(B * Ts * 3 * H);        // gradient of the projected keys
     w.pbuf = take(B * H);                   // dgh2 W_hh2 + carry, computed beside the attention backward
+    w.u_all = take(R * H); w.du_all = take(R * H); w.duk = take(B * Ts * H);
     w.total = o;
     return w;
 }
@@ -900,9 +931,15 @@ int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const f
     // after the loop: everything that does not sit on the recurrence's critical path, as large products
     VAG_TRY(vag_attn_post_bwd_launch(pe, k.qhp, Q, w.attn_v, z.ds, k.alpha, d_c_all, B, Ts, Tt, C, d_pe, z.dvp, d_enc_out,
                                      accumulate_enc, s, s16));
-    // d_enc += (sum_t alpha_t dgi2_t) (W_ih2 W_c2h): gru_2's share, through the projected keys
-    VAG_TRY(vag_attn_wsum_launch(0, k.alpha, z.dgi2, B, Ts, Tt, 3 * H, z.dencwp, s));
-    return gemm_nn(B * Ts, C, 3 * H, z.dencwp, 3 * H, p.wp, C, 1.f, d_enc_out, C, s);
+    // gru_2's share of d_enc, through the projected keys encwp = (enc W_c2h^T) W_ih2^T: du_t = dgi2_t W_ih2 for all steps (H wide),
+    // d_uk[b,s] = sum_t alpha[t,b,s] du_t[b], d_enc += d_uk W_c2h.  (Rounds 2-4: d_enc += (sum_t alpha_t dgi2_t) (W_ih2 W_c2h), 8 GFLOP.)
+    {
+        VagGemmGroup now;       // du is read by the weighted sum right below: launched at once (with whatever was queued before)
+        VAG_TRY(gemm_nn(Tt * B, H, 3 * H, z.dgi2, 3 * H, w.gru2.w_ih, H, 0.f, z.du_all, H, s));
+        VAG_TRY(now.end(s));
+    }
+    VAG_TRY(vag_attn_wsum_launch(0, k.alpha, z.du_all, B, Ts, Tt, H, z.duk, s));
+    return gemm_nn(B * Ts, C, H, z.duk, H, w.c2h, C, 1.f, d_enc_out, C, s);
 }
 
 // Parameter gradients of the decoder from the per-step tensors the loop left in `scratch` (large products; nothing
@@ -943,9 +980,11 @@ int vag_cgru_bwd_weights_chunk(const float* h0, const int64_t* tok, vag_dec_w w,
     const float* h1 = k.h1 + r0 * H;
     VAG_TRY(gemm_tn_acc(3 * H, H, n, dgh2, Q, h1, H, g.gru2.w_hh, H, s, g.gru2.b_hh));       // (each with its bias gradient)
     VAG_TRY(gemm_tn_acc(C, H, n, dqgh, Q, h1, H, g.attn_h, H, s));
-    // d(W_ih2 W_c2h) = dgi2^T c, then (vag_cgru_bwd_weights_finish) the chain rule through the folded product
-    VAG_TRY(vag_gemm_launch(3 * H, C, n, 1.f, dgi2, 1, 3 * H, c_all + r0 * C, C, 1, first ? 0.f : 1.f, z.dwp, C, nullptr, 0, s, 0,
-                            g.gru2.b_ih));
+    // gru_2's input side, gi2_t = W_ih2 u_t with u_t = W_c2h c_t = sum_s alpha[t,b,s] uk[b,s] (formed here for all steps by one
+    // weighted sum): d W_ih2 += dgi2^T u (with the bias gradient), d W_c2h += du^T c  (du = dgi2 W_ih2: the loop function left it)
+    if (first) VAG_TRY(vag_attn_wsum_launch(1, k.alpha, k.uk, B, Ts, Tt, H, z.u_all, s));
+    VAG_TRY(gemm_tn_acc(3 * H, H, n, dgi2, 3 * H, z.u_all + r0 * H, H, g.gru2.w_ih, H, s, g.gru2.b_ih));
+    VAG_TRY(gemm_tn_acc(H, C, n, z.du_all + r0 * H, H, c_all + r0 * C, C, g.c2h, C, s));
     if (h0 + B * H == h2_all) {
         // caller keeps [h0, h2_all] in one buffer: the previous states of all steps are one (R,H) operand
         VAG_TRY(gemm_tn_acc(3 * H, H, n, dgh1, 3 * H, h0 + r0 * H, H, g.gru1.w_hh, H, s, g.gru1.b_hh));
@@ -974,9 +1013,9 @@ int vag_cgru_bwd_weights_finish(vag_dec_w w, int64_t B, int64_t Ts, int64_t Tt, 
                                 float* scratch, bool with_attn_v, hipStream_t s) {
     const int64_t C = 2 * H;
     CgruBwdScratch z = cgru_bwd_scratch(scratch, B, Ts, Tt, E, H);
+    (void)w;
     if (with_attn_v) VAG_TRY(vag_colsum_launch(z.dvp, VAG_POST_CHUNKS(Ts) * B, C, C, g.attn_v, s));
-    VAG_TRY(vag_gemm_launch(3 * H, H, C, 1.f, z.dwp, C, 1, w.c2h, 1, C, 1.f, g.gru2.w_ih, H, nullptr, 0, s));
-    return vag_gemm_launch(H, C, 3 * H, 1.f, w.gru2.w_ih, 1, H, z.dwp, C, 1, 1.f, g.c2h, C, nullptr, 0, s);
+    return VAG_OK;              // (rounds 2-4: the chain rule through the folded product W_ih2 W_c2h, two more products)
 }
 extern "C" {
 
