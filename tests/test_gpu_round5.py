@@ -335,3 +335,58 @@ def test_two_drivers_on_one_device_do_not_void_each_others_steps():
     torch.cuda.synchronize()
     assert int(a.step_count.item()) == a0[3] + 1
     a.check()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (5) Marked-word hand-offs (persist.hip: tag1 / ld_rows_tagged) under skewed starts: the producer signals WITHOUT draining its
+#     stores, a consumer re-loads words whose mark is missing.  A kernel squatting on a quarter of the CUs when the persistent decoder
+#     forward is launched makes some of its workgroups start up to ~0.2 ms late (profiles/r04_exp_squatter.txt): early workgroups
+#     then poll and load while late ones have not stored anything -- every run must still equal the undisturbed one.
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_marked_handoffs_survive_skewed_workgroup_starts():
+    import ctypes as C
+    import subprocess
+    import bench
+    from vagnmt_hip import _lib as L, ops
+    so = os.path.join(ROOT, "tools", "libsquatter.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC",
+                               os.path.join(ROOT, "tools", "squatter.hip"), "-o", so])
+    SQ = C.CDLL(so)
+    SQ.squat.restype = C.c_int
+    SQ.squat.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    c = bench.CFG2
+    dev = torch.device("cuda", 0)
+    m = bench.build_model(c, dev, dropout=False).eval()
+    src, lens, tgt, im = bench.make_batch(c, 0, dev, ragged=True)
+    lt = torch.tensor(lens, dtype=torch.int32, device=dev)
+    assert L.lib().vag_recurrence_supported(1, c["B"], c["Ts"], c["Tt"], c["H"]) == 1
+    with torch.no_grad():
+        enc, mask = m._encode(src, lt, None)
+        _, ctx = m.vse_imagine.forward_bm(im, enc, mask, None)
+        h0 = ops.DecInit.apply(enc, mask, ctx, m.decoderini.weight, m.decoderini.bias, 0.5)
+        pe = ops.KeysProj.apply(enc, m.decoder.attn.attn_e.weight)
+        sos = torch.full((1, c["B"]), 2, dtype=torch.int64, device=dev)
+        tok = torch.cat([sos, tgt.t()], 0).contiguous()
+        dec = m.decoder
+
+        def run():
+            h2, cc, e = ops.cgru_decode_seq(enc, pe, mask, h0, tok, dec.embedding.weight, dec.dec_params(), V=c["V"])
+            return h2.clone(), cc.clone()
+        ref_h2, ref_c = run()
+        torch.cuda.synchronize()
+        assert L.lib().vag_persistent_timeouts() == 0
+        side = torch.cuda.Stream()
+        sink = torch.zeros(4, device=dev)
+        worst = 0.0
+        for i in range(12):
+            wgs, us = (64, 150.0) if i % 2 == 0 else (160, 60.0)
+            side.wait_stream(torch.cuda.current_stream())
+            assert SQ.squat(side.cuda_stream, wgs, 256, 16 * 1024, us, sink.data_ptr()) == 0       # resident first
+            h2, cc = run()
+            torch.cuda.synchronize()
+            # (the score shares are summed with fp32 atomics: equal to rounding, not bitwise)
+            worst = max(worst, float((h2 - ref_h2).abs().max()), float((cc - ref_c).abs().max()))
+            assert torch.isfinite(h2).all()
+        assert worst <= 2e-5, worst
+        assert L.lib().vag_persistent_timeouts() == 0
