@@ -42,6 +42,10 @@ static int gemm_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
 // refreshes them once per optimiser step (vag_derive_weights) and points the operators at that copy for the duration of a
 // call through this thread-local (same pattern as the grouped-GEMM bracket: one host thread drives a stream).
 static thread_local const float* g_derived = nullptr;
+// vag_train_step's prologue launch has zeroed the head's tmid and the encoder's dx of this step (step.hip): the two operators
+// that accumulate into them from grouped products skip their own fill launch
+static thread_local bool g_step_zeroed = false;
+void vag_step_set_zeroed(bool v) { g_step_zeroed = v; }
 void vag_set_derived_override(const float* d) { g_derived = d; }
 // 2-byte storage mode of the step driver (vag_step_cfg.storage = 1): the tensors the recurrences stream at every time step
 // -- their weights (fp16 copies in the derived buffer) and the attention keys pe / projected keys encwp -- are fp16 in
@@ -369,7 +373,7 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
     }
     VAG_TRY(grp1.end(s));
     // d(embedded inputs) = sum over the directions of dgi W_ih: both products add into a zeroed buffer, one grouped launch
-    VAG_TRY(zero_async(w.dx, R * E * sizeof(float), s));
+    if (!g_step_zeroed) VAG_TRY(zero_async(w.dx, R * E * sizeof(float), s));
     VagGemmGroup grp2;
     for (int d = 0; d < 2; ++d)
         VAG_TRY(gemm_nn(R, E, 3 * H, d_xp + d * 3 * H, 6 * H, (d == 0 ? fw : bw).w_ih, E, 1.f, w.dx, E, s));
@@ -566,6 +570,8 @@ void vag_step_zero_ranges(float* ws_enc, float* ws_dec, int64_t B, int64_t Ts, i
     p[0] = e.sync;
     n[0] = (reinterpret_cast<unsigned*>(ws_enc) + e.total) - e.sync;
     CgruWs d = cgru_ws(ws_dec, B, Ts, Tt, Et, H);
+    p[2] = reinterpret_cast<unsigned*>(e.dx);          // the encoder's d(embedded inputs): two grouped products add into it
+    n[2] = Ts * B * Es;
     p[1] = reinterpret_cast<unsigned*>(d.h1);          // h1 | psc | sync | sync_b | dal: one range
     n[1] = (reinterpret_cast<unsigned*>(ws_dec) + d.total) - p[1];
 }
@@ -835,6 +841,13 @@ static CgruBwdScratch cgru_bwd_scratch(float* p, int64_t B, int64_t Ts, int64_t 
     w.total = o;
     return w;
 }
+// where the decoder's backward keeps d(embedded inputs) (R,E) inside its scratch: a step driver lets the head's backward write its
+// share straight there (vag_cgru_bwd_weights_chunk then adds gru_1's share without a copy)
+}  // extern "C"
+float* vag_cgru_bwd_scratch_de(float* scratch, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
+    return cgru_bwd_scratch(scratch, B, Ts, Tt, E, H).de;
+}
+extern "C" {
 int64_t vag_cgru_bwd_scratch_floats(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
     return cgru_bwd_scratch(nullptr, B, Ts, Tt, E, H).total;
 }
@@ -997,8 +1010,10 @@ int vag_cgru_bwd_weights_chunk(const float* h0, const int64_t* tok, vag_dec_w w,
     }
     VAG_TRY(gemm_tn_acc(3 * H, E, n, dgi1, 3 * H, e_all + r0 * E, E, g.gru1.w_ih, E, s, g.gru1.b_ih));
     // d(embedded inputs) = dgi1 W_ih1 (+ the head's W3 path), scattered into the embedding gradient
+    // (z.de: the sum; a caller that hands over d_e_all with the scratch's own address -- the step driver, whose head backward
+    // writes there -- saves the copy)
     float* de = z.de + r0 * E;
-    if (d_e_all) VAG_TRY(copy_async(de, d_e_all + r0 * E, n * E * sizeof(float), s));
+    if (d_e_all && d_e_all != z.de) VAG_TRY(copy_async(de, d_e_all + r0 * E, n * E * sizeof(float), s));
     VAG_TRY(gemm_nn(n, E, 3 * H, dgi1, 3 * H, w.gru1.w_ih, E, d_e_all ? 1.f : 0.f, de, E, s));
     return VAG_OK;
 }
@@ -1132,7 +1147,7 @@ int vag_cgru_attn_decode_step_h(const float* pe, const float* mask, const float*
 static int head_pre_seq(const float* h2, const float* c, const float* e, const vag_head_w& w, int64_t R, int64_t E, int64_t H,
                         float p_out, const uint64_t* rng, float* tmid, hipStream_t s) {
     const int64_t C = 2 * H;
-    VAG_TRY(zero_async(tmid, R * E * sizeof(float), s));
+    if (!g_step_zeroed) VAG_TRY(zero_async(tmid, R * E * sizeof(float), s));
     VagGemmGroup grp4;
     VAG_TRY(vag_gemm_launch(R, E, H, 1.f, h2, H, 1, w.w1, 1, H, 1.f, tmid, E, w.b1, 0, s));
     VAG_TRY(vag_gemm_launch(R, E, C, 1.f, c, C, 1, w.w2, 1, C, 1.f, tmid, E, w.b2, 0, s));

@@ -179,6 +179,8 @@ int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const flo
                                   const float* qhp, const float* alpha, const float* d_h2_all, const float* dah, float* dgi2,
                                   float* dqgh, float* ds, float* dgi1, float* dgh1, float* d_h0, float* dal, unsigned* sync,
                                   int64_t B, int64_t Ts, int64_t Tt, int64_t H, hipStream_t s);
+float* vag_cgru_bwd_scratch_de(float* scratch, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H);
+void vag_step_set_zeroed(bool v);          // api.hip: the step's prologue zeroed tmid and the encoder's dx
 void vag_step_zero_ranges(float* ws_enc, float* ws_dec, int64_t B, int64_t Ts, int64_t Tt, int64_t Es, int64_t Et, int64_t H,
                           unsigned** p, int64_t* n);                 // api.hip
 void vag_persist_set_prezeroed(bool v);      // calling thread: the launches below skip zeroing their counters / exchange buffers

@@ -62,14 +62,19 @@ bool cfg_ok(const vag_step_cfg* c) {
 // V11.py:117,146), the per-sentence token counts -- one launch for the step's scalar bookkeeping.
 // Also zeroes the counters and exchange buffers of the step's four recurrence kernels (two word ranges, api.hip:
 // vag_step_zero_ranges): one launch instead of four.
+// further ranges the prologue zeroes, in 16-byte units: the decoder's hidden states h2 (exchanged between workgroups with marked
+// words, persist.hip: tag1), the head's tmid and the encoder's d(embedded inputs) (grouped products accumulate into them)
+struct ZeroRanges { uint4* p[3]; int64_t n[3]; };
 __global__ __launch_bounds__(256) void step_prologue_kernel(uint64_t* rng, const int64_t* __restrict__ tgt, int B, int Tt,
                                                             int64_t* __restrict__ tok, float* __restrict__ consts,
                                                             float* __restrict__ inv_cnt, float w_mt, float w_vse,
                                                             unsigned* __restrict__ z0, int64_t n0, unsigned* __restrict__ z1,
-                                                            int64_t n1, uint4* __restrict__ z2, int64_t n2) {
+                                                            int64_t n1, ZeroRanges zr) {
     const int64_t gid = blockIdx.x * 256ll + threadIdx.x;
     for (int64_t i = gid; i < n0; i += (int64_t)gridDim.x * 256) z0[i] = 0u;
-    for (int64_t i = gid; i < n2; i += (int64_t)gridDim.x * 256) z2[i] = make_uint4(0u, 0u, 0u, 0u);     // (16-byte units)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)                                                                           // (16-byte units)
+        for (int64_t i = gid; i < zr.n[r]; i += (int64_t)gridDim.x * 256) zr.p[r][i] = make_uint4(0u, 0u, 0u, 0u);
     {   // the large range: 16 bytes per thread (the range starts 256-byte aligned; its tail word by word)
         const int64_t n4 = n1 >> 2;
         uint4* z4 = reinterpret_cast<uint4*>(z1);
@@ -96,9 +101,9 @@ struct LossRingScope {
     explicit LossRingScope(int r) { vag_set_loss_ring(r); }
     ~LossRingScope() { vag_set_loss_ring(0); }
 };
-struct PrezeroScope {       // the recurrence kernels of this call find their counters zeroed by the step's prologue launch
-    PrezeroScope() { vag_persist_set_prezeroed(true); }
-    ~PrezeroScope() { vag_persist_set_prezeroed(false); }
+struct PrezeroScope {       // the recurrence kernels of this call find their counters zeroed by the step's prologue launch,
+    PrezeroScope() { vag_persist_set_prezeroed(true); vag_step_set_zeroed(true); }       // the head and the encoder's backward
+    ~PrezeroScope() { vag_persist_set_prezeroed(false); vag_step_set_zeroed(false); }    // their accumulation buffers
 };
 struct DerivedScope {       // points the operators at the driver's derived weights, storage mode and head chunk for one call
     const float* prev_d;    // ... and puts back what the caller had set with vag_set_operator_context ("until changed")
@@ -244,6 +249,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     float* h0 = k.hseq;                    // [h0, h2_0 .. h2_{Tt-1}] in one buffer: the W_hh1 gradient is one product
     float* h2_all = k.hseq + B * H;
     const uint64_t* crng = rng;
+    float* d_e = vag_cgru_bwd_scratch_de(k.scr_dec, B, Ts, Tt, Et, H);       // d(embedded target inputs): head's share + gru_1's, in place
     // 2-byte storage mode: what feeds the large products carries no more than fp16 there (fp16-stored keys and weights,
     // activations the next fp16 product rounds anyway), so they run on one plane: fp16 operands forward (11 significand bits),
     // bf16 operands for every gradient product (fp16 would flush small gradients; their rounding errors average over the long sums)
@@ -257,16 +263,18 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
             VAG_TRY(vag_img_proj_l2_fwd(im, w.im_w, w.im_b, B, c.I, S, c.activation_vse, k.y_im, k.nrm_im, k.im_emb, si));
         }
         {
-            unsigned* zp[2];
-            int64_t zn[2];
+            unsigned* zp[3];
+            int64_t zn[3];
             vag_step_zero_ranges(k.ws_enc, k.ws_dec, B, Ts, Tt, c.Es, Et, H, zp, zn);
             int64_t nb = cdiv64((Tt + 1) * B, 256);
             if (nb < cdiv64(zn[1], 1024)) nb = cdiv64(zn[1], 1024);
             if (nb > 1024) nb = 1024;
-            // the decoder's hidden states h2 are exchanged between workgroups with marked words (persist.hip: tag1): from zero
+            ZeroRanges zr;
+            zr.p[0] = reinterpret_cast<uint4*>(h2_all); zr.n[0] = Tt * B * H / 4;
+            zr.p[1] = reinterpret_cast<uint4*>(k.tmid); zr.n[1] = Tt * B * Et / 4;
+            zr.p[2] = reinterpret_cast<uint4*>(zp[2]); zr.n[2] = zn[2] / 4;
             hipLaunchKernelGGL(step_prologue_kernel, dim3((unsigned)nb), dim3(256), 0, s, rng, tgt, (int)B, (int)Tt, k.tok,
-                               k.consts, k.inv_cnt, w_mt, w_vse, zp[0], zn[0], zp[1], zn[1], reinterpret_cast<uint4*>(h2_all),
-                               Tt * B * H / 4);
+                               k.consts, k.inv_cnt, w_mt, w_vse, zp[0], zn[0], zp[1], zn[1], zr);
             VAG_LAUNCH_CHECK();
         }
         VAG_TRY(vag_bigru_seq_fwd(src, lengths, w.enc_emb, w.enc_fw, w.enc_bw, c.p_emb, c.p_ctx, crng, B, Ts, c.Es, H, k.enc,
@@ -309,17 +317,17 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     // + initial state: final for vse_imagine.* and decoderini.*): a data-parallel driver with three buckets calls them one by one
     if (phases & (2 | 16)) {
         VAG_TRY(vag_head_ce_seq_bwd(h2_all, k.c_all, k.e_all, w.head, tgt, vocab_weight, B, Tt, Et, H, V, c.p_out, crng, k.tmid,
-                                    k.logits, c.ldl, k.lse, k.inv_cnt, k.consts + 0, k.d_h2, k.d_c, k.d_e, g.head, k.scr_head,
+                                    k.logits, c.ldl, k.lse, k.inv_cnt, k.consts + 0, k.d_h2, k.d_c, d_e, g.head, k.scr_head,
                                     stream));
         {
             // after the backward recurrence: the products that add into d_enc (projected keys, attention keys) and the weight
             // gradients of the decoder and of attn_e are queued by layout and go out as two grouped launches
             VagGemmGroup outer(true);
             VAG_TRY(vag_cgru_attn_decode_seq_bwd_loop(k.enc, k.pe, k.mask, h0, k.tok, w.dec, B, Ts, Tt, Et, H, V, h2_all, k.c_all,
-                                                      k.e_all, k.d_h2, k.d_c, k.d_e, k.ws_dec, k.d_enc, 0, k.d_pe, k.d_h0,
+                                                      k.e_all, k.d_h2, k.d_c, d_e, k.ws_dec, k.d_enc, 0, k.d_pe, k.d_h0,
                                                       k.scr_dec, stream));
             VAG_TRY(vag_attn_keys_proj_bwd(k.enc, w.attn_e, k.d_pe, B * Ts, C, k.d_enc, 1, g.attn_e, stream));
-            VAG_TRY(vag_cgru_attn_decode_seq_bwd_weights(h0, k.tok, w.dec, B, Ts, Tt, Et, H, h2_all, k.c_all, k.e_all, k.d_e,
+            VAG_TRY(vag_cgru_attn_decode_seq_bwd_weights(h0, k.tok, w.dec, B, Ts, Tt, Et, H, h2_all, k.c_all, k.e_all, d_e,
                                                          k.ws_dec, g.dec, k.scr_dec, stream));
             VAG_TRY(outer.end(s));
         }
