@@ -182,7 +182,9 @@ int vag_cgru_attn_decode_seq_bwd_weights(const float* h0, const int64_t* tok, va
  * attends over source sentence n / rows_per_src (the reference tiles encoder_outputs by beam_size, :253).
  * tok int64[N]; h_in (N,H) -> h_out (N,H), c (N,C), e (N,E).  scratch: vag_cgru_step_scratch_floats(). */
 /* `prep`: vag_cgru_prep_floats(H) floats filled by vag_cgru_prepare() once per decode call (derived weights:
- * [attn_h ; gru_2.w_hh] stacked so both products of h1 are one launch, and gru_2.w_ih . context2hid folded). */
+ * [attn_h ; gru_2.w_hh] stacked so both products of h1 are one launch, and gru_2.w_ih . context2hid folded: decoding
+ * steps and the free-running launch chain read it; the teacher-forced sequence operators apply context2hid and gru_2.w_ih to the
+ * keys one after the other instead). */
 int64_t vag_cgru_prep_floats(int64_t H);
 int vag_cgru_prepare(vag_dec_w w, int64_t H, float* prep, vag_stream_t stream);
 int64_t vag_cgru_step_scratch_floats(int64_t N, int64_t Ts, int64_t E, int64_t H);
@@ -457,8 +459,8 @@ int vag_set_option(const char* name, int64_t value);
 /* Up to four contiguous device byte ranges copied by one launch (src[i] -> dst[i], bytes[i]; host arrays): a batch's
  * src / lengths / tgt / image rows into the step driver's static input buffers. */
 int vag_copy4(const void* const* src, void* const* dst, const int64_t* bytes, int n, vag_stream_t stream);
-/* Weights derived from the parameters alone ([attn_h; gru_2.w_hh] stacked and transposed, gru_2.w_ih . context2hid,
- * gru_1.w_hh^T, both encoder w_hh^T): per optimiser step, not per training step.  with_fp16: also the fp16 copies of the
+/* Weights derived from the parameters alone ([attn_h; gru_2.w_hh] stacked and transposed, gru_1.w_hh^T, both encoder w_hh^T;
+ * until round 4 also gru_2.w_ih . context2hid, which the training step no longer reads): per optimiser step, not per training step.  with_fp16: also the fp16 copies of the
  * recurrent matrices the 2-byte storage mode reads (vag_step_cfg.storage = 1; H % 8 == 0). */
 int64_t vag_derived_floats(int64_t H);
 int vag_derive_weights(vag_dec_w w, const float* enc_whh_fw, const float* enc_whh_bw, int64_t H, int with_fp16,
