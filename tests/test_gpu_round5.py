@@ -390,3 +390,44 @@ def test_marked_handoffs_survive_skewed_workgroup_starts():
             assert torch.isfinite(h2).all()
         assert worst <= 2e-5, worst
         assert L.lib().vag_persistent_timeouts() == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (6) The reference's checkpointing after shim steps and an evaluation pass: torch.save(model) / torch.load
+#     (nmt_multimodal_beam_DE.py:491-520, :534).
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_whole_module_checkpoint_after_shim_steps_and_decoding():
+    import io
+    T = _shim()
+    meta, P, z = load_golden("mm_dot_tied_mid_f32")
+    cm, cv = criteria(meta)
+    src, tgt, im = torch.from_numpy(z["src"]).cuda(), torch.from_numpy(z["tgt"]).cuda(), torch.from_numpy(z["im"]).cuda()
+    lens = meta["lengths"]
+    m = build(meta, P)
+    opt = _reference_optimizer(m)
+    for _ in range(3):
+        T.train_imagine_beam(src, tgt, im, lens, m, opt, cm, cv, meta["loss_w"], 1.0, clip=1.0)
+    m.eval()
+    dev = m(src, lens, tgt, im, 1.0, criterion_mt=cm, criterion_vse=cv)          # validation loss, as :431
+    want_beam = m.beamsearch_decode(src, lens, im, 3, 12)                       # (captures decode graphs on the module)
+    want_greedy = m.beamsearch_decode(src, lens, im, 1, 12)
+    buf = io.BytesIO()
+    torch.save(m, buf)                                                          # :492
+    assert buf.tell() < 3 * 4 * sum(p.numel() for p in m.parameters())          # values once: no gradient buffer, no caches
+    buf.seek(0)
+    m2 = torch.load(buf, weights_only=False)                                    # :534
+    m2.eval()
+    for (n1, p1), (n2, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2) and not hasattr(p2, "_vag_grad")
+    got = m2(src, lens, tgt, im, 1.0, criterion_mt=cm, criterion_vse=cv)
+    assert abs(float(got[0]) - float(dev[0])) <= 1e-6 * max(1.0, abs(float(dev[0])))
+    assert [list(map(int, x)) for x in m2.beamsearch_decode(src, lens, im, 3, 12)] == [list(map(int, x)) for x in want_beam]
+    assert [list(map(int, x)) for x in m2.beamsearch_decode(src, lens, im, 1, 12)] == [list(map(int, x)) for x in want_greedy]
+    # the loaded module trains through the module API with ordinary .grad tensors
+    m2.train()
+    loss, _, _ = m2(src, lens, tgt, im, 1.0, criterion_mt=cm, criterion_vse=cv)
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m2.parameters())
+    # ... and the live model goes on training on the fused step
+    T.train_imagine_beam(src, tgt, im, lens, m, opt, cm, cv, meta["loss_w"], 1.0, clip=1.0)
+    assert int(opt._vag_driver.ts.step_count.item()) == 4

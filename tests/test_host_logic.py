@@ -267,3 +267,29 @@ def test_three_bucket_layout_cuts_after_the_decoder_and_after_the_visual_groundi
         assert sorted(offs) == sorted(n for n, _ in named) and seg_off[-1] == total
         two = flat_layout(named, vse_separate=vs)
         assert two[3] == total and all(not s[0].endswith("/vse+init") for s in two[0])
+
+
+def test_whole_module_pickle_drops_decode_caches_and_gradient_routing():
+    """torch.save(model) as the reference's trainer does it right after an evaluation pass (nmt_multimodal_beam_DE.py:491-520): what
+    decoding cached on the module (captured graphs do not pickle) and the step driver's gradient routing on the parameters stay out."""
+    V11, _ = models()
+    m = V11(50, 60, 96, 16, 16, 24, 20, 0.99, tied_emb=True)
+
+    class Unpicklable:
+        def __reduce__(self):
+            raise TypeError("a captured HIP graph does not pickle")
+    m._decode_cache = {("beam", 16): {"graph": Unpicklable()}}
+    m._decode_wcache = {1: {"prep": torch.zeros(3)}}
+    from vagnmt_hip.trainer import FlatParams
+    fp = FlatParams(m)                                   # (CPU tensors: the flat re-homing is host logic)
+    p0 = next(m.parameters())
+    assert hasattr(p0, "_vag_grad")
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    assert buf.tell() < 3 * fp.n * 4                     # the values once, not the gradient buffer as well
+    buf.seek(0)
+    m2 = torch.load(buf, weights_only=False)
+    assert not hasattr(m2, "_decode_cache") and not hasattr(m2, "_decode_wcache")
+    for (n1, p1), (n2, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2) and not hasattr(p2, "_vag_grad")
+    assert hasattr(m, "_decode_cache")                   # (the live module keeps its caches)

@@ -17,6 +17,15 @@ UNK_token = 1
 class Seq2SeqBase(nn.Module):
     """encoder -> [visual grounding] -> decoder init -> cGRU decoder over the target -> loss / decode."""
 
+    def __getstate__(self):
+        """Whole-module pickles (``torch.save(model)``, nmt_multimodal_beam_DE.py:491-520, right after an evaluation pass) carry the
+        module, not what decoding cached on it: static buffers, per-weights tables and captured HIP graphs of the decode shapes
+        (``_decode_cache`` / ``_decode_wcache``: a CUDAGraph does not pickle) are rebuilt on the next decode call."""
+        state = dict(self.__dict__)
+        for k in [k for k in state if k.startswith("_decode_")]:
+            del state[k]
+        return state
+
     def reset_parameters(self):
         # models/...V11.py:77-80: every >=2-D non-bias parameter (embeddings included) gets kaiming_normal_
         for name, param in self.named_parameters():

@@ -80,6 +80,14 @@ def flat_layout(named_params, vse_separate=False, groups=None, three_buckets=Fal
     return segs, offs, seg_off, o
 
 
+def _param_pickle_state():
+    """``__getstate__`` of a re-homed parameter: nothing.  ``torch.save(model)`` (the reference checkpoints whole modules,
+    nmt_multimodal_beam_DE.py:491-520) would otherwise pickle the parameter's ``_vag_grad`` view -- the whole flat gradient buffer --
+    and a model loaded from such a pickle would route its gradients into that dead copy (vagnmt_hip.ops accumulates into
+    ``_vag_grad`` and hands autograd nothing)."""
+    return {}
+
+
 class FlatParams:
     """Re-homes a module's parameters into one flat buffer (+ gradient, Adam m/v buffers)."""
 
@@ -102,6 +110,7 @@ class FlatParams:
                 view.copy_(p.data)
                 p.data = view
                 p._vag_grad = self.grad[o:o + k].view_as(p)
+                p.__getstate__ = _param_pickle_state          # (pickles carry the values only)
                 p.grad = p._vag_grad
         self.named = named
 
