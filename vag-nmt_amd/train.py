@@ -69,7 +69,8 @@ class _Driver:
         self.model, self.optimizer = model, optimizer
         self.criteria = (criterion_mt, criterion_vse)
         self.ts = TrainStep(model, criterion_mt, criterion_vse, lr=float(g0["lr"]), clip=float(clip),
-                            teacher_force_ratio=float(tfr), betas=tuple(g0["betas"]), eps=float(g0["eps"]), groups=groups)
+                            teacher_force_ratio=float(tfr), betas=tuple(g0["betas"]), eps=float(g0["eps"]), groups=groups,
+                            capture_after=2)      # a bucketed epoch meets many (B, Ts, Tt) shapes once or twice: those stay eager
         # segment -> optimiser group (the flat layout splits a group into its encoder / non-encoder parts)
         self.seg_group = [int(name.split("/")[0][1:]) for name, _, _, _ in self.ts.fp.groups]
         self.calls = 0
