@@ -9,6 +9,9 @@
 //                        layout (no LDS staging: each weight element is used once per workgroup),
 //                        v_mfma_f32_16x16x4_f32, LDS only for the cross-wave reduction.  Epilogues: plain
 //                        (bias/addend/tanh) and the fused GRU cell.
+#ifndef VAG_CHEAT_B
+#define VAG_CHEAT_B 0
+#endif
 #include "gemm_shared.h"
 #include <algorithm>
 #include <atomic>
@@ -260,8 +263,8 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
         if (!AKC && PL == 3 && do_rs) {
             rs.x += ra.v[0] + ra.v[4]; rs.y += ra.v[1] + ra.v[5]; rs.z += ra.v[2] + ra.v[6]; rs.w += ra.v[3] + ra.v[7];
         }
-        sp_store<AKC, PL, F16, ABF>(As, ra);
-        sp_store<BKC, PL, F16>(Bs, rb);
+        sp_store<AKC, PL, F16, ABF, 8, (VAG_CHEAT_B > 1)>(As, ra);
+        sp_store<BKC, PL, F16, false, 8, VAG_CHEAT_B != 0>(Bs, rb);
         __syncthreads();
         if (t + 1 < nt) load_tile(t + 1);
         sp_compute<PL, AKC, BKC, F16>(Af, Bf, As, Bs, wm * 64, wn * 32, acc);

@@ -317,7 +317,10 @@ __device__ __forceinline__ void sp_load_bf16(const unsigned short* __restrict__ 
 }
 
 // registers -> PL (3, 2 or 1) bf16 planes in LDS, image [outer][k] per plane; F16 (PL = 1 only): one fp16 plane instead
-template <bool KC, int PL = 3, bool F16 = false, bool PRE = false, int NW = 8>
+// CHEAT (measurement builds only, -DVAG_CHEAT_B=1: tools/exp_gemm_halfsplit.py): planes 2 and 3 are copies of plane 1 -- the WRONG
+// numbers at the instruction count of an operand that arrives pre-split (one pack per pair instead of the 11-instruction split): an
+// upper bound on what splitting the weight operand once per optimiser step could buy, before its 6-bytes-per-element ingest
+template <bool KC, int PL = 3, bool F16 = false, bool PRE = false, int NW = 8, bool CHEAT = false>
 __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegsT<NW>& r) {
     constexpr int NT = 64 * NW, NI = 1024 / NT;
     static_assert(!F16 || PL == 1, "the fp16 image is a single plane");
@@ -338,6 +341,8 @@ __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegsT<N
             } else if (PL == 1) {
                 a1 = pack_bf16(r.v[4 * i + 0], r.v[4 * i + 1]); b1 = pack_bf16(r.v[4 * i + 2], r.v[4 * i + 3]);
                 a2 = a3 = b2 = b3 = 0;
+            } else if (CHEAT) {
+                a1 = a2 = a3 = pack_bf16(r.v[4 * i + 0], r.v[4 * i + 1]); b1 = b2 = b3 = pack_bf16(r.v[4 * i + 2], r.v[4 * i + 3]);
             } else {
                 split3(r.v[4 * i + 0], r.v[4 * i + 1], a1, a2, a3);
                 split3(r.v[4 * i + 2], r.v[4 * i + 3], b1, b2, b3);
@@ -361,6 +366,8 @@ __device__ __forceinline__ void sp_store(__bf16* __restrict__ S, const SpRegsT<N
             } else if (PL == 1) {
                 a1 = pack_bf16(r.v[4 * i + 0], r.v[4 * i + 1]); b1 = pack_bf16(r.v[4 * i + 2], r.v[4 * i + 3]);
                 a2 = a3 = b2 = b3 = 0;
+            } else if (CHEAT) {
+                a1 = a2 = a3 = pack_bf16(r.v[4 * i + 0], r.v[4 * i + 1]); b1 = b2 = b3 = pack_bf16(r.v[4 * i + 2], r.v[4 * i + 3]);
             } else {
                 split3(r.v[4 * i + 0], r.v[4 * i + 1], a1, a2, a3);
                 split3(r.v[4 * i + 2], r.v[4 * i + 3], b1, b2, b3);
