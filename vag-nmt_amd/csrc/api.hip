@@ -46,6 +46,9 @@ static thread_local const float* g_derived = nullptr;
 // that accumulate into them from grouped products skip their own fill launch
 static thread_local bool g_step_zeroed = false;
 void vag_step_set_zeroed(bool v) { g_step_zeroed = v; }
+// ... and has already embedded the decoder's input tokens of every step (teacher-forced form) into e_all
+static thread_local bool g_step_gathered = false;
+void vag_step_set_gathered(bool v) { g_step_gathered = v; }
 void vag_set_derived_override(const float* d) { g_derived = d; }
 // 2-byte storage mode of the step driver (vag_step_cfg.storage = 1): the tensors the recurrences stream at every time step
 // -- their weights (fp16 copies in the derived buffer) and the attention keys pe / projected keys encwp -- are fp16 in
@@ -120,7 +123,7 @@ int vag_set_option(const char* name, int64_t value) {
         {"gemm_f32mfma", &o.gemm_f32mfma}, {"gemm_nogroup", &o.gemm_nogroup}, {"gemm_big", &o.gemm_big}, {"gemm_force_tile", &o.gemm_force_tile},
         {"gemm_force_splitk", &o.gemm_force_splitk}, {"head_fuse", &o.head_fuse},
         {"head_bf16_grads", &o.head_bf16_grads}, {"persistent", &o.persistent}, {"persistent_dec_bwd", &o.persistent_dec_bwd}, {"free_persistent", &o.free_persistent}, {"attn_dot_reg", &o.attn_dot_reg},
-        {"persist_timing", &o.persist_timing}, {"s16_one_plane", &o.s16_one_plane}, {"leaf_queue", &o.leaf_queue}, {"step_fork", &o.step_fork},
+        {"persist_timing", &o.persist_timing}, {"s16_one_plane", &o.s16_one_plane}, {"leaf_queue", &o.leaf_queue}, {"attn_row", &o.attn_row}, {"step_fork", &o.step_fork},
         {"head_bf16_dlogits", &o.head_bf16_dlogits}};
     for (const auto& e : ints)
         if (strcmp(name, e.n) == 0) { *e.p = (int)value; return VAG_OK; }
@@ -675,7 +678,7 @@ int vag_cgru_attn_decode_seq_fwd(const float* enc, const float* pe, const float*
         VagGemmGroup grp;
         if (!free_run) {
             // every input token is known -> embed and project all steps at once
-            VAG_TRY(vag_embed_gather_launch(tok, B, 1, Tt, B, w.emb, E, e_all, nullptr, 0, 0.f, s));
+            if (!g_step_gathered) VAG_TRY(vag_embed_gather_launch(tok, B, 1, Tt, B, w.emb, E, e_all, nullptr, 0, 0.f, s));
             VAG_TRY(vag_gemm_launch(Tt * B, 3 * H, E, 1.f, e_all, E, 1, w.gru1.w_ih, 1, E, 0.f, k.xp1, 3 * H, w.gru1.b_ih, 0, s));
         }
         // the keys as gru_2 sees them (NMT_Decoder.py:127-129 hoisted): context2hid on the keys (joins the group), then W_ih2 on
@@ -818,6 +821,9 @@ int vag_cgru_attn_decode_free_fwd(const float* enc, const float* pe, const float
     return VAG_OK;
 }
 
+// set by vag_cgru_attn_decode_seq_bwd_loop when it has formed u_all beside d_uk, consumed by the weight-gradient function of the same
+// backward (same scratch, same host thread)
+static thread_local const float* g_u_all_ready = nullptr;
 struct CgruBwdScratch {
     float *wcatT, *wpT, *whh1T, *dgi2, *dqgh, *dalpha, *ds, *dgi1, *dgh1, *dh1d, *carry, *de, *dvp, *dwp, *dah, *dencwp, *pbuf;
     float *u_all, *du_all, *duk;          // (R,H) context2hid(c_t); (R,H) its gradient dgi2 W_ih2; (B,Ts,H) gradient of uk
@@ -846,6 +852,9 @@ static CgruBwdScratch cgru_bwd_scratch(float* p, int64_t B, int64_t Ts, int64_t 
 }  // extern "C"
 float* vag_cgru_bwd_scratch_de(float* scratch, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
     return cgru_bwd_scratch(scratch, B, Ts, Tt, E, H).de;
+}
+float* vag_cgru_bwd_scratch_du(float* scratch, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {     // (Tt*B, H): dgi2 W_ih2
+    return cgru_bwd_scratch(scratch, B, Ts, Tt, E, H).du_all;
 }
 extern "C" {
 int64_t vag_cgru_bwd_scratch_floats(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H) {
@@ -951,7 +960,9 @@ int vag_cgru_attn_decode_seq_bwd_loop(const float* enc, const float* pe, const f
         VAG_TRY(gemm_nn(Tt * B, H, 3 * H, z.dgi2, 3 * H, w.gru2.w_ih, H, 0.f, z.du_all, H, s));
         VAG_TRY(now.end(s));
     }
-    VAG_TRY(vag_attn_wsum_launch(0, k.alpha, z.du_all, B, Ts, Tt, H, z.duk, s));
+    // (in the same launch: u_t = sum_s alpha[t,b,s] uk[b,s] for all steps, which the weight-gradient function needs -- forward data only)
+    VAG_TRY(vag_attn_wsum_pair_launch(k.alpha, z.du_all, H, z.duk, k.uk, H, z.u_all, B, Ts, Tt, s));
+    g_u_all_ready = z.u_all;
     return gemm_nn(B * Ts, C, H, z.duk, H, w.c2h, C, 1.f, d_enc_out, C, s);
 }
 
@@ -995,7 +1006,10 @@ int vag_cgru_bwd_weights_chunk(const float* h0, const int64_t* tok, vag_dec_w w,
     VAG_TRY(gemm_tn_acc(C, H, n, dqgh, Q, h1, H, g.attn_h, H, s));
     // gru_2's input side, gi2_t = W_ih2 u_t with u_t = W_c2h c_t = sum_s alpha[t,b,s] uk[b,s] (formed here for all steps by one
     // weighted sum): d W_ih2 += dgi2^T u (with the bias gradient), d W_c2h += du^T c  (du = dgi2 W_ih2: the loop function left it)
-    if (first) VAG_TRY(vag_attn_wsum_launch(1, k.alpha, k.uk, B, Ts, Tt, H, z.u_all, s));
+    if (first) {
+        if (g_u_all_ready != z.u_all) VAG_TRY(vag_attn_wsum_launch(1, k.alpha, k.uk, B, Ts, Tt, H, z.u_all, s));
+        g_u_all_ready = nullptr;        // (the loop function of the same backward left it: see there)
+    }
     VAG_TRY(gemm_tn_acc(3 * H, H, n, dgi2, 3 * H, z.u_all + r0 * H, H, g.gru2.w_ih, H, s, g.gru2.b_ih));
     VAG_TRY(gemm_tn_acc(H, C, n, z.du_all + r0 * H, H, c_all + r0 * C, C, g.c2h, C, s));
     if (h0 + B * H == h2_all) {
@@ -1445,6 +1459,8 @@ int vag_imagine_attn_ctx_fwd(const float* im_emb, const float* enc, const float*
     if (method == 0) {
         // e[b,t] = (W_cc enc[b,t]) . u[b] = enc[b,t] . (W_cc^T u[b])                                 :57-64
         VAG_TRY(gemm_nn(B, C, C, w.u, C, ctx2ctx, C, 0.f, w.w, C, s));
+        if (Ts <= 4096 && vag_opt().attn_row != 0)          // scores, softmax :46 and bmm :137 in one launch
+            return vag_attn_dot_row_launch(false, enc, w.w, C, mask, nullptr, B, Ts, C, alpha, ctx, s);
         VAG_TRY(vag_attn_scores_launch(1, enc, w.w, C, nullptr, mask, B, 1, Ts, C, w.scores, s));
     } else {
         VAG_TRY(linear_fwd(B * Ts, C, C, enc, C, ctx2ctx, nullptr, 0, w.pre, C, s));              // ctx2ctx(decoder_hidden) :75
@@ -1471,11 +1487,16 @@ int vag_imagine_attn_ctx_bwd_impl(const float* im_emb, const float* enc, const f
     VAG_CHECK_ARG(B > 0 && Ts > 0 && C % 4 == 0 && S % 4 == 0);
     (void)mask;
     ImgWs w = imagine_ws(ws, B, Ts, C, method);
-    VAG_TRY(vag_attn_scores_launch(1, enc, d_ctx, C, nullptr, nullptr, B, 1, Ts, C, w.dalpha, s));   // d alpha = d_ctx . enc
-    VAG_TRY(vag_softmax_bwd_launch(alpha, w.dalpha, B, Ts, w.de, s));
+    const bool row = Ts <= 4096 && vag_opt().attn_row != 0;
+    if (row) {      // d alpha = d_ctx . enc, the softmax backward and (dot method) dw[b] = sum_t de enc in one launch
+        VAG_TRY(vag_attn_dot_row_launch(true, enc, d_ctx, C, nullptr, alpha, B, Ts, C, w.de, method == 0 ? w.dw : nullptr, s));
+    } else {
+        VAG_TRY(vag_attn_scores_launch(1, enc, d_ctx, C, nullptr, nullptr, B, 1, Ts, C, w.dalpha, s));   // d alpha = d_ctx . enc
+        VAG_TRY(vag_softmax_bwd_launch(alpha, w.dalpha, B, Ts, w.de, s));
+    }
     if (method == 0) {
         VAG_TRY(vag_outer2_launch(alpha, d_ctx, w.de, w.w, B, Ts, C, d_enc, accumulate_enc, s));
-        VAG_TRY(vag_attn_ctx_launch(0, w.de, enc, B, 1, Ts, C, nullptr, w.dw, s));                // dw[b] = sum_t de enc
+        if (!row) VAG_TRY(vag_attn_ctx_launch(0, w.de, enc, B, 1, Ts, C, nullptr, w.dw, s));      // dw[b] = sum_t de enc
         VAG_TRY(linear_fwd(B, C, C, w.dw, C, ctx2ctx, nullptr, 0, w.du, C, s));                   // du = dw W_cc^T
         VAG_TRY(gemm_tn_acc(C, C, B, w.u, C, w.dw, C, g_ctx2ctx, C, s));                          // g_cc[i,j] += u[b,i] dw[b,j]
     } else {
@@ -1514,6 +1535,7 @@ int vag_rank_loss_fwd_impl(const float* im, const float* sv, int64_t B, int64_t 
 int vag_rank_loss_bwd_impl(const float* im, const float* sv, const float* G, const float* d_loss, int64_t B, int64_t S,
                            float* d_im, float* d_s, hipStream_t s) {
     VAG_CHECK_ARG(im && sv && G && d_im && d_s && B > 0 && S > 0);
+    if (B <= 512) return vag_rank_bwd_launch(G, im, sv, d_loss, B, S, d_im, d_s, s);               // both products (and the scale) in one launch
     VAG_TRY(gemm_nn(B, S, B, G, B, sv, S, 0.f, d_im, S, s));                                       // d_im = G s
     VAG_TRY(vag_gemm_launch(B, S, B, 1.f, G, 1, B, im, S, 1, 0.f, d_s, S, nullptr, 0, s));        // d_s  = G^T im
     if (!d_loss) return VAG_OK;                                                                    // (G came pre-multiplied)
@@ -1564,10 +1586,12 @@ int vag_dec_init_bwd_impl(const float* mask, const float* xmix, const float* h0,
     VAG_TRY(vag_tanh_bwd_launch(h0, d_h0, d_h0, B * H, nullptr, 0, 0.f, s));
     VAG_TRY(gemm_tn_acc(H, C, B, d_h0, H, xmix, C, g_W, C, s));
     VAG_TRY(vag_colsum_launch(d_h0, B, H, H, g_b, s));
+    const bool ride = d_ctx && B <= 128;                       // d_ctx (+)= split * dx leaves with the product that forms dx
+    if (ride) vag_skinny_nn_out2(d_ctx, C, split, accumulate_ctx ? 1 : 0);
     VAG_TRY(gemm_nn(B, C, H, d_h0, H, W, C, 0.f, dx, C, s));
     const float s_eff = d_ctx ? split : 0.f;
     VAG_TRY(vag_meanpool_bwd_launch(mask, dx, 1.f - s_eff, B, Ts, C, d_enc, accumulate_enc, s));
-    if (d_ctx) VAG_TRY(vag_axpy_launch(split, dx, d_ctx, B * C, accumulate_ctx ? 1 : 0, s));
+    if (d_ctx && !ride) VAG_TRY(vag_axpy_launch(split, dx, d_ctx, B * C, accumulate_ctx ? 1 : 0, s));
     return VAG_OK;
 }
 extern "C" {

@@ -319,11 +319,10 @@ int vag_attn_ctx_gru_launch(const float* scores, const float* encwp, int64_t N, 
 // grid (ceil(W/256), B, ceil(T/8)) / (ceil(W/256), B, ceil(Ts/8)); thread owns one float4 column, 8 outputs in registers.
 // Round 3: 256-thread blocks, wave w takes every 4th position of the summed dimension and the four partial sums meet in LDS (one
 // wave per block walked all Ts / T positions on its own: ~5 waves per CU, a serial chain of 40 loads: 17-20 us each).
-__global__ __launch_bounds__(256) void attn_wsum_time_kernel(const float* __restrict__ a, const float* __restrict__ x, int B,
-                                                             int Ts, int T, int W, float* __restrict__ out) {
-    __shared__ float4 part[3][8][64];
+__device__ __forceinline__ void attn_wsum_time_body(float4 (&part)[3][8][64], int bz, const float* __restrict__ a,
+                                                    const float* __restrict__ x, int B, int Ts, int T, int W, float* __restrict__ out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.y, t0 = blockIdx.z * 8;
+    const int b = blockIdx.y, t0 = bz * 8;
     const int c = (blockIdx.x * 64 + lane) * 4;
     const bool cok = c < W;
     float4 acc[8];
@@ -359,11 +358,15 @@ __global__ __launch_bounds__(256) void attn_wsum_time_kernel(const float* __rest
         }
     }
 }
-__global__ __launch_bounds__(256) void attn_wsum_src_kernel(const float* __restrict__ a, const float* __restrict__ y, int B,
-                                                            int Ts, int T, int W, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void attn_wsum_time_kernel(const float* __restrict__ a, const float* __restrict__ x, int B,
+                                                             int Ts, int T, int W, float* __restrict__ out) {
     __shared__ float4 part[3][8][64];
+    attn_wsum_time_body(part, blockIdx.z, a, x, B, Ts, T, W, out);
+}
+__device__ __forceinline__ void attn_wsum_src_body(float4 (&part)[3][8][64], int bz, const float* __restrict__ a,
+                                                   const float* __restrict__ y, int B, int Ts, int T, int W, float* __restrict__ out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.y, s0 = blockIdx.z * 8;
+    const int b = blockIdx.y, s0 = bz * 8;
     const int c = (blockIdx.x * 64 + lane) * 4;
     const bool cok = c < W;
     float4 acc[8];
@@ -398,6 +401,31 @@ __global__ __launch_bounds__(256) void attn_wsum_src_kernel(const float* __restr
         }
     }
 }
+__global__ __launch_bounds__(256) void attn_wsum_src_kernel(const float* __restrict__ a, const float* __restrict__ y, int B,
+                                                            int Ts, int T, int W, float* __restrict__ out) {
+    __shared__ float4 part[3][8][64];
+    attn_wsum_src_body(part, blockIdx.z, a, y, B, Ts, T, W, out);
+}
+// Both sums over one weight tensor a (T,B,Ts) in one grid: blocks z < ceil(Ts/8): out_src (B,Ts,Wy) = sum_t a y;  the rest:
+// out_time (T,B,Wx) = sum_s a x  (the decoder's backward needs one of each and they share nothing but a)
+__global__ __launch_bounds__(256) void attn_wsum_pair_kernel(const float* __restrict__ a, const float* __restrict__ y, int Wy,
+                                                             float* __restrict__ out_src, const float* __restrict__ x, int Wx,
+                                                             float* __restrict__ out_time, int B, int Ts, int T, int nz_src) {
+    __shared__ float4 part[3][8][64];
+    if ((int)blockIdx.z < nz_src) attn_wsum_src_body(part, blockIdx.z, a, y, B, Ts, T, Wy, out_src);
+    else attn_wsum_time_body(part, blockIdx.z - nz_src, a, x, B, Ts, T, Wx, out_time);
+}
+int vag_attn_wsum_pair_launch(const float* a, const float* y, int64_t Wy, float* out_src, const float* x, int64_t Wx, float* out_time,
+                              int64_t B, int64_t Ts, int64_t T, hipStream_t s) {
+    VAG_CHECK_ARG(a && y && x && out_src && out_time && B > 0 && Ts > 0 && T > 0 && Wy > 0 && Wx > 0 && Wy % 4 == 0 && Wx % 4 == 0 &&
+                  aligned16(x) && aligned16(y) && aligned16(out_src) && aligned16(out_time));
+    const int64_t W = Wy > Wx ? Wy : Wx;
+    const int nz_src = (int)cdiv64(Ts, 8);
+    hipLaunchKernelGGL(attn_wsum_pair_kernel, dim3((unsigned)cdiv64(W, 256), (unsigned)B, (unsigned)(nz_src + cdiv64(T, 8))), dim3(256), 0, s,
+                       a, y, (int)Wy, out_src, x, (int)Wx, out_time, (int)B, (int)Ts, (int)T, nz_src);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
 int vag_attn_wsum_launch(int over_src, const float* a, const float* x, int64_t B, int64_t Ts, int64_t T, int64_t W, float* out,
                          hipStream_t s) {
     VAG_CHECK_ARG(a && x && out && B > 0 && Ts > 0 && T > 0 && W > 0 && W % 4 == 0 && aligned16(x) && aligned16(out));
@@ -426,6 +454,116 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
 int vag_softmax_bwd_launch(const float* alpha, const float* dalpha, int64_t N, int64_t Ts, float* dscore, hipStream_t s) {
     VAG_CHECK_ARG(alpha && dalpha && dscore && N > 0 && Ts > 0);
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)cdiv64(N, 4)), dim3(256), 0, s, alpha, dalpha, N, (int)Ts, dscore);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+// ------------------------------------------------------------------ one row of a dot-product attention in ONE launch
+// (visual grounding, VSE_Imagine_Enc.py:57-64,46,137 and its backward: once per batch, B rows -- the three launches it replaces
+// were ~5 us each whatever they did).  One 1024-thread workgroup per row b:
+//   forward  (BWD = false): e[t] = x[b,t,:] . q[b,:], -inf where mask == 0;  wt = softmax(e) -> wout;  sum[b,:] = sum_t wt[t] x[b,t,:]
+//   backward (BWD = true):  d[t] = x[b,t,:] . q[b,:];  wt[t] = alpha[t] (d[t] - sum alpha d) -> wout;  sum[b,:] likewise (or none: sum NULL)
+// Phase 1: wave w takes positions w, w + 16, ...; phase 3: thread = (column quad, position group), groups meet in LDS.
+constexpr int ROW_THREADS = 1024;
+template <bool BWD>
+__global__ __launch_bounds__(ROW_THREADS) void attn_dot_row_kernel(const float* __restrict__ x, const float* __restrict__ q, int64_t ldq,
+                                                                    const float* __restrict__ mask, const float* __restrict__ alpha,
+                                                                    int Ts, int C, float* __restrict__ wout, float* __restrict__ sum) {
+    extern __shared__ __attribute__((aligned(16))) float rw[];       // Ts_pad weights, then the position groups' partial sums
+    const int Tp = (Ts + 3) & ~3;
+    float4* part = reinterpret_cast<float4*>(rw + Tp);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b = blockIdx.x;
+    const float* xb = x + b * Ts * (int64_t)C;
+    const float* qr = q + b * ldq;
+    for (int t = wave; t < Ts; t += ROW_THREADS / 64) {
+        const float* xr = xb + (int64_t)t * C;
+        float acc = 0.f;
+        for (int c = lane * 4; c < C; c += 256) {
+            const float4 a = *reinterpret_cast<const float4*>(xr + c), v = *reinterpret_cast<const float4*>(qr + c);
+            acc += a.x * v.x + a.y * v.y + a.z * v.z + a.w * v.w;
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) rw[t] = (!BWD && mask && mask[b * Ts + t] == 0.f) ? -INFINITY : acc;
+    }
+    __syncthreads();
+    {   // the Ts-element reduction, by every wave for itself (it is tiny)
+        if (!BWD) {
+            float mx = -INFINITY;
+            for (int t = lane; t < Ts; t += 64) mx = fmaxf(mx, rw[t]);
+            mx = wave_max(mx);
+            float sm = 0.f;
+            for (int t = lane; t < Ts; t += 64) sm += __expf(rw[t] - mx);
+            sm = wave_sum(sm);
+            const float inv = 1.f / sm;
+            __syncthreads();
+            for (int t = threadIdx.x; t < Ts; t += ROW_THREADS) {
+                const float a = __expf(rw[t] - mx) * inv;
+                rw[t] = a;
+                wout[b * Ts + t] = a;
+            }
+        } else {
+            float dot = 0.f;
+            for (int t = lane; t < Ts; t += 64) dot += alpha[b * Ts + t] * rw[t];
+            dot = wave_sum(dot);
+            __syncthreads();
+            for (int t = threadIdx.x; t < Ts; t += ROW_THREADS) {
+                const float a = alpha[b * Ts + t] * (rw[t] - dot);
+                rw[t] = a;
+                wout[b * Ts + t] = a;
+            }
+        }
+    }
+    __syncthreads();
+    if (!sum) return;
+    const int nc4 = C >> 2;
+    const int G = nc4 >= ROW_THREADS ? 1 : ROW_THREADS / nc4;          // position groups
+    if (G == 1) {
+        for (int c4 = threadIdx.x; c4 < nc4; c4 += ROW_THREADS) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = 0; t < Ts; ++t) {
+                const float a = rw[t];
+                const float4 e = *reinterpret_cast<const float4*>(xb + (int64_t)t * C + 4 * c4);
+                acc.x += a * e.x; acc.y += a * e.y; acc.z += a * e.z; acc.w += a * e.w;
+            }
+            *reinterpret_cast<float4*>(sum + b * C + 4 * c4) = acc;
+        }
+        return;
+    }
+    const int grp = threadIdx.x / nc4, c4 = threadIdx.x - grp * nc4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (grp < G) {
+        constexpr int U = 5;
+        const float* e = xb + 4 * c4;
+        for (int t0 = grp; t0 < Ts; t0 += U * G) {
+            float4 ev[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i) ev[i] = *reinterpret_cast<const float4*>(e + (int64_t)min(t0 + i * G, Ts - 1) * C);
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const int t = t0 + i * G;
+                const float a = t < Ts ? rw[t] : 0.f;
+                acc.x += a * ev[i].x; acc.y += a * ev[i].y; acc.z += a * ev[i].z; acc.w += a * ev[i].w;
+            }
+        }
+        part[grp * nc4 + c4] = acc;
+    }
+    __syncthreads();
+    if (grp == 0) {
+        for (int g = 1; g < G; ++g) {
+            const float4 o = part[g * nc4 + c4];
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+        *reinterpret_cast<float4*>(sum + b * C + 4 * c4) = acc;
+    }
+}
+// forward: wout = alpha (B,Ts), sum = context (B,C).  backward: alpha given, wout = d(scores) (B,Ts), sum = sum_t wout x or NULL.
+int vag_attn_dot_row_launch(bool bwd, const float* x, const float* q, int64_t ldq, const float* mask, const float* alpha, int64_t B,
+                            int64_t Ts, int64_t C, float* wout, float* sum, hipStream_t s) {
+    VAG_CHECK_ARG(x && q && wout && B > 0 && Ts > 0 && Ts <= 4096 && C > 0 && C % 4 == 0 && ldq % 4 == 0 && ldq >= C && (!bwd || alpha));
+    const size_t lds = (size_t)((Ts + 3) & ~3) * sizeof(float) + (size_t)ROW_THREADS * 16;
+    if (bwd) hipLaunchKernelGGL(attn_dot_row_kernel<true>, dim3((unsigned)B), dim3(ROW_THREADS), lds, s, x, q, ldq, mask, alpha, (int)Ts, (int)C, wout, sum);
+    else hipLaunchKernelGGL(attn_dot_row_kernel<false>, dim3((unsigned)B), dim3(ROW_THREADS), lds, s, x, q, ldq, mask, alpha, (int)Ts, (int)C, wout, sum);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
@@ -638,9 +776,76 @@ __global__ __launch_bounds__(256) void outer2_kernel(const float* __restrict__ a
         *reinterpret_cast<float4*>(o) = v;
     }
 }
+// Held-back accumulations into one (B,Ts,C) tensor (vag_train_step: d_enc of the visual-grounding / initial-state backward).  Between
+// vag_rmw_defer_begin(out) and vag_rmw_defer_flush() an accumulating vag_outer2_launch / vag_meanpool_bwd_launch into `out` is only
+// recorded; the flush makes ONE pass over the tensor for both (they were two read-modify-write passes of 21 MB each).  Calling thread.
+struct RmwDefer {
+    float* out = nullptr;
+    const float *a1 = nullptr, *x1 = nullptr, *a2 = nullptr, *x2 = nullptr;      // outer2's operands
+    const float *mask = nullptr, *dx = nullptr; float coef = 0.f;                // meanpool_bwd's
+    int64_t B = 0, Ts = 0, C = 0;
+};
+static thread_local RmwDefer g_rmw;
+void vag_rmw_defer_begin(float* out) { g_rmw = RmwDefer(); g_rmw.out = out; }
+void vag_rmw_defer_abort() { g_rmw = RmwDefer(); }
+static bool rmw_shape(int64_t B, int64_t Ts, int64_t C) {
+    if (g_rmw.B == 0) { g_rmw.B = B; g_rmw.Ts = Ts; g_rmw.C = C; return true; }
+    return g_rmw.B == B && g_rmw.Ts == Ts && g_rmw.C == C;
+}
+bool vag_rmw_defer_meanpool(const float* mask, const float* dx, float coef, int64_t B, int64_t Ts, int64_t C, float* out, int accumulate) {
+    if (!g_rmw.out || out != g_rmw.out || !accumulate || g_rmw.dx || C % 4 != 0 || !rmw_shape(B, Ts, C)) return false;
+    g_rmw.mask = mask; g_rmw.dx = dx; g_rmw.coef = coef;
+    return true;
+}
+// out[b,t,c] += a1[b,t] x1[b,c] + a2[b,t] x2[b,c] + coef dx[b,c] / #(mask[b,:])   (any of the three terms may be absent)
+__global__ __launch_bounds__(256) void outer3_kernel(RmwDefer d) {
+    const int b = blockIdx.y, Ts = (int)d.Ts, C = (int)d.C;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= C) return;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 u = d.a1 ? *reinterpret_cast<const float4*>(d.x1 + (int64_t)b * C + c) : z;
+    const float4 w = d.a2 ? *reinterpret_cast<const float4*>(d.x2 + (int64_t)b * C + c) : z;
+    float4 m = z;
+    if (d.dx) {
+        float cnt = 0.f;
+        for (int t = 0; t < Ts; ++t) cnt += d.mask[(int64_t)b * Ts + t];
+        const float4 x = *reinterpret_cast<const float4*>(d.dx + (int64_t)b * C + c);
+        m = make_float4(d.coef * x.x / cnt, d.coef * x.y / cnt, d.coef * x.z / cnt, d.coef * x.w / cnt);
+    }
+    const int t0 = blockIdx.z * 4, t_end = min(Ts, t0 + 4);
+    float4 old[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (t0 + i < t_end) old[i] = *reinterpret_cast<const float4*>(d.out + ((int64_t)b * Ts + t0 + i) * C + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (t0 + i < t_end) {
+            const int t = t0 + i;
+            const float p = d.a1 ? d.a1[(int64_t)b * Ts + t] : 0.f;
+            const float r = d.a2 ? d.a2[(int64_t)b * Ts + t] : 0.f;
+            float4 v = old[i];
+            // (the order the two separate passes added in: the mean-pool term first, then the outer products)
+            v.x += m.x; v.y += m.y; v.z += m.z; v.w += m.w;
+            v.x += p * u.x + r * w.x; v.y += p * u.y + r * w.y; v.z += p * u.z + r * w.z; v.w += p * u.w + r * w.w;
+            *reinterpret_cast<float4*>(d.out + ((int64_t)b * Ts + t) * C + c) = v;
+        }
+}
+int vag_rmw_defer_flush(hipStream_t s) {
+    RmwDefer d = g_rmw;
+    g_rmw = RmwDefer();
+    if (!d.out || (!d.a1 && !d.dx)) return VAG_OK;
+    dim3 grid((unsigned)cdiv64(d.C, 1024), (unsigned)d.B, (unsigned)cdiv64(d.Ts, 4));
+    hipLaunchKernelGGL(outer3_kernel, grid, dim3(256), 0, s, d);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
 int vag_outer2_launch(const float* a1, const float* x1, const float* a2, const float* x2, int64_t B, int64_t Ts,
                       int64_t C, float* out, int accumulate, hipStream_t s) {
     VAG_CHECK_ARG(a1 && x1 && out && B > 0 && Ts > 0 && C > 0 && C % 4 == 0);
+    if (g_rmw.out && out == g_rmw.out && accumulate && !g_rmw.a1 && rmw_shape(B, Ts, C)) {
+        g_rmw.a1 = a1; g_rmw.x1 = x1; g_rmw.a2 = a2; g_rmw.x2 = a2 ? x2 : nullptr;
+        return VAG_OK;
+    }
     dim3 grid((unsigned)cdiv64(C, 1024), (unsigned)B, (unsigned)cdiv64(Ts, 4));
     hipLaunchKernelGGL(outer2_kernel, grid, dim3(256), 0, s, a1, x1, a2, x2, (int)Ts, (int)C, out, accumulate);
     VAG_LAUNCH_CHECK();

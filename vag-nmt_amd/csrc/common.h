@@ -123,6 +123,7 @@ struct VagOptions {
                                  // ONE bf16 plane (0: two bf16 planes everywhere, as the operators on their own use)
     int head_bf16_dlogits = 1;   // 2-byte storage mode, chunked head: d(logits) of a chunk is written and read as bf16 (0: fp32 in place)
     int leaf_queue = 1;          // 0: the small weight-gradient products of the VSE / initial-state backward go out one by one (round 4)
+    int attn_row = 1;            // 0: the visual-grounding attention as separate scores / softmax / context launches (rounds 1-4)
     int step_fork = 0;           // side-stream branches inside vag_train_step, bit 0: the image projection beside the encoder, bit 1: the
                                  // held-back weight-gradient leaves beside the encoder's backward.  Off: measured SLOWER
     int64_t persist_spin_limit = 0;   // > 0: polls before a persistent kernel's wait gives up (default 2^19); tests force a give-up with 1
@@ -144,6 +145,7 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
                     int a_bf16 = 0);              // A stored as bf16 (one-plane bf16 kernel, ungrouped): the 2-byte mode's d(logits)
 // out[m,n] = act(sum_k A[m,k] W[n,k] + bias[n] + addend[m,n]);  M small (decode/recurrent steps).
 void vag_gemm_set_planes(int planes);
+void vag_gemm_prezeroed_set(int slot, const float* p);      // gemm.hip: an output the caller has zeroed (a sliced overwrite skips its fill), used once
 int vag_gemm_launch_planes(int planes, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
                            const float* B, int64_t sbk, int64_t sbn, float beta, float* C, int64_t ldc, hipStream_t stream,
                            int a_bf16 = 0);      // planes 3: bf16x6 (default), 2: bf16x3 (2-byte storage mode), calling thread

@@ -260,6 +260,7 @@ __global__ __launch_bounds__(256) void meanpool_bwd_kernel(const float* __restri
 int vag_meanpool_bwd_launch(const float* mask, const float* dx, float coef, int64_t B, int64_t Ts, int64_t C,
                             float* d_enc, int accumulate, hipStream_t s) {
     VAG_CHECK_ARG(mask && dx && d_enc && B > 0 && Ts > 0 && C > 0);
+    if (vag_rmw_defer_meanpool(mask, dx, coef, B, Ts, C, d_enc, accumulate)) return VAG_OK;      // attn.hip: held back for one merged pass
     dim3 grid((unsigned)cdiv64(C, 256), (unsigned)B, (unsigned)cdiv64(Ts, 4));
     hipLaunchKernelGGL(meanpool_bwd_kernel, grid, dim3(256), 0, s, mask, dx, coef, (int)Ts, (int)C, d_enc, accumulate);
     VAG_LAUNCH_CHECK();

@@ -566,6 +566,7 @@ static thread_local int g_qn[4] = {0, 0, 0, 0};
 static thread_local GemmArgs g_q[4][GROUP_MAX];
 static int vag_gemm_launch_now(const GemmArgs& q, hipStream_t stream);
 void vag_colsum_queue_begin();
+static bool gemm_take_prezeroed(const float* C);
 int vag_colsum_queue_flush(hipStream_t stream);
 void vag_colsum_queue_abort();
 void vag_gemm_group_begin() {
@@ -714,7 +715,7 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
         // accumulating products always add atomically here (two of them may target the same gradient buffer);
         // splitk > 1 is what selects the atomic epilogue, the block count below uses the real number of k-slices
         a.splitk = a.beta != 0.f ? (s_i > 2 ? s_i : 2) : s_i;
-        if (a.beta == 0.f && s_i > 1) {          // sliced overwrite: the slices add into a zeroed output
+        if (a.beta == 0.f && s_i > 1 && !gemm_take_prezeroed(a.C)) {          // sliced overwrite: the slices add into a zeroed output
             int64_t nb = cdiv64((int64_t)a.M * a.N, 256 * 8);
             if (nb > 2048) nb = 2048;
             hipLaunchKernelGGL(fill2d_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a.C, a.ldc, (int64_t)a.M, (int64_t)a.N);
@@ -771,6 +772,15 @@ int vag_gemm_group_end(hipStream_t stream) {
 // at the flush; their operands must stay untouched until then (the step driver's do: api.hip).
 static thread_local bool g_leaf_on = false;
 static thread_local LeafTasks g_leaf;
+// Outputs a caller has already zeroed (vag_train_step's prologue launch): a sliced (split-K) overwriting product into one of them
+// skips its own fill launch.  An entry is used once.  Calling thread.
+static thread_local const float* g_gemm_prezeroed[4] = {nullptr, nullptr, nullptr, nullptr};
+void vag_gemm_prezeroed_set(int slot, const float* p) { if (slot >= 0 && slot < 4) g_gemm_prezeroed[slot] = p; }
+static bool gemm_take_prezeroed(const float* C) {
+    for (auto& q : g_gemm_prezeroed)
+        if (q && q == C) { q = nullptr; return true; }
+    return false;
+}
 void vag_leaf_begin() { g_leaf_on = vag_opt().leaf_queue != 0; g_leaf.n = 0; g_leaf.tile0[0] = 0; }
 void vag_leaf_abort() { g_leaf_on = false; g_leaf.n = 0; }
 bool vag_leaf_attach_rowsum(const float* X, int64_t rows, int64_t N, int64_t ld, float* out) {
@@ -891,7 +901,7 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
         int kc = (int)(cdiv64(cdiv64(K, sp), BK) * BK);
         sp = cdiv64(K, kc);
         g.splitk = (int)sp; g.kchunk = kc;
-        if (sp > 1 && beta == 0.f) {
+        if (sp > 1 && beta == 0.f && !gemm_take_prezeroed(C)) {
             int64_t nb = cdiv64(M * N, 256 * 8);
             if (nb > 2048) nb = 2048;
             hipLaunchKernelGGL(fill2d_kernel, dim3((unsigned)nb), dim3(256), 0, stream, C, ldc, M, N);
@@ -920,7 +930,7 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     int kchunk = (int)(cdiv64(cdiv64(K, splitk), BK) * BK);
     splitk = cdiv64(K, kchunk);
     g.splitk = (int)splitk; g.kchunk = kchunk;
-    if (splitk > 1 && beta == 0.f) {
+    if (splitk > 1 && beta == 0.f && !gemm_take_prezeroed(C)) {
         int64_t nb = cdiv64(M * N, 256 * 8);
         if (nb > 2048) nb = 2048;
         hipLaunchKernelGGL(fill2d_kernel, dim3((unsigned)nb), dim3(256), 0, stream, C, ldc, M, N);
@@ -968,6 +978,7 @@ struct SkinnyArgs {
     // the gathered rows out (the embedded inputs are needed again by the head and by the backward pass)
     const int64_t* row_idx = nullptr; float* gather_out = nullptr; int64_t ld_gather = 0;
     float a_scale = 1.f;                   // fp16-weight products only: power of two applied to A before its fp16 rounding (gradients)
+    float* out2 = nullptr; int64_t ldo2 = 0; float scale2 = 0.f; int acc2 = 0;      // skinny_bt_kernel: out2 (+)= scale2 * result as well
 };
 
 // Load pattern.  The MFMA wants lane l to hold row l&15, k-group l>>4, but a wave request whose lane QUADS each touch
@@ -1569,6 +1580,10 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_bt_kernel(SkinnyArgs a) {
     if (a.bias) v += a.bias[ej];
     if (a.addend) v += a.addend[(int64_t)em * a.ldadd + ej];
     a.out[(int64_t)em * a.ldo + ej] = v;
+    if (a.out2) {
+        float* o2 = a.out2 + (int64_t)em * a.ldo2 + ej;
+        *o2 = (a.acc2 ? *o2 : 0.f) + a.scale2 * v;
+    }
 }
 
 // Fused GRU cell: 16 rows x 16 hidden units x 3 gates per workgroup.  The 256 (row, unit) outputs are finished by the
@@ -2076,14 +2091,32 @@ int vag_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
     return VAG_OK;
 }
 
+// A second destination for the NEXT vag_skinny_nn_launch of the calling thread: out2 (M,N) (+)= scale * (A B) -- an axpy launch saved
+// (the initial state's backward: d_ctx += split * dx beside dx itself).  Consumed by that launch whatever path it takes.
+struct SkinnyOut2 { float* out2 = nullptr; int64_t ld = 0; float scale = 0.f; int acc = 0; };
+static thread_local SkinnyOut2 g_sk_out2;
+void vag_skinny_nn_out2(float* out2, int64_t ld, float scale, int accumulate) { g_sk_out2 = SkinnyOut2{out2, ld, scale, accumulate}; }
+int vag_axpy_launch(float a, const float* x, float* y, int64_t n, int accumulate, hipStream_t s);      // elem.hip
+static int vag_axpy2d_launch(float a, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t cols, int accumulate, hipStream_t s) {
+    if (ldx == cols && ldy == cols) return vag_axpy_launch(a, x, y, rows * cols, accumulate, s);
+    for (int64_t r = 0; r < rows; ++r) VAG_TRY(vag_axpy_launch(a, x + r * ldx, y + r * ldy, cols, accumulate, s));     // (not a shape of this library)
+    return VAG_OK;
+}
+
 // C (M,N) = beta C + A (M,K) B (K,N), B row-major with row stride ldb; M <= 128 (skinny path), else the tiled kernels.
 int vag_skinny_nn_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                          float beta, float* C, int64_t ldc, hipStream_t stream) {
     VAG_CHECK_ARG(M >= 0 && N >= 0 && K > 0 && A && B && C && (beta == 0.f || beta == 1.f));
+    const SkinnyOut2 o2 = g_sk_out2;
+    g_sk_out2 = SkinnyOut2();
     if (M == 0 || N == 0) return VAG_OK;
-    if (M > 128 || !aligned16(A) || lda % 4 != 0 || K % 4 != 0 || (double)M * (double)N * (double)K > 350e6)
-        return vag_gemm_launch(M, N, K, 1.f, A, lda, 1, B, ldb, 1, beta, C, ldc, nullptr, VAG_ACT_NONE, stream);
+    if (M > 128 || !aligned16(A) || lda % 4 != 0 || K % 4 != 0 || (double)M * (double)N * (double)K > 350e6) {
+        VAG_TRY(vag_gemm_launch(M, N, K, 1.f, A, lda, 1, B, ldb, 1, beta, C, ldc, nullptr, VAG_ACT_NONE, stream));
+        if (o2.out2) return vag_axpy2d_launch(o2.scale, C, ldc, o2.out2, o2.ld, M, N, o2.acc, stream);
+        return VAG_OK;
+    }
     SkinnyArgs a;
+    a.out2 = o2.out2; a.ldo2 = o2.ld; a.scale2 = o2.scale; a.acc2 = o2.acc;
     a.A = A; a.W = B; a.lda = lda; a.ldw = ldb; a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.bias = nullptr; a.addend = beta != 0.f ? C : nullptr; a.ldadd = ldc; a.out = C; a.ldo = ldc; a.act = VAG_ACT_NONE;
     dim3 grid((unsigned)cdiv64(N, 16), (unsigned)cdiv64(M, 16), 1);

@@ -180,6 +180,19 @@ int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const flo
                                   float* dqgh, float* ds, float* dgi1, float* dgh1, float* d_h0, float* dal, unsigned* sync,
                                   int64_t B, int64_t Ts, int64_t Tt, int64_t H, hipStream_t s);
 float* vag_cgru_bwd_scratch_de(float* scratch, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H);
+float* vag_cgru_bwd_scratch_du(float* scratch, int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H);
+int vag_attn_dot_row_launch(bool bwd, const float* x, const float* q, int64_t ldq, const float* mask, const float* alpha, int64_t B,
+                            int64_t Ts, int64_t C, float* wout, float* sum, hipStream_t s);      // attn.hip: one launch per dot attention
+void vag_skinny_nn_out2(float* out2, int64_t ld, float scale, int accumulate);      // gemm.hip: a second destination for the next vag_skinny_nn_launch
+int vag_rank_bwd_launch(const float* G, const float* im, const float* sv, const float* d_loss, int64_t B, int64_t S, float* d_im,
+                        float* d_s, hipStream_t s);       // vse.hip: d_im = G s and d_s = G^T im (x *d_loss) in one launch, B <= 512
+int vag_attn_wsum_pair_launch(const float* a, const float* y, int64_t Wy, float* out_src, const float* x, int64_t Wx, float* out_time,
+                              int64_t B, int64_t Ts, int64_t T, hipStream_t s);        // attn.hip: sum over t of a y and sum over s of a x, one grid
+void vag_rmw_defer_begin(float* out);      // attn.hip: hold back accumulating outer2 / meanpool_bwd launches into `out` ...
+int vag_rmw_defer_flush(hipStream_t s);    // ... and do them in one pass
+void vag_rmw_defer_abort();
+bool vag_rmw_defer_meanpool(const float* mask, const float* dx, float coef, int64_t B, int64_t Ts, int64_t C, float* out, int accumulate);
+void vag_step_set_gathered(bool v);        // api.hip: the step's prologue embedded the decoder's input tokens (e_all)
 void vag_step_set_zeroed(bool v);          // api.hip: the step's prologue zeroed tmid and the encoder's dx
 void vag_step_zero_ranges(float* ws_enc, float* ws_dec, int64_t B, int64_t Ts, int64_t Tt, int64_t Es, int64_t Et, int64_t H,
                           unsigned** p, int64_t* n);                 // api.hip

@@ -64,16 +64,29 @@ bool cfg_ok(const vag_step_cfg* c) {
 // vag_step_zero_ranges): one launch instead of four.
 // further ranges the prologue zeroes, in 16-byte units: the decoder's hidden states h2 (exchanged between workgroups with marked
 // words, persist.hip: tag1), the head's tmid and the encoder's d(embedded inputs) (grouped products accumulate into them)
-struct ZeroRanges { uint4* p[3]; int64_t n[3]; };
+// ... and two outputs of sliced overwriting products of the backward pass (d(tmid), dgi2 W_ih2), which then skip their fill launches
+struct ZeroRanges { uint4* p[5]; int64_t n[5]; };
+// the decoder's embedded input tokens of every step (teacher-forced: V11.py:117,146 -> NMT_Decoder.py:118), from the target matrix itself
+struct GatherTask { const float* emb; float* out; int E4; };
 __global__ __launch_bounds__(256) void step_prologue_kernel(uint64_t* rng, const int64_t* __restrict__ tgt, int B, int Tt,
                                                             int64_t* __restrict__ tok, float* __restrict__ consts,
                                                             float* __restrict__ inv_cnt, float w_mt, float w_vse,
                                                             unsigned* __restrict__ z0, int64_t n0, unsigned* __restrict__ z1,
-                                                            int64_t n1, ZeroRanges zr) {
+                                                            int64_t n1, ZeroRanges zr, GatherTask ga) {
     const int64_t gid = blockIdx.x * 256ll + threadIdx.x;
     for (int64_t i = gid; i < n0; i += (int64_t)gridDim.x * 256) z0[i] = 0u;
+    if (ga.out) {
+        const int64_t rows = (int64_t)Tt * B, tot = rows * ga.E4;
+        for (int64_t i = gid; i < tot; i += (int64_t)gridDim.x * 256) {
+            const int64_t row = i / ga.E4;
+            const int e4 = (int)(i - row * ga.E4);
+            const int t = (int)(row / B), b = (int)(row - (int64_t)t * B);
+            const int64_t tk = t == 0 ? 2 : tgt[(int64_t)b * Tt + (t - 1)];
+            reinterpret_cast<float4*>(ga.out)[i] = reinterpret_cast<const float4*>(ga.emb)[tk * ga.E4 + e4];
+        }
+    }
 #pragma unroll
-    for (int r = 0; r < 3; ++r)                                                                           // (16-byte units)
+    for (int r = 0; r < 5; ++r)                                                                           // (16-byte units)
         for (int64_t i = gid; i < zr.n[r]; i += (int64_t)gridDim.x * 256) zr.p[r][i] = make_uint4(0u, 0u, 0u, 0u);
     {   // the large range: 16 bytes per thread (the range starts 256-byte aligned; its tail word by word)
         const int64_t n4 = n1 >> 2;
@@ -103,7 +116,10 @@ struct LossRingScope {
 };
 struct PrezeroScope {       // the recurrence kernels of this call find their counters zeroed by the step's prologue launch,
     PrezeroScope() { vag_persist_set_prezeroed(true); vag_step_set_zeroed(true); }       // the head and the encoder's backward
-    ~PrezeroScope() { vag_persist_set_prezeroed(false); vag_step_set_zeroed(false); }    // their accumulation buffers
+    ~PrezeroScope() {                                                                    // their accumulation buffers
+        vag_persist_set_prezeroed(false); vag_step_set_zeroed(false); vag_step_set_gathered(false);
+        vag_gemm_prezeroed_set(0, nullptr); vag_gemm_prezeroed_set(1, nullptr);
+    }
 };
 struct DerivedScope {       // points the operators at the driver's derived weights, storage mode and head chunk for one call
     const float* prev_d;    // ... and puts back what the caller had set with vag_set_operator_context ("until changed")
@@ -273,9 +289,14 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
             zr.p[0] = reinterpret_cast<uint4*>(h2_all); zr.n[0] = Tt * B * H / 4;
             zr.p[1] = reinterpret_cast<uint4*>(k.tmid); zr.n[1] = Tt * B * Et / 4;
             zr.p[2] = reinterpret_cast<uint4*>(zp[2]); zr.n[2] = zn[2] / 4;
+            zr.p[3] = reinterpret_cast<uint4*>(k.scr_head); zr.n[3] = chunk > 0 ? 0 : Tt * B * Et / 4;
+            zr.p[4] = reinterpret_cast<uint4*>(vag_cgru_bwd_scratch_du(k.scr_dec, B, Ts, Tt, Et, H)); zr.n[4] = Tt * B * H / 4;
+            GatherTask ga = {nullptr, nullptr, 0};
+            if (!c.free_run) { ga.emb = w.dec.emb; ga.out = k.e_all; ga.E4 = (int)(Et / 4); }
             hipLaunchKernelGGL(step_prologue_kernel, dim3((unsigned)nb), dim3(256), 0, s, rng, tgt, (int)B, (int)Tt, k.tok,
-                               k.consts, k.inv_cnt, w_mt, w_vse, zp[0], zn[0], zp[1], zn[1], zr);
+                               k.consts, k.inv_cnt, w_mt, w_vse, zp[0], zn[0], zp[1], zn[1], zr, ga);
             VAG_LAUNCH_CHECK();
+            if (ga.out) vag_step_set_gathered(true);
         }
         VAG_TRY(vag_bigru_seq_fwd(src, lengths, w.enc_emb, w.enc_fw, w.enc_bw, c.p_emb, c.p_ctx, crng, B, Ts, c.Es, H, k.enc,
                                   k.mask, k.ws_enc, stream));                                           // V11.py:111
@@ -316,6 +337,9 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     // phase 2 = its two halves 16 (head + decoder: final for the head's, the decoder's and attn_e's gradients) and 32 (visual grounding
     // + initial state: final for vse_imagine.* and decoderini.*): a data-parallel driver with three buckets calls them one by one
     if (phases & (2 | 16)) {
+        // zeroed by this step's prologue launch (a backward-only call: by the forward call of the same step)
+        if (chunk == 0) vag_gemm_prezeroed_set(0, k.scr_head);
+        vag_gemm_prezeroed_set(1, vag_cgru_bwd_scratch_du(k.scr_dec, B, Ts, Tt, Et, H));
         VAG_TRY(vag_head_ce_seq_bwd(h2_all, k.c_all, k.e_all, w.head, tgt, vocab_weight, B, Tt, Et, H, V, c.p_out, crng, k.tmid,
                                     k.logits, c.ldl, k.lse, k.inv_cnt, k.consts + 0, k.d_h2, k.d_c, d_e, g.head, k.scr_head,
                                     stream));
@@ -336,6 +360,8 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
         // the weight-gradient products of the VSE branch and of the initial state (rank-B updates nothing later in the step reads)
         // and their bias sums are held back and leave as ONE launch, on a side branch that joins before the optimiser
         struct LeafScope { bool on = true; LeafScope() { vag_leaf_begin(); } ~LeafScope() { if (on) vag_leaf_abort(); } } leaf;
+        // ... and the two accumulations into d_enc of this block (initial state: mean pool; visual attention: outer products) are one pass
+        struct RmwScope { RmwScope(float* p) { vag_rmw_defer_begin(p); } ~RmwScope() { vag_rmw_defer_abort(); } } rmw(k.d_enc);
         if (mm) {
             if (has_vse) {
                 VAG_TRY(vag_rank_loss_bwd_impl(k.im_emb, k.txt_emb, k.G, nullptr, B, S, k.d_im, k.d_txt, s));
@@ -355,6 +381,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
             VAG_TRY(vag_img_proj_l2_bwd(im, w.im_w, k.y_im, k.nrm_im, k.im_emb, k.d_im, B, c.I, S, c.activation_vse, nullptr,
                                         g.im_w, g.im_b, stream));
         }
+        VAG_TRY(vag_rmw_defer_flush(s));
         leaf.on = false;
         {
             // with the encoder's backward in the same call the leaves run beside its recurrence; a data-parallel driver's phase

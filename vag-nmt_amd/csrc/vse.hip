@@ -108,6 +108,46 @@ int vag_rank_loss_launch(const float* scores, int64_t B, float margin, int kind,
     return VAG_OK;
 }
 
+// Both gradients of the similarity matrix in one launch: d_im = G s (PairwiseRankingLoss.py:12: scores = im s^T), d_s = G^T im.
+// grid (ceil(S/64), ceil(B/16), 2); block = 64 columns x 4 row groups of 4 rows; the 16 x B slice of G (or G^T) sits in LDS.
+__global__ __launch_bounds__(256) void rank_bwd_kernel(const float* __restrict__ G, const float* __restrict__ im,
+                                                       const float* __restrict__ sv, const float* __restrict__ d_loss, int B, int S,
+                                                       float* __restrict__ d_im, float* __restrict__ d_s) {
+    extern __shared__ float gsh[];              // [16][B]
+    const bool tr = blockIdx.z == 1;            // d_s: rows of G^T
+    const float* x = tr ? im : sv;
+    float* out = tr ? d_s : d_im;
+    const int i0 = blockIdx.y * 16;
+    for (int e = threadIdx.x; e < 16 * B; e += 256) {
+        const int r = e / B, j = e - r * B, i = i0 + r;
+        gsh[e] = i < B ? (tr ? G[(int64_t)j * B + i] : G[(int64_t)i * B + j]) : 0.f;
+    }
+    __syncthreads();
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    if (c >= S) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* g = gsh + 4 * rg * B;
+    for (int j = 0; j < B; ++j) {
+        const float xv = x[(int64_t)j * S + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += g[r * B + j] * xv;
+    }
+    const float sc = d_loss ? d_loss[0] : 1.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 4 * rg + r;
+        if (i < B) out[(int64_t)i * S + c] = acc[r] * sc;
+    }
+}
+int vag_rank_bwd_launch(const float* G, const float* im, const float* sv, const float* d_loss, int64_t B, int64_t S, float* d_im,
+                        float* d_s, hipStream_t s) {
+    VAG_CHECK_ARG(G && im && sv && d_im && d_s && B > 0 && B <= 512 && S > 0);
+    dim3 grid((unsigned)cdiv64(S, 64), (unsigned)cdiv64(B, 16), 2);
+    hipLaunchKernelGGL(rank_bwd_kernel, grid, dim3(256), (size_t)(16 * B) * sizeof(float), s, G, im, sv, d_loss, (int)B, (int)S, d_im, d_s);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
 __global__ __launch_bounds__(256) void scale_by_dev_kernel(float* __restrict__ x, int64_t n, const float* __restrict__ sc) {
     const float a = sc[0];
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= a;
