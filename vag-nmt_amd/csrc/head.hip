@@ -161,10 +161,9 @@ int vag_inv_cnt_launch(const int64_t* tgt, int64_t B, int64_t Tt, float* inv_cnt
 // loss = (1/B) sum_b inv_cnt[b] sum_t nll[t,b]    (single block; fixed summation order -> deterministic).
 // Thread (g, b) = (tid / 64, tid % 64) walks t = g, g+4, ... of sentences b, b+64, ...; partial sums meet in LDS.
 // losses != NULL: also the weighted total of V11.py:166 (losses = {loss, loss_mt, loss_vse}).
-__global__ __launch_bounds__(256) void loss_mt_kernel(const float* __restrict__ nll, const float* __restrict__ inv_cnt,
-                                                      int B, int Tt, float* __restrict__ loss, float* __restrict__ losses,
-                                                      float w_mt, float w_vse, int has_vse, int ring) {
-    __shared__ float sh[4];
+__device__ __forceinline__ void loss_mt_body(float (&sh)[4], const float* __restrict__ nll, const float* __restrict__ inv_cnt,
+                                             int B, int Tt, float* __restrict__ loss, float* __restrict__ losses,
+                                             float w_mt, float w_vse, int has_vse, int ring) {
     const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float acc = 0.f;
     for (int b = lane; b < B; b += 64) {
@@ -190,6 +189,35 @@ __global__ __launch_bounds__(256) void loss_mt_kernel(const float* __restrict__ 
         }
     }
 }
+__global__ __launch_bounds__(256) void loss_mt_kernel(const float* __restrict__ nll, const float* __restrict__ inv_cnt,
+                                                      int B, int Tt, float* __restrict__ loss, float* __restrict__ losses,
+                                                      float w_mt, float w_vse, int has_vse, int ring) {
+    __shared__ float sh[4];
+    loss_mt_body(sh, nll, inv_cnt, B, Tt, loss, losses, w_mt, w_vse, has_vse, ring);
+}
+// The loss reduction as a passenger of the launch that follows it in a training step (ce_bwd_colsum_kernel, which needs none of its
+// results: d(loss) is a constant of the step): between vag_loss_defer_begin() and vag_loss_defer_flush() a vag_loss_mt_mix_launch is
+// held back and handed to the next vag_ce_bwd_colsum_launch, whose block (0,0) does it first; the flush launches it on its own if
+// no such launch came.  Calling thread.
+struct LossTask {
+    const float* nll = nullptr; const float* inv_cnt = nullptr; float* losses = nullptr;
+    int B = 0, Tt = 0, has_vse = 0, ring = 0;
+    float w_mt = 0.f, w_vse = 0.f;
+};
+static thread_local LossTask g_loss_task;
+static thread_local bool g_loss_defer = false;
+static thread_local hipStream_t g_loss_stream = nullptr;
+void vag_loss_defer_begin() { g_loss_defer = true; g_loss_task = LossTask(); }
+int vag_loss_defer_flush() {
+    g_loss_defer = false;
+    const LossTask t = g_loss_task;
+    g_loss_task = LossTask();
+    if (!t.nll) return VAG_OK;
+    hipLaunchKernelGGL(loss_mt_kernel, dim3(1), dim3(256), 0, g_loss_stream, t.nll, t.inv_cnt, t.B, t.Tt, (float*)nullptr, t.losses,
+                       t.w_mt, t.w_vse, t.has_vse, t.ring);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
 static thread_local int g_loss_ring = 0;        // vag_train_step sets it for its call (vag_step_cfg.loss_ring)
 void vag_set_loss_ring(int r) { g_loss_ring = r; }
 int vag_loss_mt_launch(const float* nll, const float* inv_cnt, int64_t B, int64_t Tt, float* loss, hipStream_t s) {
@@ -202,6 +230,13 @@ int vag_loss_mt_launch(const float* nll, const float* inv_cnt, int64_t B, int64_
 int vag_loss_mt_mix_launch(const float* nll, const float* inv_cnt, int64_t B, int64_t Tt, float* losses, float w_mt,
                            float w_vse, int has_vse, hipStream_t s) {
     VAG_CHECK_ARG(nll && inv_cnt && losses && B > 0 && Tt > 0);
+    if (g_loss_defer) {
+        LossTask& t = g_loss_task;
+        t.nll = nll; t.inv_cnt = inv_cnt; t.losses = losses; t.B = (int)B; t.Tt = (int)Tt; t.has_vse = has_vse; t.ring = g_loss_ring;
+        t.w_mt = w_mt; t.w_vse = w_vse;
+        g_loss_stream = s;
+        return VAG_OK;
+    }
     hipLaunchKernelGGL(loss_mt_kernel, dim3(1), dim3(256), 0, s, nll, inv_cnt, (int)B, (int)Tt, (float*)nullptr, losses, w_mt,
                        w_vse, has_vse, g_loss_ring);
     VAG_LAUNCH_CHECK();
@@ -249,7 +284,11 @@ __global__ __launch_bounds__(256) void ce_bwd_colsum_kernel(float* __restrict__ 
                                                             const float* __restrict__ vw, const float* __restrict__ lse,
                                                             const float* __restrict__ inv_cnt,
                                                             const float* __restrict__ d_loss, int rows, int rows_per,
-                                                            float* __restrict__ g_bias, unsigned short* __restrict__ out16) {
+                                                            float* __restrict__ g_bias, unsigned short* __restrict__ out16,
+                                                            LossTask lt) {
+    __shared__ float lsh[4];
+    if (lt.nll && blockIdx.x == 0 && blockIdx.y == 0)           // a held-back loss reduction (see LossTask)
+        loss_mt_body(lsh, lt.nll, lt.inv_cnt, lt.B, lt.Tt, nullptr, lt.losses, lt.w_mt, lt.w_vse, lt.has_vse, lt.ring);
     // out16 != NULL (2-byte storage mode, chunked head): d(logits) is written as bf16 into out16 (row stride ldl elements) and
     // the fp32 logits are left alone -- its two consumers round it to one bf16 plane anyway, and read half the bytes this way.
     // Round 4: a thread owns FOUR consecutive columns (16-byte loads, 16-byte fp32 / 8-byte bf16 stores; ldl % 4 == 0): with one
@@ -320,8 +359,10 @@ int vag_ce_bwd_colsum_launch(float* logits, int64_t ldl, int64_t rows, int64_t V
     if (splits > cdiv64(rows, 8)) splits = cdiv64(rows, 8);
     const int rows_per = (int)cdiv64(rows, splits);
     dim3 grid((unsigned)nbx, (unsigned)cdiv64(rows, rows_per));
+    LossTask lt;
+    if (g_loss_task.nll && g_loss_stream == s) { lt = g_loss_task; g_loss_task = LossTask(); }
     hipLaunchKernelGGL(ce_bwd_colsum_kernel, grid, dim3(256), 0, s, logits, ldl, (int)V, tgt, (int)B, (int)Tt, vw, lse,
-                       inv_cnt, d_loss, (int)rows, rows_per, g_bias, reinterpret_cast<unsigned short*>(out16));
+                       inv_cnt, d_loss, (int)rows, rows_per, g_bias, reinterpret_cast<unsigned short*>(out16), lt);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

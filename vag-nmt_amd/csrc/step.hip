@@ -119,6 +119,7 @@ struct PrezeroScope {       // the recurrence kernels of this call find their co
     ~PrezeroScope() {                                                                    // their accumulation buffers
         vag_persist_set_prezeroed(false); vag_step_set_zeroed(false); vag_step_set_gathered(false);
         vag_gemm_prezeroed_set(0, nullptr); vag_gemm_prezeroed_set(1, nullptr);
+        (void)vag_loss_defer_flush();       // (an error return between the head's forward and backward: the loss is still written)
     }
 };
 struct DerivedScope {       // points the operators at the driver's derived weights, storage mode and head chunk for one call
@@ -329,6 +330,8 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
                                                  c.ldl, stream));                                       // V11.py:138-160
             VAG_TRY(outer.end(s));
         }
+        // with the head's backward in the same call the loss reduction rides in that backward's first launch
+        if ((phases & (2 | 16)) && chunk == 0 && vag_opt().loss_ride != 0) vag_loss_defer_begin();
         VAG_TRY(vag_head_ce_seq_fwd_impl(h2_all, k.c_all, k.e_all, w.head, tgt, vocab_weight, B, Tt, Et, H, V, c.p_out, crng,
                                          c.free_run ? 1 : 0, k.tmid, k.logits, c.ldl, k.lse, k.nll, k.inv_cnt, 1, nullptr,
                                          losses, w_mt, w_vse, has_vse ? 1 : 0, s));                     // V11.py:140,164-166
@@ -343,6 +346,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
         VAG_TRY(vag_head_ce_seq_bwd(h2_all, k.c_all, k.e_all, w.head, tgt, vocab_weight, B, Tt, Et, H, V, c.p_out, crng, k.tmid,
                                     k.logits, c.ldl, k.lse, k.inv_cnt, k.consts + 0, k.d_h2, k.d_c, d_e, g.head, k.scr_head,
                                     stream));
+        VAG_TRY(vag_loss_defer_flush());
         {
             // after the backward recurrence: the products that add into d_enc (projected keys, attention keys) and the weight
             // gradients of the decoder and of attn_e are queued by layout and go out as two grouped launches
