@@ -431,3 +431,36 @@ def test_whole_module_checkpoint_after_shim_steps_and_decoding():
     # ... and the live model goes on training on the fused step
     T.train_imagine_beam(src, tgt, im, lens, m, opt, cm, cv, meta["loss_w"], 1.0, clip=1.0)
     assert int(opt._vag_driver.ts.step_count.item()) == 4
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (7) The launches merged late in round 5 (one-launch dot attention with the mean-pool rider, loss reduction riding in the head's
+#     backward) against the separate launches they replace, over the register kernel's position counts (Ts <= 16, 32, 48, 64) and
+#     past them (the generic row kernel).
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Ts", [9, 16, 17, 33, 48, 52, 64, 70])
+def test_merged_visual_attention_launches_equal_the_separate_ones(Ts):
+    import bench
+    from vagnmt_hip import _lib as L
+    from test_gpu_benched_path import _driver, _run_phases
+    c = dict(bench.CFG2, Ts=Ts, Tt=7, B=24)
+    dev = torch.device("cuda", 0)
+    m, ts = _driver(c, dropout=False, use_graph=False)
+    batch = bench.make_batch(c, 3, dev, ragged=True)
+    m.train()
+    got = {}
+    try:
+        for mode in (1, 0):
+            L.set_option("attn_row", mode)
+            L.set_option("loss_ride", mode)
+            got[mode] = _run_phases(ts, batch, 1)[0]
+    finally:
+        L.set_option("attn_row", 1)
+        L.set_option("loss_ride", 1)
+    (l1, g1), (l0, g0) = got[1], got[0]
+    assert np.allclose(l1, l0, rtol=2e-6, atol=1e-6), (l1, l0)
+    for n in g0:
+        ref = float(g0[n].abs().max())
+        err = float((g1[n] - g0[n]).abs().max())
+        assert err <= 2e-5 * max(ref, 1e-3), (n, err, ref)
+    ts.check()

@@ -1535,7 +1535,7 @@ int vag_rank_loss_fwd_impl(const float* im, const float* sv, int64_t B, int64_t 
 int vag_rank_loss_bwd_impl(const float* im, const float* sv, const float* G, const float* d_loss, int64_t B, int64_t S,
                            float* d_im, float* d_s, hipStream_t s) {
     VAG_CHECK_ARG(im && sv && G && d_im && d_s && B > 0 && S > 0);
-    if (B <= 512) return vag_rank_bwd_launch(G, im, sv, d_loss, B, S, d_im, d_s, s);               // both products (and the scale) in one launch
+    if (B <= 128) return vag_rank_bwd_launch(G, im, sv, d_loss, B, S, d_im, d_s, s);               // both products (and the scale) in one launch
     VAG_TRY(gemm_nn(B, S, B, G, B, sv, S, 0.f, d_im, S, s));                                       // d_im = G s
     VAG_TRY(vag_gemm_launch(B, S, B, 1.f, G, 1, B, im, S, 1, 0.f, d_s, S, nullptr, 0, s));        // d_s  = G^T im
     if (!d_loss) return VAG_OK;                                                                    // (G came pre-multiplied)
@@ -1568,7 +1568,8 @@ int vag_dec_init_fwd(const float* enc, const float* mask, const float* ctx, floa
                      int64_t B, int64_t Ts, int64_t C, int64_t H, float* xmix, float* h0, vag_stream_t stream) {
     hipStream_t s = S_(stream);
     VAG_CHECK_ARG(enc && mask && W && b && xmix && h0 && B > 0 && Ts > 0 && C % 4 == 0 && H > 0);
-    VAG_TRY(vag_meanpool_mix_launch(enc, mask, ctx, split, B, Ts, C, xmix, s));
+    // (a step driver's visual-attention launch may already have left xmix: vag_attn_row_mix_request)
+    if (!(ctx && vag_attn_row_mix_done(xmix))) VAG_TRY(vag_meanpool_mix_launch(enc, mask, ctx, split, B, Ts, C, xmix, s));
     return linear_fwd(B, H, C, xmix, C, W, b, VAG_ACT_TANH, h0, H, s);
 }
 int vag_dec_init_bwd(const float* mask, const float* xmix, const float* h0, float split, const float* W, float* d_h0,

@@ -557,10 +557,150 @@ __global__ __launch_bounds__(ROW_THREADS) void attn_dot_row_kernel(const float* 
         *reinterpret_cast<float4*>(sum + b * C + 4 * c4) = acc;
     }
 }
+// The same with the row of x held in REGISTERS between the phases (C = 256 NC, Ts <= 16 NP, NC * NP <= 16 float4 per thread): x is
+// read from memory once (the kernel above reads it twice, ~50 GB/s per CU: 11.7 us for 2 x 160 KB at configs[1] -- no faster than the
+// launches it replaced).  Thread (wave w, lane l) holds x[b, w + 16 p, 4 l + 256 j .. + 3].  The 16 waves' partial sums meet in a
+// four-round tree through LDS (fixed order).  MIX (forward only): also xmix[b,:] = split * sum[b,:] + (1 - split) * mean_t x[b,t,:]
+// (V11.py:118: the initial state's input; mean over the sentence's own length, cnt = #(mask[b,:])) -- the mean-pool launch saved.
+template <bool BWD, int NC, int NP, bool MIX>
+__global__ __launch_bounds__(ROW_THREADS) void attn_dot_row_reg_kernel(const float* __restrict__ x, const float* __restrict__ q, int64_t ldq,
+                                                                        const float* __restrict__ mask, const float* __restrict__ alpha,
+                                                                        int Ts, float* __restrict__ wout, float* __restrict__ sum,
+                                                                        float* __restrict__ xmix, float split) {
+    constexpr int C = 256 * NC, NACC = NC * (MIX ? 2 : 1);
+    extern __shared__ __attribute__((aligned(16))) float rw[];       // 64 weights (+ cnt at [64]), then part[8][NACC][64] float4
+    float4* part = reinterpret_cast<float4*>(rw + 80);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b = blockIdx.x;
+    const float* xb = x + b * Ts * (int64_t)C + 4 * lane;
+    float4 xr[NP][NC], qv[NC];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int t = wave + 16 * p;
+            xr[p][j] = t < Ts ? *reinterpret_cast<const float4*>(xb + (int64_t)t * C + 256 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) qv[j] = *reinterpret_cast<const float4*>(q + b * ldq + 4 * lane + 256 * j);
+    if (MIX && threadIdx.x < 64) {
+        float cnt = 0.f;
+        for (int t = lane; t < Ts; t += 64) cnt += mask[b * Ts + t];
+        cnt = wave_sum(cnt);
+        if (lane == 0) rw[64] = cnt;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) acc += xr[p][j].x * qv[j].x + xr[p][j].y * qv[j].y + xr[p][j].z * qv[j].z + xr[p][j].w * qv[j].w;
+        acc = wave_sum(acc);
+        const int t = wave + 16 * p;
+        if (lane == 0 && t < Ts) rw[t] = (!BWD && mask && mask[b * Ts + t] == 0.f) ? -INFINITY : acc;
+    }
+    __syncthreads();
+    float wt[NP];
+    {
+        const float e = lane < Ts ? rw[lane] : (BWD ? 0.f : -INFINITY);          // Ts <= 64: one value per lane, every wave for itself
+        float a;
+        if (!BWD) {
+            const float mx = wave_max(e);
+            const float ex = lane < Ts ? __expf(e - mx) : 0.f;
+            a = ex / wave_sum(ex);
+        } else {
+            const float al = lane < Ts ? alpha[b * Ts + lane] : 0.f;
+            const float dot = wave_sum(al * e);
+            a = al * (e - dot);
+        }
+        if (wave == 0 && lane < Ts) wout[b * Ts + lane] = a;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) wt[p] = __shfl(a, min(wave + 16 * p, 63), 64);      // (positions past Ts hold zero rows)
+    }
+    if (!sum) return;
+    float4 acc[NACC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), m = v;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            v.x += wt[p] * xr[p][j].x; v.y += wt[p] * xr[p][j].y; v.z += wt[p] * xr[p][j].z; v.w += wt[p] * xr[p][j].w;
+            if (MIX) { m.x += xr[p][j].x; m.y += xr[p][j].y; m.z += xr[p][j].z; m.w += xr[p][j].w; }
+        }
+        acc[j] = v;
+        if (MIX) acc[NC + j] = m;
+    }
+#pragma unroll
+    for (int half = 8; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) part[((wave - half) * NACC + j) * 64 + lane] = acc[j];
+        }
+        __syncthreads();
+        if (wave < half) {
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) {
+                const float4 o = part[(wave * NACC + j) * 64 + lane];
+                acc[j].x += o.x; acc[j].y += o.y; acc[j].z += o.z; acc[j].w += o.w;
+            }
+        }
+        if (half > 1) __syncthreads();
+    }
+    if (wave == 0) {
+        const float cnt = MIX ? rw[64] : 1.f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            *reinterpret_cast<float4*>(sum + b * C + 4 * lane + 256 * j) = acc[j];
+            if (MIX) {
+                const float4 m = acc[NC + j];
+                const float k = (1.f - split) / cnt;
+                *reinterpret_cast<float4*>(xmix + b * C + 4 * lane + 256 * j) =
+                    make_float4(split * acc[j].x + k * m.x, split * acc[j].y + k * m.y, split * acc[j].z + k * m.z, split * acc[j].w + k * m.w);
+            }
+        }
+    }
+}
+// A rider for the next forward row launch of the calling thread: it also leaves xmix (B,C) = split * context + (1 - split) * mean-pool
+// (what vag_dec_init_fwd would compute from that context with a launch of its own).  vag_attn_row_mix_done(xmix) tells whether it did.
+struct RowMix { float* xmix = nullptr; float split = 0.f; };
+static thread_local RowMix g_row_mix;
+static thread_local const float* g_row_mix_done = nullptr;
+void vag_attn_row_mix_request(float* xmix, float split) { g_row_mix = RowMix{xmix, split}; g_row_mix_done = nullptr; }
+void vag_attn_row_mix_cancel() { g_row_mix = RowMix(); }
+bool vag_attn_row_mix_done(const float* xmix) { const bool d = xmix && g_row_mix_done == xmix; g_row_mix_done = nullptr; return d; }
+
+template <bool BWD, int NC, int NP, bool MIX>
+static int row_reg_go(const float* x, const float* q, int64_t ldq, const float* mask, const float* alpha, int64_t B, int64_t Ts,
+                      float* wout, float* sum, float* xmix, float split, hipStream_t s) {
+    constexpr size_t lds = 80 * sizeof(float) + (size_t)8 * NC * (MIX ? 2 : 1) * 64 * 16;
+    static bool attr = false;
+    if (!attr && lds > 65536) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_dot_row_reg_kernel<BWD, NC, NP, MIX>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VAG_EINVAL;
+        attr = true;
+    }
+    hipLaunchKernelGGL((attn_dot_row_reg_kernel<BWD, NC, NP, MIX>), dim3((unsigned)B), dim3(ROW_THREADS), lds, s, x, q, ldq, mask, alpha,
+                       (int)Ts, wout, sum, xmix, split);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
 // forward: wout = alpha (B,Ts), sum = context (B,C).  backward: alpha given, wout = d(scores) (B,Ts), sum = sum_t wout x or NULL.
 int vag_attn_dot_row_launch(bool bwd, const float* x, const float* q, int64_t ldq, const float* mask, const float* alpha, int64_t B,
                             int64_t Ts, int64_t C, float* wout, float* sum, hipStream_t s) {
     VAG_CHECK_ARG(x && q && wout && B > 0 && Ts > 0 && Ts <= 4096 && C > 0 && C % 4 == 0 && ldq % 4 == 0 && ldq >= C && (!bwd || alpha));
+    const RowMix mix = g_row_mix;
+    g_row_mix = RowMix();
+    const int np = (int)cdiv64(Ts, 16);
+    if (aligned16(x) && aligned16(q) && (!sum || aligned16(sum)) && np <= 4 && (C == 1024 || C == 512)) {
+        const bool mx = !bwd && mix.xmix && mask && sum && aligned16(mix.xmix);
+#define VAG_ROW(NC_, NP_)                                                                                                            \
+        { if (bwd) return row_reg_go<true, NC_, NP_, false>(x, q, ldq, mask, alpha, B, Ts, wout, sum, nullptr, 0.f, s);               \
+          if (!mx) return row_reg_go<false, NC_, NP_, false>(x, q, ldq, mask, alpha, B, Ts, wout, sum, nullptr, 0.f, s);              \
+          VAG_TRY((row_reg_go<false, NC_, NP_, true>(x, q, ldq, mask, alpha, B, Ts, wout, sum, mix.xmix, mix.split, s)));             \
+          g_row_mix_done = mix.xmix; return VAG_OK; }
+        if (C == 1024) { if (np == 1) VAG_ROW(4, 1) else if (np == 2) VAG_ROW(4, 2) else if (np == 3) VAG_ROW(4, 3) else VAG_ROW(4, 4) }
+        else { if (np == 1) VAG_ROW(2, 1) else if (np == 2) VAG_ROW(2, 2) else if (np == 3) VAG_ROW(2, 3) else VAG_ROW(2, 4) }
+#undef VAG_ROW
+    }
     const size_t lds = (size_t)((Ts + 3) & ~3) * sizeof(float) + (size_t)ROW_THREADS * 16;
     if (bwd) hipLaunchKernelGGL(attn_dot_row_kernel<true>, dim3((unsigned)B), dim3(ROW_THREADS), lds, s, x, q, ldq, mask, alpha, (int)Ts, (int)C, wout, sum);
     else hipLaunchKernelGGL(attn_dot_row_kernel<false>, dim3((unsigned)B), dim3(ROW_THREADS), lds, s, x, q, ldq, mask, alpha, (int)Ts, (int)C, wout, sum);

@@ -185,11 +185,14 @@ int vag_attn_dot_row_launch(bool bwd, const float* x, const float* q, int64_t ld
                             int64_t Ts, int64_t C, float* wout, float* sum, hipStream_t s);      // attn.hip: one launch per dot attention
 void vag_skinny_nn_out2(float* out2, int64_t ld, float scale, int accumulate);      // gemm.hip: a second destination for the next vag_skinny_nn_launch
 int vag_rank_bwd_launch(const float* G, const float* im, const float* sv, const float* d_loss, int64_t B, int64_t S, float* d_im,
-                        float* d_s, hipStream_t s);       // vse.hip: d_im = G s and d_s = G^T im (x *d_loss) in one launch, B <= 512
+                        float* d_s, hipStream_t s);       // vse.hip: d_im = G s and d_s = G^T im (x *d_loss) in one launch, B <= 128
 int vag_attn_wsum_pair_launch(const float* a, const float* y, int64_t Wy, float* out_src, const float* x, int64_t Wx, float* out_time,
                               int64_t B, int64_t Ts, int64_t T, hipStream_t s);        // attn.hip: sum over t of a y and sum over s of a x, one grid
 void vag_loss_defer_begin();                // head.hip: hold the loss reduction back for the next ce_bwd_colsum launch ...
 int vag_loss_defer_flush();                 // ... or launch it now if none came
+void vag_attn_row_mix_request(float* xmix, float split);     // attn.hip: the next forward row launch also leaves the initial state's input ...
+void vag_attn_row_mix_cancel();                                  // ... (a request nobody took must not outlive the call that made it)
+bool vag_attn_row_mix_done(const float* xmix);               // ... if it could (asked once: resets)
 void vag_rmw_defer_begin(float* out);      // attn.hip: hold back accumulating outer2 / meanpool_bwd launches into `out` ...
 int vag_rmw_defer_flush(hipStream_t s);    // ... and do them in one pass
 void vag_rmw_defer_abort();

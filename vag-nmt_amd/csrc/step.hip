@@ -303,8 +303,11 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
                                   k.mask, k.ws_enc, stream));                                           // V11.py:111
         if (mm) {                                                                                       // V11.py:114
             VAG_TRY(br_im.join(s, 1));
-            VAG_TRY(vag_imagine_attn_ctx_fwd(k.im_emb, k.enc, k.mask, w.ctx2ctx, w.emb2ctx, w.mlp_w, c.attn_method, B, Ts, C, S,
-                                             k.alpha_v, k.ctx, k.ws_img, stream));
+            vag_attn_row_mix_request(k.xmix, c.init_split);     // (consumed by the dot method's one-launch attention, else dropped)
+            const int rc_att = vag_imagine_attn_ctx_fwd(k.im_emb, k.enc, k.mask, w.ctx2ctx, w.emb2ctx, w.mlp_w, c.attn_method, B, Ts, C, S,
+                                                        k.alpha_v, k.ctx, k.ws_img, stream);
+            vag_attn_row_mix_cancel();
+            VAG_TRY(rc_att);
             VAG_TRY(vag_img_proj_l2_fwd(k.ctx, w.txt_w, w.txt_b, B, C, S, c.activation_vse, k.y_txt, k.nrm_txt, k.txt_emb,
                                         stream));
             if (has_vse)

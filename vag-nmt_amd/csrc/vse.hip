@@ -109,26 +109,32 @@ int vag_rank_loss_launch(const float* scores, int64_t B, float margin, int kind,
 }
 
 // Both gradients of the similarity matrix in one launch: d_im = G s (PairwiseRankingLoss.py:12: scores = im s^T), d_s = G^T im.
-// grid (ceil(S/64), ceil(B/16), 2); block = 64 columns x 4 row groups of 4 rows; the 16 x B slice of G (or G^T) sits in LDS.
+// grid (ceil(S/64), ceil(B/16), 2); block = 64 columns x 4 row groups of 4 rows; the 16 x B slice of G (or G^T) and the B x 64 tile
+// of the other operand are staged in LDS with every load of the block in flight at once (the k loop then runs out of LDS).
 __global__ __launch_bounds__(256) void rank_bwd_kernel(const float* __restrict__ G, const float* __restrict__ im,
                                                        const float* __restrict__ sv, const float* __restrict__ d_loss, int B, int S,
                                                        float* __restrict__ d_im, float* __restrict__ d_s) {
-    extern __shared__ float gsh[];              // [16][B]
+    extern __shared__ float gsh[];              // [16][B] slice of G / G^T, then [B][64] tile of x
+    float* xs = gsh + 16 * B;
     const bool tr = blockIdx.z == 1;            // d_s: rows of G^T
     const float* x = tr ? im : sv;
     float* out = tr ? d_s : d_im;
-    const int i0 = blockIdx.y * 16;
+    const int i0 = blockIdx.y * 16, c0 = blockIdx.x * 64;
     for (int e = threadIdx.x; e < 16 * B; e += 256) {
         const int r = e / B, j = e - r * B, i = i0 + r;
         gsh[e] = i < B ? (tr ? G[(int64_t)j * B + i] : G[(int64_t)i * B + j]) : 0.f;
     }
+    for (int e = threadIdx.x; e < B * 64; e += 256) {
+        const int j = e >> 6, c = c0 + (e & 63);
+        xs[e] = c < S ? x[(int64_t)j * S + c] : 0.f;
+    }
     __syncthreads();
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int cl = threadIdx.x & 63, c = c0 + cl, rg = threadIdx.x >> 6;
     if (c >= S) return;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     const float* g = gsh + 4 * rg * B;
     for (int j = 0; j < B; ++j) {
-        const float xv = x[(int64_t)j * S + c];
+        const float xv = xs[j * 64 + cl];
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] += g[r * B + j] * xv;
     }
@@ -141,9 +147,9 @@ __global__ __launch_bounds__(256) void rank_bwd_kernel(const float* __restrict__
 }
 int vag_rank_bwd_launch(const float* G, const float* im, const float* sv, const float* d_loss, int64_t B, int64_t S, float* d_im,
                         float* d_s, hipStream_t s) {
-    VAG_CHECK_ARG(G && im && sv && d_im && d_s && B > 0 && B <= 512 && S > 0);
+    VAG_CHECK_ARG(G && im && sv && d_im && d_s && B > 0 && B <= 128 && S > 0);
     dim3 grid((unsigned)cdiv64(S, 64), (unsigned)cdiv64(B, 16), 2);
-    hipLaunchKernelGGL(rank_bwd_kernel, grid, dim3(256), (size_t)(16 * B) * sizeof(float), s, G, im, sv, d_loss, (int)B, (int)S, d_im, d_s);
+    hipLaunchKernelGGL(rank_bwd_kernel, grid, dim3(256), (size_t)(80 * B) * sizeof(float), s, G, im, sv, d_loss, (int)B, (int)S, d_im, d_s);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
