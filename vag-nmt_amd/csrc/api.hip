@@ -1535,7 +1535,7 @@ int vag_rank_loss_fwd_impl(const float* im, const float* sv, int64_t B, int64_t 
 int vag_rank_loss_bwd_impl(const float* im, const float* sv, const float* G, const float* d_loss, int64_t B, int64_t S,
                            float* d_im, float* d_s, hipStream_t s) {
     VAG_CHECK_ARG(im && sv && G && d_im && d_s && B > 0 && S > 0);
-    if (B <= 128) return vag_rank_bwd_launch(G, im, sv, d_loss, B, S, d_im, d_s, s);               // both products (and the scale) in one launch
+    if (B <= 128 && B % 16 == 0 && S % 4 == 0 && aligned16(G) && aligned16(im) && aligned16(sv)) return vag_rank_bwd_launch(G, im, sv, d_loss, B, S, d_im, d_s, s);               // both products (and the scale) in one launch
     VAG_TRY(gemm_nn(B, S, B, G, B, sv, S, 0.f, d_im, S, s));                                       // d_im = G s
     VAG_TRY(vag_gemm_launch(B, S, B, 1.f, G, 1, B, im, S, 1, 0.f, d_s, S, nullptr, 0, s));        // d_s  = G^T im
     if (!d_loss) return VAG_OK;                                                                    // (G came pre-multiplied)
@@ -1584,7 +1584,8 @@ int vag_dec_init_bwd_impl(const float* mask, const float* xmix, const float* h0,
                           int accumulate_ctx, float* g_W, float* g_b, float* scratch, hipStream_t s) {
     VAG_CHECK_ARG(mask && xmix && h0 && W && d_h0 && d_enc && g_W && g_b && scratch && B > 0 && Ts > 0 && C % 4 == 0);
     float* dx = scratch;    // (B,C)
-    VAG_TRY(vag_tanh_bwd_launch(h0, d_h0, d_h0, B * H, nullptr, 0, 0.f, s));
+    // (a step driver's persistent decoder backward may already have applied the tanh's derivative: vag_persist_dh0_tanh_request)
+    if (!vag_persist_dh0_tanh_done(d_h0)) VAG_TRY(vag_tanh_bwd_launch(h0, d_h0, d_h0, B * H, nullptr, 0, 0.f, s));
     VAG_TRY(gemm_tn_acc(H, C, B, d_h0, H, xmix, C, g_W, C, s));
     VAG_TRY(vag_colsum_launch(d_h0, B, H, H, g_b, s));
     const bool ride = d_ctx && B <= 128;                       // d_ctx (+)= split * dx leaves with the product that forms dx

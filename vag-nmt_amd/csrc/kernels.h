@@ -193,6 +193,8 @@ int vag_loss_defer_flush();                 // ... or launch it now if none came
 void vag_attn_row_mix_request(float* xmix, float split);     // attn.hip: the next forward row launch also leaves the initial state's input ...
 void vag_attn_row_mix_cancel();                                  // ... (a request nobody took must not outlive the call that made it)
 bool vag_attn_row_mix_done(const float* xmix);               // ... if it could (asked once: resets)
+void vag_persist_dh0_tanh_request(bool on);          // persist.hip: the next decoder backward launch applies (1 - h0^2) to d_h0 ...
+bool vag_persist_dh0_tanh_done(const float* d_h0);   // ... whether it did (asked once: resets)
 void vag_rmw_defer_begin(float* out);      // attn.hip: hold back accumulating outer2 / meanpool_bwd launches into `out` ...
 int vag_rmw_defer_flush(hipStream_t s);    // ... and do them in one pass
 void vag_rmw_defer_abort();

@@ -1478,6 +1478,7 @@ struct DecBArgs {
     unsigned spin;
     unsigned long long* dbg;    // NULL, or [Tt][8] timestamps of workgroup 0 (tools/exp_dec_bwd_phases.py)
     int B, Ts, Tt, H, RT;
+    int h0_tanh;                // 1: d_h0 leaves as the gradient of the PRE-activation of h0 = tanh(.) (V11.py:118): d_h0 * (1 - h0^2)
 };
 
 // GRU cell backward for 4 units (see gru_bwd_elem_kernel): dh = total gradient of the cell's output
@@ -1786,7 +1787,14 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
                 const float4 c1 = *reinterpret_cast<const float4*>(c1_s + fr * 8 + 4 * hq);
                 const float dh2[4] = {x[0] + c1.x + dadd.x, x[1] + c1.y + dadd.y, x[2] + c1.z + dadd.z, x[3] + c1.w + dadd.w};
                 if (t > 0) cell2_bwd(t - 1, dh2, s2, hp2);
-                else *reinterpret_cast<float4*>(a.d_h0 + (int64_t)em * H + eu) = make_float4(dh2[0], dh2[1], dh2[2], dh2[3]);
+                else {
+                    float4 o = make_float4(dh2[0], dh2[1], dh2[2], dh2[3]);
+                    if (a.h0_tanh) {
+                        const float4 h = *reinterpret_cast<const float4*>(a.h0 + (int64_t)em * H + eu);
+                        o.x *= 1.f - h.x * h.x; o.y *= 1.f - h.y * h.y; o.z *= 1.f - h.z * h.z; o.w *= 1.f - h.w * h.w;
+                    }
+                    *reinterpret_cast<float4*>(a.d_h0 + (int64_t)em * H + eu) = o;
+                }
             }
         }
         __syncthreads();
@@ -2164,6 +2172,12 @@ static int64_t dec_bwd_persistent_lds_bytes(int64_t Ts) {
 bool vag_dec_bwd_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H) {
     return vag_dec_persistent_ok(B, Ts, Tt, H) && dec_bwd_persistent_lds_bytes(Ts) <= 160 * 1024;
 }
+// A step driver whose initial state is h0 = tanh(.) asks the next backward launch of the calling thread to apply the tanh's
+// derivative to d_h0 on its way out (a launch saved); vag_persist_dh0_tanh_done(d_h0) tells the consumer whether it happened.
+static thread_local bool g_dh0_tanh_req = false;
+static thread_local const float* g_dh0_tanh_done = nullptr;
+void vag_persist_dh0_tanh_request(bool on) { g_dh0_tanh_req = on; if (on) g_dh0_tanh_done = nullptr; }
+bool vag_persist_dh0_tanh_done(const float* d_h0) { const bool d = d_h0 && g_dh0_tanh_done == d_h0; g_dh0_tanh_done = nullptr; return d; }
 int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const float* v, const float* wcatT, const float* whh1T,
                                   const float* h0, const float* h2_all, const float* h1, const float* g1, const float* g2,
                                   const float* qhp, const float* alpha, const float* d_h2_all, const float* dah, float* dgi2,
@@ -2178,6 +2192,9 @@ int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const flo
     a.pe = pe; a.encwp = encwp; a.v = v; a.wcatT = wcatT; a.whh1T = whh1T; a.h0 = h0; a.h2_all = h2_all; a.h1 = h1; a.g1 = g1;
     a.g2 = g2; a.qhp = qhp; a.alpha = alpha; a.d_h2_all = d_h2_all; a.dah = dah; a.dgi2 = dgi2; a.dqgh = dqgh; a.ds = ds;
     a.dgi1 = dgi1; a.dgh1 = dgh1; a.d_h0 = d_h0; a.dal = dal;
+    a.h0_tanh = g_dh0_tanh_req ? 1 : 0;
+    if (g_dh0_tanh_req) g_dh0_tanh_done = d_h0;
+    g_dh0_tanh_req = false;
 #ifdef VAG_LAB
     a.dbg = reinterpret_cast<unsigned long long*>(vag_opt().dec_bwd_stamps);
 #else

@@ -354,6 +354,8 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
             // after the backward recurrence: the products that add into d_enc (projected keys, attention keys) and the weight
             // gradients of the decoder and of attn_e are queued by layout and go out as two grouped launches
             VagGemmGroup outer(true);
+            // the initial state's backward follows in this call: d_h0 leaves the recurrence kernel as the gradient of tanh's argument
+            struct Dh0 { Dh0(bool on) { vag_persist_dh0_tanh_request(on); } ~Dh0() { vag_persist_dh0_tanh_request(false); } } dh0((phases & 2) != 0);
             VAG_TRY(vag_cgru_attn_decode_seq_bwd_loop(k.enc, k.pe, k.mask, h0, k.tok, w.dec, B, Ts, Tt, Et, H, V, h2_all, k.c_all,
                                                       k.e_all, k.d_h2, k.d_c, d_e, k.ws_dec, k.d_enc, 0, k.d_pe, k.d_h0,
                                                       k.scr_dec, stream));

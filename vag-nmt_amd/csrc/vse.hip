@@ -114,19 +114,50 @@ int vag_rank_loss_launch(const float* scores, int64_t B, float margin, int kind,
 __global__ __launch_bounds__(256) void rank_bwd_kernel(const float* __restrict__ G, const float* __restrict__ im,
                                                        const float* __restrict__ sv, const float* __restrict__ d_loss, int B, int S,
                                                        float* __restrict__ d_im, float* __restrict__ d_s) {
-    extern __shared__ float gsh[];              // [16][B] slice of G / G^T, then [B][64] tile of x
+    extern __shared__ __attribute__((aligned(16))) float gsh[];      // [16][B] slice of G / G^T, then [B][64] tile of x
     float* xs = gsh + 16 * B;
     const bool tr = blockIdx.z == 1;            // d_s: rows of G^T
     const float* x = tr ? im : sv;
     float* out = tr ? d_s : d_im;
     const int i0 = blockIdx.y * 16, c0 = blockIdx.x * 64;
-    for (int e = threadIdx.x; e < 16 * B; e += 256) {
-        const int r = e / B, j = e - r * B, i = i0 + r;
-        gsh[e] = i < B ? (tr ? G[(int64_t)j * B + i] : G[(int64_t)i * B + j]) : 0.f;
-    }
-    for (int e = threadIdx.x; e < B * 64; e += 256) {
-        const int j = e >> 6, c = c0 + (e & 63);
-        xs[e] = c < S ? x[(int64_t)j * S + c] : 0.f;
+    // every load of the block is issued before the first LDS store (B % 16 == 0, S % 4 == 0: 16-byte loads; one at a time -- a
+    // load, its store, the next load -- the staging alone took ~10 us out of cold memory)
+    {
+        const int B4 = B >> 2;
+        constexpr int U = 4;
+        for (int e0 = threadIdx.x; e0 < 4 * B; e0 += 256 * U) {          // G slice: 16 rows x B (or B rows x 16 of G for G^T)
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + 256 * u;
+                if (e < 4 * B) v[u] = tr ? *reinterpret_cast<const float4*>(G + (int64_t)(e >> 2) * B + i0 + 4 * (e & 3))
+                                         : *reinterpret_cast<const float4*>(G + (int64_t)(i0 + e / B4) * B + 4 * (e % B4));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + 256 * u;
+                if (e >= 4 * B) continue;
+                if (tr) {
+                    const int j = e >> 2, r = 4 * (e & 3);
+                    gsh[(r + 0) * B + j] = v[u].x; gsh[(r + 1) * B + j] = v[u].y; gsh[(r + 2) * B + j] = v[u].z; gsh[(r + 3) * B + j] = v[u].w;
+                } else {
+                    *reinterpret_cast<float4*>(gsh + (e / B4) * B + 4 * (e % B4)) = v[u];
+                }
+            }
+        }
+        for (int e0 = threadIdx.x; e0 < 16 * B; e0 += 256 * U) {         // x tile: B rows x 64 columns
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + 256 * u, j = e >> 4, c = c0 + 4 * (e & 15);
+                v[u] = (e < 16 * B && c < S) ? *reinterpret_cast<const float4*>(x + (int64_t)j * S + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + 256 * u;
+                if (e < 16 * B) *reinterpret_cast<float4*>(xs + 4 * e) = v[u];
+            }
+        }
     }
     __syncthreads();
     const int cl = threadIdx.x & 63, c = c0 + cl, rg = threadIdx.x >> 6;
@@ -147,7 +178,8 @@ __global__ __launch_bounds__(256) void rank_bwd_kernel(const float* __restrict__
 }
 int vag_rank_bwd_launch(const float* G, const float* im, const float* sv, const float* d_loss, int64_t B, int64_t S, float* d_im,
                         float* d_s, hipStream_t s) {
-    VAG_CHECK_ARG(G && im && sv && d_im && d_s && B > 0 && B <= 128 && S > 0);
+    VAG_CHECK_ARG(G && im && sv && d_im && d_s && B > 0 && B <= 128 && B % 16 == 0 && S > 0 && S % 4 == 0 && aligned16(G) && aligned16(im) &&
+                  aligned16(sv));
     dim3 grid((unsigned)cdiv64(S, 64), (unsigned)cdiv64(B, 16), 2);
     hipLaunchKernelGGL(rank_bwd_kernel, grid, dim3(256), (size_t)(80 * B) * sizeof(float), s, G, im, sv, d_loss, (int)B, (int)S, d_im, d_s);
     VAG_LAUNCH_CHECK();
