@@ -946,6 +946,12 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
     unsigned long long* cb_s = reinterpret_cast<unsigned long long*>(q_s);            // FREE: [128] arg-max partials (q_s is idle then)
     bf16x8* tm_s = reinterpret_cast<bf16x8*>(red);                                   // FREE: [3 planes][8 k-steps][64 lanes] the head's hidden layer, while `red` is idle
 
+#ifdef VAG_LAB          // prologue stamps (teacher-forced form): entry | weights in registers | keys in LDS, in row Tt of the stamp array
+#define VAG_PSTAMP(k) do { if (!FREE && a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[Tt * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define VAG_PSTAMP(k) do { } while (0)
+#endif
+    VAG_PSTAMP(0);
     // ---- weights as bf16 planes in registers (A operands: rows = output columns).  Row of a tile held by lane fr:
     //   cell tiles: tile 0 = [r | z] of the 8 own units (fr < 8: gate r, unit fr; else gate z, unit fr - 8), tile 1 = [n | n again]
     bf16x8 w1[KS][2][3], w2[KS][3][3];
@@ -969,8 +975,10 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
             split8(*reinterpret_cast<const float4*>(q2), *reinterpret_cast<const float4*>(q2 + 4), w2[s][2]);
         }
     }
+    VAG_PSTAMP(1);
     // ---- own 16 query columns of the keys of all 16 x Ts pairs, own 24 gate columns of the projected keys -> LDS (read from
-    // memory once per sequence)
+    // memory once per sequence: 11.4-11.6 us of the launch, tools/exp_dec_phases.py; batching the loads of a thread -- eight in flight
+    // before the first LDS store -- changed nothing, so it is the 64-byte pieces out of 26 MB, not load latency, that set it)
     for (int x = threadIdx.x; x < 16 * Ts * 4; x += 512) {           // (pair, column quad) -> one float4
         const int P = x >> 2, c4 = x & 3;
         const int r = P / Ts, sp = P - r * Ts, b = min(m0 + r, B - 1);
@@ -1019,6 +1027,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
     constexpr unsigned PER_SHARD = DEC_WGS / SHARDS;
     bool dead = false;
     __syncthreads();
+    VAG_PSTAMP(2);
 #ifdef VAG_LAB          // phase timestamps: lab builds only (make LAB=1 -> libvagnmt_lab.so); the product kernels carry no hook
     const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
 #define VAG_STAMP(k) do { if (stamp) a.dbg[t * (FREE ? 16 : 8) + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
