@@ -464,3 +464,36 @@ def test_merged_visual_attention_launches_equal_the_separate_ones(Ts):
         err = float((g1[n] - g0[n]).abs().max())
         assert err <= 2e-5 * max(ref, 1e-3), (n, err, ref)
     ts.check()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("Ts", [11, 32])
+def test_fused_decoding_step_attention_matches_the_two_launches_and_the_oracle(Ts):
+    """attn_row_gru_kernel (scores + softmax + projected context + gru_2 + W2 c of a beam step in one launch; H = 512, Ts <= 32)
+    against the separate launches (option attn_row = 0: same winners, scores to rounding) and against the oracle's beam search."""
+    from oracle import vag_oracle as O
+    from vagnmt_hip import _lib as L
+    from test_gpu_round2 import make
+    lens = sorted([max(3, Ts - 2 * i) for i in range(8)], reverse=True)
+    lens[0] = Ts
+    m, src, tgt, im = make(8507, 9391, 2048, 256, 512, 512, 8, Ts, 6, lens, seed=33)
+    with torch.no_grad():
+        m.decoder.out.bias[3] += 2.0
+    P = {n: p.detach().clone() for n, p in m.named_parameters()}
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    want, want_scores = O.beam_search(P, src, lens, im, beam_size=12, max_length=30, return_scores=True)
+    mg = m.cuda().eval()
+    res = {}
+    try:
+        for mode in (1, 0):
+            L.set_option("attn_row", mode)
+            mg.__dict__.pop("_decode_cache", None)
+            got = [[int(t) for t in h] for h in mg.beamsearch_decode(src.cuda(), lens, im.cuda(), 12, 30)]
+            res[mode] = (got, mg.last_beam_scores.cpu().numpy().copy())
+    finally:
+        L.set_option("attn_row", 1)
+        mg.__dict__.pop("_decode_cache", None)
+    assert np.allclose(res[1][1], res[0][1], rtol=1e-5, atol=1e-5)
+    assert sum(a == b for a, b in zip(res[1][0], res[0][0])) >= 7
+    assert np.allclose(res[1][1], want_scores.numpy(), rtol=2e-4, atol=2e-4), np.abs(res[1][1] - want_scores.numpy()).max()
+    assert sum(a == b for a, b in zip(res[1][0], want)) >= 7

@@ -1148,6 +1148,10 @@ int vag_cgru_attn_decode_step_h(const float* pe, const float* mask, const float*
     // (the training chain lets W_hh2 h1 ride in the score kernel's grid; at 192 rows the one (q | hp2) product + the plain score
     // kernel measured 3.5 us less than q + scores-with-rider: the rider is a long K loop of few workgroups)
     VAG_TRY(vag_skinny_launch(N, Q, H, h1, H, p.wcat, H, p.bcat, nullptr, 0, qhp, Q, 0, s));                  // attn_h(h1) :47 | W_hh2 h1 + b
+    if (vag_attn_row_gru_ok(N, Ts, H, E) && aligned16(pe) && aligned16(w.attn_v) && aligned16(w.gru2.b_ih) && aligned16(h_out) &&
+        aligned16(cw))                                                                                        // :47-51, :41-44, :126-129
+        return vag_attn_row_gru_launch(pe, qhp, Q, w.attn_v, mask, keys, encw2, N, rows_per_src, Ts, H, E, w.gru2.b_ih, qhp + C, Q, h1,
+                                       alpha, h_out, cw, s);
     VAG_TRY(vag_attn_scores_launch(0, pe, qhp, Q, w.attn_v, mask, N, rows_per_src, Ts, C, scores, s));        // :47-51, :41-43
     return vag_attn_ctx_gru_launch(scores, keys, N, rows_per_src, Ts, H, w.gru2.b_ih, qhp + C, Q, h1, alpha, h_out, nullptr, s,
                                    false, encw2, E, cw);                                                                 // :44, :126-129

@@ -314,6 +314,172 @@ int vag_attn_ctx_gru_launch(const float* scores, const float* encwp, int64_t N, 
     return VAG_OK;
 }
 
+// ------------------------------------------------------------------ a decoding step's attention and second cell in ONE launch
+// (beam search / step-wise decoding at N = B k hypothesis rows: NMT_Decoder.py:47-51, :41-44, :126-129 and the head's W2 c).
+// attn_scores_kernel + attn_ctx_gru_kernel were 5.9 + 9.8 us per step at 192 rows, two launches of mostly launch and ramp.  Here one
+// 512-thread workgroup per hypothesis row n (source sentence b = n / rps): wave w takes the positions s = w, w + 8, ... in BOTH
+// passes -- (1) e[s] = v . tanh(pe[b,s,:] + q[n,:]) with its four 16-byte loads per lane and position all in flight, (2) softmax in
+// every wave, (3) the weighted sums over the projected keys (3H gate columns) and over enc W2^T (E columns): NG + NW float4 per lane
+// and position, the first two positions requested before pass 1 starts -- the eight waves' partial sums meet in LDS, then the
+// cell (threads 0 .. H/4 - 1) and the head's share (the next NW x 64 threads).  C = 2H = 1024, 3H = 256 NG, E = 256 NW.
+template <int NG, int NW>
+__global__ __launch_bounds__(512) void attn_row_gru_kernel(const float* __restrict__ pe, const float* __restrict__ q, int64_t ldq,
+                                                           const float* __restrict__ v, const float* __restrict__ mask,
+                                                           const float* __restrict__ keys, const float* __restrict__ x2, int rps,
+                                                           int Ts, const float* __restrict__ b_ih, const float* __restrict__ hp,
+                                                           int64_t ldhp, const float* __restrict__ hprev,
+                                                           float* __restrict__ alpha, float* __restrict__ hout,
+                                                           float* __restrict__ out2) {
+    constexpr int C = 1024, H3 = 256 * NG, H = H3 / 3, W2 = 256 * NW, NA = NG + NW, PRE = 2;
+    extern __shared__ __attribute__((aligned(16))) float rsm[];      // Ts_pad scores -> weights, then part[8][NA][64] float4
+    const int Tp = (Ts + 3) & ~3;
+    float4* part = reinterpret_cast<float4*>(rsm + Tp);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n = blockIdx.x, b = rps == 1 ? n : (int64_t)((int)blockIdx.x / rps);
+    const float* kb = keys + b * Ts * (int64_t)H3 + 4 * lane;
+    const float* xb = x2 + b * Ts * (int64_t)W2 + 4 * lane;
+    auto load_keys = [&](int s, float4 (&k)[NA]) {
+#pragma unroll
+        for (int j = 0; j < NG; ++j) k[j] = *reinterpret_cast<const float4*>(kb + (int64_t)s * H3 + 256 * j);
+#pragma unroll
+        for (int j = 0; j < NW; ++j) k[NG + j] = *reinterpret_cast<const float4*>(xb + (int64_t)s * W2 + 256 * j);
+    };
+    float4 kpre[PRE][NA];
+#pragma unroll
+    for (int p = 0; p < PRE; ++p) load_keys(min(wave + 8 * p, Ts - 1), kpre[p]);
+    // the cell's other operands (threads 0 .. H/4 - 1): requested now, used after pass 3
+    float4 bb[3], hg[3], h1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool cellt = threadIdx.x < H / 4;
+    if (cellt) {
+        const int u = 4 * threadIdx.x;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            bb[g] = *reinterpret_cast<const float4*>(b_ih + g * H + u);
+            hg[g] = *reinterpret_cast<const float4*>(hp + n * ldhp + g * H + u);
+        }
+        h1 = *reinterpret_cast<const float4*>(hprev + n * H + u);
+    }
+    // ---- pass 1: scores
+    {
+        float4 qv[4], vv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            qv[j] = *reinterpret_cast<const float4*>(q + n * ldq + 4 * lane + 256 * j);
+            vv[j] = *reinterpret_cast<const float4*>(v + 4 * lane + 256 * j);
+        }
+        const float* pb = pe + b * Ts * (int64_t)C + 4 * lane;
+        for (int s0 = wave; s0 < Ts; s0 += 32) {
+            float4 x[4][4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[p][j] = *reinterpret_cast<const float4*>(pb + (int64_t)min(s0 + 8 * p, Ts - 1) * C + 256 * j);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int sp = s0 + 8 * p;
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc += vv[j].x * vag_tanh(x[p][j].x + qv[j].x) + vv[j].y * vag_tanh(x[p][j].y + qv[j].y);
+                    acc += vv[j].z * vag_tanh(x[p][j].z + qv[j].z) + vv[j].w * vag_tanh(x[p][j].w + qv[j].w);
+                }
+                acc = wave_sum(acc);
+                if (lane == 0 && sp < Ts) rsm[sp] = (mask && mask[b * Ts + sp] == 0.f) ? -INFINITY : acc;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- pass 2: softmax (every wave for itself), weights to LDS
+    {
+        float mx = -INFINITY;
+        for (int s = lane; s < Ts; s += 64) mx = fmaxf(mx, rsm[s]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int s = lane; s < Ts; s += 64) sum += __expf(rsm[s] - mx);
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        __syncthreads();
+        for (int s = threadIdx.x; s < Ts; s += 512) {
+            const float a = __expf(rsm[s] - mx) * inv;
+            rsm[s] = a;
+            if (alpha) alpha[n * Ts + s] = a;
+        }
+    }
+    __syncthreads();
+    // ---- pass 3: weighted sums of the wave's positions
+    float4 acc[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add = [&](int s, const float4 (&k)[NA]) {
+        const float a = s < Ts ? rsm[s] : 0.f;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) { acc[j].x += a * k[j].x; acc[j].y += a * k[j].y; acc[j].z += a * k[j].z; acc[j].w += a * k[j].w; }
+    };
+#pragma unroll
+    for (int p = 0; p < PRE; ++p) add(wave + 8 * p, kpre[p]);
+    for (int s0 = wave + 8 * PRE; s0 < Ts; s0 += 8 * PRE) {
+        float4 k[PRE][NA];
+#pragma unroll
+        for (int p = 0; p < PRE; ++p) load_keys(min(s0 + 8 * p, Ts - 1), k[p]);
+#pragma unroll
+        for (int p = 0; p < PRE; ++p) add(s0 + 8 * p, k[p]);
+    }
+#pragma unroll
+    for (int j = 0; j < NA; ++j) part[(wave * NA + j) * 64 + lane] = acc[j];
+    __syncthreads();
+    // column quad c4 of [gi2 (3H) | W2 c (E)] lives at part[w][c4 / 64][c4 % 64]
+    auto colsum = [&](int c4) {
+        float4 t = part[(c4 >> 6) * 64 + (c4 & 63)];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) {
+            const float4 o = part[(w * NA + (c4 >> 6)) * 64 + (c4 & 63)];
+            t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+        }
+        return t;
+    };
+    if (cellt) {
+        const int u4 = threadIdx.x;
+        float gi[3][4];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const float4 t = colsum(g * (H / 4) + u4);
+            gi[g][0] = t.x + bb[g].x; gi[g][1] = t.y + bb[g].y; gi[g][2] = t.z + bb[g].z; gi[g][3] = t.w + bb[g].w;
+        }
+        const float ghr[4] = {hg[0].x, hg[0].y, hg[0].z, hg[0].w}, ghz[4] = {hg[1].x, hg[1].y, hg[1].z, hg[1].w};
+        const float ghn[4] = {hg[2].x, hg[2].y, hg[2].z, hg[2].w}, hpv[4] = {h1.x, h1.y, h1.z, h1.w};
+        float ho[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float rr = vag_sigmoid(gi[0][i] + ghr[i]);
+            const float zz = vag_sigmoid(gi[1][i] + ghz[i]);
+            const float nn = vag_tanh(gi[2][i] + rr * ghn[i]);
+            ho[i] = (1.f - zz) * nn + zz * hpv[i];
+        }
+        *reinterpret_cast<float4*>(hout + n * H + 4 * u4) = make_float4(ho[0], ho[1], ho[2], ho[3]);
+    } else if ((int)threadIdx.x < H / 4 + W2 / 4) {
+        const int e4 = threadIdx.x - H / 4;
+        *reinterpret_cast<float4*>(out2 + n * W2 + 4 * e4) = colsum(64 * NG + e4);
+    }
+}
+// H = 512, E = 256 (configs[1]'s decoder): NG = 6, NW = 1, and source lengths up to 32: one workgroup streams the whole row's keys
+// (11 KB per position) through ONE CU, ~50 GB/s -- measured at 192 rows, us per beam step, fused | two launches (tools/exp_row_gru.py):
+// Ts 12: 87.3 | 89.3, 16: 86.9 | 89.3, 24: 88.0 | 90.6, 32: 89.4 | 91.4, 40: 94.6 | 93.7.  Other shapes: the two launches.
+bool vag_attn_row_gru_ok(int64_t N, int64_t Ts, int64_t H, int64_t W2) {
+    return vag_opt().attn_row != 0 && H == 512 && W2 == 256 && N > 0 && N < (1ll << 30) && Ts > 0 && Ts <= 32;
+}
+int vag_attn_row_gru_launch(const float* pe, const float* q, int64_t ldq, const float* v, const float* mask, const float* keys,
+                            const float* x2, int64_t N, int64_t rps, int64_t Ts, int64_t H, int64_t W2, const float* b_ih,
+                            const float* hp, int64_t ldhp, const float* hprev, float* alpha, float* hout, float* out2, hipStream_t s) {
+    VAG_CHECK_ARG(vag_attn_row_gru_ok(N, Ts, H, W2) && pe && q && v && keys && x2 && b_ih && hp && hprev && hout && out2 && rps >= 1 &&
+                  ldq % 4 == 0 && ldhp % 4 == 0 && aligned16(pe) && aligned16(q) && aligned16(v) && aligned16(keys) && aligned16(x2) &&
+                  aligned16(b_ih) && aligned16(hp) && aligned16(hprev) && aligned16(hout) && aligned16(out2));
+    const size_t lds = (size_t)((Ts + 3) & ~3) * sizeof(float) + (size_t)8 * 7 * 64 * 16;
+    hipLaunchKernelGGL((attn_row_gru_kernel<6, 1>), dim3((unsigned)N), dim3(512), lds, s, pe, q, ldq, v, mask, keys, x2, (int)rps, (int)Ts,
+                       b_ih, hp, ldhp, hprev, alpha, hout, out2);
+    VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
 // ------------------------------------------------------------------ batched over time: out[t,b,:] = sum_s a[t,b,s] x[b,s,:]
 // (the contexts of all steps after the loop) and out[b,s,:] = sum_t a[t,b,s] y[t,b,:] (gradient of the projected keys).
 // grid (ceil(W/256), B, ceil(T/8)) / (ceil(W/256), B, ceil(Ts/8)); thread owns one float4 column, 8 outputs in registers.

@@ -195,6 +195,10 @@ void vag_attn_row_mix_cancel();                                  // ... (a reque
 bool vag_attn_row_mix_done(const float* xmix);               // ... if it could (asked once: resets)
 void vag_persist_dh0_tanh_request(bool on);          // persist.hip: the next decoder backward launch applies (1 - h0^2) to d_h0 ...
 bool vag_persist_dh0_tanh_done(const float* d_h0);   // ... whether it did (asked once: resets)
+bool vag_attn_row_gru_ok(int64_t N, int64_t Ts, int64_t H, int64_t W2);       // attn.hip: a decoding step's attention + gru_2 + W2 c in one launch
+int vag_attn_row_gru_launch(const float* pe, const float* q, int64_t ldq, const float* v, const float* mask, const float* keys,
+                            const float* x2, int64_t N, int64_t rps, int64_t Ts, int64_t H, int64_t W2, const float* b_ih,
+                            const float* hp, int64_t ldhp, const float* hprev, float* alpha, float* hout, float* out2, hipStream_t s);
 void vag_rmw_defer_begin(float* out);      // attn.hip: hold back accumulating outer2 / meanpool_bwd launches into `out` ...
 int vag_rmw_defer_flush(hipStream_t s);    // ... and do them in one pass
 void vag_rmw_defer_abort();
