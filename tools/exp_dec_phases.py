@@ -11,16 +11,20 @@ L.use_lab_build()          # the product library carries no stamp / debug hooks 
 c = bench.CFG2
 dev = torch.device("cuda:0")
 Tt = c["Tt"]
-st = torch.zeros((Tt + 1) * 8, dtype=torch.int64, device=dev)
+st = torch.zeros((Tt + 4) * 8, dtype=torch.int64, device=dev)
 L.set_option("dec_stamps", st.data_ptr())
 fam = bench.measure_operators(c, dev)
 torch.cuda.synchronize()
 L.set_option("dec_stamps", 0)
-raw = st.cpu().numpy().reshape(Tt + 1, 8).astype(np.float64) * 0.01        # us
+raw = st.cpu().numpy().reshape(Tt + 4, 8).astype(np.float64) * 0.01        # us
 s = raw[:Tt]
 pro = raw[Tt]
 print("prologue of workgroup 0 (us): weights -> registers %.2f, keys -> LDS %.2f, entry -> first step %.2f; last step's end - entry %.2f"
       % (pro[1] - pro[0], pro[2] - pro[1], s[0][0] - pro[0], s[Tt - 1][7] - pro[0]))
+nt = (c["B"] + 15) // 16
+t0 = raw[Tt + 1][:nt].min()
+print("row tiles (us after the first entry): entry of workgroup 0 %s, entry of workgroup 63 %s, exit of workgroup 0 %s"
+      % (np.round(raw[Tt + 1][:nt] - t0, 2).tolist(), np.round(raw[Tt + 3][:nt] - t0, 2).tolist(), np.round(raw[Tt + 2][:nt] - t0, 2).tolist()))
 rows = []
 for t in range(1, Tt - 1):
     a = s[t]

@@ -952,6 +952,12 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
 #define VAG_PSTAMP(k) do { } while (0)
 #endif
     VAG_PSTAMP(0);
+#ifdef VAG_LAB          // ... and per row tile: entry and exit of its first workgroup (rows Tt + 1, Tt + 2), entry of its LAST one (row Tt + 3)
+    if (!FREE && a.dbg && threadIdx.x == 0 && rt < 8) {
+        if (i == 0) a.dbg[(Tt + 1) * 8 + rt] = __builtin_amdgcn_s_memrealtime();
+        if (i == DEC_WGS - 1) a.dbg[(Tt + 3) * 8 + rt] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     // ---- weights as bf16 planes in registers (A operands: rows = output columns).  Row of a tile held by lane fr:
     //   cell tiles: tile 0 = [r | z] of the 8 own units (fr < 8: gate r, unit fr; else gate z, unit fr - 8), tile 1 = [n | n again]
     bf16x8 w1[KS][2][3], w2[KS][3][3];
@@ -1460,6 +1466,9 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
         }
         if (tx == 0 && (!VAG_TAGGED || !eok)) arrive(c1 + t * CNT_WORDS, i);
     }
+#ifdef VAG_LAB
+    if (!FREE && a.dbg && threadIdx.x == 0 && i == 0 && rt < 8) a.dbg[(Tt + 2) * 8 + rt] = __builtin_amdgcn_s_memrealtime();
+#endif
 #undef VAG_STAMP
 }
 
