@@ -438,12 +438,13 @@ def test_whole_module_checkpoint_after_shim_steps_and_decoding():
 #     backward) against the separate launches they replace, over the register kernel's position counts (Ts <= 16, 32, 48, 64) and
 #     past them (the generic row kernel).
 # ---------------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("Ts", [9, 16, 17, 33, 48, 52, 64, 70])
-def test_merged_visual_attention_launches_equal_the_separate_ones(Ts):
+@pytest.mark.parametrize("Ts,H", [(9, 512), (16, 512), (17, 512), (33, 512), (48, 512), (52, 512), (64, 512), (70, 512),
+                                  (12, 256), (40, 256), (64, 256)])
+def test_merged_visual_attention_launches_equal_the_separate_ones(Ts, H):
     import bench
     from vagnmt_hip import _lib as L
     from test_gpu_benched_path import _driver, _run_phases
-    c = dict(bench.CFG2, Ts=Ts, Tt=7, B=24)
+    c = dict(bench.CFG2, Ts=Ts, Tt=7, B=24, H=H)       # H = 256: context width 512, the register kernel's other instantiation
     dev = torch.device("cuda", 0)
     m, ts = _driver(c, dropout=False, use_graph=False)
     batch = bench.make_batch(c, 3, dev, ragged=True)
