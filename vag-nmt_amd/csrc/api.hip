@@ -123,7 +123,7 @@ int vag_set_option(const char* name, int64_t value) {
         {"gemm_f32mfma", &o.gemm_f32mfma}, {"gemm_nogroup", &o.gemm_nogroup}, {"gemm_big", &o.gemm_big}, {"gemm_force_tile", &o.gemm_force_tile},
         {"gemm_force_splitk", &o.gemm_force_splitk}, {"head_fuse", &o.head_fuse},
         {"head_bf16_grads", &o.head_bf16_grads}, {"persistent", &o.persistent}, {"persistent_dec_bwd", &o.persistent_dec_bwd}, {"free_persistent", &o.free_persistent}, {"attn_dot_reg", &o.attn_dot_reg},
-        {"persist_timing", &o.persist_timing}, {"s16_one_plane", &o.s16_one_plane}, {"leaf_queue", &o.leaf_queue}, {"attn_row", &o.attn_row}, {"loss_ride", &o.loss_ride}, {"step_fork", &o.step_fork},
+        {"persist_timing", &o.persist_timing}, {"s16_one_plane", &o.s16_one_plane}, {"leaf_queue", &o.leaf_queue}, {"attn_row", &o.attn_row}, {"dec_xcd_map", &o.dec_xcd_map}, {"loss_ride", &o.loss_ride}, {"step_fork", &o.step_fork},
         {"head_bf16_dlogits", &o.head_bf16_dlogits}};
     for (const auto& e : ints)
         if (strcmp(name, e.n) == 0) { *e.p = (int)value; return VAG_OK; }

@@ -866,6 +866,7 @@ struct DecPArgs {
     const uint64_t* rng;        // output dropout (:140-141), NULL / p_out = 0: none
     float p_out;
     int V, ldl;
+    int xcd_map;                // 1: slices dealt so that the blocks of one XCD hold consecutive ones (see the kernel)
 };
 
 // A counter of the decoder kernel is 4 shards, 64 bytes apart (64 arrivals on ONE word serialise at the memory side, ~12 ns
@@ -902,6 +903,19 @@ __device__ __forceinline__ void ld_acc_shards(const float* p0, const float* p1, 
 }
 
 constexpr int DEC_WGS = 64;          // workgroups per row tile
+// Workgroup -> (slice i, row tile rt).  Blocks b and b + 8 share an XCD (round-robin placement: observed, speed only), and consecutive
+// slices share memory lines of the key images the kernels copy into LDS (two slices per 128-byte line of pe, four per line of the
+// projected keys' gate blocks).  So the eight blocks of a row tile that share an XCD take eight CONSECUTIVE slices: the second to
+// fourth reader of a line finds it in that XCD's L2 instead of fetching it again across the fabric (forward kernel, keys into LDS:
+// 11.4 -> 6.6 us per launch, the launch 484.7 -> 469.2 us; optimiser step 2.947 -> 2.934 ms on one box).  Forward kernel only: the same
+// map made the decoder's backward kernel 5 us and the encoder's backward kernel 3 us SLOWER per launch (their exchanged pieces are 32 and
+// 64 bytes: writers of one line on one XCD), the encoder's forward kernel is indifferent.  Giving each row tile the blocks of 8 / RT XCDs,
+// so that its exchanges fill two L2s instead of eight, measured the same as this (2.934 / 2.933): not kept.
+__device__ __forceinline__ void dec_slice_map(int mode, int& i, int& rt) {
+    const int bx = blockIdx.x % DEC_WGS;
+    rt = blockIdx.x / DEC_WGS;
+    i = mode ? (bx & 7) * 8 + (bx >> 3) : bx;
+}
 // The 64 workgroups of a row tile add their shares of a step's scores (forward) / d alpha (backward) with fp32 atomics.  Atomics
 // execute at the memory side and adds to ONE address serialise there (~12 ns each: MI355X_MICROARCH.md, global float atomics /
 // fanin): 64 adders per word kept every wave's atomics outstanding for ~1.1 us.  So the accumulators exist in ACC_SHARDS copies,
@@ -920,7 +934,8 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
     extern __shared__ __attribute__((aligned(16))) float dlds[];
     constexpr int H = DEC_WGS * DEC_U, C = 2 * H, Q = C + 3 * H, KS = 2;       // K share of a wave: H / 8 = 64 = 2 k-steps
     constexpr int E = DEC_E;
-    const int i = blockIdx.x % DEC_WGS, rt = blockIdx.x / DEC_WGS;
+    int i, rt;
+    dec_slice_map(a.xcd_map, i, rt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int B = a.B, Ts = a.Ts, Tt = a.Tt;
     const int m0 = rt * 16, u0 = i * DEC_U;
@@ -1496,6 +1511,7 @@ struct DecBArgs {
     unsigned spin;
     unsigned long long* dbg;    // NULL, or [Tt][8] timestamps of workgroup 0 (tools/exp_dec_bwd_phases.py)
     int B, Ts, Tt, H, RT;
+    int xcd_map;                // as DecPArgs::xcd_map
     int h0_tanh;                // 1: d_h0 leaves as the gradient of the PRE-activation of h0 = tanh(.) (V11.py:118): d_h0 * (1 - h0^2)
 };
 
@@ -1520,7 +1536,8 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
     extern __shared__ __attribute__((aligned(16))) float dlds[];
     constexpr int H = DEC_WGS * DEC_U, C = 2 * H, Q = C + 3 * H;
     constexpr unsigned PER_SHARD = DEC_WGS / SHARDS;
-    const int i = blockIdx.x % DEC_WGS, rt = blockIdx.x / DEC_WGS;
+    int i, rt;
+    dec_slice_map(a.xcd_map, i, rt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int B = a.B, Ts = a.Ts, Tt = a.Tt;
     const int m0 = rt * 16, u0 = i * DEC_U;
@@ -1979,7 +1996,7 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
     a.b_ih2 = b_ih2; a.h1 = h1; a.g1 = g1; a.qhp = qhp; a.alpha = alpha; a.h2_all = h2_all; a.g2 = g2; a.psc = psc;
     a.B = (int)B; a.Ts = (int)Ts; a.Tt = (int)Tt; a.H = (int)H; a.RT = (int)cdiv64(B, 16);
     const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
-    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard();
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard(); a.xcd_map = vag_opt().dec_xcd_map;
 #ifdef VAG_LAB
     a.dbg = reinterpret_cast<unsigned long long*>(vag_opt().dec_stamps);
 #else
@@ -2045,7 +2062,7 @@ int vag_dec_free_persistent_launch(const float* pe, const float* mask, const flo
     a.hw1 = hw1; a.hb1 = hb1; a.hb2 = hb2; a.hb3 = hb3; a.out_w = out_w; a.out_b = out_b; a.tmid = tmid; a.logits = logits;
     a.tok = tok; a.rng = rng; a.p_out = p_out; a.V = (int)V; a.ldl = (int)ldl;
     const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
-    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard();
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard(); a.xcd_map = vag_opt().dec_xcd_map;
 #ifdef VAG_LAB
     a.dbg = reinterpret_cast<unsigned long long*>(vag_opt().dec_stamps);       // (Tt + 1) x 16 words in this form
 #else
@@ -2220,7 +2237,7 @@ int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const flo
 #endif
     a.B = (int)B; a.Ts = (int)Ts; a.Tt = (int)Tt; a.H = (int)H; a.RT = (int)cdiv64(B, 16);
     const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
-    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard();
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard(); a.xcd_map = 0;      // (measured: the backward kernel is 5 us SLOWER per launch with the forward kernel's slice map)
     const int nsc = (int)(Tt * B * Ts) * ACC_SHARDS;
     if (!g_prezeroed) {
         hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64((int64_t)nwords + nsc, 256)), dim3(256), 0, s, sync, nwords,
