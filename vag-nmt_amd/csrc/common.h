@@ -125,7 +125,8 @@ struct VagOptions {
     int leaf_queue = 1;          // 0: the small weight-gradient products of the VSE / initial-state backward go out one by one (round 4)
     int attn_row = 1;            // 0: the visual-grounding attention as separate scores / softmax / context launches (rounds 1-4)
     int loss_ride = 1;           // 0: the loss reduction of a training step is its own launch (rounds 1-4)
-    int dec_xcd_map = 1;         // 0: the persistent decoder forward kernel deals its slices in block order (rounds 3-5), 1: consecutive slices per XCD
+    int dec_xcd_map = 33;        // slice placement of the persistent decoder kernels (persist.hip: dec_slice_map), forward | backward << 4;
+                                 // 0: block order (rounds 3-5), 1 / 2 / 3: eight / two / four consecutive slices per XCD
     int step_fork = 0;           // side-stream branches inside vag_train_step, bit 0: the image projection beside the encoder, bit 1: the
                                  // held-back weight-gradient leaves beside the encoder's backward.  Off: measured SLOWER
     int64_t persist_spin_limit = 0;   // > 0: polls before a persistent kernel's wait gives up (default 2^19); tests force a give-up with 1

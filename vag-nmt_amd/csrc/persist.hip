@@ -905,16 +905,19 @@ __device__ __forceinline__ void ld_acc_shards(const float* p0, const float* p1, 
 constexpr int DEC_WGS = 64;          // workgroups per row tile
 // Workgroup -> (slice i, row tile rt).  Blocks b and b + 8 share an XCD (round-robin placement: observed, speed only), and consecutive
 // slices share memory lines of the key images the kernels copy into LDS (two slices per 128-byte line of pe, four per line of the
-// projected keys' gate blocks).  So the eight blocks of a row tile that share an XCD take eight CONSECUTIVE slices: the second to
-// fourth reader of a line finds it in that XCD's L2 instead of fetching it again across the fabric (forward kernel, keys into LDS:
-// 11.4 -> 6.6 us per launch, the launch 484.7 -> 469.2 us; optimiser step 2.947 -> 2.934 ms on one box).  Forward kernel only: the same
-// map made the decoder's backward kernel 5 us and the encoder's backward kernel 3 us SLOWER per launch (their exchanged pieces are 32 and
-// 64 bytes: writers of one line on one XCD), the encoder's forward kernel is indifferent.  Giving each row tile the blocks of 8 / RT XCDs,
-// so that its exchanges fill two L2s instead of eight, measured the same as this (2.934 / 2.933): not kept.
+// projected keys' gate blocks) and of the pieces they exchange.  In block order every line crossed the fabric once per slice.
+// mode 1: the eight blocks of a row tile that share an XCD take eight CONSECUTIVE slices -- the second to fourth reader of a line
+// finds it in that XCD's L2 (forward kernel, keys into LDS: 11.4 -> 6.6 us per launch, the launch 484.7 -> 469.2 us; optimiser step
+// -10..13 us on three boxes).  The backward kernel is 0..5 us per launch SLOWER with it (its 32- and 64-byte pieces are WRITTEN by
+// neighbouring slices under a drained hand-off) and 5-9 us faster with PAIRS of consecutive slices per XCD (mode 2: 832.7 / 833.7 /
+// 834.8 -> 829.7 / 828.0 / 829.3 us, one box, alternating runs); four per XCD (mode 3) and pairs for the forward kernel are within
+// noise of those.  One row tile per XCD pair (its exchanges into two L2s instead of eight) measured the same as mode 1: not kept.
+// The encoder's kernels: no gain (forward) / +3 us (backward) with mode 1: they keep block order.
 __device__ __forceinline__ void dec_slice_map(int mode, int& i, int& rt) {
     const int bx = blockIdx.x % DEC_WGS;
     rt = blockIdx.x / DEC_WGS;
-    i = mode ? (bx & 7) * 8 + (bx >> 3) : bx;
+    const int g = mode == 1 ? 8 : (mode == 2 ? 2 : (mode == 3 ? 4 : 1));      // consecutive slices per XCD
+    i = (bx & 7) * g + ((bx >> 3) % g) + 8 * g * (bx / (8 * g));
 }
 // The 64 workgroups of a row tile add their shares of a step's scores (forward) / d alpha (backward) with fp32 atomics.  Atomics
 // execute at the memory side and adds to ONE address serialise there (~12 ns each: MI355X_MICROARCH.md, global float atomics /
@@ -1996,7 +1999,7 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
     a.b_ih2 = b_ih2; a.h1 = h1; a.g1 = g1; a.qhp = qhp; a.alpha = alpha; a.h2_all = h2_all; a.g2 = g2; a.psc = psc;
     a.B = (int)B; a.Ts = (int)Ts; a.Tt = (int)Tt; a.H = (int)H; a.RT = (int)cdiv64(B, 16);
     const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
-    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard(); a.xcd_map = vag_opt().dec_xcd_map;
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard(); a.xcd_map = vag_opt().dec_xcd_map & 15;
 #ifdef VAG_LAB
     a.dbg = reinterpret_cast<unsigned long long*>(vag_opt().dec_stamps);
 #else
@@ -2062,7 +2065,7 @@ int vag_dec_free_persistent_launch(const float* pe, const float* mask, const flo
     a.hw1 = hw1; a.hb1 = hb1; a.hb2 = hb2; a.hb3 = hb3; a.out_w = out_w; a.out_b = out_b; a.tmid = tmid; a.logits = logits;
     a.tok = tok; a.rng = rng; a.p_out = p_out; a.V = (int)V; a.ldl = (int)ldl;
     const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
-    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard(); a.xcd_map = vag_opt().dec_xcd_map;
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard(); a.xcd_map = vag_opt().dec_xcd_map & 15;
 #ifdef VAG_LAB
     a.dbg = reinterpret_cast<unsigned long long*>(vag_opt().dec_stamps);       // (Tt + 1) x 16 words in this form
 #else
@@ -2237,7 +2240,7 @@ int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const flo
 #endif
     a.B = (int)B; a.Ts = (int)Ts; a.Tt = (int)Tt; a.H = (int)H; a.RT = (int)cdiv64(B, 16);
     const int nwords = (int)vag_dec_persistent_sync_words(B, Tt);
-    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard(); a.xcd_map = 0;      // (measured: the backward kernel is 5 us SLOWER per launch with the forward kernel's slice map)
+    a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard(); a.xcd_map = vag_opt().dec_xcd_map >> 4;
     const int nsc = (int)(Tt * B * Ts) * ACC_SHARDS;
     if (!g_prezeroed) {
         hipLaunchKernelGGL(zero2_u32_kernel, dim3((unsigned)cdiv64((int64_t)nwords + nsc, 256)), dim3(256), 0, s, sync, nwords,
