@@ -20,12 +20,15 @@ src, lens, tgt, im = bench.make_batch(c, 0, dev)
 lt = torch.tensor(lens, dtype=torch.int32, device=dev)
 for _ in range(3):
     ts.step(src, lt, tgt, im, teacher=True)
-st = torch.zeros(Tt * 8, dtype=torch.int64, device=dev)
+st = torch.zeros((Tt + 1) * 8, dtype=torch.int64, device=dev)
 L.set_option("dec_bwd_stamps", st.data_ptr())
 ts.step(src, lt, tgt, im, teacher=True)
 torch.cuda.synchronize()
 L.set_option("dec_bwd_stamps", 0)
-s = st.cpu().numpy().reshape(Tt, 8).astype(np.float64) * 0.01
+raw = st.cpu().numpy().reshape(Tt + 1, 8).astype(np.float64) * 0.01
+s = raw[:Tt]
+pro = raw[Tt]
+print("workgroup 0 (us): entry -> images in LDS %.2f, entry -> first stamp of step Tt-2 %.2f, entry -> exit %.2f" % (pro[1] - pro[0], s[Tt - 2][0] - pro[0], pro[2] - pro[0]))
 rows = []
 for t in range(Tt - 2, 0, -1):          # steps run Tt-1 .. 0; the next step after t is t-1
     a = s[t]

@@ -1543,6 +1543,12 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
     dec_slice_map(a.xcd_map, i, rt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int B = a.B, Ts = a.Ts, Tt = a.Tt;
+#ifdef VAG_LAB          // prologue / exit stamps of block 0 in rows Tt .. of the stamp array (tools/exp_dec_bwd_phases.py)
+#define VAG_BPSTAMP(k) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[Tt * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define VAG_BPSTAMP(k) do { } while (0)
+#endif
+    VAG_BPSTAMP(0);
     const int m0 = rt * 16, u0 = i * DEC_U;
     const int fr = lane & 15, fg = lane >> 4;
     const int64_t BH = (int64_t)B * H;
@@ -1625,6 +1631,7 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
         x[0] = sum.x; x[1] = sum.y; x[2] = sum.z; x[3] = sum.w;
     };
 
+    VAG_BPSTAMP(1);
     // ---- step Tt-1: nothing arrives from a later step
     if (ep) {
         if (eok) {
@@ -1837,6 +1844,7 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
         }
         __syncthreads();
     }
+    VAG_BPSTAMP(2);
 #undef VAG_STAMP
 }
 
