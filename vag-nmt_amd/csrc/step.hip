@@ -120,6 +120,8 @@ struct PrezeroScope {       // the recurrence kernels of this call find their co
         vag_persist_set_prezeroed(false); vag_step_set_zeroed(false); vag_step_set_gathered(false);
         vag_gemm_prezeroed_set(0, nullptr); vag_gemm_prezeroed_set(1, nullptr);
         (void)vag_loss_defer_flush();       // (an error return between the head's forward and backward: the loss is still written)
+        // requests of this call that nobody consumed (an error return in between) must not outlive it
+        (void)vag_attn_row_mix_done(nullptr); (void)vag_persist_dh0_tanh_done(nullptr); vag_attn_row_mix_cancel();
     }
 };
 struct DerivedScope {       // points the operators at the driver's derived weights, storage mode and head chunk for one call
