@@ -902,6 +902,34 @@ __device__ __forceinline__ void ld_acc_shards(const float* p0, const float* p1, 
     v1 = (b0 + b1) + (b2 + b3);
 }
 
+// ld_acc_shards and the six k-steps of a wave's share of a handed-off row (ld_rows_sc1<6>) in ONE statement: the decoder backward
+// requests the dgh2 rows of its hidden-side product together with the d-alpha words of phase B, one round of memory latency for both
+// (the rows then wait in registers through phase B instead of costing the hidden-side product a round trip of its own).
+// 12 + 8 outputs + 9 addresses: 29 operands, the asm statement's limit is 30.
+__device__ __forceinline__ void ld_acc_shards_and_rows6(const float* p0, const float* p1, int64_t stride, float& v0, float& v1,
+                                                        const float* rows, float4 (&a)[6], float4 (&b)[6]) {
+    float a0, a1, a2, a3, b0, b1, b2, b3;
+    const float *p02 = p0 + 2 * stride, *p12 = p1 + 2 * stride;
+    const float *p01 = p0 + stride, *p03 = p02 + stride, *p11 = p1 + stride, *p13 = p12 + stride;
+    asm volatile("global_load_dword %0, %20, off sc1\n\tglobal_load_dword %1, %21, off sc1\n\t"
+                 "global_load_dword %2, %22, off sc1\n\tglobal_load_dword %3, %23, off sc1\n\t"
+                 "global_load_dword %4, %24, off sc1\n\tglobal_load_dword %5, %25, off sc1\n\t"
+                 "global_load_dword %6, %26, off sc1\n\tglobal_load_dword %7, %27, off sc1\n\t"
+                 "global_load_dwordx4 %8, %28, off sc1\n\tglobal_load_dwordx4 %9, %28, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %10, %28, off offset:128 sc1\n\tglobal_load_dwordx4 %11, %28, off offset:144 sc1\n\t"
+                 "global_load_dwordx4 %12, %28, off offset:256 sc1\n\tglobal_load_dwordx4 %13, %28, off offset:272 sc1\n\t"
+                 "global_load_dwordx4 %14, %28, off offset:384 sc1\n\tglobal_load_dwordx4 %15, %28, off offset:400 sc1\n\t"
+                 "global_load_dwordx4 %16, %28, off offset:512 sc1\n\tglobal_load_dwordx4 %17, %28, off offset:528 sc1\n\t"
+                 "global_load_dwordx4 %18, %28, off offset:640 sc1\n\tglobal_load_dwordx4 %19, %28, off offset:656 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3),
+                   "=&v"(a[0]), "=&v"(b[0]), "=&v"(a[1]), "=&v"(b[1]), "=&v"(a[2]), "=&v"(b[2]), "=&v"(a[3]), "=&v"(b[3]),
+                   "=&v"(a[4]), "=&v"(b[4]), "=&v"(a[5]), "=&v"(b[5])
+                 : "v"(p0), "v"(p01), "v"(p02), "v"(p03), "v"(p1), "v"(p11), "v"(p12), "v"(p13), "v"(rows) : "memory");
+    v0 = (a0 + a1) + (a2 + a3);
+    v1 = (b0 + b1) + (b2 + b3);
+}
+
 constexpr int DEC_WGS = 64;          // workgroups per row tile
 // Workgroup -> (slice i, row tile rt).  Blocks b and b + 8 share an XCD (round-robin placement: observed, speed only), and consecutive
 // slices share memory lines of the key images the kernels copy into LDS (two slices per 128-byte line of pe, four per line of the
@@ -1673,6 +1701,9 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
         if (threadIdx.x == 0) arrive(cA + t * CNT_WORDS, i);
         VAG_STAMP(1);
         // operands of phase B that do not depend on the hand-off
+        float4 hga[KC], hgb[KC];                                // dgh2 rows of the hidden-side product, requested in phase B (its weight rows
+                                                                // too: 70 instead of 18 spilled registers -- they stay where they are used)
+        static_assert(KC == 6, "ld_acc_shards_and_rows6");
         float al0 = 0.f, al1 = 0.f, dh0 = 0.f, dh1_ = 0.f;
         const int x0 = threadIdx.x, x1 = threadIdx.x + 512;
         {
@@ -1688,7 +1719,9 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
             float v0, v1;
             const float* p0 = a.dal + o0 + (int64_t)t * (ACC_SHARDS - 1) * B * Ts;      // (o0 = (t B + row) Ts + s: shard 0 of step t)
             const float* p1 = a.dal + o1 + (int64_t)t * (ACC_SHARDS - 1) * B * Ts;
-            ld_acc_shards(p0, p1, (int64_t)B * Ts, v0, v1);
+            // (with them: this wave's share of the dgh2 rows for the hidden-side product below -- complete since cA as well)
+            ld_acc_shards_and_rows6(p0, p1, (int64_t)B * Ts, v0, v1,
+                                    a.dqgh + ((int64_t)t * B + lrow) * Q + C + wave * (3 * H >> 3) + 8 * (lane & 3), hga, hgb);
             if (x0 < NP) { da_s[x0] = v0 + dh0; al_s[x0] = al0; }
             if (x1 < NP) { da_s[x1] = v1 + dh1_; al_s[x1] = al1; }
             __syncthreads();
@@ -1729,16 +1762,12 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
         // ---- beside that hand-off: hidden side of dh1 for the own units, dgh2[t] W_hh2 + z2 * dh2 (dgh2 rows: complete since cA)
         {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            float4 ga[KC], gb[KC];
-            ld_rows_sc1<KC>(a.dqgh + ((int64_t)t * B + lrow) * Q + C + wave * (3 * H >> 3) + 8 * (lane & 3), ga, gb);
-#pragma unroll
-            for (int s = 0; s < KC; ++s) { ga[s] = perm4(ga[s], src4); gb[s] = perm4(gb[s], src4); }
 #pragma unroll
             for (int s = 0; s < KC; ++s) {
                 bf16x8 wf[3], hf[3];
                 split8(perm4(*reinterpret_cast<const float4*>(wa_row + 32 * s), src4),
                        perm4(*reinterpret_cast<const float4*>(wa_row + 32 * s + 4), src4), wf);
-                split8(ga[s], gb[s], hf);
+                split8(perm4(hga[s], src4), perm4(hgb[s], src4), hf);
                 acc = mma6(wf, hf, acc);
             }
             red[wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
