@@ -1712,7 +1712,7 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
             const int64_t o1 = ((int64_t)t * B + min(m0 + r1, B - 1)) * Ts + (min(x1, NP - 1) - r1 * Ts);
             al0 = a.alpha[o0]; dh0 = a.dah[o0];
             if (x1 < NP) { al1 = a.alpha[o1]; dh1_ = a.dah[o1]; }
-            const float qv = threadIdx.x < 256 ? a.qhp[((int64_t)t * B + min(m0 + (int)(threadIdx.x >> 4), B - 1)) * Q + 16 * i + (threadIdx.x & 15)] : 0.f;
+            const float qv = a.qhp[((int64_t)t * B + min(m0 + (int)((threadIdx.x & 255) >> 4), B - 1)) * Q + 16 * i + (threadIdx.x & 15)];
             // ================= B: complete d alpha -> ds -> dq of the own query columns =================
             wait_count(cA + t * CNT_WORDS, PER_SHARD, a.err, a.guard, a.spin, dead);
             VAG_STAMP(2);
@@ -1736,19 +1736,23 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
                 }
             }
             __syncthreads();
-            if (threadIdx.x < 256) {
-                const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+            {   // thread (half, row r, column c): the positions of its parity; the halves meet in the (idle) reduction space
+                const int tt = threadIdx.x & 255, half = threadIdx.x >> 8;
+                const int r = tt >> 4, c = tt & 15;
                 const float* pr = pe_s + (int64_t)r * Ts * 16 + c;
                 const float* dsr = da_s + r * Ts;
                 float acc0 = 0.f, acc1 = 0.f;
-                int sp = 0;
-                for (; sp + 1 < Ts; sp += 2) {
-                    const float t0 = vag_tanh(pr[sp * 16] + qv), t1 = vag_tanh(pr[(sp + 1) * 16] + qv);
+                int sp = half;
+                for (; sp + 2 < Ts; sp += 4) {
+                    const float t0 = vag_tanh(pr[sp * 16] + qv), t1 = vag_tanh(pr[(sp + 2) * 16] + qv);
                     acc0 += dsr[sp] * (1.f - t0 * t0);
-                    acc1 += dsr[sp + 1] * (1.f - t1 * t1);
+                    acc1 += dsr[sp + 2] * (1.f - t1 * t1);
                 }
                 if (sp < Ts) { const float t0 = vag_tanh(pr[sp * 16] + qv); acc0 += dsr[sp] * (1.f - t0 * t0); }
-                dq_s[threadIdx.x] = (acc0 + acc1) * vq;
+                float* half_s = reinterpret_cast<float*>(red);
+                if (half) half_s[tt] = acc0 + acc1;
+                __syncthreads();
+                if (!half) dq_s[tt] = ((acc0 + acc1) + half_s[tt]) * vq;
             }
             __syncthreads();
             if (threadIdx.x < 64) {                             // 16 rows x 4 column quads: one 16-byte sc1 store each
