@@ -764,6 +764,77 @@ def pmc_step(cfg):
     return None
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n, argv, smoke_dp=False):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N bench.py <same argv>` in a CHILD process and relay its output and exit code.  This process has made no HIP call
+    (torch.cuda.device_count() does not initialise the GPU on this image) and makes none: a process that has touched the GPU must
+    not be replaced, and the ranks must each own their device.  Returns the exit code.  The reference has no launcher of its own
+    (its nn.DataParallel lines are commented out: nmt_multimodal_beam_DE.py:277-282)."""
+    import subprocess
+    if not smoke_dp and os.environ.get("VAG_BENCH_LAUNCH_ONLY") != "1":
+        have = torch.cuda.device_count()
+        if have < n:
+            print("bench.py: --gpus %d but this node shows %d GPU(s); not measuring fewer ranks than asked for" % (n, have),
+                  file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL's buffer exchange between the ranks needs it here
+    env.setdefault("OMP_NUM_THREADS", "4")
+    port = int(env.get("MASTER_PORT") or _free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("[bench] launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for ln in proc.stdout:                 # rank 0's one JSON line (anything else a rank prints to stdout goes to stderr here)
+        lines.append(ln)
+    rc = proc.wait()
+    result = None
+    for ln in lines:
+        t = ln.strip()
+        if t.startswith("{") and '"n_gpus"' in t:
+            result = t
+        else:
+            sys.stderr.write(ln)
+    if rc != 0:
+        print("bench.py: the %d-rank run exited with code %d" % (n, rc), file=sys.stderr)
+        return rc
+    if result is None:
+        print("bench.py: the %d-rank run printed no result line" % n, file=sys.stderr)
+        return 3
+    if json.loads(result).get("n_gpus") != n:
+        print("bench.py: the result line says n_gpus=%r, asked for %d" % (json.loads(result).get("n_gpus"), n), file=sys.stderr)
+        return 4
+    print(result, flush=True)
+    return 0
+
+
+def launch_only(rank, world, args):
+    """VAG_BENCH_LAUNCH_ONLY=1 (CPU tests of the launcher): every rank joins a gloo group, the ranks are gathered, rank 0 prints a
+    line with what a real line would say about the job's shape -- no model, no GPU, no measurement (`value` is null)."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        got = [None] * world
+        dist.all_gather_object(got, (rank, os.getpid()))
+    else:
+        got = [(rank, os.getpid())]
+    if rank == 0:
+        print(json.dumps({"metric": "launch check only", "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ranks": sorted(r for r, _ in got), "pids": len({p for _, p in got}), "launch_only": True}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -784,6 +855,10 @@ def main():
                          "communicator (vag_comm_*, include/vag_nmt.h)")
     ap.add_argument("--buckets", type=int, choices=[2, 3], default=2,
                     help="multi-GPU: gradient buckets (3 = a third cut after the decoder's backward, TrainStep(three_buckets=True))")
+    ap.add_argument("--dp-encoder-chain", action="store_true",
+                    help="multi-GPU A/B: the encoder's backward recurrence (the only persistent kernel of the phase that runs beside "
+                         "bucket 0's all-reduce) as a launch chain; every other recurrence stays one launch (persistent_enc_bwd=0)")
+    ap.add_argument("--single-window", action="store_true", help="time ONE window of K steps even when K < 100")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="library option for A/B runs (vag_set_option), e.g. --opt persistent=0")
     ap.add_argument("--config", choices=["cfg2", "cfg5", "cfg5-f32", "cfg1"], default="cfg2",
@@ -791,13 +866,24 @@ def main():
                          "V=40k) with fp16 storage of the per-step streams; cfg5-f32 = the same sizes, fp32 storage")
     args = ap.parse_args()
 
+    # VAG_DP_SMOKE=1: rehearse the multi-rank code path on ONE GPU (all ranks on cuda:0, gloo transport)
+    smoke_dp = os.environ.get("VAG_DP_SMOKE") == "1"
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks (it never touches the GPU itself)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], smoke_dp))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    # VAG_DP_SMOKE=1: rehearse the multi-rank code path on ONE GPU (all ranks on cuda:0, gloo transport)
-    smoke_dp = os.environ.get("VAG_DP_SMOKE") == "1"
+    if world != args.gpus:
+        # never a line whose n_gpus differs from --gpus
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or plain "
+                         "`python bench.py --gpus %d`, which starts the ranks itself)" % (args.gpus, world, args.gpus, args.gpus))
+    if not smoke_dp and os.environ.get("VAG_BENCH_LAUNCH_ONLY") != "1" and torch.cuda.device_count() < max(world, local_rank + 1):
+        raise SystemExit("bench.py: --gpus %d but this node shows %d GPU(s)" % (args.gpus, torch.cuda.device_count()))
+    if os.environ.get("VAG_BENCH_LAUNCH_ONLY") == "1":
+        return launch_only(rank, world, args)
     if smoke_dp:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -823,6 +909,8 @@ def main():
     for kv in args.opt:
         name, val = kv.split("=", 1)
         _L.set_option(name, int(val))
+    if args.dp_encoder_chain and world > 1:
+        _L.set_option("persistent_enc_bwd", 0)
     if smoke_dp:
         # several ranks share ONE GPU here: the persistent recurrence kernels need every workgroup of their grid resident
         # (one per CU), which two processes cannot both have -- their bounded waits would give up.  Launch chains instead.
@@ -869,18 +957,26 @@ def main():
         if i < 6:
             torch.cuda.synchronize()
             log("warm-up step %d done (loss %.4f)" % (i, float(out[0].item())))
-    barrier()
-    log("timing %d steps" % args.steps)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = ts.step(src, lens_t, tgt, im)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # The timed region: exactly K steps between barrier + synchronize on both sides, the maximum over the ranks.  A short region
+    # (K < 100: 20 steps are a 58 ms window, and boxes differ by several per cent run to run) is timed FIVE times back to back,
+    # each window exactly K steps with the same brackets; the line reports the median window and the spread of the five.
+    n_windows = 5 if args.steps < 100 and not args.single_window else 1
+    windows = []
+    for wi in range(n_windows):
+        barrier()
+        log("timing %d steps (window %d of %d)" % (args.steps, wi + 1, n_windows))
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = ts.step(src, lens_t, tgt, im)
+        barrier()
+        dtw = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dtw], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtw = float(t.item())
+        windows.append(dtw)
+    dt = sorted(windows)[len(windows) // 2]
     loss = float(out[0].item())
 
     log("timed region done: %.3f ms/step" % (dt / args.steps * 1e3))
@@ -913,7 +1009,9 @@ def main():
                    "per_rank_ms_per_step_without_allreduce": [float(x[1]) for x in allv],
                    "exposed_comm_ms": max(float(x[0]) for x in allv) - max(float(x[1]) for x in allv),
                    "gradient_bytes": ts.fp.n * 4, "buckets_bytes": [(hi - lo) * 4 for lo, hi in ts.fp.buckets()],
-                   "backend": dist.get_backend(), "steps": n}
+                   "backend": dist.get_backend(), "steps": n, "comm": args.comm, "buckets": args.buckets,
+                   "encoder_backward": "launch chain (--dp-encoder-chain)" if args.dp_encoder_chain else "persistent kernel",
+                   "persistent_kernels": not smoke_dp}
         if rank == 0:
             import glob
             lines = []
@@ -932,7 +1030,8 @@ def main():
         # configs[4] prices every streamed element at 2 bytes (F_dec = 199.3 MB)
         ab = algorithmic_bytes(c, w=2 if args.config == "cfg5" else 4)
         if args.no_operators:
-            print(json.dumps({"ms_per_step": dt / args.steps * 1e3, "final_loss": loss}))
+            print(json.dumps({"ms_per_step": dt / args.steps * 1e3, "final_loss": loss, "n_gpus": world, "steps": args.steps,
+                              "value": c["B"] * world * args.steps / dt, "dp": dp_info}))
             if world > 1:
                 import torch.distributed as dist
                 dist.barrier()
@@ -955,6 +1054,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "spread_ms": (max(windows) - min(windows)) / args.steps * 1e3,
+            "windows_ms_per_step": [w / args.steps * 1e3 for w in windows],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

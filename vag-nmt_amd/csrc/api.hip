@@ -122,7 +122,7 @@ int vag_set_option(const char* name, int64_t value) {
     const struct { const char* n; int* p; } ints[] = {
         {"gemm_f32mfma", &o.gemm_f32mfma}, {"gemm_nogroup", &o.gemm_nogroup}, {"gemm_big", &o.gemm_big}, {"gemm_force_tile", &o.gemm_force_tile},
         {"gemm_force_splitk", &o.gemm_force_splitk}, {"head_fuse", &o.head_fuse},
-        {"head_bf16_grads", &o.head_bf16_grads}, {"persistent", &o.persistent}, {"persistent_dec_bwd", &o.persistent_dec_bwd}, {"free_persistent", &o.free_persistent}, {"attn_dot_reg", &o.attn_dot_reg},
+        {"head_bf16_grads", &o.head_bf16_grads}, {"persistent", &o.persistent}, {"persistent_dec_bwd", &o.persistent_dec_bwd}, {"persistent_enc_bwd", &o.persistent_enc_bwd}, {"free_persistent", &o.free_persistent}, {"attn_dot_reg", &o.attn_dot_reg},
         {"persist_timing", &o.persist_timing}, {"s16_one_plane", &o.s16_one_plane}, {"leaf_queue", &o.leaf_queue}, {"attn_row", &o.attn_row}, {"dec_xcd_map", &o.dec_xcd_map}, {"loss_ride", &o.loss_ride}, {"step_fork", &o.step_fork},
         {"head_bf16_dlogits", &o.head_bf16_dlogits}};
     for (const auto& e : ints)
@@ -307,8 +307,9 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
             VAG_TRY(vag_transpose_launch(g.w_hh, 3 * H, H, w.whhT + d * 3 * H * H, s));
         }
     }
-    const bool wide16 = s16 && vag_opt().persistent && vag_enc_wide16_ok(B, Ts, H) && B >= 64;
-    const bool persist = wide16 || (!s16 && vag_opt().persistent && H == 512 && vag_enc_persistent_ok(B, Ts, H));
+    const bool pers_on = vag_opt().persistent && vag_opt().persistent_enc_bwd;
+    const bool wide16 = s16 && pers_on && vag_enc_wide16_ok(B, Ts, H) && B >= 64;
+    const bool persist = wide16 || (!s16 && pers_on && H == 512 && vag_enc_persistent_ok(B, Ts, H));
     if (wide16) {
         // 2-byte mode, wide batches: the twin of the forward's one-launch kernel (fp16 W_hh^T slice in registers, gate gradients
         // exchanged as fp16 x 2^12 -- what the chain's fp16-pipe product rounds them to)

@@ -117,6 +117,8 @@ struct VagOptions {
     int head_bf16_grads = 1;     // 2-byte storage mode: one bf16 plane in the head's two vocabulary-sized gradient products
     int persistent = 1;          // 0: the recurrences always run as chains of per-step launches (persist.hip off)
     int persistent_dec_bwd = 1;  // 0: only the decoder's backward recurrence stays a launch chain
+    int persistent_enc_bwd = 1;  // 0: only the encoder's backward recurrence stays a launch chain (data parallelism: the one persistent
+                                 // kernel that shares its window with a collective's kernels -- bench.py --dp-encoder-chain)
     int attn_dot_reg = 1;        // 0: the per-step score / d-alpha reductions of the launch chains keep the round-2 kernel (q re-read per position)
     int free_persistent = 1;     // 0: free-running decoder steps (and greedy decoding) stay chains of per-step launches
     int s16_one_plane = 1;       // 2-byte storage mode of the step driver: forward products on ONE fp16 plane, gradient products on
