@@ -74,3 +74,51 @@ def test_argument_errors_are_negative_codes_not_crashes():
                                       None) == -22
     assert L.vag_head_logits_parts_count(_lib.HeadW(), 192, 256, 9391) == 0        # no weights: nothing to take
     assert L.vag_cgru_free_supported(64, 40, 40, 256, 512, 9391) in (0, 1)          # (0 without a device: the CU count decides)
+
+
+def test_host_side_under_sanitizers():
+    """`make asan` (csrc/Makefile): the host pass of every translation unit under AddressSanitizer + UBSan, the device code untouched
+    (host-side sanitizer build; GPU sanitizers do not exist on this pool).  The ABI and host-logic tests of this
+    directory run against that library in a child process with the sanitizer runtime preloaded: the argument checks, workspace layout
+    arithmetic, group planner and the thread-local request state are what it watches.  Any report makes the child exit non-zero."""
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "vag-nmt_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "asan", "-j8"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    so = os.path.join(ROOT, "vag-nmt_amd", "lib", "libvagnmt_asan.so")
+    rt = subprocess.run(["/opt/rocm/lib/llvm/bin/clang", "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True,
+                        text=True).stdout.strip()
+    assert os.path.isfile(so) and os.path.isfile(rt), (so, rt)
+    env = dict(os.environ, VAG_LIB=so, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    code = "\n".join([
+        "import sys, ctypes as C",
+        "sys.path[:0] = [%r, %r]" % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "vag-nmt_amd")),
+        "import test_abi as T",
+        "from vagnmt_hip import _lib",
+        "assert _lib.LIB_PATH.endswith('libvagnmt_asan.so')",
+        "T.test_library_exports_every_declared_symbol()",
+        "T.test_workspace_size_queries_are_pure_host_calls()",
+        "T.test_argument_errors_are_negative_codes_not_crashes()",
+        "L = _lib.lib()",
+        "# the grouped-product planner (host code with its own scratch vectors) over many random groups",
+        "import random",
+        "random.seed(0)",
+        "for _ in range(300):",
+        "    n = random.randint(1, 12)",
+        "    M = (C.c_int64 * n)(*[random.choice([64, 512, 1536, 2560, 9391]) for _ in range(n)])",
+        "    N = (C.c_int64 * n)(*[random.choice([64, 256, 512, 1024, 3072]) for _ in range(n)])",
+        "    K = (C.c_int64 * n)(*[random.choice([64, 256, 2560, 5120]) for _ in range(n)])",
+        "    acc = (C.c_int * n)(*[random.randint(0, 1) for _ in range(n)])",
+        "    split, order = (C.c_int * n)(), (C.c_int * n)()",
+        "    assert L.vag_gemm_group_plan(n, M, N, K, acc, split, order) == 0",
+        "    assert sorted(order) == list(range(n)) and all(s >= 1 for s in split)",
+        "for name in ('persistent', 'leaf_queue', 'head_chunk', 'persist_spin_limit', 'persistent_enc_bwd'):",
+        "    assert L.vag_set_option(name.encode(), 1) == 0",
+        "assert L.vag_set_option(b'no_such_option', 1) == -22",
+        "L.vag_set_option(b'head_chunk', -1); L.vag_set_option(b'persist_spin_limit', 0)",
+        "print('SANITIZED-OK')"])
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SANITIZED-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr, r.stderr[-3000:]

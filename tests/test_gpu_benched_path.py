@@ -21,6 +21,7 @@ if ROOT not in sys.path:
 pytestmark = pytest.mark.gpu
 
 LOSS_TOL, GRAD_TOL = 1e-4, 3e-4
+GRAD_L2_TOL = 1e-3          # per tensor: ||g - g_oracle||_2 <= 1e-3 ||g_oracle||_2 and cos(g, g_oracle) >= 1 - 1e-6
 
 
 def _driver(c, dropout, **kw):
@@ -48,7 +49,11 @@ def _oracle(m, batch, masks=None, hoist=True, ckpt=False, threads=None):
     return {k: float(out[k]) for k in ("loss", "loss_mt", "loss_vse")}, grads
 
 
-def _check(tag, losses, grads, want_l, want_g, ltol=LOSS_TOL, gtol=GRAD_TOL):
+RL2_SEEN = [0.0]          # largest per-tensor relative L2 error met by _check in this process (printed by the last test of the file)
+
+
+def _check(tag, losses, grads, want_l, want_g, ltol=LOSS_TOL, gtol=GRAD_TOL, l2tol=None):
+    l2tol = GRAD_L2_TOL if l2tol is None else l2tol
     for i, k in enumerate(("loss", "loss_mt", "loss_vse")):
         assert abs(losses[i] - want_l[k]) <= ltol * max(1.0, abs(want_l[k])), (tag, k, losses[i], want_l[k])
     worst = (0.0, None)
@@ -58,6 +63,19 @@ def _check(tag, losses, grads, want_l, want_g, ltol=LOSS_TOL, gtol=GRAD_TOL):
         if rel > worst[0]:
             worst = (rel, n)
         assert rel <= gtol, (tag, n, err, ref.abs().max().item())
+        # round 6: a bound relative to the tensor's LARGEST entry says little about tensors whose entries
+        # are all small (the biases of the visual-grounding branch at loss weight 0.01) -- so, per tensor, also the relative L2
+        # error and the cosine against the oracle's gradient, which do not depend on the tensor's scale
+        g, r = grads[n].detach().cpu().double().flatten(), ref.double().flatten()
+        rn = r.norm().item()
+        if rn > 0.0:
+            rl2 = (g - r).norm().item() / rn
+            cos = (g @ r).item() / max(g.norm().item() * rn, 1e-300)
+            RL2_SEEN[0] = max(RL2_SEEN[0], rl2)
+            assert rl2 <= l2tol and cos >= 1.0 - l2tol * l2tol, (tag, n, "relative L2", rl2, "cosine", cos, "norm", rn)
+        else:
+            assert g.abs().max().item() <= 1e-12, (tag, n, "oracle gradient is exactly zero", g.abs().max().item())
+    print("[parity] %s: worst max-entry-relative gradient error %.2e (%s); worst relative L2 so far %.2e" % (tag, worst[0], worst[1], RL2_SEEN[0]))
     return worst
 
 
@@ -194,7 +212,7 @@ def test_cfg5_full_size_fp32_and_fp16_storage_against_oracle():
     m16.train()
     runs16 = _run_phases(ts16, batch, 2)
     for tag, (losses, grads) in zip(("cfg5 f16 eager", "cfg5 f16 replay"), runs16):
-        _check(tag, losses, grads, want_l, want_g, ltol=2e-3, gtol=1e-2)
+        _check(tag, losses, grads, want_l, want_g, ltol=2e-3, gtol=1e-2, l2tol=5e-2)
 
 
 def test_fp16_storage_small_batches_run():

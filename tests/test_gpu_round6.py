@@ -31,3 +31,90 @@ def test_bench_self_launch_two_ranks_smoke():
     assert d["n_gpus"] == 2 and d["steps"] == 3
     assert d["dp"]["backend"] == "gloo" and len(d["dp"]["per_rank_ms_per_step"]) == 2
     assert np.isfinite(d["final_loss"]) and d["value"] > 0
+
+
+# ---------------------------------------------------------------------------------------------- give-up accounting
+R4_DIMS = (300, 333, 64, 32, 512, 48)       # Vs, Vt, I, E, H, S: H = 512 / B = 64 is a shape the persistent kernels take
+
+
+def _r4_model(seed=0):
+    from machine_translation_vision.models import NMT_AttentionImagine_Seq2Seq_Beam_V11
+    Vs, Vt, I, E, H, S = R4_DIMS
+    torch.manual_seed(seed)
+    return NMT_AttentionImagine_Seq2Seq_Beam_V11(Vs, Vt, I, E, E, H, S, 0.99, tied_emb=True).cuda()
+
+
+def _r4_batch(seed, B=64, Ts=12, Tt=5):
+    Vs, Vt, I = R4_DIMS[:3]
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(4, Vs, (B, Ts), generator=g)
+    tgt = torch.randint(4, Vt, (B, Tt), generator=g)
+    tgt[:, -1] = 3
+    return src.cuda(), [Ts] * B, tgt.cuda(), torch.randn(B, I, generator=g).abs().cuda()
+
+
+def _r4_driver(seed=0, **kw):
+    from machine_translation_vision.losses import PairwiseRankingLoss
+    from vagnmt_hip.trainer import TrainStep
+    m = _r4_model(seed)
+    vw = torch.ones(R4_DIMS[1], device="cuda")
+    vw[0] = 0
+    return m, TrainStep(m, torch.nn.NLLLoss(weight=vw, reduction="none"), PairwiseRankingLoss(0.1), teacher_force_ratio=1.0, **kw)
+
+
+def test_give_up_in_autograd_backward_thread_voids_the_step_of_its_driver():
+    """Per-operator path (TrainStep(fused=False): model(...) + loss.backward() + the flat optimiser).  autograd runs the backward
+    operators on its own worker thread; their persistent launches must still report to the DRIVER's guard pair, so the optimiser
+    skips the step and check() raises -- not to the process-wide pair nobody reads (train.py:44-49 semantics for applied steps)."""
+    from vagnmt_hip import _lib as L
+    m, ts = _r4_driver(use_graph=False, fused=False)
+    assert type(ts.backend).__name__ == "_AutogradBackend"
+    for s in range(2):
+        ts.step(*_r4_batch(10 + s), teacher=True)
+    torch.cuda.synchronize()
+    assert ts.skipped_steps() == 0
+    L.lib().vag_persistent_timeouts()
+    before = (ts.fp.flat.clone(), int(ts.step_count.item()))
+    L.set_option("persist_spin_limit", 1)
+    try:
+        ts.step(*_r4_batch(21), teacher=True)
+        torch.cuda.synchronize()
+    finally:
+        L.set_option("persist_spin_limit", 0)
+    assert torch.equal(before[0], ts.fp.flat) and int(ts.step_count.item()) == before[1]
+    assert ts.skipped_steps() == 1
+    guard = ts._scratch.view(torch.int32)[ts.GUARD_OFFSET // 4 + 1]
+    assert int(guard) > 0                                    # the give-ups of forward AND backward launches were counted here
+    with pytest.raises(L.VagError):
+        ts.check()
+    ts.step(*_r4_batch(22), teacher=True)                    # healthy again
+    torch.cuda.synchronize()
+    assert int(ts.step_count.item()) == before[1] + 1 and not torch.equal(before[0], ts.fp.flat)
+    ts.check()
+
+
+def test_unguarded_step_consumes_the_process_wide_flag():
+    """vag_train_step with cfg.guard == NULL (FusedStep used without a TrainStep) reports give-ups to the process-wide pair and turns
+    them into a non-finite gradient entry.  That step must also CLEAR the pair: before, one transient give-up anywhere in the
+    process poisoned every later unguarded step for good."""
+    from vagnmt_hip import _lib as L
+    m, ts = _r4_driver(use_graph=False)
+    f = ts.backend.f
+    f.guard = None                                            # the bare C-API form
+    src, lens, tgt, im = _r4_batch(40)
+    lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    m.train()
+    g00 = m.encoder.embedding.weight._vag_grad[0, 0]
+    L.set_option("persist_spin_limit", 1)
+    try:
+        ts.backend.run(src, lt, tgt, im, True, 7)
+        torch.cuda.synchronize()
+    finally:
+        L.set_option("persist_spin_limit", 0)
+    assert torch.isinf(g00)                                   # void step: injected
+    ts.fp.grad.zero_()
+    ts.backend.run(src, lt, tgt, im, True, 7)                 # a healthy step right after, nobody polled the count in between
+    torch.cuda.synchronize()
+    assert float(g00) == 0.0 and torch.isfinite(ts.fp.grad).all()
+    assert L.lib().vag_persistent_timeouts() > 0              # the count is still there for whoever polls it
+    assert L.lib().vag_persistent_timeouts() == 0

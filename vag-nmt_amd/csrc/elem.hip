@@ -46,12 +46,17 @@ int vag_embed_gather_launch(const int64_t* idx, int64_t ist, int64_t isb, int64_
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ idx, int64_t ist, int64_t isb,
                                                             int T, int B, const float* __restrict__ g, int E,
                                                             float* __restrict__ gW, const uint64_t* rng, int sid,
-                                                            float p, const unsigned* poison) {
+                                                            float p, unsigned* poison, int consume) {
     // a persistent recurrence of this step gave up a wait (persist.hip: g_persist_poison): its gradient is void.  The padding
     // row's first entry (never touched otherwise) becomes non-finite, so that the norm pass -- after the all-reduce, on every
     // replica -- sees it and the optimiser skips the step (optim.hip)
-    if (poison && blockIdx.x == 0 && threadIdx.x == 0 && __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
-        gW[0] = __builtin_inff();
+    // `consume`: the flag is the PROCESS-WIDE one (a step without a guard pair of its own, vag_step_cfg.guard == NULL): nothing else
+    // ever clears that word -- adam_prep_kernel resets only its driver's pair -- so the step that turns it into a skipped update takes
+    // it down as well; one transient give-up anywhere in the process must not void every later unguarded step.
+    if (poison && blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned f = consume ? atomicExch(poison, 0u) : __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f != 0u) gW[0] = __builtin_inff();
+    }
     // One WAVE per (row, 64-float column block): its lanes add 64 CONSECUTIVE floats, i.e. every atomic wave-instruction covers
     // 256 contiguous bytes -- the shape float atomics run at full rate for (MI355X_MICROARCH.md, global float atomics).  Round 3
     // gave every lane a float4 and issued four atomics of one dword every 16 bytes: a quarter of each 64-byte atomic request
@@ -77,7 +82,7 @@ int vag_embed_scatter_launch(const int64_t* idx, int64_t ist, int64_t isb, int64
     VAG_CHECK_ARG(idx && g && gW && E > 0 && E % 4 == 0 && T >= 0 && B >= 0);
     if (T * B == 0) return VAG_OK;
     hipLaunchKernelGGL(embed_scatter_kernel, grid1d(T * B * ((E + 63) / 64) * 64), dim3(256), 0, s, idx, ist, isb, (int)T, (int)B, g,
-                       (int)E, gW, rng, sid, p, poison);
+                       (int)E, gW, rng, sid, p, const_cast<unsigned*>(poison), (poison && vag_persist_guard_peek() == nullptr) ? 1 : 0);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }

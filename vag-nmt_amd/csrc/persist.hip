@@ -2237,10 +2237,14 @@ unsigned* vag_persist_guard(void) {
     return reinterpret_cast<unsigned*>(p);
 }
 // Number of waits that gave up since the last call (synchronises the device).  0 in a healthy run.
+// Reading the count also takes the process-wide guard pair down: whoever polls the count has been told about the give-ups, and
+// nothing else resets that pair (a driver's own pair is reset by its optimiser kernels / its check()).
 int vag_persistent_timeouts_read(void) {
     unsigned v = 0, z = 0;
+    const unsigned zz[2] = {0u, 0u};
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_persist_timeouts), sizeof(v)) != hipSuccess) return -1;
-    if (v != 0 && hipMemcpyToSymbol(HIP_SYMBOL(g_persist_timeouts), &z, sizeof(z)) != hipSuccess) return -1;
+    if (v != 0 && (hipMemcpyToSymbol(HIP_SYMBOL(g_persist_timeouts), &z, sizeof(z)) != hipSuccess ||
+                   hipMemcpyToSymbol(HIP_SYMBOL(g_persist_guard), zz, sizeof(zz)) != hipSuccess)) return -1;
     return (int)v;
 }
 

@@ -1,7 +1,7 @@
 """Names of the reference package that are NOT on the hot path (the METEOR wrapper,
-sixteen research model variants, their layers) are served from the user's own checkout of the reference, when one sits
-later on ``sys.path`` than this package: ``python nmt_multimodal_beam_DE.py`` run from a checkout puts the checkout's
-directory there by itself.  Nothing of the reference is copied: this module only extends package search paths.
+sixteen research model variants, their layers) are served from the user's own checkout of the reference: the directory of the
+script ``python -m vagnmt_hip.run SCRIPT`` launched (recorded in ``VAG_REFERENCE_CHECKOUT``; a user may name another).
+Nothing of the reference is copied: this module only extends package search paths.
 
 * ``machine_translation_vision.meteor`` (imported by all four entry scripts, e.g. nmt_multimodal_beam_DE.py:14) resolves to
   the checkout's sub-package because the top package's ``__path__`` ends with the checkout's package directory.
@@ -36,19 +36,20 @@ _checkout = False       # False: not searched yet; None: searched, none there; s
 
 
 def find_checkout():
-    """Package directory of a reference checkout on ``sys.path`` (the first ``<entry>/machine_translation_vision`` that is
-    not this package and has the reference's ``meteor`` sub-package or model variants), or None."""
+    """Package directory of the reference checkout: ``$VAG_REFERENCE_CHECKOUT/machine_translation_vision`` -- the directory of the
+    script ``python -m vagnmt_hip.run`` launched, or what the user named -- if it is not this package and has the reference's
+    ``meteor`` sub-package or model variants; else None.  sys.path is not searched (round 6: whatever happened to come first on it
+    was adopted)."""
     global _checkout
     if _checkout is not False:
         return _checkout
     _checkout = None
-    for entry in list(sys.path):
-        d = os.path.join(os.path.abspath(entry or os.getcwd()), _PKG)
-        if not os.path.isfile(os.path.join(d, "__init__.py")) or os.path.realpath(d) == os.path.realpath(_HERE):
-            continue
-        if os.path.isdir(os.path.join(d, "meteor")) or os.path.isfile(os.path.join(d, "models", "NMT_Seq2Seq_Beam.py")):
+    root = os.environ.get("VAG_REFERENCE_CHECKOUT")
+    if root:
+        d = os.path.join(os.path.abspath(root), _PKG)
+        if os.path.isfile(os.path.join(d, "__init__.py")) and os.path.realpath(d) != os.path.realpath(_HERE) and \
+                (os.path.isdir(os.path.join(d, "meteor")) or os.path.isfile(os.path.join(d, "models", "NMT_Seq2Seq_Beam.py"))):
             _checkout = d
-            break
     return _checkout
 
 

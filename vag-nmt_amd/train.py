@@ -10,7 +10,8 @@ Under ``python -m vagnmt_hip.run SCRIPT`` this directory sits ahead of the user'
 (train.py:19-32), same signatures, same return values (Python floats) -- and run the step as ONE library call
 (``vag_train_step`` + fused clip/Adam, replayed from a HIP graph per batch shape: vagnmt_hip.trainer.TrainStep).  Every other
 name of the module (``random_sample_display``, ``train_imagine_beam_v2``, ``MAX_LENGTH``, ``SOS_token`` ...) is served from
-the checkout's own ``train.py``, loaded from the next ``sys.path`` entry that has one; nothing of it is copied here.
+the checkout's own ``train.py`` -- the one in the launched script's directory (``VAG_REFERENCE_CHECKOUT``), nowhere else;
+nothing of it is copied here.
 
 What the fused step takes from the caller's objects, every call:
   * the optimiser's param groups (nmt_multimodal_beam_DE.py:303-332): which parameters, each group's ``lr`` /
@@ -33,17 +34,29 @@ _HERE = _os.path.dirname(_os.path.abspath(__file__))
 
 
 def _load_checkout_module():
-    """The checkout's train.py: the first ``<entry>/train.py`` on sys.path that is not this file."""
-    for entry in list(_sys.path):
-        d = _os.path.abspath(entry or _os.getcwd())
-        f = _os.path.join(d, "train.py")
-        if _os.path.realpath(d) == _os.path.realpath(_HERE) or not _os.path.isfile(f):
-            continue
-        spec = _ilu.spec_from_file_location("_vag_checkout_train", f)
-        mod = _ilu.module_from_spec(spec)
-        spec.loader.exec_module(mod)
-        return mod
-    return None
+    """The checkout's train.py: ``$VAG_REFERENCE_CHECKOUT/train.py`` -- the directory of the script ``python -m vagnmt_hip.run``
+    launched (or what the user put there) -- and only if its text defines the reference's step functions.  sys.path and the working
+    directory are NOT searched: an unrelated ``train.py`` lying around must never be executed at import time."""
+    d = _os.environ.get("VAG_REFERENCE_CHECKOUT")
+    if not d:
+        return None
+    d = _os.path.abspath(d)
+    f = _os.path.join(d, "train.py")
+    if _os.path.realpath(d) == _os.path.realpath(_HERE) or not _os.path.isfile(f):
+        return None
+    try:
+        with open(f, errors="replace") as fh:
+            text = fh.read()
+    except OSError:
+        return None
+    if "def train_imagine_beam" not in text and "def train_nmt" not in text:
+        import warnings
+        warnings.warn("%s does not define train_imagine_beam / train_nmt: not the reference's train.py, ignored" % f)
+        return None
+    spec = _ilu.spec_from_file_location("_vag_checkout_train", f)
+    mod = _ilu.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 _checkout = _load_checkout_module()

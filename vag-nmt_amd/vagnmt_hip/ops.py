@@ -19,6 +19,31 @@ from ._lib import DecW, GruW, HeadW, call, gru_w, ptr, stream
 I64 = torch.int64
 
 
+# Guard pair {void flag, give-up count} of the step driver the operators currently run for (trainer._AutogradBackend): a PROCESS-wide
+# Python value, because autograd runs backward() on its own device worker thread -- a thread-local set by the driver's thread
+# (vag_set_operator_guard alone) never reaches the backward recurrences, whose give-ups then landed in the process-wide pair that
+# the driver's optimiser does not read.  The recurrence operators below carry it into each ABI call themselves.
+_OPERATOR_GUARD = None
+
+
+def set_operator_guard(address):
+    """Device address of the guard pair (or None) for the persistent recurrence launches of the operators, on every thread."""
+    global _OPERATOR_GUARD
+    _OPERATOR_GUARD = address
+
+
+def _recurrence_call(name, *args):
+    """An ABI call that may launch a persistent recurrence kernel: runs with the current driver's guard pair on THIS thread."""
+    g = _OPERATOR_GUARD
+    if g is None:
+        return call(name, *args)
+    call("vag_set_operator_guard", g)
+    try:
+        return call(name, *args)
+    finally:
+        call("vag_set_operator_guard", None)
+
+
 def _f32(*shape, like):
     return torch.empty(*shape, dtype=torch.float32, device=like.device)
 
@@ -57,7 +82,7 @@ class BiGRUEncode(Function):
         mask = _f32(B, Ts, like=emb)
         ws = _f32(L.lib().vag_bigru_ws_floats(B, Ts, E, H), like=emb)
         src = _c(src)
-        call("vag_bigru_seq_fwd", ptr(src, I64), ptr(lengths, torch.int32), ptr(emb),
+        _recurrence_call("vag_bigru_seq_fwd", ptr(src, I64), ptr(lengths, torch.int32), ptr(emb),
              gru_w(wf_ih, wf_hh, bf_ih, bf_hh), gru_w(wb_ih, wb_hh, bb_ih, bb_hh), p_emb, p_ctx,
              ptr(rng, torch.int64) if rng is not None else None, B, Ts, E, H, ptr(enc), ptr(mask), ptr(ws), stream())
         params = (emb, wf_ih, wf_hh, bf_ih, bf_hh, wb_ih, wb_hh, bb_ih, bb_hh)
@@ -74,7 +99,7 @@ class BiGRUEncode(Function):
         d_enc = _c(d_enc)
         t = _grad_targets(ctx.gviews, ctx.saved_tensors[3:])
         g = [x[0] for x in t]
-        call("vag_bigru_seq_bwd", ptr(src, I64), ptr(lengths, torch.int32), gru_w(wf_ih, wf_hh, bf_ih, bf_hh),
+        _recurrence_call("vag_bigru_seq_bwd", ptr(src, I64), ptr(lengths, torch.int32), gru_w(wf_ih, wf_hh, bf_ih, bf_hh),
              gru_w(wb_ih, wb_hh, bb_ih, bb_hh), p_emb, p_ctx, ptr(rng, torch.int64) if rng is not None else None,
              B, Ts, E, H, ptr(d_enc), ptr(ws), ptr(g[0]), gru_w(g[1], g[2], g[3], g[4]), gru_w(g[5], g[6], g[7], g[8]),
              stream())
@@ -201,11 +226,11 @@ class _CGRUDecodeSeq(Function):
         if free_run and L.lib().vag_cgru_free_supported(B, Ts, Tt, E, H, V):
             # one launch for all steps (persist.hip, free-running form); same outputs and saved tensors
             tables = _f32(L.lib().vag_cgru_free_tables_floats(B, Ts, Tt, E, H, V), like=enc)
-            call("vag_cgru_attn_decode_free_fwd", ptr(enc), ptr(pe), ptr(mask), ptr(h0), ptr(tok, I64), _dec_w(emb, dec),
+            _recurrence_call("vag_cgru_attn_decode_free_fwd", ptr(enc), ptr(pe), ptr(mask), ptr(h0), ptr(tok, I64), _dec_w(emb, dec),
                  B, Ts, Tt, E, H, V, ptr(h2), ptr(c), ptr(e), ptr(ws), hw, float(p_out),
                  ptr(rng, torch.int64) if rng is not None else None, ptr(tmid), ptr(logits), ldl, ptr(tables), stream())
         else:
-            call("vag_cgru_attn_decode_seq_fwd", ptr(enc), ptr(pe), ptr(mask), ptr(h0), ptr(tok, I64), _dec_w(emb, dec),
+            _recurrence_call("vag_cgru_attn_decode_seq_fwd", ptr(enc), ptr(pe), ptr(mask), ptr(h0), ptr(tok, I64), _dec_w(emb, dec),
                  B, Ts, Tt, E, H, V, ptr(h2), ptr(c), ptr(e), ptr(ws), int(bool(free_run)), hw, float(p_out),
                  ptr(rng, torch.int64) if rng is not None else None, ptr(tmid), ptr(logits), ldl, stream())
         ctx.save_for_backward(enc, pe, mask, h0, tok, ws, h2, c, e, emb, *dec)
@@ -235,7 +260,7 @@ class _CGRUDecodeSeq(Function):
         g = [x[0] for x in t]
         gdec = DecW(ptr(g[0]), gru_w(g[1], g[2], g[3], g[4]), ptr(g[5]), ptr(g[6]), ptr(g[7]),
                     gru_w(g[8], g[9], g[10], g[11]))
-        call("vag_cgru_attn_decode_seq_bwd", ptr(enc), ptr(pe), ptr(mask), ptr(h0), ptr(tok, I64), _dec_w(emb, dec),
+        _recurrence_call("vag_cgru_attn_decode_seq_bwd", ptr(enc), ptr(pe), ptr(mask), ptr(h0), ptr(tok, I64), _dec_w(emb, dec),
              B, Ts, Tt, E, H, V, ptr(h2), ptr(c), ptr(e), ptr(d_h2), ptr(d_c), ptr(d_e), ptr(ws), ptr(d_enc), 0,
              ptr(d_pe), ptr(d_h0), gdec, ptr(scratch), stream())
         r = _ret(t)

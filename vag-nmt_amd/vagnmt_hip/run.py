@@ -6,8 +6,8 @@
 the reference's ``machine_translation_vision`` package: a plain ``PYTHONPATH=vag-nmt_amd python nmt_multimodal_beam_DE.py``
 therefore still imports the reference's classes.  This launcher orders the path -- this package's parent first, the
 script's directory (the checkout: ``preprocessing``, ``train``, ``bleu``, and everything of ``machine_translation_vision``
-that is off the hot path, see machine_translation_vision/_checkout.py) right behind it -- and runs the script unchanged as
-``__main__``."""
+that is off the hot path, see machine_translation_vision/_checkout.py) right behind it -- records the script's directory as
+THE checkout (``VAG_REFERENCE_CHECKOUT``, unless the user set it) and runs the script unchanged as ``__main__``."""
 import os
 import runpy
 import sys
@@ -18,6 +18,10 @@ def order_path(script):
     sdir = os.path.dirname(os.path.abspath(script))
     rest = [p for p in sys.path if os.path.realpath(p or os.getcwd()) not in (os.path.realpath(here), os.path.realpath(sdir))]
     sys.path[:] = [here, sdir] + rest
+    # where the shadow modules look for the checkout (train.py, machine_translation_vision/_checkout.py): the launched script's
+    # own directory and nothing else -- not "the first hit on sys.path", which could be an unrelated train.py in the working
+    # directory.  A user who keeps the script elsewhere names the checkout in VAG_REFERENCE_CHECKOUT.
+    os.environ.setdefault("VAG_REFERENCE_CHECKOUT", sdir)
     stale = [m for m in sys.modules if m == "machine_translation_vision" or m.startswith("machine_translation_vision.")]
     for m in stale:                                                             # imported from the wrong place before us
         f = getattr(sys.modules[m], "__file__", None) or ""

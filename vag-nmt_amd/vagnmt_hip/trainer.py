@@ -468,14 +468,14 @@ class _AutogradBackend:
     def run(self, src, lengths, tgt, im, teacher, phases, reuse=False):
         ts = self.ts
         tfr = 1.0 if teacher else 0.0       # the coin is drawn by the caller
-        g = ts.guard_ptr()
-        if g is not None:                   # the operators' persistent launches report to this driver's guard pair
-            call("vag_set_operator_guard", g)
+        # the operators' persistent launches -- forward on this thread, backward on autograd's worker thread -- report to this
+        # driver's guard pair, which its optimiser kernels read (ops._recurrence_call carries it into each call)
+        from . import ops
+        ops.set_operator_guard(ts.guard_ptr())
         try:
             self._run(src, lengths, tgt, im, tfr)
         finally:
-            if g is not None:
-                call("vag_set_operator_guard", None)
+            ops.set_operator_guard(None)
 
     def _run(self, src, lengths, tgt, im, tfr):
         ts = self.ts
