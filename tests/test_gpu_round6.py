@@ -118,3 +118,55 @@ def test_unguarded_step_consumes_the_process_wide_flag():
     assert float(g00) == 0.0 and torch.isfinite(ts.fp.grad).all()
     assert L.lib().vag_persistent_timeouts() > 0              # the count is still there for whoever polls it
     assert L.lib().vag_persistent_timeouts() == 0
+
+
+# ---------------------------------------------------------------- wider persistent recurrences
+@pytest.mark.parametrize("H,B,Ts,Tt", [(256, 16, 40, 40), (256, 64, 12, 5), (256, 37, 9, 7), (256, 5, 7, 3), (256, 128, 8, 4),
+                                        (256, 150, 6, 3), (512, 128, 9, 4), (512, 100, 7, 5), (512, 250, 5, 3)])
+def test_wider_persistent_decoder_equals_launch_chain(H, B, Ts, Tt):
+    """The one-launch decoder recurrences (forward and backward) and the one-launch encoder backward at H = 256 (BASELINE configs[0]:
+    32 workgroups per row tile instead of 64) and for batches wider than one launch holds (B > 64 at H = 512, > 128 at H = 256:
+    passes of row tiles through the same kernel) against the per-step launch chains: losses to 2e-6, every gradient to 2e-5 of its
+    tensor's largest entry, no wait gave up (layers/NMT_Decoder.py:109-145 x models/...V11.py:138-146, layers/Encoder.py:58)."""
+    from test_gpu_round3 import _model, _batch
+    from vagnmt_hip import _lib as L
+    from machine_translation_vision.losses import PairwiseRankingLoss
+    assert L.lib().vag_recurrence_supported(1, B, Ts, Tt, H) == 1          # the shape takes the persistent decoder now
+    src, lens, tgt, im = _batch(B, Ts, Tt, seed=3)
+    vw = torch.ones(333, device="cuda")
+    vw[0] = 0
+    crit = torch.nn.NLLLoss(weight=vw, reduction="none")
+    res = {}
+    L.lib().vag_persistent_timeouts()
+    for mode in (0, 1):
+        L.set_option("persistent", mode)
+        try:
+            m = _model(H, seed=2)
+            loss, loss_mt, _ = m(src, lens, tgt, im, 1.0, criterion_mt=crit, criterion_vse=PairwiseRankingLoss(0.1))
+            loss.backward()
+            torch.cuda.synchronize()
+            res[mode] = (float(loss), float(loss_mt), {n: p.grad.detach().clone() for n, p in m.named_parameters()})
+        finally:
+            L.set_option("persistent", 1)
+    (l0, m0, g0), (l1, m1, g1) = res[0], res[1]
+    assert L.lib().vag_persistent_timeouts() == 0
+    assert np.isfinite(l1)
+    assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0)), (l0, l1)
+    assert abs(m0 - m1) <= 2e-6 * max(1.0, abs(m0)), (m0, m1)
+    differs = False
+    for n in g0:
+        scale = max(g0[n].abs().max().item(), 1e-3)
+        err = (g0[n] - g1[n]).abs().max().item()
+        assert err <= 2e-5 * scale, (n, err, scale)
+        differs = differs or err > 0.0
+    assert differs                          # (the two paths sum in different orders: identical bits would mean the same kernels ran)
+
+
+def test_persistent_decoder_eligibility_edges():
+    from vagnmt_hip import _lib as L
+    sup = L.lib().vag_recurrence_supported
+    assert sup(1, 64, 40, 40, 512) == 1 and sup(1, 16, 40, 40, 256) == 1
+    assert sup(1, 256, 40, 40, 512) == 1 and sup(1, 257, 40, 40, 512) == 0      # four passes of four row tiles at most
+    assert sup(1, 512, 40, 40, 256) == 1 and sup(1, 513, 40, 40, 256) == 0
+    assert sup(1, 64, 40, 40, 1024) == 0 and sup(1, 64, 40, 40, 128) == 0       # (configs[4]'s width: launch chains, DESIGN 0)
+    assert sup(1, 64, 600, 40, 512) == 0                                        # keys of a row tile must fit the LDS

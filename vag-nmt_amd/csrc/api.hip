@@ -309,7 +309,7 @@ int vag_bigru_seq_bwd(const int64_t* src, const int32_t* lengths, vag_gru_w fw, 
     }
     const bool pers_on = vag_opt().persistent && vag_opt().persistent_enc_bwd;
     const bool wide16 = s16 && pers_on && vag_enc_wide16_ok(B, Ts, H) && B >= 64;
-    const bool persist = wide16 || (!s16 && pers_on && H == 512 && vag_enc_persistent_ok(B, Ts, H));
+    const bool persist = wide16 || (!s16 && pers_on && (H == 512 || H == 256) && vag_enc_persistent_ok(B, Ts, H));
     if (wide16) {
         // 2-byte mode, wide batches: the twin of the forward's one-launch kernel (fp16 W_hh^T slice in registers, gate gradients
         // exchanged as fp16 x 2^12 -- what the chain's fp16-pipe product rounds them to)

@@ -20,6 +20,7 @@
 //     fences.  A step waits only for the 32 workgroups of its own direction and row tile.
 #include "kernels.h"
 #include "gemm_shared.h"
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 
@@ -82,6 +83,13 @@ template <> __device__ __forceinline__ void ld_rows_sc1<2>(const float* p, float
                  "global_load_dwordx4 %2, %4, off offset:128 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:144 sc1\n\t"
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(a[0]), "=&v"(b[0]), "=&v"(a[1]), "=&v"(b[1]) : "v"(p) : "memory");
+}
+template <> __device__ __forceinline__ void ld_rows_sc1<3>(const float* p, float4 (&a)[3], float4 (&b)[3]) {
+    asm volatile("global_load_dwordx4 %0, %6, off sc1\n\tglobal_load_dwordx4 %1, %6, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off offset:128 sc1\n\tglobal_load_dwordx4 %3, %6, off offset:144 sc1\n\t"
+                 "global_load_dwordx4 %4, %6, off offset:256 sc1\n\tglobal_load_dwordx4 %5, %6, off offset:272 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a[0]), "=&v"(b[0]), "=&v"(a[1]), "=&v"(b[1]), "=&v"(a[2]), "=&v"(b[2]) : "v"(p) : "memory");
 }
 template <> __device__ __forceinline__ void ld_rows_sc1<4>(const float* p, float4 (&a)[4], float4 (&b)[4]) {
     asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
@@ -853,7 +861,8 @@ struct DecPArgs {
     unsigned* guard;            // {void flag, give-up count} of the driver this launch belongs to
     unsigned spin;
     unsigned long long* dbg;    // NULL, or [Tt][8] 100 MHz timestamps of workgroup 0's phase boundaries (tools/exp_dec_phases.py)
-    int B, Ts, Tt, H, RT;
+    int B, Ts, Tt, H, RT;       // RT: row tiles of the whole batch (the counters are indexed by the global row tile)
+    int rt0;                    // first row tile of THIS launch (batches wider than the chip: passes of row tiles)
     // ---- free-running form (FREE = true): the kernel feeds its own arg-max back (V11.py:148-160 / :207-226), xp1 is not read
     const float *embp;          // (V, 3H)  emb W_ih1^T + b_ih1: the input projection of gru_1 for every possible token
     const float *embw3;         // (V, E)   emb W3^T: the head's share of the embedded input (NMT_Decoder.py:137)
@@ -930,7 +939,36 @@ __device__ __forceinline__ void ld_acc_shards_and_rows6(const float* p0, const f
     v1 = (b0 + b1) + (b2 + b3);
 }
 
-constexpr int DEC_WGS = 64;          // workgroups per row tile
+// ... and three k-steps (H = 256)
+__device__ __forceinline__ void ld_acc_shards_and_rows3(const float* p0, const float* p1, int64_t stride, float& v0, float& v1,
+                                                        const float* rows, float4 (&a)[3], float4 (&b)[3]) {
+    float a0, a1, a2, a3, b0, b1, b2, b3;
+    const float *p02 = p0 + 2 * stride, *p12 = p1 + 2 * stride;
+    const float *p01 = p0 + stride, *p03 = p02 + stride, *p11 = p1 + stride, *p13 = p12 + stride;
+    asm volatile("global_load_dword %0, %14, off sc1\n\tglobal_load_dword %1, %15, off sc1\n\t"
+                 "global_load_dword %2, %16, off sc1\n\tglobal_load_dword %3, %17, off sc1\n\t"
+                 "global_load_dword %4, %18, off sc1\n\tglobal_load_dword %5, %19, off sc1\n\t"
+                 "global_load_dword %6, %20, off sc1\n\tglobal_load_dword %7, %21, off sc1\n\t"
+                 "global_load_dwordx4 %8, %22, off sc1\n\tglobal_load_dwordx4 %9, %22, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %10, %22, off offset:128 sc1\n\tglobal_load_dwordx4 %11, %22, off offset:144 sc1\n\t"
+                 "global_load_dwordx4 %12, %22, off offset:256 sc1\n\tglobal_load_dwordx4 %13, %22, off offset:272 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3),
+                   "=&v"(a[0]), "=&v"(b[0]), "=&v"(a[1]), "=&v"(b[1]), "=&v"(a[2]), "=&v"(b[2])
+                 : "v"(p0), "v"(p01), "v"(p02), "v"(p03), "v"(p1), "v"(p11), "v"(p12), "v"(p13), "v"(rows) : "memory");
+    v0 = (a0 + a1) + (a2 + a3);
+    v1 = (b0 + b1) + (b2 + b3);
+}
+__device__ __forceinline__ void ld_acc_shards_and_rows(const float* p0, const float* p1, int64_t stride, float& v0, float& v1,
+                                                       const float* rows, float4 (&a)[6], float4 (&b)[6]) {
+    ld_acc_shards_and_rows6(p0, p1, stride, v0, v1, rows, a, b);
+}
+__device__ __forceinline__ void ld_acc_shards_and_rows(const float* p0, const float* p1, int64_t stride, float& v0, float& v1,
+                                                       const float* rows, float4 (&a)[3], float4 (&b)[3]) {
+    ld_acc_shards_and_rows3(p0, p1, stride, v0, v1, rows, a, b);
+}
+
+constexpr int DEC_WGS = 64;          // workgroups per row tile (H = 512)
 // Workgroup -> (slice i, row tile rt).  Blocks b and b + 8 share an XCD (round-robin placement: observed, speed only), and consecutive
 // slices share memory lines of the key images the kernels copy into LDS (two slices per 128-byte line of pe, four per line of the
 // projected keys' gate blocks) and of the pieces they exchange.  In block order every line crossed the fabric once per slice.
@@ -941,10 +979,14 @@ constexpr int DEC_WGS = 64;          // workgroups per row tile
 // 834.8 -> 829.7 / 828.0 / 829.3 us, one box, alternating runs); four per XCD (mode 3) and pairs for the forward kernel are within
 // noise of those.  One row tile per XCD pair (its exchanges into two L2s instead of eight) measured the same as mode 1: not kept.
 // The encoder's kernels: no gain (forward) / +3 us (backward) with mode 1: they keep block order.
-__device__ __forceinline__ void dec_slice_map(int mode, int& i, int& rt) {
-    const int bx = blockIdx.x % DEC_WGS;
-    rt = blockIdx.x / DEC_WGS;
-    const int g = mode == 1 ? 8 : (mode == 2 ? 2 : (mode == 3 ? 4 : 1));      // consecutive slices per XCD
+// WGS: workgroups per row tile (64 at H = 512, 32 at H = 256: a row tile then has four blocks per XCD, so at most four consecutive
+// slices can share one).  rt0: the first row tile of this launch (a batch wider than the chip is taken in passes of row tiles).
+template <int WGS>
+__device__ __forceinline__ void dec_slice_map(int mode, int rt0, int& i, int& rt) {
+    const int bx = blockIdx.x % WGS;
+    rt = rt0 + blockIdx.x / WGS;
+    int g = mode == 1 ? 8 : (mode == 2 ? 2 : (mode == 3 ? 4 : 1));      // consecutive slices per XCD
+    if (g > WGS / 8) g = WGS / 8;
     i = (bx & 7) * g + ((bx >> 3) % g) + 8 * g * (bx / (8 * g));
 }
 // The 64 workgroups of a row tile add their shares of a step's scores (forward) / d alpha (backward) with fp32 atomics.  Atomics
@@ -960,13 +1002,17 @@ __device__ __forceinline__ unsigned long long cand_key(float v, int idx) {      
     return ((unsigned long long)(u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u)) << 32) | (unsigned long long)(0xffffffffu - (unsigned)idx);
 }
 
-template <bool FREE>
+// WGS workgroups per row tile, each owning DEC_U = 8 hidden units: H = 8 WGS (512 or 256).  The attention width is C = 2H, so a
+// workgroup's share of the query is C / WGS = 16 columns at either size; only the K share of a wave (H / 8: two k-steps or one) and
+// the fan-in of the exchanges change.  The free-running form exists at H = 512 only (its head slices assume E = 4 WGS = 256).
+template <bool FREE, int WGS = DEC_WGS>
 __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) {
     extern __shared__ __attribute__((aligned(16))) float dlds[];
-    constexpr int H = DEC_WGS * DEC_U, C = 2 * H, Q = C + 3 * H, KS = 2;       // K share of a wave: H / 8 = 64 = 2 k-steps
+    static_assert(WGS == 64 || (WGS == 32 && !FREE), "H = 512 (both forms) or H = 256 (teacher-forced form)");
+    constexpr int H = WGS * DEC_U, C = 2 * H, Q = C + 3 * H, KS = H / 256;     // K share of a wave: H / 8 = 32 KS
     constexpr int E = DEC_E;
     int i, rt;
-    dec_slice_map(a.xcd_map, i, rt);
+    dec_slice_map<WGS>(a.xcd_map, a.rt0, i, rt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int B = a.B, Ts = a.Ts, Tt = a.Tt;
     const int m0 = rt * 16, u0 = i * DEC_U;
@@ -1001,7 +1047,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
 #ifdef VAG_LAB          // ... and per row tile: entry and exit of its first workgroup (rows Tt + 1, Tt + 2), entry of its LAST one (row Tt + 3)
     if (!FREE && a.dbg && threadIdx.x == 0 && rt < 8) {
         if (i == 0) a.dbg[(Tt + 1) * 8 + rt] = __builtin_amdgcn_s_memrealtime();
-        if (i == DEC_WGS - 1) a.dbg[(Tt + 3) * 8 + rt] = __builtin_amdgcn_s_memrealtime();
+        if (i == WGS - 1) a.dbg[(Tt + 3) * 8 + rt] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
     // ---- weights as bf16 planes in registers (A operands: rows = output columns).  Row of a tile held by lane fr:
@@ -1076,7 +1122,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
     gu32* c4 = (gu32*)(a.cnt + ((int64_t)3 * a.RT + rt) * Tt * CNT_WORDS);       // scores
     gu32* c5 = (gu32*)(a.cnt + ((int64_t)2 * a.RT + rt) * Tt * CNT_WORDS);       // FREE: the head's hidden layer of step t
     gu32* c6 = (gu32*)(a.cnt + ((int64_t)4 * a.RT + rt) * Tt * CNT_WORDS);       // FREE: arg-max candidates of step t
-    constexpr unsigned PER_SHARD = DEC_WGS / SHARDS;
+    constexpr unsigned PER_SHARD = WGS / SHARDS;
     bool dead = false;
     __syncthreads();
     VAG_PSTAMP(2);
@@ -1446,7 +1492,7 @@ __global__ __launch_bounds__(512, 1) void dec_fwd_persistent_kernel(DecPArgs a) 
                 const float al = __expf(sc_s[r * Ts + sp] - mx) * inv;
                 sc_s[r * Ts + sp] = al;
                 // saved for the backward pass; every workgroup of the tile holds all weights: each writes 1/64 of them
-                if (((r * Ts + sp) & (DEC_WGS - 1)) == i && m0 + r < B) a.alpha[((int64_t)t * B + m0 + r) * Ts + sp] = al;
+                if (((r * Ts + sp) & (WGS - 1)) == i && m0 + r < B) a.alpha[((int64_t)t * B + m0 + r) * Ts + sp] = al;
             }
         }
         __syncthreads();
@@ -1541,7 +1587,8 @@ struct DecBArgs {
     unsigned* guard;            // {void flag, give-up count} of the driver this launch belongs to
     unsigned spin;
     unsigned long long* dbg;    // NULL, or [Tt][8] timestamps of workgroup 0 (tools/exp_dec_bwd_phases.py)
-    int B, Ts, Tt, H, RT;
+    int B, Ts, Tt, H, RT;       // RT: row tiles of the whole batch
+    int rt0;                    // first row tile of this launch (see DecPArgs::rt0)
     int xcd_map;                // as DecPArgs::xcd_map
     int h0_tanh;                // 1: d_h0 leaves as the gradient of the PRE-activation of h0 = tanh(.) (V11.py:118): d_h0 * (1 - h0^2)
 };
@@ -1563,12 +1610,13 @@ __device__ __forceinline__ void cell_bwd4(const float (&dh)[4], const float4 (&s
     }
 }
 
+template <int WGS>               // workgroups per row tile: H = 8 WGS (64 -> 512, 32 -> 256), as the forward kernel
 __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) {
     extern __shared__ __attribute__((aligned(16))) float dlds[];
-    constexpr int H = DEC_WGS * DEC_U, C = 2 * H, Q = C + 3 * H;
-    constexpr unsigned PER_SHARD = DEC_WGS / SHARDS;
+    constexpr int H = WGS * DEC_U, C = 2 * H, Q = C + 3 * H;
+    constexpr unsigned PER_SHARD = WGS / SHARDS;
     int i, rt;
-    dec_slice_map(a.xcd_map, i, rt);
+    dec_slice_map<WGS>(a.xcd_map, a.rt0, i, rt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int B = a.B, Ts = a.Ts, Tt = a.Tt;
 #ifdef VAG_LAB          // prologue / exit stamps of block 0 in rows Tt .. of the stamp array (tools/exp_dec_bwd_phases.py)
@@ -1703,7 +1751,7 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
         // operands of phase B that do not depend on the hand-off
         float4 hga[KC], hgb[KC];                                // dgh2 rows of the hidden-side product, requested in phase B (its weight rows
                                                                 // too: 70 instead of 18 spilled registers -- they stay where they are used)
-        static_assert(KC == 6, "ld_acc_shards_and_rows6");
+        static_assert(KC == 6 || KC == 3, "ld_acc_shards_and_rows<KC>");
         float al0 = 0.f, al1 = 0.f, dh0 = 0.f, dh1_ = 0.f;
         const int x0 = threadIdx.x, x1 = threadIdx.x + 512;
         {
@@ -1720,8 +1768,8 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
             const float* p0 = a.dal + o0 + (int64_t)t * (ACC_SHARDS - 1) * B * Ts;      // (o0 = (t B + row) Ts + s: shard 0 of step t)
             const float* p1 = a.dal + o1 + (int64_t)t * (ACC_SHARDS - 1) * B * Ts;
             // (with them: this wave's share of the dgh2 rows for the hidden-side product below -- complete since cA as well)
-            ld_acc_shards_and_rows6(p0, p1, (int64_t)B * Ts, v0, v1,
-                                    a.dqgh + ((int64_t)t * B + lrow) * Q + C + wave * (3 * H >> 3) + 8 * (lane & 3), hga, hgb);
+            ld_acc_shards_and_rows(p0, p1, (int64_t)B * Ts, v0, v1,
+                                   a.dqgh + ((int64_t)t * B + lrow) * Q + C + wave * (3 * H >> 3) + 8 * (lane & 3), hga, hgb);
             if (x0 < NP) { da_s[x0] = v0 + dh0; al_s[x0] = al0; }
             if (x1 < NP) { da_s[x1] = v1 + dh1_; al_s[x1] = al1; }
             __syncthreads();
@@ -1732,7 +1780,7 @@ __global__ __launch_bounds__(512, 1) void dec_bwd_persistent_kernel(DecBArgs a) 
                 for (int sp = lane; sp < Ts; sp += 64) {
                     const float d = al_s[r * Ts + sp] * (da_s[r * Ts + sp] - dot);
                     da_s[r * Ts + sp] = d;
-                    if (((r * Ts + sp) & (DEC_WGS - 1)) == i && m0 + r < B) a.ds[((int64_t)t * B + m0 + r) * Ts + sp] = d;
+                    if (((r * Ts + sp) & (WGS - 1)) == i && m0 + r < B) a.ds[((int64_t)t * B + m0 + r) * Ts + sp] = d;
                 }
             }
             __syncthreads();
@@ -2013,16 +2061,26 @@ int vag_enc_fwd_persistent_launch(const float* xp, const float* w_fw, const floa
     return VAG_OK;
 }
 
-// Eligibility of the persistent decoder: H = 512 (8 units per workgroup x 64 workgroups per row tile), at most 4 row tiles
-// (B <= 64: 256 workgroups, one per CU), keys of a row tile fit the LDS, 4-float alignment of the row strides.
+// Eligibility of the persistent decoder: H = 512 or 256 (8 units per workgroup x H / 8 workgroups per row tile), keys of a row tile
+// fit the LDS, 4-float alignment of the row strides.  One launch holds as many 16-row tiles as the chip has room for, one
+// workgroup per CU (B <= 64 at H = 512, <= 128 at H = 256 on 256 CUs); a wider batch is taken in PASSES of row tiles, launch after
+// launch -- batch rows never meet inside the recurrence, and every per-row array is indexed by the global row, so a pass is the
+// same kernel with a row-tile offset.  Up to DEC_MAX_PASSES (beyond that the launch chains' wide tiles win: measured).
+constexpr int DEC_MAX_PASSES = 4;
 static int64_t dec_persistent_lds_bytes(int64_t Ts, bool free_run = false) {
     return 4 * (6144 + 16 * Ts * 16 + 16 * Ts * 24 + 16 * Ts + 16 * 24 + 16 * 24 + 80 + 256 + 1024 + 16 * Ts + 256 +
                 (free_run ? 64 + 16 + 16 + 16 * Ts * 4 : 0));
 }
-bool vag_dec_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H) {
-    if (H != 512 || B <= 0 || B > 64 || Ts <= 0 || Tt <= 0 || Ts > 512) return false;
+static int dec_wgs(int64_t H) { return (int)(H / DEC_U); }                   // workgroups per row tile
+static int dec_tiles_per_pass(int64_t H) {                                   // row tiles one launch holds (0: none)
     const int cus = persist_cu_count();
-    return cdiv64(B, 16) * DEC_WGS <= cus && dec_persistent_lds_bytes(Ts) <= 160 * 1024 && persist_lds_ok(160 * 1024);
+    return (H == 256 || H == 512) ? cus / dec_wgs(H) : 0;
+}
+bool vag_dec_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H) {
+    if ((H != 512 && H != 256) || B <= 0 || Ts <= 0 || Tt <= 0 || Ts > 512) return false;
+    const int tpp = dec_tiles_per_pass(H);
+    if (tpp <= 0 || cdiv64(B, 16) > (int64_t)tpp * DEC_MAX_PASSES) return false;
+    return dec_persistent_lds_bytes(Ts) <= 160 * 1024 && persist_lds_ok(160 * 1024);
 }
 int64_t vag_dec_persistent_sync_words(int64_t B, int64_t Tt) { return 5 * cdiv64(B, 16) * Tt * CNT_WORDS + 64; }
 
@@ -2062,8 +2120,15 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
     if (lds < 84 * 1024) lds = 84 * 1024;                            // never two workgroups on one CU
     static AttrOnce once;
     if (!set_max_lds_once(once, reinterpret_cast<const void*>(dec_fwd_persistent_kernel<false>))) return VAG_EINVAL;
+    static AttrOnce once256;
+    if (H == 256 && !set_max_lds_once(once256, reinterpret_cast<const void*>(dec_fwd_persistent_kernel<false, 32>))) return VAG_EINVAL;
     const bool timed = ptimer_begin(1, s);
-    hipLaunchKernelGGL(dec_fwd_persistent_kernel<false>, dim3((unsigned)(a.RT * DEC_WGS)), dim3(512), (size_t)lds, s, a);
+    const int tpp = dec_tiles_per_pass(H);
+    for (a.rt0 = 0; a.rt0 < a.RT; a.rt0 += tpp) {                    // passes of row tiles (one at B <= 64 / 128)
+        const unsigned tiles = (unsigned)std::min(tpp, a.RT - a.rt0);
+        if (H == 512) hipLaunchKernelGGL((dec_fwd_persistent_kernel<false, 64>), dim3(tiles * 64), dim3(512), (size_t)lds, s, a);
+        else hipLaunchKernelGGL((dec_fwd_persistent_kernel<false, 32>), dim3(tiles * 32), dim3(512), (size_t)lds, s, a);
+    }
     if (timed) ptimer_end(1, s);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
@@ -2073,7 +2138,7 @@ int vag_dec_fwd_persistent_launch(const float* pe, const float* mask, const floa
 // computes the head's hidden layer, the logits of its own vocabulary tiles and the arg-max itself and feeds the token back,
 // two more hand-offs per step.  E = 256 (four head columns per workgroup); the keys' share of the head is one more LDS slice.
 bool vag_dec_free_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t E, int64_t H, int64_t V) {
-    if (H != 512 || E != DEC_E || B <= 0 || B > 64 || Ts <= 0 || Tt <= 0 || V < 16 || V >= (1ll << 30)) return false;
+    if (H != 512 || E != DEC_E || B <= 0 || B > 64 || Ts <= 0 || Tt <= 0 || Ts > 512 || V < 16 || V >= (1ll << 30)) return false;
     const int cus = persist_cu_count();
     return cdiv64(B, 16) * DEC_WGS <= cus && dec_persistent_lds_bytes(Ts, true) <= 160 * 1024 && persist_lds_ok(160 * 1024);
 }
@@ -2206,7 +2271,7 @@ int vag_enc_bwd_wide16_launch(const vag_half* wt16, const float* d_enc, const fl
 int vag_enc_bwd_persistent_launch(const float* whhT, const float* d_enc, const float* gates, const float* hst, const int* lengths,
                                   const uint64_t* rng, float p_ctx, float* d_xp, float* dgh, unsigned* sync, int64_t B, int64_t Ts,
                                   int64_t H, hipStream_t s) {
-    VAG_CHECK_ARG(whhT && d_enc && gates && hst && lengths && d_xp && dgh && sync && H == 512 && vag_enc_persistent_ok(B, Ts, H));
+    VAG_CHECK_ARG(whhT && d_enc && gates && hst && lengths && d_xp && dgh && sync && (H == 512 || H == 256) && vag_enc_persistent_ok(B, Ts, H));
     VAG_CHECK_ARG(aligned16(whhT) && aligned16(d_enc) && aligned16(gates) && aligned16(hst) && aligned16(d_xp) && aligned16(dgh));
     EncBArgs a;
     a.WT[0] = whhT; a.WT[1] = whhT + 3 * H * H; a.d_enc = d_enc; a.gates = gates; a.hst = hst; a.lengths = lengths;
@@ -2219,7 +2284,8 @@ int vag_enc_bwd_persistent_launch(const float* whhT, const float* d_enc, const f
         VAG_LAUNCH_CHECK();
     }
     const bool timed = ptimer_begin(2, s);
-    hipLaunchKernelGGL(enc_bwd_persistent_kernel<6>, dim3((unsigned)(2 * a.RT * a.CS)), dim3(512), 0, s, a);
+    if (H == 512) hipLaunchKernelGGL(enc_bwd_persistent_kernel<6>, dim3((unsigned)(2 * a.RT * a.CS)), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(enc_bwd_persistent_kernel<3>, dim3((unsigned)(2 * a.RT * a.CS)), dim3(512), 0, s, a);
     if (timed) ptimer_end(2, s);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
@@ -2248,12 +2314,12 @@ int vag_persistent_timeouts_read(void) {
     return (int)v;
 }
 
-static int64_t dec_bwd_persistent_lds_bytes(int64_t Ts) {
+static int64_t dec_bwd_persistent_lds_bytes(int64_t Ts, int64_t H = 512) {
     const int64_t NP = 16 * Ts;
-    return 4 * (2048 + NP * 16 + 24 * NP + 2 * NP + 384 + 3 * 128 + 256 + 8 * 1028 + 64);
+    return 4 * (2048 + NP * 16 + 24 * NP + 2 * NP + 384 + 3 * 128 + 256 + 8 * (2 * H + 4) + 64);
 }
 bool vag_dec_bwd_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H) {
-    return vag_dec_persistent_ok(B, Ts, Tt, H) && dec_bwd_persistent_lds_bytes(Ts) <= 160 * 1024;
+    return vag_dec_persistent_ok(B, Ts, Tt, H) && dec_bwd_persistent_lds_bytes(Ts, H) <= 160 * 1024;
 }
 // A step driver whose initial state is h0 = tanh(.) asks the next backward launch of the calling thread to apply the tanh's
 // derivative to d_h0 on its way out (a launch saved); vag_persist_dh0_tanh_done(d_h0) tells the consumer whether it happened.
@@ -2292,12 +2358,18 @@ int vag_dec_bwd_persistent_launch(const float* pe, const float* encwp, const flo
                            reinterpret_cast<unsigned*>(dal), nsc);
         VAG_LAUNCH_CHECK();
     }
-    int64_t lds = dec_bwd_persistent_lds_bytes(Ts);
+    int64_t lds = dec_bwd_persistent_lds_bytes(Ts, H);
     if (lds < 84 * 1024) lds = 84 * 1024;
-    static AttrOnce once;
-    if (!set_max_lds_once(once, reinterpret_cast<const void*>(dec_bwd_persistent_kernel))) return VAG_EINVAL;
+    static AttrOnce once, once256;
+    if (!set_max_lds_once(once, reinterpret_cast<const void*>(dec_bwd_persistent_kernel<64>))) return VAG_EINVAL;
+    if (H == 256 && !set_max_lds_once(once256, reinterpret_cast<const void*>(dec_bwd_persistent_kernel<32>))) return VAG_EINVAL;
     const bool timed = ptimer_begin(3, s);
-    hipLaunchKernelGGL(dec_bwd_persistent_kernel, dim3((unsigned)(a.RT * DEC_WGS)), dim3(512), (size_t)lds, s, a);
+    const int tpp = dec_tiles_per_pass(H);
+    for (a.rt0 = 0; a.rt0 < a.RT; a.rt0 += tpp) {                    // passes of row tiles, as the forward launch
+        const unsigned tiles = (unsigned)std::min(tpp, a.RT - a.rt0);
+        if (H == 512) hipLaunchKernelGGL(dec_bwd_persistent_kernel<64>, dim3(tiles * 64), dim3(512), (size_t)lds, s, a);
+        else hipLaunchKernelGGL(dec_bwd_persistent_kernel<32>, dim3(tiles * 32), dim3(512), (size_t)lds, s, a);
+    }
     if (timed) ptimer_end(3, s);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
