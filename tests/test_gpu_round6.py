@@ -122,7 +122,7 @@ def test_unguarded_step_consumes_the_process_wide_flag():
 
 # ---------------------------------------------------------------- wider persistent recurrences
 @pytest.mark.parametrize("H,B,Ts,Tt", [(256, 16, 40, 40), (256, 64, 12, 5), (256, 37, 9, 7), (256, 5, 7, 3), (256, 128, 8, 4),
-                                        (256, 150, 6, 3), (512, 128, 9, 4), (512, 100, 7, 5), (512, 250, 5, 3)])
+                                        (256, 230, 6, 3), (256, 256, 5, 3), (512, 128, 9, 4), (512, 115, 7, 5), (512, 120, 5, 3)])
 def test_wider_persistent_decoder_equals_launch_chain(H, B, Ts, Tt):
     """The one-launch decoder recurrences (forward and backward) and the one-launch encoder backward at H = 256 (BASELINE configs[0]:
     32 workgroups per row tile instead of 64) and for batches wider than one launch holds (B > 64 at H = 512, > 128 at H = 256:
@@ -166,7 +166,8 @@ def test_persistent_decoder_eligibility_edges():
     from vagnmt_hip import _lib as L
     sup = L.lib().vag_recurrence_supported
     assert sup(1, 64, 40, 40, 512) == 1 and sup(1, 16, 40, 40, 256) == 1
-    assert sup(1, 256, 40, 40, 512) == 1 and sup(1, 257, 40, 40, 512) == 0      # four passes of four row tiles at most
-    assert sup(1, 512, 40, 40, 256) == 1 and sup(1, 513, 40, 40, 256) == 0
+    # two passes of row tiles at most (64 rows each at H = 512, 128 at H = 256), the second at least three quarters full
+    assert sup(1, 128, 40, 40, 512) == 1 and sup(1, 129, 40, 40, 512) == 0 and sup(1, 96, 40, 40, 512) == 0 and sup(1, 97, 40, 40, 512) == 1
+    assert sup(1, 256, 40, 40, 256) == 1 and sup(1, 257, 40, 40, 256) == 0 and sup(1, 200, 40, 40, 256) == 0
     assert sup(1, 64, 40, 40, 1024) == 0 and sup(1, 64, 40, 40, 128) == 0       # (configs[4]'s width: launch chains)
     assert sup(1, 64, 600, 40, 512) == 0                                        # keys of a row tile must fit the LDS

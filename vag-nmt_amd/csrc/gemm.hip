@@ -754,10 +754,31 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
     VAG_LAUNCH_CHECK();
     return VAG_OK;
 }
+// A side stream for the weight-gradient layout (TN: both operands outer-contiguous, gemm_tn_acc: g_W += dY^T X with its bias sums)
+// of the group flushes of the calling thread, until taken back: the step driver sends the decoder's weight gradients there
+// (step.hip, step_fork bit 2).  Only leaves have that layout -- nothing later in a step but the optimiser reads what they write --
+// and it is flushed first, so it depends on nothing else in its flush; the event is recorded on the flushing stream right before,
+// i.e. behind every launch that produced the operands.
+static thread_local hipStream_t g_group_leaf_stream = nullptr;
+static thread_local hipEvent_t g_group_leaf_event = nullptr;
+static thread_local bool g_group_leaf_used = false;
+void vag_gemm_group_leaf_stream(hipStream_t s, hipEvent_t ev) { g_group_leaf_stream = s; g_group_leaf_event = ev; if (s) g_group_leaf_used = false; }
+bool vag_gemm_group_leaf_used() { return g_group_leaf_used; }
 int vag_gemm_group_end(hipStream_t stream) {
     if (g_group_depth <= 0) return VAG_OK;
     int rc = vag_colsum_queue_flush(stream);
-    for (int lay = 0; lay < 4 && rc == VAG_OK; ++lay) rc = gemm_group_flush_layout(lay, stream);
+    for (int lay = 0; lay < 4 && rc == VAG_OK; ++lay) {
+        hipStream_t to = stream;
+        if (lay == 0 && g_group_leaf_stream && g_qn[0] > 0 && g_group_leaf_stream != stream) {
+            if (hipEventRecord(g_group_leaf_event, stream) == hipSuccess && hipStreamWaitEvent(g_group_leaf_stream, g_group_leaf_event, 0) == hipSuccess) {
+                to = g_group_leaf_stream;
+                g_group_leaf_used = true;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        rc = gemm_group_flush_layout(lay, to);
+    }
     if (--g_group_depth == 0 || rc != VAG_OK) {
         if (rc != VAG_OK) vag_gemm_group_abort();
         else vag_colsum_queue_abort();           // bracket closed: later column sums launch at once

@@ -2065,8 +2065,11 @@ int vag_enc_fwd_persistent_launch(const float* xp, const float* w_fw, const floa
 // fit the LDS, 4-float alignment of the row strides.  One launch holds as many 16-row tiles as the chip has room for, one
 // workgroup per CU (B <= 64 at H = 512, <= 128 at H = 256 on 256 CUs); a wider batch is taken in PASSES of row tiles, launch after
 // launch -- batch rows never meet inside the recurrence, and every per-row array is indexed by the global row, so a pass is the
-// same kernel with a row-tile offset.  Up to DEC_MAX_PASSES (beyond that the launch chains' wide tiles win: measured).
-constexpr int DEC_MAX_PASSES = 4;
+// same kernel with a row-tile offset.  A pass costs what a full launch costs however many tiles it holds, while the launch chains
+// grow with the batch, so passes pay only while they are few and full (tools/exp_dec_passes.py, whole optimiser steps, Ts = Tt = 40:
+// H = 512 B = 128 5.43 vs 5.99 ms, B = 96 5.01 vs 4.74, B = 192 8.20 vs 8.00, B = 256 10.3 vs 9.3; H = 256 B = 256 5.18 vs 5.33,
+// B = 384 7.74 vs 7.57): at most DEC_MAX_PASSES = 2, the last one at least three quarters full.
+constexpr int DEC_MAX_PASSES = 2;
 static int64_t dec_persistent_lds_bytes(int64_t Ts, bool free_run = false) {
     return 4 * (6144 + 16 * Ts * 16 + 16 * Ts * 24 + 16 * Ts + 16 * 24 + 16 * 24 + 80 + 256 + 1024 + 16 * Ts + 256 +
                 (free_run ? 64 + 16 + 16 + 16 * Ts * 4 : 0));
@@ -2079,7 +2082,9 @@ static int dec_tiles_per_pass(int64_t H) {                                   // 
 bool vag_dec_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H) {
     if ((H != 512 && H != 256) || B <= 0 || Ts <= 0 || Tt <= 0 || Ts > 512) return false;
     const int tpp = dec_tiles_per_pass(H);
-    if (tpp <= 0 || cdiv64(B, 16) > (int64_t)tpp * DEC_MAX_PASSES) return false;
+    const int64_t rt = cdiv64(B, 16);
+    if (tpp <= 0 || rt > (int64_t)tpp * DEC_MAX_PASSES) return false;
+    if (rt > tpp && 4 * (rt - tpp * ((rt - 1) / tpp)) < 3 * tpp) return false;          // a mostly empty last pass: the chains win
     return dec_persistent_lds_bytes(Ts) <= 160 * 1024 && persist_lds_ok(160 * 1024);
 }
 int64_t vag_dec_persistent_sync_words(int64_t B, int64_t Tt) { return 5 * cdiv64(B, 16) * Tt * CNT_WORDS + 64; }

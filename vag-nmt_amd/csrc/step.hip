@@ -176,7 +176,7 @@ int64_t vag_step_ws_offset(const vag_step_cfg* cfg, int which) {
 // capture through the event), eagerly they are two cheap runtime calls each.  One side stream and four events per host thread
 // and device, created on first use, never destroyed (a handful per process).
 namespace {
-struct ForkState { hipStream_t side = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; int dev = -1; };
+struct ForkState { hipStream_t side = nullptr; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; int dev = -1; };
 thread_local ForkState g_fork[8];
 ForkState* fork_state() {
     int dev = 0;
@@ -186,7 +186,10 @@ ForkState* fork_state() {
     if (!f) for (auto& x : g_fork) if (x.dev < 0) { f = &x; break; }
     if (!f) return nullptr;
     if (!f->side) {
-        if (hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); f->side = nullptr; return nullptr; }
+        // lowest priority: what runs here is throughput work nothing waits for soon; the chain on the caller's stream goes first
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = 0; }
+        if (hipStreamCreateWithPriority(&f->side, hipStreamNonBlocking, lo) != hipSuccess) { (void)hipGetLastError(); f->side = nullptr; return nullptr; }
         for (auto& e : f->ev)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         f->dev = dev;
@@ -273,7 +276,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     // activations the next fp16 product rounds anyway), so they run on one plane: fp16 operands forward (11 significand bits),
     // bf16 operands for every gradient product (fp16 would flush small gradients; their rounding errors average over the long sums)
     const bool one_plane = c.storage == 1 && !c.free_run && vag_opt().s16_one_plane != 0;
-    StepBranch br_im, br_leaf;
+    StepBranch br_im, br_leaf, br_dw;
     if (phases & 1) {
         if (one_plane) vag_gemm_set_planes(11);
         if (mm) {
@@ -356,6 +359,15 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
             // after the backward recurrence: the products that add into d_enc (projected keys, attention keys) and the weight
             // gradients of the decoder and of attn_e are queued by layout and go out as two grouped launches
             VagGemmGroup outer(true);
+            // step_fork bit 2 (value 4; round 6): the decoder's weight-gradient products (the TN layout of this
+            // bracket's flushes: eight K = Tt*B products that only the optimiser reads) leave on the low-priority side stream and run
+            // beside the VSE / initial-state backward and the encoder's backward recurrence.  Only when that backward follows in this
+            // call: a data-parallel driver's phase call ends here and all-reduces these gradients next.
+            struct DwSide {
+                ForkState* f = nullptr;
+                explicit DwSide(bool on) { if (on && (f = fork_state())) vag_gemm_group_leaf_stream(f->side, f->ev[4]); }
+                ~DwSide() { if (f) vag_gemm_group_leaf_stream(nullptr, nullptr); }
+            } dw_side((phases & 4) && (phases & (2 | 32)) && (vag_opt().step_fork & 4));
             // the initial state's backward follows in this call: d_h0 leaves the recurrence kernel as the gradient of tanh's argument
             struct Dh0 { Dh0(bool on) { vag_persist_dh0_tanh_request(on); } ~Dh0() { vag_persist_dh0_tanh_request(false); } } dh0((phases & 2) != 0);
             VAG_TRY(vag_cgru_attn_decode_seq_bwd_loop(k.enc, k.pe, k.mask, h0, k.tok, w.dec, B, Ts, Tt, Et, H, V, h2_all, k.c_all,
@@ -365,6 +377,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
             VAG_TRY(vag_cgru_attn_decode_seq_bwd_weights(h0, k.tok, w.dec, B, Ts, Tt, Et, H, h2_all, k.c_all, k.e_all, d_e,
                                                          k.ws_dec, g.dec, k.scr_dec, stream));
             VAG_TRY(outer.end(s));
+            if (dw_side.f && vag_gemm_group_leaf_used()) { br_dw.f = dw_side.f; br_dw.open = true; }      // joined at the end of the call
         }
     }
     if (phases & (2 | 32)) {
@@ -409,6 +422,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
                                   g.enc_emb, g.enc_fw, g.enc_bw, stream));
     }
     VAG_TRY(br_leaf.join(s, 3));
+    VAG_TRY(br_dw.join(s, 5));
     return VAG_OK;
 }
 
