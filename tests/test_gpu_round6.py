@@ -171,3 +171,89 @@ def test_persistent_decoder_eligibility_edges():
     assert sup(1, 256, 40, 40, 256) == 1 and sup(1, 257, 40, 40, 256) == 0 and sup(1, 200, 40, 40, 256) == 0
     assert sup(1, 64, 40, 40, 1024) == 0 and sup(1, 64, 40, 40, 128) == 0       # (configs[4]'s width: launch chains)
     assert sup(1, 64, 600, 40, 512) == 0                                        # keys of a row tile must fit the LDS
+
+
+def test_public_beamsearch_with_the_reference_argument_layout():
+    """models/...V11.py:233 / NMT_Seq2Seq_Beam_V2.py:173: `beamsearch(encoder_outputs (Ts,B,2H), context_mask (Ts,B), decoder_input (B,1),
+    decoder_hidden (1,B,H), beam_size, max_length)` is a public method of the reference's models.  Called the way beamsearch_decode
+    calls it there (:199-226), it must return the golden hypotheses of the reference run."""
+    from conftest import load_golden
+    from test_gpu_golden import build
+    for name in ("mm_dot_tied_s0_f32", "text_tied_s0_f32"):
+        meta, P, z = load_golden(name)
+        m = build(meta, P)
+        src = torch.from_numpy(z["src"]).cuda()
+        lens = meta["lengths"]
+        with torch.no_grad():
+            if meta["kind"] == "mm":
+                enc, mask, _, h0 = m._prologue(src, lens, torch.from_numpy(z["im"]).cuda(), None, None)
+            else:
+                enc, mask, h0 = m._prologue(src, lens, None)
+        B = src.shape[0]
+        assert m._validate_args(src, None, 17) == (B, 17)
+        for k, want in meta["decode"].items():
+            k = int(k)
+            if k == 1:
+                continue
+            got = m.beamsearch(enc.transpose(0, 1), mask.transpose(0, 1), torch.full((B, 1), 2, dtype=torch.int64, device="cuda"),
+                               h0.unsqueeze(0), k, meta["max_len"])
+            assert [[int(t) for t in h] for h in got] == want, (name, k)
+        with pytest.raises(NotImplementedError):
+            m.beamsearch(enc.transpose(0, 1), mask.transpose(0, 1), None, h0.unsqueeze(0), 2, 5, avoid_unk=True)
+
+
+def test_shim_adopts_restored_and_pre_stepped_optimizer_state():
+    """ADVICE r5 (vag-nmt_amd/train.py): (a) optimizer.load_state_dict() on an optimiser that already has a fused driver replaces the
+    installed views of the flat moment buffers -- the next fused step must continue from the RESTORED moments and step count, not from
+    the stale flat buffers; (b) an optimiser that has stepped by itself before the first fused call is adopted (its moments copied into
+    the flat buffers) instead of being demoted to the unfused path for the whole run.  Reference: two torch.optim.Adam runs on the
+    per-operator path with the same sequence of calls (train.py:38-51)."""
+    import copy
+    from conftest import load_golden
+    from test_gpu_golden import build, criteria
+    from test_gpu_round5 import _shim, _reference_optimizer, _literal
+    T = _shim()
+    meta, P, z = load_golden("mm_dot_tied_mid_f32")
+    cm, cv = criteria(meta)
+    src, tgt, im = torch.from_numpy(z["src"]).cuda(), torch.from_numpy(z["tgt"]).cuda(), torch.from_numpy(z["im"]).cuda()
+    lens = meta["lengths"]
+    batch = (src, lens, tgt, im)
+    # (a) three fused steps, snapshot, two more, restore the snapshot (weights + optimiser), two more: equals five literal steps
+    # with the same restore in the middle
+    ma, mb = build(meta, P), build(meta, P)
+    oa, ob = _reference_optimizer(ma), _reference_optimizer(mb)
+
+    def fused():
+        return T.train_imagine_beam(src, tgt, im, lens, ma, oa, cm, cv, meta["loss_w"], 1.0, clip=1.0)
+    for _ in range(3):
+        fused(); _literal(mb, ob, cm, cv, batch, 1.0, True)
+    snap_a = (copy.deepcopy(oa.state_dict()), {n: p.detach().clone() for n, p in ma.named_parameters()})
+    snap_b = (copy.deepcopy(ob.state_dict()), {n: p.detach().clone() for n, p in mb.named_parameters()})
+    for _ in range(2):
+        fused(); _literal(mb, ob, cm, cv, batch, 1.0, True)
+    for (sd, pw), m_, o_ in ((snap_a, ma, oa), (snap_b, mb, ob)):
+        with torch.no_grad():
+            for n, p in m_.named_parameters():
+                p.copy_(pw[n])
+        o_.load_state_dict(sd)
+    d = oa._vag_driver
+    assert not d.views_intact()                                # load_state_dict put fresh tensors into optimizer.state
+    for i in range(2):
+        got = fused(); want = _literal(mb, ob, cm, cv, batch, 1.0, True)
+        assert np.allclose(got, want, rtol=2e-4, atol=2e-5), (i, got, want)
+    assert d.views_intact() and int(d.ts.step_count.item()) == 5 and type(d.ts.backend).__name__ == "_FusedBackend"
+    for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert (pa - pb).abs().max().item() <= 3e-5 * max(1.0, pb.abs().max().item()), n
+    # (b) two literal torch.optim.Adam steps first, then the shim: fused from its first call on, continuing that state
+    mc, md = build(meta, P), build(meta, P)
+    oc, od = _reference_optimizer(mc), _reference_optimizer(md)
+    for _ in range(2):
+        _literal(mc, oc, cm, cv, batch, 1.0, True); _literal(md, od, cm, cv, batch, 1.0, True)
+    for i in range(3):
+        got = T.train_imagine_beam(src, tgt, im, lens, mc, oc, cm, cv, meta["loss_w"], 1.0, clip=1.0)
+        want = _literal(md, od, cm, cv, batch, 1.0, True)
+        assert np.allclose(got, want, rtol=2e-4, atol=2e-5), (i, got, want)
+    dc = oc._vag_driver
+    assert type(dc.ts.backend).__name__ == "_FusedBackend" and int(dc.ts.step_count.item()) == 5
+    for (n, pa), (_, pb) in zip(mc.named_parameters(), md.named_parameters()):
+        assert (pa - pb).abs().max().item() <= 3e-5 * max(1.0, pb.abs().max().item()), n

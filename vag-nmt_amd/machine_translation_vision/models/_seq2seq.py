@@ -313,6 +313,26 @@ class Seq2SeqBase(nn.Module):
         self.last_decode_steps = steps            # decoder steps actually run (bench.py prices one step)
         return self._cut(out.cpu().numpy())
 
+    def _validate_args(self, src_var, tgt_var, max_length):
+        """(batch_size, tgt_l) as the reference computes them (models/...V11.py:170-177, NMT_Seq2Seq_Beam_V2.py:115-122)."""
+        return src_var.size()[0], (max_length if tgt_var is None else tgt_var.size()[1])
+
+    def beamsearch(self, encoder_outputs, context_mask, decoder_input, decoder_hidden, beam_size, max_length, avoid_double=True,
+                   avoid_unk=False):
+        """The reference's public entry to the batched beam search (models/...V11.py:233-337, NMT_Seq2Seq_Beam_V2.py:173-277), with
+        ITS argument layout: encoder_outputs (Ts, B, 2H) time-major, context_mask (Ts, B), decoder_input (B, 1) = SOS,
+        decoder_hidden (1, B, H).  Returns the list of token lists cut at EOS.  Only the reference's defaults are implemented
+        (avoid_double=True: EOS hypotheses only continue with EOS; avoid_unk=False); no entry script passes anything else."""
+        if not avoid_double or avoid_unk:
+            raise NotImplementedError("beamsearch: only avoid_double=True, avoid_unk=False (the reference's defaults) run on the HIP path")
+        if decoder_input is not None and not bool((decoder_input == SOS_token).all()):
+            raise ValueError("beamsearch starts every hypothesis from SOS (models/...V11.py:186-188)")
+        enc = encoder_outputs.transpose(0, 1).contiguous()
+        mask = context_mask.transpose(0, 1).contiguous().to(enc.dtype)
+        h = decoder_hidden.reshape(-1, decoder_hidden.shape[-1]).contiguous()
+        with torch.no_grad():
+            return self._beam(enc, mask, h, int(beam_size), int(max_length))
+
     @staticmethod
     def _cut(hyps):
         final = []

@@ -88,13 +88,38 @@ class _Driver:
         self.seg_group = [int(name.split("/")[0][1:]) for name, _, _, _ in self.ts.fp.groups]
         self.calls = 0
         self.n_groups = len(optimizer.param_groups)
-        fp = self.ts.fp
-        for n, p in fp.named:                 # Adam's moments under torch.optim.Adam's names, as views of the flat buffers
-            o, k = fp.offsets[n], p.numel()
-            optimizer.state[p] = {"step": _torch.zeros((), dtype=_torch.float32), "exp_avg": fp.m[o:o + k].view_as(p),
-                                  "exp_avg_sq": fp.v[o:o + k].view_as(p)}
+        self.install_state_views(adopt=True)
         if hasattr(optimizer, "register_state_dict_pre_hook"):
             optimizer.register_state_dict_pre_hook(lambda opt: self.export_steps())
+
+    def install_state_views(self, adopt):
+        """Adam's moments under torch.optim.Adam's names, as views of the step driver's flat buffers.  ``adopt``: what the optimiser
+        holds for a parameter right now (it stepped by itself before the first fused step, or ``optimizer.load_state_dict()`` put
+        restored tensors there) is copied into the flat buffers first, and the largest restored ``step`` becomes the device's
+        counter -- the fused step then continues from the restored moments instead of silently ignoring them."""
+        fp, opt = self.ts.fp, self.optimizer
+        steps = []
+        with _torch.no_grad():
+            for n, p in fp.named:
+                o, k = fp.offsets[n], p.numel()
+                mv, vv = fp.m[o:o + k].view_as(p), fp.v[o:o + k].view_as(p)
+                st = opt.state.get(p)
+                if adopt and st and "exp_avg" in st and st["exp_avg"].data_ptr() != mv.data_ptr():
+                    mv.copy_(st["exp_avg"])
+                    vv.copy_(st["exp_avg_sq"])
+                    if "step" in st:
+                        steps.append(int(float(st["step"])))
+                opt.state[p] = {"step": _torch.zeros((), dtype=_torch.float32), "exp_avg": mv, "exp_avg_sq": vv}
+        if steps:
+            self.ts.step_count.fill_(max(steps))
+            self.export_steps()
+
+    def views_intact(self):
+        """False once something (``optimizer.load_state_dict``) has replaced the installed views by other tensors."""
+        fp = self.ts.fp
+        n, p = fp.named[0]
+        st = self.optimizer.state.get(p)
+        return bool(st) and "exp_avg" in st and st["exp_avg"].data_ptr() == fp.m[fp.offsets[n]:].data_ptr()
 
     def export_steps(self):
         """The device's step counter into torch's per-parameter ``step`` entries (before ``optimizer.state_dict()``, and before
@@ -161,14 +186,18 @@ def _driver(model, optimizer, criterion_mt, criterion_vse, clip, tfr):
     if d is not None:
         same = d.model is model and d.criteria[0] is criterion_mt and d.criteria[1] is criterion_vse and \
             _plain_adam(optimizer) and len(optimizer.param_groups) == d.n_groups
+        if same and not d.views_intact():     # optimizer.load_state_dict() since the last call: take the restored moments over
+            d.install_state_views(adopt=True)
+            d.model._vag_weights_version = getattr(d.model, "_vag_weights_version", 0) + 1
+            if hasattr(d.ts.backend, "after_optimizer"):
+                d.ts.backend.after_optimizer()      # a restore writes the weights too: what derives from them follows
         return (d if same else None), d
     from vagnmt_hip.fused import fusable
     p0 = next(model.parameters())
     if not (p0.is_cuda and fusable(model, criterion_mt, criterion_vse) and _plain_adam(optimizer) and
             _covers(model, optimizer)):
         return None, None
-    if any("exp_avg" in st for st in optimizer.state.values()):
-        return None, None                     # the optimiser has already stepped on its own: its moments stay torch's
+    # (an optimiser that has already stepped on its own, or was restored from a checkpoint: its moments and step count are adopted)
     d = _Driver(model, optimizer, criterion_mt, criterion_vse, clip, tfr)
     optimizer._vag_driver = d
     return d, d
