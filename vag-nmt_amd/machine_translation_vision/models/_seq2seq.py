@@ -99,6 +99,14 @@ class Seq2SeqBase(nn.Module):
     decode_raw_logits = True      # beam search: expansion on raw logits + log-sum-exp pieces (no normalising pass) where available
     decode_hoisted = True         # decoding steps on keys projected once per call (4 launches, no context): ops.decode_step_h
 
+    def _decode_pool(self):
+        """One graph memory pool for every decode shape this model captures (their per-step outputs are allocated inside the captures):
+        bounded by the largest shapes met, not by the number of shapes."""
+        pool = self.__dict__.get("_decode_pool_h")
+        if pool is None:
+            pool = self.__dict__["_decode_pool_h"] = torch.cuda.graph_pool_handle()
+        return pool
+
     def _decode_weights(self, dp, hp, emb, hoisted):
         """What decoding derives from the WEIGHTS alone -- the stacked / folded decoder matrices (ops.decode_prepare) and, for
         the hoisted step, the per-token tables (ops.decode_tables) -- shared by every decode shape and kept until the weights
@@ -192,7 +200,7 @@ class Seq2SeqBase(nn.Module):
             st["chunk"] = torch.empty(CH, B, dtype=torch.int64, device=dev)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with _lib.capture(g):
+            with _lib.capture(g, pool=self._decode_pool()):
                 hc, tc = st["h"], st["tok"]
                 for i in range(CH):
                     tin = tc
@@ -282,7 +290,7 @@ class Seq2SeqBase(nn.Module):
                 # raw logits + the pieces of their rows' log-sum-exp where the vocabulary product provides them: the beam
                 # expansion normalises on the fly, no pass over the (B k, V) logits in between
                 nparts = ops.head_logits_parts_count(hp, B * k, emb.shape[1], V) if self.decode_raw_logits else 0
-                with _lib.capture(g):
+                with _lib.capture(g, pool=self._decode_pool()):
                     for _ in range(CH):
                         if hoisted:
                             h2, c, e, _ = ops.decode_step_h(pe, mask_s, keys, k, st["tok"], st["h"], emb, dp, prep, tables=tables)

@@ -204,16 +204,20 @@ class capture:
     Not ``torch.cuda.graph(graph)``: that context manager runs ``torch.cuda.synchronize(); gc.collect(); torch.cuda.empty_cache()``
     on entry -- ~25 ms per capture here, and every cached block of the allocator handed back to the driver, so the steps after a
     capture pay ``hipMalloc`` again.  A bucketed batch stream meets a new (B, Ts, Tt) shape every few steps: with those captures an
-    epoch-shaped run was 4-5x SLOWER than eager launches (profiles/r05_exp_stream.txt).  The captured regions of this package
-    allocate nothing (static workspaces), so none of the three is needed.
+    epoch-shaped run was 4-5x SLOWER than eager launches (profiles/r05_exp_stream.txt).  The training step's captured regions
+    allocate nothing (static workspaces), so none of the three is needed there.  The DECODE graphs (models/_seq2seq.py) do allocate
+    inside their captures -- the per-step outputs of ``ops.decode_step_h`` / ``head_logits_step`` -- which works because a capture
+    opens a private memory pool; pass ``pool=`` (one ``torch.cuda.graph_pool_handle()`` per model) so that all decode shapes of a
+    model draw from ONE pool whose blocks are reused from capture to capture instead of one pool per captured shape.
     The collector stays off because a collection that runs INSIDE a capture can free tensors whose storage the caching allocator
     must first fence on another stream (anything that went through ``record_stream``, e.g. gradient buckets handed to an exchange
     stream): that event record on a non-capturing stream aborts the process (found as a silent abort ~100 tests after a
     data-parallel test, always inside a decode-graph capture)."""
     _streams = {}
 
-    def __init__(self, graph):
+    def __init__(self, graph, pool=None):
         self._graph = graph
+        self._pool = pool
         self._gc = False
         self._ctx = None
 
@@ -231,7 +235,10 @@ class capture:
             self._ctx = torch.cuda.stream(side)
             self._ctx.__enter__()
             try:
-                self._graph.capture_begin(capture_error_mode="thread_local")
+                if self._pool is not None:
+                    self._graph.capture_begin(pool=self._pool, capture_error_mode="thread_local")
+                else:
+                    self._graph.capture_begin(capture_error_mode="thread_local")
             except BaseException:
                 self._ctx.__exit__(None, None, None)
                 raise
