@@ -257,3 +257,20 @@ def test_shim_adopts_restored_and_pre_stepped_optimizer_state():
     assert type(dc.ts.backend).__name__ == "_FusedBackend" and int(dc.ts.step_count.item()) == 5
     for (n, pa), (_, pb) in zip(mc.named_parameters(), md.named_parameters()):
         assert (pa - pb).abs().max().item() <= 3e-5 * max(1.0, pb.abs().max().item()), n
+
+
+@pytest.mark.parametrize("H,B,Ts", [(512, 128, 6), (512, 115, 9), (1024, 64, 5), (256, 256, 4)])
+def test_persistent_encoder_in_passes_equals_launch_chain(H, B, Ts):
+    """The encoder's one-launch recurrences for a batch wider than one launch holds (2 x B/16 x H/16 workgroups > 256 CUs): two
+    passes of row tiles through the same kernels, against the per-step launch chain (layers/Encoder.py:55-60)."""
+    import test_gpu_round3 as R3
+    from vagnmt_hip import _lib as L
+    assert L.lib().vag_recurrence_supported(0, B, Ts, 1, H) == 1
+    R3.test_persistent_encoder_equals_launch_chain(H, B, Ts)
+
+
+def test_persistent_encoder_eligibility_edges():
+    from vagnmt_hip import _lib as L
+    sup = L.lib().vag_recurrence_supported
+    assert sup(0, 64, 40, 1, 512) == 1 and sup(0, 128, 40, 1, 512) == 1 and sup(0, 129, 40, 1, 512) == 0 and sup(0, 96, 40, 1, 512) == 0
+    assert sup(0, 256, 40, 1, 256) == 1 and sup(0, 32, 40, 1, 1024) == 1 and sup(0, 64, 40, 1, 1024) == 1 and sup(0, 65, 40, 1, 1024) == 0

@@ -66,7 +66,8 @@ struct EncPArgs {
     unsigned spin;              // polls before a wait gives up
     const uint64_t* rng;        // context dropout (Encoder.py:63-64) applied to enc as it is written (NULL / p_ctx = 0: none)
     float p_ctx;
-    int B, Ts, H, RT, CS;
+    int B, Ts, H, RT, CS;       // RT: row tiles of the whole batch (the counters are indexed by the global row tile)
+    int rt0, RTP;               // this launch: row tiles [rt0, rt0 + RTP) (a batch wider than the chip goes in passes of row tiles)
 };
 
 // N x 32 floats of one row read back from another workgroup's sc1 stores: 2 N sc1 loads of 16 bytes (k-step s: floats
@@ -201,7 +202,7 @@ template <int KS>
 __global__ __launch_bounds__(512, 1) void enc_fwd_persistent_kernel(EncPArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[21504];      // 84 KB: [0, 6144) reduction; the rest keeps the CU to ourselves
     const int wg = blockIdx.x;
-    const int cs = wg % a.CS, rt = (wg / a.CS) % a.RT, d = wg / (a.CS * a.RT);
+    const int cs = wg % a.CS, rt = a.rt0 + (wg / a.CS) % a.RTP, d = wg / (a.CS * a.RTP);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int H = a.H, B = a.B, Ts = a.Ts;
     const int m0 = rt * 16, u0 = cs * 16;
@@ -552,12 +553,13 @@ struct EncBArgs {
     unsigned* guard;            // {void flag, give-up count} of the driver this launch belongs to
     unsigned spin;
     int B, Ts, H, RT, CS;
+    int rt0, RTP;               // as EncPArgs
 };
 template <int KS>               // k-steps of 32 per wave: 3H / 8 / 32 (H = 512: 6)
 __global__ __launch_bounds__(512, 1) void enc_bwd_persistent_kernel(EncBArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[21504];      // 84 KB: [0, 2048) reduction; the rest keeps the CU to ourselves
     const int wg = blockIdx.x;
-    const int cs = wg % a.CS, rt = (wg / a.CS) % a.RT, d = wg / (a.CS * a.RT);
+    const int cs = wg % a.CS, rt = a.rt0 + (wg / a.CS) % a.RTP, d = wg / (a.CS * a.RTP);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int H = a.H, B = a.B, Ts = a.Ts, K = 3 * H;
     const int m0 = rt * 16, u0 = cs * 16;
@@ -2027,11 +2029,19 @@ static bool set_max_lds_once(AttrOnce& o, const void* fn) {
     o.done.fetch_or(bit, std::memory_order_release);
     return true;
 }
-bool vag_enc_persistent_ok(int64_t B, int64_t Ts, int64_t H) {
+// Row tiles one launch of the encoder kernels holds (both directions, one workgroup per CU), and the pass policy of the decoder
+// kernels (dec_passes_ok below): a wider batch goes in at most two passes, the second at least three quarters full.
+static int enc_tiles_per_pass(int64_t H) {
     const int cus = persist_cu_count();
+    return (H == 256 || H == 512 || H == 1024) ? (int)(cus / (2 * (H / 16))) : 0;
+}
+static bool passes_ok(int64_t rt, int tpp, int max_passes) {
+    if (tpp <= 0 || rt > (int64_t)tpp * max_passes) return false;
+    return rt <= tpp || 4 * (rt - tpp * ((rt - 1) / tpp)) >= 3 * tpp;
+}
+bool vag_enc_persistent_ok(int64_t B, int64_t Ts, int64_t H) {
     if (!(H == 256 || H == 512 || H == 1024) || B <= 0 || Ts <= 0) return false;
-    const int64_t wgs = 2 * cdiv64(B, 16) * (H / 16);
-    return wgs <= cus && persist_lds_ok(84 * 1024) && (int64_t)(Ts + 1) * B * H * 4 < (1ll << 31);
+    return passes_ok(cdiv64(B, 16), enc_tiles_per_pass(H), 2) && persist_lds_ok(84 * 1024) && (int64_t)(Ts + 1) * B * H * 4 < (1ll << 31);
 }
 int64_t vag_enc_persistent_sync_words(int64_t B, int64_t Ts) { return 2 * cdiv64(B, 16) * Ts + 64; }
 
@@ -2051,11 +2061,15 @@ int vag_enc_fwd_persistent_launch(const float* xp, const float* w_fw, const floa
         hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)cdiv64(nwords, 256)), dim3(256), 0, s, sync, nwords);
         VAG_LAUNCH_CHECK();
     }
-    const dim3 grid((unsigned)(2 * a.RT * a.CS));
     const bool timed = ptimer_begin(0, s);
-    if (H == 256) hipLaunchKernelGGL(enc_fwd_persistent_kernel<1>, grid, dim3(512), 0, s, a);
-    else if (H == 512) hipLaunchKernelGGL(enc_fwd_persistent_kernel<2>, grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(enc_fwd_persistent_kernel<4>, grid, dim3(512), 0, s, a);
+    const int tpp = enc_tiles_per_pass(H);
+    for (a.rt0 = 0; a.rt0 < a.RT; a.rt0 += tpp) {                    // passes of row tiles (one at B <= 64 for H = 512)
+        a.RTP = std::min(tpp, a.RT - a.rt0);
+        const dim3 grid((unsigned)(2 * a.RTP * a.CS));
+        if (H == 256) hipLaunchKernelGGL(enc_fwd_persistent_kernel<1>, grid, dim3(512), 0, s, a);
+        else if (H == 512) hipLaunchKernelGGL(enc_fwd_persistent_kernel<2>, grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL(enc_fwd_persistent_kernel<4>, grid, dim3(512), 0, s, a);
+    }
     if (timed) ptimer_end(0, s);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
@@ -2082,9 +2096,7 @@ static int dec_tiles_per_pass(int64_t H) {                                   // 
 bool vag_dec_persistent_ok(int64_t B, int64_t Ts, int64_t Tt, int64_t H) {
     if ((H != 512 && H != 256) || B <= 0 || Ts <= 0 || Tt <= 0 || Ts > 512) return false;
     const int tpp = dec_tiles_per_pass(H);
-    const int64_t rt = cdiv64(B, 16);
-    if (tpp <= 0 || rt > (int64_t)tpp * DEC_MAX_PASSES) return false;
-    if (rt > tpp && 4 * (rt - tpp * ((rt - 1) / tpp)) < 3 * tpp) return false;          // a mostly empty last pass: the chains win
+    if (!passes_ok(cdiv64(B, 16), tpp, DEC_MAX_PASSES)) return false;                     // (a mostly empty last pass: the chains win)
     return dec_persistent_lds_bytes(Ts) <= 160 * 1024 && persist_lds_ok(160 * 1024);
 }
 int64_t vag_dec_persistent_sync_words(int64_t B, int64_t Tt) { return 5 * cdiv64(B, 16) * Tt * CNT_WORDS + 64; }
@@ -2289,8 +2301,13 @@ int vag_enc_bwd_persistent_launch(const float* whhT, const float* d_enc, const f
         VAG_LAUNCH_CHECK();
     }
     const bool timed = ptimer_begin(2, s);
-    if (H == 512) hipLaunchKernelGGL(enc_bwd_persistent_kernel<6>, dim3((unsigned)(2 * a.RT * a.CS)), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(enc_bwd_persistent_kernel<3>, dim3((unsigned)(2 * a.RT * a.CS)), dim3(512), 0, s, a);
+    const int tpp = enc_tiles_per_pass(H);
+    for (a.rt0 = 0; a.rt0 < a.RT; a.rt0 += tpp) {
+        a.RTP = std::min(tpp, a.RT - a.rt0);
+        const dim3 grid((unsigned)(2 * a.RTP * a.CS));
+        if (H == 512) hipLaunchKernelGGL(enc_bwd_persistent_kernel<6>, grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL(enc_bwd_persistent_kernel<3>, grid, dim3(512), 0, s, a);
+    }
     if (timed) ptimer_end(2, s);
     VAG_LAUNCH_CHECK();
     return VAG_OK;
