@@ -855,6 +855,9 @@ def main():
                          "communicator (vag_comm_*, include/vag_nmt.h)")
     ap.add_argument("--buckets", type=int, choices=[2, 3], default=2,
                     help="multi-GPU: gradient buckets (3 = a third cut after the decoder's backward, TrainStep(three_buckets=True))")
+    ap.add_argument("--zero1", action="store_true",
+                    help="multi-GPU A/B: reduce-scatter -> sharded clip + Adam -> all-gather (TrainStep(zero1=True)) instead of bucketed "
+                         "all-reduces + the replicated optimiser")
     ap.add_argument("--dp-encoder-chain", action="store_true",
                     help="multi-GPU A/B: the encoder's backward recurrence (the only persistent kernel of the phase that runs beside "
                          "bucket 0's all-reduce) as a launch chain; every other recurrence stays one launch (persistent_enc_bwd=0)")
@@ -937,7 +940,8 @@ def main():
         comm = Comm(rank=rank, world_size=world)       # the id travels over the default process group
     ts = TrainStep(model, crit_mt, crit_vse, lr=4e-4, weight_decay=1e-5, clip=1.0, teacher_force_ratio=args.tfr,
                    use_graph=not args.no_graph, process_group=pg, world_size=world, fused=not args.no_fused,
-                   storage="f16" if args.config == "cfg5" else "f32", comm=comm, three_buckets=args.buckets == 3)
+                   storage="f16" if args.config == "cfg5" else "f32", comm=comm, three_buckets=args.buckets == 3,
+                   zero1=args.zero1 and world > 1)
     src, lens, tgt, im = make_batch(c, rank, dev, ragged=args.ragged)
     lens_t = torch.tensor(lens, dtype=torch.int32, device=dev)
 
@@ -1011,7 +1015,8 @@ def main():
                    "gradient_bytes": ts.fp.n * 4, "buckets_bytes": [(hi - lo) * 4 for lo, hi in ts.fp.buckets()],
                    "backend": dist.get_backend(), "steps": n, "comm": args.comm, "buckets": args.buckets,
                    "encoder_backward": "launch chain (--dp-encoder-chain)" if args.dp_encoder_chain else "persistent kernel",
-                   "persistent_kernels": not smoke_dp}
+                   "persistent_kernels": not smoke_dp,
+                   "optimizer": "sharded (zero1: reduce-scatter, vag_clip_adam_shard, all-gather)" if ts.zero1 else "replicated"}
         if rank == 0:
             import glob
             lines = []

@@ -383,6 +383,18 @@ int vag_clip_adam_flat(float* p, float* g, float* m, float* v, int64_t n, int ns
                        float beta2, float eps, int zero_grad, int32_t* step, float* norm_out, void* scratch,
                        const float* lr_dev, vag_stream_t stream);
 
+/* The same optimiser step for ONE contiguous shard [lo, hi) of the flat buffer (lo a multiple of 4): the data-parallel option of
+ * SURVEY.md 8e / section 5 for train.py:46-49 -- gradient by reduce-scatter, sharded sum of squares / clip / Adam, parameters back by
+ * all-gather (vagnmt_hip.trainer.TrainStep(zero1=True)).  Two calls per step with one all-reduce of ONE double in between:
+ *   phase 0: sumsq[0] (device) = sum of squares of g[lo, hi)            -- the caller sums it over the ranks
+ *   phase 1: clip coefficient from that global sum (norm_out: the global norm), step counter, Adam on the segments cut to [lo, hi);
+ *            zero_grad: all of g[0, n) is zeroed.  Skips (non-finite norm, guard flag) as vag_clip_adam_flat; the step counter
+ *            advances on every rank alike because every rank sees the same global sum. */
+int vag_clip_adam_shard(float* p, float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
+                        const float* seg_lr, const float* seg_wd, float clip, float grad_scale, float beta1,
+                        float beta2, float eps, int zero_grad, int32_t* step, float* norm_out, void* scratch,
+                        const float* lr_dev, int64_t lo, int64_t hi, int phase, double* sumsq, vag_stream_t stream);
+
 /* ---- a2 + a13: the whole training step (train.py:36-51 around models/...V11.py:82-168 and
  * NMT_Seq2Seq_Beam_V2.py:58-113) as ONE call: every operator above in the order autograd would run them, on one
  * caller-owned workspace.  Gradients are ACCUMULATED into g (keep it zeroed between steps: vag_clip_adam_flat with

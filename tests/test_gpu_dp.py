@@ -40,7 +40,7 @@ def _criteria():
     return torch.nn.NLLLoss(weight=vw, reduction="none"), PairwiseRankingLoss(0.1)
 
 
-def _worker(rank, world, port, q, use_graph, three=False):
+def _worker(rank, world, port, q, use_graph, three=False, zero1=False):
     for p in (ROOT, PKG):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -52,7 +52,10 @@ def _worker(rank, world, port, q, use_graph, three=False):
     from vagnmt_hip.trainer import TrainStep
     m = _model(100 + rank)
     cm, cv = _criteria()
-    ts = TrainStep(m, cm, cv, use_graph=use_graph, world_size=world, three_buckets=three)
+    ts = TrainStep(m, cm, cv, use_graph=use_graph, world_size=world, three_buckets=three, zero1=zero1)
+    if zero1:
+        lo, hi, size, r = ts._shard()
+        assert r == rank and size * world == ts.fp.n_alloc and size % 64 == 0 and 0 <= lo <= hi <= ts.fp.n
     if three:
         assert len(ts.fp.buckets()) == 3
     losses = []
@@ -60,21 +63,33 @@ def _worker(rank, world, port, q, use_graph, three=False):
         out = ts.step(*_batch(1000 + 10 * step + rank), teacher=(step % 2 == 0))
         losses.append(float(out[0]))
     torch.cuda.synchronize()
+    if zero1:
+        # Adam's moments are current on the owner's shard only until gathered (what save_checkpoint does first)
+        lo, hi, size, _ = ts._shard()
+        own_m = ts.fp.m[lo:hi].clone()
+        ts.gather_optimizer_state()
+        assert torch.equal(ts.fp.m[lo:hi], own_m) and float(ts.fp.m.abs().max()) > 0.0
+        other = ts.fp.m[:lo] if rank == world - 1 else ts.fp.m[hi:]
+        assert float(other.abs().max()) > 0.0                   # the other rank's shard arrived
     q.put((rank, ts.fp.flat.cpu().numpy().copy(), losses, dict(ts.stats)))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("use_graph,three", [(False, False), (True, False), (True, True)])
-def test_two_ranks_on_one_gpu_equal_single_process_mean_gradient(use_graph, three):
-    """three: the three-bucket cut (TrainStep(three_buckets=True): vag_train_step phases 1|16, 32, 4 with an all-reduce after each)
+@pytest.mark.parametrize("use_graph,three,zero1", [(False, False, False), (True, False, False), (True, True, False),
+                                                   (False, False, True), (True, False, True)])
+def test_two_ranks_on_one_gpu_equal_single_process_mean_gradient(use_graph, three, zero1):
+    """zero1: TrainStep(zero1=True) -- gradient by reduce-scatter (gloo: an all-reduce with the same sums), sum of squares / clip / Adam
+    on each rank's shard of the flat buffers (vag_clip_adam_shard, two phases around an all-reduce of one double), parameters back by
+    all-gather -- against the same single-process reference: SURVEY 8e option for train.py:46-49.
+    three: the three-bucket cut (TrainStep(three_buckets=True): vag_train_step phases 1|16, 32, 4 with an all-reduce after each)
     against the same single-process reference -- the flat layout differs (vse_imagine.* / decoderini.* form a bucket of their own),
     so the comparison goes parameter by parameter."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + os.getpid() % 2000 + (1 if use_graph else 0) + (2 if three else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, use_graph, three)) for r in range(2)]
+    port = 29600 + os.getpid() % 2000 + (1 if use_graph else 0) + (2 if three else 0) + (4 if zero1 else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, use_graph, three, zero1)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=500) for _ in range(2)], key=lambda x: x[0])
@@ -85,7 +100,7 @@ def test_two_ranks_on_one_gpu_equal_single_process_mean_gradient(use_graph, thre
     assert np.array_equal(flat_a, flat_b)
     assert losses_a != losses_b
     if use_graph:
-        assert stats_a["captures"] >= (3 if three else 2) and stats_a["replays"] >= 2, stats_a      # every phase graph of a shape
+        assert stats_a["captures"] >= (1 if zero1 else (3 if three else 2)) and stats_a["replays"] >= 2, stats_a      # every phase graph of a shape
     # single process: dropout is on in both runs (train mode) but the model here has p = 0 everywhere
     from vagnmt_hip.trainer import TrainStep
     m = _model(100)
@@ -200,3 +215,30 @@ def test_phased_sequence_with_vag_comm_world1():
     (fa, la), (fb, lb) = res["phased"], res["single"]
     assert np.allclose(la, lb, rtol=2e-4), (la, lb)
     assert np.allclose(fa, fb, rtol=2e-4, atol=2e-6), np.abs(fa - fb).max()
+
+
+def test_zero1_at_world_1_is_the_replicated_step():
+    """One rank: the shard is the whole buffer, no exchange -- vag_clip_adam_shard's two phases must do what vag_clip_adam_flat does
+    (parameters, moments, step counter, reported norm to the run-to-run bound of the atomics), incl. a skipped (non-finite) step."""
+    from vagnmt_hip.trainer import TrainStep
+    res = {}
+    for zero1 in (False, True):
+        m = _model(100)
+        cm, cv = _criteria()
+        ts = TrainStep(m, cm, cv, use_graph=False, zero1=zero1)
+        norms = []
+        for s_ in range(4):
+            if s_ == 2:
+                ts.fp.grad[11] = float("inf")               # a void gradient: the step must be skipped on the device
+            ts.step(*_batch(1000 + 10 * s_), teacher=True)
+            norms.append(float(ts.grad_norm[0]))
+        torch.cuda.synchronize()
+        res[zero1] = (ts.fp.flat.clone(), ts.fp.m.clone(), ts.fp.v.clone(), int(ts.step_count.item()), norms, ts.skipped_steps(),
+                      float(ts.fp.grad.abs().max()))
+    a, b = res[False], res[True]
+    # (the backward pass adds with atomics: two runs of the SAME driver differ in the last bits, so "equal" is the run-to-run bound)
+    for x, y, what in ((a[0], b[0], "parameters"), (a[1], b[1], "exp_avg"), (a[2], b[2], "exp_avg_sq")):
+        assert torch.allclose(x, y, rtol=1e-4, atol=1e-7), (what, float((x - y).abs().max()))
+    assert a[3] == b[3] == 3 and a[5] == b[5] == 1 and a[6] == b[6] == 0.0
+    assert np.isnan(a[4][2]) and np.isnan(b[4][2])
+    assert np.allclose([a[4][0], a[4][1], a[4][3]], [b[4][0], b[4][1], b[4][3]], rtol=1e-5)

@@ -1643,6 +1643,14 @@ int vag_clip_adam_flat(float* p, float* g, float* m, float* v, int64_t n, int ns
                                 step, norm_out, scratch, lr_dev, S_(stream));
 }
 
+int vag_clip_adam_shard(float* p, float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off, const float* seg_lr,
+                        const float* seg_wd, float clip, float grad_scale, float beta1, float beta2, float eps, int zero_grad,
+                        int32_t* step, float* norm_out, void* scratch, const float* lr_dev, int64_t lo, int64_t hi, int phase,
+                        double* sumsq, vag_stream_t stream) {
+    return vag_clip_adam_shard_launch(p, g, m, v, n, nseg, seg_off, seg_lr, seg_wd, clip, grad_scale, beta1, beta2, eps, zero_grad,
+                                      step, norm_out, scratch, lr_dev, lo, hi, phase, sumsq, S_(stream));
+}
+
 int vag_copy4(const void* const* src, void* const* dst, const int64_t* bytes, int n, vag_stream_t stream) {
     return vag_copy4_launch(src, dst, bytes, n, S_(stream));
 }

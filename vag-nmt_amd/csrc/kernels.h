@@ -145,6 +145,10 @@ int vag_retrieval_rank_launch(const float* scores, int64_t N, int* ranks, hipStr
 int vag_scale_by_dev_launch(float* x, int64_t n, const float* scalar, hipStream_t s);
 
 // ---------------- optim.hip ----------------
+int vag_clip_adam_shard_launch(float* p, float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
+                               const float* seg_lr, const float* seg_wd, float clip, float grad_scale, float beta1, float beta2,
+                               float eps, int zero_grad, int32_t* step, float* norm_out, void* scratch, const float* lr_dev,
+                               int64_t lo, int64_t hi, int phase, double* sumsq, hipStream_t s);
 int vag_clip_adam_launch(float* p, float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
                          const float* seg_lr, const float* seg_wd, float clip, float grad_scale, float beta1,
                          float beta2, float eps, int zero_grad, int32_t* step, float* norm_out, void* scratch, const float* lr_dev,

@@ -99,6 +99,20 @@ __global__ void adam_prep_kernel(AdamScalars* sc, float clip, float grad_scale, 
     if (norm_out) norm_out[0] = (float)norm;
 }
 
+// Sharded form (vag_clip_adam_shard): the slots' sum into a caller-visible double (which the caller all-reduces over the ranks),
+// slots re-zeroed.
+__global__ void sumsq_collect_kernel(AdamScalars* sc, double* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double ss = 0.0;
+    for (int k = 0; k < SUMSQ_SLOTS; ++k) { ss += sc->part[k]; sc->part[k] = 0.0; }
+    out[0] = ss;
+}
+// ... and, after that all-reduce, the total back into slot 0, where adam_prep_kernel looks for it
+__global__ void sumsq_restore_kernel(AdamScalars* sc, const double* in) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    sc->part[0] = in[0];
+}
+
 constexpr int ADAM_MAX_SEG = 16;
 struct AdamSegs {
     int64_t off[ADAM_MAX_SEG], cnt[ADAM_MAX_SEG];
@@ -163,5 +177,59 @@ int vag_clip_adam_launch(float* p, float* g, float* m, float* v, int64_t n, int 
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)b, (unsigned)nseg), dim3(256), 0, s, p, g, m, v, sg, beta1, beta2, eps,
                        zero_grad, sc);
     VAG_LAUNCH_CHECK();
+    return VAG_OK;
+}
+
+// ZeRO-1 style sharded optimiser step (SURVEY 8e option; train.py:46-49 semantics unchanged): every rank holds the whole flat
+// parameter and gradient buffers but updates only ONE contiguous shard [lo, hi) of them -- the gradient arrives by reduce-scatter
+// (each rank receives the sum of its shard), the updated shards leave by all-gather; Adam's moments exist for the shard only as far
+// as traffic goes (7 x 4 B per parameter / world per step instead of per rank).
+//   phase 0: sumsq[0] = sum of squares of g[lo, hi)                 -> the caller all-reduces sumsq[0] (sum) over the ranks
+//   phase 1: clip coefficient from sumsq[0] (the GLOBAL sum now), step counter, Adam on the segments cut to [lo, hi);
+//            zero_grad: the WHOLE gradient buffer g[0, n) is left zeroed (the next step accumulates into all of it)
+int vag_clip_adam_shard_launch(float* p, float* g, float* m, float* v, int64_t n, int nseg, const int64_t* seg_off,
+                               const float* seg_lr, const float* seg_wd, float clip, float grad_scale, float beta1, float beta2,
+                               float eps, int zero_grad, int32_t* step, float* norm_out, void* scratch, const float* lr_dev,
+                               int64_t lo, int64_t hi, int phase, double* sumsq, hipStream_t s) {
+    VAG_CHECK_ARG(p && g && m && v && n > 0 && nseg >= 1 && nseg <= ADAM_MAX_SEG && seg_off && seg_lr && seg_wd && step && scratch && sumsq);
+    VAG_CHECK_ARG(aligned16(g) && seg_off[0] == 0 && seg_off[nseg] == n && 0 <= lo && lo <= hi && hi <= n && lo % 4 == 0);
+    VAG_CHECK_ARG(phase == 0 || phase == 1);
+    AdamScalars* sc = reinterpret_cast<AdamScalars*>(scratch);
+    if (phase == 0) {
+        if (hi > lo) {
+            int64_t blocks = cdiv64((hi - lo) / 4 + 1, 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g + lo, hi - lo, sc);
+            VAG_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(sumsq_collect_kernel, dim3(1), dim3(64), 0, s, sc, sumsq);
+        VAG_LAUNCH_CHECK();
+        return VAG_OK;
+    }
+    hipLaunchKernelGGL(sumsq_restore_kernel, dim3(1), dim3(64), 0, s, sc, sumsq);
+    VAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, sc, clip, grad_scale, beta1, beta2, step, norm_out, lr_dev);
+    VAG_LAUNCH_CHECK();
+    AdamSegs sg;
+    int ns = 0;
+    int64_t maxcnt = 0;
+    for (int i = 0; i < nseg; ++i) {                       // the segments cut to the shard
+        const int64_t a = seg_off[i] > lo ? seg_off[i] : lo, b = seg_off[i + 1] < hi ? seg_off[i + 1] : hi;
+        VAG_CHECK_ARG(seg_off[i + 1] >= seg_off[i]);
+        if (b <= a) continue;
+        sg.off[ns] = a; sg.cnt[ns] = b - a; sg.lr[ns] = seg_lr[i]; sg.wd[ns] = seg_wd[i];
+        if (b - a > maxcnt) maxcnt = b - a;
+        ++ns;
+    }
+    if (ns > 0) {
+        int64_t b = cdiv64(maxcnt, 256);
+        if (b > 4096) b = 4096;
+        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)b, (unsigned)ns), dim3(256), 0, s, p, g, m, v, sg, beta1, beta2, eps, zero_grad, sc);
+        VAG_LAUNCH_CHECK();
+    }
+    if (zero_grad) {                                        // what lies outside the shard (other ranks' sums, partly reduced data)
+        if (lo > 0) VAG_TRY(vag_axpy_launch(0.f, g, g, lo, 2, s));
+        if (hi < n) VAG_TRY(vag_axpy_launch(0.f, g + hi, g + hi, n - hi, 2, s));
+    }
     return VAG_OK;
 }

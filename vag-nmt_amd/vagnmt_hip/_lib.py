@@ -115,6 +115,8 @@ PROTOS = {
     "vag_beam_finish": (I32, [P, P, I64, I64, I64, I64, P, P, P]),
     "vag_clip_adam_flat": (I32, [P, P, P, P, I64, I32, C.POINTER(I64), C.POINTER(F), C.POINTER(F), F, F, F, F, F, I32, P,
                                  P, P, P, P]),
+    "vag_clip_adam_shard": (I32, [P, P, P, P, I64, I32, C.POINTER(I64), C.POINTER(F), C.POINTER(F), F, F, F, F, F, I32, P,
+                                  P, P, P, I64, I64, I32, P, P]),
     "vag_step_ws_floats": (I64, [C.POINTER(StepCfg)]),
     "vag_step_ws_offset": (I64, [C.POINTER(StepCfg), I32]),
     "vag_train_step": (I32, [C.POINTER(StepCfg), C.POINTER(ModelW), C.POINTER(ModelW), P, P, P, P, P, P, P, P, P, I32, P]),

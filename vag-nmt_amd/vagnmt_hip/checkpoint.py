@@ -20,6 +20,8 @@ def save_checkpoint(path, model, train_step=None, extra=None):
     if train_step is not None:
         if hasattr(train_step, "check") and train_step.fp.flat.is_cuda:
             train_step.check()            # never write a checkpoint over steps the device had to skip without saying so
+        if hasattr(train_step, "gather_optimizer_state"):
+            train_step.gather_optimizer_state()      # (sharded optimiser: every rank's copy of the moments made whole first)
         fp = train_step.fp
         m, v = {}, {}
         for name, p in fp.named:

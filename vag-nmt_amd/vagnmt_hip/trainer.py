@@ -91,18 +91,20 @@ def _param_pickle_state():
 class FlatParams:
     """Re-homes a module's parameters into one flat buffer (+ gradient, Adam m/v buffers)."""
 
-    def __init__(self, model, vse_separate=False, groups=None, three_buckets=False):
+    def __init__(self, model, vse_separate=False, groups=None, three_buckets=False, pad_to=1):
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]      # tied weights appear once
         dev = named[0][1].device
         self.groups, self.offsets, self.seg_off, self.n = flat_layout(named, vse_separate, groups, three_buckets)
+        # pad_to (the sharded optimiser: world_size x 64): the four buffers are ALLOCATED to a multiple of it so that they cut into
+        # equal shards for reduce-scatter / all-gather; self.n stays the number of floats that belong to parameters
+        self.n_alloc = (self.n + pad_to - 1) // pad_to * pad_to
         n_early = sum(1 for g in self.groups if not g[0].endswith("/encoder"))
         self.early_end = self.seg_off[n_early]              # [0, early_end): final before the encoder's backward
         n_first = sum(1 for g in self.groups if not g[0].endswith("/encoder") and not g[0].endswith("/vse+init"))
         self.first_end = self.seg_off[n_first]              # three buckets: [0, first_end) is final after the decoder's backward
-        self.flat = torch.zeros(self.n, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(self.n, dtype=torch.float32, device=dev)
-        self.m = torch.zeros(self.n, dtype=torch.float32, device=dev)
-        self.v = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self._alloc = [torch.zeros(self.n_alloc, dtype=torch.float32, device=dev) for _ in range(4)]
+        self.flat, self.grad, self.m, self.v = [t[:self.n] for t in self._alloc]
+        self.flat_alloc, self.grad_alloc, self.m_alloc, self.v_alloc = self._alloc
         with torch.no_grad():
             for n, p in named:
                 k, o = p.numel(), self.offsets[n]
@@ -129,7 +131,7 @@ class TrainStep:
     def __init__(self, model, criterion_mt, criterion_vse=None, lr=4e-4, weight_decay=1e-5, clip=1.0,
                  teacher_force_ratio=0.8, betas=(0.9, 0.999), eps=1e-8, vse_separate=False, use_graph=True,
                  process_group=None, world_size=1, max_graphs=256, pad_src=4, fused=None, backend=None,
-                 force_phased=False, storage="f32", comm=None, groups=None, capture_after=1, three_buckets=False):
+                 force_phased=False, storage="f32", comm=None, groups=None, capture_after=1, three_buckets=False, zero1=False):
         self.model = model
         self.criterion_mt = criterion_mt
         self.criterion_vse = criterion_vse
@@ -153,7 +155,15 @@ class TrainStep:
         # three_buckets: a third cut of the flat gradient after the decoder's backward (31.6 of bucket 0's 45.6 MB at configs[1] start
         # their all-reduce ~0.15 ms earlier, behind the VSE / initial-state backward and the encoder's); a switch for the first
         # multi-GPU session to A/B (what it buys depends on link bandwidth): the default stays two buckets
-        self.fp = FlatParams(model, vse_separate, groups, three_buckets)
+        # zero1 (SURVEY 8e / section 5 option for train.py:46-49): reduce-scatter of the flat gradient, each rank clips and updates ONE
+        # contiguous shard (vag_clip_adam_shard), the updated shards come back by all-gather.  Optimiser traffic per rank drops from
+        # 7 x 4 B per parameter to 1/world of it, the exchange moves the same bytes as the all-reduce it replaces but its second half
+        # (the all-gather) can no longer hide behind the backward pass: an option for models whose optimiser pass outweighs that; at
+        # configs[1] (16 M parameters: 72 us of Adam) the replicated default is expected to win.  Off by default.
+        self.zero1 = bool(zero1)
+        if self.zero1 and comm is not None:
+            raise ValueError("zero1 uses torch.distributed's reduce-scatter / all-gather (process_group), not a vag Comm")
+        self.fp = FlatParams(model, vse_separate, groups, three_buckets, pad_to=max(1, world_size) * 64 if self.zero1 else 1)
         dev = self.fp.flat.device
         if world_size > 1:
             import torch.distributed as dist
@@ -233,9 +243,63 @@ class TrainStep:
         if hasattr(self.backend, "after_optimizer"):
             self.backend.after_optimizer()
 
+    def _shard(self):
+        """[lo, hi) of this rank's shard of the flat buffers, and the (equal, padded) shard length."""
+        import torch.distributed as dist
+        rank = dist.get_rank(self.pg) if (self.world > 1 and dist.is_initialized()) else 0
+        size = self.fp.n_alloc // max(1, self.world)
+        lo = min(rank * size, self.fp.n)
+        return lo, min(lo + size, self.fp.n), size, rank
+
+    def _zero1_optimizer(self):
+        """Reduce-scatter -> sharded sum of squares -> all-reduce of one double -> clip + Adam on the shard -> all-gather."""
+        import torch.distributed as dist
+        fp = self.fp
+        lo, hi, size, rank = self._shard()
+        multi = self.world > 1 and dist.is_initialized()
+        if multi and self.comm_enabled:
+            own = fp.grad_alloc[rank * size:(rank + 1) * size]
+            try:
+                dist.reduce_scatter_tensor(own, fp.grad_alloc, op=dist.ReduceOp.SUM, group=self.pg)      # RCCL: in place
+            except (RuntimeError, NotImplementedError):
+                dist.all_reduce(fp.grad_alloc, op=dist.ReduceOp.SUM, group=self.pg)      # (gloo has no reduce-scatter: same sums)
+        if not hasattr(self, "_sumsq"):
+            self._sumsq = torch.zeros(1, dtype=torch.float64, device=fp.flat.device)
+        ns = len(fp.groups)
+        args = (ptr(fp.flat), ptr(fp.grad), ptr(fp.m), ptr(fp.v), fp.n, ns, self._seg_off, self._seg_lr, self._seg_wd,
+                float(self.clip), 1.0 / self.world, self.betas[0], self.betas[1], self.eps, 1, ptr(self.step_count, torch.int32),
+                ptr(self.grad_norm), self._scratch.data_ptr(), ptr(self._lr_dev), lo, hi)
+        call("vag_clip_adam_shard", *args, 0, ptr(self._sumsq, torch.float64), stream())
+        if multi and self.comm_enabled:
+            dist.all_reduce(self._sumsq, op=dist.ReduceOp.SUM, group=self.pg)
+        call("vag_clip_adam_shard", *args, 1, ptr(self._sumsq, torch.float64), stream())
+        if multi and self.comm_enabled:
+            own = fp.flat_alloc[rank * size:(rank + 1) * size]
+            try:
+                dist.all_gather_into_tensor(fp.flat_alloc, own, group=self.pg)
+            except (RuntimeError, NotImplementedError):
+                parts = [torch.empty_like(own) for _ in range(self.world)]
+                dist.all_gather(parts, own.clone(), group=self.pg)
+                fp.flat_alloc.copy_(torch.cat(parts))
+        if hasattr(self.backend, "after_optimizer"):
+            self.backend.after_optimizer()
+
+    def gather_optimizer_state(self):
+        """zero1: Adam's moments are current on the owning rank's shard only; make every rank's m / v whole (checkpointing)."""
+        import torch.distributed as dist
+        if not (self.zero1 and self.world > 1 and dist.is_initialized()):
+            return
+        _, _, size, rank = self._shard()
+        for buf in (self.fp.m_alloc, self.fp.v_alloc):
+            parts = [torch.empty(size, dtype=buf.dtype, device=buf.device) for _ in range(self.world)]
+            dist.all_gather(parts, buf[rank * size:(rank + 1) * size].clone(), group=self.pg)
+            buf.copy_(torch.cat(parts))
+
     def _run_optimizer(self):
         """Clip + Adam (+ derived-weight refresh) replayed from a small graph of its own (one graph: the rate is a device word)."""
         self.model._vag_weights_version = getattr(self.model, "_vag_weights_version", 0) + 1      # (see step())
+        if self.zero1 and not hasattr(self.backend, "optimizer"):
+            return self._zero1_optimizer()        # (eager: two small launches around an all-reduce of one double)
         if not (self.use_graph and self.fp.flat.is_cuda) or hasattr(self.backend, "optimizer"):
             return self._optimizer()
         key = ("opt",)
@@ -325,6 +389,12 @@ class TrainStep:
         if be is None:
             raise RuntimeError("TrainStep needs HIP tensors and criteria (or an injected backend) to run a step")
         bks = self.fp.buckets()
+        if self.zero1 and not hasattr(be, "optimizer"):
+            # the whole backward, then the sharded optimiser (its reduce-scatter needs every bucket final)
+            be.run(src, lengths, tgt, im, teacher, 7)
+            out = be.outputs()
+            self._run_optimizer()
+            return out
         if (self.world > 1 or (self.force_phased and (self.pg is not None or self.comm is not None))) and \
                 getattr(be, "phased", False):
             if len(bks) == 3:
