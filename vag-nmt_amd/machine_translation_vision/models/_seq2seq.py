@@ -101,10 +101,12 @@ class Seq2SeqBase(nn.Module):
 
     def _decode_pool(self):
         """One graph memory pool for every decode shape this model captures (their per-step outputs are allocated inside the captures):
-        bounded by the largest shapes met, not by the number of shapes."""
-        pool = self.__dict__.get("_decode_pool_h")
+        bounded by the largest shapes met, not by the number of shapes.  The handle lives IN the decode cache: a pool
+        dies with the last graph that used it, and the cache is where those graphs live -- dropped or cleared together."""
+        cache = self.__dict__.setdefault("_decode_cache", {})
+        pool = cache.get("__pool__")
         if pool is None:
-            pool = self.__dict__["_decode_pool_h"] = torch.cuda.graph_pool_handle()
+            pool = cache["__pool__"] = torch.cuda.graph_pool_handle()
         return pool
 
     def _decode_weights(self, dp, hp, emb, hoisted):
