@@ -21,7 +21,10 @@ if ROOT not in sys.path:
 pytestmark = pytest.mark.gpu
 
 LOSS_TOL, GRAD_TOL = 1e-4, 3e-4
-GRAD_L2_TOL = 1e-3          # per tensor: ||g - g_oracle||_2 <= 1e-3 ||g_oracle||_2 and cos(g, g_oracle) >= 1 - 1e-6
+# per tensor: ||g - g_oracle||_2 <= tol ||g_oracle||_2 and cos(g, g_oracle) >= 1 - tol^2.  Observed on an MI355X (round 6,
+# gpurun_out/r06_parity.txt): configs[1] 2.3e-5 (bound 2e-4); configs[4] fp32 storage 9.1e-4 -- the fp32 CPU oracle's own sums run
+# over 20480 rows there -- (bound 3e-3); configs[4] 2-byte storage 4.0e-3 (bound 2e-2)
+GRAD_L2_TOL = 2e-4
 
 
 def _driver(c, dropout, **kw):
@@ -200,7 +203,7 @@ def test_cfg5_full_size_fp32_and_fp16_storage_against_oracle():
     runs32 = _run_phases(ts, batch, 2)                         # eager, then capture + replay
     want_l, want_g = _oracle(m, batch, ckpt=True, threads=min(64, os.cpu_count() or 8))
     for tag, (losses, grads) in zip(("cfg5 f32 eager", "cfg5 f32 replay"), runs32):
-        _check(tag, losses, grads, want_l, want_g)
+        _check(tag, losses, grads, want_l, want_g, l2tol=3e-3)
     state = {n: p.detach().clone() for n, p in m.named_parameters()}
     del ts, m, runs32
     torch.cuda.empty_cache()
@@ -212,7 +215,7 @@ def test_cfg5_full_size_fp32_and_fp16_storage_against_oracle():
     m16.train()
     runs16 = _run_phases(ts16, batch, 2)
     for tag, (losses, grads) in zip(("cfg5 f16 eager", "cfg5 f16 replay"), runs16):
-        _check(tag, losses, grads, want_l, want_g, ltol=2e-3, gtol=1e-2, l2tol=5e-2)
+        _check(tag, losses, grads, want_l, want_g, ltol=2e-3, gtol=1e-2, l2tol=2e-2)
 
 
 def test_fp16_storage_small_batches_run():
