@@ -870,7 +870,9 @@ def main():
     args = ap.parse_args()
 
     # VAG_DP_SMOKE=1: rehearse the multi-rank code path on ONE GPU (all ranks on cuda:0, gloo transport)
-    smoke_dp = os.environ.get("VAG_DP_SMOKE") == "1"
+    # (VAG_DP_SMOKE=2: the same, but the persistent kernels stay ON -- the ranks then starve each other's grids of residency, which is
+    # how the tests reach the fallback below on a one-GPU box)
+    smoke_dp = os.environ.get("VAG_DP_SMOKE") in ("1", "2")
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -914,7 +916,7 @@ def main():
         _L.set_option(name, int(val))
     if args.dp_encoder_chain and world > 1:
         _L.set_option("persistent_enc_bwd", 0)
-    if smoke_dp:
+    if smoke_dp and os.environ.get("VAG_DP_SMOKE") == "1":
         # several ranks share ONE GPU here: the persistent recurrence kernels need every workgroup of their grid resident
         # (one per CU), which two processes cannot both have -- their bounded waits would give up.  Launch chains instead.
         _L.set_option("persistent", 0)
@@ -955,36 +957,74 @@ def main():
         if rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
-    log("model built; warm-up")
-    for i in range(max(args.warmup, 3)):
-        out = ts.step(src, lens_t, tgt, im)
-        if i < 6:
-            torch.cuda.synchronize()
-            log("warm-up step %d done (loss %.4f)" % (i, float(out[0].item())))
     # The timed region: exactly K steps between barrier + synchronize on both sides, the maximum over the ranks.  A short region
     # (K < 100: 20 steps are a 58 ms window, and boxes differ by several per cent run to run) is timed FIVE times back to back,
     # each window exactly K steps with the same brackets; the line reports the median window and the spread of the five.
     n_windows = 5 if args.steps < 100 and not args.single_window else 1
-    windows = []
-    for wi in range(n_windows):
-        barrier()
-        log("timing %d steps (window %d of %d)" % (args.steps, wi + 1, n_windows))
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
+
+    def warm_and_time():
+        out = None
+        for i in range(max(args.warmup, 3)):
             out = ts.step(src, lens_t, tgt, im)
-        barrier()
-        dtw = time.perf_counter() - t0
+            if i < 6:
+                torch.cuda.synchronize()
+                log("warm-up step %d done (loss %.4f)" % (i, float(out[0].item())))
+        windows = []
+        for wi in range(n_windows):
+            barrier()
+            log("timing %d steps (window %d of %d)" % (args.steps, wi + 1, n_windows))
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out = ts.step(src, lens_t, tgt, im)
+            barrier()
+            dtw = time.perf_counter() - t0
+            if world > 1:
+                import torch.distributed as dist
+                t = torch.tensor([dtw], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dtw = float(t.item())
+            windows.append(dtw)
+        return windows, float(out[0].item())
+
+    def steps_were_void():
+        """True on EVERY rank when any rank's driver reports skipped steps / give-ups of its persistent kernels (whose waits are
+        bounded: a collective's kernels holding CUs in the encoder backward's window can starve a persistent grid of residency)."""
+        from vagnmt_hip._lib import VagError
+        bad = 0
+        try:
+            ts.check()
+        except VagError as e:
+            log("the timed region is void: %s" % e)
+            bad = 1
         if world > 1:
             import torch.distributed as dist
-            t = torch.tensor([dtw], device=dev, dtype=torch.float64)
+            t = torch.tensor([bad], device=dev, dtype=torch.int32)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dtw = float(t.item())
-        windows.append(dtw)
-    dt = sorted(windows)[len(windows) // 2]
-    loss = float(out[0].item())
+            bad = int(t.item())
+        return bad != 0
 
+    log("model built; warm-up")
+    windows, loss = warm_and_time()
+    fallback = None
+    if steps_were_void():
+        if world == 1:
+            raise SystemExit("bench.py: persistent recurrence kernels gave up waits on a GPU this process should have to itself")
+        # Multi-GPU: a line with void steps in it would be worthless, and so would no line.  Take the persistent kernels back in two
+        # stages -- first the one that shares its window with bucket 0's all-reduce, then all of them -- re-time, and SAY so.
+        for name, what in (("persistent_enc_bwd", "the encoder's backward recurrence as a launch chain"),
+                           ("persistent", "every recurrence as a launch chain")):
+            _L.set_option(name, 0)
+            ts._graphs.clear(); ts._seen.clear(); ts._opt_graphs.clear()
+            ts.resync()
+            log("re-timing with %s" % what)
+            windows, loss = warm_and_time()
+            fallback = what + " (persistent waits gave up beside the collectives: vag_set_option('%s', 0))" % name
+            if not steps_were_void():
+                break
+        else:
+            raise SystemExit("bench.py: optimiser steps are still being skipped with every recurrence as a launch chain")
+    dt = sorted(windows)[len(windows) // 2]
     log("timed region done: %.3f ms/step" % (dt / args.steps * 1e3))
-    ts.check()            # no persistent-kernel wait gave up (would void the steps)
     dp_info = None
     if world > 1:
         # per-rank step time with and without the collectives (same phases, all-reduces skipped): the difference is the
@@ -1015,8 +1055,9 @@ def main():
                    "gradient_bytes": ts.fp.n * 4, "buckets_bytes": [(hi - lo) * 4 for lo, hi in ts.fp.buckets()],
                    "backend": dist.get_backend(), "steps": n, "comm": args.comm, "buckets": args.buckets,
                    "encoder_backward": "launch chain (--dp-encoder-chain)" if args.dp_encoder_chain else "persistent kernel",
-                   "persistent_kernels": not smoke_dp,
-                   "optimizer": "sharded (zero1: reduce-scatter, vag_clip_adam_shard, all-gather)" if ts.zero1 else "replicated"}
+                   "persistent_kernels": os.environ.get("VAG_DP_SMOKE") != "1" and fallback is None,
+                   "optimizer": "sharded (zero1: reduce-scatter, vag_clip_adam_shard, all-gather)" if ts.zero1 else "replicated",
+                   "fallback": fallback}
         if rank == 0:
             import glob
             lines = []

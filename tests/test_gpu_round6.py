@@ -274,3 +274,22 @@ def test_persistent_encoder_eligibility_edges():
     sup = L.lib().vag_recurrence_supported
     assert sup(0, 64, 40, 1, 512) == 1 and sup(0, 128, 40, 1, 512) == 1 and sup(0, 129, 40, 1, 512) == 0 and sup(0, 96, 40, 1, 512) == 0
     assert sup(0, 256, 40, 1, 256) == 1 and sup(0, 32, 40, 1, 1024) == 1 and sup(0, 64, 40, 1, 1024) == 1 and sup(0, 65, 40, 1, 1024) == 0
+
+
+@pytest.mark.timeout(1200)
+def test_bench_multi_rank_falls_back_when_persistent_waits_give_up():
+    """Two ranks on ONE card with the persistent kernels left on (VAG_DP_SMOKE=2) cannot both keep their 256-workgroup grids resident:
+    bounded waits give up (forced here: spin limit 1 -- the one-GPU box time-slices the two processes and never starves a grid by itself), the optimiser skips those steps on every replica -- and a line
+    timed over skipped steps would be worthless.  bench.py must notice (TrainStep.check on every rank, agreed by an all-reduce), take
+    the persistent kernels back in stages, re-time and say so in dp.fallback: what keeps a first multi-GPU session from ending
+    without a number should a collective's kernels starve the encoder backward's grid."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["VAG_DP_SMOKE"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--no-operators", "--no-cpu-baseline", "--no-extras", "--single-window", "--opt", "persist_spin_limit=1"],
+                       env=env, capture_output=True, text=True, timeout=1100)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert d["n_gpus"] == 2 and np.isfinite(d["final_loss"])
+    assert d["dp"]["fallback"] and "launch chain" in d["dp"]["fallback"], d["dp"]
+    assert d["dp"]["persistent_kernels"] is False
