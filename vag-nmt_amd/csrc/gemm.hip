@@ -764,26 +764,8 @@ static thread_local hipEvent_t g_group_leaf_event = nullptr;
 static thread_local bool g_group_leaf_used = false;
 void vag_gemm_group_leaf_stream(hipStream_t s, hipEvent_t ev) { g_group_leaf_stream = s; g_group_leaf_event = ev; if (s) g_group_leaf_used = false; }
 bool vag_gemm_group_leaf_used() { return g_group_leaf_used; }
-// ... and a redirect of WHOLE flushes (every layout) to a side stream the caller has already forked from `stream`: after each such
-// flush `stream` is made to wait for it (the event is recorded on the side stream behind the flush).  What `stream` was given
-// BEFORE the flush runs beside it; what it is given afterwards (the recurrence kernel that reads the products) behind it.  The step
-// driver's forward uses it for the decoder's per-batch products, which need the encoder's states only, beside the visual-grounding
-// chain (step.hip, step_fork bit 3).
-static thread_local hipStream_t g_group_redirect = nullptr;
-static thread_local hipEvent_t g_group_redirect_join = nullptr;
-void vag_gemm_group_redirect(hipStream_t side, hipEvent_t join) { g_group_redirect = side; g_group_redirect_join = join; }
 int vag_gemm_group_end(hipStream_t stream) {
     if (g_group_depth <= 0) return VAG_OK;
-    if (g_group_redirect && g_group_redirect != stream) {
-        hipStream_t side = g_group_redirect;
-        g_group_redirect = nullptr;                    // (the flush below is this function again, on the side stream)
-        const int rc_side = vag_gemm_group_end(side);
-        g_group_redirect = side;
-        if (rc_side != VAG_OK) return rc_side;
-        if (hipEventRecord(g_group_redirect_join, side) != hipSuccess || hipStreamWaitEvent(stream, g_group_redirect_join, 0) != hipSuccess)
-            return (int)hipGetLastError();
-        return VAG_OK;
-    }
     int rc = vag_colsum_queue_flush(stream);
     for (int lay = 0; lay < 4 && rc == VAG_OK; ++lay) {
         hipStream_t to = stream;

@@ -173,7 +173,6 @@ int vag_enc_bwd_wide16_launch(const vag_half* wt16, const float* d_enc, const fl
 int vag_gemm_group_plan_host(int n, const int64_t* M, const int64_t* N, const int64_t* K, const int* accumulate, int* split,
                              int* order);
 void vag_gemm_group_leaf_stream(hipStream_t s, hipEvent_t ev);      // gemm.hip: side stream of the TN (weight-gradient) layout of the group flushes that follow (NULL: none)
-void vag_gemm_group_redirect(hipStream_t side, hipEvent_t join);       // gemm.hip: every group flush that follows goes to `side`, the flushing stream waits for it (NULL: off)
 bool vag_gemm_group_leaf_used();                                    // ... whether a flush went there since it was set
 int vag_persistent_timeouts_read(void);
 unsigned* vag_persist_guard(void);           // {void flag, give-up count} pair of the launches the calling thread enqueues (persist.hip)

@@ -176,7 +176,7 @@ int64_t vag_step_ws_offset(const vag_step_cfg* cfg, int which) {
 // capture through the event), eagerly they are two cheap runtime calls each.  One side stream and four events per host thread
 // and device, created on first use, never destroyed (a handful per process).
 namespace {
-struct ForkState { hipStream_t side = nullptr; hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; int dev = -1; };
+struct ForkState { hipStream_t side = nullptr; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; int dev = -1; };
 thread_local ForkState g_fork[8];
 ForkState* fork_state() {
     int dev = 0;
@@ -276,7 +276,7 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     // activations the next fp16 product rounds anyway), so they run on one plane: fp16 operands forward (11 significand bits),
     // bf16 operands for every gradient product (fp16 would flush small gradients; their rounding errors average over the long sums)
     const bool one_plane = c.storage == 1 && !c.free_run && vag_opt().s16_one_plane != 0;
-    StepBranch br_im, br_leaf, br_dw, br_keys;
+    StepBranch br_im, br_leaf, br_dw;
     if (phases & 1) {
         if (one_plane) vag_gemm_set_planes(11);
         if (mm) {
@@ -306,17 +306,6 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
         }
         VAG_TRY(vag_bigru_seq_fwd(src, lengths, w.enc_emb, w.enc_fw, w.enc_bw, c.p_emb, c.p_ctx, crng, B, Ts, c.Es, H, k.enc,
                                   k.mask, k.ws_enc, stream));                                           // V11.py:111
-        // step_fork bit 3 (value 8, round 6): the decoder's per-batch products (attention keys, projected keys, input projections:
-        // two flushes, ~90 us at configs[1]) need the encoder's states and nothing of the visual-grounding chain or the initial
-        // state that the main stream launches next (eight small dependent kernels, ~46 us): they go to the low-priority side
-        // stream, forked HERE, and the main stream waits for each flush where it happens -- right in front of the recurrence.
-        // (Only the flushes of the decoder operator's prologue are redirected -- see below: a redirected flush does not wait for
-        // what the main stream launched after the fork, and the visual-grounding operators have brackets of their own.)
-        hipStream_t keys_stream = s;
-        if (derived != nullptr && !c.free_run) {
-            keys_stream = br_keys.fork(s, 6, 8);
-            br_keys.open = false;                                                                       // (joined flush by flush)
-        }
         if (mm) {                                                                                       // V11.py:114
             VAG_TRY(br_im.join(s, 1));
             vag_attn_row_mix_request(k.xmix, c.init_split);     // (consumed by the dot method's one-launch attention, else dropped)
@@ -338,11 +327,6 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
             // (Only with the driver's derived weights: otherwise the operator first builds W_ih2 W_c2h, which the queue
             // would hold back.)
             VagGemmGroup outer(derived != nullptr);
-            struct Redirect {
-                bool on;
-                Redirect(hipStream_t side, hipStream_t main_, hipEvent_t join) : on(side != main_) { if (on) vag_gemm_group_redirect(side, join); }
-                ~Redirect() { if (on) vag_gemm_group_redirect(nullptr, nullptr); }
-            } redirect(keys_stream, s, keys_stream != s ? br_keys.f->ev[7] : nullptr);
             VAG_TRY(vag_attn_keys_proj(k.enc, w.attn_e, B * Ts, C, k.pe, stream));                      // NMT_Decoder.py:47
             if (c.free_run && vag_cgru_free_supported(B, Ts, Tt, Et, H, V))
                 VAG_TRY(vag_cgru_attn_decode_free_fwd(k.enc, k.pe, k.mask, h0, k.tok, w.dec, B, Ts, Tt, Et, H, V, h2_all, k.c_all,
