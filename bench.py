@@ -803,16 +803,17 @@ def self_launch(n, argv, smoke_dp=False):
             result = t
         else:
             sys.stderr.write(ln)
+    if result is not None and json.loads(result).get("n_gpus") != n:
+        print("bench.py: the result line says n_gpus=%r, asked for %d" % (json.loads(result).get("n_gpus"), n), file=sys.stderr)
+        return 4
+    if result is not None:
+        print(result, flush=True)          # (a measurement that was completed is handed on even if a rank then fails its teardown)
     if rc != 0:
         print("bench.py: the %d-rank run exited with code %d" % (n, rc), file=sys.stderr)
         return rc
     if result is None:
         print("bench.py: the %d-rank run printed no result line" % n, file=sys.stderr)
         return 3
-    if json.loads(result).get("n_gpus") != n:
-        print("bench.py: the result line says n_gpus=%r, asked for %d" % (json.loads(result).get("n_gpus"), n), file=sys.stderr)
-        return 4
-    print(result, flush=True)
     return 0
 
 
