@@ -1,7 +1,7 @@
 """Soak run of the configs[1] training loop as the reference drives it: N optimiser steps at teacher forcing ratio 0.8 (a python
 coin per batch), ragged and full-length batches alternating, a beam-12 and a greedy decode of an eval batch every 200 steps,
 check() (device-side skip counter, persistent-kernel give-ups, result-ring consistency) at the end.
-Usage (GPU box): python tools/soak.py [steps] >> profiles/r04_soak.txt"""
+Usage (GPU box): python tools/soak.py [steps] [H=256] [B=128] >> profiles/rNN_soak.txt"""
 import os, sys, time, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "vag-nmt_amd"))
@@ -10,7 +10,11 @@ from machine_translation_vision.losses import PairwiseRankingLoss
 from vagnmt_hip.trainer import TrainStep
 from vagnmt_hip import _lib as L
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
-c = bench.CFG2
+c = dict(bench.CFG2)
+for kv in sys.argv[2:]:           # e.g. H=256 B=128: the round-6 shapes of the one-launch recurrences (H = 256; two passes of row tiles)
+    k_, v_ = kv.split("=")
+    c[k_] = int(v_)
+print("# soak: %s" % {k_: c[k_] for k_ in ("B", "Ts", "Tt", "H")}, flush=True)
 dev = torch.device("cuda:0")
 model = bench.build_model(c, dev)
 vw = torch.ones(c["V"], device=dev); vw[0] = 0
