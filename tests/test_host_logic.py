@@ -293,3 +293,40 @@ def test_whole_module_pickle_drops_decode_caches_and_gradient_routing():
     for (n1, p1), (n2, p2) in zip(m.named_parameters(), m2.named_parameters()):
         assert n1 == n2 and torch.equal(p1, p2) and not hasattr(p2, "_vag_grad")
     assert hasattr(m, "_decode_cache")                   # (the live module keeps its caches)
+
+
+def test_sharded_optimizer_layout_is_equal_shards_of_padded_buffers():
+    """TrainStep(zero1=True) (SURVEY 8e option for train.py:46-49): the four flat buffers are ALLOCATED to a multiple of world x 64
+    floats so that reduce-scatter / all-gather cut them into equal, 256-byte aligned shards; the parameters' views and the segment
+    table are those of the replicated layout (pure host logic: no GPU, no process group)."""
+    import torch
+    from machine_translation_vision.models import NMT_AttentionImagine_Seq2Seq_Beam_V11
+    from vagnmt_hip.trainer import FlatParams, TrainStep
+    torch.manual_seed(0)
+    m0 = NMT_AttentionImagine_Seq2Seq_Beam_V11(50, 60, 96, 16, 16, 24, 20, 0.99, tied_emb=True)
+    ref = FlatParams(m0)
+    assert ref.n_alloc == ref.n
+    for world in (2, 3, 8):
+        torch.manual_seed(0)
+        m = NMT_AttentionImagine_Seq2Seq_Beam_V11(50, 60, 96, 16, 16, 24, 20, 0.99, tied_emb=True)
+        fp = FlatParams(m, pad_to=world * 64)
+        assert fp.n == ref.n and fp.offsets == ref.offsets and fp.seg_off == ref.seg_off
+        assert fp.n_alloc % (world * 64) == 0 and 0 <= fp.n_alloc - fp.n < world * 64
+        assert fp.flat.numel() == fp.n and fp.flat_alloc.numel() == fp.n_alloc
+        assert fp.flat.data_ptr() == fp.flat_alloc.data_ptr() and fp.grad.data_ptr() == fp.grad_alloc.data_ptr()
+        assert float(fp.flat_alloc[fp.n:].abs().sum()) == 0.0
+        assert torch.equal(fp.flat, ref.flat)                       # same values at the same offsets
+        size = fp.n_alloc // world
+        assert size % 64 == 0
+        covered = 0
+        for rank in range(world):                                   # what TrainStep._shard hands vag_clip_adam_shard
+            lo = min(rank * size, fp.n)
+            hi = min(lo + size, fp.n)
+            assert lo % 4 == 0 and lo <= hi
+            covered += hi - lo
+        assert covered == fp.n
+    ts = TrainStep(m0, None, None, use_graph=False, zero1=True, backend=object())
+    assert ts.zero1 and ts._shard()[:2] == (0, ts.fp.n)
+    import pytest
+    with pytest.raises(ValueError):
+        TrainStep(m0, None, None, zero1=True, comm=object(), backend=object())
