@@ -293,3 +293,44 @@ def test_bench_multi_rank_falls_back_when_persistent_waits_give_up():
     assert d["n_gpus"] == 2 and np.isfinite(d["final_loss"])
     assert d["dp"]["fallback"] and "launch chain" in d["dp"]["fallback"], d["dp"]
     assert d["dp"]["persistent_kernels"] is False
+
+
+def test_split_k_through_slabs_equals_split_k_through_atomics():
+    """Inside vag_train_step the k-slices of a 128 x 128 output tile park their accumulators in slabs of the step's workspace and the
+    last arriver sums them in slice order (gemm.hip: GemmArgs::slab) instead of every slice adding into the output with one atomic
+    per element: same sums to fp32 rounding, at configs[1] size where the planner really cuts products into 2-12 slices.  The slab
+    region and the tickets are part of the workspace (vag_step_ws_floats grows with them)."""
+    import bench
+    from vagnmt_hip import _lib as L
+    from test_gpu_benched_path import _driver
+    c = bench.CFG2
+    dev = torch.device("cuda", 0)
+    batch = bench.make_batch(c, 0, dev)
+    src, lens, tgt, im = batch
+    lt = torch.tensor(lens, dtype=torch.int32, device=dev)
+    res = {}
+    try:
+        for flag in (0, 1):
+            L.set_option("gemm_slabs", flag)
+            m, ts = _driver(c, dropout=False, use_graph=False)
+            m.train()
+            ts.backend.run(src, lt, tgt, im, True, 7)
+            torch.cuda.synchronize()
+            res[flag] = ([float(x) for x in ts.backend.outputs()], {n: p._vag_grad.detach().clone() for n, p in m.named_parameters()})
+            import ctypes as C
+            f = ts.backend.f
+            need = int(L.lib().vag_step_ws_floats(C.byref(f.cfg(c["B"], src.shape[1], c["Tt"], True, False))))
+            tick = f.ws.view(torch.int32)[need - 16384:need]       # the tickets are the last region of the workspace
+            assert int(tick.abs().max()) == 0                      # every tile's last block put its ticket back
+            del m, ts
+    finally:
+        L.set_option("gemm_slabs", 1)
+    (l0, g0), (l1, g1) = res[0], res[1]
+    assert np.allclose(l0, l1, rtol=1e-6, atol=1e-7), (l0, l1)
+    differs = False
+    for n in g0:
+        scale = max(g0[n].abs().max().item(), 1e-6)
+        err = (g0[n] - g1[n]).abs().max().item()
+        assert err <= 1e-5 * scale, (n, err, scale)
+        differs = differs or err > 0.0
+    assert differs                                                 # (another summation order: the slab path really ran)

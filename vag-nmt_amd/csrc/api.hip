@@ -120,7 +120,7 @@ int vag_set_option(const char* name, int64_t value) {
     VAG_CHECK_ARG(name != nullptr);
     VagOptions& o = vag_opt();
     const struct { const char* n; int* p; } ints[] = {
-        {"gemm_f32mfma", &o.gemm_f32mfma}, {"gemm_nogroup", &o.gemm_nogroup}, {"gemm_big", &o.gemm_big}, {"gemm_force_tile", &o.gemm_force_tile},
+        {"gemm_f32mfma", &o.gemm_f32mfma}, {"gemm_slabs", &o.gemm_slabs}, {"gemm_nogroup", &o.gemm_nogroup}, {"gemm_big", &o.gemm_big}, {"gemm_force_tile", &o.gemm_force_tile},
         {"gemm_force_splitk", &o.gemm_force_splitk}, {"head_fuse", &o.head_fuse},
         {"head_bf16_grads", &o.head_bf16_grads}, {"persistent", &o.persistent}, {"persistent_dec_bwd", &o.persistent_dec_bwd}, {"persistent_enc_bwd", &o.persistent_enc_bwd}, {"free_persistent", &o.free_persistent}, {"attn_dot_reg", &o.attn_dot_reg},
         {"persist_timing", &o.persist_timing}, {"s16_one_plane", &o.s16_one_plane}, {"leaf_queue", &o.leaf_queue}, {"attn_row", &o.attn_row}, {"dec_xcd_map", &o.dec_xcd_map}, {"loss_ride", &o.loss_ride}, {"step_fork", &o.step_fork},

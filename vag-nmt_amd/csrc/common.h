@@ -108,6 +108,7 @@ template <bool XH> __device__ __forceinline__ float ld1_any(const float* base, i
 struct VagOptions {
     int gemm_f32mfma = 0;        // 1: every product on the f32-input MFMA kernels (no bf16 split)
     int gemm_big = 1;            // 0: the one-plane products of the 2-byte storage mode stay on 128 x 128 tiles (round-3 kernels)
+    int gemm_slabs = 1;          // 0: split-K slices add into C with atomics even where a slab scratch is at hand (rounds 1-5)
     int gemm_nogroup = 0;        // 1: products inside a group bracket are launched one by one
     int gemm_force_tile = 0;     // 64 / 128 together with gemm_force_splitk >= 1: override the tile / split-K choice
     int gemm_force_splitk = 0;

@@ -290,8 +290,67 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
     }
 
     // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    const bool atomic = a.splitk > 1;
-    const bool first = bz == 0;
+    bool atomic = a.splitk > 1;
+    bool first = bz == 0;
+    if (a.slab != nullptr && a.nslices > 1) {
+        // ---- split-K through slabs (GemmArgs::slab).  Atomics execute at the memory side at ~1.3 TB/s chip-wide (MI355X_MICROARCH.md,
+        // global float atomics): a 2560 x 512 output in six slices is 31 MB of them, 24 us -- more than the slices' MFMA work -- and
+        // they arrive in one burst when the launch is a single round of blocks.  Here a slice stores its 128 x 128 accumulators as they
+        // lie in the registers (16 bytes per lane and store, write-through), drains, and one lane takes the tile's ticket; whoever
+        // draws the last ticket loads ALL slabs of the tile in slice order (its own included: the sum then does not depend on who was
+        // last -- bitwise reproducible, unlike the atomics) and finishes the tile alone.  Hand-off as persist.hip's (sc1 stores,
+        // vmcnt(0), barrier, one agent-scope add whose RETURN value names the last arriver, sc1 loads): no fences, and no block
+        // ever waits for another, so the scheme holds whatever part of the grid is resident.
+        const int tile = by * ((a.N + 127) >> 7) + bx;
+        float4* mine = reinterpret_cast<float4*>(a.slab) + ((int64_t)tile * a.nslices + bz) * 4096 + (wave * 8) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+                // (s_nop: a store of more than 64 bits must not be followed at once by a write of its data registers -- the compiler
+                // knows that hazard for its own stores, not for inline asm)
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(mine + (i * 4 + q) * 64), "v"(v) : "memory");
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                          // (also: every wave is done with the LDS planes)
+        int* flag = reinterpret_cast<int*>(smem);
+        if (threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(a.ticket + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = t == (unsigned)(a.nslices - 1);
+            if (last) __hip_atomic_store(a.ticket + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+            flag[0] = last ? 1 : 0;
+        }
+        __syncthreads();
+        if (flag[0] == 0) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        const float4* all = reinterpret_cast<const float4*>(a.slab) + (int64_t)tile * a.nslices * 4096 + (wave * 8) * 64 + lane;
+        // (One slice per round trip.  Two in flight -- loads of slice z + 1 issued before slice z is waited for -- was tried: at the
+        // kernels' 128-register cap the second buffer spills, scratch traffic then counts in vmcnt and the compiler saves load
+        // targets before their data has arrived: wrong sums.  The tail this leaves is nslices x ~1.5 us on the last block of a tile.)
+        for (int z = 0; z < a.nslices; ++z) {
+            f32x4 v[8];
+            const float4* p = all + (int64_t)z * 4096;
+            asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:1024 sc1\n\t"
+                         "global_load_dwordx4 %2, %8, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %8, off offset:3072 sc1\n\t"
+                         "global_load_dwordx4 %4, %9, off sc1\n\tglobal_load_dwordx4 %5, %9, off offset:1024 sc1\n\t"
+                         "global_load_dwordx4 %6, %9, off offset:2048 sc1\n\tglobal_load_dwordx4 %7, %9, off offset:3072 sc1\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                         : "v"(p), "v"(p + 256) : "memory");
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][4 * q + e] += v[i * 4 + q][e];
+        }
+        atomic = a.beta != 0.f;            // an accumulating product still ADDS its (one) result: another product may target the same C
+        first = true;                      // (the bias rides with the one epilogue)
+    }
     const int col = n0 + wn * 32 + (lane & 31);
     if (col >= a.N) return;
     const float bv = (a.bias && first) ? a.bias[col] : 0.f;
@@ -587,16 +646,16 @@ void vag_gemm_group_abort() {        // error path: drop the queues
 // priced by simulating that schedule (block cost = slice length + a fixed prologue / epilogue share) plus the extra atomic
 // traffic of the slices.  (The first version aimed at ~512 blocks with one common split: totals of 528 / 576 blocks -- the
 // decoder / encoder weight-gradient groups -- ran a full second round for 16 / 64 blocks: 204 and 108 us.)
-struct GroupPlanEntry { int n, tile; int m[GROUP_MAX], nn[GROUP_MAX], k[GROUP_MAX]; bool acc[GROUP_MAX], half[GROUP_MAX]; int split[GROUP_MAX], order[GROUP_MAX]; };
-static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order, int tile);
+struct GroupPlanEntry { int n, tile; bool slabs; int m[GROUP_MAX], nn[GROUP_MAX], k[GROUP_MAX]; bool acc[GROUP_MAX], half[GROUP_MAX]; int split[GROUP_MAX], order[GROUP_MAX]; };
+static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order, int tile, bool slabs = false);
 // plans are remembered per list of shapes (a training run repeats a handful of them; the simulation costs ~1 ms of host time)
-static void group_plan(const GemmArgs* q, int n, int* split, int* order, int tile = 128) {
+static void group_plan(const GemmArgs* q, int n, int* split, int* order, int tile = 128, bool slabs = false) {
     constexpr int CACHE = 64;
     static thread_local GroupPlanEntry cache[CACHE];
     static thread_local int used = 0, next = 0;
     for (int e = 0; e < used; ++e) {
         const GroupPlanEntry& c = cache[e];
-        bool same = c.n == n && c.tile == tile;
+        bool same = c.n == n && c.tile == tile && c.slabs == slabs;
         for (int i = 0; same && i < n; ++i)
             same = c.m[i] == q[i].M && c.nn[i] == q[i].N && c.k[i] == q[i].K && c.acc[i] == (q[i].beta != 0.f) &&
                    c.half[i] == (q[i].c_half != 0);
@@ -605,17 +664,17 @@ static void group_plan(const GemmArgs* q, int n, int* split, int* order, int til
             return;
         }
     }
-    group_plan_compute(q, n, split, order, tile);
+    group_plan_compute(q, n, split, order, tile, slabs);
     GroupPlanEntry& c = cache[next];
     next = (next + 1) % CACHE;
     if (used < CACHE) ++used;
-    c.n = n; c.tile = tile;
+    c.n = n; c.tile = tile; c.slabs = slabs;
     for (int i = 0; i < n; ++i) {
         c.m[i] = q[i].M; c.nn[i] = q[i].N; c.k[i] = q[i].K; c.acc[i] = q[i].beta != 0.f; c.half[i] = q[i].c_half != 0;
         c.split[i] = split[i]; c.order[i] = order[i];
     }
 }
-static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order, int tile) {
+static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order, int tile, bool slabs) {
     constexpr int MAXSLOTS = 512;
     const int SLOTS = tile == 256 ? 256 : 512;  // 256 x 256 one-plane blocks (gemm_big_kernel): one per CU
     const double C0 = tile == 256 ? 8.0 : 4.0;  // k-steps a block spends outside its main loop
@@ -643,7 +702,8 @@ static void group_plan_compute(const GemmArgs* q, int n, int* split, int* order,
             const int smax = q[i].c_half ? 1 : std::max(1, q[i].K / 256);
             s_i = std::max(1, std::min(s_i, smax));
             const double out_bytes = (double)q[i].M * (double)q[i].N * 4.0;
-            if (q[i].beta != 0.f) atomic_us += (double)s_i * out_bytes / 3.0e6;
+            if (slabs && s_i > 1) atomic_us += (double)s_i * out_bytes / 4.0e6 + 1.5 * s_i / 4.0 + out_bytes / (q[i].beta != 0.f ? 3.0e6 : 4.0e6);
+            else if (q[i].beta != 0.f) atomic_us += (double)s_i * out_bytes / 3.0e6;
             else if (s_i > 1) atomic_us += (double)s_i * out_bytes / 3.0e6 + 4.0 + out_bytes / 4.0e6;   // + a fill launch first
             sp[i] = s_i;
             len[i] = (ks + s_i - 1) / s_i;
@@ -684,7 +744,27 @@ int vag_gemm_group_plan_host(int n, const int64_t* M, const int64_t* N, const in
     group_plan_compute(q, n, split, order, 128);
     return VAG_OK;
 }
-static int gemm_group_flush_layout(int lay, hipStream_t stream) {
+// Scratch of the slab form of split-K (GemmArgs::slab): caller-owned, handed over per thread for the duration of a call (the step
+// driver's workspace: step.hip).  A launch takes what its products need from the start of it -- launches of one stream follow each
+// other, so the next one may reuse the same floats; a launch that goes to ANOTHER stream gets none (atomics, as before).
+struct GemmScratch { float* slab = nullptr; int64_t floats = 0; unsigned* tickets = nullptr; int64_t ntickets = 0; };
+static thread_local GemmScratch g_gemm_scratch;
+void vag_gemm_set_scratch(float* slab, int64_t floats, unsigned* tickets, int64_t ntickets) {
+    g_gemm_scratch.slab = slab; g_gemm_scratch.floats = slab ? floats : 0;
+    g_gemm_scratch.tickets = tickets; g_gemm_scratch.ntickets = tickets ? ntickets : 0;
+}
+// slabs and tickets for a product of `tiles` output tiles in `slices` k-slices, from running offsets; false: does not fit (or off)
+static bool gemm_take_slabs(GemmArgs& a, int64_t tiles, int slices, int64_t& used_f, int64_t& used_t) {
+    a.slab = nullptr; a.ticket = nullptr; a.nslices = slices;
+    const GemmScratch& sc = g_gemm_scratch;
+    if (slices <= 1 || !sc.slab || !sc.tickets || vag_opt().gemm_slabs == 0) return false;
+    const int64_t need = tiles * slices * 16384;
+    if (used_f + need > sc.floats || used_t + tiles > sc.ntickets) return false;
+    a.slab = sc.slab + used_f; a.ticket = sc.tickets + used_t;
+    used_f += need; used_t += tiles;
+    return true;
+}
+static int gemm_group_flush_layout(int lay, hipStream_t stream, bool own_stream = true) {
     const int n = g_qn[lay];
     g_qn[lay] = 0;
     if (n == 0) return VAG_OK;
@@ -703,8 +783,10 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
     bool big = (g_gemm_planes == 1 || g_gemm_planes == 11) && vag_opt().gemm_big != 0;
     for (int j = 0; j < n && big; ++j) big = q[j].M >= 192 && q[j].N >= 192 && q[j].rowsum == nullptr && !q[j].a_bf16;
     const int T = big ? 256 : 128;
-    group_plan(q, n, split, order, T);
+    const bool slabs_on = !big && own_stream && g_gemm_planes == 3 && g_gemm_scratch.slab != nullptr && vag_opt().gemm_slabs != 0;
+    group_plan(q, n, split, order, T, slabs_on);
     int total = 0;
+    int64_t slab_used = 0, ticket_used = 0;
     for (int j = 0; j < n; ++j) {
         GemmArgs& a = G.p[j];
         a = q[order[j]];
@@ -715,7 +797,10 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream) {
         // accumulating products always add atomically here (two of them may target the same gradient buffer);
         // splitk > 1 is what selects the atomic epilogue, the block count below uses the real number of k-slices
         a.splitk = a.beta != 0.f ? (s_i > 2 ? s_i : 2) : s_i;
-        if (a.beta == 0.f && s_i > 1 && !gemm_take_prezeroed(a.C)) {          // sliced overwrite: the slices add into a zeroed output
+        const bool slabs = !big && own_stream && (g_gemm_planes == 3) &&
+                           gemm_take_slabs(a, cdiv64(a.M, T) * cdiv64(a.N, T), s_i, slab_used, ticket_used);
+        if (!slabs) { a.slab = nullptr; a.ticket = nullptr; a.nslices = s_i; }
+        if (a.beta == 0.f && s_i > 1 && !slabs && !gemm_take_prezeroed(a.C)) {          // sliced overwrite: the slices add into a zeroed output
             int64_t nb = cdiv64((int64_t)a.M * a.N, 256 * 8);
             if (nb > 2048) nb = 2048;
             hipLaunchKernelGGL(fill2d_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a.C, a.ldc, (int64_t)a.M, (int64_t)a.N);
@@ -777,7 +862,7 @@ int vag_gemm_group_end(hipStream_t stream) {
                 (void)hipGetLastError();
             }
         }
-        rc = gemm_group_flush_layout(lay, to);
+        rc = gemm_group_flush_layout(lay, to, to == stream);
     }
     if (--g_group_depth == 0 || rc != VAG_OK) {
         if (rc != VAG_OK) vag_gemm_group_abort();
@@ -847,6 +932,7 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     VAG_CHECK_ARG(sam == 1 || sak == 1);
     VAG_CHECK_ARG(sbk == 1 || sbn == 1);
     GemmArgs g;
+    g.slab = nullptr; g.ticket = nullptr; g.nslices = 1;
     g.A = A; g.B = B; g.C = C; g.bias = bias;
     const bool akc = (sak == 1);        // A: k contiguous
     const bool bkc = (sbk == 1);        // B: k contiguous
@@ -896,7 +982,11 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
             }
             const double t_mfma = rounds * (double)kper * (double)(t * t) * 2.0 / (256.0 * eff) / 2400.0;
             const double bytes = (double)M * (double)N * 4.0;
-            const double t_out = sp > 1 ? sp * bytes / atomic_rate + (beta == 0.f ? bytes / 4.0e6 + 2.0 : 0.0)
+            // (slab form of split-K, when the caller's scratch is at hand: the slices' slabs as plain stores, then the last block
+            // of a tile reads them back one round trip per slice, plus the one result)
+            const bool slabs_on = g_gemm_scratch.slab != nullptr && vag_opt().gemm_slabs != 0 && t == 128 && g_gemm_planes == 3 && !opt_f32mfma;
+            const double t_out = sp > 1 ? (slabs_on ? sp * bytes / 4.0e6 + 1.5 * sp + bytes / (beta != 0.f ? atomic_rate : 4.0e6)
+                                                    : sp * bytes / atomic_rate + (beta == 0.f ? bytes / 4.0e6 + 2.0 : 0.0))
                                         : bytes * (beta != 0.f ? 2.0 : 1.0) / 4.0e6;
             const double cost = t_mfma + t_out;
             if (cost < best) { best = cost; T = t; splitk = sp; }
@@ -951,7 +1041,11 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     int kchunk = (int)(cdiv64(cdiv64(K, splitk), BK) * BK);
     splitk = cdiv64(K, kchunk);
     g.splitk = (int)splitk; g.kchunk = kchunk;
-    if (splitk > 1 && beta == 0.f && !gemm_take_prezeroed(C)) {
+    int64_t slab_used = 0, ticket_used = 0;
+    const bool slabs = big && !opt_f32mfma && g_gemm_planes == 3 && !a_bf16 &&
+                       gemm_take_slabs(g, cdiv64(M, T) * cdiv64(N, T), (int)splitk, slab_used, ticket_used);
+    if (!slabs) { g.slab = nullptr; g.ticket = nullptr; g.nslices = (int)splitk; }
+    if (splitk > 1 && beta == 0.f && !slabs && !gemm_take_prezeroed(C)) {
         int64_t nb = cdiv64(M * N, 256 * 8);
         if (nb > 2048) nb = 2048;
         hipLaunchKernelGGL(fill2d_kernel, dim3((unsigned)nb), dim3(256), 0, stream, C, ldc, M, N);

@@ -15,6 +15,12 @@ struct GemmArgs {
     int a_bf16;           // 1: A is stored as bf16 (2 bytes per element, same element strides): one-plane bf16 kernel only
     float* rowsum;        // optional (A outer-contiguous only): rowsum[m] += sum_k A(m,k), i.e. the bias gradient sum_r dY[r,m] of a
                           // weight-gradient product g_W += dY^T X, taken from the A tiles the product loads anyway
+    // Split-K WITHOUT one atomic per element and slice (round 6, bf16x6 128 x 128 kernels): every k-slice of an output tile parks
+    // its accumulators in a slab of its own (64 KB, write-through stores), takes a ticket, and the block that arrives LAST sums all
+    // `nslices` slabs in slice order and runs the ordinary epilogue once.  NULL: the slices add into C with atomics (rounds 1-5).
+    float* slab;          // [tiles][nslices][128 x 128] floats of the caller's scratch (vag_gemm_set_scratch)
+    unsigned* ticket;     // [tiles] arrival counters, zero between launches (the last block puts its tile's back to zero)
+    int nslices;          // k-slices per output tile of THIS product (grid z of a single launch)
 };
 
 

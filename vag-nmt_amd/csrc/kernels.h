@@ -172,6 +172,7 @@ int vag_enc_bwd_wide16_launch(const vag_half* wt16, const float* d_enc, const fl
                               int64_t Ts, int64_t H, hipStream_t s);
 int vag_gemm_group_plan_host(int n, const int64_t* M, const int64_t* N, const int64_t* K, const int* accumulate, int* split,
                              int* order);
+void vag_gemm_set_scratch(float* slab, int64_t floats, unsigned* tickets, int64_t ntickets);      // gemm.hip: scratch of the slab form of split-K for the calling thread (NULL: none)
 void vag_gemm_group_leaf_stream(hipStream_t s, hipEvent_t ev);      // gemm.hip: side stream of the TN (weight-gradient) layout of the group flushes that follow (NULL: none)
 bool vag_gemm_group_leaf_used();                                    // ... whether a flush went there since it was set
 int vag_persistent_timeouts_read(void);

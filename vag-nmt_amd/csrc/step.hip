@@ -21,6 +21,9 @@ struct StepWs {
     int64_t* tok;
     float *d_enc, *d_pe, *d_h2, *d_c, *d_e, *d_h0, *d_ctx, *d_im, *d_txt, *scr_dec, *scr_head, *scr_ini;
     float* free_tab;            // tables of the one-launch free-running decoder (shapes it can take only)
+    float* gemm_slab;           // scratch of the slab form of split-K (gemm.hip: GemmArgs::slab), fp32 storage only
+    unsigned* gemm_ticket;      // ... and its per-tile arrival counters (zeroed by the step's prologue launch)
+    int64_t gemm_slab_floats, gemm_tickets;
     int64_t total;
 };
 
@@ -47,6 +50,14 @@ StepWs step_ws(float* p, const vag_step_cfg& c) {
     w.scr_dec = take(vag_cgru_bwd_scratch_floats(B, Ts, Tt, c.Et, H)); w.scr_head = take(R * c.Et); w.scr_ini = take(B * C);
     // (by shape, not by device: a workspace size must not depend on where it is asked for)
     w.free_tab = take(H == 512 && c.Et == 256 && B <= 64 ? vag_dec_free_tables_floats(B, Ts, Tt, c.Et, H, c.V) : 0);
+    // split-K slabs: the largest flush of a step parks (k-slices x its output elements) floats -- at configs[1] 17 M (the d_enc /
+    // d_e group), 14 M (the decoder's weight gradients), 7.8 M (d tmid in 12 slices): twelve times the widest activation covers them;
+    // a product that does not fit keeps its atomics.  The 2-byte mode's one-plane kernels do not use slabs.
+    const int64_t widest = std::max(std::max(B * Ts * C, R * 3 * H), std::max(3 * H * C, R * c.Et));
+    w.gemm_slab_floats = c.storage == 0 ? 12 * widest : 0;
+    w.gemm_tickets = c.storage == 0 ? 16384 : 0;
+    w.gemm_slab = take(w.gemm_slab_floats);
+    w.gemm_ticket = reinterpret_cast<unsigned*>(take(w.gemm_tickets));
     w.total = o;
     return w;
 }
@@ -65,7 +76,7 @@ bool cfg_ok(const vag_step_cfg* c) {
 // further ranges the prologue zeroes, in 16-byte units: the decoder's hidden states h2 (exchanged between workgroups with marked
 // words, persist.hip: tag1), the head's tmid and the encoder's d(embedded inputs) (grouped products accumulate into them)
 // ... and two outputs of sliced overwriting products of the backward pass (d(tmid), dgi2 W_ih2), which then skip their fill launches
-struct ZeroRanges { uint4* p[5]; int64_t n[5]; };
+struct ZeroRanges { uint4* p[6]; int64_t n[6]; };
 // the decoder's embedded input tokens of every step (teacher-forced: V11.py:117,146 -> NMT_Decoder.py:118), from the target matrix itself
 struct GatherTask { const float* emb; float* out; int E4; };
 __global__ __launch_bounds__(256) void step_prologue_kernel(uint64_t* rng, const int64_t* __restrict__ tgt, int B, int Tt,
@@ -86,7 +97,7 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(uint64_t* rng, const
         }
     }
 #pragma unroll
-    for (int r = 0; r < 5; ++r)                                                                           // (16-byte units)
+    for (int r = 0; r < 6; ++r)                                                                           // (16-byte units)
         for (int64_t i = gid; i < zr.n[r]; i += (int64_t)gridDim.x * 256) zr.p[r][i] = make_uint4(0u, 0u, 0u, 0u);
     {   // the large range: 16 bytes per thread (the range starts 256-byte aligned; its tail word by word)
         const int64_t n4 = n1 >> 2;
@@ -254,6 +265,12 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
     DerivedScope scope(derived, c.storage == 1, chunk);
     LossRingScope lring(c.loss_ring);
     PrezeroScope prezero;           // (a backward-only call relies on the forward call of the same step having run first)
+    // the grouped / single bf16x6 products of this call park their split-K slices in the workspace's slab region instead of adding
+    // them into their outputs with one atomic per element and slice (gemm.hip: GemmArgs::slab)
+    struct SlabScope {
+        SlabScope(float* p, int64_t n, unsigned* t, int64_t nt) { vag_gemm_set_scratch(p, n, t, nt); }
+        ~SlabScope() { vag_gemm_set_scratch(nullptr, 0, nullptr, 0); }
+    } slab_scope(k.gemm_slab, k.gemm_slab_floats, k.gemm_ticket, k.gemm_tickets);
     // this call's persistent recurrence launches report a give-up to the caller's guard pair (vag_step_cfg.guard), not process-wide
     struct GuardScope {
         unsigned* prev; bool on;
@@ -297,6 +314,8 @@ int vag_train_step(const vag_step_cfg* cfg, const vag_model_w* wp, const vag_mod
             zr.p[2] = reinterpret_cast<uint4*>(zp[2]); zr.n[2] = zn[2] / 4;
             zr.p[3] = reinterpret_cast<uint4*>(k.scr_head); zr.n[3] = chunk > 0 ? 0 : Tt * B * Et / 4;
             zr.p[4] = reinterpret_cast<uint4*>(vag_cgru_bwd_scratch_du(k.scr_dec, B, Ts, Tt, Et, H)); zr.n[4] = Tt * B * H / 4;
+            zr.p[5] = reinterpret_cast<uint4*>(k.gemm_ticket); zr.n[5] = k.gemm_tickets / 4;      // split-K tickets (gemm.hip; the last block of a
+                                                                                                   // tile resets its own: this is the belt to those braces)
             GatherTask ga = {nullptr, nullptr, 0};
             if (!c.free_run) { ga.emb = w.dec.emb; ga.out = k.e_all; ga.E4 = (int)(Et / 4); }
             hipLaunchKernelGGL(step_prologue_kernel, dim3((unsigned)nb), dim3(256), 0, s, rng, tgt, (int)B, (int)Tt, k.tok,
