@@ -77,14 +77,14 @@ def test_argument_errors_are_negative_codes_not_crashes():
 
 
 def test_host_side_under_sanitizers():
-    """`make asan` (csrc/Makefile): the host pass of every translation unit under AddressSanitizer + UBSan, the device code untouched
+    """`make -f asan.mk` (csrc/asan.mk; a recipe of its own, kept off the GPU boxes by .gpurunignore): the host pass of every translation unit under AddressSanitizer + UBSan, the device code untouched
     (host-side sanitizer build; GPU sanitizers do not exist on this pool).  The ABI and host-logic tests of this
     directory run against that library in a child process with the sanitizer runtime preloaded: the argument checks, workspace layout
     arithmetic, group planner and the thread-local request state are what it watches.  Any report makes the child exit non-zero."""
     import subprocess
     import sys
     csrc = os.path.join(ROOT, "vag-nmt_amd", "csrc")
-    r = subprocess.run(["make", "-C", csrc, "asan", "-j8"], capture_output=True, text=True, timeout=1500)
+    r = subprocess.run(["make", "-C", csrc, "-f", "asan.mk", "asan", "-j8"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     so = os.path.join(ROOT, "vag-nmt_amd", "lib", "libvagnmt_asan.so")
     rt = subprocess.run(["/opt/rocm/lib/llvm/bin/clang", "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True,
