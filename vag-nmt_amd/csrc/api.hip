@@ -113,7 +113,7 @@ VagOptions& vag_opt() {
 
 extern "C" {
 
-int vag_version(void) { return 300; }
+int vag_version(void) { return 310; }      // 310: vag_clip_adam_shard, the slab scratch inside vag_step_ws_floats (round 6)
 
 // Debug / tuning options by name (common.h: VagOptions); process-wide, takes effect for calls enqueued afterwards.
 int vag_set_option(const char* name, int64_t value) {
