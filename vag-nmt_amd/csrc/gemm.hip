@@ -455,10 +455,19 @@ __device__ __forceinline__ void gemm_big_body(const GemmArgs& a, __bf16* smem, i
             }
         }
     };
+    // row sums of an outer-contiguous fp32 A (the bias gradient of a weight-gradient product g_W += dY^T X), taken from the tiles on
+    // their way into LDS by the first column of blocks, as the 128 x 128 three-plane kernel does (round 6: the 2-byte mode's products
+    // ran a separate column-sum pass over dY for them, 0.45 ms per step at configs[4])
+    const bool do_rs = !AKC && !ABF && a.rowsum != nullptr && bx == 0;
+    float4 rs[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     auto store_tile = [&](int stage) {
         __bf16* S = smem + stage * BIG_STAGE;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            if (!AKC && !ABF && do_rs) {
+                rs[h].x += ra[h].v[0] + ra[h].v[4]; rs[h].y += ra[h].v[1] + ra[h].v[5];
+                rs[h].z += ra[h].v[2] + ra[h].v[6]; rs[h].w += ra[h].v[3] + ra[h].v[7];
+            }
             sp_store<AKC, 1, F16, ABF>(S + h * SP_PLANE, ra[h]);
             sp_store<BKC, 1, F16>(S + (2 + h) * SP_PLANE, rb[h]);
         }
@@ -498,6 +507,27 @@ __device__ __forceinline__ void gemm_big_body(const GemmArgs& a, __bf16* smem, i
         if (t + 2 < nt) load_tile(t + 2);
         compute(st);
         big_barrier();
+    }
+    if (!AKC && !ABF && do_rs) {      // (uniform over the block) 16 threads hold partial sums of the same four rows of a half: meet in LDS
+        float4* rs_s = reinterpret_cast<float4*>(smem);
+        __syncthreads();
+        rs_s[threadIdx.x] = rs[0];
+        rs_s[512 + threadIdx.x] = rs[1];
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int h = threadIdx.x >> 5, g = threadIdx.x & 31;
+            float4 t = rs_s[h * 512 + g];
+#pragma unroll
+            for (int q = 1; q < 16; ++q) {
+                const float4 o = rs_s[h * 512 + g + 32 * q];
+                t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+            }
+            const int m = m0 + 128 * h + 4 * g;
+            if (m + 0 < a.M) atomicAdd(a.rowsum + m + 0, t.x);
+            if (m + 1 < a.M) atomicAdd(a.rowsum + m + 1, t.y);
+            if (m + 2 < a.M) atomicAdd(a.rowsum + m + 2, t.z);
+            if (m + 3 < a.M) atomicAdd(a.rowsum + m + 3, t.w);
+        }
     }
     const bool atomic = a.splitk > 1;
     const bool first = bz == 0;
@@ -784,8 +814,15 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream, bool own_stream 
     int split[GROUP_MAX], order[GROUP_MAX];
     // the 2-byte storage mode's one-plane products: 256 x 256 tiles when every product of the group is large enough for them
     bool big = (g_gemm_planes == 1 || g_gemm_planes == 11) && vag_opt().gemm_big != 0;
-    for (int j = 0; j < n && big; ++j) big = q[j].M >= 192 && q[j].N >= 192 && q[j].rowsum == nullptr && !q[j].a_bf16;
+    for (int j = 0; j < n && big; ++j) big = q[j].M >= 192 && q[j].N >= 192 && !q[j].a_bf16;
     const int T = big ? 256 : 128;
+    if (!big && g_gemm_planes != 3)             // row sums ride on the three-plane 128 x 128 kernel and on the 256 x 256 one only
+        for (int j = 0; j < n; ++j)
+            if (g_q[lay][j].rowsum) {
+                GemmArgs& r = g_q[lay][j];
+                VAG_TRY(vag_colsum_launch(r.A, r.K, r.M, r.sa_k, r.rowsum, stream));
+                r.rowsum = nullptr;
+            }
     const bool slabs_on = !big && own_stream && g_gemm_planes == 3 && g_gemm_scratch.slab != nullptr && vag_opt().gemm_slabs != 0;
     group_plan(q, n, split, order, T, slabs_on);
     int total = 0;
@@ -945,7 +982,11 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     VAG_CHECK_ARG(!a_bf16 || (g_gemm_planes == 1 && g_group_depth == 0 && !rowsum));     // one-plane bf16 kernel, launched at once
     VAG_CHECK_ARG(!c_half || beta == 0.f);      // fp16 output: plain stores only (no split-K, no accumulation)
     VAG_CHECK_ARG(!rowsum || sam == 1);         // row sums ride on outer-contiguous A tiles only
-    if (rowsum && g_gemm_planes != 3) {         // ... and on the three-plane kernels only: otherwise a column-sum pass over A
+    // ... and on the three-plane kernels, or (round 6) on the 256 x 256 one-plane kernel of the 2-byte mode's gradient products;
+    // otherwise a column-sum pass over A
+    const bool rs_big_ok = (g_gemm_planes == 1 || g_gemm_planes == 11) && !akc && !a_bf16 && vag_opt().gemm_big != 0 && M >= 192 && N >= 192 &&
+                           !opt_f32mfma;
+    if (rowsum && g_gemm_planes != 3 && !rs_big_ok) {
         VAG_TRY(vag_colsum_launch(A, K, M, sak, rowsum, stream));
         g.rowsum = rowsum = nullptr;
     }
@@ -1008,7 +1049,7 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     // 256 CUs about once; a bf16-stored A (d(logits) chunks) included
     // (only where the cost model above chose the 128 x 128 one-plane kernel: products it sends to the exact f32 64 x 64 kernel stay there)
     if (T == 128 && (g_gemm_planes == 1 || g_gemm_planes == 11) && vec && !opt_f32mfma && vag_opt().gemm_big != 0 && M >= 192 && N >= 192 &&
-        !g.rowsum && (!a_bf16 || !bkc) && vag_opt().gemm_force_tile == 0) {
+        (!a_bf16 || !bkc) && vag_opt().gemm_force_tile == 0) {
         const int64_t tiles = cdiv64(M, 256) * cdiv64(N, 256);
         int64_t sp = 1;
         if (can_split) while (tiles * sp < 208 && K / (sp + 1) >= 512 && sp < 32) ++sp;
@@ -1037,7 +1078,7 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     }
     const bool big = (T == 128);
     VAG_CHECK_ARG(!a_bf16 || (big && !opt_f32mfma));       // a bf16-stored operand exists for the one-plane split kernel only
-    if (rowsum && (!big || opt_f32mfma)) {          // the other kernels do not carry row sums: a column-sum pass over A instead
+    if (g.rowsum && (!big || opt_f32mfma || g_gemm_planes != 3)) {          // the other kernels do not carry row sums: a column-sum pass over A instead
         VAG_TRY(vag_colsum_launch(A, K, M, sak, rowsum, stream));
         g.rowsum = nullptr;
     }
