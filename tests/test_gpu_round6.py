@@ -334,3 +334,44 @@ def test_split_k_through_slabs_equals_split_k_through_atomics():
         assert err <= 1e-5 * scale, (n, err, scale)
         differs = differs or err > 0.0
     assert differs                                                 # (another summation order: the slab path really ran)
+
+
+def test_wide_fp16_encoder_applies_the_context_dropout_itself():
+    """2-byte storage mode at configs[4] widths, TRAIN mode with dropout on: enc_fwd_wide16_kernel multiplies the encoder states by the
+    counter-based context-dropout mask as it writes them (Encoder.py:63-64; round 6: a separate pass before) -- the same mask the
+    launch chain's separate pass applies and the backward kernels recompute.  Encoder states against the launch chain (fp16 exchange:
+    2e-3 absolute), exact zeros in the same places, losses and gradients within the mode's tolerances."""
+    import ctypes as C
+    from test_gpu_round2 import _fp16_case
+    from vagnmt_hip import _lib as L
+    from vagnmt_hip.trainer import TrainStep
+    m_of, (src, lens, tgt, im), cm, cv = _fp16_case("wide")
+    lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    out = {}
+    try:
+        for persistent in (0, 1):
+            L.set_option("persistent", persistent)
+            m = m_of()
+            m.encoder.dropout_ctx = 0.5                            # the context dropout on (the fixture builds every dropout at 0)
+            ts = TrainStep(m, cm, cv, use_graph=False, storage="f16", pad_src=1)
+            m.train()
+            ts.backend.run(src, lt, tgt, im, True, 7)
+            torch.cuda.synchronize()
+            f = ts.backend.f
+            B, Ts = src.shape
+            c = f.cfg(B, Ts, tgt.shape[1], True, True)
+            assert abs(c.p_ctx - 0.5) < 1e-6                       # the step really runs with the context dropout
+            off = L.lib().vag_step_ws_offset(C.byref(c), 0)
+            enc = f.ws[off:off + B * Ts * 2 * 1024].detach().clone()
+            out[persistent] = (enc, [float(x) for x in ts.backend.outputs()], ts.fp.grad.detach().clone())
+            assert L.lib().vag_persistent_timeouts() == 0
+    finally:
+        L.set_option("persistent", 1)
+    (e0, l0, g0), (e1, l1, g1) = out[0], out[1]
+    assert torch.isfinite(e1).all()
+    live = e0.view(src.shape[0], src.shape[1], -1)[0, 0] != 0       # a full-length row: about half of its 2H entries are dropped
+    assert 0.35 < float(live.float().mean()) < 0.65
+    assert torch.equal(e0 == 0, e1 == 0)                            # the same mask
+    assert (e0 - e1).abs().max().item() <= 4e-3                     # (kept entries are scaled by 1 / (1 - p) = 2)
+    assert np.allclose(l0, l1, rtol=1e-3, atol=1e-4), (l0, l1)
+    assert (g0 - g1).abs().max().item() <= 1e-2 * g0.abs().max().item()

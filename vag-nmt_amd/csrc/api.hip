@@ -256,9 +256,9 @@ int vag_bigru_seq_fwd(const int64_t* src, const int32_t* lengths, const float* e
     if (s16 && vag_opt().persistent && vag_enc_wide16_ok(B, Ts, H) && B >= 64) {
         // 2-byte mode, wide batches: one launch, the fp16 weight slice of a workgroup in registers, four row tiles through
         // it per step; the fp16 copy of the states that the workgroups exchange lives in the backward's (still unused) dgh
-        VAG_TRY(vag_enc_fwd_wide16_launch(w.xp, w16, w16 + 3 * H * H, fw.b_hh, bw.b_hh, lengths, w.hst, w.gates, enc,
-                                          reinterpret_cast<vag_half*>(w.dgh), w.sync, B, Ts, H, s));
-        return vag_dropout_apply_launch(enc, B * Ts * 2 * H, 0, rng, VAG_DROP_ENC_CTX, p_ctx, s);
+        // (the context dropout is applied as the kernel writes enc, as in the fp32 kernel: no separate pass)
+        return vag_enc_fwd_wide16_launch(w.xp, w16, w16 + 3 * H * H, fw.b_hh, bw.b_hh, lengths, w.hst, w.gates, enc,
+                                         reinterpret_cast<vag_half*>(w.dgh), w.sync, rng, p_ctx, B, Ts, H, s);
     }
     {
         const VagJob zj[2] = {{nullptr, w.hst, B, H, H, H, 0}, {nullptr, w.hst + (Ts + 1) * BH, B, H, H, H, 0}};

@@ -165,8 +165,8 @@ int vag_enc_bwd_persistent_launch(const float* whhT, const float* d_enc, const f
                                   int64_t H, hipStream_t s);
 bool vag_enc_wide16_ok(int64_t B, int64_t Ts, int64_t H);
 int vag_enc_fwd_wide16_launch(const float* xp, const vag_half* w16_fw, const vag_half* w16_bw, const float* b_fw, const float* b_bw,
-                              const int* lengths, float* hst, float* gates, float* enc, vag_half* hx, unsigned* sync, int64_t B,
-                              int64_t Ts, int64_t H, hipStream_t s);
+                              const int* lengths, float* hst, float* gates, float* enc, vag_half* hx, unsigned* sync, const uint64_t* rng,
+                              float p_ctx, int64_t B, int64_t Ts, int64_t H, hipStream_t s);
 int vag_enc_bwd_wide16_launch(const vag_half* wt16, const float* d_enc, const float* gates, const float* hst, const int* lengths,
                               const uint64_t* rng, float p_ctx, float* d_xp, float* dgh, vag_half* gx, unsigned* sync, int64_t B,
                               int64_t Ts, int64_t H, hipStream_t s);

@@ -366,6 +366,8 @@ struct EncWArgs {
     unsigned* guard;            // {void flag, give-up count} of the driver this launch belongs to
     unsigned spin;
     int B, Ts, H, RG, CS;
+    const uint64_t* rng;        // context dropout (Encoder.py:63-64) applied to enc as it is written, as the fp32 kernel does (round 6:
+    float p_ctx;                // a separate pass over the 2 x B x Ts x H outputs before); NULL / 0: none
 };
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 // N sc1 loads of 16 bytes at a 64-byte stride (k-steps of 32 halves) + their wait in one statement
@@ -525,7 +527,12 @@ __global__ __launch_bounds__(512, 1) void enc_fwd_wide16_kernel(EncWArgs a) {
             *reinterpret_cast<float4*>(sv + BH) = make_float4(zz[0], zz[1], zz[2], zz[3]);
             *reinterpret_cast<float4*>(sv + 2 * BH) = make_float4(nn[0], nn[1], nn[2], nn[3]);
             *reinterpret_cast<float4*>(sv + 3 * BH) = c[2];
-            *reinterpret_cast<float4*>(a.enc + ((int64_t)em * Ts + t) * 2 * H + d * H + eu) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+            const int64_t eo = ((int64_t)em * Ts + t) * 2 * H + d * H + eu;
+            if (a.rng && a.p_ctx > 0.f) {               // the counter-based mask of this element (the backward kernel recomputes it)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o2[i] *= vag_drop_mul(a.rng, VAG_DROP_ENC_CTX, (uint64_t)eo + i, a.p_ctx);
+            }
+            *reinterpret_cast<float4*>(a.enc + eo) = make_float4(o2[0], o2[1], o2[2], o2[3]);
         } else if (lane == 0) {
             __hip_atomic_fetch_add(cnt + k, 1u, RLX_AGENT);                     // a tile wholly past the batch edge still signs
         }
@@ -2225,15 +2232,15 @@ bool vag_enc_wide16_ok(int64_t B, int64_t Ts, int64_t H) {
     return 2 * cdiv64(B, 64) * Ts + 64 <= vag_enc_persistent_sync_words(B, Ts);
 }
 int vag_enc_fwd_wide16_launch(const float* xp, const vag_half* w16_fw, const vag_half* w16_bw, const float* b_fw, const float* b_bw,
-                              const int* lengths, float* hst, float* gates, float* enc, vag_half* hx, unsigned* sync, int64_t B,
-                              int64_t Ts, int64_t H, hipStream_t s) {
+                              const int* lengths, float* hst, float* gates, float* enc, vag_half* hx, unsigned* sync, const uint64_t* rng,
+                              float p_ctx, int64_t B, int64_t Ts, int64_t H, hipStream_t s) {
     VAG_CHECK_ARG(xp && w16_fw && w16_bw && b_fw && b_bw && lengths && hst && gates && enc && hx && sync &&
                   vag_enc_wide16_ok(B, Ts, H));
     VAG_CHECK_ARG(aligned16(xp) && aligned16(w16_fw) && aligned16(w16_bw) && aligned16(b_fw) && aligned16(b_bw) && aligned16(hst) &&
                   aligned16(gates) && aligned16(enc) && aligned16(hx));
     EncWArgs a;
     a.xp = xp; a.W16[0] = w16_fw; a.W16[1] = w16_bw; a.bias[0] = b_fw; a.bias[1] = b_bw; a.lengths = lengths;
-    a.hst = hst; a.gates = gates; a.enc = enc; a.hx = hx;
+    a.hst = hst; a.gates = gates; a.enc = enc; a.hx = hx; a.rng = rng; a.p_ctx = p_ctx;
     a.B = (int)B; a.Ts = (int)Ts; a.H = (int)H; a.RG = (int)cdiv64(B, 64); a.CS = (int)(H / 32);
     const int nwords = (int)vag_enc_persistent_sync_words(B, Ts);
     a.cnt = sync; a.err = sync + (nwords - 64); a.spin = spin_limit(); a.guard = vag_persist_guard();
