@@ -840,6 +840,7 @@ static int gemm_group_flush_layout(int lay, hipStream_t stream, bool own_stream 
         const bool slabs = !big && own_stream && (g_gemm_planes == 3) &&
                            gemm_take_slabs(a, cdiv64(a.M, T) * cdiv64(a.N, T), s_i, slab_used, ticket_used);
         if (!slabs) { a.slab = nullptr; a.ticket = nullptr; a.nslices = s_i; }
+        if (slabs && a.beta == 0.f) (void)gemm_take_prezeroed(a.C);      // (a prezeroed mark on this output is spent either way)
         if (a.beta == 0.f && s_i > 1 && !slabs && !gemm_take_prezeroed(a.C)) {          // sliced overwrite: the slices add into a zeroed output
             int64_t nb = cdiv64((int64_t)a.M * a.N, 256 * 8);
             if (nb > 2048) nb = 2048;
@@ -1089,6 +1090,7 @@ int vag_gemm_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A
     const bool slabs = big && !opt_f32mfma && g_gemm_planes == 3 && !a_bf16 &&
                        gemm_take_slabs(g, cdiv64(M, T) * cdiv64(N, T), (int)splitk, slab_used, ticket_used);
     if (!slabs) { g.slab = nullptr; g.ticket = nullptr; g.nslices = (int)splitk; }
+    if (slabs && beta == 0.f) (void)gemm_take_prezeroed(C);
     if (splitk > 1 && beta == 0.f && !slabs && !gemm_take_prezeroed(C)) {
         int64_t nb = cdiv64(M * N, 256 * 8);
         if (nb > 2048) nb = 2048;
