@@ -292,7 +292,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& a, __bf16* smem,
     // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     bool atomic = a.splitk > 1;
     bool first = bz == 0;
-    if (a.slab != nullptr && a.nslices > 1) {
+    if (PL == 3 && !F16 && !ABF && a.slab != nullptr && a.nslices > 1) {      // (three-plane kernels only: the one-plane ones sit at an 80-register cap)
         // ---- split-K through slabs (GemmArgs::slab).  Atomics execute at the memory side at ~1.3 TB/s chip-wide (MI355X_MICROARCH.md,
         // global float atomics): a 2560 x 512 output in six slices is 31 MB of them, 24 us -- more than the slices' MFMA work -- and
         // they arrive in one burst when the launch is a single round of blocks.  Here a slice stores its 128 x 128 accumulators as they
