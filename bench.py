@@ -431,6 +431,28 @@ def measure_extras(c, dev, ts, args):
             t2.step(b2[0], l2, b2[2], b2[3], teacher=True)
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
+    if c is CFG2:
+        # a batch wider than one launch of the persistent recurrences holds (round 6: two passes of row tiles): configs[1] at B = 128,
+        # the one-launch kernels against the per-step launch chains on the same driver shape
+        try:
+            from vagnmt_hip import _lib as _Lw
+            cw = dict(CFG2, B=128)
+            row = {"workload": "configs[1] sizes at B = 128 (two passes of four 16-row tiles through the persistent kernels)",
+                   "supported": bool(_Lw.lib().vag_recurrence_supported(1, 128, cw["Ts"], cw["Tt"], cw["H"]))}
+            for name, flag in (("persistent_passes", 1), ("launch_chains", 0)):
+                _Lw.set_option("persistent", flag)
+                try:
+                    t2, b2, l2 = fresh(cw)
+                    msw = timed(t2, b2, l2, 20)
+                    t2.check()
+                    row[name] = {"ms_per_step": msw, "pairs_per_s": 128 / msw * 1e3}
+                    del t2, b2, l2
+                finally:
+                    _Lw.set_option("persistent", 1)
+            out["wide_batch_B128"] = row
+            torch.cuda.empty_cache()
+        except Exception as e:   # noqa: BLE001
+            out["wide_batch_B128"] = {"error": repr(e)[:200]}
     if c is CFG2 and not args.no_cfg5_row:
         try:
             torch.cuda.empty_cache()
