@@ -375,3 +375,42 @@ def test_wide_fp16_encoder_applies_the_context_dropout_itself():
     assert (e0 - e1).abs().max().item() <= 4e-3                     # (kept entries are scaled by 1 / (1 - p) = 2)
     assert np.allclose(l0, l1, rtol=1e-3, atol=1e-4), (l0, l1)
     assert (g0 - g1).abs().max().item() <= 1e-2 * g0.abs().max().item()
+
+
+@pytest.mark.parametrize("H,B", [(512, 128), (256, 256)])
+def test_two_pass_recurrences_match_the_oracle(H, B):
+    """A batch two launches wide (B = 128 at H = 512, 256 at H = 256: two passes of row tiles through every persistent recurrence
+    kernel) through the fused step against the CPU oracle itself, not only against the launch chains: losses 1e-4, every gradient
+    3e-4 of its largest entry and 2e-4 relative L2 (models/...V11.py:82-168)."""
+    from test_gpu_benched_path import _oracle, _check
+    from machine_translation_vision.models import NMT_AttentionImagine_Seq2Seq_Beam_V11
+    from machine_translation_vision.losses import PairwiseRankingLoss
+    from vagnmt_hip.trainer import TrainStep
+    from vagnmt_hip import _lib as L
+    Vs, Vt, I, E, S, Ts, Tt = 300, 333, 64, 32, 48, 9, 6
+    assert L.lib().vag_recurrence_supported(1, B, Ts, Tt, H) == 1 and L.lib().vag_recurrence_supported(0, B, Ts, 1, H) == 1
+    torch.manual_seed(5)
+    m = NMT_AttentionImagine_Seq2Seq_Beam_V11(Vs, Vt, I, E, E, H, S, 0.99, tied_emb=True).cuda()
+    g = torch.Generator().manual_seed(6)
+    lens = sorted([int(x) for x in torch.randint(1, Ts + 1, (B,), generator=g)], reverse=True)
+    lens[0] = Ts
+    src = torch.zeros(B, Ts, dtype=torch.long)
+    for b, n in enumerate(lens):
+        src[b, :n] = torch.randint(4, Vs, (n,), generator=g)
+    tgt = torch.randint(4, Vt, (B, Tt), generator=g)
+    tgt[:, -1] = 3
+    im = torch.randn(B, I, generator=g).abs()
+    vw = torch.ones(Vt, device="cuda")
+    vw[0] = 0
+    ts = TrainStep(m, torch.nn.NLLLoss(weight=vw, reduction="none"), PairwiseRankingLoss(margin=0.1), use_graph=False, pad_src=1)
+    m.eval()
+    batch = (src.cuda(), lens, tgt.cuda(), im.cuda())
+    lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    L.lib().vag_persistent_timeouts()
+    ts.backend.run(batch[0], lt, batch[2], batch[3], True, 7)
+    torch.cuda.synchronize()
+    assert L.lib().vag_persistent_timeouts() == 0
+    losses = [float(x) for x in ts.backend.outputs()]
+    grads = {n: p._vag_grad.detach().clone() for n, p in m.named_parameters()}
+    want_l, want_g = _oracle(m, batch)
+    _check("two passes H=%d B=%d" % (H, B), losses, grads, want_l, want_g)
