@@ -52,9 +52,9 @@ StepWs step_ws(float* p, const vag_step_cfg& c) {
     w.free_tab = take(H == 512 && c.Et == 256 && B <= 64 ? vag_dec_free_tables_floats(B, Ts, Tt, c.Et, H, c.V) : 0);
     // split-K slabs: the largest flush of a step parks (k-slices x its output elements) floats -- at configs[1] 17 M (the d_enc /
     // d_e group), 14 M (the decoder's weight gradients), 7.8 M (d tmid in 12 slices): twelve times the widest activation covers them;
-    // a product that does not fit keeps its atomics.  The 2-byte mode's one-plane kernels do not use slabs.
+    // a product that does not fit keeps its atomics (gemm_take_slabs).  The 2-byte mode's one-plane kernels do not use slabs.
     const int64_t widest = std::max(std::max(B * Ts * C, R * 3 * H), std::max(3 * H * C, R * c.Et));
-    w.gemm_slab_floats = c.storage == 0 ? 12 * widest : 0;
+    w.gemm_slab_floats = c.storage == 0 ? std::min<int64_t>(12 * widest, 192ll << 20) : 0;      // (at most 768 MB: configs[4] sizes in fp32)
     w.gemm_tickets = c.storage == 0 ? 16384 : 0;
     w.gemm_slab = take(w.gemm_slab_floats);
     w.gemm_ticket = reinterpret_cast<unsigned*>(take(w.gemm_tickets));
